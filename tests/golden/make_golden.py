@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Runs only in the build container (needs oracle/_ref/*, built by `make -C oracle ref` from
+/root/reference).  The outputs (small JSON files: inputs + the reference's outputs) are
+committed; this script and the harness sources are committed too, the reference is not.
+
+  replay_*.json : rela::PrioritizedReplay<FFTransition> driven by oracle/ref_harness/replay_kat.cc
+  nstep_*.json  : rela::MultiStepTransitionBuffer driven by oracle/ref_harness/nstep_kat.cc
+  ffnet_*.json  : pyrela/net.py AtariFFNet + pyrela/apex.py ApexAgent imported from
+                  /root/reference/pyrela (Q-values, greedy action, priority, loss)
+"""
+import json
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from synth import synth_obs, synth_params  # noqa: E402  (tests/synth.py)
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFBIN = os.path.join(ROOT, "oracle", "_ref")
+
+
+def f2h(x):
+    return struct.pack(">f", float(np.float32(x))).hex()
+
+
+def run(binary, script):
+    out = subprocess.run(
+        [os.path.join(REFBIN, binary)], input="\n".join(script) + "\n", capture_output=True, text=True, check=True
+    )
+    return [json.loads(l) for l in out.stdout.splitlines() if l.strip()]
+
+
+def save(name, script, expect, **meta):
+    path = os.path.join(HERE, name + ".json")
+    with open(path, "w") as f:
+        json.dump({"name": name, "script": script, "expect": expect, **meta}, f, separators=(",", ":"))
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+# ------------------------------------------------------------------ replay cases
+def replay_kat(name, cap, seed, alpha, beta, batch, rounds):
+    """capacity 32, priorities arange(32), update ones*(round+2)."""
+    s = ["new %d %d %s %s 0" % (cap, seed, f2h(alpha), f2h(beta))]
+    s.append("add %d 0 %s" % (cap, " ".join(f2h(i) for i in range(cap))))
+    for r in range(rounds):
+        s.append("sample %d" % batch)
+        s.append("update %d %s" % (batch, " ".join(f2h(r + 2) for _ in range(batch))))
+    save(name, s, run("replay_kat", s))
+
+
+def replay_random(name, cap, seed, alpha, beta, batch, block, n_blocks, sample_every, prio_fn, rng_seed):
+    rng = np.random.default_rng(rng_seed)
+    ring = int(1.25 * cap)
+    s = ["new %d %d %s %s 0" % (cap, seed, f2h(alpha), f2h(beta))]
+    tag = 0
+    size = 0
+    for b in range(n_blocks):
+        if size + block > ring:
+            # the reference would block here; sample to evict
+            s.append("sample %d" % batch)
+            s.append("update %d %s" % (batch, " ".join(f2h(p) for p in prio_fn(rng, batch))))
+            size = min(size, cap)
+        s.append("add %d %d %s" % (block, tag, " ".join(f2h(p) for p in prio_fn(rng, block))))
+        tag += block
+        size += block
+        if (b + 1) % sample_every == 0 and size >= batch:
+            s.append("sample %d" % batch)
+            s.append("update %d %s" % (batch, " ".join(f2h(p) for p in prio_fn(rng, batch))))
+            size = min(size, cap)
+    save(name, s, run("replay_kat", s))
+
+
+def p_uniform(rng, n):
+    return rng.uniform(0.01, 2.0, n).astype(np.float32)
+
+
+def p_loguniform(rng, n):
+    return np.exp(rng.uniform(np.log(1e-6), np.log(1e3), n)).astype(np.float32)
+
+
+def p_sparse(rng, n):
+    p = rng.uniform(0.0, 1.0, n).astype(np.float32)
+    p[rng.uniform(size=n) < 0.6] = 0.0
+    return p
+
+
+def p_spiky(rng, n):
+    p = rng.uniform(0.001, 0.01, n).astype(np.float32)
+    p[rng.uniform(size=n) < 0.05] = 1000.0
+    return p
+
+
+def replay_cases():
+    replay_kat("replay_kat_a1_b1_seed42", 32, 42, 1.0, 1.0, 8, 3)
+    replay_kat("replay_kat_a06_b04_seed7", 32, 7, 0.6, 0.4, 8, 3)
+    # wrap-around + eviction + updates of evicted ids
+    replay_random("replay_wrap_evict_a1", 64, 10002, 1.0, 0.4, 8, 16, 40, 2, p_uniform, 1)
+    replay_random("replay_wrap_evict_a06", 64, 10002, 0.6, 0.4, 8, 16, 40, 2, p_uniform, 2)
+    # zero priorities (leading zeros, acc > 0 guard)
+    replay_random("replay_zeros_a1", 128, 5, 1.0, 1.0, 16, 32, 12, 3, p_sparse, 3)
+    # duplicates: a few huge weights take several strata each
+    replay_random("replay_spiky_a1", 256, 77, 1.0, 0.4, 32, 64, 12, 2, p_spiky, 4)
+    # wide dynamic range: exercises f64 rounding in the sequential accumulator
+    replay_random("replay_lograng_a1", 2048, 123, 1.0, 0.4, 64, 256, 14, 4, p_loguniform, 5)
+    replay_random("replay_lograng_a06", 2048, 321, 0.6, 0.4, 64, 256, 14, 4, p_loguniform, 6)
+    # tiny sum: sum - 0.2 < 0 clamps every target below zero (first positive weight wins)
+    s = ["new 16 9 %s %s 0" % (f2h(1.0), f2h(1.0))]
+    s.append("add 8 0 " + " ".join(f2h(v) for v in [0, 0, 0.01, 0.02, 0, 0.03, 0.01, 0.02]))
+    s.append("sample 4")
+    s.append("update 4 " + " ".join(f2h(v) for v in [0.5, 0.25, 0.125, 0.0625]))
+    s.append("sample 4")
+    s.append("update 4 " + " ".join(f2h(v) for v in [1, 1, 1, 1]))
+    s.append("sample 4")
+    save("replay_tiny_sum_clamp", s, run("replay_kat", s))
+
+
+# ------------------------------------------------------------------ n-step cases
+def nstep_cases():
+    for n, gamma, seed in [(1, 0.99, 11), (3, 0.997, 12), (5, 0.997, 13), (3, 0.5, 14)]:
+        rng = np.random.default_rng(seed)
+        K = 6
+        s = ["new %d %d %s" % (n, K, f2h(gamma))]
+        for _ in range(48):
+            if seed % 2:
+                r = rng.integers(-1, 2, K).astype(np.float32)
+            else:
+                r = rng.normal(0, 1, K).astype(np.float32)
+            t = (rng.uniform(size=K) < 0.15).astype(int)
+            s.append("step %s %s" % (" ".join(f2h(v) for v in r), " ".join(str(v) for v in t)))
+        save("nstep_n%d_seed%d" % (n, seed), s, run("nstep_kat", s), multi_step=n, K=K, gamma=f2h(gamma))
+
+
+# ------------------------------------------------------------------ network cases
+def ffnet_cases():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference/pyrela")
+    import torch
+    from apex import ApexAgent  # noqa: the reference's own modules
+    from net import AtariFFNet
+
+    torch.set_num_threads(4)
+    for name, A, N, legal_mode in [("ffnet_A18_N5", 18, 5, "ones"), ("ffnet_A6_N3_masked", 6, 3, "mask")]:
+        agent = ApexAgent(lambda: AtariFFNet(A), 3, 0.997)
+        on, tg = synth_params(A, 1001), synth_params(A, 2002)
+        agent.online_net.load_state_dict({k: torch.from_numpy(v) for k, v in on.items()})
+        agent.target_net.load_state_dict({k: torch.from_numpy(v) for k, v in tg.items()})
+        s, ns = synth_obs(N, 31), synth_obs(N, 32)
+        rng = np.random.default_rng(33)
+        legal = np.ones((N, A), np.float32)
+        if legal_mode == "mask":
+            legal[:, 1::2] = 0.0
+        action = rng.integers(0, A, N)
+        if legal_mode == "mask":
+            action = (action // 2) * 2
+        reward = rng.integers(-1, 2, N).astype(np.float32)
+        bootstrap = (rng.uniform(size=N) < 0.8).astype(np.float32)
+        obs = {"s": torch.from_numpy(s), "legal_move": torch.from_numpy(legal), "eps": torch.zeros(N, 1)}
+        nobs = {"s": torch.from_numpy(ns), "legal_move": torch.from_numpy(legal), "eps": torch.zeros(N, 1)}
+        with torch.no_grad():
+            q = agent.online_net(obs)
+            qn = agent.online_net(nobs)
+            qt = agent.target_net(nobs)
+            greedy = agent.greedy_act(obs)
+            act = agent.act(obs)["a"]  # eps == 0 -> greedy branch
+            prio = agent.compute_priority(
+                obs, {"a": torch.from_numpy(action)}, torch.from_numpy(reward), torch.zeros(N, dtype=torch.bool),
+                torch.from_numpy(bootstrap), nobs)
+            err = agent.td_err(obs, {"a": torch.from_numpy(action)}, torch.from_numpy(reward),
+                               torch.from_numpy(bootstrap), nobs)
+        save(name, [], [], num_action=A, N=N, legal_mode=legal_mode, online_seed=1001, target_seed=2002,
+             obs_seed=31, next_obs_seed=32, misc_seed=33, multi_step=3, gamma=0.997,
+             action=action.tolist(), reward=reward.tolist(), bootstrap=bootstrap.tolist(),
+             q=q.numpy().astype(np.float64).tolist(), q_next_online=qn.numpy().astype(np.float64).tolist(),
+             q_next_target=qt.numpy().astype(np.float64).tolist(), greedy=greedy.tolist(), act_eps0=act.tolist(),
+             priority=prio.numpy().astype(np.float64).tolist(), td_err=err.numpy().astype(np.float64).tolist())
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["replay", "nstep", "ffnet"]
+    if "replay" in which:
+        replay_cases()
+    if "nstep" in which:
+        nstep_cases()
+    if "ffnet" in which:
+        ffnet_cases()
