@@ -1,0 +1,165 @@
+/* rela_amd.h -- C ABI of the MI355X-native actor-learner hot path (librela_amd.so).
+ *
+ * Plain pointers, sizes and int status codes only; no torch / pybind types.  This is the
+ * boundary the reference's own binding layer (rela/pybind.cc) would call into: every entry
+ * point cites the reference interface it stands in for (paths under the reference repo).
+ * The pybind module `rela` in rela_amd/pybind/ is a thin marshalling layer over this file
+ * (see INTEGRATION.md for the binding a reference maintainer would add).
+ *
+ * Conventions
+ *   - "dev" pointers are device (HBM) addresses on the GPU the object was created on;
+ *     "host" pointers are ordinary process memory.
+ *   - `stream` arguments are hipStream_t handles passed as void* (NULL = default stream).
+ *     Work is stream-ordered; no entry point synchronises the device unless it says so.
+ *   - Every function returns RELA_OK (0) or a negative RELA_E* code and never throws.
+ *   - There is no CPU fallback: without a usable GPU the create calls return RELA_ENODEV.
+ */
+#ifndef RELA_AMD_H
+#define RELA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RELA_OK 0
+#define RELA_EINVAL (-1)     /* bad argument / shape                                          */
+#define RELA_ENODEV (-2)     /* no HIP device / HIP runtime error (see rela_last_error)       */
+#define RELA_ENOMEM (-3)     /* device allocation failed                                      */
+#define RELA_ESTATE (-4)     /* protocol violation, e.g. sample() twice without update        */
+#define RELA_ESCAN (-5)      /* a stratified target ran off the end of the ring               */
+#define RELA_EWOULDBLOCK (-6) /* non-blocking add: ring is full                                */
+
+const char* rela_last_error(void); /* thread-local message of the last failing call          */
+int rela_abi_version(void);
+
+/* ===================================================================================
+ * Prioritized replay  --  rela/prioritized_replay.h:173-348 (PrioritizedReplay<T>) over
+ * :14-171 (ConcurrentQueue<T>), bound in rela/pybind.cc:37-59.
+ *
+ * Storage is device resident: one f32 weight ring of int(1.25*capacity) slots (:181),
+ * an evicted-flag ring, the f64 running sum, and one row array per field of the
+ * transition (structure of arrays, row r of field f at base_f + slot*row_bytes_f).
+ * =================================================================================== */
+typedef struct rela_replay rela_replay;
+
+/* PrioritizedReplay(capacity, seed, alpha, beta, prefetch)  prioritized_replay.h:175-184.
+ * `prefetch` is accepted for signature parity; sampling here is asynchronous device work,
+ * so results always follow the prefetch == 0 ordering.                                    */
+int rela_replay_create(rela_replay** out, int capacity, int seed, float alpha, float beta,
+                       int prefetch, int device);
+void rela_replay_destroy(rela_replay* r);
+
+/* Declares the transition layout once, before the first add: nfields rows per slot, field
+ * f being row_bytes[f] bytes (FFTransition: types.h:18-51; RNNTransition: types.h:53-73).  */
+int rela_replay_set_schema(rela_replay* r, int nfields, const int64_t* row_bytes);
+
+/* add(sample, priority)  prioritized_replay.h:186-200 -> blockAppend :43-78.
+ * rows_dev[f] points at n consecutive rows of field f (device); priority_dev is f32[n]
+ * (device).  Weights are pow(priority, alpha) (:188).  Blocks while the ring cannot take n
+ * more slots (:47) unless `nonblocking`, in which case it returns RELA_EWOULDBLOCK.
+ * `stream` is the producer's stream: the copy is ordered after work already queued there
+ * and the producer may reuse its buffers for work queued on that stream afterwards.        */
+int rela_replay_add(rela_replay* r, int n, const void* const* rows_dev, const float* priority_dev,
+                    int nonblocking, void* stream);
+
+/* sample(batchsize, device)  prioritized_replay.h:202-233 -> sample_ :258-328 + makeBatch
+ * (types.cc:8-46).  Writes batch rows of every field to out_rows_dev[f] (device, batch rows
+ * each) and the importance weights (:320-322) to out_weight_dev (f32[batch], device).
+ * out_rows_dev may be NULL to skip the gather (benchmark.py:93-96 ignores the batch).
+ * `stream`: the consumer's stream; outputs are valid for work queued on it afterwards.
+ * Exactly one batch may be outstanding (:203-206) -> RELA_ESTATE.                          */
+int rela_replay_sample(rela_replay* r, int batch, void* const* out_rows_dev, float* out_weight_dev,
+                       void* stream);
+
+/* updatePriority(priority)  prioritized_replay.h:235-245 -> update :105-119.
+ * priority is f32[n] for the outstanding batch; on_device selects host or device memory
+ * (the reference takes a CPU tensor; a device pointer avoids the learner's per-step sync,
+ * pyrela/apex.py:90).  `stream`: the stream that produced a device-side priority.          */
+int rela_replay_update_priority(rela_replay* r, int n, const float* priority, int on_device,
+                                void* stream);
+
+int rela_replay_size(const rela_replay* r);        /* size()    :245-247 */
+int64_t rela_replay_num_add(const rela_replay* r); /* numAdd()  :251-253 */
+
+/* Test / diagnostic taps (synchronise the replay's stream).  ids_host receives the
+ * physical slots of the outstanding batch (sampledIds_), raw_w_host their un-normalised
+ * weights, targets_host the stratified targets; any of them may be NULL.                    */
+typedef struct {
+  int32_t head, tail, size, safe_size, ring, n_sampled;
+  int64_t num_add;
+  double sum;       /* ConcurrentQueue::sum_ */
+  int32_t dev_error; /* sticky device-side error flag (RELA_ESCAN ...) */
+  int32_t pad;
+} rela_replay_state;
+int rela_replay_debug_state(rela_replay* r, rela_replay_state* out, int32_t* ids_host,
+                            float* raw_w_host, float* targets_host);
+int rela_replay_debug_weights(rela_replay* r, float* weights_host, uint8_t* evicted_host);
+
+/* The scan primitive on its own: for nt targets (f64, host, ascending not required) over the
+ * logical range [head, head+size) of a device weight ring, the first index whose
+ * sequentially-rounded f64 prefix sum reaches the target (:266-308).  Synchronous; for
+ * tests and for the scan roofline measurement.  out_* are host arrays of nt.               */
+int rela_seqscan_search(const float* ring_dev, int64_t ring, int64_t head, int64_t size,
+                        const double* targets_host, int nt, int64_t* out_index, double* out_acc,
+                        float* out_w, double* out_total, void* stream);
+
+/* ===================================================================================
+ * n-step return  --  MultiStepTransitionBuffer::popTransition, rela/dqn_actor.h:58-106.
+ * reward_hist / terminal_hist are [multi_step+1][K] device arrays (row 0 oldest).
+ * =================================================================================== */
+int rela_nstep_return(int multi_step, int K, float gamma, const float* reward_hist_dev,
+                      const uint8_t* terminal_hist_dev, float* out_reward_dev,
+                      float* out_bootstrap_dev, uint8_t* out_terminal_dev, void* stream);
+
+/* ===================================================================================
+ * Ape-X network and agent ops  --  pyrela/net.py:8-55 (AtariFFNet), pyrela/apex.py:30-78.
+ * A net object owns one immutable, kernel-friendly copy of the parameters; ModelLocker
+ * (rela/model_locker.h:11-65) swaps whole net objects.
+ * =================================================================================== */
+typedef struct rela_ffnet rela_ffnet;
+
+typedef struct {
+  const float *conv1_w, *conv1_b; /* net.0.weight (32,4,8,8),   net.0.bias (32)  */
+  const float *conv2_w, *conv2_b; /* net.2.weight (64,32,4,4),  net.2.bias (64)  */
+  const float *conv3_w, *conv3_b; /* net.4.weight (64,64,3,3),  net.4.bias (64)  */
+  const float *fc_w, *fc_b;       /* linear.0.weight (512,3136), linear.0.bias   */
+  const float *v_w, *v_b;         /* fc_v.weight (1,512),  fc_v.bias (1)         */
+  const float *a_w, *a_b;         /* fc_a.weight (A,512),  fc_a.bias (A)         */
+} rela_ffnet_params;
+
+int rela_ffnet_create(rela_ffnet** out, int num_action, int device);
+void rela_ffnet_destroy(rela_ffnet* net);
+/* load_state_dict (model_locker.h:31): params are f32 in state_dict layout, host or device */
+int rela_ffnet_load(rela_ffnet* net, const rela_ffnet_params* params, int params_on_device,
+                    void* stream);
+int rela_ffnet_num_action(const rela_ffnet* net);
+/* bytes of scratch rela_ffnet_forward needs for a batch of n */
+int64_t rela_ffnet_workspace_bytes(const rela_ffnet* net, int n);
+
+/* AtariFFNet.forward  net.py:42-55: q[n,A] (device f32) from s u8[n,4,84,84], legal f32[n,A] */
+int rela_ffnet_forward(const rela_ffnet* net, int n, const uint8_t* s_dev, const float* legal_dev,
+                       float* q_dev, void* workspace_dev, int64_t workspace_bytes, void* stream);
+
+/* ApexAgent.act  apex.py:57-65 on top of greedy_act :48-54: eps-greedy over q[n,A].
+ * eps_dev f32[n]; rng_seed/rng_offset select the Philox stream for the random branch
+ * (the reference uses the torch global generator: only the eps==0 branch is reproducible,
+ * SURVEY H4).  action_dev is int64[n].                                                     */
+int rela_apex_act_from_q(int n, int num_action, const float* q_dev, const float* legal_dev,
+                         const float* eps_dev, uint64_t rng_seed, uint64_t rng_offset,
+                         int64_t* action_dev, void* stream);
+
+/* ApexAgent.td_err / compute_priority  apex.py:30-45,68-78 from the three Q tables:
+ * q = online(s), q_next_online = online(s'), q_next_target = target(s').
+ * td_err_dev (signed, may be NULL) and priority_dev (= |td_err|, may be NULL) are f32[n]. */
+int rela_apex_td_from_q(int n, int num_action, const float* q_dev, const float* q_next_online_dev,
+                        const float* q_next_target_dev, const float* next_legal_dev,
+                        const int64_t* action_dev, const float* reward_dev,
+                        const float* bootstrap_dev, float gamma_n, float* td_err_dev,
+                        float* priority_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELA_AMD_H */

@@ -1,0 +1,83 @@
+"""ctypes binding of include/rela_amd.h (librela_amd.so).
+
+There is no fallback: if the shared library is missing the import fails loudly.  Build it with
+`python -m rela_amd.build` (or __graft_entry__.build()).
+"""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "librela_amd.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "rela_amd: %s is missing -- the HIP extension has not been built (python -m rela_amd.build). "
+        "There is no CPU fallback for this path." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+OK, EINVAL, ENODEV, ENOMEM, ESTATE, ESCAN, EWOULDBLOCK = 0, -1, -2, -3, -4, -5, -6
+
+vp, i32, i64, u64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double
+P = C.POINTER
+
+
+class ReplayState(C.Structure):
+    _fields_ = [("head", C.c_int32), ("tail", C.c_int32), ("size", C.c_int32), ("safe_size", C.c_int32),
+                ("ring", C.c_int32), ("n_sampled", C.c_int32), ("num_add", C.c_int64), ("sum", C.c_double),
+                ("dev_error", C.c_int32), ("pad", C.c_int32)]
+
+
+class FFNetParams(C.Structure):
+    _fields_ = [(n, vp) for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "conv3_w", "conv3_b", "fc_w", "fc_b",
+                                  "v_w", "v_b", "a_w", "a_b")]
+
+
+MISSING = []  # symbols of include/rela_amd.h the loaded library lacks (tests assert this is empty)
+
+
+def _sig(name, restype, argtypes):
+    try:
+        fn = getattr(lib, name)
+    except AttributeError:
+        MISSING.append(name)
+        return None
+    fn.restype = restype
+    fn.argtypes = argtypes
+    return fn
+
+
+_sig("rela_last_error", C.c_char_p, [])
+_sig("rela_abi_version", i32, [])
+_sig("rela_replay_create", i32, [P(vp), i32, i32, f32, f32, i32, i32])
+_sig("rela_replay_destroy", None, [vp])
+_sig("rela_replay_set_schema", i32, [vp, i32, P(i64)])
+_sig("rela_replay_add", i32, [vp, i32, P(vp), vp, i32, vp])
+_sig("rela_replay_sample", i32, [vp, i32, P(vp), vp, vp])
+_sig("rela_replay_update_priority", i32, [vp, i32, vp, i32, vp])
+_sig("rela_replay_size", i32, [vp])
+_sig("rela_replay_num_add", i64, [vp])
+_sig("rela_replay_debug_state", i32, [vp, P(ReplayState), vp, vp, vp])
+_sig("rela_replay_debug_weights", i32, [vp, vp, vp])
+_sig("rela_seqscan_search", i32, [vp, i64, i64, i64, vp, i32, vp, vp, vp, P(f64), vp])
+_sig("rela_nstep_return", i32, [i32, i32, f32, vp, vp, vp, vp, vp, vp])
+_sig("rela_ffnet_create", i32, [P(vp), i32, i32])
+_sig("rela_ffnet_destroy", None, [vp])
+_sig("rela_ffnet_load", i32, [vp, P(FFNetParams), i32, vp])
+_sig("rela_ffnet_num_action", i32, [vp])
+_sig("rela_ffnet_workspace_bytes", i64, [vp, i32])
+_sig("rela_ffnet_forward", i32, [vp, i32, vp, vp, vp, vp, i64, vp])
+_sig("rela_apex_act_from_q", i32, [i32, i32, vp, vp, vp, u64, u64, vp, vp])
+_sig("rela_apex_td_from_q", i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp])
+
+
+class RelaError(RuntimeError):
+    def __init__(self, code, where):
+        msg = lib.rela_last_error()
+        super().__init__("%s failed with code %d: %s" % (where, code, msg.decode() if msg else ""))
+        self.code = code
+
+
+def check(code, where):
+    if code != OK:
+        raise RelaError(code, where)

@@ -1,0 +1,537 @@
+// replay.hip -- device-resident prioritized replay behind the C ABI of include/rela_amd.h.
+//
+// Restates rela/prioritized_replay.h: ConcurrentQueue (:14-171) + PrioritizedReplay (:173-348).
+//
+// Split of responsibilities
+//   host  : the integer bookkeeping of ConcurrentQueue (head_/tail_/size_, back-pressure on
+//           cvSize_ :47, the one-outstanding-batch protocol :203-206) and the std::mt19937
+//           that draws the stratified samples (:267,279,346).  The host never reads weights.
+//   device: the f32 weight ring, the evicted flags, the f64 running sum_ and every float /
+//           double operation on them, in the reference's order:
+//             add      w = pow(p, alpha) :188; float block sum added to the f64 sum_ :58-66,73
+//             sample_  sum narrowed to float :30-36; targets u*segment + i*segment clamped to
+//                      sum - 0.2f :264-280; sequential f64 scan :282-308 (seqsum_core.h);
+//                      eviction diff :85-95; IS weights :320-322; batch gather (types.cc:8-46)
+//             update   diff += (new - old) in float, accumulated in f64 :105-119
+//   All device work of one replay is serialised on its own stream in the order the host
+//   committed it, which is exactly the in-slot-order commit the reference enforces with
+//   cvTail_ (:69-74); producers/consumers are tied in with events, never with host syncs.
+//
+// HBM layout: weights f32[ring], evicted u8[ring], field f rows at base_f + slot*row_bytes_f.
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <random>
+#include <vector>
+
+#include "common.h"
+#include "seqsum_dev.h"
+
+namespace rela_amd {
+
+static thread_local char g_err[512] = "";
+void set_last_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+struct ReplayDevState {
+  double sum;       // ConcurrentQueue::sum_
+  float sum_f;      // sum_ narrowed at the last sample_ (:261-262)
+  int32_t err;      // sticky device-side error
+  double last_pop;  // diff of the last blockPop (diagnostic)
+};
+
+namespace {
+
+constexpr int kMaxBatch = 4096;
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float pow_alpha(float p, float alpha) {
+  // ATen copies for exponent 1 (the reference's own test uses alpha = 1,
+  // rela/tests/test_prioritized_replay.cc:19); otherwise powf (SLEEF there, ocml here).
+  return alpha == 1.0f ? p : powf(p, alpha);
+}
+
+// ---- add ------------------------------------------------------------------------------
+// blockAppend :57-66,73.  One workgroup: weights in parallel, then lane 0 accumulates the
+// block sum in FLOAT in slot order (exactly `sum += weightAcc[i]`) and adds it to sum_.
+__global__ __launch_bounds__(kThreads) void replay_append_weights(const float* __restrict__ prio, int n,
+                                                                  float alpha, float* __restrict__ w,
+                                                                  int ring, int start,
+                                                                  ReplayDevState* __restrict__ st) {
+  __shared__ float chunk[2048];
+  float fsum = 0.f;
+  for (int base = 0; base < n; base += 2048) {
+    const int m = min(2048, n - base);
+    for (int i = threadIdx.x; i < m; i += kThreads) {
+      const float v = pow_alpha(prio[base + i], alpha);
+      chunk[i] = v;
+      w[(int)(((int64_t)start + base + i) % ring)] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < m; ++i) fsum += chunk[i];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) st->sum += (double)fsum;
+}
+
+// copies n rows of one field into ring slots start.. (mod ring); 16-byte lanes when possible
+__global__ __launch_bounds__(kThreads) void replay_scatter_rows(const uint8_t* __restrict__ src,
+                                                                uint8_t* __restrict__ dst, int64_t row_bytes,
+                                                                int n, int ring, int start, int vec16) {
+  for (int row = blockIdx.y; row < n; row += gridDim.y) {
+    const int slot = (int)(((int64_t)start + row) % ring);
+    const uint8_t* s = src + (int64_t)row * row_bytes;
+    uint8_t* d = dst + (int64_t)slot * row_bytes;
+    if (vec16) {
+      const int64_t nv = row_bytes >> 4;
+      const uint4* s4 = reinterpret_cast<const uint4*>(s);
+      uint4* d4 = reinterpret_cast<uint4*>(d);
+      for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kThreads)
+        d4[i] = s4[i];
+    } else {
+      for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < row_bytes; i += (int64_t)gridDim.x * kThreads)
+        d[i] = s[i];
+    }
+  }
+}
+
+// gathers batch rows of one field: out[i] = field[ids[i]]   (makeBatch, types.cc:8-46)
+__global__ __launch_bounds__(kThreads) void replay_gather_rows(const uint8_t* __restrict__ field,
+                                                               const int32_t* __restrict__ ids,
+                                                               uint8_t* __restrict__ out, int64_t row_bytes,
+                                                               int vec16) {
+  const int row = blockIdx.y;
+  const uint8_t* s = field + (int64_t)ids[row] * row_bytes;
+  uint8_t* d = out + (int64_t)row * row_bytes;
+  if (vec16) {
+    const int64_t nv = row_bytes >> 4;
+    const uint4* s4 = reinterpret_cast<const uint4*>(s);
+    uint4* d4 = reinterpret_cast<uint4*>(d);
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kThreads)
+      d4[i] = s4[i];
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < row_bytes; i += (int64_t)gridDim.x * kThreads)
+      d[i] = s[i];
+  }
+}
+
+// ---- sample ---------------------------------------------------------------------------
+// Stratified targets :261-280 from the raw mt19937 draws.  libstdc++'s
+// uniform_real_distribution<float>(0, segment) is canonical*(segment-0)+0 with
+// canonical = float(u32)/2^32 clamped below 1 (oracle/mt19937.c restates it).
+// The reference scans once for all targets and never moves backwards, so the effective
+// target of sample i is max(rand_0..rand_i); a non-positive target means "first acc > 0".
+__global__ void replay_targets(const uint32_t* __restrict__ draws, int batch, ReplayDevState* __restrict__ st,
+                               float* __restrict__ targets, double* __restrict__ eff) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float sum = (float)st->sum;
+  st->sum_f = sum;
+  const float segment = sum / (float)batch;
+  const float cap = sum - 0.2f;
+  double run = 4.9406564584124654e-324;  // denorm_min: acc >= it  <=>  acc > 0
+  for (int i = 0; i < batch; ++i) {
+    float c = (float)draws[i] * 2.3283064365386963e-10f;  // exact scaling by 2^-32
+    if (c >= 1.0f) c = 0.99999994f;
+    const float u = c * segment + 0.0f;
+    const float off = (float)i * segment;
+    float r = u + off;
+    r = (r < cap) ? r : cap;  // std::min(sum - 0.2f, rand)
+    targets[i] = r;
+    const double rd = (double)r;
+    if (rd > run) run = rd;
+    eff[i] = run;
+  }
+}
+
+__global__ void replay_search(SeqView v, const double* __restrict__ eff, int batch, int32_t* __restrict__ ids,
+                              float* __restrict__ raw_w, uint8_t* __restrict__ evicted,
+                              ReplayDevState* __restrict__ st) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= batch) return;
+  const SeqHit h = seq_find(v, eff[i]);
+  int64_t k = h.k;
+  if (!h.found) {  // :297-302 (the reference aborts here)
+    st->err = RELA_ESCAN;
+    k = v.size > 0 ? v.size - 1 : 0;
+  }
+  const int64_t p = seq_phys(v, k);
+  ids[i] = (int32_t)p;
+  raw_w[i] = h.found ? h.w : 0.f;
+  evicted[p] = 0;  // getElementAndMark :124-128
+}
+
+// blockPop :84-103.  The evicted range is the first n_pop logical slots of the range the scan
+// just indexed, and `diff -= w` from zero is the negated sequential prefix (RNE is symmetric).
+__global__ __launch_bounds__(kThreads) void replay_pop(SeqView v, int n_pop, uint8_t* __restrict__ evicted,
+                                                       ReplayDevState* __restrict__ st) {
+  const int tid = blockIdx.x * kThreads + threadIdx.x;
+  for (int k = tid; k < n_pop; k += gridDim.x * kThreads) evicted[seq_phys(v, k)] = 1;
+  if (tid == 0) {
+    const double diff = -seq_prefix(v, n_pop);
+    st->last_pop = diff;
+    st->sum += diff;
+  }
+}
+
+// IS weights :320-322: w/sum -> pow(size*w, -beta) -> /= max     (one workgroup)
+__global__ __launch_bounds__(1024) void replay_is_weights(const float* __restrict__ raw_w, int batch,
+                                                          float size_f, float beta,
+                                                          const ReplayDevState* __restrict__ st,
+                                                          float* __restrict__ out) {
+  __shared__ float red[1024];
+  const float sum = st->sum_f;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < batch; i += blockDim.x) {
+    const float q = raw_w[i] / sum;
+    const float s = size_f * q;
+    const float p = (beta == 1.0f) ? 1.0f / s : powf(s, -beta);
+    out[i] = p;
+    mx = fmaxf(mx, p);
+  }
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
+    if (threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
+    __syncthreads();
+  }
+  mx = red[0];
+  for (int i = threadIdx.x; i < batch; i += blockDim.x) out[i] = out[i] / mx;
+}
+
+// ---- update ---------------------------------------------------------------------------
+// update :105-119 for the outstanding batch.  Sequential semantics with duplicate ids: the
+// i-th occurrence sees the weight written by the previous occurrence.  One workgroup:
+// pow + old-weight gather + duplicate resolution in parallel, the f64 diff chain on lane 0.
+__global__ __launch_bounds__(1024) void replay_update(const float* __restrict__ prio, int n, float alpha,
+                                                      const int32_t* __restrict__ ids,
+                                                      const uint8_t* __restrict__ evicted,
+                                                      float* __restrict__ w, ReplayDevState* __restrict__ st) {
+  __shared__ float neww[kMaxBatch];
+  __shared__ float dlt[kMaxBatch];
+  __shared__ int32_t sid[kMaxBatch];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    neww[i] = pow_alpha(prio[i], alpha);
+    sid[i] = ids[i];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int id = sid[i];
+    float d = 0.f;
+    bool last = true;
+    if (!evicted[id]) {
+      int prev = -1;
+      for (int j = i - 1; j >= 0; --j)
+        if (sid[j] == id) {
+          prev = j;
+          break;
+        }
+      const float old = prev >= 0 ? neww[prev] : w[id];
+      d = neww[i] - old;  // float - float :113
+      for (int j = i + 1; j < n; ++j)
+        if (sid[j] == id) {
+          last = false;
+          break;
+        }
+    } else {
+      last = false;
+    }
+    dlt[i] = d;
+    // all reads of w[] above must finish before anyone writes: writes happen after the barrier
+    sid[i] = last ? id : -1 - id;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    if (sid[i] >= 0) w[sid[i]] = neww[i];
+  if (threadIdx.x == 0) {
+    double diff = 0;
+    for (int i = 0; i < n; ++i) diff += (double)dlt[i];  // evicted ids contribute +0.0f (a no-op)
+    st->sum += diff;
+  }
+}
+
+}  // namespace
+}  // namespace rela_amd
+
+using namespace rela_amd;
+
+struct rela_replay {
+  int device = 0;
+  int capacity = 0, ring = 0, prefetch = 0;
+  float alpha = 0, beta = 0;
+  std::mt19937 rng;
+  mutable std::mutex m;
+  std::condition_variable cv_size;
+  int head = 0, tail = 0, size = 0;
+  std::atomic<int64_t> num_add{0};
+  int n_sampled = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  float* d_w = nullptr;
+  uint8_t* d_evicted = nullptr;
+  ReplayDevState* d_state = nullptr;
+  int32_t* d_ids = nullptr;
+  float* d_raw_w = nullptr;
+  float* d_targets = nullptr;
+  double* d_eff = nullptr;
+  uint32_t* d_draws = nullptr;
+  float* d_prio = nullptr;  // staging for host-side priorities
+  std::vector<int64_t> row_bytes;
+  std::vector<uint8_t*> d_fields;
+  SeqIndex ix;
+};
+
+extern "C" const char* rela_last_error(void) { return g_err; }
+extern "C" int rela_abi_version(void) { return 1; }
+
+extern "C" int rela_replay_create(rela_replay** out, int capacity, int seed, float alpha, float beta,
+                                  int prefetch, int device) {
+  RELA_CHECK(out && capacity > 0, RELA_EINVAL, "rela_replay_create: bad arguments");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    set_last_error("rela_replay_create: HIP device %d not available (%d visible); there is no CPU path", device,
+                   ndev);
+    return RELA_ENODEV;
+  }
+  DeviceGuard g(device);
+  auto* r = new rela_replay();
+  r->device = device;
+  r->capacity = capacity;
+  r->ring = (int)(1.25 * capacity);  // :181
+  r->alpha = alpha;
+  r->beta = beta;
+  r->prefetch = prefetch;
+  r->rng.seed(seed);  // :183
+  RELA_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+  RELA_HIP(hipEventCreateWithFlags(&r->ev_in, hipEventDisableTiming));
+  RELA_HIP(hipEventCreateWithFlags(&r->ev_out, hipEventDisableTiming));
+  RELA_HIP(hipMalloc(&r->d_w, sizeof(float) * (size_t)r->ring));
+  RELA_HIP(hipMalloc(&r->d_evicted, (size_t)r->ring));
+  RELA_HIP(hipMalloc(&r->d_state, sizeof(ReplayDevState)));
+  RELA_HIP(hipMalloc(&r->d_ids, sizeof(int32_t) * kMaxBatch));
+  RELA_HIP(hipMalloc(&r->d_raw_w, sizeof(float) * kMaxBatch));
+  RELA_HIP(hipMalloc(&r->d_targets, sizeof(float) * kMaxBatch));
+  RELA_HIP(hipMalloc(&r->d_eff, sizeof(double) * kMaxBatch));
+  RELA_HIP(hipMalloc(&r->d_draws, sizeof(uint32_t) * kMaxBatch));
+  RELA_HIP(hipMalloc(&r->d_prio, sizeof(float) * kMaxBatch));
+  RELA_HIP(hipMemsetAsync(r->d_w, 0, sizeof(float) * (size_t)r->ring, r->stream));
+  RELA_HIP(hipMemsetAsync(r->d_evicted, 0, (size_t)r->ring, r->stream));
+  RELA_HIP(hipMemsetAsync(r->d_state, 0, sizeof(ReplayDevState), r->stream));
+  int rc = seq_index_alloc(&r->ix, r->ring);
+  if (rc != RELA_OK) return rc;
+  RELA_HIP(hipStreamSynchronize(r->stream));
+  *out = r;
+  return RELA_OK;
+}
+
+extern "C" void rela_replay_destroy(rela_replay* r) {
+  if (!r) return;
+  DeviceGuard g(r->device);
+  (void)hipStreamSynchronize(r->stream);
+  for (auto* p : r->d_fields) (void)hipFree(p);
+  seq_index_free(&r->ix);
+  (void)hipFree(r->d_w);
+  (void)hipFree(r->d_evicted);
+  (void)hipFree(r->d_state);
+  (void)hipFree(r->d_ids);
+  (void)hipFree(r->d_raw_w);
+  (void)hipFree(r->d_targets);
+  (void)hipFree(r->d_eff);
+  (void)hipFree(r->d_draws);
+  (void)hipFree(r->d_prio);
+  (void)hipEventDestroy(r->ev_in);
+  (void)hipEventDestroy(r->ev_out);
+  (void)hipStreamDestroy(r->stream);
+  delete r;
+}
+
+extern "C" int rela_replay_set_schema(rela_replay* r, int nfields, const int64_t* row_bytes) {
+  RELA_CHECK(r && nfields >= 0 && (nfields == 0 || row_bytes), RELA_EINVAL, "rela_replay_set_schema: bad arguments");
+  std::lock_guard<std::mutex> lk(r->m);
+  RELA_CHECK(r->d_fields.empty() && r->num_add.load() == 0, RELA_ESTATE,
+             "rela_replay_set_schema: schema already set or replay not empty");
+  DeviceGuard g(r->device);
+  for (int f = 0; f < nfields; ++f) {
+    RELA_CHECK(row_bytes[f] > 0, RELA_EINVAL, "rela_replay_set_schema: field %d has %lld bytes", f,
+               (long long)row_bytes[f]);
+    uint8_t* p = nullptr;
+    RELA_HIP(hipMalloc(&p, (size_t)row_bytes[f] * (size_t)r->ring));
+    r->d_fields.push_back(p);
+    r->row_bytes.push_back(row_bytes[f]);
+  }
+  return RELA_OK;
+}
+
+static inline int vec16_ok(const void* a, const void* b, int64_t row_bytes) {
+  return ((row_bytes & 15) == 0) && (((uintptr_t)a & 15) == 0) && (((uintptr_t)b & 15) == 0);
+}
+
+extern "C" int rela_replay_add(rela_replay* r, int n, const void* const* rows_dev, const float* priority_dev,
+                               int nonblocking, void* stream_) {
+  RELA_CHECK(r && n > 0 && priority_dev, RELA_EINVAL, "rela_replay_add: bad arguments");
+  RELA_CHECK(n <= r->ring, RELA_EINVAL, "rela_replay_add: block of %d exceeds the ring (%d)", n, r->ring);
+  RELA_CHECK(r->d_fields.empty() || rows_dev, RELA_EINVAL, "rela_replay_add: rows_dev is NULL");
+  hipStream_t producer = (hipStream_t)stream_;
+  DeviceGuard g(r->device);
+  std::unique_lock<std::mutex> lk(r->m);
+  if (r->size + n > r->ring) {  // cvSize_.wait :47
+    if (nonblocking) return RELA_EWOULDBLOCK;
+    r->cv_size.wait(lk, [&] { return r->size + n <= r->ring; });
+  }
+  const int start = r->tail;
+  r->tail = (r->tail + n) % r->ring;
+  r->size += n;
+  // order after the producer's queued work, run on the replay stream, then let the producer
+  // continue only after its rows were consumed
+  RELA_HIP(hipEventRecord(r->ev_in, producer));
+  RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
+  hipLaunchKernelGGL(replay_append_weights, dim3(1), dim3(kThreads), 0, r->stream, priority_dev, n, r->alpha,
+                     r->d_w, r->ring, start, r->d_state);
+  for (size_t f = 0; f < r->d_fields.size(); ++f) {
+    const int64_t rb = r->row_bytes[f];
+    const int v16 = vec16_ok(rows_dev[f], r->d_fields[f], rb);
+    const int64_t units = v16 ? (rb >> 4) : rb;
+    int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (units + kThreads - 1) / kThreads), 64);
+    hipLaunchKernelGGL(replay_scatter_rows, dim3(gx, std::min(n, 32768)), dim3(kThreads), 0, r->stream,
+                       (const uint8_t*)rows_dev[f], r->d_fields[f], rb, n, r->ring, start, v16);
+  }
+  RELA_LAUNCH_CHECK();
+  RELA_HIP(hipEventRecord(r->ev_out, r->stream));
+  RELA_HIP(hipStreamWaitEvent(producer, r->ev_out, 0));
+  r->num_add += n;  // :190
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_rows_dev, float* out_weight_dev,
+                                  void* stream_) {
+  RELA_CHECK(r && batch > 0 && batch <= kMaxBatch && out_weight_dev, RELA_EINVAL,
+             "rela_replay_sample: bad arguments (batch must be 1..%d)", kMaxBatch);
+  hipStream_t consumer = (hipStream_t)stream_;
+  DeviceGuard g(r->device);
+  std::unique_lock<std::mutex> lk(r->m);
+  RELA_CHECK(r->n_sampled == 0, RELA_ESTATE,
+             "Error: previous samples' priority has not been updated.");  // :203-206
+  RELA_CHECK(r->size > 0, RELA_ESTATE, "rela_replay_sample: replay is empty");
+  // raw 32-bit draws, one per sample (generate_canonical<float,24> consumes exactly one)
+  std::vector<uint32_t> draws(batch);
+  for (int i = 0; i < batch; ++i) draws[i] = (uint32_t)r->rng();
+  // outputs belong to the consumer: do not overwrite them before its queued work is done
+  RELA_HIP(hipEventRecord(r->ev_in, consumer));
+  RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
+  RELA_HIP(hipMemcpyAsync(r->d_draws, draws.data(), sizeof(uint32_t) * batch, hipMemcpyHostToDevice, r->stream));
+  const int size = r->size;  // == safeSize_: reservation and commit are one step here
+  SeqView v;
+  int rc = seq_index_build(r->ix, r->d_w, r->ring, r->head, size, r->stream, &v);
+  if (rc != RELA_OK) return rc;
+  hipLaunchKernelGGL(replay_targets, dim3(1), dim3(64), 0, r->stream, r->d_draws, batch, r->d_state,
+                     r->d_targets, r->d_eff);
+  hipLaunchKernelGGL(replay_search, dim3(ceil_div(batch, 64)), dim3(64), 0, r->stream, v, r->d_eff, batch,
+                     r->d_ids, r->d_raw_w, r->d_evicted, r->d_state);
+  // pop storage if full :311-315 (size re-read, then IS weights use the pre-pop size :321)
+  const int n_pop = size > r->capacity ? size - r->capacity : 0;
+  if (n_pop > 0) {
+    hipLaunchKernelGGL(replay_pop, dim3(std::min(ceil_div(n_pop, kThreads), 256)), dim3(kThreads), 0, r->stream, v,
+                       n_pop, r->d_evicted, r->d_state);
+    r->head = (r->head + n_pop) % r->ring;
+    r->size -= n_pop;
+  }
+  hipLaunchKernelGGL(replay_is_weights, dim3(1), dim3(1024), 0, r->stream, r->d_raw_w, batch, (float)size, r->beta,
+                     r->d_state, out_weight_dev);
+  if (out_rows_dev) {
+    for (size_t f = 0; f < r->d_fields.size(); ++f) {
+      if (!out_rows_dev[f]) continue;
+      const int64_t rb = r->row_bytes[f];
+      const int v16 = vec16_ok(out_rows_dev[f], r->d_fields[f], rb);
+      const int64_t units = v16 ? (rb >> 4) : rb;
+      int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (units + kThreads - 1) / kThreads), 64);
+      hipLaunchKernelGGL(replay_gather_rows, dim3(gx, batch), dim3(kThreads), 0, r->stream, r->d_fields[f],
+                         r->d_ids, (uint8_t*)out_rows_dev[f], rb, v16);
+    }
+  }
+  RELA_LAUNCH_CHECK();
+  RELA_HIP(hipEventRecord(r->ev_out, r->stream));
+  RELA_HIP(hipStreamWaitEvent(consumer, r->ev_out, 0));
+  r->n_sampled = batch;
+  lk.unlock();
+  if (n_pop > 0) r->cv_size.notify_all();
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_update_priority(rela_replay* r, int n, const float* priority, int on_device,
+                                           void* stream_) {
+  RELA_CHECK(r && priority, RELA_EINVAL, "rela_replay_update_priority: bad arguments");
+  hipStream_t producer = (hipStream_t)stream_;
+  DeviceGuard g(r->device);
+  std::unique_lock<std::mutex> lk(r->m);
+  RELA_CHECK(n == r->n_sampled && n > 0, RELA_ESTATE,
+             "rela_replay_update_priority: %d priorities for an outstanding batch of %d", n, r->n_sampled);  // :237
+  const float* p = priority;
+  if (on_device) {
+    RELA_HIP(hipEventRecord(r->ev_in, producer));
+    RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
+  } else {
+    RELA_HIP(hipMemcpyAsync(r->d_prio, priority, sizeof(float) * n, hipMemcpyHostToDevice, r->stream));
+    p = r->d_prio;
+  }
+  hipLaunchKernelGGL(replay_update, dim3(1), dim3(1024), 0, r->stream, p, n, r->alpha, r->d_ids, r->d_evicted,
+                     r->d_w, r->d_state);
+  RELA_LAUNCH_CHECK();
+  if (on_device) {
+    RELA_HIP(hipEventRecord(r->ev_out, r->stream));
+    RELA_HIP(hipStreamWaitEvent(producer, r->ev_out, 0));
+  }
+  r->n_sampled = 0;  // sampledIds_.clear() :244
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_size(const rela_replay* r) {
+  if (!r) return 0;
+  std::lock_guard<std::mutex> lk(r->m);
+  return r->size;
+}
+
+extern "C" int64_t rela_replay_num_add(const rela_replay* r) { return r ? r->num_add.load() : 0; }
+
+extern "C" int rela_replay_debug_state(rela_replay* r, rela_replay_state* out, int32_t* ids_host, float* raw_w_host,
+                                       float* targets_host) {
+  RELA_CHECK(r && out, RELA_EINVAL, "rela_replay_debug_state: bad arguments");
+  DeviceGuard g(r->device);
+  std::lock_guard<std::mutex> lk(r->m);
+  ReplayDevState st;
+  RELA_HIP(hipMemcpyAsync(&st, r->d_state, sizeof(st), hipMemcpyDeviceToHost, r->stream));
+  const int n = r->n_sampled;
+  if (n > 0 && ids_host) RELA_HIP(hipMemcpyAsync(ids_host, r->d_ids, sizeof(int32_t) * n, hipMemcpyDeviceToHost, r->stream));
+  if (n > 0 && raw_w_host)
+    RELA_HIP(hipMemcpyAsync(raw_w_host, r->d_raw_w, sizeof(float) * n, hipMemcpyDeviceToHost, r->stream));
+  if (n > 0 && targets_host)
+    RELA_HIP(hipMemcpyAsync(targets_host, r->d_targets, sizeof(float) * n, hipMemcpyDeviceToHost, r->stream));
+  RELA_HIP(hipStreamSynchronize(r->stream));
+  out->head = r->head;
+  out->tail = r->tail;
+  out->size = r->size;
+  out->safe_size = r->size;
+  out->ring = r->ring;
+  out->n_sampled = n;
+  out->num_add = r->num_add.load();
+  out->sum = st.sum;
+  out->dev_error = st.err;
+  out->pad = 0;
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_debug_weights(rela_replay* r, float* weights_host, uint8_t* evicted_host) {
+  RELA_CHECK(r, RELA_EINVAL, "rela_replay_debug_weights: bad arguments");
+  DeviceGuard g(r->device);
+  std::lock_guard<std::mutex> lk(r->m);
+  if (weights_host)
+    RELA_HIP(hipMemcpyAsync(weights_host, r->d_w, sizeof(float) * (size_t)r->ring, hipMemcpyDeviceToHost, r->stream));
+  if (evicted_host)
+    RELA_HIP(hipMemcpyAsync(evicted_host, r->d_evicted, (size_t)r->ring, hipMemcpyDeviceToHost, r->stream));
+  RELA_HIP(hipStreamSynchronize(r->stream));
+  return RELA_OK;
+}

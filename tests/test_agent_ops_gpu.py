@@ -1,0 +1,128 @@
+"""GPU parity tests for the small actor-side ops (n-step return, eps-greedy act, TD priority),
+through the C ABI, against the golden vectors of the real reference and the CPU oracle."""
+import ctypes as C
+import glob
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def h2f(h):
+    return struct.unpack(">f", bytes.fromhex(h))[0]
+
+
+def f2h(x):
+    return struct.pack(">f", float(np.float32(x))).hex()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "nstep_*.json"))), ids=os.path.basename)
+def test_nstep_golden(path):
+    """rela_nstep_return vs MultiStepTransitionBuffer::popTransition (dqn_actor.h:58-106): bit-exact."""
+    import torch
+
+    from gpu_util import cur_stream, dev, ptr
+    from rela_amd import _capi as capi
+
+    case = json.load(open(path))
+    n, K, gamma = case["multi_step"], case["K"], h2f(case["gamma"])
+    rh, th = [], []
+    for line, exp in zip(case["script"][1:], case["expect"][1:]):
+        tok = line.split()[1:]
+        rh.append([h2f(t) for t in tok[:K]])
+        th.append([int(t) for t in tok[K:]])
+        if not exp["pop"]:
+            continue
+        r, t = dev(np.array(rh, np.float32)), dev(np.array(th, np.uint8))
+        o_r = torch.empty(K, device="cuda")
+        o_b = torch.empty(K, device="cuda")
+        o_t = torch.empty(K, dtype=torch.uint8, device="cuda")
+        capi.check(capi.lib.rela_nstep_return(n, K, gamma, ptr(r), ptr(t), ptr(o_r), ptr(o_b), ptr(o_t), cur_stream()),
+                   "rela_nstep_return")
+        assert [f2h(x) for x in o_r.cpu().numpy()] == exp["reward"]
+        assert o_b.cpu().numpy().tolist() == exp["bootstrap"]
+        assert o_t.cpu().numpy().tolist() == exp["terminal"]
+        rh.pop(0)
+        th.pop(0)
+
+
+@pytest.mark.parametrize("n,A,masked", [(1, 18, False), (80, 18, False), (80, 6, True), (6400, 18, False)])
+def test_act_and_td_from_q(n, A, masked):
+    """Greedy branch (eps = 0) and TD priority vs the oracle (apex.py:30-78): exact, same f32 ops."""
+    import torch
+
+    from gpu_util import cur_stream, dev, ptr
+    from oracle_lib import load
+    from rela_amd import _capi as capi
+
+    lib = load()
+    rng = np.random.default_rng(n * 100 + A)
+    q = rng.normal(0, 1, (n, A)).astype(np.float32)
+    qn = rng.normal(0, 1, (n, A)).astype(np.float32)
+    qt = rng.normal(0, 1, (n, A)).astype(np.float32)
+    legal = np.ones((n, A), np.float32)
+    if masked:
+        legal[:, 1::2] = 0
+    action = rng.integers(0, A, n).astype(np.int64)
+    reward = rng.integers(-1, 2, n).astype(np.float32)
+    boot = (rng.uniform(size=n) < 0.8).astype(np.float32)
+    gamma_n = np.float32(0.997 ** 3)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    # oracle greedy
+    exp_act = np.zeros(n, np.int64)
+    lib.oracle_greedy.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
+    lib.oracle_greedy(n, A, fp(q), fp(legal), exp_act.ctypes.data_as(C.POINTER(C.c_int64)))
+    d_act = torch.empty(n, dtype=torch.int64, device="cuda")
+    capi.check(capi.lib.rela_apex_act_from_q(n, A, ptr(dev(q)), ptr(dev(legal)), ptr(dev(np.zeros(n, np.float32))), 1, 0,
+                                             ptr(d_act), cur_stream()), "act")
+    np.testing.assert_array_equal(d_act.cpu().numpy(), exp_act)
+    # oracle td from the three tables
+    na = np.zeros(n, np.int64)
+    lib.oracle_greedy(n, A, fp(qn), fp(legal), na.ctypes.data_as(C.POINTER(C.c_int64)))
+    qa = q[np.arange(n), action]
+    bq = qt[np.arange(n), na]
+    tgt = (reward + ((boot * gamma_n).astype(np.float32) * bq).astype(np.float32)).astype(np.float32)
+    err = (tgt - qa).astype(np.float32)
+    d_td = torch.empty(n, device="cuda")
+    d_pr = torch.empty(n, device="cuda")
+    capi.check(capi.lib.rela_apex_td_from_q(n, A, ptr(dev(q)), ptr(dev(qn)), ptr(dev(qt)), ptr(dev(legal)),
+                                            ptr(dev(action)), ptr(dev(reward)), ptr(dev(boot)), C.c_float(gamma_n),
+                                            ptr(d_td), ptr(d_pr), cur_stream()), "td")
+    np.testing.assert_array_equal(d_td.cpu().numpy(), err)
+    np.testing.assert_array_equal(d_pr.cpu().numpy(), np.abs(err))
+
+
+def test_eps_greedy_statistics():
+    """Random branch: statistical parity only.  With eps = 0.5 about half the rows
+    deviate from greedy towards a uniformly random LEGAL action; never an illegal one."""
+    import torch
+
+    from gpu_util import cur_stream, dev, ptr
+    from rela_amd import _capi as capi
+
+    n, A = 4096, 18
+    rng = np.random.default_rng(5)
+    q = rng.normal(0, 1, (n, A)).astype(np.float32)
+    legal = np.ones((n, A), np.float32)
+    legal[:, ::3] = 0
+    eps = np.full(n, 0.5, np.float32)
+    acts = []
+    for off in (0, n):
+        d_act = torch.empty(n, dtype=torch.int64, device="cuda")
+        capi.check(capi.lib.rela_apex_act_from_q(n, A, ptr(dev(q)), ptr(dev(legal)), ptr(dev(eps)), 99, off, ptr(d_act),
+                                                 cur_stream()), "act")
+        acts.append(d_act.cpu().numpy())
+    greedy = np.argmax((1 + q - q.min()) * legal, 1)
+    for a in acts:
+        assert (legal[np.arange(n), a] == 1).all()
+        frac = (a != greedy).mean()
+        assert 0.5 * (11 / 12) - 0.05 < frac < 0.5 * (11 / 12) + 0.05
+    assert (acts[0] != acts[1]).any()  # different Philox offsets -> different draws
+    hist = np.bincount(acts[0][acts[0] != greedy], minlength=A)[legal[0] == 1]
+    assert hist.min() > 0.5 * hist.mean()
