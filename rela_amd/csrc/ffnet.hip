@@ -1,0 +1,486 @@
+// ffnet.hip -- AtariFFNet forward (pyrela/net.py:8-55) as hand-written CDNA4 kernels.
+//
+// s u8[N,4,84,84] -> conv 8x8s4 (4->32) -> conv 4x4s2 (32->64) -> conv 3x3s1 (64->64)
+//   -> fc 3136->512 -> {fc_v 512->1, fc_a 512->A} -> dueling (net.py:33-39).
+// 9,352,704 MAC = 18.7 MFLOP per sample: MFMA-bound, not HBM-bound
+// (660 FLOP per input byte), so every contraction runs on the matrix cores in exact fp32:
+// v_mfma_f32_16x16x4_f32 is bit-for-bit a k-ordered fmaf chain (guide: FP32-input MFMA), which
+// keeps Q-values within fp32 round-off of the reference (tests use 1e-4 abs+rel).
+//
+// Formulation: implicit GEMM  Out[m = (sample, oy, ox)][n = out channel] = sum_k A[m][k] W[k][n]
+//   MFMA A operand = im2col row, read straight out of an LDS copy of the input tile
+//                    (no im2col matrix is ever materialised); lane (i = l&15, kk = l>>4)
+//                    supplies A[row i][k0 + kk],
+//   MFMA B operand = weights, pre-packed at load time in FRAGMENT ORDER
+//                    Bfrag[(col_tile*KS + kstep)*64 + lane] so a wavefront's B load is one
+//                    coalesced 256-byte read that stays L2-resident,
+//   accumulators   = 16x16 tiles, 4 VGPRs each; one wave owns one 16-channel column tile
+//                    and several row tiles, so each B fragment is reused across all of them.
+// Activations are channel-last f32 ([N][pos][C]) between layers; fc weights are permuted
+// at load time to match (k = pos*64 + c instead of torch's c*49 + pos).  LDS pixel strides
+// are padded (33 / 66 floats) so the 16 rows of a fragment hit distinct banks.
+// conv1 reads the raw u8 frames from LDS and converts in-register; the /255 of net.py:46 is
+// folded into conv1's weights at load time.
+#include "common.h"
+
+namespace rela_amd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct FFNetDev {
+  float *B1 = nullptr, *b1 = nullptr;  // conv1 frags [2][64][64], bias[32]
+  float *B2 = nullptr, *b2 = nullptr;  // conv2 frags [4][128][64], bias[64]
+  float *B3 = nullptr, *b3 = nullptr;  // conv3 frags [4][144][64], bias[64]
+  float *Bf = nullptr, *bf = nullptr;  // fc    frags [32][784][64], bias[512]
+  float *Bh = nullptr, *bh = nullptr;  // heads frags [2][128][64], bias[32]  (cols 0..A-1 = fc_a, col 31 = fc_v)
+};
+
+namespace {
+
+constexpr int kWaves = 8;
+constexpr int kThreads = kWaves * 64;
+
+template <int CIN_, int IH_, int IW_, int KH_, int KW_, int STRIDE_, int OH_, int OW_, int OC_, int S_, bool U8_>
+struct ConvCfg {
+  static constexpr int CIN = CIN_, IH = IH_, IW = IW_, KH = KH_, KW = KW_, STRIDE = STRIDE_, OH = OH_, OW = OW_,
+                       OC = OC_, S = S_;
+  static constexpr bool U8 = U8_;
+  static constexpr int P = OH * OW;
+  static constexpr int M = S * P;
+  static constexpr int RT = (M + 15) / 16;
+  static constexpr int CT = OC / 16;
+  static constexpr int RG = kWaves / CT;
+  static constexpr int RPW = (RT + RG - 1) / RG;
+  static constexpr int K = CIN * KH * KW;
+  static constexpr int KS = K / 4;
+  static constexpr int PIX = U8 ? 0 : (CIN + (STRIDE == 2 ? 1 : 2));  // floats per LDS pixel
+  static constexpr int IN_ELEMS = CIN * IH * IW;                        // per sample
+  static constexpr int LDS_BYTES = U8 ? S * IN_ELEMS : S * IH * IW * PIX * 4;
+};
+
+using Conv1 = ConvCfg<4, 84, 84, 8, 8, 4, 20, 20, 32, 2, true>;
+using Conv2 = ConvCfg<32, 20, 20, 4, 4, 2, 9, 9, 64, 2, false>;
+using Conv3 = ConvCfg<64, 9, 9, 3, 3, 1, 7, 7, 64, 4, false>;
+
+template <class C>
+__global__ __launch_bounds__(kThreads) void conv_mfma(const void* __restrict__ in_, const float* __restrict__ Bfrag,
+                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                      int N) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.x * C::S;
+  const int ns = min(C::S, N - n0);
+
+  // ---- stage the input tile of S samples in LDS -----------------------------------------
+  if constexpr (C::U8) {
+    const uint4* src = reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(in_) + (size_t)n0 * C::IN_ELEMS);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    constexpr int per = C::IN_ELEMS / 16;
+    for (int i = tid; i < C::S * per; i += kThreads) dst[i] = (i < ns * per) ? src[i] : make_uint4(0, 0, 0, 0);
+  } else {
+    const float4* src = reinterpret_cast<const float4*>(static_cast<const float*>(in_) + (size_t)n0 * C::IN_ELEMS);
+    float* dst = reinterpret_cast<float*>(smem);
+    constexpr int cq_n = C::CIN / 4;
+    constexpr int per = C::IN_ELEMS / 4;
+    for (int i = tid; i < C::S * per; i += kThreads) {
+      const float4 v = (i < ns * per) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int pixel = i / cq_n, cq = i - pixel * cq_n;
+      float* d = dst + pixel * C::PIX + cq * 4;
+      d[0] = v.x;
+      d[1] = v.y;
+      d[2] = v.z;
+      d[3] = v.w;
+    }
+  }
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int ct = wave % C::CT, rg = wave / C::CT;
+  const int li = lane & 15, kk = lane >> 4;
+
+  int abase[C::RPW];
+#pragma unroll
+  for (int t = 0; t < C::RPW; ++t) {
+    const int m = (rg + t * C::RG) * 16 + li;
+    const int mm = (m < C::M) ? m : 0;
+    const int s = mm / C::P, pos = mm - s * C::P;
+    const int oy = pos / C::OW, ox = pos - oy * C::OW;
+    if constexpr (C::U8)
+      abase[t] = s * C::IN_ELEMS + oy * C::STRIDE * C::IW + ox * C::STRIDE + kk;
+    else
+      abase[t] = ((s * C::IH * C::IW + oy * C::STRIDE * C::IW + ox * C::STRIDE) * C::PIX + kk) * 4;
+  }
+
+  f32x4 acc[C::RPW];
+#pragma unroll
+  for (int t = 0; t < C::RPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* bptr = Bfrag + (size_t)ct * C::KS * 64 + lane;
+
+  if constexpr (C::U8) {
+    // k = (c, kh, kw), kw fastest: one k-step = 4 consecutive bytes of one input row
+    for (int c = 0; c < C::CIN; ++c) {
+#pragma unroll 2
+      for (int kh = 0; kh < C::KH; ++kh) {
+#pragma unroll
+        for (int q = 0; q < C::KW / 4; ++q) {
+          const int ks = (c * C::KH + kh) * (C::KW / 4) + q;
+          const int koff = c * C::IH * C::IW + kh * C::IW + q * 4;
+          const float b = bptr[(size_t)ks * 64];
+#pragma unroll
+          for (int t = 0; t < C::RPW; ++t) {
+            const float a = (float)smem[abase[t] + koff];
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  } else {
+    // k = (kh, kw, c), c fastest: one k-step = 4 consecutive channels of one input pixel
+    for (int kh = 0; kh < C::KH; ++kh) {
+      for (int kw = 0; kw < C::KW; ++kw) {
+#pragma unroll
+        for (int cq = 0; cq < C::CIN / 4; ++cq) {
+          const int ks = (kh * C::KW + kw) * (C::CIN / 4) + cq;
+          const int koff = ((kh * C::IW + kw) * C::PIX + cq * 4) * 4;
+          const float b = bptr[(size_t)ks * 64];
+#pragma unroll
+          for (int t = 0; t < C::RPW; ++t) {
+            const float a = *reinterpret_cast<const float*>(smem + abase[t] + koff);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: bias + ReLU, channel-last store ------------------------------------------
+  const int col = ct * 16 + li;
+  const float bv = bias[col];
+  const int mlim = ns * C::P;
+#pragma unroll
+  for (int t = 0; t < C::RPW; ++t) {
+    const int rt = rg + t * C::RG;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = rt * 16 + kk * 4 + r;
+      if (m < mlim) {
+        const float v = acc[t][r] + bv;
+        out[((size_t)n0 * C::P + m) * C::OC + col] = v > 0.f ? v : 0.f;
+      }
+    }
+  }
+}
+
+// Dense layer  out[N][OC] = act(A[N][K] * W + bias)  on the same MFMA tiling.
+// Block = BM rows x (CTB*16) columns; A is staged through LDS in K-chunks of 32 (double
+// buffered, row stride 34 floats -> conflict-free fragment reads), B fragments stream from L2.
+template <int K_, int OC_, int BM_, bool RELU_>
+struct GemmCfg {
+  static constexpr int K = K_, OC = OC_, BM = BM_;
+  static constexpr bool RELU = RELU_;
+  static constexpr int CT = OC / 16;
+  static constexpr int CTB = CT < kWaves ? CT : kWaves;  // column tiles per block
+  static constexpr int RGB = kWaves / CTB;               // row groups per block
+  static constexpr int RT = BM / 16;
+  static constexpr int RPW = RT / RGB;
+  static constexpr int KC = 32;
+  static constexpr int NCH = K / KC;
+  static constexpr int KS = K / 4;
+  static constexpr int LDA = 34;
+  static constexpr int VPT = BM * KC / 4 / kThreads;  // float4 per thread per chunk
+};
+
+using GemmFc = GemmCfg<3136, 512, 128, true>;
+using GemmHeads = GemmCfg<512, 32, 128, false>;
+
+template <class G>
+__global__ __launch_bounds__(kThreads) void gemm_mfma(const float* __restrict__ A, const float* __restrict__ Bfrag,
+                                                      const float* __restrict__ bias, float* __restrict__ out,
+                                                      int N) {
+  __shared__ __attribute__((aligned(16))) float sA[2][G::BM * G::LDA];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, kk = lane >> 4;
+  const int ctw = wave % G::CTB, rg = wave / G::CTB;
+  const int ct = blockIdx.x * G::CTB + ctw;
+  const int row0 = blockIdx.y * G::BM;
+
+  float4 stage[G::VPT];
+  auto load_chunk = [&](int ch) {
+#pragma unroll
+    for (int v = 0; v < G::VPT; ++v) {
+      const int idx = tid + v * kThreads;
+      const int r = idx >> 3, q = idx & 7;  // KC/4 == 8 float4 per row
+      const int row = row0 + r;
+      stage[v] = (row < N) ? *reinterpret_cast<const float4*>(A + (size_t)row * G::K + ch * G::KC + q * 4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < G::VPT; ++v) {
+      const int idx = tid + v * kThreads;
+      const int r = idx >> 3, q = idx & 7;
+      float* d = &sA[buf][r * G::LDA + q * 4];
+      *reinterpret_cast<float2*>(d) = make_float2(stage[v].x, stage[v].y);
+      *reinterpret_cast<float2*>(d + 2) = make_float2(stage[v].z, stage[v].w);
+    }
+  };
+
+  f32x4 acc[G::RPW];
+#pragma unroll
+  for (int t = 0; t < G::RPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* bptr = Bfrag + (size_t)ct * G::KS * 64 + lane;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  for (int ch = 0; ch < G::NCH; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < G::NCH) load_chunk(ch + 1);
+    float bfr[G::KC / 4];
+#pragma unroll
+    for (int j = 0; j < G::KC / 4; ++j) bfr[j] = bptr[(size_t)(ch * (G::KC / 4) + j) * 64];
+#pragma unroll
+    for (int j = 0; j < G::KC / 4; ++j) {
+#pragma unroll
+      for (int t = 0; t < G::RPW; ++t) {
+        const int r = (rg * G::RPW + t) * 16 + li;
+        const float a = sA[buf][r * G::LDA + j * 4 + kk];
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfr[j], acc[t], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < G::NCH) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  const int col = ct * 16 + li;
+  const float bv = bias[col];
+#pragma unroll
+  for (int t = 0; t < G::RPW; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + (rg * G::RPW + t) * 16 + kk * 4 + r;
+      if (row < N) {
+        float v = acc[t][r] + bv;
+        if (G::RELU) v = v > 0.f ? v : 0.f;
+        out[(size_t)row * G::OC + col] = v;
+      }
+    }
+  }
+}
+
+// duel(): q = v + a*legal - mean_A(a*legal)   net.py:33-39 (mean over A, not over #legal)
+__global__ void dueling_kernel(const float* __restrict__ ha, const float* __restrict__ legal, float* __restrict__ q,
+                               int N, int A) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float* row = ha + (size_t)n * 32;
+  const float v = row[31];
+  float la[31];
+  float sum = 0.f;
+  for (int j = 0; j < A; ++j) {
+    la[j] = row[j] * legal[(size_t)n * A + j];
+    sum += la[j];
+  }
+  const float mean = sum / (float)A;
+  for (int j = 0; j < A; ++j) q[(size_t)n * A + j] = (v + la[j]) - mean;
+}
+
+// ---- weight packing (load_state_dict time) ------------------------------------------------
+enum PackMode { kPackConv1 = 0, kPackConv2 = 1, kPackConv3 = 2, kPackFc = 3, kPackHeads = 4 };
+
+__global__ void pack_frags(int mode, const float* __restrict__ w, const float* __restrict__ w2, int num_action,
+                           float* __restrict__ frag, int CT, int KS) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)CT * KS * 64;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  const int ks = (int)((idx >> 6) % KS);
+  const int ct = (int)((idx >> 6) / KS);
+  const int k = ks * 4 + (lane >> 4);
+  const int oc = ct * 16 + (lane & 15);
+  float v = 0.f;
+  switch (mode) {
+    case kPackConv1:  // k = (c, kh, kw) = state_dict order; fold s/255 (net.py:46)
+      v = w[oc * 256 + k] / 255.0f;
+      break;
+    case kPackConv2: {  // k = (kh, kw, c)
+      const int c = k & 31, kw = (k >> 5) & 3, kh = k >> 7;
+      v = w[((oc * 32 + c) * 4 + kh) * 4 + kw];
+      break;
+    }
+    case kPackConv3: {  // k = (kh, kw, c)
+      const int c = k & 63, r = k >> 6, kw = r % 3, kh = r / 3;
+      v = w[((oc * 64 + c) * 3 + kh) * 3 + kw];
+      break;
+    }
+    case kPackFc: {  // k = pos*64 + c  <-  torch flatten c*49 + pos (net.py:49)
+      const int c = k & 63, p = k >> 6;
+      v = w[(size_t)oc * 3136 + c * 49 + p];
+      break;
+    }
+    case kPackHeads:
+      if (oc < num_action)
+        v = w[oc * 512 + k];  // fc_a
+      else if (oc == 31)
+        v = w2[k];  // fc_v
+      break;
+  }
+  frag[idx] = v;
+}
+
+__global__ void pack_head_bias(const float* __restrict__ ab, const float* __restrict__ vb, int A, float* __restrict__ out) {
+  const int j = threadIdx.x;
+  if (j < 32) out[j] = j < A ? ab[j] : (j == 31 ? vb[0] : 0.f);
+}
+
+}  // namespace
+}  // namespace rela_amd
+
+using namespace rela_amd;
+
+struct rela_ffnet {
+  int device = 0;
+  int num_action = 0;
+  FFNetDev d;
+  bool loaded = false;
+};
+
+namespace {
+constexpr int64_t kA1 = 400 * 32, kA2 = 81 * 64, kA3 = 49 * 64, kH = 512, kHA = 32;
+constexpr int64_t kWsFloatsPerSample = kA1 + kA2 + kA3 + kH + kHA;
+}  // namespace
+
+extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
+  RELA_CHECK(out && num_action >= 1 && num_action <= 31, RELA_EINVAL,
+             "rela_ffnet_create: num_action must be in 1..31 (got %d)", num_action);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    set_last_error("rela_ffnet_create: HIP device %d not available (%d visible); there is no CPU path", device, ndev);
+    return RELA_ENODEV;
+  }
+  DeviceGuard g(device);
+  auto* n = new rela_ffnet();
+  n->device = device;
+  n->num_action = num_action;
+  FFNetDev& d = n->d;
+  RELA_HIP(hipMalloc(&d.B1, sizeof(float) * 2 * 64 * 64));
+  RELA_HIP(hipMalloc(&d.b1, sizeof(float) * 32));
+  RELA_HIP(hipMalloc(&d.B2, sizeof(float) * 4 * 128 * 64));
+  RELA_HIP(hipMalloc(&d.b2, sizeof(float) * 64));
+  RELA_HIP(hipMalloc(&d.B3, sizeof(float) * 4 * 144 * 64));
+  RELA_HIP(hipMalloc(&d.b3, sizeof(float) * 64));
+  RELA_HIP(hipMalloc(&d.Bf, sizeof(float) * 32 * 784 * 64));
+  RELA_HIP(hipMalloc(&d.bf, sizeof(float) * 512));
+  RELA_HIP(hipMalloc(&d.Bh, sizeof(float) * 2 * 128 * 64));
+  RELA_HIP(hipMalloc(&d.bh, sizeof(float) * 32));
+  // opt in to > 64 KB of dynamic LDS once per process/device
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv1::LDS_BYTES));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv2::LDS_BYTES));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv3::LDS_BYTES));
+  *out = n;
+  return RELA_OK;
+}
+
+extern "C" void rela_ffnet_destroy(rela_ffnet* n) {
+  if (!n) return;
+  DeviceGuard g(n->device);
+  (void)hipDeviceSynchronize();
+  float* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bf, n->d.bf, n->d.Bh, n->d.bh};
+  for (float* p : ps) (void)hipFree(p);
+  delete n;
+}
+
+extern "C" int rela_ffnet_num_action(const rela_ffnet* n) { return n ? n->num_action : 0; }
+
+extern "C" int64_t rela_ffnet_workspace_bytes(const rela_ffnet* n, int batch) {
+  (void)n;
+  return (int64_t)sizeof(float) * kWsFloatsPerSample * (batch > 0 ? batch : 0) + 256;
+}
+
+extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on_device, void* stream_) {
+  RELA_CHECK(n && p, RELA_EINVAL, "rela_ffnet_load: bad arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  DeviceGuard g(n->device);
+  const int A = n->num_action;
+  const size_t cnt[12] = {32 * 256, 32, 64 * 512, 64, 64 * 576, 64, (size_t)512 * 3136, 512, 512, 1, (size_t)A * 512,
+                          (size_t)A};
+  const float* src[12] = {p->conv1_w, p->conv1_b, p->conv2_w, p->conv2_b, p->conv3_w, p->conv3_b,
+                          p->fc_w,    p->fc_b,    p->v_w,     p->v_b,     p->a_w,     p->a_b};
+  const float* dv[12];
+  float* tmp = nullptr;
+  if (on_device) {
+    for (int i = 0; i < 12; ++i) {
+      RELA_CHECK(src[i], RELA_EINVAL, "rela_ffnet_load: parameter %d is NULL", i);
+      dv[i] = src[i];
+    }
+  } else {
+    size_t total = 0;
+    for (int i = 0; i < 12; ++i) total += cnt[i];
+    RELA_HIP(hipMalloc(&tmp, sizeof(float) * total));
+    size_t off = 0;
+    for (int i = 0; i < 12; ++i) {
+      RELA_CHECK(src[i], RELA_EINVAL, "rela_ffnet_load: parameter %d is NULL", i);
+      RELA_HIP(hipMemcpyAsync(tmp + off, src[i], sizeof(float) * cnt[i], hipMemcpyHostToDevice, s));
+      dv[i] = tmp + off;
+      off += cnt[i];
+    }
+  }
+  auto pack = [&](int mode, const float* w, const float* w2, float* frag, int CT, int KS) {
+    const int64_t total = (int64_t)CT * KS * 64;
+    hipLaunchKernelGGL(pack_frags, dim3(ceil_div(total, 256)), dim3(256), 0, s, mode, w, w2, A, frag, CT, KS);
+  };
+  pack(kPackConv1, dv[0], nullptr, n->d.B1, 2, 64);
+  pack(kPackConv2, dv[2], nullptr, n->d.B2, 4, 128);
+  pack(kPackConv3, dv[4], nullptr, n->d.B3, 4, 144);
+  pack(kPackFc, dv[6], nullptr, n->d.Bf, 32, 784);
+  pack(kPackHeads, dv[10], dv[8], n->d.Bh, 2, 128);
+  RELA_HIP(hipMemcpyAsync(n->d.b1, dv[1], sizeof(float) * 32, hipMemcpyDeviceToDevice, s));
+  RELA_HIP(hipMemcpyAsync(n->d.b2, dv[3], sizeof(float) * 64, hipMemcpyDeviceToDevice, s));
+  RELA_HIP(hipMemcpyAsync(n->d.b3, dv[5], sizeof(float) * 64, hipMemcpyDeviceToDevice, s));
+  RELA_HIP(hipMemcpyAsync(n->d.bf, dv[7], sizeof(float) * 512, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(pack_head_bias, dim3(1), dim3(64), 0, s, dv[11], dv[9], A, n->d.bh);
+  RELA_LAUNCH_CHECK();
+  if (tmp) {
+    RELA_HIP(hipStreamSynchronize(s));
+    (void)hipFree(tmp);
+  }
+  n->loaded = true;
+  return RELA_OK;
+}
+
+extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_dev, const float* legal_dev,
+                                  float* q_dev, void* ws, int64_t ws_bytes, void* stream_) {
+  RELA_CHECK(n && n->loaded, RELA_ESTATE, "rela_ffnet_forward: parameters were never loaded");
+  RELA_CHECK(N >= 1 && s_dev && legal_dev && q_dev && ws, RELA_EINVAL, "rela_ffnet_forward: bad arguments");
+  RELA_CHECK(ws_bytes >= rela_ffnet_workspace_bytes(n, N), RELA_EINVAL,
+             "rela_ffnet_forward: workspace of %lld bytes is too small for batch %d", (long long)ws_bytes, N);
+  RELA_CHECK(((uintptr_t)s_dev & 15) == 0 && ((uintptr_t)ws & 15) == 0, RELA_EINVAL,
+             "rela_ffnet_forward: s_dev and workspace must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream_;
+  float* a1 = static_cast<float*>(ws);
+  float* a2 = a1 + kA1 * N;
+  float* a3 = a2 + kA2 * N;
+  float* h = a3 + kA3 * N;
+  float* ha = h + kH * N;
+  const FFNetDev& d = n->d;
+  hipLaunchKernelGGL(conv_mfma<Conv1>, dim3(ceil_div(N, Conv1::S)), dim3(kThreads), Conv1::LDS_BYTES, s,
+                     (const void*)s_dev, d.B1, d.b1, a1, N);
+  hipLaunchKernelGGL(conv_mfma<Conv2>, dim3(ceil_div(N, Conv2::S)), dim3(kThreads), Conv2::LDS_BYTES, s,
+                     (const void*)a1, d.B2, d.b2, a2, N);
+  hipLaunchKernelGGL(conv_mfma<Conv3>, dim3(ceil_div(N, Conv3::S)), dim3(kThreads), Conv3::LDS_BYTES, s,
+                     (const void*)a2, d.B3, d.b3, a3, N);
+  hipLaunchKernelGGL(gemm_mfma<GemmFc>, dim3(GemmFc::CT / GemmFc::CTB, ceil_div(N, GemmFc::BM)), dim3(kThreads), 0, s,
+                     a3, d.Bf, d.bf, h, N);
+  hipLaunchKernelGGL(gemm_mfma<GemmHeads>, dim3(GemmHeads::CT / GemmHeads::CTB, ceil_div(N, GemmHeads::BM)),
+                     dim3(kThreads), 0, s, h, d.Bh, d.bh, ha, N);
+  hipLaunchKernelGGL(dueling_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, ha, legal_dev, q_dev, N, n->num_action);
+  RELA_LAUNCH_CHECK();
+  return RELA_OK;
+}

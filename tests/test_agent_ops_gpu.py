@@ -79,8 +79,12 @@ def test_act_and_td_from_q(n, A, masked):
     lib.oracle_greedy.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int64)]
     lib.oracle_greedy(n, A, fp(q), fp(legal), exp_act.ctypes.data_as(C.POINTER(C.c_int64)))
     d_act = torch.empty(n, dtype=torch.int64, device="cuda")
-    capi.check(capi.lib.rela_apex_act_from_q(n, A, ptr(dev(q)), ptr(dev(legal)), ptr(dev(np.zeros(n, np.float32))), 1, 0,
-                                             ptr(d_act), cur_stream()), "act")
+    # keep every device tensor alive in a local: a temporary would be freed (and its block
+    # reused by the next allocation) before the kernel runs
+    d_q, d_qn, d_qt, d_legal, d_eps = dev(q), dev(qn), dev(qt), dev(legal), dev(np.zeros(n, np.float32))
+    d_action, d_reward, d_boot = dev(action), dev(reward), dev(boot)
+    capi.check(capi.lib.rela_apex_act_from_q(n, A, ptr(d_q), ptr(d_legal), ptr(d_eps), 1, 0, ptr(d_act), cur_stream()),
+               "act")
     np.testing.assert_array_equal(d_act.cpu().numpy(), exp_act)
     # oracle td from the three tables
     na = np.zeros(n, np.int64)
@@ -91,9 +95,9 @@ def test_act_and_td_from_q(n, A, masked):
     err = (tgt - qa).astype(np.float32)
     d_td = torch.empty(n, device="cuda")
     d_pr = torch.empty(n, device="cuda")
-    capi.check(capi.lib.rela_apex_td_from_q(n, A, ptr(dev(q)), ptr(dev(qn)), ptr(dev(qt)), ptr(dev(legal)),
-                                            ptr(dev(action)), ptr(dev(reward)), ptr(dev(boot)), C.c_float(gamma_n),
-                                            ptr(d_td), ptr(d_pr), cur_stream()), "td")
+    capi.check(capi.lib.rela_apex_td_from_q(n, A, ptr(d_q), ptr(d_qn), ptr(d_qt), ptr(d_legal), ptr(d_action),
+                                            ptr(d_reward), ptr(d_boot), C.c_float(gamma_n), ptr(d_td), ptr(d_pr),
+                                            cur_stream()), "td")
     np.testing.assert_array_equal(d_td.cpu().numpy(), err)
     np.testing.assert_array_equal(d_pr.cpu().numpy(), np.abs(err))
 
@@ -113,9 +117,10 @@ def test_eps_greedy_statistics():
     legal[:, ::3] = 0
     eps = np.full(n, 0.5, np.float32)
     acts = []
+    d_q, d_legal, d_eps = dev(q), dev(legal), dev(eps)
     for off in (0, n):
         d_act = torch.empty(n, dtype=torch.int64, device="cuda")
-        capi.check(capi.lib.rela_apex_act_from_q(n, A, ptr(dev(q)), ptr(dev(legal)), ptr(dev(eps)), 99, off, ptr(d_act),
+        capi.check(capi.lib.rela_apex_act_from_q(n, A, ptr(d_q), ptr(d_legal), ptr(d_eps), 99, off, ptr(d_act),
                                                  cur_stream()), "act")
         acts.append(d_act.cpu().numpy())
     greedy = np.argmax((1 + q - q.min()) * legal, 1)
