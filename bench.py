@@ -1,0 +1,324 @@
+#!/usr/bin/env python3
+"""bench.py -- Ape-X hot path throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): Ape-X DQN, 80 actor threads x 80 games = 6,400 envs,
+one MI355X running actors + learner, replay 2^20 (ring 1,310,720 slots, device resident),
+synthetic 84x84x4 uint8 frames already in HBM, A = 18 actions, n = 3, gamma = 0.997,
+alpha = 0.6, beta = 0.4, learner batch 512 (pyrela/main.py:28-65 defaults).
+
+One STEP = what the reference does per env-step of every actor thread plus one learner update:
+  actor tick over 6,400 envs  (rela/thread_loop.h:74-105 -> rela/dqn_actor.h:153-203)
+      act: 1 trunk forward + eps-greedy; post_step: n-step return, TD priority (3 trunk
+      forwards: online(s_t), online(s_t+n), target(s_t+n)), replay insert of 6,400 transitions
+  learner step                (pyrela/main.py:206-251)
+      replay.sample(512) [exact sequential-sum scan + gather] -> ApexAgent.loss -> backward
+      -> clip 40 -> RMSprop -> update_priority; actor weights re-published every 20 steps,
+      target net every 2,500.
+Nothing is cached or skipped: all four forwards run every tick (no reuse of act-time Q-values).
+
+Prints ONE JSON line (rank 0).  `value` = env-steps/s summed over ranks.  Extra keys carry the
+learner rate, the live roofline of the dominant kernel and the CPU baseline (oracle port).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+T_THREADS, K_GAMES = 80, 80
+ROWS = T_THREADS * K_GAMES
+NUM_ACTION = 18
+MULTI_STEP, GAMMA = 3, 0.997
+ALPHA, BETA = 0.6, 0.4
+BATCH = 512
+REPLAY_CAP = 1 << 20
+SEED = 10002
+
+# algorithmic FLOPs per sample-forward: 2 * MACs
+FLOP = {"conv1_mfma": 2 * 400 * 32 * 256, "conv2_mfma": 2 * 81 * 64 * 512, "conv3_mfma": 2 * 49 * 64 * 576,
+        "fc_mfma": 2 * 3136 * 512, "heads_mfma": 2 * 512 * 19}
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def generate_eps(base_eps, alpha, num_actor):
+    """eps_i = base ** (1 + i/(N-1) * alpha)   (pyrela/utils.py:88-96)."""
+    if num_actor == 1:
+        return [base_eps]
+    return [base_eps ** (1 + i / (num_actor - 1) * alpha) for i in range(num_actor)]
+
+
+def cpu_baseline(budget_s=15.0):
+    """The oracle (plain-C port of the same path) timed on this box's host cores: one actor tick
+    (act + n-step + TD priority + replay insert) over a bounded number of envs."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth import synth_obs, synth_params
+
+    odir = os.path.join(ROOT, "oracle")
+    so = os.path.join(odir, "liboracle_native.so")
+    srcs = [os.path.join(odir, f) for f in ("replay_oracle.c", "mt19937.c", "nstep_oracle.c", "dqn_oracle.c")]
+    subprocess.run(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-ffp-contract=off", "-shared", "-o", so] + srcs
+                   + ["-lm", "-lpthread"], check=True)
+    lib = C.CDLL(so)
+    cores = min(len(os.sched_getaffinity(0)), 16)  # the GPU box's CPU share for one GPU
+    lib.oracle_set_threads.argtypes = [C.c_int]
+    lib.oracle_set_threads(cores)
+    A = NUM_ACTION
+
+    class Net(C.Structure):
+        _fields_ = [("num_action", C.c_int)] + [(n, C.POINTER(C.c_float)) for n in
+                                                ("c1w", "c1b", "c2w", "c2b", "c3w", "c3b", "l1w", "l1b", "vw", "vb",
+                                                 "aw", "ab")]
+
+    keys = ["net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
+            "linear.0.weight", "linear.0.bias", "fc_v.weight", "fc_v.bias", "fc_a.weight", "fc_a.bias"]
+
+    def mk(seed):
+        p = synth_params(A, seed)
+        net = Net()
+        net.num_action = A
+        keep = []
+        for (f, _), k in zip(Net._fields_[1:], keys):
+            a = np.ascontiguousarray(p[k], np.float32)
+            keep.append(a)
+            setattr(net, f, a.ctypes.data_as(C.POINTER(C.c_float)))
+        net._keep = keep
+        return net
+
+    on, tg = mk(1), mk(2)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    up = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    lib.oracle_replay_new.restype = C.c_void_p
+    lib.oracle_replay_new.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float]
+    lib.oracle_replay_add.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_float)]
+    lib.oracle_apex_priority.argtypes = [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 7 + [C.c_float, C.c_void_p,
+                                                                                             C.c_void_p]
+    rep = lib.oracle_replay_new(1 << 16, SEED, ALPHA, BETA)
+
+    def tick(n_env):
+        s, ns = synth_obs(n_env, 1), synth_obs(n_env, 2)
+        legal = np.ones((n_env, A), np.float32)
+        q = np.zeros((n_env, A), np.float32)
+        act = np.zeros(n_env, np.int64)
+        rh = np.zeros((MULTI_STEP + 1, n_env), np.float32)
+        th = np.zeros((MULTI_STEP + 1, n_env), np.uint8)
+        r, b, prio = np.zeros(n_env, np.float32), np.zeros(n_env, np.float32), np.zeros(n_env, np.float32)
+        t = np.zeros(n_env, np.uint8)
+        t0 = time.perf_counter()
+        for g0 in range(0, n_env, K_GAMES):  # one reference actor thread = K envs per call
+            g1 = min(n_env, g0 + K_GAMES)
+            m = g1 - g0
+            lib.oracle_ffnet_forward(C.byref(on), m, up(s[g0:g1]), fp(legal[g0:g1]), fp(q[g0:g1]))
+            lib.oracle_greedy(m, A, fp(q[g0:g1]), fp(legal[g0:g1]), ip(act[g0:g1]))
+            lib.oracle_nstep_pop(MULTI_STEP, m, C.c_float(GAMMA), fp(np.ascontiguousarray(rh[:, g0:g1])),
+                                 up(np.ascontiguousarray(th[:, g0:g1])), fp(r[g0:g1]), fp(b[g0:g1]), up(t[g0:g1]))
+            lib.oracle_apex_priority(C.byref(on), C.byref(tg), m, up(s[g0:g1]), fp(legal[g0:g1]), ip(act[g0:g1]),
+                                     fp(r[g0:g1]), fp(b[g0:g1]), up(ns[g0:g1]), fp(legal[g0:g1]),
+                                     C.c_float(GAMMA ** MULTI_STEP), None, fp(prio[g0:g1]))
+            lib.oracle_replay_add(rep, m, ip(np.arange(g0, g1, dtype=np.int64)), fp(prio[g0:g1]))
+        return time.perf_counter() - t0
+
+    probe_n = max(cores, 8)
+    t_probe = tick(probe_n)
+    per_env = t_probe / probe_n
+    n_env = int(min(ROWS, max(K_GAMES, (budget_s / max(per_env, 1e-6)) // K_GAMES * K_GAMES)))
+    dt = tick(n_env)
+    return {"value": n_env / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "one actor tick (act + n-step + TD priority with 3 forwards + replay insert) over %d envs in "
+                      "groups of K=%d, oracle/ plain-C port, gcc -O3 -march=native, %d pthreads, %.1f s"
+                      % (n_env, K_GAMES, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replay-cap", type=int, default=REPLAY_CAP)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from rela_amd import build as _build
+
+    if rank == 0 or world == 1:
+        _build.build_native()
+    if world > 1:
+        dist.barrier()
+    from rela_amd import _capi as capi
+    from rela_amd.engine import ApexActorEngine, FFNetHandle
+    from rela_amd.learner import allreduce_grads
+    from rela_amd.pyrela.apex import ApexAgent
+    from rela_amd.pyrela.net import AtariFFNet
+    from rela_amd.replay import FFReplay
+
+    torch.manual_seed(SEED + 2 + rank)
+    agent = ApexAgent(lambda: AtariFFNet(NUM_ACTION), MULTI_STEP, GAMMA).to(device)
+    if world > 1:  # identical replicas
+        for p in agent.parameters():
+            dist.broadcast(p.data, 0)
+    optim = torch.optim.RMSprop(agent.online_net.parameters(), lr=6.25e-5, eps=1.5e-4)
+    online, target = FFNetHandle(NUM_ACTION, device), FFNetHandle(NUM_ACTION, device)
+    online.load_state_dict(agent.online_net.state_dict())
+    target.load_state_dict(agent.target_net.state_dict())
+
+    replay = FFReplay(args.replay_cap, SEED + rank, ALPHA, BETA, 0, NUM_ACTION, device)
+    eps_all = generate_eps(0.4, 7, ROWS * world)
+    eps = eps_all[rank * ROWS:(rank + 1) * ROWS]
+    engine = ApexActorEngine(ROWS, K_GAMES, NUM_ACTION, MULTI_STEP, GAMMA, replay, eps, device, seed=SEED + rank)
+
+    # synthetic inputs resident in HBM: the observation history ring doubles as the frame pool
+    g = torch.Generator(device=device)
+    g.manual_seed(SEED + 7 + rank)
+    for h in range(MULTI_STEP + 1):
+        engine.obs_hist[h].copy_(torch.randint(0, 256, engine.obs_hist[h].shape, dtype=torch.uint8, device=device,
+                                               generator=g))
+    n_pool = 16
+    reward_pool = torch.randint(-1, 2, (n_pool, ROWS), device=device, generator=g).float()
+    term_pool = (torch.rand((n_pool, ROWS), device=device, generator=g) < 0.005).to(torch.uint8)
+
+    step_idx = [0]
+
+    def actor_tick():
+        i = step_idx[0] % n_pool
+        engine.act(online)
+        engine.post_step(reward_pool[i], term_pool[i], online, target, nonblocking=True)
+
+    def learner_step():
+        k = step_idx[0]
+        if k % 2500 == 0:
+            agent.sync_target_with_online()
+        if k % 20 == 0:  # ModelLocker.update_model, main.py:213-215
+            online.load_state_dict(agent.online_net.state_dict())
+            target.load_state_dict(agent.target_net.state_dict())
+        batch, weight = replay.sample(BATCH)
+        loss, prio = agent.loss(batch, sync_priority=False)
+        (loss * weight).mean().backward()
+        if world > 1:
+            allreduce_grads(agent.online_net.parameters(), world)
+        torch.nn.utils.clip_grad_norm_(agent.online_net.parameters(), 40.0)
+        optim.step()
+        optim.zero_grad(set_to_none=True)
+        replay.update_priority(prio)
+
+    # fill the ring to capacity (untimed): real ticks for the history, then bulk inserts
+    for _ in range(MULTI_STEP + 1):
+        actor_tick()
+        step_idx[0] += 1
+    prio = torch.empty(ROWS, device=device)
+    while replay.size() + ROWS <= args.replay_cap:
+        prio.uniform_(0.01, 2.0, generator=g)
+        obs_a, obs_b = engine.obs_hist[0], engine.obs_hist[1]
+        ptrs = [obs_a.data_ptr(), obs_b.data_ptr(), engine.eps.data_ptr(), engine.eps.data_ptr(),
+                engine.legal.data_ptr(), engine.legal.data_ptr(), engine.act_hist[0].data_ptr(),
+                engine.out_r.data_ptr(), engine.out_t.data_ptr(), engine.out_b.data_ptr()]
+        replay.add_rows(ROWS, ptrs, prio)
+    torch.cuda.synchronize()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        actor_tick()
+        learner_step()
+        step_idx[0] += 1
+    sync_all()
+    capi.lib.rela_prof_enable(1)
+    add0 = replay.num_add()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        actor_tick()
+        learner_step()
+        step_idx[0] += 1
+    sync_all()
+    dt = time.perf_counter() - t0
+    capi.lib.rela_prof_enable(0)
+    adds = replay.num_add() - add0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        a = torch.tensor([adds], device=device, dtype=torch.float64)
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        adds = float(a.item())
+
+    buf = C.create_string_buffer(1 << 16)
+    capi.check(capi.lib.rela_prof_summary_json(buf, len(buf)), "rela_prof_summary_json")
+    prof = json.loads(buf.value.decode())
+    st = replay.debug_state()
+    assert st["dev_error"] == 0, "replay reported device error %d" % st["dev_error"]
+
+    if rank == 0:
+        env_steps = ROWS * world * args.steps
+        # dominant kernel = largest total time among the timed hot-path kernels
+        name, rec = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+        avg_ms = rec["total_ms"] / rec["count"]
+        if name in FLOP:
+            flops = FLOP[name] * ROWS
+            roof = {"kernel": name, "bound": "mfma", "achieved": flops / (avg_ms * 1e-3) / 1e12,
+                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": None,
+                    "avg_launch_ms": avg_ms, "launches": rec["count"],
+                    "algorithmic_flop_per_launch": flops}
+        else:
+            roof = {"kernel": name, "bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "traffic": None, "avg_launch_ms": avg_ms, "launches": rec["count"]}
+        if roof["achieved"] is not None:
+            roof["frac"] = roof["achieved"] / roof["peak"]
+        fwd_ms = sum(prof[k]["total_ms"] for k in FLOP if k in prof)
+        fwd_cnt = prof.get("conv1_mfma", {"count": 1})["count"]
+        scan_ms = sum(v["total_ms"] for k, v in prof.items() if k.startswith("seq_") or k in (
+            "replay_targets", "replay_search", "replay_pop", "replay_is_weights"))
+        out = {
+            "metric": "env-steps/s (Ape-X Atari 84x84x4, actor tick + learner grad-step)",
+            "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Ape-X DQN, 80 threads x 80 games (6400 envs) per GPU, actor+learner on one "
+                                   "MI355X, replay 2^20 device-resident, A=18, n=3, learner batch 512 per GPU",
+                       "envs_per_gpu": ROWS, "replay_capacity": args.replay_cap, "learner_batch": BATCH,
+                       "parallelism": "replicas%d+grad-allreduce" % world if world > 1 else "single"},
+            "grad_steps_per_s": args.steps / dt, "train_samples_per_s": args.steps * BATCH * world / dt,
+            "buffer_add_per_s": adds / dt,
+            "forward_ms_per_6400": fwd_ms / max(fwd_cnt, 1),
+            "forward_tflops": sum(FLOP.values()) * ROWS / (fwd_ms / max(fwd_cnt, 1) * 1e-3) / 1e12,
+            "replay_sample_scan_ms": scan_ms / args.steps,
+            "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(prof.items())},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

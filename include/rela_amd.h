@@ -107,11 +107,13 @@ int rela_seqscan_search(const float* ring_dev, int64_t ring, int64_t head, int64
 
 /* ===================================================================================
  * n-step return  --  MultiStepTransitionBuffer::popTransition, rela/dqn_actor.h:58-106.
- * reward_hist / terminal_hist are [multi_step+1][K] device arrays (row 0 oldest).
+ * reward_hist / terminal_hist are [multi_step+1][K] device arrays holding the deque of
+ * dqn_actor.h:120-123 as a ring: step j (0 = oldest) lives in row (first_row + j) % (n+1).
  * =================================================================================== */
-int rela_nstep_return(int multi_step, int K, float gamma, const float* reward_hist_dev,
-                      const uint8_t* terminal_hist_dev, float* out_reward_dev,
-                      float* out_bootstrap_dev, uint8_t* out_terminal_dev, void* stream);
+int rela_nstep_return(int multi_step, int K, float gamma, int first_row,
+                      const float* reward_hist_dev, const uint8_t* terminal_hist_dev,
+                      float* out_reward_dev, float* out_bootstrap_dev, uint8_t* out_terminal_dev,
+                      void* stream);
 
 /* ===================================================================================
  * Ape-X network and agent ops  --  pyrela/net.py:8-55 (AtariFFNet), pyrela/apex.py:30-78.
@@ -145,19 +147,32 @@ int rela_ffnet_forward(const rela_ffnet* net, int n, const uint8_t* s_dev, const
 /* ApexAgent.act  apex.py:57-65 on top of greedy_act :48-54: eps-greedy over q[n,A].
  * eps_dev f32[n]; rng_seed/rng_offset select the Philox stream for the random branch
  * (the reference uses the torch global generator: only the eps==0 branch is reproducible,
- * SURVEY H4).  action_dev is int64[n].                                                     */
-int rela_apex_act_from_q(int n, int num_action, const float* q_dev, const float* legal_dev,
-                         const float* eps_dev, uint64_t rng_seed, uint64_t rng_offset,
-                         int64_t* action_dev, void* stream);
+ * SURVEY H4).  action_dev is int64[n].
+ * group_rows: greedy_act's q.min() (apex.py:51) spans one TorchScript call, i.e. the K rows of
+ * one actor thread.  A launch that batches several actors passes K here and the minimum is
+ * taken per group of K consecutive rows; 0 means the whole batch is one group.             */
+int rela_apex_act_from_q(int n, int num_action, int group_rows, const float* q_dev,
+                         const float* legal_dev, const float* eps_dev, uint64_t rng_seed,
+                         uint64_t rng_offset, int64_t* action_dev, void* stream);
 
 /* ApexAgent.td_err / compute_priority  apex.py:30-45,68-78 from the three Q tables:
  * q = online(s), q_next_online = online(s'), q_next_target = target(s').
  * td_err_dev (signed, may be NULL) and priority_dev (= |td_err|, may be NULL) are f32[n]. */
-int rela_apex_td_from_q(int n, int num_action, const float* q_dev, const float* q_next_online_dev,
+int rela_apex_td_from_q(int n, int num_action, int group_rows, const float* q_dev,
+                        const float* q_next_online_dev,
                         const float* q_next_target_dev, const float* next_legal_dev,
                         const int64_t* action_dev, const float* reward_dev,
                         const float* bootstrap_dev, float gamma_n, float* td_err_dev,
                         float* priority_dev, void* stream);
+
+/* ===================================================================================
+ * Live per-kernel timing (HIP events on the launch stream) for bench.py's roofline line.
+ * No reference counterpart: the reference times sections with torch.cuda.synchronize()
+ * (pyrela/common_utils/stopwatch.py:17-54).
+ * =================================================================================== */
+int rela_prof_enable(int on);
+/* synchronises the device; writes {"kernel":{"count":n,"total_ms":t},...} and clears */
+int rela_prof_summary_json(char* out, int64_t cap);
 
 #ifdef __cplusplus
 }

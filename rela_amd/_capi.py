@@ -6,6 +6,10 @@ There is no fallback: if the shared library is missing the import fails loudly. 
 import ctypes as C
 import os
 
+# PyTorch-ROCm bundles its own libamdhip64.so.7; librela_amd.so links the same SONAME.  Load
+# torch FIRST so the process has exactly one HIP runtime (two copies = "0 devices visible").
+import torch  # noqa: F401,E402
+
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "librela_amd.so")
 
@@ -60,15 +64,17 @@ _sig("rela_replay_num_add", i64, [vp])
 _sig("rela_replay_debug_state", i32, [vp, P(ReplayState), vp, vp, vp])
 _sig("rela_replay_debug_weights", i32, [vp, vp, vp])
 _sig("rela_seqscan_search", i32, [vp, i64, i64, i64, vp, i32, vp, vp, vp, P(f64), vp])
-_sig("rela_nstep_return", i32, [i32, i32, f32, vp, vp, vp, vp, vp, vp])
+_sig("rela_nstep_return", i32, [i32, i32, f32, i32, vp, vp, vp, vp, vp, vp])
 _sig("rela_ffnet_create", i32, [P(vp), i32, i32])
 _sig("rela_ffnet_destroy", None, [vp])
 _sig("rela_ffnet_load", i32, [vp, P(FFNetParams), i32, vp])
 _sig("rela_ffnet_num_action", i32, [vp])
 _sig("rela_ffnet_workspace_bytes", i64, [vp, i32])
 _sig("rela_ffnet_forward", i32, [vp, i32, vp, vp, vp, vp, i64, vp])
-_sig("rela_apex_act_from_q", i32, [i32, i32, vp, vp, vp, u64, u64, vp, vp])
-_sig("rela_apex_td_from_q", i32, [i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp])
+_sig("rela_apex_act_from_q", i32, [i32, i32, i32, vp, vp, vp, u64, u64, vp, vp])
+_sig("rela_apex_td_from_q", i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp])
+_sig("rela_prof_enable", i32, [i32])
+_sig("rela_prof_summary_json", i32, [C.c_char_p, i64])
 
 
 class RelaError(RuntimeError):

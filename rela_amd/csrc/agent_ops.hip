@@ -8,6 +8,7 @@
 // batch-global q.min() of greedy_act (apex.py:51) needs no second launch.
 // HBM-bound in principle, launch-latency-bound in practice.
 #include "common.h"
+#include "prof.h"
 
 namespace rela_amd {
 namespace {
@@ -15,7 +16,7 @@ namespace {
 constexpr int kT = 1024;
 
 // ---- n-step --------------------------------------------------------------------------
-__global__ void nstep_kernel(int n, int K, float gamma, const float* __restrict__ rh,
+__global__ void nstep_kernel(int n, int K, float gamma, int first, const float* __restrict__ rh,
                              const uint8_t* __restrict__ th, float* __restrict__ out_r,
                              float* __restrict__ out_b, uint8_t* __restrict__ out_t) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -23,7 +24,7 @@ __global__ void nstep_kernel(int n, int K, float gamma, const float* __restrict_
   float bootstrap = 1.0f;
   int next_idx = n;
   for (int step = 0; step < n; ++step) {
-    if (th[step * K + i]) {  // dqn_actor.h:75-80
+    if (th[((first + step) % (n + 1)) * K + i]) {  // dqn_actor.h:75-80
       bootstrap = 0.0f;
       next_idx = step;
       break;
@@ -33,11 +34,11 @@ __global__ void nstep_kernel(int n, int K, float gamma, const float* __restrict_
   float acc = 0.0f;
   for (int step = initial; step >= 0; --step) {
     const float prod = __fmul_rn(gamma, acc);  // un-fused, SURVEY H8
-    acc = __fadd_rn(rh[step * K + i], prod);   // :96
+    acc = __fadd_rn(rh[((first + step) % (n + 1)) * K + i], prod);  // :96
   }
   out_r[i] = acc;
   out_b[i] = bootstrap;
-  out_t[i] = th[i];  // terminal of step 0 only :66
+  out_t[i] = th[(first % (n + 1)) * K + i];  // terminal of step 0 only :66
 }
 
 // ---- block-wide min over a [n*A] table -------------------------------------------------
@@ -101,12 +102,15 @@ __device__ __forceinline__ void philox(uint64_t seed, uint64_t ctr, uint32_t out
   out[3] = c3;
 }
 
-__global__ __launch_bounds__(kT) void act_kernel(int n, int A, const float* __restrict__ q,
+// one workgroup per group of `group` rows (= one reference TorchScript call)
+__global__ __launch_bounds__(kT) void act_kernel(int n, int A, int group, const float* __restrict__ q,
                                                  const float* __restrict__ legal, const float* __restrict__ eps,
                                                  uint64_t seed, uint64_t offset, int64_t* __restrict__ action) {
   __shared__ float red[kT];
-  const float qmin = block_min(q, n * A, red);
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  const int r0 = blockIdx.x * group;
+  const int r1 = min(n, r0 + group);
+  const float qmin = block_min(q + (size_t)r0 * A, (r1 - r0) * A, red);
+  for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
     const int g = greedy_row(q + (size_t)i * A, legal + (size_t)i * A, A, qmin);
     int a = g;
     const float e = eps ? eps[i] : 0.0f;
@@ -135,14 +139,16 @@ __global__ __launch_bounds__(kT) void act_kernel(int n, int A, const float* __re
   }
 }
 
-__global__ __launch_bounds__(kT) void td_kernel(int n, int A, const float* __restrict__ q,
+__global__ __launch_bounds__(kT) void td_kernel(int n, int A, int group, const float* __restrict__ q,
                                                 const float* __restrict__ qno, const float* __restrict__ qnt,
                                                 const float* __restrict__ nlegal, const int64_t* __restrict__ action,
                                                 const float* __restrict__ reward, const float* __restrict__ bootstrap,
                                                 float gamma_n, float* __restrict__ td, float* __restrict__ prio) {
   __shared__ float red[kT];
-  const float qmin = block_min(qno, n * A, red);  // greedy_act(next_obs) apex.py:41,51
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+  const int r0 = blockIdx.x * group;
+  const int r1 = min(n, r0 + group);
+  const float qmin = block_min(qno + (size_t)r0 * A, (r1 - r0) * A, red);  // greedy_act(next_obs) apex.py:41,51
+  for (int i = r0 + threadIdx.x; i < r1; i += blockDim.x) {
     const int na = greedy_row(qno + (size_t)i * A, nlegal + (size_t)i * A, A, qmin);
     const float qa = q[(size_t)i * A + (int)action[i]];   // :39
     const float bq = qnt[(size_t)i * A + na];              // :43
@@ -159,37 +165,46 @@ __global__ __launch_bounds__(kT) void td_kernel(int n, int A, const float* __res
 
 using namespace rela_amd;
 
-extern "C" int rela_nstep_return(int multi_step, int K, float gamma, const float* reward_hist_dev,
+extern "C" int rela_nstep_return(int multi_step, int K, float gamma, int first_row, const float* reward_hist_dev,
                                  const uint8_t* terminal_hist_dev, float* out_reward_dev, float* out_bootstrap_dev,
                                  uint8_t* out_terminal_dev, void* stream) {
-  RELA_CHECK(multi_step >= 1 && K >= 1 && reward_hist_dev && terminal_hist_dev && out_reward_dev &&
+  RELA_CHECK(multi_step >= 1 && K >= 1 && first_row >= 0 && first_row <= multi_step && reward_hist_dev && terminal_hist_dev && out_reward_dev &&
                  out_bootstrap_dev && out_terminal_dev,
              RELA_EINVAL, "rela_nstep_return: bad arguments");
+  ProfScope prof("nstep_kernel", (hipStream_t)stream);
   hipLaunchKernelGGL(nstep_kernel, dim3(ceil_div(K, 256)), dim3(256), 0, (hipStream_t)stream, multi_step, K, gamma,
-                     reward_hist_dev, terminal_hist_dev, out_reward_dev, out_bootstrap_dev, out_terminal_dev);
+                     first_row, reward_hist_dev, terminal_hist_dev, out_reward_dev, out_bootstrap_dev, out_terminal_dev);
   RELA_LAUNCH_CHECK();
   return RELA_OK;
 }
 
-extern "C" int rela_apex_act_from_q(int n, int num_action, const float* q_dev, const float* legal_dev,
-                                    const float* eps_dev, uint64_t rng_seed, uint64_t rng_offset, int64_t* action_dev,
-                                    void* stream) {
-  RELA_CHECK(n >= 1 && num_action >= 1 && q_dev && legal_dev && action_dev, RELA_EINVAL,
+extern "C" int rela_apex_act_from_q(int n, int num_action, int group_rows, const float* q_dev,
+                                    const float* legal_dev, const float* eps_dev, uint64_t rng_seed,
+                                    uint64_t rng_offset, int64_t* action_dev, void* stream) {
+  RELA_CHECK(n >= 1 && num_action >= 1 && group_rows >= 0 && q_dev && legal_dev && action_dev, RELA_EINVAL,
              "rela_apex_act_from_q: bad arguments");
-  hipLaunchKernelGGL(act_kernel, dim3(1), dim3(kT), 0, (hipStream_t)stream, n, num_action, q_dev, legal_dev, eps_dev,
-                     rng_seed, rng_offset, action_dev);
+  const int group = group_rows > 0 ? group_rows : n;
+  const int threads = group >= 512 ? kT : 256;
+  ProfScope prof("act_kernel", (hipStream_t)stream);
+  hipLaunchKernelGGL(act_kernel, dim3(ceil_div(n, group)), dim3(threads), 0, (hipStream_t)stream, n, num_action, group,
+                     q_dev, legal_dev, eps_dev, rng_seed, rng_offset, action_dev);
   RELA_LAUNCH_CHECK();
   return RELA_OK;
 }
 
-extern "C" int rela_apex_td_from_q(int n, int num_action, const float* q_dev, const float* q_next_online_dev,
-                                   const float* q_next_target_dev, const float* next_legal_dev,
+extern "C" int rela_apex_td_from_q(int n, int num_action, int group_rows, const float* q_dev,
+                                   const float* q_next_online_dev, const float* q_next_target_dev,
+                                   const float* next_legal_dev,
                                    const int64_t* action_dev, const float* reward_dev, const float* bootstrap_dev,
                                    float gamma_n, float* td_err_dev, float* priority_dev, void* stream) {
-  RELA_CHECK(n >= 1 && num_action >= 1 && q_dev && q_next_online_dev && q_next_target_dev && next_legal_dev &&
-                 action_dev && reward_dev && bootstrap_dev,
+  RELA_CHECK(n >= 1 && num_action >= 1 && group_rows >= 0 && q_dev && q_next_online_dev && q_next_target_dev &&
+                 next_legal_dev && action_dev && reward_dev && bootstrap_dev,
              RELA_EINVAL, "rela_apex_td_from_q: bad arguments");
-  hipLaunchKernelGGL(td_kernel, dim3(1), dim3(kT), 0, (hipStream_t)stream, n, num_action, q_dev, q_next_online_dev,
+  const int group = group_rows > 0 ? group_rows : n;
+  const int threads = group >= 512 ? kT : 256;
+  ProfScope prof("td_kernel", (hipStream_t)stream);
+  hipLaunchKernelGGL(td_kernel, dim3(ceil_div(n, group)), dim3(threads), 0, (hipStream_t)stream, n, num_action, group,
+                     q_dev, q_next_online_dev,
                      q_next_target_dev, next_legal_dev, action_dev, reward_dev, bootstrap_dev, gamma_n, td_err_dev,
                      priority_dev);
   RELA_LAUNCH_CHECK();

@@ -22,6 +22,7 @@
 // conv1 reads the raw u8 frames from LDS and converts in-register; the /255 of net.py:46 is
 // folded into conv1's weights at load time.
 #include "common.h"
+#include "prof.h"
 
 namespace rela_amd {
 
@@ -470,17 +471,35 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
   float* h = a3 + kA3 * N;
   float* ha = h + kH * N;
   const FFNetDev& d = n->d;
-  hipLaunchKernelGGL(conv_mfma<Conv1>, dim3(ceil_div(N, Conv1::S)), dim3(kThreads), Conv1::LDS_BYTES, s,
-                     (const void*)s_dev, d.B1, d.b1, a1, N);
-  hipLaunchKernelGGL(conv_mfma<Conv2>, dim3(ceil_div(N, Conv2::S)), dim3(kThreads), Conv2::LDS_BYTES, s,
-                     (const void*)a1, d.B2, d.b2, a2, N);
-  hipLaunchKernelGGL(conv_mfma<Conv3>, dim3(ceil_div(N, Conv3::S)), dim3(kThreads), Conv3::LDS_BYTES, s,
-                     (const void*)a2, d.B3, d.b3, a3, N);
-  hipLaunchKernelGGL(gemm_mfma<GemmFc>, dim3(GemmFc::CT / GemmFc::CTB, ceil_div(N, GemmFc::BM)), dim3(kThreads), 0, s,
-                     a3, d.Bf, d.bf, h, N);
-  hipLaunchKernelGGL(gemm_mfma<GemmHeads>, dim3(GemmHeads::CT / GemmHeads::CTB, ceil_div(N, GemmHeads::BM)),
-                     dim3(kThreads), 0, s, h, d.Bh, d.bh, ha, N);
-  hipLaunchKernelGGL(dueling_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, ha, legal_dev, q_dev, N, n->num_action);
+  {
+    ProfScope prof("conv1_mfma", s);
+    hipLaunchKernelGGL(conv_mfma<Conv1>, dim3(ceil_div(N, Conv1::S)), dim3(kThreads), Conv1::LDS_BYTES, s,
+                       (const void*)s_dev, d.B1, d.b1, a1, N);
+  }
+  {
+    ProfScope prof("conv2_mfma", s);
+    hipLaunchKernelGGL(conv_mfma<Conv2>, dim3(ceil_div(N, Conv2::S)), dim3(kThreads), Conv2::LDS_BYTES, s,
+                       (const void*)a1, d.B2, d.b2, a2, N);
+  }
+  {
+    ProfScope prof("conv3_mfma", s);
+    hipLaunchKernelGGL(conv_mfma<Conv3>, dim3(ceil_div(N, Conv3::S)), dim3(kThreads), Conv3::LDS_BYTES, s,
+                       (const void*)a2, d.B3, d.b3, a3, N);
+  }
+  {
+    ProfScope prof("fc_mfma", s);
+    hipLaunchKernelGGL(gemm_mfma<GemmFc>, dim3(GemmFc::CT / GemmFc::CTB, ceil_div(N, GemmFc::BM)), dim3(kThreads), 0, s,
+                       a3, d.Bf, d.bf, h, N);
+  }
+  {
+    ProfScope prof("heads_mfma", s);
+    hipLaunchKernelGGL(gemm_mfma<GemmHeads>, dim3(GemmHeads::CT / GemmHeads::CTB, ceil_div(N, GemmHeads::BM)),
+                       dim3(kThreads), 0, s, h, d.Bh, d.bh, ha, N);
+  }
+  {
+    ProfScope prof("dueling", s);
+    hipLaunchKernelGGL(dueling_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, ha, legal_dev, q_dev, N, n->num_action);
+  }
   RELA_LAUNCH_CHECK();
   return RELA_OK;
 }

@@ -1,0 +1,91 @@
+// prof.hip -- see prof.h.  Events are recorded on the same stream the kernel is launched on, so
+// the measured interval is that kernel's execution (plus the inter-kernel gap before it drains).
+#include <atomic>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "prof.h"
+
+namespace rela_amd {
+namespace {
+std::atomic<int> g_on{0};
+std::mutex g_m;
+struct Rec {
+  const char* name;
+  hipEvent_t a, b;
+};
+std::vector<Rec> g_recs;
+std::vector<hipEvent_t> g_pool;
+
+hipEvent_t get_event() {
+  if (!g_pool.empty()) {
+    hipEvent_t e = g_pool.back();
+    g_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+
+ProfScope::ProfScope(const char* name, hipStream_t s) : slot(-1), stream(s) {
+  if (!g_on.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_m);
+  Rec r{name, get_event(), get_event()};
+  (void)hipEventRecord(r.a, s);
+  g_recs.push_back(r);
+  slot = (int)g_recs.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+  if (slot < 0) return;
+  std::lock_guard<std::mutex> lk(g_m);
+  if (slot < (int)g_recs.size()) (void)hipEventRecord(g_recs[slot].b, stream);
+}
+
+}  // namespace rela_amd
+
+using namespace rela_amd;
+
+extern "C" int rela_prof_enable(int on) {
+  g_on.store(on ? 1 : 0);
+  return RELA_OK;
+}
+
+// Synchronises the device, aggregates and clears the recorded intervals.  Writes a JSON object
+// {"kernel": {"count": n, "total_ms": t}, ...} into out (NUL terminated).
+extern "C" int rela_prof_summary_json(char* out, int64_t cap) {
+  RELA_CHECK(out && cap > 2, RELA_EINVAL, "rela_prof_summary_json: bad arguments");
+  RELA_HIP(hipDeviceSynchronize());
+  std::lock_guard<std::mutex> lk(g_m);
+  std::map<std::string, std::pair<long, double>> agg;
+  for (auto& r : g_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      auto& e = agg[r.name];
+      e.first += 1;
+      e.second += ms;
+    }
+    g_pool.push_back(r.a);
+    g_pool.push_back(r.b);
+  }
+  g_recs.clear();
+  std::string s = "{";
+  bool first = true;
+  for (auto& kv : agg) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s\"%s\":{\"count\":%ld,\"total_ms\":%.6f}", first ? "" : ",", kv.first.c_str(),
+             kv.second.first, kv.second.second);
+    s += buf;
+    first = false;
+  }
+  s += "}";
+  RELA_CHECK((int64_t)s.size() + 1 <= cap, RELA_EINVAL, "rela_prof_summary_json: buffer too small");
+  memcpy(out, s.c_str(), s.size() + 1);
+  return RELA_OK;
+}

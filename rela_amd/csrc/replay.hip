@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "common.h"
+#include "prof.h"
 #include "seqsum_dev.h"
 
 namespace rela_amd {
@@ -390,15 +391,21 @@ extern "C" int rela_replay_add(rela_replay* r, int n, const void* const* rows_de
   // continue only after its rows were consumed
   RELA_HIP(hipEventRecord(r->ev_in, producer));
   RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
-  hipLaunchKernelGGL(replay_append_weights, dim3(1), dim3(kThreads), 0, r->stream, priority_dev, n, r->alpha,
-                     r->d_w, r->ring, start, r->d_state);
+  {
+    ProfScope prof("replay_append_weights", r->stream);
+    hipLaunchKernelGGL(replay_append_weights, dim3(1), dim3(kThreads), 0, r->stream, priority_dev, n, r->alpha,
+                       r->d_w, r->ring, start, r->d_state);
+  }
   for (size_t f = 0; f < r->d_fields.size(); ++f) {
     const int64_t rb = r->row_bytes[f];
     const int v16 = vec16_ok(rows_dev[f], r->d_fields[f], rb);
     const int64_t units = v16 ? (rb >> 4) : rb;
     int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (units + kThreads - 1) / kThreads), 64);
-    hipLaunchKernelGGL(replay_scatter_rows, dim3(gx, std::min(n, 32768)), dim3(kThreads), 0, r->stream,
-                       (const uint8_t*)rows_dev[f], r->d_fields[f], rb, n, r->ring, start, v16);
+    {
+      ProfScope prof("replay_scatter_rows", r->stream);
+      hipLaunchKernelGGL(replay_scatter_rows, dim3(gx, std::min(n, 32768)), dim3(kThreads), 0, r->stream,
+                         (const uint8_t*)rows_dev[f], r->d_fields[f], rb, n, r->ring, start, v16);
+    }
   }
   RELA_LAUNCH_CHECK();
   RELA_HIP(hipEventRecord(r->ev_out, r->stream));
@@ -428,20 +435,32 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
   SeqView v;
   int rc = seq_index_build(r->ix, r->d_w, r->ring, r->head, size, r->stream, &v);
   if (rc != RELA_OK) return rc;
-  hipLaunchKernelGGL(replay_targets, dim3(1), dim3(64), 0, r->stream, r->d_draws, batch, r->d_state,
-                     r->d_targets, r->d_eff);
-  hipLaunchKernelGGL(replay_search, dim3(ceil_div(batch, 64)), dim3(64), 0, r->stream, v, r->d_eff, batch,
-                     r->d_ids, r->d_raw_w, r->d_evicted, r->d_state);
+  {
+    ProfScope prof("replay_targets", r->stream);
+    hipLaunchKernelGGL(replay_targets, dim3(1), dim3(64), 0, r->stream, r->d_draws, batch, r->d_state,
+                       r->d_targets, r->d_eff);
+  }
+  {
+    ProfScope prof("replay_search", r->stream);
+    hipLaunchKernelGGL(replay_search, dim3(ceil_div(batch, 64)), dim3(64), 0, r->stream, v, r->d_eff, batch,
+                       r->d_ids, r->d_raw_w, r->d_evicted, r->d_state);
+  }
   // pop storage if full :311-315 (size re-read, then IS weights use the pre-pop size :321)
   const int n_pop = size > r->capacity ? size - r->capacity : 0;
   if (n_pop > 0) {
-    hipLaunchKernelGGL(replay_pop, dim3(std::min(ceil_div(n_pop, kThreads), 256)), dim3(kThreads), 0, r->stream, v,
-                       n_pop, r->d_evicted, r->d_state);
+    {
+      ProfScope prof("replay_pop", r->stream);
+      hipLaunchKernelGGL(replay_pop, dim3(std::min(ceil_div(n_pop, kThreads), 256)), dim3(kThreads), 0, r->stream, v,
+                         n_pop, r->d_evicted, r->d_state);
+    }
     r->head = (r->head + n_pop) % r->ring;
     r->size -= n_pop;
   }
-  hipLaunchKernelGGL(replay_is_weights, dim3(1), dim3(1024), 0, r->stream, r->d_raw_w, batch, (float)size, r->beta,
-                     r->d_state, out_weight_dev);
+  {
+    ProfScope prof("replay_is_weights", r->stream);
+    hipLaunchKernelGGL(replay_is_weights, dim3(1), dim3(1024), 0, r->stream, r->d_raw_w, batch, (float)size, r->beta,
+                       r->d_state, out_weight_dev);
+  }
   if (out_rows_dev) {
     for (size_t f = 0; f < r->d_fields.size(); ++f) {
       if (!out_rows_dev[f]) continue;
@@ -449,8 +468,11 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
       const int v16 = vec16_ok(out_rows_dev[f], r->d_fields[f], rb);
       const int64_t units = v16 ? (rb >> 4) : rb;
       int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (units + kThreads - 1) / kThreads), 64);
-      hipLaunchKernelGGL(replay_gather_rows, dim3(gx, batch), dim3(kThreads), 0, r->stream, r->d_fields[f],
-                         r->d_ids, (uint8_t*)out_rows_dev[f], rb, v16);
+      {
+        ProfScope prof("replay_gather_rows", r->stream);
+        hipLaunchKernelGGL(replay_gather_rows, dim3(gx, batch), dim3(kThreads), 0, r->stream, r->d_fields[f],
+                           r->d_ids, (uint8_t*)out_rows_dev[f], rb, v16);
+      }
     }
   }
   RELA_LAUNCH_CHECK();
@@ -478,8 +500,11 @@ extern "C" int rela_replay_update_priority(rela_replay* r, int n, const float* p
     RELA_HIP(hipMemcpyAsync(r->d_prio, priority, sizeof(float) * n, hipMemcpyHostToDevice, r->stream));
     p = r->d_prio;
   }
-  hipLaunchKernelGGL(replay_update, dim3(1), dim3(1024), 0, r->stream, p, n, r->alpha, r->d_ids, r->d_evicted,
-                     r->d_w, r->d_state);
+  {
+    ProfScope prof("replay_update", r->stream);
+    hipLaunchKernelGGL(replay_update, dim3(1), dim3(1024), 0, r->stream, p, n, r->alpha, r->d_ids, r->d_evicted,
+                       r->d_w, r->d_state);
+  }
   RELA_LAUNCH_CHECK();
   if (on_device) {
     RELA_HIP(hipEventRecord(r->ev_out, r->stream));

@@ -12,6 +12,7 @@
 // Algorithmic bytes: 4N (the reference's linear scan reads each weight once);
 // this pipeline reads them twice, the second time from L2 / Infinity Cache.
 #include "common.h"
+#include "prof.h"
 #include "seqsum_dev.h"
 
 namespace rela_amd {
@@ -215,14 +216,29 @@ int seq_index_build(const SeqIndex& ix, const float* ring_dev, int64_t ring, int
   const int n3 = ceil_div(size, kL3);
   RELA_CHECK(n2 <= ix.n2cap && n3 <= ix.n3cap, RELA_EINVAL, "seq_index_build: index too small");
   if (n2 > 0) {
-    hipLaunchKernelGGL(seq_l2_sums, dim3(n2), dim3(kBlock), 0, stream, ring_dev, ring, head, size, ix.bsum2);
-    hipLaunchKernelGGL(seq_l2_scan, dim3(1), dim3(kBlock), 0, stream, ix.bsum2, n2, ix.S0);
-    hipLaunchKernelGGL(seq_tables, dim3(n2), dim3(kBlock), 0, stream, ring_dev, ring, head, size, ix.S0, ix.T1,
-                       ix.T2);
-    hipLaunchKernelGGL(seq_l3_tables, dim3(ceil_div(n3, 64)), dim3(64), 0, stream, ix.T2, n2, ix.T3, n3);
+    {
+      ProfScope prof("seq_l2_sums", stream);
+      hipLaunchKernelGGL(seq_l2_sums, dim3(n2), dim3(kBlock), 0, stream, ring_dev, ring, head, size, ix.bsum2);
+    }
+    {
+      ProfScope prof("seq_l2_scan", stream);
+      hipLaunchKernelGGL(seq_l2_scan, dim3(1), dim3(kBlock), 0, stream, ix.bsum2, n2, ix.S0);
+    }
+    {
+      ProfScope prof("seq_tables", stream);
+      hipLaunchKernelGGL(seq_tables, dim3(n2), dim3(kBlock), 0, stream, ring_dev, ring, head, size, ix.S0, ix.T1,
+                         ix.T2);
+    }
+    {
+      ProfScope prof("seq_l3_tables", stream);
+      hipLaunchKernelGGL(seq_l3_tables, dim3(ceil_div(n3, 64)), dim3(64), 0, stream, ix.T2, n2, ix.T3, n3);
+    }
   }
-  hipLaunchKernelGGL(seq_chain, dim3(1), dim3(64), 0, stream, ring_dev, ring, head, size, ix.T1, ix.T2, ix.T3, n3,
-                     ix.A3);
+  {
+    ProfScope prof("seq_chain", stream);
+    hipLaunchKernelGGL(seq_chain, dim3(1), dim3(64), 0, stream, ring_dev, ring, head, size, ix.T1, ix.T2, ix.T3, n3,
+                       ix.A3);
+  }
   RELA_LAUNCH_CHECK();
   view->w = ring_dev;
   view->ring = ring;

@@ -1,0 +1,105 @@
+"""Python view of the device-resident prioritized replay (C ABI: include/rela_amd.h).
+
+`FFReplay` stores FFTransition records (rela/types.h:18-51) as ten SoA fields and hands batches
+back as torch tensors that alias preallocated device buffers (zero host copies).  It mirrors
+FFPrioritizedReplay's Python surface (rela/pybind.cc:37-47): size / num_add / sample /
+update_priority; `add` is reachable only from the actor engine, as in the reference.
+"""
+import ctypes as C
+from types import SimpleNamespace
+
+import torch
+
+from . import _capi as capi
+
+OBS_BYTES = 4 * 84 * 84
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class FFReplay:
+    """FFPrioritizedReplay(capacity, seed, alpha, beta, prefetch) -- prioritized_replay.h:175-184."""
+
+    FIELDS = ("s", "next_s", "eps", "next_eps", "legal_move", "next_legal_move", "a", "reward", "terminal",
+              "bootstrap")
+
+    def __init__(self, capacity, seed, alpha, beta, prefetch, num_action, device="cuda:0"):
+        self.device = torch.device(device)
+        self.num_action = num_action
+        h = C.c_void_p()
+        capi.check(capi.lib.rela_replay_create(C.byref(h), capacity, seed, alpha, beta, prefetch,
+                                               self.device.index or 0), "rela_replay_create")
+        self.h = h
+        A = num_action
+        self.row_bytes = [OBS_BYTES, OBS_BYTES, 4, 4, 4 * A, 4 * A, 8, 4, 1, 4]
+        rb = (C.c_int64 * len(self.row_bytes))(*self.row_bytes)
+        capi.check(capi.lib.rela_replay_set_schema(h, len(self.row_bytes), rb), "rela_replay_set_schema")
+        self._out = {}
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib.rela_replay_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def size(self):
+        return capi.lib.rela_replay_size(self.h)
+
+    def num_add(self):
+        return capi.lib.rela_replay_num_add(self.h)
+
+    # -- actor side ---------------------------------------------------------------------
+    def add_rows(self, n, ptrs, priority, nonblocking=False):
+        """ptrs: ten device pointers in FIELDS order, n rows each; priority: cuda f32[n]."""
+        rows = (C.c_void_p * len(ptrs))(*ptrs)
+        rc = capi.lib.rela_replay_add(self.h, n, rows, C.c_void_p(priority.data_ptr()), int(nonblocking),
+                                      _stream_ptr(self.device))
+        if rc != capi.EWOULDBLOCK:
+            capi.check(rc, "rela_replay_add")
+        return rc
+
+    # -- learner side -------------------------------------------------------------------
+    def _buffers(self, batch):
+        if batch not in self._out:
+            dev, A = self.device, self.num_action
+            mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+            self._out[batch] = dict(
+                s=mk((batch, 4, 84, 84), torch.uint8), next_s=mk((batch, 4, 84, 84), torch.uint8),
+                eps=mk((batch, 1), torch.float32), next_eps=mk((batch, 1), torch.float32),
+                legal_move=mk((batch, A), torch.float32), next_legal_move=mk((batch, A), torch.float32),
+                a=mk((batch,), torch.int64), reward=mk((batch,), torch.float32), terminal=mk((batch,), torch.bool),
+                bootstrap=mk((batch,), torch.float32), weight=mk((batch,), torch.float32))
+        return self._out[batch]
+
+    def sample(self, batchsize, device=None, gather=True):
+        """-> (FFTransition-like namespace, IS weights); tensors live on the replay's GPU."""
+        b = self._buffers(batchsize)
+        rows = (C.c_void_p * len(self.FIELDS))(*[b[f].data_ptr() for f in self.FIELDS]) if gather else None
+        capi.check(capi.lib.rela_replay_sample(self.h, batchsize, rows, C.c_void_p(b["weight"].data_ptr()),
+                                               _stream_ptr(self.device)), "rela_replay_sample")
+        batch = SimpleNamespace(
+            obs={"s": b["s"], "eps": b["eps"], "legal_move": b["legal_move"]}, action={"a": b["a"]},
+            reward=b["reward"], terminal=b["terminal"], bootstrap=b["bootstrap"],
+            next_obs={"s": b["next_s"], "eps": b["next_eps"], "legal_move": b["next_legal_move"]})
+        return batch, b["weight"]
+
+    def update_priority(self, priority):
+        """CPU tensor as in the reference, or a CUDA tensor (no host sync)."""
+        p = priority.detach().contiguous().float()
+        self._keep = p
+        if p.is_cuda:
+            rc = capi.lib.rela_replay_update_priority(self.h, p.numel(), C.c_void_p(p.data_ptr()), 1,
+                                                      _stream_ptr(self.device))
+        else:
+            rc = capi.lib.rela_replay_update_priority(self.h, p.numel(), C.c_void_p(p.data_ptr()), 0, None)
+        capi.check(rc, "rela_replay_update_priority")
+
+    def debug_state(self):
+        st = capi.ReplayState()
+        capi.check(capi.lib.rela_replay_debug_state(self.h, C.byref(st), None, None, None), "rela_replay_debug_state")
+        return {k: getattr(st, k) for k, _ in capi.ReplayState._fields_}

@@ -39,11 +39,15 @@ def test_nstep_golden(path):
         th.append([int(t) for t in tok[K:]])
         if not exp["pop"]:
             continue
-        r, t = dev(np.array(rh, np.float32)), dev(np.array(th, np.uint8))
+        # store the deque as a ring rotated by `first` to exercise the first_row argument
+        first = len(rh) % (n + 1) if n > 0 else 0
+        first = (first + exp["obs_step"]) % (n + 1)
+        rot = lambda a: np.roll(np.array(a), first, axis=0)
+        r, t = dev(rot(rh).astype(np.float32)), dev(rot(th).astype(np.uint8))
         o_r = torch.empty(K, device="cuda")
         o_b = torch.empty(K, device="cuda")
         o_t = torch.empty(K, dtype=torch.uint8, device="cuda")
-        capi.check(capi.lib.rela_nstep_return(n, K, gamma, ptr(r), ptr(t), ptr(o_r), ptr(o_b), ptr(o_t), cur_stream()),
+        capi.check(capi.lib.rela_nstep_return(n, K, gamma, first, ptr(r), ptr(t), ptr(o_r), ptr(o_b), ptr(o_t), cur_stream()),
                    "rela_nstep_return")
         assert [f2h(x) for x in o_r.cpu().numpy()] == exp["reward"]
         assert o_b.cpu().numpy().tolist() == exp["bootstrap"]
@@ -83,7 +87,7 @@ def test_act_and_td_from_q(n, A, masked):
     # reused by the next allocation) before the kernel runs
     d_q, d_qn, d_qt, d_legal, d_eps = dev(q), dev(qn), dev(qt), dev(legal), dev(np.zeros(n, np.float32))
     d_action, d_reward, d_boot = dev(action), dev(reward), dev(boot)
-    capi.check(capi.lib.rela_apex_act_from_q(n, A, ptr(d_q), ptr(d_legal), ptr(d_eps), 1, 0, ptr(d_act), cur_stream()),
+    capi.check(capi.lib.rela_apex_act_from_q(n, A, 0, ptr(d_q), ptr(d_legal), ptr(d_eps), 1, 0, ptr(d_act), cur_stream()),
                "act")
     np.testing.assert_array_equal(d_act.cpu().numpy(), exp_act)
     # oracle td from the three tables
@@ -95,7 +99,7 @@ def test_act_and_td_from_q(n, A, masked):
     err = (tgt - qa).astype(np.float32)
     d_td = torch.empty(n, device="cuda")
     d_pr = torch.empty(n, device="cuda")
-    capi.check(capi.lib.rela_apex_td_from_q(n, A, ptr(d_q), ptr(d_qn), ptr(d_qt), ptr(d_legal), ptr(d_action),
+    capi.check(capi.lib.rela_apex_td_from_q(n, A, 0, ptr(d_q), ptr(d_qn), ptr(d_qt), ptr(d_legal), ptr(d_action),
                                             ptr(d_reward), ptr(d_boot), C.c_float(gamma_n), ptr(d_td), ptr(d_pr),
                                             cur_stream()), "td")
     np.testing.assert_array_equal(d_td.cpu().numpy(), err)
@@ -120,7 +124,7 @@ def test_eps_greedy_statistics():
     d_q, d_legal, d_eps = dev(q), dev(legal), dev(eps)
     for off in (0, n):
         d_act = torch.empty(n, dtype=torch.int64, device="cuda")
-        capi.check(capi.lib.rela_apex_act_from_q(n, A, ptr(d_q), ptr(d_legal), ptr(d_eps), 99, off, ptr(d_act),
+        capi.check(capi.lib.rela_apex_act_from_q(n, A, 0, ptr(d_q), ptr(d_legal), ptr(d_eps), 99, off, ptr(d_act),
                                                  cur_stream()), "act")
         acts.append(d_act.cpu().numpy())
     greedy = np.argmax((1 + q - q.min()) * legal, 1)

@@ -78,13 +78,13 @@ def test_ffnet_golden(path):
     capi = on.capi
     d_legal, d_eps = dev(legal), dev(np.zeros(N, np.float32))
     act = torch.empty(N, dtype=torch.int64, device="cuda")
-    capi.check(capi.lib.rela_apex_act_from_q(N, A, ptr(q), ptr(d_legal), ptr(d_eps), 0, 0, ptr(act), cur_stream()), "act")
+    capi.check(capi.lib.rela_apex_act_from_q(N, A, 0, ptr(q), ptr(d_legal), ptr(d_eps), 0, 0, ptr(act), cur_stream()), "act")
     assert act.cpu().numpy().tolist() == g["greedy"] == g["act_eps0"]
     d_a, d_r, d_b = dev(np.array(g["action"], np.int64)), dev(np.array(g["reward"], np.float32)), dev(
         np.array(g["bootstrap"], np.float32))
     td, pr = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
     gamma_n = np.float32(np.float64(g["gamma"]) ** g["multi_step"])
-    capi.check(capi.lib.rela_apex_td_from_q(N, A, ptr(q), ptr(qn), ptr(qt), ptr(d_legal), ptr(d_a), ptr(d_r), ptr(d_b),
+    capi.check(capi.lib.rela_apex_td_from_q(N, A, 0, ptr(q), ptr(qn), ptr(qt), ptr(d_legal), ptr(d_a), ptr(d_r), ptr(d_b),
                                             C.c_float(gamma_n), ptr(td), ptr(pr), cur_stream()), "td")
     np.testing.assert_allclose(td.cpu().numpy(), np.array(g["td_err"]), rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(pr.cpu().numpy(), np.array(g["priority"]), rtol=RTOL, atol=ATOL)
