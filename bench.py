@@ -230,12 +230,15 @@ def main():
         actor_tick()
         step_idx[0] += 1
     prio = torch.empty(ROWS, device=device)
+    z_a = torch.zeros(ROWS, dtype=torch.int64, device=device)
+    z_f = torch.zeros(ROWS, device=device)
+    z_b = torch.zeros(ROWS, dtype=torch.uint8, device=device)
     while replay.size() + ROWS <= args.replay_cap:
         prio.uniform_(0.01, 2.0, generator=g)
         obs_a, obs_b = engine.obs_hist[0], engine.obs_hist[1]
         ptrs = [obs_a.data_ptr(), obs_b.data_ptr(), engine.eps.data_ptr(), engine.eps.data_ptr(),
-                engine.legal.data_ptr(), engine.legal.data_ptr(), engine.act_hist[0].data_ptr(),
-                engine.out_r.data_ptr(), engine.out_t.data_ptr(), engine.out_b.data_ptr()]
+                engine.legal.data_ptr(), engine.legal.data_ptr(), z_a.data_ptr(), z_f.data_ptr(), z_b.data_ptr(),
+                z_f.data_ptr()]
         replay.add_rows(ROWS, ptrs, prio)
     torch.cuda.synchronize()
 

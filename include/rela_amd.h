@@ -34,6 +34,12 @@ extern "C" {
 const char* rela_last_error(void); /* thread-local message of the last failing call          */
 int rela_abi_version(void);
 
+/* A private non-blocking HIP stream for one host thread (each reference actor thread,
+ * rela/context.h:39-46, gets its own so actor shards overlap on the GPU).                    */
+int rela_stream_create(void** out, int device);
+void rela_stream_destroy(void* stream, int device);
+int rela_stream_synchronize(void* stream, int device);
+
 /* ===================================================================================
  * Prioritized replay  --  rela/prioritized_replay.h:173-348 (PrioritizedReplay<T>) over
  * :14-171 (ConcurrentQueue<T>), bound in rela/pybind.cc:37-59.
@@ -164,6 +170,52 @@ int rela_apex_td_from_q(int n, int num_action, int group_rows, const float* q_de
                         const int64_t* action_dev, const float* reward_dev,
                         const float* bootstrap_dev, float gamma_n, float* td_err_dev,
                         float* priority_dev, void* stream);
+
+/* ===================================================================================
+ * Ape-X actor shard  --  DQNActor + MultiStepTransitionBuffer, rela/dqn_actor.h:15-211, as one
+ * device-resident object for `rows` envs (rows = K for one reference actor thread, or T*K when
+ * several threads are batched into one launch; group_rows = K keeps every batch-global reduction
+ * of the reference at its original scope).  The observation history (multi_step+1 frame stacks
+ * per env) lives in HBM: obs_t / obs_{t+n} are never re-uploaded for the priority pass and the
+ * replay insert is a device-to-device row copy.  replay may be NULL (evaluation actor,
+ * dqn_actor.h:141-147): then only act() is legal.
+ * =================================================================================== */
+typedef struct rela_apex_actor rela_apex_actor;
+
+int rela_apex_actor_create(rela_apex_actor** out, int rows, int group_rows, int num_action,
+                           int multi_step, float gamma, rela_replay* replay, uint64_t seed,
+                           int device);
+void rela_apex_actor_destroy(rela_apex_actor* a);
+
+/* Device address ([rows][4][84][84] u8) the env layer may write the NEXT observation batch into
+ * directly (then pass obs_host = NULL to act).                                              */
+void* rela_apex_actor_obs_slot(rela_apex_actor* a);
+/* Device addresses of the per-env constants; eps f32[rows], legal f32[rows][A].             */
+float* rela_apex_actor_eps_dev(rela_apex_actor* a);
+float* rela_apex_actor_legal_dev(rela_apex_actor* a);
+
+/* DQNActor::act  dqn_actor.h:153-171 (TorchScript "act" = apex.py:57-65).
+ * obs_host / eps_host / legal_host: host copies of obs["s"], obs["eps"], obs["legal_move"] for
+ * this step, or NULL when the device copies are already current.  The chosen actions are left
+ * in device memory (*action_dev_out, int64[rows], valid until the next act) and, if action_host
+ * is not NULL, copied there and the stream is synchronised (the env layer needs them).        */
+int rela_apex_actor_act(rela_apex_actor* a, const rela_ffnet* online, const uint8_t* obs_host,
+                        const float* eps_host, const float* legal_host, int64_t* action_host,
+                        const int64_t** action_dev_out, void* stream);
+
+/* setRewardAndTerminal + postStep  dqn_actor.h:174-203: pushes (r, t) of the step just acted;
+ * once multi_step+1 steps are buffered pops one n-step transition (:58-106), computes its TD
+ * priority with the online/target nets (compute_priority, apex.py:68-78) and appends it to the
+ * replay (:189).  *inserted (may be NULL) reports whether a block was appended.
+ * With nonblocking != 0 a full ring drops the block (RELA_EWOULDBLOCK) instead of waiting.   */
+int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward, const uint8_t* terminal,
+                              int on_device, const rela_ffnet* online, const rela_ffnet* target,
+                              int nonblocking, int* inserted, void* stream);
+
+int64_t rela_apex_actor_num_act(const rela_apex_actor* a); /* numAct()  dqn_actor.h:149-151 */
+/* diagnostic: device pointers of the last Q table of act() and of the last priorities       */
+const float* rela_apex_actor_last_q_dev(const rela_apex_actor* a);
+const float* rela_apex_actor_last_priority_dev(const rela_apex_actor* a);
 
 /* ===================================================================================
  * Live per-kernel timing (HIP events on the launch stream) for bench.py's roofline line.

@@ -53,6 +53,9 @@ def _sig(name, restype, argtypes):
 
 _sig("rela_last_error", C.c_char_p, [])
 _sig("rela_abi_version", i32, [])
+_sig("rela_stream_create", i32, [P(vp), i32])
+_sig("rela_stream_destroy", None, [vp, i32])
+_sig("rela_stream_synchronize", i32, [vp, i32])
 _sig("rela_replay_create", i32, [P(vp), i32, i32, f32, f32, i32, i32])
 _sig("rela_replay_destroy", None, [vp])
 _sig("rela_replay_set_schema", i32, [vp, i32, P(i64)])
@@ -73,6 +76,16 @@ _sig("rela_ffnet_workspace_bytes", i64, [vp, i32])
 _sig("rela_ffnet_forward", i32, [vp, i32, vp, vp, vp, vp, i64, vp])
 _sig("rela_apex_act_from_q", i32, [i32, i32, i32, vp, vp, vp, u64, u64, vp, vp])
 _sig("rela_apex_td_from_q", i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp])
+_sig("rela_apex_actor_create", i32, [P(vp), i32, i32, i32, i32, f32, vp, u64, i32])
+_sig("rela_apex_actor_destroy", None, [vp])
+_sig("rela_apex_actor_obs_slot", vp, [vp])
+_sig("rela_apex_actor_eps_dev", vp, [vp])
+_sig("rela_apex_actor_legal_dev", vp, [vp])
+_sig("rela_apex_actor_act", i32, [vp, vp, vp, vp, vp, vp, P(vp), vp])
+_sig("rela_apex_actor_post_step", i32, [vp, vp, vp, i32, vp, vp, i32, P(i32), vp])
+_sig("rela_apex_actor_num_act", i64, [vp])
+_sig("rela_apex_actor_last_q_dev", vp, [vp])
+_sig("rela_apex_actor_last_priority_dev", vp, [vp])
 _sig("rela_prof_enable", i32, [i32])
 _sig("rela_prof_summary_json", i32, [C.c_char_p, i64])
 

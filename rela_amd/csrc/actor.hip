@@ -1,0 +1,184 @@
+// actor.hip -- device-resident Ape-X actor shard (C ABI: rela_apex_actor_*).
+//
+// Restates the per-step work BasicThreadLoop::mainLoop (rela/thread_loop.h:74-105) drives through
+// DQNActor (rela/dqn_actor.h:126-211) and MultiStepTransitionBuffer (:15-124):
+//   act        push (obs, action) :23-29,153-171      -> 1 trunk forward + eps-greedy
+//   post_step  push (r, t) :31-40; canPop :46-48; popTransition :58-106; computePriority :193-203
+//              (3 trunk forwards, apex.py:30-45); replay add :189
+// The deque of :120-123 is a ring of multi_step+1 slots in HBM; "pop_front" is a head increment.
+#include <atomic>
+#include <cmath>
+#include <vector>
+
+#include "common.h"
+
+using namespace rela_amd;
+
+struct rela_apex_actor {
+  int device = 0;
+  int R = 0, K = 0, A = 0, n = 0;
+  float gamma = 0.f, gamma_n = 0.f;
+  rela_replay* replay = nullptr;
+  uint64_t seed = 0;
+  uint64_t act_calls = 0;
+  std::atomic<int64_t> num_act{0};
+  int head = 0, count = 0, cur = -1;
+  // device state
+  uint8_t* obs = nullptr;   // [n+1][R][28224]
+  int64_t* act = nullptr;   // [n+1][R]
+  float* rew = nullptr;     // [n+1][R]
+  uint8_t* term = nullptr;  // [n+1][R]
+  float* eps = nullptr;     // [R]
+  float* legal = nullptr;   // [R][A]
+  float* q = nullptr;       // [4][R][A]
+  float *out_r = nullptr, *out_b = nullptr, *prio = nullptr;
+  uint8_t* out_t = nullptr;
+  void* ws = nullptr;
+  int64_t ws_bytes = 0;
+};
+
+namespace {
+constexpr int64_t kObs = 4 * 84 * 84;
+}
+
+extern "C" int rela_apex_actor_create(rela_apex_actor** out, int rows, int group_rows, int num_action, int multi_step,
+                                      float gamma, rela_replay* replay, uint64_t seed, int device) {
+  RELA_CHECK(out && rows >= 1 && group_rows >= 1 && rows % group_rows == 0 && num_action >= 1 && num_action <= 31 &&
+                 multi_step >= 1,
+             RELA_EINVAL, "rela_apex_actor_create: bad arguments (rows=%d group=%d A=%d n=%d)", rows, group_rows,
+             num_action, multi_step);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    set_last_error("rela_apex_actor_create: HIP device %d not available (%d visible); there is no CPU path", device,
+                   ndev);
+    return RELA_ENODEV;
+  }
+  DeviceGuard g(device);
+  auto* a = new rela_apex_actor();
+  a->device = device;
+  a->R = rows;
+  a->K = group_rows;
+  a->A = num_action;
+  a->n = multi_step;
+  a->gamma = gamma;
+  a->gamma_n = (float)pow((double)gamma, (double)multi_step);  // gamma ** multi_step, apex.py:44
+  a->replay = replay;
+  a->seed = seed;
+  const size_t H = (size_t)multi_step + 1, R = (size_t)rows, A = (size_t)num_action;
+  RELA_HIP(hipMalloc(&a->obs, H * R * kObs));
+  RELA_HIP(hipMalloc(&a->act, H * R * sizeof(int64_t)));
+  RELA_HIP(hipMalloc(&a->rew, H * R * sizeof(float)));
+  RELA_HIP(hipMalloc(&a->term, H * R));
+  RELA_HIP(hipMalloc(&a->eps, R * sizeof(float)));
+  RELA_HIP(hipMalloc(&a->legal, R * A * sizeof(float)));
+  RELA_HIP(hipMalloc(&a->q, 4 * R * A * sizeof(float)));
+  RELA_HIP(hipMalloc(&a->out_r, R * sizeof(float)));
+  RELA_HIP(hipMalloc(&a->out_b, R * sizeof(float)));
+  RELA_HIP(hipMalloc(&a->prio, R * sizeof(float)));
+  RELA_HIP(hipMalloc(&a->out_t, R));
+  a->ws_bytes = rela_ffnet_workspace_bytes(nullptr, rows);
+  RELA_HIP(hipMalloc(&a->ws, (size_t)a->ws_bytes));
+  RELA_HIP(hipMemset(a->obs, 0, H * R * kObs));
+  RELA_HIP(hipMemset(a->act, 0, H * R * sizeof(int64_t)));
+  RELA_HIP(hipMemset(a->rew, 0, H * R * sizeof(float)));
+  RELA_HIP(hipMemset(a->term, 0, H * R));
+  RELA_HIP(hipMemset(a->eps, 0, R * sizeof(float)));
+  {  // legal_move defaults to all ones
+    std::vector<float> ones(R * A, 1.0f);
+    RELA_HIP(hipMemcpy(a->legal, ones.data(), R * A * sizeof(float), hipMemcpyHostToDevice));
+  }
+  *out = a;
+  return RELA_OK;
+}
+
+extern "C" void rela_apex_actor_destroy(rela_apex_actor* a) {
+  if (!a) return;
+  DeviceGuard g(a->device);
+  (void)hipDeviceSynchronize();
+  void* ps[] = {a->obs, a->act, a->rew, a->term, a->eps, a->legal, a->q, a->out_r, a->out_b, a->prio, a->out_t, a->ws};
+  for (void* p : ps) (void)hipFree(p);
+  delete a;
+}
+
+static inline int next_slot(const rela_apex_actor* a) { return (a->head + a->count) % (a->n + 1); }
+
+extern "C" void* rela_apex_actor_obs_slot(rela_apex_actor* a) {
+  return a ? a->obs + (size_t)next_slot(a) * a->R * kObs : nullptr;
+}
+extern "C" float* rela_apex_actor_eps_dev(rela_apex_actor* a) { return a ? a->eps : nullptr; }
+extern "C" float* rela_apex_actor_legal_dev(rela_apex_actor* a) { return a ? a->legal : nullptr; }
+extern "C" int64_t rela_apex_actor_num_act(const rela_apex_actor* a) { return a ? a->num_act.load() : 0; }
+extern "C" const float* rela_apex_actor_last_q_dev(const rela_apex_actor* a) { return a ? a->q : nullptr; }
+extern "C" const float* rela_apex_actor_last_priority_dev(const rela_apex_actor* a) { return a ? a->prio : nullptr; }
+
+extern "C" int rela_apex_actor_act(rela_apex_actor* a, const rela_ffnet* online, const uint8_t* obs_host,
+                                   const float* eps_host, const float* legal_host, int64_t* action_host,
+                                   const int64_t** action_dev_out, void* stream_) {
+  RELA_CHECK(a && online, RELA_EINVAL, "rela_apex_actor_act: bad arguments");
+  RELA_CHECK(rela_ffnet_num_action(online) == a->A, RELA_EINVAL, "rela_apex_actor_act: net has %d actions, actor %d",
+             rela_ffnet_num_action(online), a->A);
+  RELA_CHECK(a->count <= a->n, RELA_ESTATE, "rela_apex_actor_act: act() twice without post_step()");  // :24-25
+  hipStream_t s = (hipStream_t)stream_;
+  DeviceGuard g(a->device);
+  const int slot = next_slot(a);
+  uint8_t* obs = a->obs + (size_t)slot * a->R * kObs;
+  if (obs_host) RELA_HIP(hipMemcpyAsync(obs, obs_host, (size_t)a->R * kObs, hipMemcpyHostToDevice, s));
+  if (eps_host) RELA_HIP(hipMemcpyAsync(a->eps, eps_host, (size_t)a->R * sizeof(float), hipMemcpyHostToDevice, s));
+  if (legal_host)
+    RELA_HIP(hipMemcpyAsync(a->legal, legal_host, (size_t)a->R * a->A * sizeof(float), hipMemcpyHostToDevice, s));
+  int rc = rela_ffnet_forward(online, a->R, obs, a->legal, a->q, a->ws, a->ws_bytes, s);
+  if (rc != RELA_OK) return rc;
+  int64_t* act = a->act + (size_t)slot * a->R;
+  rc = rela_apex_act_from_q(a->R, a->A, a->K, a->q, a->legal, a->eps, a->seed, a->act_calls * (uint64_t)a->R, act, s);
+  if (rc != RELA_OK) return rc;
+  a->act_calls += 1;
+  a->cur = slot;
+  a->num_act += a->R;  // :169
+  if (action_dev_out) *action_dev_out = act;
+  if (action_host) {
+    RELA_HIP(hipMemcpyAsync(action_host, act, (size_t)a->R * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    RELA_HIP(hipStreamSynchronize(s));
+  }
+  return RELA_OK;
+}
+
+extern "C" int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward, const uint8_t* terminal,
+                                         int on_device, const rela_ffnet* online, const rela_ffnet* target,
+                                         int nonblocking, int* inserted, void* stream_) {
+  RELA_CHECK(a && reward && terminal && online && target, RELA_EINVAL, "rela_apex_actor_post_step: bad arguments");
+  RELA_CHECK(a->replay, RELA_ESTATE, "rela_apex_actor_post_step: evaluation actor has no replay");  // :175,182
+  RELA_CHECK(a->cur >= 0, RELA_ESTATE, "rela_apex_actor_post_step: no act() to attach the reward to");  // :33
+  hipStream_t s = (hipStream_t)stream_;
+  DeviceGuard g(a->device);
+  if (inserted) *inserted = 0;
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  RELA_HIP(hipMemcpyAsync(a->rew + (size_t)a->cur * a->R, reward, (size_t)a->R * sizeof(float), kind, s));
+  RELA_HIP(hipMemcpyAsync(a->term + (size_t)a->cur * a->R, terminal, (size_t)a->R, kind, s));
+  a->cur = -1;
+  a->count += 1;
+  if (a->count < a->n + 1) return RELA_OK;  // canPop :46-48
+  const int H = a->n + 1;
+  const int first = a->head, last = (a->head + a->n) % H;
+  int rc = rela_nstep_return(a->n, a->R, a->gamma, first, a->rew, a->term, a->out_r, a->out_b, a->out_t, s);
+  if (rc != RELA_OK) return rc;
+  const uint8_t* obs_t = a->obs + (size_t)first * a->R * kObs;
+  const uint8_t* obs_n = a->obs + (size_t)last * a->R * kObs;
+  const size_t QA = (size_t)a->R * a->A;
+  rc = rela_ffnet_forward(online, a->R, obs_t, a->legal, a->q + QA, a->ws, a->ws_bytes, s);  // apex.py:38
+  if (rc != RELA_OK) return rc;
+  rc = rela_ffnet_forward(online, a->R, obs_n, a->legal, a->q + 2 * QA, a->ws, a->ws_bytes, s);  // :41
+  if (rc != RELA_OK) return rc;
+  rc = rela_ffnet_forward(target, a->R, obs_n, a->legal, a->q + 3 * QA, a->ws, a->ws_bytes, s);  // :42
+  if (rc != RELA_OK) return rc;
+  const int64_t* act_t = a->act + (size_t)first * a->R;
+  rc = rela_apex_td_from_q(a->R, a->A, a->K, a->q + QA, a->q + 2 * QA, a->q + 3 * QA, a->legal, act_t, a->out_r,
+                           a->out_b, a->gamma_n, nullptr, a->prio, s);
+  if (rc != RELA_OK) return rc;
+  // FFTransition rows (types.h:18-51): obs{s,eps,legal_move}, next_obs{...}, action{a}, reward, terminal, bootstrap
+  const void* rows[10] = {obs_t, obs_n, a->eps, a->eps, a->legal, a->legal, act_t, a->out_r, a->out_t, a->out_b};
+  rc = rela_replay_add(a->replay, a->R, rows, a->prio, nonblocking, s);
+  a->head = (a->head + 1) % H;  // pop_front :101-104
+  a->count -= 1;
+  if (rc == RELA_OK && inserted) *inserted = 1;
+  return rc;
+}

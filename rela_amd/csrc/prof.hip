@@ -89,3 +89,26 @@ extern "C" int rela_prof_summary_json(char* out, int64_t cap) {
   memcpy(out, s.c_str(), s.size() + 1);
   return RELA_OK;
 }
+
+extern "C" int rela_stream_create(void** out, int device) {
+  RELA_CHECK(out, RELA_EINVAL, "rela_stream_create: bad arguments");
+  DeviceGuard g(device);
+  RELA_CHECK(g.ok, RELA_ENODEV, "rela_stream_create: HIP device %d not available; there is no CPU path", device);
+  hipStream_t s = nullptr;
+  RELA_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *out = s;
+  return RELA_OK;
+}
+
+extern "C" void rela_stream_destroy(void* stream, int device) {
+  if (!stream) return;
+  DeviceGuard g(device);
+  (void)hipStreamSynchronize((hipStream_t)stream);
+  (void)hipStreamDestroy((hipStream_t)stream);
+}
+
+extern "C" int rela_stream_synchronize(void* stream, int device) {
+  DeviceGuard g(device);
+  RELA_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return RELA_OK;
+}

@@ -54,97 +54,74 @@ class FFNetHandle:
         self.close()
 
 
+class _DevMem:
+    """Exposes a raw device allocation owned by the C library through __cuda_array_interface__."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def dev_view(ptr, shape, dtype, device):
+    typestr = {torch.uint8: "|u1", torch.float32: "<f4", torch.int64: "<i8"}[dtype]
+    return torch.as_tensor(_DevMem(ptr, shape, typestr), device=device)
+
+
 class ApexActorEngine:
+    """Thin Python handle on the native actor shard (rela_apex_actor_*, csrc/actor.hip)."""
+
     def __init__(self, rows, group_rows, num_action, multi_step, gamma, replay, eps, device="cuda:0", seed=1):
-        assert rows % group_rows == 0
         self.R, self.K, self.A, self.n = rows, group_rows, num_action, multi_step
-        self.gamma = float(gamma)
-        self.gamma_n = float(torch.tensor(self.gamma ** multi_step, dtype=torch.float32))
         self.replay = replay
         self.device = torch.device(device)
-        self.seed = seed
+        h = C.c_void_p()
+        capi.check(capi.lib.rela_apex_actor_create(C.byref(h), rows, group_rows, num_action, multi_step, gamma,
+                                                   replay.h if replay is not None else None, seed,
+                                                   self.device.index or 0), "rela_apex_actor_create")
+        self.h = h
         dev = self.device
-        H = multi_step + 1
-        self.obs_hist = torch.zeros((H, rows, 4, 84, 84), dtype=torch.uint8, device=dev)
-        self.act_hist = torch.zeros((H, rows), dtype=torch.int64, device=dev)
-        self.rew_hist = torch.zeros((H, rows), dtype=torch.float32, device=dev)
-        self.term_hist = torch.zeros((H, rows), dtype=torch.uint8, device=dev)
-        self.eps = torch.as_tensor(eps, dtype=torch.float32, device=dev).reshape(rows, 1).contiguous()
-        self.legal = torch.ones((rows, num_action), dtype=torch.float32, device=dev)
-        self.q = torch.empty((4, rows, num_action), dtype=torch.float32, device=dev)
-        self.out_r = torch.empty(rows, dtype=torch.float32, device=dev)
-        self.out_b = torch.empty(rows, dtype=torch.float32, device=dev)
-        self.out_t = torch.empty(rows, dtype=torch.uint8, device=dev)
-        self.prio = torch.empty(rows, dtype=torch.float32, device=dev)
-        self.ws_bytes = 0
-        self.ws = None
-        self.count = 0      # entries currently in the history (<= n+1)
-        self.head = 0       # ring row of the oldest entry
-        self.num_act = 0
-        self.act_calls = 0
+        base = capi.lib.rela_apex_actor_obs_slot(h)  # head = count = 0 -> slot 0 = base of the history
+        self.obs_hist = dev_view(base, (multi_step + 1, rows, 4, 84, 84), torch.uint8, dev)
+        self.eps = dev_view(capi.lib.rela_apex_actor_eps_dev(h), (rows, 1), torch.float32, dev)
+        self.legal = dev_view(capi.lib.rela_apex_actor_legal_dev(h), (rows, num_action), torch.float32, dev)
+        self.q = dev_view(capi.lib.rela_apex_actor_last_q_dev(h), (4, rows, num_action), torch.float32, dev)
+        self.prio = dev_view(capi.lib.rela_apex_actor_last_priority_dev(h), (rows,), torch.float32, dev)
+        self.eps.copy_(torch.as_tensor(eps, dtype=torch.float32).reshape(rows, 1))
+        self._slot = 0
 
-    # -- plumbing -----------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib.rela_apex_actor_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _forward(self, net, obs, q_out):
-        if self.ws is None:
-            self.ws_bytes = capi.lib.rela_ffnet_workspace_bytes(net.h, self.R)
-            self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
-        capi.check(capi.lib.rela_ffnet_forward(net.h, self.R, C.c_void_p(obs.data_ptr()),
-                                               C.c_void_p(self.legal.data_ptr()), C.c_void_p(q_out.data_ptr()),
-                                               C.c_void_p(self.ws.data_ptr()), self.ws_bytes, self._stream()),
-                   "rela_ffnet_forward")
+    @property
+    def num_act(self):
+        return capi.lib.rela_apex_actor_num_act(self.h)
 
     def next_obs_slot(self):
         """The HBM slot the env layer writes the next observation batch into ([R,4,84,84] u8)."""
-        return self.obs_hist[(self.head + self.count) % (self.n + 1)]
+        ptr = capi.lib.rela_apex_actor_obs_slot(self.h)
+        return dev_view(ptr, (self.R, 4, 84, 84), torch.uint8, self.device)
 
-    # -- DQNActor::act ------------------------------------------------------------------
     def act(self, online):
-        """Consumes the observation already written to next_obs_slot(); returns actions (cuda i64[R])."""
-        slot = (self.head + self.count) % (self.n + 1)
-        self._forward(online, self.obs_hist[slot], self.q[0])
-        a = self.act_hist[slot]
-        capi.check(capi.lib.rela_apex_act_from_q(self.R, self.A, self.K, C.c_void_p(self.q[0].data_ptr()),
-                                                 C.c_void_p(self.legal.data_ptr()), C.c_void_p(self.eps.data_ptr()),
-                                                 self.seed, self.act_calls * self.R, C.c_void_p(a.data_ptr()),
-                                                 self._stream()), "rela_apex_act_from_q")
-        self.act_calls += 1
-        self.num_act += self.R
-        self._cur = slot
-        return a
+        """DQNActor::act on the observation already written to next_obs_slot(); cuda i64[R]."""
+        out = C.c_void_p()
+        capi.check(capi.lib.rela_apex_actor_act(self.h, online.h, None, None, None, None, C.byref(out), self._stream()),
+                   "rela_apex_actor_act")
+        return dev_view(out.value, (self.R,), torch.int64, self.device)
 
-    # -- setRewardAndTerminal + postStep --------------------------------------------------
     def post_step(self, reward, terminal, online, target, nonblocking=False):
-        """reward f32[R], terminal u8/bool[R] on the device.  Returns True if a block was inserted."""
-        self.rew_hist[self._cur].copy_(reward)
-        self.term_hist[self._cur].copy_(terminal)
-        self.count += 1
-        if self.count < self.n + 1:
-            return False
-        H = self.n + 1
-        first, last = self.head, (self.head + self.n) % H
-        s = self._stream()
-        capi.check(capi.lib.rela_nstep_return(self.n, self.R, self.gamma, first, C.c_void_p(self.rew_hist.data_ptr()),
-                                              C.c_void_p(self.term_hist.data_ptr()), C.c_void_p(self.out_r.data_ptr()),
-                                              C.c_void_p(self.out_b.data_ptr()), C.c_void_p(self.out_t.data_ptr()), s),
-                   "rela_nstep_return")
-        obs_t, obs_n = self.obs_hist[first], self.obs_hist[last]
-        self._forward(online, obs_t, self.q[1])   # online_net(obs)       apex.py:38
-        self._forward(online, obs_n, self.q[2])   # greedy_act(next_obs)  apex.py:41
-        self._forward(target, obs_n, self.q[3])   # target_net(next_obs)  apex.py:42
-        capi.check(capi.lib.rela_apex_td_from_q(self.R, self.A, self.K, C.c_void_p(self.q[1].data_ptr()),
-                                                C.c_void_p(self.q[2].data_ptr()), C.c_void_p(self.q[3].data_ptr()),
-                                                C.c_void_p(self.legal.data_ptr()),
-                                                C.c_void_p(self.act_hist[first].data_ptr()),
-                                                C.c_void_p(self.out_r.data_ptr()), C.c_void_p(self.out_b.data_ptr()),
-                                                C.c_float(self.gamma_n), None, C.c_void_p(self.prio.data_ptr()), s),
-                   "rela_apex_td_from_q")
-        ptrs = [obs_t.data_ptr(), obs_n.data_ptr(), self.eps.data_ptr(), self.eps.data_ptr(), self.legal.data_ptr(),
-                self.legal.data_ptr(), self.act_hist[first].data_ptr(), self.out_r.data_ptr(), self.out_t.data_ptr(),
-                self.out_b.data_ptr()]
-        rc = self.replay.add_rows(self.R, ptrs, self.prio, nonblocking=nonblocking)
-        self.head = (self.head + 1) % H  # pop_front, dqn_actor.h:101-104
-        self.count -= 1
-        return rc == 0
+        """setRewardAndTerminal + postStep; reward f32[R] / terminal u8[R] on the device."""
+        ins = C.c_int(0)
+        self._keep = (reward, terminal)
+        rc = capi.lib.rela_apex_actor_post_step(self.h, C.c_void_p(reward.data_ptr()), C.c_void_p(terminal.data_ptr()),
+                                                1, online.h, target.h, int(nonblocking), C.byref(ins), self._stream())
+        if rc != capi.EWOULDBLOCK:
+            capi.check(rc, "rela_apex_actor_post_step")
+        return bool(ins.value)

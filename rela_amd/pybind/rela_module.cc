@@ -1,0 +1,642 @@
+// rela_module.cc -- the pybind11 module `rela`: drop-in for the reference's rela/pybind.cc:19-108.
+//
+// Same 13 Python names, constructor signatures and method names; underneath, every hot-path
+// object is a handle on the C ABI of include/rela_amd.h (librela_amd.so, HIP/gfx950):
+//
+//   FFPrioritizedReplay  -> rela_replay_*        (device-resident ring, exact scan)
+//   DQNActor             -> rela_apex_actor_*    (device-resident history, MFMA forward)
+//   ModelLocker          -> rela_ffnet_*         (N versioned device weight sets + in-flight counts)
+//   Context / BasicThreadLoop / VectorEnv / Env  -> host C++ threads, as in the reference
+//
+// Threading and error behaviour follow SURVEY 8b: bound methods run with the GIL held, actor
+// threads never take it; protocol violations raise on the Python thread and terminate on actor
+// threads.  There is no CPU execution path: actors need a "cuda:N" ModelLocker.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+#include <torch/extension.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <thread>
+
+#include "rela/env.h"
+#include "rela/types.h"
+#include "rela_amd.h"
+
+namespace py = pybind11;
+using namespace rela;
+
+namespace {
+
+[[noreturn]] void fail(const std::string& where, int code) {
+  throw std::runtime_error(where + " failed (" + std::to_string(code) + "): " + rela_last_error());
+}
+inline void check(int code, const char* where) {
+  if (code != RELA_OK) fail(where, code);
+}
+
+int parseDevice(const std::string& device) {
+  if (device == "cpu") return -1;
+  if (device == "cuda") return 0;
+  if (device.rfind("cuda:", 0) == 0) return std::stoi(device.substr(5));
+  throw std::invalid_argument("unsupported device string: " + device);
+}
+
+// hipStream_t of torch's current stream on `device`, fetched through Python (GIL held).
+void* torchCurrentStream(int device) {
+  py::object s = py::module_::import("torch").attr("cuda").attr("current_stream")(device);
+  return reinterpret_cast<void*>(s.attr("cuda_stream").cast<uintptr_t>());
+}
+
+constexpr int64_t kObsBytes = 4 * 84 * 84;
+
+}  // namespace
+
+// =====================================================================================
+// VectorEnv (rela/env.h:29-102) -- persistent batch buffers
+// =====================================================================================
+namespace rela {
+
+void VectorEnv::storeRow(const TensorDict& obs, int row) {
+  const int K = (int)envs_.size();
+  for (const auto& kv : obs) {
+    auto it = batch_.find(kv.first);
+    if (it == batch_.end()) {
+      std::vector<int64_t> shape{K};
+      for (auto d : kv.second.sizes()) shape.push_back(d);
+      auto t = torch::zeros(shape, kv.second.options().device(torch::kCPU));
+      if (torch::cuda::is_available()) t = t.pin_memory();
+      it = batch_.emplace(kv.first, t).first;
+    }
+    auto dst = it->second[row];
+    const auto& src = kv.second;
+    if (src.is_contiguous() && src.device().is_cpu() && src.dtype() == dst.dtype() && src.numel() == dst.numel()) {
+      std::memcpy(dst.data_ptr(), src.data_ptr(), (size_t)src.nbytes());
+    } else {
+      dst.copy_(src);
+    }
+  }
+}
+
+TensorDict VectorEnv::reset(const TensorDict& previous) {
+  const bool first = previous.empty();
+  for (size_t i = 0; i < envs_.size(); ++i) {
+    if (first || envs_[i]->terminated()) storeRow(envs_[i]->reset(), (int)i);
+  }
+  return batch_;
+}
+
+std::tuple<TensorDict, torch::Tensor, torch::Tensor> VectorEnv::step(const TensorDict& action) {
+  const int K = (int)envs_.size();
+  if (!reward_.defined()) {
+    reward_ = torch::zeros({K}, torch::kFloat32);
+    terminal_ = torch::zeros({K}, torch::kBool);
+  }
+  float* r = reward_.data_ptr<float>();
+  bool* t = terminal_.data_ptr<bool>();
+  for (int i = 0; i < K; ++i) {
+    TensorDict a;
+    for (const auto& kv : action) a.emplace(kv.first, kv.second[i]);
+    TensorDict obs;
+    float reward;
+    bool terminal;
+    std::tie(obs, reward, terminal) = envs_[i]->step(a);
+    storeRow(obs, i);
+    r[i] = reward;
+    t[i] = terminal;
+  }
+  return std::make_tuple(batch_, reward_, terminal_);
+}
+
+bool VectorEnv::anyTerminated() const {
+  for (const auto& e : envs_)
+    if (e->terminated()) return true;
+  return false;
+}
+
+bool VectorEnv::allTerminated() const {
+  for (const auto& e : envs_)
+    if (!e->terminated()) return false;
+  return true;
+}
+
+// =====================================================================================
+// Actor interface (rela/actor.h:9-21)
+// =====================================================================================
+class Actor {
+ public:
+  virtual ~Actor() = default;
+  virtual TensorDict act(TensorDict& obs) = 0;
+  virtual void setRewardAndTerminal(torch::Tensor& r, torch::Tensor& t) = 0;
+  virtual void postStep() = 0;
+};
+
+// =====================================================================================
+// ModelLocker (rela/model_locker.h:11-65): N weight versions per act device, each an
+// (online, target) pair of rela_ffnet objects, with in-flight counts.  update_model waits until
+// the next slot is idle, refills it from pyModel.state_dict() and publishes it.
+// =====================================================================================
+class ModelLocker {
+ public:
+  struct Lease {
+    int id;
+    const rela_ffnet* online;
+    const rela_ffnet* target;
+  };
+
+  ModelLocker(std::vector<py::object> pyModels, const std::string& device)
+      : device(device), deviceIndex(parseDevice(device)), pyModels_(std::move(pyModels)) {
+    if (pyModels_.empty()) throw std::invalid_argument("ModelLocker needs at least one model");
+    const size_t n = pyModels_.size();
+    online_.assign(n, nullptr);
+    target_.assign(n, nullptr);
+    inFlight_.assign(n, 0);
+    if (deviceIndex >= 0) loadSlot(0, pyModels_[0]);
+  }
+
+  ~ModelLocker() {
+    for (auto* p : online_) rela_ffnet_destroy(p);
+    for (auto* p : target_) rela_ffnet_destroy(p);
+  }
+
+  void updateModel(py::object pyModel) {
+    int id;
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      id = (latest_ + 1) % (int)inFlight_.size();
+      cv_.wait(lk, [&] { return inFlight_[id] == 0; });  // model_locker.h:27-28
+    }
+    if (deviceIndex >= 0) {
+      loadSlot(id, pyModel);
+    } else {
+      pyModels_[id].attr("load_state_dict")(pyModel.attr("state_dict")());  // cpu locker: bookkeeping only
+    }
+    std::lock_guard<std::mutex> lk(m_);
+    latest_ = id;
+  }
+
+  Lease getModel() {
+    if (deviceIndex < 0)
+      throw std::runtime_error("ModelLocker('cpu'): this engine has no CPU actor path; use a cuda device");
+    std::lock_guard<std::mutex> lk(m_);
+    ++inFlight_[latest_];
+    return Lease{latest_, online_[latest_], target_[latest_]};
+  }
+
+  void releaseModel(int id) {
+    std::lock_guard<std::mutex> lk(m_);
+    if (--inFlight_[id] == 0) cv_.notify_all();
+  }
+
+  int numAction() const { return numAction_; }
+
+  const std::string device;
+  const int deviceIndex;
+
+ private:
+  static const char* const* keys() {
+    static const char* k[12] = {"net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias",
+                                "net.4.weight", "net.4.bias", "linear.0.weight", "linear.0.bias",
+                                "fc_v.weight",  "fc_v.bias",  "fc_a.weight",     "fc_a.bias"};
+    return k;
+  }
+
+  void loadNet(rela_ffnet*& net, py::dict& sd, const std::string& prefix) {
+    std::vector<torch::Tensor> keep;
+    const float* ptr[12];
+    for (int i = 0; i < 12; ++i) {
+      const std::string key = prefix + keys()[i];
+      if (!sd.contains(py::str(key)))
+        throw std::runtime_error("ModelLocker: state_dict has no '" + key +
+                                 "' (only AtariFFNet-shaped agents are supported on this path)");
+      auto t = sd[py::str(key)].cast<torch::Tensor>().detach();
+      t = t.to(torch::Device(torch::kCUDA, (c10::DeviceIndex)deviceIndex), torch::kFloat32).contiguous();
+      keep.push_back(t);
+      ptr[i] = t.data_ptr<float>();
+    }
+    const int A = (int)keep[10].size(0);
+    if (numAction_ == 0) numAction_ = A;
+    if (A != numAction_) throw std::runtime_error("ModelLocker: num_action changed between updates");
+    if (!net) check(rela_ffnet_create(&net, A, deviceIndex), "rela_ffnet_create");
+    rela_ffnet_params p{ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5], ptr[6], ptr[7], ptr[8], ptr[9], ptr[10], ptr[11]};
+    void* stream = torchCurrentStream(deviceIndex);
+    check(rela_ffnet_load(net, &p, 1, stream), "rela_ffnet_load");
+    // the packing kernels read `keep` on torch's stream: finish them before the tensors die
+    py::module_::import("torch").attr("cuda").attr("current_stream")(deviceIndex).attr("synchronize")();
+  }
+
+  void loadSlot(int id, py::object& pyModel) {
+    // Leases are released when an actor has QUEUED its kernels; drain the device so nothing that
+    // still reads this slot's old weights is in flight (the reference's model call is synchronous).
+    py::module_::import("torch").attr("cuda").attr("synchronize")(deviceIndex);
+    py::dict sd = pyModel.attr("state_dict")();
+    loadNet(online_[id], sd, "online_net.");
+    loadNet(target_[id], sd, "target_net.");
+  }
+
+  std::vector<py::object> pyModels_;
+  std::vector<rela_ffnet*> online_, target_;
+  std::vector<int> inFlight_;
+  int latest_ = 0;
+  int numAction_ = 0;
+  std::mutex m_;
+  std::condition_variable cv_;
+};
+
+// =====================================================================================
+// FFPrioritizedReplay (rela/prioritized_replay.h:173-348 as bound in pybind.cc:37-47)
+// =====================================================================================
+class FFPrioritizedReplay {
+ public:
+  FFPrioritizedReplay(int capacity, int seed, float alpha, float beta, int prefetch)
+      : capacity_(capacity), seed_(seed), alpha_(alpha), beta_(beta), prefetch_(prefetch) {}
+
+  ~FFPrioritizedReplay() { rela_replay_destroy(h_); }
+
+  // created lazily by the first actor that knows the device and the action count
+  rela_replay* handle(int device, int numAction) {
+    std::lock_guard<std::mutex> lk(m_);
+    if (!h_) {
+      check(rela_replay_create(&h_, capacity_, seed_, alpha_, beta_, prefetch_, device), "rela_replay_create");
+      const int64_t A = numAction;
+      const int64_t rb[10] = {kObsBytes, kObsBytes, 4, 4, 4 * A, 4 * A, 8, 4, 1, 4};
+      check(rela_replay_set_schema(h_, 10, rb), "rela_replay_set_schema");
+      device_ = device;
+      numAction_ = numAction;
+    } else if (device != device_ || numAction != numAction_) {
+      throw std::runtime_error(
+          "FFPrioritizedReplay: one replay partition lives on one GPU; actors on another device need their own "
+          "partition (SURVEY 8e)");
+    }
+    return h_;
+  }
+
+  int size() const { return h_ ? rela_replay_size(h_) : 0; }
+  int numAdd() const { return h_ ? (int)rela_replay_num_add(h_) : 0; }
+
+  std::tuple<FFTransition, torch::Tensor> sample(int batchsize, const std::string& device) {
+    if (!h_) throw std::runtime_error("FFPrioritizedReplay.sample: the replay is empty");
+    const auto dev = torch::Device(torch::kCUDA, (c10::DeviceIndex)device_);
+    auto u8 = torch::TensorOptions().dtype(torch::kUInt8).device(dev);
+    auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
+    const int64_t B = batchsize, A = numAction_;
+    FFTransition b;
+    b.obs["s"] = torch::empty({B, 4, 84, 84}, u8);
+    b.nextObs["s"] = torch::empty({B, 4, 84, 84}, u8);
+    b.obs["eps"] = torch::empty({B, 1}, f32);
+    b.nextObs["eps"] = torch::empty({B, 1}, f32);
+    b.obs["legal_move"] = torch::empty({B, A}, f32);
+    b.nextObs["legal_move"] = torch::empty({B, A}, f32);
+    b.action["a"] = torch::empty({B}, torch::TensorOptions().dtype(torch::kInt64).device(dev));
+    b.reward = torch::empty({B}, f32);
+    b.terminal = torch::empty({B}, torch::TensorOptions().dtype(torch::kBool).device(dev));
+    b.bootstrap = torch::empty({B}, f32);
+    auto weight = torch::empty({B}, f32);
+    void* rows[10] = {b.obs["s"].data_ptr(),          b.nextObs["s"].data_ptr(),          b.obs["eps"].data_ptr(),
+                      b.nextObs["eps"].data_ptr(),    b.obs["legal_move"].data_ptr(),     b.nextObs["legal_move"].data_ptr(),
+                      b.action["a"].data_ptr(),       b.reward.data_ptr(),                b.terminal.data_ptr(),
+                      b.bootstrap.data_ptr()};
+    check(rela_replay_sample(h_, batchsize, rows, weight.data_ptr<float>(), torchCurrentStream(device_)),
+          "FFPrioritizedReplay.sample");
+    const int want = parseDevice(device);
+    if (want != device_) {  // learner on another GPU (or the cpu): move the batch, types.cc:34-43
+      const auto target = want < 0 ? torch::Device(torch::kCPU) : torch::Device(torch::kCUDA, (c10::DeviceIndex)want);
+      auto mv = [&](torch::Tensor& t) { t = t.to(target); };
+      for (auto* d : {&b.obs, &b.action, &b.nextObs})
+        for (auto& kv : *d) mv(kv.second);
+      mv(b.reward);
+      mv(b.terminal);
+      mv(b.bootstrap);
+      mv(weight);
+    }
+    return std::make_tuple(std::move(b), weight);
+  }
+
+  void updatePriority(const torch::Tensor& priority) {
+    if (!h_) throw std::runtime_error("FFPrioritizedReplay.update_priority: nothing was sampled");
+    if (priority.dim() != 1) throw std::invalid_argument("update_priority expects a 1-D tensor");  // :236
+    auto p = priority.detach().to(torch::kFloat32).contiguous();
+    if (p.is_cuda()) {
+      if (p.device().index() != device_) p = p.to(torch::Device(torch::kCUDA, (c10::DeviceIndex)device_));
+      check(rela_replay_update_priority(h_, (int)p.numel(), p.data_ptr<float>(), 1, torchCurrentStream(device_)),
+            "FFPrioritizedReplay.update_priority");
+      keep_ = p;  // consumed asynchronously on the replay's stream
+    } else {
+      check(rela_replay_update_priority(h_, (int)p.numel(), p.data_ptr<float>(), 0, nullptr),
+            "FFPrioritizedReplay.update_priority");
+    }
+  }
+
+ private:
+  const int capacity_, seed_;
+  const float alpha_, beta_;
+  const int prefetch_;
+  std::mutex m_;
+  rela_replay* h_ = nullptr;
+  int device_ = -1, numAction_ = 0;
+  torch::Tensor keep_;
+};
+
+// R2D2 rows of SURVEY 8a (T2, A4, A5) are not built yet: the names exist so that scripts which
+// only reference them import cleanly, and they fail loudly when used.
+class RNNPrioritizedReplay {
+ public:
+  RNNPrioritizedReplay(int, int, float, float, int) {
+    throw std::runtime_error("RNNPrioritizedReplay: the R2D2 path is not implemented in this build yet");
+  }
+  int size() const { return 0; }
+  int numAdd() const { return 0; }
+};
+
+// =====================================================================================
+// DQNActor (rela/dqn_actor.h:126-211)
+// =====================================================================================
+class DQNActor : public Actor {
+ public:
+  DQNActor(std::shared_ptr<ModelLocker> locker, int multiStep, int batchsize, float gamma,
+           std::shared_ptr<FFPrioritizedReplay> replay)
+      : batchsize_(batchsize), multiStep_(multiStep), gamma_(gamma), locker_(std::move(locker)),
+        replay_(std::move(replay)) {}
+
+  // evaluation mode: one env, no replay (dqn_actor.h:141-147)
+  explicit DQNActor(std::shared_ptr<ModelLocker> locker)
+      : batchsize_(1), multiStep_(1), gamma_(1.f), locker_(std::move(locker)), replay_(nullptr) {}
+
+  ~DQNActor() override {
+    rela_apex_actor_destroy(h_);
+    if (stream_) rela_stream_destroy(stream_, locker_->deviceIndex);
+  }
+
+  int numAct() const { return h_ ? (int)rela_apex_actor_num_act(h_) : 0; }
+
+  TensorDict act(TensorDict& obs) override {
+    const auto& s = obs.at("s");
+    const auto& legal = obs.at("legal_move");
+    const auto& eps = obs.at("eps");
+    if (s.size(0) != batchsize_ || s.numel() != (int64_t)batchsize_ * kObsBytes || s.dtype() != torch::kUInt8)
+      throw std::runtime_error("DQNActor.act: obs['s'] must be uint8 [batchsize,4,84,84]");
+    const int A = (int)legal.size(1);
+    if (!h_) {
+      static std::atomic<uint64_t> counter{0};
+      rela_replay* rep = replay_ ? replay_->handle(locker_->deviceIndex, A) : nullptr;
+      check(rela_stream_create(&stream_, locker_->deviceIndex), "rela_stream_create");
+      check(rela_apex_actor_create(&h_, batchsize_, batchsize_, A, multiStep_, gamma_, rep,
+                                   0x9E3779B97F4A7C15ull * (++counter), locker_->deviceIndex),
+            "rela_apex_actor_create");
+      action_ = torch::zeros({batchsize_}, torch::kInt64);
+      if (torch::cuda::is_available()) action_ = action_.pin_memory();
+      epsHost_ = torch::zeros({batchsize_}, torch::kFloat32);
+      legalHost_ = torch::zeros({batchsize_, A}, torch::kFloat32);
+    }
+    // per-env constants: upload only when they changed
+    const float* epsPtr = nullptr;
+    const float* legalPtr = nullptr;
+    auto e = eps.reshape({batchsize_}).to(torch::kFloat32).contiguous();
+    if (!constsValid_ || std::memcmp(e.data_ptr(), epsHost_.data_ptr(), e.nbytes()) != 0) {
+      epsHost_.copy_(e);
+      epsPtr = epsHost_.data_ptr<float>();
+    }
+    auto l = legal.to(torch::kFloat32).contiguous();
+    if (!constsValid_ || std::memcmp(l.data_ptr(), legalHost_.data_ptr(), l.nbytes()) != 0) {
+      legalHost_.copy_(l);
+      legalPtr = legalHost_.data_ptr<float>();
+    }
+    constsValid_ = true;
+    auto sc = s.contiguous();
+    auto lease = locker_->getModel();
+    const int rc = rela_apex_actor_act(h_, lease.online, sc.data_ptr<uint8_t>(), epsPtr, legalPtr,
+                                       action_.data_ptr<int64_t>(), nullptr, stream_);
+    locker_->releaseModel(lease.id);
+    check(rc, "DQNActor.act");
+    return TensorDict{{"a", action_}};
+  }
+
+  void setRewardAndTerminal(torch::Tensor& r, torch::Tensor& t) override {
+    if (!replay_) throw std::runtime_error("DQNActor: evaluation actor has no replay");  // :175
+    reward_ = r.to(torch::kFloat32).contiguous();
+    terminal_ = t.to(torch::kBool).contiguous();
+  }
+
+  void postStep() override {
+    if (!replay_) throw std::runtime_error("DQNActor: evaluation actor has no replay");  // :182
+    auto lease = locker_->getModel();
+    const int rc = rela_apex_actor_post_step(h_, reward_.data_ptr<float>(),
+                                             reinterpret_cast<const uint8_t*>(terminal_.data_ptr<bool>()), 0,
+                                             lease.online, lease.target, 0, nullptr, stream_);
+    locker_->releaseModel(lease.id);
+    check(rc, "DQNActor.postStep");
+  }
+
+ private:
+  const int batchsize_, multiStep_;
+  const float gamma_;
+  std::shared_ptr<ModelLocker> locker_;
+  std::shared_ptr<FFPrioritizedReplay> replay_;
+  rela_apex_actor* h_ = nullptr;
+  void* stream_ = nullptr;  // this actor thread's private HIP stream
+  torch::Tensor action_, epsHost_, legalHost_, reward_, terminal_;
+  bool constsValid_ = false;
+};
+
+class R2D2Actor : public Actor {
+ public:
+  R2D2Actor(std::shared_ptr<ModelLocker>, int, int, float, int, int, std::shared_ptr<RNNPrioritizedReplay>) {
+    throw std::runtime_error("R2D2Actor: the R2D2 path is not implemented in this build yet");
+  }
+  explicit R2D2Actor(std::shared_ptr<ModelLocker>) {
+    throw std::runtime_error("R2D2Actor: the R2D2 path is not implemented in this build yet");
+  }
+  int numAct() const { return 0; }
+  TensorDict act(TensorDict&) override { return {}; }
+  void setRewardAndTerminal(torch::Tensor&, torch::Tensor&) override {}
+  void postStep() override {}
+};
+
+// =====================================================================================
+// ThreadLoop / BasicThreadLoop / Context (rela/thread_loop.h:12-111, rela/context.h:14-76)
+// =====================================================================================
+class ThreadLoop {
+ public:
+  ThreadLoop() = default;
+  ThreadLoop(const ThreadLoop&) = delete;
+  ThreadLoop& operator=(const ThreadLoop&) = delete;
+  virtual ~ThreadLoop() = default;
+
+  virtual void terminate() { stop_.store(true); }
+  virtual void pause() {
+    std::lock_guard<std::mutex> lk(m_);
+    paused_ = true;
+  }
+  virtual void resume() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      paused_ = false;
+    }
+    cv_.notify_all();
+  }
+  virtual bool terminated() { return stop_.load(); }
+  virtual void mainLoop() = 0;
+
+ protected:
+  // blocks while paused; like the reference, terminate() alone does not wake a paused loop
+  void pauseGate() {
+    std::unique_lock<std::mutex> lk(m_);
+    cv_.wait(lk, [this] { return !paused_; });
+  }
+
+ private:
+  std::atomic<bool> stop_{false};
+  std::mutex m_;
+  std::condition_variable cv_;
+  bool paused_ = false;
+};
+
+class BasicThreadLoop : public ThreadLoop {
+ public:
+  BasicThreadLoop(std::shared_ptr<Actor> actor, std::shared_ptr<VectorEnv> env, bool eval)
+      : actor_(std::move(actor)), env_(std::move(env)), eval_(eval) {
+    if (eval_ && env_->size() != 1) throw std::invalid_argument("eval thread loops drive exactly one env");
+  }
+
+  void mainLoop() final {
+    TensorDict obs;
+    torch::Tensor r, t;
+    while (!terminated()) {
+      obs = env_->reset(obs);
+      while (!env_->anyTerminated() && !terminated()) {
+        pauseGate();
+        TensorDict action = actor_->act(obs);
+        std::tie(obs, r, t) = env_->step(action);
+        if (eval_) continue;
+        actor_->setRewardAndTerminal(r, t);
+        actor_->postStep();
+      }
+      if (eval_) break;  // one episode
+    }
+  }
+
+ private:
+  std::shared_ptr<Actor> actor_;
+  std::shared_ptr<VectorEnv> env_;
+  const bool eval_;
+};
+
+class Context {
+ public:
+  Context() = default;
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+
+  ~Context() {
+    for (auto& l : loops_) l->terminate();
+    for (auto& l : loops_) l->resume();  // unlike the reference, never leave a paused thread unjoinable
+    for (auto& th : threads_)
+      if (th.joinable()) th.join();
+  }
+
+  int pushThreadLoop(std::shared_ptr<ThreadLoop> loop) {
+    if (started_) throw std::runtime_error("Context: push_env_thread after start");
+    loops_.push_back(std::move(loop));
+    return (int)loops_.size();
+  }
+
+  void start() {
+    started_ = true;
+    for (size_t i = 0; i < loops_.size(); ++i) {
+      threads_.emplace_back([this, i] {
+        loops_[i]->mainLoop();
+        ++done_;
+      });
+    }
+  }
+  void pause() {
+    for (auto& l : loops_) l->pause();
+  }
+  void resume() {
+    for (auto& l : loops_) l->resume();
+  }
+  void terminate() {
+    for (auto& l : loops_) l->terminate();
+  }
+  bool terminated() { return done_.load() == (int)loops_.size(); }
+
+ private:
+  bool started_ = false;
+  std::atomic<int> done_{0};
+  std::vector<std::shared_ptr<ThreadLoop>> loops_;
+  std::vector<std::thread> threads_;
+};
+
+}  // namespace rela
+
+PYBIND11_MODULE(rela, m) {
+  m.doc() = "MI355X-native drop-in for facebookresearch/rela's `rela` module (C ABI: include/rela_amd.h)";
+
+  py::class_<FFTransition, std::shared_ptr<FFTransition>>(m, "FFTransition")
+      .def_readwrite("obs", &FFTransition::obs)
+      .def_readwrite("action", &FFTransition::action)
+      .def_readwrite("reward", &FFTransition::reward)
+      .def_readwrite("terminal", &FFTransition::terminal)
+      .def_readwrite("bootstrap", &FFTransition::bootstrap)
+      .def_readwrite("next_obs", &FFTransition::nextObs);
+
+  py::class_<RNNTransition, std::shared_ptr<RNNTransition>>(m, "RNNTransition")
+      .def_readwrite("obs", &RNNTransition::obs)
+      .def_readwrite("h0", &RNNTransition::h0)
+      .def_readwrite("action", &RNNTransition::action)
+      .def_readwrite("reward", &RNNTransition::reward)
+      .def_readwrite("terminal", &RNNTransition::terminal)
+      .def_readwrite("bootstrap", &RNNTransition::bootstrap)
+      .def_readwrite("seq_len", &RNNTransition::seqLen);
+
+  py::class_<FFPrioritizedReplay, std::shared_ptr<FFPrioritizedReplay>>(m, "FFPrioritizedReplay")
+      .def(py::init<int, int, float, float, int>())  // capacity, seed, alpha, beta, prefetch
+      .def("size", &FFPrioritizedReplay::size)
+      .def("num_add", &FFPrioritizedReplay::numAdd)
+      .def("sample", &FFPrioritizedReplay::sample)
+      .def("update_priority", &FFPrioritizedReplay::updatePriority);
+
+  py::class_<RNNPrioritizedReplay, std::shared_ptr<RNNPrioritizedReplay>>(m, "RNNPrioritizedReplay")
+      .def(py::init<int, int, float, float, int>())
+      .def("size", &RNNPrioritizedReplay::size)
+      .def("num_add", &RNNPrioritizedReplay::numAdd);
+
+  py::class_<Env, std::shared_ptr<Env>>(m, "Env");
+
+  py::class_<VectorEnv, std::shared_ptr<VectorEnv>>(m, "VectorEnv")
+      .def(py::init<>())
+      .def("append", &VectorEnv::append, py::keep_alive<1, 2>());
+
+  py::class_<ThreadLoop, std::shared_ptr<ThreadLoop>>(m, "ThreadLoop");
+
+  py::class_<BasicThreadLoop, ThreadLoop, std::shared_ptr<BasicThreadLoop>>(m, "BasicThreadLoop")
+      .def(py::init<std::shared_ptr<Actor>, std::shared_ptr<VectorEnv>, bool>());
+
+  py::class_<Context>(m, "Context")
+      .def(py::init<>())
+      .def("push_env_thread", &Context::pushThreadLoop, py::keep_alive<1, 2>())
+      .def("start", &Context::start)
+      .def("pause", &Context::pause)
+      .def("resume", &Context::resume)
+      .def("terminate", &Context::terminate)
+      .def("terminated", &Context::terminated);
+
+  py::class_<ModelLocker, std::shared_ptr<ModelLocker>>(m, "ModelLocker")
+      .def(py::init<std::vector<py::object>, const std::string&>())
+      .def("update_model", &ModelLocker::updateModel);
+
+  py::class_<Actor, std::shared_ptr<Actor>>(m, "Actor");
+
+  py::class_<DQNActor, Actor, std::shared_ptr<DQNActor>>(m, "DQNActor")
+      .def(py::init<std::shared_ptr<ModelLocker>, int, int, float, std::shared_ptr<FFPrioritizedReplay>>())
+      .def(py::init<std::shared_ptr<ModelLocker>>())
+      .def("num_act", &DQNActor::numAct);
+
+  py::class_<R2D2Actor, Actor, std::shared_ptr<R2D2Actor>>(m, "R2D2Actor")
+      .def(py::init<std::shared_ptr<ModelLocker>, int, int, float, int, int, std::shared_ptr<RNNPrioritizedReplay>>())
+      .def(py::init<std::shared_ptr<ModelLocker>>())
+      .def("num_act", &R2D2Actor::numAct);
+}

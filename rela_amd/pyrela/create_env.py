@@ -1,0 +1,43 @@
+"""Builds T threads x K synthetic envs wired to actors (counterpart of pyrela/create_atari.py:64-98).
+
+Real ALE is unreachable in this pipeline (no submodule, no ROMs), so `game` only selects the
+action count; everything else -- per-env seed = seed + thread*K + game (create_atari.py:84),
+per-env eps from the Ape-X schedule, VectorEnv -> BasicThreadLoop -> Context -- is as upstream.
+"""
+import os
+import sys
+
+PYBIND_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pybind")
+if PYBIND_DIR not in sys.path:
+    sys.path.insert(0, PYBIND_DIR)
+
+import torch  # noqa: E402,F401  (must precede the native modules: one HIP runtime per process)
+import rela  # noqa: E402
+import synth_atari  # noqa: E402
+
+NUM_ACTION = 18  # ALE's legal action set size, what atari_env.h:78-80 reports for every game
+
+
+def get_num_action(game_name):
+    return NUM_ACTION
+
+
+def create_game(seed, eps, episode_len):
+    return synth_atari.SyntheticAtariEnv(seed, eps, NUM_ACTION, episode_len)
+
+
+def create_train_env(seed, eps, episode_len, num_thread, num_game_per_thread, actor_creator):
+    context = rela.Context()
+    games, actors = [], []
+    for t in range(num_thread):
+        vec = rela.VectorEnv()
+        for g in range(num_game_per_thread):
+            idx = t * num_game_per_thread + g
+            game = create_game(seed + idx, eps[idx], episode_len)
+            games.append(game)
+            vec.append(game)
+        actor = actor_creator(t)
+        actors.append(actor)
+        context.push_env_thread(rela.BasicThreadLoop(actor, vec, False))
+    print("Finished creating environments with %d games" % len(games))
+    return context, games, actors

@@ -1,0 +1,79 @@
+"""Deterministic end-to-end drive of the `rela` surface, shared by the golden generator (real
+reference, CPU TorchScript actor) and the GPU test (this repo's module).
+
+One actor thread with K synthetic envs (eps = 0) fills a tiny replay until back-pressure parks
+it (ring full, prioritized_replay.h:47); the main thread then samples, lets the parked block
+land, and only then updates priorities -- so every replay mutation is totally ordered and the
+run is reproducible.  Each round records the sampled batch.
+"""
+import time
+
+import numpy as np
+import torch
+
+CFG = dict(K=4, multi_step=3, gamma=0.997, capacity=16, alpha=1.0, beta=1.0, seed=5, episode_len=7,
+           num_action=18, rounds=6, batch=8, online_seed=1001, target_seed=2002, env_seed=900)
+
+
+def _wait(cond, what, timeout=120.0):
+    t0 = time.time()
+    while not cond():
+        if time.time() - t0 > timeout:
+            raise TimeoutError(what)
+        time.sleep(0.002)
+
+
+def run_lockstep(rela, synth_atari, agent, act_device, sample_device, cfg=CFG):
+    """agent: an ApexAgent-shaped module whose state_dict carries online_net.* / target_net.*."""
+    ring = int(1.25 * cfg["capacity"])
+    replay = rela.FFPrioritizedReplay(cfg["capacity"], cfg["seed"], cfg["alpha"], cfg["beta"], 0)
+    locker = rela.ModelLocker([agent], act_device)
+    actor = rela.DQNActor(locker, cfg["multi_step"], cfg["K"], cfg["gamma"], replay)
+    vec = rela.VectorEnv()
+    games = []
+    for g in range(cfg["K"]):
+        game = synth_atari.SyntheticAtariEnv(cfg["env_seed"] + g, 0.0, cfg["num_action"], cfg["episode_len"])
+        games.append(game)
+        vec.append(game)
+    ctx = rela.Context()
+    ctx.push_env_thread(rela.BasicThreadLoop(actor, vec, False))
+    ctx.start()
+    rounds = []
+    for r in range(cfg["rounds"]):
+        _wait(lambda: replay.size() == ring, "actor never filled the ring")
+        batch, w = replay.sample(cfg["batch"], sample_device)
+        _wait(lambda: replay.size() == ring, "parked block never landed")  # append happens-before update
+        s = batch.obs["s"].cpu().numpy().astype(np.int64)
+        ns = batch.next_obs["s"].cpu().numpy().astype(np.int64)
+        rounds.append(dict(
+            s_sum=s.reshape(len(s), -1).sum(1).tolist(), s_head=s.reshape(len(s), -1)[:, :4].tolist(),
+            next_s_sum=ns.reshape(len(ns), -1).sum(1).tolist(),
+            a=batch.action["a"].cpu().tolist(), reward=batch.reward.cpu().tolist(),
+            terminal=[int(x) for x in batch.terminal.cpu().tolist()], bootstrap=batch.bootstrap.cpu().tolist(),
+            eps=batch.obs["eps"].cpu().reshape(-1).tolist(),
+            legal_sum=batch.obs["legal_move"].cpu().sum(1).tolist(),
+            weight=w.cpu().double().tolist(), num_add=replay.num_add()))
+        newp = torch.linspace(0.5, 2.0, cfg["batch"]) * (1 + 0.25 * r)
+        replay.update_priority(newp)
+    ctx.terminate()
+    ctx.resume()
+    t0 = time.time()
+    while not ctx.terminated():  # the actor may be parked on the full ring: drain until it exits
+        if replay.size() >= cfg["batch"]:
+            batch, w = replay.sample(cfg["batch"], sample_device)
+            replay.update_priority(torch.ones(cfg["batch"]))
+        time.sleep(0.005)
+        if time.time() - t0 > 120:
+            raise TimeoutError("context did not terminate")
+    return rounds
+
+
+def load_agent_params(agent, cfg=CFG):
+    from synth import synth_params
+
+    sd = {}
+    for prefix, seed in (("online_net.", cfg["online_seed"]), ("target_net.", cfg["target_seed"])):
+        for k, v in synth_params(cfg["num_action"], seed).items():
+            sd[prefix + k] = torch.from_numpy(v)
+    agent.load_state_dict(sd)
+    return agent

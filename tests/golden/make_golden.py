@@ -181,8 +181,34 @@ def ffnet_cases():
              priority=prio.numpy().astype(np.float64).tolist(), td_err=err.numpy().astype(np.float64).tolist())
 
 
+def e2e_cases():
+    """The REAL reference end to end: its pybind module (oracle/_ref/rela*.so), its TorchScript
+    ApexAgent on the CPU, our synthetic env compiled against its rela/env.h."""
+    code = r"""
+import json, sys
+sys.dont_write_bytecode = True
+sys.path[:0] = [%r, %r, "/root/reference/pyrela"]
+import torch
+torch.set_num_threads(1)
+import rela, synth_atari
+assert "_ref" in rela.__file__
+from apex import ApexAgent
+from net import AtariFFNet
+from e2e_lockstep import CFG, run_lockstep, load_agent_params
+agent = load_agent_params(ApexAgent(lambda: AtariFFNet(CFG["num_action"]), CFG["multi_step"], CFG["gamma"]))
+rounds = run_lockstep(rela, synth_atari, agent, "cpu", "cpu")
+print("RESULT" + json.dumps(rounds))
+""" % (REFBIN, os.path.dirname(HERE))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1]
+    from e2e_lockstep import CFG
+    save("e2e_lockstep_apex", [], json.loads(line[len("RESULT"):]), cfg=CFG)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["replay", "nstep", "ffnet"]
+    which = sys.argv[1:] or ["replay", "nstep", "ffnet", "e2e"]
+    if "e2e" in which:
+        e2e_cases()
     if "replay" in which:
         replay_cases()
     if "nstep" in which:

@@ -1,0 +1,133 @@
+"""CPU-side checks of the pybind module `rela` (drop-in surface of rela/pybind.cc:19-108) and of
+the second native module `synth_atari` that plugs a C++ Env into it.  No GPU needed: only
+host logic (class surface, Env ABI across modules, VectorEnv batching, Context lifecycle,
+ModelLocker('cpu') bookkeeping, loud failures for the not-yet-built R2D2 names)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from rela_amd import build
+
+    build.build_native()
+    build.build_pybind()
+    sys.path.insert(0, os.path.join(ROOT, "rela_amd", "pybind"))
+    import rela
+    import synth_atari
+
+    assert rela.__file__.endswith(".so") and "rela_amd/pybind" in rela.__file__
+    return rela, synth_atari
+
+
+def test_surface_matches_reference_binding(mods):
+    rela, _ = mods
+    names = {"FFTransition", "RNNTransition", "FFPrioritizedReplay", "RNNPrioritizedReplay", "Env", "VectorEnv",
+             "ThreadLoop", "BasicThreadLoop", "Context", "ModelLocker", "Actor", "DQNActor", "R2D2Actor"}
+    assert names <= set(dir(rela))  # the 13 classes of rela/pybind.cc
+    for attr in ("obs", "action", "reward", "terminal", "bootstrap", "next_obs"):
+        assert hasattr(rela.FFTransition, attr)
+    for attr in ("obs", "h0", "action", "reward", "terminal", "bootstrap", "seq_len"):
+        assert hasattr(rela.RNNTransition, attr)
+    for m in ("size", "num_add", "sample", "update_priority"):
+        assert hasattr(rela.FFPrioritizedReplay, m)
+    assert not hasattr(rela.FFPrioritizedReplay, "add")  # add is C++-only upstream too (pybind.cc:37-47)
+    for m in ("push_env_thread", "start", "pause", "resume", "terminate", "terminated"):
+        assert hasattr(rela.Context, m)
+    with pytest.raises(TypeError):
+        rela.Env()  # opaque base, no constructor (pybind.cc:61)
+    r = rela.FFPrioritizedReplay(16, 1, 0.6, 0.4, 0)
+    assert r.size() == 0 and r.num_add() == 0
+    with pytest.raises(RuntimeError):
+        r.sample(4, "cpu")
+
+
+def test_synthetic_env_contract(mods):
+    """Observation contract of atari/atari_env.h:83-155 and the LCG of SURVEY 8d."""
+    rela, synth = mods
+    e = synth.SyntheticAtariEnv(5, 0.25, 18, 3)
+    assert isinstance(e, rela.Env)
+    assert e.terminated()  # like a fresh AtariEnv: must be reset first
+    o = e.reset()
+    assert o["s"].shape == (4, 84, 84) and o["s"].dtype == torch.uint8
+    assert o["eps"].shape == (1,) and abs(float(o["eps"][0]) - 0.25) < 1e-7
+    assert o["legal_move"].shape == (18,) and float(o["legal_move"].sum()) == 18
+    x, frame = 5, []
+    for _ in range(6):
+        x = (x * 1664525 + 1013904223) & 0xFFFFFFFF
+        frame.append(x >> 24)
+    assert o["s"].flatten()[:6].tolist() == frame
+    rewards = []
+    for i in range(3):
+        o, r, t = e.step({"a": torch.tensor(2 * i)})
+        rewards.append(r)
+        assert t == (i == 2) and e.terminated() == (i == 2)
+    assert set(rewards) <= {-1.0, 0.0, 1.0}
+    _, r, _ = (lambda: (e.reset(), e.step({"a": torch.tensor(1)}))[1])()
+    assert r == 0.0  # odd actions never pay
+    with pytest.raises(IndexError):
+        e.step({"a": torch.tensor(18)})
+
+
+def test_context_lifecycle_without_threads(mods):
+    rela, _ = mods
+    c = rela.Context()
+    assert c.terminated()  # zero loops: vacuously done (context.h:64-67)
+    c.start()
+    c.pause()
+    c.resume()
+    c.terminate()
+    assert c.terminated()
+
+
+def test_model_locker_cpu_and_r2d2_guards(mods):
+    rela, _ = mods
+    from rela_amd.pyrela.apex import ApexAgent
+    from rela_amd.pyrela.net import AtariFFNet
+
+    a = ApexAgent(lambda: AtariFFNet(18), 3, 0.997)
+    b = ApexAgent.clone(a, "cpu")
+    locker = rela.ModelLocker([b], "cpu")  # eval locker of pyrela/main.py:116 constructs
+    with torch.no_grad():
+        a.online_net.fc_v.bias.add_(1.0)
+    locker.update_model(a)  # cpu locker keeps the Python replicas in sync (model_locker.h:31)
+    assert torch.equal(b.online_net.fc_v.bias, a.online_net.fc_v.bias)
+    with pytest.raises(RuntimeError, match="not implemented"):
+        rela.RNNPrioritizedReplay(8, 1, 0.9, 0.6, 0)
+    with pytest.raises(RuntimeError, match="not implemented"):
+        rela.R2D2Actor(locker)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            rela.ModelLocker([a], "cuda:0")  # no silent CPU fallback
+
+
+def test_generate_eps_and_speed_line(capsys):
+    """generate_eps (pyrela/utils.py:88-96) and the Tachometer line pyrela/parse_log.py reads."""
+    from rela_amd.pyrela import utils
+
+    eps = utils.generate_eps(0.4, 7, 5)
+    assert eps[0] == 0.4 and abs(eps[-1] - 0.4 ** 8) < 1e-12 and all(np.diff(eps) < 0)
+    assert utils.generate_eps(0.4, 7, 1) == [0.4]
+
+    class A:
+        def num_act(self):
+            return 640
+
+    class R:
+        def num_add(self):
+            return 320
+
+        def size(self):
+            return 99
+
+    t = utils.Tachometer()
+    t.start()
+    t.lap([A(), A()], R(), 512)
+    out = capsys.readouterr().out
+    assert out.startswith("Speed: train: ") and ", act: " in out and ", buffer_add: " in out and "buffer_size: 99" in out
