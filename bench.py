@@ -202,19 +202,28 @@ def main():
     term_pool = (torch.rand((n_pool, ROWS), device=device, generator=g) < 0.005).to(torch.uint8)
 
     step_idx = [0]
+    # Actors and learner run concurrently in the reference (C++ actor threads next to the Python
+    # learner loop, pyrela/main.py:185-251).  Here the actor tick goes to its own HIP stream and
+    # the learner step stays on torch's default stream; they meet only through the replay, whose
+    # private stream serialises insert / sample / update in commit order.
+    actor_stream = torch.cuda.Stream(device=device)
+    main_stream = torch.cuda.current_stream(device)
 
     def actor_tick():
         i = step_idx[0] % n_pool
-        engine.act(online)
-        engine.post_step(reward_pool[i], term_pool[i], online, target, nonblocking=True)
+        with torch.cuda.stream(actor_stream):
+            engine.act(online)
+            engine.post_step(reward_pool[i], term_pool[i], online, target, nonblocking=True)
 
     def learner_step():
         k = step_idx[0]
         if k % 2500 == 0:
             agent.sync_target_with_online()
-        if k % 20 == 0:  # ModelLocker.update_model, main.py:213-215
+        if k % 20 == 0:  # ModelLocker.update_model, main.py:213-215 (waits for in-flight actor work)
+            main_stream.wait_stream(actor_stream)
             online.load_state_dict(agent.online_net.state_dict())
             target.load_state_dict(agent.target_net.state_dict())
+            actor_stream.wait_stream(main_stream)
         batch, weight = replay.sample(BATCH)
         loss, prio = agent.loss(batch, sync_priority=False)
         (loss * weight).mean().backward()
@@ -224,6 +233,14 @@ def main():
         optim.step()
         optim.zero_grad(set_to_none=True)
         replay.update_priority(prio)
+
+    def one_step():
+        # The learner samples the replay as the previous tick left it and runs next to this tick
+        # (had the tick been queued first, `sample` would sit behind the tick's `add` on the replay
+        # stream and the two would serialise).  Join at the end: one step = one tick + one update.
+        learner_step()
+        actor_tick()
+        main_stream.wait_stream(actor_stream)
 
     # fill the ring to capacity (untimed): real ticks for the history, then bulk inserts
     for _ in range(MULTI_STEP + 1):
@@ -249,16 +266,14 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        actor_tick()
-        learner_step()
+        one_step()
         step_idx[0] += 1
     sync_all()
     capi.lib.rela_prof_enable(1)
     add0 = replay.num_add()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        actor_tick()
-        learner_step()
+        one_step()
         step_idx[0] += 1
     sync_all()
     dt = time.perf_counter() - t0

@@ -1,0 +1,70 @@
+"""N > 1 learner path on the CPU: two gloo ranks, replicated learners, one flat gradient
+all-reduce per step (rela_amd/learner.py) -- replicas must stay bit-identical and equal to a
+single learner fed the concatenated batch."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rela_amd.learner import allreduce_grads
+
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 1))
+    opt = torch.optim.RMSprop(model.parameters(), lr=1e-2, eps=1.5e-4)
+    g = torch.Generator().manual_seed(123)
+    x_all, y_all = torch.randn(3, 8, 6, generator=g), torch.randn(3, 8, 1, generator=g)
+    for step in range(3):
+        x, y = x_all[step].chunk(world)[rank], y_all[step].chunk(world)[rank]  # batch split B/G
+        ((model(x) - y) ** 2).mean().backward()
+        allreduce_grads(model.parameters(), world)
+        opt.step()
+        opt.zero_grad()
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    if rank == 0:
+        out.put([t.tolist() for t in gathered])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_keeps_replicas_identical():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = torch.tensor(res[0]), torch.tensor(res[1])
+    assert torch.equal(a, b)
+    # single learner on the full batch: mean of the two half-batch gradients == full-batch gradient
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 1))
+    opt = torch.optim.RMSprop(model.parameters(), lr=1e-2, eps=1.5e-4)
+    g = torch.Generator().manual_seed(123)
+    x_all, y_all = torch.randn(3, 8, 6, generator=g), torch.randn(3, 8, 1, generator=g)
+    for step in range(3):
+        ((model(x_all[step]) - y_all[step]) ** 2).mean().backward()
+        opt.step()
+        opt.zero_grad()
+    ref = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    torch.testing.assert_close(a, ref, rtol=1e-5, atol=1e-6)
