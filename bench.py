@@ -45,7 +45,7 @@ REPLAY_CAP = 1 << 20
 SEED = 10002
 
 # algorithmic FLOPs per sample-forward: 2 * MACs
-FLOP = {"conv1_mfma": 2 * 400 * 32 * 256, "conv2_mfma": 2 * 81 * 64 * 512, "conv3_mfma": 2 * 49 * 64 * 576,
+FLOP = {"conv1_bf16x3": 2 * 400 * 32 * 256, "conv2_mfma": 2 * 81 * 64 * 512, "conv3_mfma": 2 * 49 * 64 * 576,
         "fc_mfma": 2 * 3136 * 512, "heads_mfma": 2 * 512 * 19}
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_GBS = 8000.0
@@ -310,7 +310,7 @@ def main():
         if roof["achieved"] is not None:
             roof["frac"] = roof["achieved"] / roof["peak"]
         fwd_ms = sum(prof[k]["total_ms"] for k in FLOP if k in prof)
-        fwd_cnt = prof.get("conv1_mfma", {"count": 1})["count"]
+        fwd_cnt = prof.get("conv1_bf16x3", {"count": 1})["count"]
         scan_ms = sum(v["total_ms"] for k, v in prof.items() if k.startswith("seq_") or k in (
             "replay_targets", "replay_search", "replay_pop", "replay_is_weights"))
         out = {

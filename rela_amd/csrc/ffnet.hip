@@ -19,7 +19,11 @@
 // Activations are channel-last f32 ([N][pos][C]) between layers; fc weights are permuted
 // at load time to match (k = pos*64 + c instead of torch's c*49 + pos).  LDS pixel strides
 // are padded (33 / 66 floats) so the 16 rows of a fragment hit distinct banks.
-// conv1 reads the raw u8 frames from LDS and converts in-register; the /255 of net.py:46 is
+// conv1 is special: its inputs are u8 frames, which are EXACT in bf16, and an fp32 weight is
+// exactly the sum of three bf16 pieces (24-bit significand = 3 x 8).  So conv1 runs on
+// v_mfma_f32_16x16x32_bf16 (16x the fp32 MFMA rate) as three passes hi/mid/lo with fp32
+// accumulation: every product is exact and the result is fp32-accurate, while the layer drops
+// from MFMA-bound to HBM-bound (28 KB in + 51 KB out per sample).  The /255 of net.py:46 is
 // folded into conv1's weights at load time.
 #include "common.h"
 #include "prof.h"
@@ -29,7 +33,8 @@ namespace rela_amd {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct FFNetDev {
-  float *B1 = nullptr, *b1 = nullptr;  // conv1 frags [2][64][64], bias[32]
+  uint4* B1 = nullptr;                 // conv1 bf16 frags [piece 3][ct 2][ks 8][lane 64] x 8 bf16
+  float* b1 = nullptr;                 // conv1 bias[32]
   float *B2 = nullptr, *b2 = nullptr;  // conv2 frags [4][128][64], bias[64]
   float *B3 = nullptr, *b3 = nullptr;  // conv3 frags [4][144][64], bias[64]
   float *Bf = nullptr, *bf = nullptr;  // fc    frags [32][784][64], bias[512]
@@ -59,7 +64,6 @@ struct ConvCfg {
   static constexpr int LDS_BYTES = U8 ? S * IN_ELEMS : S * IH * IW * PIX * 4;
 };
 
-using Conv1 = ConvCfg<4, 84, 84, 8, 8, 4, 20, 20, 32, 2, true>;
 using Conv2 = ConvCfg<32, 20, 20, 4, 4, 2, 9, 9, 64, 2, false>;
 using Conv3 = ConvCfg<64, 9, 9, 3, 3, 1, 7, 7, 64, 4, false>;
 
@@ -171,6 +175,134 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const void* __restrict__ i
       }
     }
   }
+}
+
+// ---- conv1 on bf16 MFMA, exact-weight split ------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct Conv1B {
+  static constexpr int S = 2, P = 400, M = S * P, RT = M / 16, OC = 32, CT = 2, KS = 8;
+  static constexpr int RPW = (RT + kWaves - 1) / kWaves;  // 7 row tiles per wave (last ones masked)
+  static constexpr int IN_ELEMS = 4 * 84 * 84;
+  static constexpr int LDS_BYTES = S * IN_ELEMS;
+  static constexpr int FRAG_UINT4 = 3 * CT * KS * 64;  // [piece][ct][ks][lane] x 8 bf16
+};
+
+// 8 consecutive input bytes -> 8 bf16 (exact): v_cvt_f32_ubyteN + v_perm_b32 taking the high halves
+__device__ __forceinline__ uint4 u8x8_to_bf16x8(uint32_t d0, uint32_t d1) {
+  auto pk = [](uint32_t d, int lo) -> uint32_t {
+    const float f0 = (float)((d >> (8 * lo)) & 0xff), f1 = (float)((d >> (8 * lo + 8)) & 0xff);
+    return __builtin_amdgcn_perm(__float_as_uint(f1), __float_as_uint(f0), 0x07060302u);
+  };
+  return make_uint4(pk(d0, 0), pk(d0, 2), pk(d1, 0), pk(d1, 2));
+}
+
+__global__ __launch_bounds__(kThreads) void conv1_bf16x3(const uint8_t* __restrict__ in,
+                                                         const uint4* __restrict__ Bfrag,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         int N) {
+  using C = Conv1B;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x;
+  const int n0 = blockIdx.x * C::S;
+  const int ns = min(C::S, N - n0);
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)n0 * C::IN_ELEMS);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    constexpr int per = C::IN_ELEMS / 16;
+    for (int i = tid; i < C::S * per; i += kThreads) dst[i] = (i < ns * per) ? src[i] : make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+
+  // k = (c, kh, kw): a k-step of 32 = 4 kernel rows x 8 columns of one channel; lane group g
+  // owns kernel row 4*(ks&1) + g, its 8 k's are 8 CONSECUTIVE input bytes (4-byte aligned).
+  int abase[C::RPW];
+#pragma unroll
+  for (int t = 0; t < C::RPW; ++t) {
+    const int rt = wave + t * kWaves;
+    const int m = ((rt < C::RT) ? rt : 0) * 16 + li;
+    const int s = m / C::P, pos = m - s * C::P;
+    const int oy = pos / 20, ox = pos - oy * 20;
+    abase[t] = s * C::IN_ELEMS + (4 * oy + g) * 84 + 4 * ox;
+  }
+  f32x4 acc[C::RPW][C::CT];
+#pragma unroll
+  for (int t = 0; t < C::RPW; ++t)
+#pragma unroll
+    for (int c = 0; c < C::CT; ++c) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+  for (int ks = 0; ks < C::KS; ++ks) {
+    const int koff = (ks >> 1) * 84 * 84 + (ks & 1) * 4 * 84;
+    bf16x8 b[3][C::CT];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int c = 0; c < C::CT; ++c)
+        b[p][c] = __builtin_bit_cast(bf16x8, Bfrag[((p * C::CT + c) * C::KS + ks) * 64 + lane]);
+#pragma unroll
+    for (int t = 0; t < C::RPW; ++t) {
+      const uint32_t* ap = reinterpret_cast<const uint32_t*>(smem + abase[t] + koff);
+      const bf16x8 a = __builtin_bit_cast(bf16x8, u8x8_to_bf16x8(ap[0], ap[1]));
+#pragma unroll
+      for (int c = 0; c < C::CT; ++c) {
+        // smallest piece first so the big one is added last
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[2][c], acc[t][c], 0, 0, 0);
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[1][c], acc[t][c], 0, 0, 0);
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[0][c], acc[t][c], 0, 0, 0);
+      }
+    }
+  }
+
+  const int mlim = ns * C::P;
+#pragma unroll
+  for (int t = 0; t < C::RPW; ++t) {
+    const int rt = wave + t * kWaves;
+    if (rt >= C::RT) continue;
+#pragma unroll
+    for (int c = 0; c < C::CT; ++c) {
+      const int col = c * 16 + li;
+      const float bv = bias[col];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = rt * 16 + g * 4 + r;
+        if (m < mlim) {
+          const float v = acc[t][c][r] + bv;
+          out[((size_t)n0 * C::P + m) * C::OC + col] = v > 0.f ? v : 0.f;
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float x) {
+  uint32_t u = __float_as_uint(x);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// conv1 weights (32,4,8,8)/255 -> three bf16 planes in MFMA 16x16x32 fragment order.
+// w == hi + mid + lo exactly for every finite fp32 weight (each residual is exact in fp32).
+__global__ void pack_conv1_bf16x3(const float* __restrict__ w, uint16_t* __restrict__ frag) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // [ct 2][ks 8][lane 64][j 8]
+  if (idx >= 2 * 8 * 64 * 8) return;
+  const int j = idx & 7, lane = (idx >> 3) & 63, ks = (idx >> 9) & 7, ct = idx >> 12;
+  const int k = ks * 32 + (lane >> 4) * 8 + j;
+  const int oc = ct * 16 + (lane & 15);
+  const float v = w[oc * 256 + k] / 255.0f;
+  const uint16_t hi = f32_to_bf16_rne(v);
+  const float r1 = v - bf16_to_f32(hi);
+  const uint16_t mid = f32_to_bf16_rne(r1);
+  const float r2 = r1 - bf16_to_f32(mid);
+  const uint16_t lo = f32_to_bf16_rne(r2);
+  const int plane = 2 * 8 * 64 * 8;
+  frag[idx] = hi;
+  frag[plane + idx] = mid;
+  frag[2 * plane + idx] = lo;
 }
 
 // Dense layer  out[N][OC] = act(A[N][K] * W + bias)  on the same MFMA tiling.
@@ -368,7 +500,7 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
   n->device = device;
   n->num_action = num_action;
   FFNetDev& d = n->d;
-  RELA_HIP(hipMalloc(&d.B1, sizeof(float) * 2 * 64 * 64));
+  RELA_HIP(hipMalloc(&d.B1, sizeof(uint4) * Conv1B::FRAG_UINT4));
   RELA_HIP(hipMalloc(&d.b1, sizeof(float) * 32));
   RELA_HIP(hipMalloc(&d.B2, sizeof(float) * 4 * 128 * 64));
   RELA_HIP(hipMalloc(&d.b2, sizeof(float) * 64));
@@ -379,8 +511,8 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
   RELA_HIP(hipMalloc(&d.Bh, sizeof(float) * 2 * 128 * 64));
   RELA_HIP(hipMalloc(&d.bh, sizeof(float) * 32));
   // opt in to > 64 KB of dynamic LDS once per process/device
-  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv1>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv1::LDS_BYTES));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv1B::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv2::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv3>),
@@ -393,8 +525,8 @@ extern "C" void rela_ffnet_destroy(rela_ffnet* n) {
   if (!n) return;
   DeviceGuard g(n->device);
   (void)hipDeviceSynchronize();
-  float* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bf, n->d.bf, n->d.Bh, n->d.bh};
-  for (float* p : ps) (void)hipFree(p);
+  void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bf, n->d.bf, n->d.Bh, n->d.bh};
+  for (void* p : ps) (void)hipFree(p);
   delete n;
 }
 
@@ -437,7 +569,8 @@ extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on
     const int64_t total = (int64_t)CT * KS * 64;
     hipLaunchKernelGGL(pack_frags, dim3(ceil_div(total, 256)), dim3(256), 0, s, mode, w, w2, A, frag, CT, KS);
   };
-  pack(kPackConv1, dv[0], nullptr, n->d.B1, 2, 64);
+  hipLaunchKernelGGL(pack_conv1_bf16x3, dim3(ceil_div(2 * 8 * 64 * 8, 256)), dim3(256), 0, s, dv[0],
+                     reinterpret_cast<uint16_t*>(n->d.B1));
   pack(kPackConv2, dv[2], nullptr, n->d.B2, 4, 128);
   pack(kPackConv3, dv[4], nullptr, n->d.B3, 4, 144);
   pack(kPackFc, dv[6], nullptr, n->d.Bf, 32, 784);
@@ -472,9 +605,9 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
   float* ha = h + kH * N;
   const FFNetDev& d = n->d;
   {
-    ProfScope prof("conv1_mfma", s);
-    hipLaunchKernelGGL(conv_mfma<Conv1>, dim3(ceil_div(N, Conv1::S)), dim3(kThreads), Conv1::LDS_BYTES, s,
-                       (const void*)s_dev, d.B1, d.b1, a1, N);
+    ProfScope prof("conv1_bf16x3", s);
+    hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
+                       d.B1, d.b1, a1, N);
   }
   {
     ProfScope prof("conv2_mfma", s);
