@@ -121,6 +121,23 @@ void oracle_apex_priority(const oracle_ffnet* online, const oracle_ffnet* target
                           const float* next_legal, float gamma_n, float* td_err_signed,
                           float* priority);
 
+/* ------------------------------------------------------- R2D2 sequence buffer ---
+ * rela/r2d2_actor.h:10-187 (R2D2TransitionBuffer) on scalar tags, and
+ * R2D2Agent.aggregate_priority (pyrela/r2d2.py:103-120).                                  */
+typedef struct oracle_r2d2buf oracle_r2d2buf;
+oracle_r2d2buf* oracle_r2d2buf_new(int K, int multi_step, int seq_len, int burn_in);
+void oracle_r2d2buf_free(oracle_r2d2buf* b);
+/* push :29-87 for all K envs; returns canPop */
+int oracle_r2d2buf_push(oracle_r2d2buf* b, const int64_t* tag, const int64_t* action, const float* reward,
+                        const float* bootstrap, const uint8_t* terminal, const float* priority,
+                        const float* hid_tag);
+/* popTransition :93-170; outputs hold up to 2K sequences of T = burn+seq+n slots ([q][T]) and
+ * seq_len priorities ([q][seq]); returns the number of sequences emitted                   */
+int oracle_r2d2buf_pop(oracle_r2d2buf* b, float* out_len, float* out_h0, int* out_env, int64_t* tag,
+                       int64_t* action, float* reward, uint8_t* terminal, float* bootstrap, float* prio);
+void oracle_r2d2_aggregate(int nseq, int seq_len_const, int burn_in, float eta, const float* priority,
+                           const float* seq_len, float* out);
+
 #ifdef __cplusplus
 }
 #endif

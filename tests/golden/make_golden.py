@@ -181,6 +181,50 @@ def ffnet_cases():
              priority=prio.numpy().astype(np.float64).tolist(), td_err=err.numpy().astype(np.float64).tolist())
 
 
+def r2d2buf_cases():
+    """R2D2TransitionBuffer traces: episodes shorter than the window, full windows with carry-over,
+    terminals inside the carried region, overlapping carry (burn+n > seq), burn_in = 0."""
+    for name, K, n, seq, burn, pterm, seed in [("r2d2buf_k3_n3_s8_b4", 3, 3, 8, 4, 0.07, 1),
+                                                ("r2d2buf_k2_n1_s4_b4", 2, 1, 4, 4, 0.10, 2),
+                                                ("r2d2buf_k4_n3_s8_b0", 4, 3, 8, 0, 0.06, 3),
+                                                ("r2d2buf_k2_n5_s6_b2", 2, 5, 6, 2, 0.05, 4),
+                                                ("r2d2buf_k1_n3_s80_b40", 1, 3, 80, 40, 0.01, 5)]:
+        rng = np.random.default_rng(seed)
+        s = ["new %d %d %d %d" % (K, n, seq, burn)]
+        for _ in range(400 if seq == 80 else 150):
+            t = (rng.uniform(size=K) < pterm).astype(int)
+            p = rng.uniform(0, 2, K).astype(np.float32)
+            s.append("push %s %s" % (" ".join(str(v) for v in t), " ".join(f2h(v) for v in p)))
+        save(name, s, run("r2d2_kat", s), K=K, multi_step=n, seq_len=seq, burn_in=burn)
+
+
+def r2d2agg_cases():
+    """R2D2Agent.aggregate_priority from the reference's own pyrela/r2d2.py."""
+    import types
+
+    sys.dont_write_bytecode = True
+    sys.modules.setdefault("tensorboardX", types.ModuleType("tensorboardX"))
+    sys.modules["tensorboardX"].SummaryWriter = object
+    sys.path.insert(0, "/root/reference/pyrela")
+    import torch
+    from net import AtariLSTMNet
+    from r2d2 import R2D2Agent
+
+    out = []
+    for seq, burn, eta, seed in [(8, 4, 0.9, 1), (80, 40, 0.9, 2), (6, 0, 0.5, 3)]:
+        agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, 6), "cpu", 3, 0.997, eta, seq, burn, 0)
+        rng = np.random.default_rng(seed)
+        nseq = 5
+        prio = rng.uniform(0, 3, (nseq, seq)).astype(np.float32)
+        lens = rng.integers(burn + 1, burn + seq + 1, nseq).astype(np.float32)
+        for q in range(nseq):  # what the buffer hands over: zeros past the episode end
+            prio[q, max(0, int(lens[q]) - burn):] = 0
+        agg = agent.aggregate_priority(torch.from_numpy(prio), torch.from_numpy(lens))
+        out.append(dict(seq_len=seq, burn_in=burn, eta=eta, priority=[[f2h(v) for v in row] for row in prio],
+                        lens=lens.tolist(), agg=[f2h(v) for v in agg.numpy()]))
+    save("r2d2_aggregate", [], out)
+
+
 def e2e_cases():
     """The REAL reference end to end: its pybind module (oracle/_ref/rela*.so), its TorchScript
     ApexAgent on the CPU, our synthetic env compiled against its rela/env.h."""
@@ -206,7 +250,11 @@ print("RESULT" + json.dumps(rounds))
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["replay", "nstep", "ffnet", "e2e"]
+    which = sys.argv[1:] or ["replay", "nstep", "ffnet", "e2e", "r2d2buf", "r2d2agg"]
+    if "r2d2buf" in which:
+        r2d2buf_cases()
+    if "r2d2agg" in which:
+        r2d2agg_cases()
     if "e2e" in which:
         e2e_cases()
     if "replay" in which:
