@@ -172,6 +172,36 @@ int rela_apex_td_from_q(int n, int num_action, int group_rows, const float* q_de
                         float* priority_dev, void* stream);
 
 /* ===================================================================================
+ * R2D2 network  --  AtariLSTMNet, pyrela/net.py:58-163: the same conv trunk, then one LSTM layer
+ * 3136 -> 512 (torch gate order i,f,g,o) and the dueling heads on the LSTM output.
+ * =================================================================================== */
+typedef struct rela_lstmnet rela_lstmnet;
+
+typedef struct {
+  const float *conv1_w, *conv1_b, *conv2_w, *conv2_b, *conv3_w, *conv3_b; /* net.{0,2,4}.*          */
+  const float *w_ih, *w_hh;   /* lstm.weight_ih_l0 (2048,3136), lstm.weight_hh_l0 (2048,512)         */
+  const float *b_ih, *b_hh;   /* lstm.bias_ih_l0 (2048), lstm.bias_hh_l0 (2048)                       */
+  const float *v_w, *v_b;     /* fc_v.weight (1,512), fc_v.bias (1)                                   */
+  const float *a_w, *a_b;     /* fc_a.weight (A,512), fc_a.bias (A)                                   */
+} rela_lstmnet_params;
+
+int rela_lstmnet_create(rela_lstmnet** out, int num_action, int device);
+void rela_lstmnet_destroy(rela_lstmnet* net);
+int rela_lstmnet_load(rela_lstmnet* net, const rela_lstmnet_params* params, int params_on_device,
+                      void* stream);
+int rela_lstmnet_num_action(const rela_lstmnet* net);
+int64_t rela_lstmnet_workspace_bytes(const rela_lstmnet* net, int n);
+
+/* One time step for n rows: what AtariLSTMNet.act (net.py:110-124) and .forward with seq = 1
+ * (:140-163) compute.  h_in/c_in/h_out/c_out are f32[n,512] (in and out may not alias);
+ * q_dev (dueling Q, may be NULL) and adv_dev (raw fc_a output, the tensor `act` ranks, may be
+ * NULL) are f32[n,A].                                                                        */
+int rela_lstmnet_step(const rela_lstmnet* net, int n, const uint8_t* s_dev, const float* legal_dev,
+                      const float* h_in, const float* c_in, float* h_out, float* c_out,
+                      float* q_dev, float* adv_dev, void* workspace_dev, int64_t workspace_bytes,
+                      void* stream);
+
+/* ===================================================================================
  * Ape-X actor shard  --  DQNActor + MultiStepTransitionBuffer, rela/dqn_actor.h:15-211, as one
  * device-resident object for `rows` envs (rows = K for one reference actor thread, or T*K when
  * several threads are batched into one launch; group_rows = K keeps every batch-global reduction

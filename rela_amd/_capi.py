@@ -32,6 +32,11 @@ class ReplayState(C.Structure):
                 ("dev_error", C.c_int32), ("pad", C.c_int32)]
 
 
+class LSTMNetParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "conv3_w", "conv3_b", "w_ih",
+                                          "w_hh", "b_ih", "b_hh", "v_w", "v_b", "a_w", "a_b")]
+
+
 class FFNetParams(C.Structure):
     _fields_ = [(n, vp) for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "conv3_w", "conv3_b", "fc_w", "fc_b",
                                   "v_w", "v_b", "a_w", "a_b")]
@@ -74,6 +79,12 @@ _sig("rela_ffnet_load", i32, [vp, P(FFNetParams), i32, vp])
 _sig("rela_ffnet_num_action", i32, [vp])
 _sig("rela_ffnet_workspace_bytes", i64, [vp, i32])
 _sig("rela_ffnet_forward", i32, [vp, i32, vp, vp, vp, vp, i64, vp])
+_sig("rela_lstmnet_create", i32, [P(vp), i32, i32])
+_sig("rela_lstmnet_destroy", None, [vp])
+_sig("rela_lstmnet_load", i32, [vp, P(LSTMNetParams), i32, vp])
+_sig("rela_lstmnet_num_action", i32, [vp])
+_sig("rela_lstmnet_workspace_bytes", i64, [vp, i32])
+_sig("rela_lstmnet_step", i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp])
 _sig("rela_apex_act_from_q", i32, [i32, i32, i32, vp, vp, vp, u64, u64, vp, vp])
 _sig("rela_apex_td_from_q", i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp])
 _sig("rela_apex_actor_create", i32, [P(vp), i32, i32, i32, i32, f32, vp, u64, i32])

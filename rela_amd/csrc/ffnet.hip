@@ -308,10 +308,14 @@ __global__ void pack_conv1_bf16x3(const float* __restrict__ w, uint16_t* __restr
 // Dense layer  out[N][OC] = act(A[N][K] * W + bias)  on the same MFMA tiling.
 // Block = BM rows x (CTB*16) columns; A is staged through LDS in K-chunks of 32 (double
 // buffered, row stride 34 floats -> conflict-free fragment reads), B fragments stream from L2.
-template <int K_, int OC_, int BM_, bool RELU_>
+enum GemmEpilogue { kEpiBias = 0, kEpiBiasRelu = 1, kEpiLstmCell = 2 };
+
+// K1_ = leading part of K that comes from the first A matrix ([N][K1]); the rest comes from a
+// second matrix ([N][K-K1]) -- the LSTM gate GEMM reads [conv features | previous h].
+template <int K_, int OC_, int BM_, int EPI_, int K1_ = K_>
 struct GemmCfg {
-  static constexpr int K = K_, OC = OC_, BM = BM_;
-  static constexpr bool RELU = RELU_;
+  static constexpr int K = K_, OC = OC_, BM = BM_, EPI = EPI_, K1 = K1_;
+  static constexpr bool RELU = EPI_ == kEpiBiasRelu;
   static constexpr int CT = OC / 16;
   static constexpr int CTB = CT < kWaves ? CT : kWaves;  // column tiles per block
   static constexpr int RGB = kWaves / CTB;               // row groups per block
@@ -324,12 +328,19 @@ struct GemmCfg {
   static constexpr int VPT = BM * KC / 4 / kThreads;  // float4 per thread per chunk
 };
 
-using GemmFc = GemmCfg<3136, 512, 128, true>;
-using GemmHeads = GemmCfg<512, 32, 128, false>;
+using GemmFc = GemmCfg<3136, 512, 128, kEpiBiasRelu>;
+using GemmHeads = GemmCfg<512, 32, 128, kEpiBias>;
+// LSTM gates: [x(3136) | h(512)] x [3648][2048]; columns permuted to 4*unit + gate (i,f,g,o) so the
+// four gates of a hidden unit sit in four adjacent lanes of one accumulator tile.
+using GemmLstm = GemmCfg<3648, 2048, 128, kEpiLstmCell, 3136>;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 template <class G>
-__global__ __launch_bounds__(kThreads) void gemm_mfma(const float* __restrict__ A, const float* __restrict__ Bfrag,
+__global__ __launch_bounds__(kThreads) void gemm_mfma(const float* __restrict__ A, const float* __restrict__ A2,
+                                                      const float* __restrict__ Bfrag,
                                                       const float* __restrict__ bias, float* __restrict__ out,
+                                                      const float* __restrict__ c_in, float* __restrict__ c_out,
                                                       int N) {
   __shared__ __attribute__((aligned(16))) float sA[2][G::BM * G::LDA];
   const int tid = threadIdx.x;
@@ -346,8 +357,10 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma(const float* __restrict__ 
       const int idx = tid + v * kThreads;
       const int r = idx >> 3, q = idx & 7;  // KC/4 == 8 float4 per row
       const int row = row0 + r;
-      stage[v] = (row < N) ? *reinterpret_cast<const float4*>(A + (size_t)row * G::K + ch * G::KC + q * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int k = ch * G::KC + q * 4;
+      const float* src = (G::K1 == G::K || k < G::K1) ? A + (size_t)row * G::K1 + k
+                                                        : A2 + (size_t)row * (G::K - G::K1) + (k - G::K1);
+      stage[v] = (row < N) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store_chunk = [&](int buf) {
@@ -396,7 +409,20 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma(const float* __restrict__ 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = row0 + (rg * G::RPW + t) * 16 + kk * 4 + r;
-      if (row < N) {
+      if constexpr (G::EPI == kEpiLstmCell) {
+        // torch LSTM cell (gate order i,f,g,o): c' = sig(f)*c + sig(i)*tanh(g); h' = sig(o)*tanh(c')
+        const float pre = acc[t][r] + bv;
+        const int base = lane & ~3;
+        const float gi = __shfl(pre, base + 0, 64), gf = __shfl(pre, base + 1, 64);
+        const float gg = __shfl(pre, base + 2, 64), go = __shfl(pre, base + 3, 64);
+        if ((li & 3) == 0 && row < N) {
+          const int unit = col >> 2;
+          const float cp = c_in[(size_t)row * (G::OC / 4) + unit];
+          const float c = sigmoidf_(gf) * cp + sigmoidf_(gi) * tanhf(gg);
+          c_out[(size_t)row * (G::OC / 4) + unit] = c;
+          out[(size_t)row * (G::OC / 4) + unit] = sigmoidf_(go) * tanhf(c);
+        }
+      } else if (row < N) {
         float v = acc[t][r] + bv;
         if (G::RELU) v = v > 0.f ? v : 0.f;
         out[(size_t)row * G::OC + col] = v;
@@ -406,8 +432,9 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma(const float* __restrict__ 
 }
 
 // duel(): q = v + a*legal - mean_A(a*legal)   net.py:33-39 (mean over A, not over #legal)
+// adv (optional) receives the raw fc_a outputs, which AtariLSTMNet.act ranks (net.py:119-123)
 __global__ void dueling_kernel(const float* __restrict__ ha, const float* __restrict__ legal, float* __restrict__ q,
-                               int N, int A) {
+                               float* __restrict__ adv, int N, int A) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   const float* row = ha + (size_t)n * 32;
@@ -415,15 +442,17 @@ __global__ void dueling_kernel(const float* __restrict__ ha, const float* __rest
   float la[31];
   float sum = 0.f;
   for (int j = 0; j < A; ++j) {
+    if (adv) adv[(size_t)n * A + j] = row[j];
     la[j] = row[j] * legal[(size_t)n * A + j];
     sum += la[j];
   }
   const float mean = sum / (float)A;
-  for (int j = 0; j < A; ++j) q[(size_t)n * A + j] = (v + la[j]) - mean;
+  if (q)
+    for (int j = 0; j < A; ++j) q[(size_t)n * A + j] = (v + la[j]) - mean;
 }
 
 // ---- weight packing (load_state_dict time) ------------------------------------------------
-enum PackMode { kPackConv1 = 0, kPackConv2 = 1, kPackConv3 = 2, kPackFc = 3, kPackHeads = 4 };
+enum PackMode { kPackConv1 = 0, kPackConv2 = 1, kPackConv3 = 2, kPackFc = 3, kPackHeads = 4, kPackLstm = 5 };
 
 __global__ void pack_frags(int mode, const float* __restrict__ w, const float* __restrict__ w2, int num_action,
                            float* __restrict__ frag, int CT, int KS) {
@@ -455,6 +484,16 @@ __global__ void pack_frags(int mode, const float* __restrict__ w, const float* _
       v = w[(size_t)oc * 3136 + c * 49 + p];
       break;
     }
+    case kPackLstm: {  // col' = 4*unit + gate  <-  row gate*512 + unit of weight_ih_l0 / weight_hh_l0
+      const int row = (oc & 3) * 512 + (oc >> 2);
+      if (k < 3136) {
+        const int c = k & 63, p = k >> 6;  // k = pos*64 + c  <-  c*49 + pos (net.py:105-106)
+        v = w[(size_t)row * 3136 + c * 49 + p];
+      } else {
+        v = w2[(size_t)row * 512 + (k - 3136)];
+      }
+      break;
+    }
     case kPackHeads:
       if (oc < num_action)
         v = w[oc * 512 + k];  // fc_a
@@ -463,6 +502,14 @@ __global__ void pack_frags(int mode, const float* __restrict__ w, const float* _
       break;
   }
   frag[idx] = v;
+}
+
+__global__ void pack_lstm_bias(const float* __restrict__ bih, const float* __restrict__ bhh, float* __restrict__ out) {
+  const int oc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (oc < 2048) {
+    const int row = (oc & 3) * 512 + (oc >> 2);
+    out[oc] = bih[row] + bhh[row];
+  }
 }
 
 __global__ void pack_head_bias(const float* __restrict__ ab, const float* __restrict__ vb, int A, float* __restrict__ out) {
@@ -622,16 +669,191 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
   {
     ProfScope prof("fc_mfma", s);
     hipLaunchKernelGGL(gemm_mfma<GemmFc>, dim3(GemmFc::CT / GemmFc::CTB, ceil_div(N, GemmFc::BM)), dim3(kThreads), 0, s,
-                       a3, d.Bf, d.bf, h, N);
+                       (const float*)a3, (const float*)nullptr, (const float*)d.Bf, (const float*)d.bf, h,
+                       (const float*)nullptr, (float*)nullptr, N);
   }
   {
     ProfScope prof("heads_mfma", s);
     hipLaunchKernelGGL(gemm_mfma<GemmHeads>, dim3(GemmHeads::CT / GemmHeads::CTB, ceil_div(N, GemmHeads::BM)),
-                       dim3(kThreads), 0, s, h, d.Bh, d.bh, ha, N);
+                       dim3(kThreads), 0, s, (const float*)h, (const float*)nullptr, (const float*)d.Bh,
+                       (const float*)d.bh, ha, (const float*)nullptr, (float*)nullptr, N);
   }
   {
     ProfScope prof("dueling", s);
-    hipLaunchKernelGGL(dueling_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, ha, legal_dev, q_dev, N, n->num_action);
+    hipLaunchKernelGGL(dueling_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, (const float*)ha, legal_dev, q_dev,
+                       (float*)nullptr, N, n->num_action);
+  }
+  RELA_LAUNCH_CHECK();
+  return RELA_OK;
+}
+
+// =====================================================================================
+// AtariLSTMNet (pyrela/net.py:58-163): trunk -> LSTM gates + cell (one fused GEMM) -> heads
+// =====================================================================================
+struct rela_lstmnet {
+  int device = 0;
+  int num_action = 0;
+  FFNetDev d;            // B1..b3 (trunk) and Bh/bh (heads); Bf/bf unused
+  float* Bl = nullptr;   // lstm frags [128][912][64]
+  float* bl = nullptr;   // b_ih + b_hh, permuted [2048]
+  bool loaded = false;
+};
+
+namespace {
+constexpr int64_t kLstmWsFloats = kA1 + kA2 + kA3 + kHA;
+}
+
+extern "C" int rela_lstmnet_create(rela_lstmnet** out, int num_action, int device) {
+  RELA_CHECK(out && num_action >= 1 && num_action <= 31, RELA_EINVAL,
+             "rela_lstmnet_create: num_action must be in 1..31 (got %d)", num_action);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    set_last_error("rela_lstmnet_create: HIP device %d not available (%d visible); there is no CPU path", device, ndev);
+    return RELA_ENODEV;
+  }
+  DeviceGuard g(device);
+  auto* n = new rela_lstmnet();
+  n->device = device;
+  n->num_action = num_action;
+  FFNetDev& d = n->d;
+  RELA_HIP(hipMalloc(&d.B1, sizeof(uint4) * Conv1B::FRAG_UINT4));
+  RELA_HIP(hipMalloc(&d.b1, sizeof(float) * 32));
+  RELA_HIP(hipMalloc(&d.B2, sizeof(float) * 4 * 128 * 64));
+  RELA_HIP(hipMalloc(&d.b2, sizeof(float) * 64));
+  RELA_HIP(hipMalloc(&d.B3, sizeof(float) * 4 * 144 * 64));
+  RELA_HIP(hipMalloc(&d.b3, sizeof(float) * 64));
+  RELA_HIP(hipMalloc(&d.Bh, sizeof(float) * 2 * 128 * 64));
+  RELA_HIP(hipMalloc(&d.bh, sizeof(float) * 32));
+  RELA_HIP(hipMalloc(&n->Bl, sizeof(float) * (size_t)GemmLstm::CT * GemmLstm::KS * 64));
+  RELA_HIP(hipMalloc(&n->bl, sizeof(float) * 2048));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv1B::LDS_BYTES));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv2::LDS_BYTES));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv3::LDS_BYTES));
+  *out = n;
+  return RELA_OK;
+}
+
+extern "C" void rela_lstmnet_destroy(rela_lstmnet* n) {
+  if (!n) return;
+  DeviceGuard g(n->device);
+  (void)hipDeviceSynchronize();
+  void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bh, n->d.bh, n->Bl, n->bl};
+  for (void* p : ps) (void)hipFree(p);
+  delete n;
+}
+
+extern "C" int rela_lstmnet_num_action(const rela_lstmnet* n) { return n ? n->num_action : 0; }
+
+extern "C" int64_t rela_lstmnet_workspace_bytes(const rela_lstmnet* n, int batch) {
+  (void)n;
+  return (int64_t)sizeof(float) * kLstmWsFloats * (batch > 0 ? batch : 0) + 256;
+}
+
+extern "C" int rela_lstmnet_load(rela_lstmnet* n, const rela_lstmnet_params* p, int on_device, void* stream_) {
+  RELA_CHECK(n && p, RELA_EINVAL, "rela_lstmnet_load: bad arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  DeviceGuard g(n->device);
+  const int A = n->num_action;
+  const size_t cnt[14] = {32 * 256, 32, 64 * 512, 64, 64 * 576, 64, (size_t)2048 * 3136, (size_t)2048 * 512, 2048, 2048,
+                          512, 1, (size_t)A * 512, (size_t)A};
+  const float* src[14] = {p->conv1_w, p->conv1_b, p->conv2_w, p->conv2_b, p->conv3_w, p->conv3_b, p->w_ih,
+                          p->w_hh,    p->b_ih,    p->b_hh,    p->v_w,     p->v_b,     p->a_w,     p->a_b};
+  const float* dv[14];
+  float* tmp = nullptr;
+  if (on_device) {
+    for (int i = 0; i < 14; ++i) {
+      RELA_CHECK(src[i], RELA_EINVAL, "rela_lstmnet_load: parameter %d is NULL", i);
+      dv[i] = src[i];
+    }
+  } else {
+    size_t total = 0;
+    for (int i = 0; i < 14; ++i) total += cnt[i];
+    RELA_HIP(hipMalloc(&tmp, sizeof(float) * total));
+    size_t off = 0;
+    for (int i = 0; i < 14; ++i) {
+      RELA_CHECK(src[i], RELA_EINVAL, "rela_lstmnet_load: parameter %d is NULL", i);
+      RELA_HIP(hipMemcpyAsync(tmp + off, src[i], sizeof(float) * cnt[i], hipMemcpyHostToDevice, s));
+      dv[i] = tmp + off;
+      off += cnt[i];
+    }
+  }
+  auto pack = [&](int mode, const float* w, const float* w2, float* frag, int CT, int KS) {
+    const int64_t total = (int64_t)CT * KS * 64;
+    hipLaunchKernelGGL(pack_frags, dim3(ceil_div(total, 256)), dim3(256), 0, s, mode, w, w2, A, frag, CT, KS);
+  };
+  hipLaunchKernelGGL(pack_conv1_bf16x3, dim3(ceil_div(2 * 8 * 64 * 8, 256)), dim3(256), 0, s, dv[0],
+                     reinterpret_cast<uint16_t*>(n->d.B1));
+  pack(kPackConv2, dv[2], nullptr, n->d.B2, 4, 128);
+  pack(kPackConv3, dv[4], nullptr, n->d.B3, 4, 144);
+  pack(kPackLstm, dv[6], dv[7], n->Bl, GemmLstm::CT, GemmLstm::KS);
+  pack(kPackHeads, dv[12], dv[10], n->d.Bh, 2, 128);
+  RELA_HIP(hipMemcpyAsync(n->d.b1, dv[1], sizeof(float) * 32, hipMemcpyDeviceToDevice, s));
+  RELA_HIP(hipMemcpyAsync(n->d.b2, dv[3], sizeof(float) * 64, hipMemcpyDeviceToDevice, s));
+  RELA_HIP(hipMemcpyAsync(n->d.b3, dv[5], sizeof(float) * 64, hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(pack_lstm_bias, dim3(8), dim3(256), 0, s, dv[8], dv[9], n->bl);
+  hipLaunchKernelGGL(pack_head_bias, dim3(1), dim3(64), 0, s, dv[13], dv[11], A, n->d.bh);
+  RELA_LAUNCH_CHECK();
+  if (tmp) {
+    RELA_HIP(hipStreamSynchronize(s));
+    (void)hipFree(tmp);
+  }
+  n->loaded = true;
+  return RELA_OK;
+}
+
+extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_dev, const float* legal_dev,
+                                 const float* h_in, const float* c_in, float* h_out, float* c_out, float* q_dev,
+                                 float* adv_dev, void* ws, int64_t ws_bytes, void* stream_) {
+  RELA_CHECK(n && n->loaded, RELA_ESTATE, "rela_lstmnet_step: parameters were never loaded");
+  RELA_CHECK(N >= 1 && s_dev && legal_dev && h_in && c_in && h_out && c_out && ws, RELA_EINVAL,
+             "rela_lstmnet_step: bad arguments");
+  RELA_CHECK(h_in != h_out && c_in != c_out, RELA_EINVAL, "rela_lstmnet_step: state may not be updated in place");
+  RELA_CHECK(ws_bytes >= rela_lstmnet_workspace_bytes(n, N), RELA_EINVAL,
+             "rela_lstmnet_step: workspace of %lld bytes is too small for batch %d", (long long)ws_bytes, N);
+  RELA_CHECK(((uintptr_t)s_dev & 15) == 0 && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)h_in & 15) == 0, RELA_EINVAL,
+             "rela_lstmnet_step: s_dev, h_in and workspace must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream_;
+  float* a1 = static_cast<float*>(ws);
+  float* a2 = a1 + kA1 * N;
+  float* a3 = a2 + kA2 * N;
+  float* ha = a3 + kA3 * N;
+  const FFNetDev& d = n->d;
+  {
+    ProfScope prof("conv1_bf16x3", s);
+    hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
+                       d.b1, a1, N);
+  }
+  {
+    ProfScope prof("conv2_mfma", s);
+    hipLaunchKernelGGL(conv_mfma<Conv2>, dim3(ceil_div(N, Conv2::S)), dim3(kThreads), Conv2::LDS_BYTES, s,
+                       (const void*)a1, d.B2, d.b2, a2, N);
+  }
+  {
+    ProfScope prof("conv3_mfma", s);
+    hipLaunchKernelGGL(conv_mfma<Conv3>, dim3(ceil_div(N, Conv3::S)), dim3(kThreads), Conv3::LDS_BYTES, s,
+                       (const void*)a2, d.B3, d.b3, a3, N);
+  }
+  {
+    ProfScope prof("lstm_gates_mfma", s);
+    hipLaunchKernelGGL(gemm_mfma<GemmLstm>, dim3(GemmLstm::CT / GemmLstm::CTB, ceil_div(N, GemmLstm::BM)),
+                       dim3(kThreads), 0, s, (const float*)a3, h_in, (const float*)n->Bl, (const float*)n->bl, h_out,
+                       c_in, c_out, N);
+  }
+  if (q_dev || adv_dev) {
+    {
+      ProfScope prof("heads_mfma", s);
+      hipLaunchKernelGGL(gemm_mfma<GemmHeads>, dim3(GemmHeads::CT / GemmHeads::CTB, ceil_div(N, GemmHeads::BM)),
+                         dim3(kThreads), 0, s, (const float*)h_out, (const float*)nullptr, (const float*)d.Bh,
+                         (const float*)d.bh, ha, (const float*)nullptr, (float*)nullptr, N);
+    }
+    {
+      ProfScope prof("dueling", s);
+      hipLaunchKernelGGL(dueling_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, (const float*)ha, legal_dev, q_dev,
+                         adv_dev, N, n->num_action);
+    }
   }
   RELA_LAUNCH_CHECK();
   return RELA_OK;

@@ -46,3 +46,50 @@ class AtariFFNet(nn.Module):
         feat = self.net(x).flatten(1)
         hid = self.linear(feat)
         return dueling_q(self.fc_v(hid), self.fc_a(hid), obs["legal_move"], 1)
+
+
+class AtariLSTMNet(nn.Module):
+    """R2D2 network: conv trunk -> one LSTM layer (3136 -> 512) -> dueling heads.
+
+    Parameter contract = the reference's AtariLSTMNet state_dict (pyrela/net.py:69-84; SURVEY 8a
+    N2): net.{0,2,4}.*, lstm.{weight_ih_l0 (2048,3136), weight_hh_l0 (2048,512), bias_ih_l0,
+    bias_hh_l0 (2048)}, fc_v.*, fc_a.*; torch gate order i,f,g,o.
+    """
+
+    def __init__(self, device, num_action: int):
+        super().__init__()
+        self.num_action = num_action
+        self.net = _conv_trunk()
+        self.lstm = nn.LSTM(FLAT, HIDDEN, num_layers=1).to(device)
+        self.fc_v = nn.Linear(HIDDEN, 1)
+        self.fc_a = nn.Linear(HIDDEN, num_action)
+
+    def get_h0(self, batchsize: int) -> Dict[str, torch.Tensor]:
+        z = torch.zeros(1, batchsize, HIDDEN)
+        return {"h0": z, "c0": z.clone()}
+
+    def _features(self, s: torch.Tensor) -> torch.Tensor:
+        return self.net(s.float() / 255.0).flatten(1)
+
+    def act(self, obs: Dict[str, torch.Tensor], hid: Dict[str, torch.Tensor]):
+        """One step; ranks the raw ADVANTAGES shifted by their batch minimum (net.py:110-124)."""
+        x = self._features(obs["s"]).unsqueeze(0)
+        o, (h, c) = self.lstm(x, (hid["h0"], hid["c0"]))
+        adv = self.fc_a(o).squeeze(0)
+        greedy = ((1 + adv - adv.min()) * obs["legal_move"]).argmax(1)
+        return greedy.detach(), {"h0": h.detach(), "c0": c.detach()}
+
+    def unroll_rnn(self, obs: Dict[str, torch.Tensor], hid: Dict[str, torch.Tensor]):
+        s = obs["s"]
+        seq, batch = s.shape[:2]
+        x = self._features(s.reshape(seq * batch, *s.shape[2:])).view(seq, batch, FLAT)
+        o, (h, c) = self.lstm(x, (hid["h0"], hid["c0"]))
+        return o, {"h0": h, "c0": c}
+
+    def forward(self, obs, hid, action):
+        """-> (Q(s_t, a_t) [seq,batch], greedy action [seq,batch]) for a [seq,batch,...] unroll."""
+        o, _ = self.unroll_rnn(obs, hid)
+        q = dueling_q(self.fc_v(o), self.fc_a(o), obs["legal_move"], 2)
+        qa = q.gather(2, action.unsqueeze(2)).squeeze(2)
+        greedy = ((1 + q - q.min()) * obs["legal_move"]).argmax(2)
+        return qa, greedy.detach()

@@ -1,0 +1,79 @@
+"""GPU parity of the AtariLSTMNet step (conv trunk -> fused LSTM gates/cell GEMM -> heads) against
+a plain PyTorch fp32 forward of the same architecture (rela_amd/pyrela/net.py, itself checked to
+be identical to the reference's pyrela/net.py).  Tolerance 1e-4 abs+rel."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ["net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
+        "lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0", "fc_v.weight", "fc_v.bias",
+        "fc_a.weight", "fc_a.bias"]
+
+
+class GpuLstmNet:
+    def __init__(self, params, A):
+        from rela_amd import _capi as capi
+
+        self.capi, self.A = capi, A
+        h = C.c_void_p()
+        capi.check(capi.lib.rela_lstmnet_create(C.byref(h), A, 0), "rela_lstmnet_create")
+        self.h = h
+        p = capi.LSTMNetParams()
+        keep = []
+        for (field, _), k in zip(capi.LSTMNetParams._fields_, KEYS):
+            a = np.ascontiguousarray(params[k], np.float32)
+            keep.append(a)
+            setattr(p, field, a.ctypes.data_as(C.c_void_p))
+        capi.check(capi.lib.rela_lstmnet_load(h, C.byref(p), 0, None), "rela_lstmnet_load")
+
+    def step(self, s, legal, h_in, c_in):
+        import torch
+
+        from gpu_util import cur_stream, dev, ptr
+
+        n = s.shape[0]
+        d = [dev(x) for x in (s, legal, h_in, c_in)]
+        h_out, c_out = torch.empty((n, 512), device="cuda"), torch.empty((n, 512), device="cuda")
+        q, adv = torch.empty((n, self.A), device="cuda"), torch.empty((n, self.A), device="cuda")
+        nb = self.capi.lib.rela_lstmnet_workspace_bytes(self.h, n)
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        self.capi.check(self.capi.lib.rela_lstmnet_step(self.h, n, ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(h_out),
+                                                        ptr(c_out), ptr(q), ptr(adv), ptr(ws), nb, cur_stream()), "step")
+        torch.cuda.synchronize()
+        return h_out.cpu().numpy(), c_out.cpu().numpy(), q.cpu().numpy(), adv.cpu().numpy()
+
+    def close(self):
+        self.capi.lib.rela_lstmnet_destroy(self.h)
+
+
+@pytest.mark.parametrize("N,A", [(1, 18), (5, 6), (80, 18), (131, 18)])
+def test_lstm_step_vs_torch(N, A):
+    import torch
+
+    from rela_amd.pyrela.net import AtariLSTMNet, dueling_q
+    from synth import synth_lstm_params, synth_obs
+
+    p = synth_lstm_params(A, 40 + A)
+    net = GpuLstmNet(p, A)
+    rng = np.random.default_rng(N)
+    s = synth_obs(N, 500 + N)
+    legal = (rng.uniform(size=(N, A)) < 0.85).astype(np.float32)
+    h_in = rng.normal(0, 0.3, (N, 512)).astype(np.float32)
+    c_in = rng.normal(0, 0.5, (N, 512)).astype(np.float32)
+    h, c, q, adv = net.step(s, legal, h_in, c_in)
+    ref = AtariLSTMNet("cpu", A)
+    ref.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
+    with torch.no_grad():
+        x = ref._features(torch.from_numpy(s)).unsqueeze(0)
+        o, (hr, cr) = ref.lstm(x, (torch.from_numpy(h_in).unsqueeze(0), torch.from_numpy(c_in).unsqueeze(0)))
+        adv_r = ref.fc_a(o).squeeze(0)
+        q_r = dueling_q(ref.fc_v(o), ref.fc_a(o), torch.from_numpy(legal).unsqueeze(0), 2).squeeze(0)
+    tol = dict(rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(h, hr.squeeze(0).numpy(), **tol)
+    np.testing.assert_allclose(c, cr.squeeze(0).numpy(), **tol)
+    np.testing.assert_allclose(adv, adv_r.numpy(), **tol)
+    np.testing.assert_allclose(q, q_r.numpy(), **tol)
+    net.close()
