@@ -61,6 +61,26 @@ void rela_replay_destroy(rela_replay* r);
  * f being row_bytes[f] bytes (FFTransition: types.h:18-51; RNNTransition: types.h:53-73).  */
 int rela_replay_set_schema(rela_replay* r, int nfields, const int64_t* row_bytes);
 
+/* Sequence layout (RNNTransition, rela/types.h:53-73): like set_schema, but a field with
+ * steps[f] = T > 1 is a sequence of T equal sub-rows and is gathered TIME-MAJOR on sample,
+ * out[(t*batch + b)] = slot_b[t], i.e. RNNTransition::makeBatch's stack along dim 1
+ * (rela/types.cc:140-182).  steps[f] = 1 keeps the plain [batch][row] layout.               */
+int rela_replay_set_schema_seq(rela_replay* r, int nfields, const int64_t* row_bytes,
+                               const int32_t* steps);
+
+/* blockAppend in its three phases (prioritized_replay.h:43-78), for producers that assemble a
+ * block piecewise (the R2D2 actor emits several sequences per pop):
+ *   begin  :46-56  reserve n slots (blocks while the ring is full unless nonblocking)
+ *   write  :61-66  copy rows into reserved slots [first_slot+offset, +count)
+ *   commit :69-76  wait for in-order commit, then store pow(priority, alpha), add the FLOAT block
+ *                  sum to sum_, and make the block visible to sample().
+ * rela_replay_add is begin + write + commit.                                               */
+int rela_replay_begin_add(rela_replay* r, int n, int nonblocking, int* first_slot);
+int rela_replay_write_rows(rela_replay* r, int first_slot, int offset, int count,
+                           const void* const* rows_dev, void* stream);
+int rela_replay_commit_add(rela_replay* r, int first_slot, int n, const float* priority_dev,
+                           void* stream);
+
 /* add(sample, priority)  prioritized_replay.h:186-200 -> blockAppend :43-78.
  * rows_dev[f] points at n consecutive rows of field f (device); priority_dev is f32[n]
  * (device).  Weights are pow(priority, alpha) (:188).  Blocks while the ring cannot take n
@@ -246,6 +266,39 @@ int64_t rela_apex_actor_num_act(const rela_apex_actor* a); /* numAct()  dqn_acto
 /* diagnostic: device pointers of the last Q table of act() and of the last priorities       */
 const float* rela_apex_actor_last_q_dev(const rela_apex_actor* a);
 const float* rela_apex_actor_last_priority_dev(const rela_apex_actor* a);
+
+/* ===================================================================================
+ * R2D2 actor shard  --  R2D2Actor + R2D2TransitionBuffer + MultiStepTransitionBuffer,
+ * rela/r2d2_actor.h:10-353.  Per env: the n-step ring of the Ape-X shard, the recurrent state
+ * with its history (historyHidden_ :345), and one window of burn_in + seq_len + multi_step slots
+ * per field in HBM laid out as one replay row, so emitting a sequence is a row copy.  `eta` is
+ * the max/mean mixing weight of aggregate_priority (pyrela/r2d2.py:103-120), a model constant in
+ * the reference.  The replay must use the 10-field sequence schema
+ *   s[T*28224] eps[T*4] legal_move[T*4A] a[T*8] reward[T*4] terminal[T] bootstrap[T*4]
+ *   h0[2048] c0[2048] seq_len[4]          (RNNTransition, rela/types.h:53-73; T = window length)
+ * =================================================================================== */
+typedef struct rela_r2d2_actor rela_r2d2_actor;
+
+int rela_r2d2_actor_create(rela_r2d2_actor** out, int rows, int group_rows, int num_action,
+                           int multi_step, float gamma, int seq_len, int burn_in, double eta,
+                           rela_replay* replay, uint64_t seed, int device);
+void rela_r2d2_actor_destroy(rela_r2d2_actor* a);
+void* rela_r2d2_actor_obs_slot(rela_r2d2_actor* a);
+/* R2D2Actor::act  r2d2_actor.h:221-249; arguments as rela_apex_actor_act */
+int rela_r2d2_actor_act(rela_r2d2_actor* a, const rela_lstmnet* online, const uint8_t* obs_host,
+                        const float* eps_host, const float* legal_host, int64_t* action_host,
+                        const int64_t** action_dev_out, void* stream);
+/* setRewardAndTerminal + postStep  r2d2_actor.h:252-302.  reward/terminal are HOST arrays (the
+ * window bookkeeping branches on the terminal flags).  *n_sequences (may be NULL) = sequences
+ * appended to the replay by this call.                                                      */
+int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward_host,
+                              const uint8_t* terminal_host, const rela_lstmnet* online,
+                              const rela_lstmnet* target, int nonblocking, int* n_sequences,
+                              void* stream);
+int64_t rela_r2d2_actor_num_act(const rela_r2d2_actor* a);
+/* diagnostics: current recurrent state (which = 0: h, 1: c) f32[rows,512]; last step priorities */
+const float* rela_r2d2_actor_hidden_dev(const rela_r2d2_actor* a, int which);
+const float* rela_r2d2_actor_last_priority_dev(const rela_r2d2_actor* a);
 
 /* ===================================================================================
  * Live per-kernel timing (HIP events on the launch stream) for bench.py's roofline line.

@@ -64,6 +64,10 @@ _sig("rela_stream_synchronize", i32, [vp, i32])
 _sig("rela_replay_create", i32, [P(vp), i32, i32, f32, f32, i32, i32])
 _sig("rela_replay_destroy", None, [vp])
 _sig("rela_replay_set_schema", i32, [vp, i32, P(i64)])
+_sig("rela_replay_set_schema_seq", i32, [vp, i32, P(i64), P(C.c_int32)])
+_sig("rela_replay_begin_add", i32, [vp, i32, i32, P(i32)])
+_sig("rela_replay_write_rows", i32, [vp, i32, i32, i32, P(vp), vp])
+_sig("rela_replay_commit_add", i32, [vp, i32, i32, vp, vp])
 _sig("rela_replay_add", i32, [vp, i32, P(vp), vp, i32, vp])
 _sig("rela_replay_sample", i32, [vp, i32, P(vp), vp, vp])
 _sig("rela_replay_update_priority", i32, [vp, i32, vp, i32, vp])
@@ -97,6 +101,14 @@ _sig("rela_apex_actor_post_step", i32, [vp, vp, vp, i32, vp, vp, i32, P(i32), vp
 _sig("rela_apex_actor_num_act", i64, [vp])
 _sig("rela_apex_actor_last_q_dev", vp, [vp])
 _sig("rela_apex_actor_last_priority_dev", vp, [vp])
+_sig("rela_r2d2_actor_create", i32, [P(vp), i32, i32, i32, i32, f32, i32, i32, f64, vp, u64, i32])
+_sig("rela_r2d2_actor_destroy", None, [vp])
+_sig("rela_r2d2_actor_obs_slot", vp, [vp])
+_sig("rela_r2d2_actor_act", i32, [vp, vp, vp, vp, vp, vp, P(vp), vp])
+_sig("rela_r2d2_actor_post_step", i32, [vp, vp, vp, vp, vp, i32, P(i32), vp])
+_sig("rela_r2d2_actor_num_act", i64, [vp])
+_sig("rela_r2d2_actor_hidden_dev", vp, [vp, i32])
+_sig("rela_r2d2_actor_last_priority_dev", vp, [vp])
 _sig("rela_prof_enable", i32, [i32])
 _sig("rela_prof_summary_json", i32, [C.c_char_p, i64])
 

@@ -103,13 +103,16 @@ __global__ __launch_bounds__(kThreads) void replay_scatter_rows(const uint8_t* _
 }
 
 // gathers batch rows of one field: out[i] = field[ids[i]]   (makeBatch, types.cc:8-46)
+// `steps` > 1: the row is a sequence of `steps` sub-rows and the output is time-major,
+// out[t][b] = slot_b[t]  (RNNTransition::makeBatch, types.cc:140-182)
 __global__ __launch_bounds__(kThreads) void replay_gather_rows(const uint8_t* __restrict__ field,
                                                                const int32_t* __restrict__ ids,
-                                                               uint8_t* __restrict__ out, int64_t row_bytes,
-                                                               int vec16) {
-  const int row = blockIdx.y;
-  const uint8_t* s = field + (int64_t)ids[row] * row_bytes;
-  uint8_t* d = out + (int64_t)row * row_bytes;
+                                                               uint8_t* __restrict__ out, int64_t slot_bytes,
+                                                               int steps, int batch, int vec16) {
+  const int b = blockIdx.y % batch, t = blockIdx.y / batch;
+  const int64_t row_bytes = slot_bytes / steps;
+  const uint8_t* s = field + (int64_t)ids[b] * slot_bytes + (int64_t)t * row_bytes;
+  uint8_t* d = out + ((int64_t)t * batch + b) * row_bytes;
   if (vec16) {
     const int64_t nv = row_bytes >> 4;
     const uint4* s4 = reinterpret_cast<const uint4*>(s);
@@ -216,6 +219,7 @@ __global__ __launch_bounds__(1024) void replay_update(const float* __restrict__ 
   __shared__ float neww[kMaxBatch];
   __shared__ float dlt[kMaxBatch];
   __shared__ int32_t sid[kMaxBatch];
+  __shared__ uint8_t is_last[kMaxBatch];  // separate from sid[]: other lanes are still scanning sid[]
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     neww[i] = pow_alpha(prio[i], alpha);
     sid[i] = ids[i];
@@ -243,12 +247,12 @@ __global__ __launch_bounds__(1024) void replay_update(const float* __restrict__ 
       last = false;
     }
     dlt[i] = d;
-    // all reads of w[] above must finish before anyone writes: writes happen after the barrier
-    sid[i] = last ? id : -1 - id;
+    is_last[i] = last ? 1 : 0;
   }
+  // all reads of w[] above must finish before anyone writes: writes happen after the barrier
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += blockDim.x)
-    if (sid[i] >= 0) w[sid[i]] = neww[i];
+    if (is_last[i]) w[sid[i]] = neww[i];
   if (threadIdx.x == 0) {
     double diff = 0;
     for (int i = 0; i < n; ++i) diff += (double)dlt[i];  // evicted ids contribute +0.0f (a no-op)
@@ -269,6 +273,8 @@ struct rela_replay {
   mutable std::mutex m;
   std::condition_variable cv_size;
   int head = 0, tail = 0, size = 0;
+  int safe_tail = 0, safe_size = 0;  // committed prefix, ConcurrentQueue::safeTail_/safeSize_
+  std::condition_variable cv_tail;
   std::atomic<int64_t> num_add{0};
   int n_sampled = 0;
   hipStream_t stream = nullptr;
@@ -283,6 +289,7 @@ struct rela_replay {
   uint32_t* d_draws = nullptr;
   float* d_prio = nullptr;  // staging for host-side priorities
   std::vector<int64_t> row_bytes;
+  std::vector<int32_t> steps;  // sub-rows per slot (1 = plain field)
   std::vector<uint8_t*> d_fields;
   SeqIndex ix;
 };
@@ -351,7 +358,15 @@ extern "C" void rela_replay_destroy(rela_replay* r) {
   delete r;
 }
 
+extern "C" int rela_replay_set_schema_seq(rela_replay* r, int nfields, const int64_t* row_bytes,
+                                          const int32_t* steps);
+
 extern "C" int rela_replay_set_schema(rela_replay* r, int nfields, const int64_t* row_bytes) {
+  return rela_replay_set_schema_seq(r, nfields, row_bytes, nullptr);
+}
+
+extern "C" int rela_replay_set_schema_seq(rela_replay* r, int nfields, const int64_t* row_bytes,
+                                          const int32_t* steps) {
   RELA_CHECK(r && nfields >= 0 && (nfields == 0 || row_bytes), RELA_EINVAL, "rela_replay_set_schema: bad arguments");
   std::lock_guard<std::mutex> lk(r->m);
   RELA_CHECK(r->d_fields.empty() && r->num_add.load() == 0, RELA_ESTATE,
@@ -362,8 +377,12 @@ extern "C" int rela_replay_set_schema(rela_replay* r, int nfields, const int64_t
                (long long)row_bytes[f]);
     uint8_t* p = nullptr;
     RELA_HIP(hipMalloc(&p, (size_t)row_bytes[f] * (size_t)r->ring));
+    const int st = steps ? steps[f] : 1;
+    RELA_CHECK(st >= 1 && row_bytes[f] % st == 0, RELA_EINVAL, "rela_replay_set_schema: field %d: %lld bytes not divisible into %d steps",
+               f, (long long)row_bytes[f], st);
     r->d_fields.push_back(p);
     r->row_bytes.push_back(row_bytes[f]);
+    r->steps.push_back(st);
   }
   return RELA_OK;
 }
@@ -372,46 +391,88 @@ static inline int vec16_ok(const void* a, const void* b, int64_t row_bytes) {
   return ((row_bytes & 15) == 0) && (((uintptr_t)a & 15) == 0) && (((uintptr_t)b & 15) == 0);
 }
 
-extern "C" int rela_replay_add(rela_replay* r, int n, const void* const* rows_dev, const float* priority_dev,
-                               int nonblocking, void* stream_) {
-  RELA_CHECK(r && n > 0 && priority_dev, RELA_EINVAL, "rela_replay_add: bad arguments");
-  RELA_CHECK(n <= r->ring, RELA_EINVAL, "rela_replay_add: block of %d exceeds the ring (%d)", n, r->ring);
-  RELA_CHECK(r->d_fields.empty() || rows_dev, RELA_EINVAL, "rela_replay_add: rows_dev is NULL");
-  hipStream_t producer = (hipStream_t)stream_;
-  DeviceGuard g(r->device);
+extern "C" int rela_replay_begin_add(rela_replay* r, int n, int nonblocking, int* first_slot) {
+  RELA_CHECK(r && n > 0 && first_slot, RELA_EINVAL, "rela_replay_begin_add: bad arguments");
+  RELA_CHECK(n <= r->ring, RELA_EINVAL, "rela_replay_begin_add: block of %d exceeds the ring (%d)", n, r->ring);
   std::unique_lock<std::mutex> lk(r->m);
   if (r->size + n > r->ring) {  // cvSize_.wait :47
     if (nonblocking) return RELA_EWOULDBLOCK;
     r->cv_size.wait(lk, [&] { return r->size + n <= r->ring; });
   }
-  const int start = r->tail;
+  *first_slot = r->tail;
   r->tail = (r->tail + n) % r->ring;
   r->size += n;
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_write_rows(rela_replay* r, int first_slot, int offset, int count,
+                                      const void* const* rows_dev, void* stream_) {
+  RELA_CHECK(r && count > 0 && offset >= 0 && first_slot >= 0 && first_slot < r->ring, RELA_EINVAL,
+             "rela_replay_write_rows: bad arguments");
+  RELA_CHECK(r->d_fields.empty() || rows_dev, RELA_EINVAL, "rela_replay_write_rows: rows_dev is NULL");
+  hipStream_t producer = (hipStream_t)stream_;
+  DeviceGuard g(r->device);
+  std::lock_guard<std::mutex> lk(r->m);
+  const int start = (int)(((int64_t)first_slot + offset) % r->ring);
   // order after the producer's queued work, run on the replay stream, then let the producer
   // continue only after its rows were consumed
   RELA_HIP(hipEventRecord(r->ev_in, producer));
   RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
-  {
-    ProfScope prof("replay_append_weights", r->stream);
-    hipLaunchKernelGGL(replay_append_weights, dim3(1), dim3(kThreads), 0, r->stream, priority_dev, n, r->alpha,
-                       r->d_w, r->ring, start, r->d_state);
-  }
   for (size_t f = 0; f < r->d_fields.size(); ++f) {
+    if (!rows_dev[f]) continue;
     const int64_t rb = r->row_bytes[f];
     const int v16 = vec16_ok(rows_dev[f], r->d_fields[f], rb);
     const int64_t units = v16 ? (rb >> 4) : rb;
     int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (units + kThreads - 1) / kThreads), 64);
     {
       ProfScope prof("replay_scatter_rows", r->stream);
-      hipLaunchKernelGGL(replay_scatter_rows, dim3(gx, std::min(n, 32768)), dim3(kThreads), 0, r->stream,
-                         (const uint8_t*)rows_dev[f], r->d_fields[f], rb, n, r->ring, start, v16);
+      hipLaunchKernelGGL(replay_scatter_rows, dim3(gx, std::min(count, 32768)), dim3(kThreads), 0, r->stream,
+                         (const uint8_t*)rows_dev[f], r->d_fields[f], rb, count, r->ring, start, v16);
     }
   }
   RELA_LAUNCH_CHECK();
   RELA_HIP(hipEventRecord(r->ev_out, r->stream));
   RELA_HIP(hipStreamWaitEvent(producer, r->ev_out, 0));
-  r->num_add += n;  // :190
   return RELA_OK;
+}
+
+extern "C" int rela_replay_commit_add(rela_replay* r, int first_slot, int n, const float* priority_dev,
+                                      void* stream_) {
+  RELA_CHECK(r && n > 0 && priority_dev, RELA_EINVAL, "rela_replay_commit_add: bad arguments");
+  hipStream_t producer = (hipStream_t)stream_;
+  DeviceGuard g(r->device);
+  std::unique_lock<std::mutex> lk(r->m);
+  r->cv_tail.wait(lk, [&] { return r->safe_tail == first_slot; });  // in-order commit :69
+  RELA_HIP(hipEventRecord(r->ev_in, producer));
+  RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
+  {
+    ProfScope prof("replay_append_weights", r->stream);
+    hipLaunchKernelGGL(replay_append_weights, dim3(1), dim3(kThreads), 0, r->stream, priority_dev, n, r->alpha,
+                       r->d_w, r->ring, first_slot, r->d_state);
+  }
+  RELA_LAUNCH_CHECK();
+  RELA_HIP(hipEventRecord(r->ev_out, r->stream));
+  RELA_HIP(hipStreamWaitEvent(producer, r->ev_out, 0));
+  r->safe_tail = (first_slot + n) % r->ring;  // :70-73
+  r->safe_size += n;
+  r->num_add += n;  // :190
+  lk.unlock();
+  r->cv_tail.notify_all();
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_add(rela_replay* r, int n, const void* const* rows_dev, const float* priority_dev,
+                               int nonblocking, void* stream_) {
+  RELA_CHECK(r && n > 0 && priority_dev, RELA_EINVAL, "rela_replay_add: bad arguments");
+  RELA_CHECK(r->d_fields.empty() || rows_dev, RELA_EINVAL, "rela_replay_add: rows_dev is NULL");
+  int slot = 0;
+  int rc = rela_replay_begin_add(r, n, nonblocking, &slot);
+  if (rc != RELA_OK) return rc;
+  if (!r->d_fields.empty()) {
+    rc = rela_replay_write_rows(r, slot, 0, n, rows_dev, stream_);
+    if (rc != RELA_OK) return rc;
+  }
+  return rela_replay_commit_add(r, slot, n, priority_dev, stream_);
 }
 
 extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_rows_dev, float* out_weight_dev,
@@ -423,7 +484,7 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
   std::unique_lock<std::mutex> lk(r->m);
   RELA_CHECK(r->n_sampled == 0, RELA_ESTATE,
              "Error: previous samples' priority has not been updated.");  // :203-206
-  RELA_CHECK(r->size > 0, RELA_ESTATE, "rela_replay_sample: replay is empty");
+  RELA_CHECK(r->safe_size > 0, RELA_ESTATE, "rela_replay_sample: replay is empty");
   // raw 32-bit draws, one per sample (generate_canonical<float,24> consumes exactly one)
   std::vector<uint32_t> draws(batch);
   for (int i = 0; i < batch; ++i) draws[i] = (uint32_t)r->rng();
@@ -431,7 +492,7 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
   RELA_HIP(hipEventRecord(r->ev_in, consumer));
   RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
   RELA_HIP(hipMemcpyAsync(r->d_draws, draws.data(), sizeof(uint32_t) * batch, hipMemcpyHostToDevice, r->stream));
-  const int size = r->size;  // == safeSize_: reservation and commit are one step here
+  const int size = r->safe_size;  // storage_ [0, safeSize) is static during the scan :261-263
   SeqView v;
   int rc = seq_index_build(r->ix, r->d_w, r->ring, r->head, size, r->stream, &v);
   if (rc != RELA_OK) return rc;
@@ -445,8 +506,10 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
     hipLaunchKernelGGL(replay_search, dim3(ceil_div(batch, 64)), dim3(64), 0, r->stream, v, r->d_eff, batch,
                        r->d_ids, r->d_raw_w, r->d_evicted, r->d_state);
   }
-  // pop storage if full :311-315 (size re-read, then IS weights use the pre-pop size :321)
-  const int n_pop = size > r->capacity ? size - r->capacity : 0;
+  // pop storage if full :311-315: `size` is re-read as size_ (reserved blocks included), and the
+  // IS weights below use that value (:312,321).  Only committed slots can be evicted.
+  const int full_size = r->size;
+  const int n_pop = full_size > r->capacity ? std::min(full_size - r->capacity, size) : 0;
   if (n_pop > 0) {
     {
       ProfScope prof("replay_pop", r->stream);
@@ -455,6 +518,7 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
     }
     r->head = (r->head + n_pop) % r->ring;
     r->size -= n_pop;
+    r->safe_size -= n_pop;
   }
   {
     ProfScope prof("replay_is_weights", r->stream);
@@ -465,13 +529,15 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
     for (size_t f = 0; f < r->d_fields.size(); ++f) {
       if (!out_rows_dev[f]) continue;
       const int64_t rb = r->row_bytes[f];
-      const int v16 = vec16_ok(out_rows_dev[f], r->d_fields[f], rb);
-      const int64_t units = v16 ? (rb >> 4) : rb;
+      const int st = r->steps[f];
+      const int64_t sub = rb / st;
+      const int v16 = vec16_ok(out_rows_dev[f], r->d_fields[f], sub) && (rb % 16 == 0);
+      const int64_t units = v16 ? (sub >> 4) : sub;
       int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (units + kThreads - 1) / kThreads), 64);
       {
         ProfScope prof("replay_gather_rows", r->stream);
-        hipLaunchKernelGGL(replay_gather_rows, dim3(gx, batch), dim3(kThreads), 0, r->stream, r->d_fields[f],
-                           r->d_ids, (uint8_t*)out_rows_dev[f], rb, v16);
+        hipLaunchKernelGGL(replay_gather_rows, dim3(gx, batch * st), dim3(kThreads), 0, r->stream, r->d_fields[f],
+                           r->d_ids, (uint8_t*)out_rows_dev[f], rb, st, batch, v16);
       }
     }
   }
@@ -517,7 +583,7 @@ extern "C" int rela_replay_update_priority(rela_replay* r, int n, const float* p
 extern "C" int rela_replay_size(const rela_replay* r) {
   if (!r) return 0;
   std::lock_guard<std::mutex> lk(r->m);
-  return r->size;
+  return r->safe_size;  // safeSize(nullptr) :245-247
 }
 
 extern "C" int64_t rela_replay_num_add(const rela_replay* r) { return r ? r->num_add.load() : 0; }
@@ -539,7 +605,7 @@ extern "C" int rela_replay_debug_state(rela_replay* r, rela_replay_state* out, i
   out->head = r->head;
   out->tail = r->tail;
   out->size = r->size;
-  out->safe_size = r->size;
+  out->safe_size = r->safe_size;
   out->ring = r->ring;
   out->n_sampled = n;
   out->num_add = r->num_add.load();

@@ -141,10 +141,12 @@ class Actor {
 // =====================================================================================
 class ModelLocker {
  public:
+  enum Kind { kFF = 0, kLSTM = 1 };
   struct Lease {
     int id;
-    const rela_ffnet* online;
-    const rela_ffnet* target;
+    Kind kind;
+    const void* online;  // rela_ffnet* or rela_lstmnet*
+    const void* target;
   };
 
   ModelLocker(std::vector<py::object> pyModels, const std::string& device)
@@ -154,12 +156,13 @@ class ModelLocker {
     online_.assign(n, nullptr);
     target_.assign(n, nullptr);
     inFlight_.assign(n, 0);
+    if (py::hasattr(pyModels_[0], "eta")) eta_ = pyModels_[0].attr("eta").cast<double>();
     if (deviceIndex >= 0) loadSlot(0, pyModels_[0]);
   }
 
   ~ModelLocker() {
-    for (auto* p : online_) rela_ffnet_destroy(p);
-    for (auto* p : target_) rela_ffnet_destroy(p);
+    for (auto* p : online_) destroyNet(p);
+    for (auto* p : target_) destroyNet(p);
   }
 
   void updateModel(py::object pyModel) {
@@ -183,7 +186,7 @@ class ModelLocker {
       throw std::runtime_error("ModelLocker('cpu'): this engine has no CPU actor path; use a cuda device");
     std::lock_guard<std::mutex> lk(m_);
     ++inFlight_[latest_];
-    return Lease{latest_, online_[latest_], target_[latest_]};
+    return Lease{latest_, kind_, online_[latest_], target_[latest_]};
   }
 
   void releaseModel(int id) {
@@ -192,40 +195,64 @@ class ModelLocker {
   }
 
   int numAction() const { return numAction_; }
+  Kind kind() const { return kind_; }
+  double eta() const { return eta_; }
 
   const std::string device;
   const int deviceIndex;
 
  private:
-  static const char* const* keys() {
-    static const char* k[12] = {"net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias",
-                                "net.4.weight", "net.4.bias", "linear.0.weight", "linear.0.bias",
-                                "fc_v.weight",  "fc_v.bias",  "fc_a.weight",     "fc_a.bias"};
-    return k;
+  void destroyNet(void* p) {
+    if (!p) return;
+    if (kind_ == kFF) rela_ffnet_destroy(static_cast<rela_ffnet*>(p));
+    else rela_lstmnet_destroy(static_cast<rela_lstmnet*>(p));
   }
 
-  void loadNet(rela_ffnet*& net, py::dict& sd, const std::string& prefix) {
-    std::vector<torch::Tensor> keep;
-    const float* ptr[12];
-    for (int i = 0; i < 12; ++i) {
-      const std::string key = prefix + keys()[i];
-      if (!sd.contains(py::str(key)))
-        throw std::runtime_error("ModelLocker: state_dict has no '" + key +
-                                 "' (only AtariFFNet-shaped agents are supported on this path)");
+  std::vector<torch::Tensor> fetch(py::dict& sd, const std::string& prefix, const std::vector<const char*>& keys) {
+    std::vector<torch::Tensor> out;
+    for (const char* k : keys) {
+      const std::string key = prefix + k;
+      if (!sd.contains(py::str(key))) throw std::runtime_error("ModelLocker: state_dict has no '" + key + "'");
       auto t = sd[py::str(key)].cast<torch::Tensor>().detach();
-      t = t.to(torch::Device(torch::kCUDA, (c10::DeviceIndex)deviceIndex), torch::kFloat32).contiguous();
-      keep.push_back(t);
-      ptr[i] = t.data_ptr<float>();
+      out.push_back(t.to(torch::Device(torch::kCUDA, (c10::DeviceIndex)deviceIndex), torch::kFloat32).contiguous());
     }
-    const int A = (int)keep[10].size(0);
+    return out;
+  }
+
+  void loadNet(void*& net, py::dict& sd, const std::string& prefix) {
+    void* stream = torchCurrentStream(deviceIndex);
+    std::vector<torch::Tensor> t;
+    if (kind_ == kFF) {
+      t = fetch(sd, prefix, {"net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
+                             "linear.0.weight", "linear.0.bias", "fc_v.weight", "fc_v.bias", "fc_a.weight", "fc_a.bias"});
+      const int A = (int)t[10].size(0);
+      checkActions(A);
+      auto* n = static_cast<rela_ffnet*>(net);
+      if (!n) check(rela_ffnet_create(&n, A, deviceIndex), "rela_ffnet_create");
+      net = n;
+      auto f = [&](int i) { return t[i].data_ptr<float>(); };
+      rela_ffnet_params p{f(0), f(1), f(2), f(3), f(4), f(5), f(6), f(7), f(8), f(9), f(10), f(11)};
+      check(rela_ffnet_load(n, &p, 1, stream), "rela_ffnet_load");
+    } else {
+      t = fetch(sd, prefix, {"net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
+                             "lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0",
+                             "fc_v.weight", "fc_v.bias", "fc_a.weight", "fc_a.bias"});
+      const int A = (int)t[12].size(0);
+      checkActions(A);
+      auto* n = static_cast<rela_lstmnet*>(net);
+      if (!n) check(rela_lstmnet_create(&n, A, deviceIndex), "rela_lstmnet_create");
+      net = n;
+      auto f = [&](int i) { return t[i].data_ptr<float>(); };
+      rela_lstmnet_params p{f(0), f(1), f(2), f(3), f(4), f(5), f(6), f(7), f(8), f(9), f(10), f(11), f(12), f(13)};
+      check(rela_lstmnet_load(n, &p, 1, stream), "rela_lstmnet_load");
+    }
+    // the packing kernels read `t` on torch's stream: finish them before the tensors die
+    py::module_::import("torch").attr("cuda").attr("current_stream")(deviceIndex).attr("synchronize")();
+  }
+
+  void checkActions(int A) {
     if (numAction_ == 0) numAction_ = A;
     if (A != numAction_) throw std::runtime_error("ModelLocker: num_action changed between updates");
-    if (!net) check(rela_ffnet_create(&net, A, deviceIndex), "rela_ffnet_create");
-    rela_ffnet_params p{ptr[0], ptr[1], ptr[2], ptr[3], ptr[4], ptr[5], ptr[6], ptr[7], ptr[8], ptr[9], ptr[10], ptr[11]};
-    void* stream = torchCurrentStream(deviceIndex);
-    check(rela_ffnet_load(net, &p, 1, stream), "rela_ffnet_load");
-    // the packing kernels read `keep` on torch's stream: finish them before the tensors die
-    py::module_::import("torch").attr("cuda").attr("current_stream")(deviceIndex).attr("synchronize")();
   }
 
   void loadSlot(int id, py::object& pyModel) {
@@ -233,15 +260,22 @@ class ModelLocker {
     // still reads this slot's old weights is in flight (the reference's model call is synchronous).
     py::module_::import("torch").attr("cuda").attr("synchronize")(deviceIndex);
     py::dict sd = pyModel.attr("state_dict")();
+    if (!kindKnown_) {
+      kind_ = sd.contains(py::str("online_net.lstm.weight_ih_l0")) ? kLSTM : kFF;
+      kindKnown_ = true;
+    }
     loadNet(online_[id], sd, "online_net.");
     loadNet(target_[id], sd, "target_net.");
   }
 
   std::vector<py::object> pyModels_;
-  std::vector<rela_ffnet*> online_, target_;
+  std::vector<void*> online_, target_;
   std::vector<int> inFlight_;
   int latest_ = 0;
   int numAction_ = 0;
+  Kind kind_ = kFF;
+  bool kindKnown_ = false;
+  double eta_ = 0.9;
   std::mutex m_;
   std::condition_variable cv_;
 };
@@ -340,15 +374,96 @@ class FFPrioritizedReplay {
   torch::Tensor keep_;
 };
 
-// R2D2 rows of SURVEY 8a (T2, A4, A5) are not built yet: the names exist so that scripts which
-// only reference them import cleanly, and they fail loudly when used.
+// =====================================================================================
+// RNNPrioritizedReplay (PrioritizedReplay<RNNTransition>, pybind.cc:49-59): one slot = one sequence
+// of T = burn_in + seq_len + multi_step steps; batches come back time-major (types.cc:140-182).
+// =====================================================================================
 class RNNPrioritizedReplay {
  public:
-  RNNPrioritizedReplay(int, int, float, float, int) {
-    throw std::runtime_error("RNNPrioritizedReplay: the R2D2 path is not implemented in this build yet");
+  RNNPrioritizedReplay(int capacity, int seed, float alpha, float beta, int prefetch)
+      : capacity_(capacity), seed_(seed), alpha_(alpha), beta_(beta), prefetch_(prefetch) {}
+  ~RNNPrioritizedReplay() { rela_replay_destroy(h_); }
+
+  rela_replay* handle(int device, int numAction, int T) {
+    std::lock_guard<std::mutex> lk(m_);
+    if (!h_) {
+      check(rela_replay_create(&h_, capacity_, seed_, alpha_, beta_, prefetch_, device), "rela_replay_create");
+      const int64_t A = numAction, t = T;
+      const int64_t rb[10] = {t * kObsBytes, t * 4, t * 4 * A, t * 8, t * 4, t, t * 4, 2048, 2048, 4};
+      const int32_t st[10] = {T, T, T, T, T, T, T, 1, 1, 1};
+      check(rela_replay_set_schema_seq(h_, 10, rb, st), "rela_replay_set_schema_seq");
+      device_ = device;
+      numAction_ = numAction;
+      T_ = T;
+    } else if (device != device_ || numAction != numAction_ || T != T_) {
+      throw std::runtime_error("RNNPrioritizedReplay: actors disagree on device / action count / window length");
+    }
+    return h_;
   }
-  int size() const { return 0; }
-  int numAdd() const { return 0; }
+
+  int size() const { return h_ ? rela_replay_size(h_) : 0; }
+  int numAdd() const { return h_ ? (int)rela_replay_num_add(h_) : 0; }
+
+  std::tuple<RNNTransition, torch::Tensor> sample(int batchsize, const std::string& device) {
+    if (!h_) throw std::runtime_error("RNNPrioritizedReplay.sample: the replay is empty");
+    const auto dev = torch::Device(torch::kCUDA, (c10::DeviceIndex)device_);
+    auto opt = [&](torch::ScalarType t) { return torch::TensorOptions().dtype(t).device(dev); };
+    const int64_t B = batchsize, A = numAction_, T = T_;
+    RNNTransition b;
+    b.obs["s"] = torch::empty({T, B, 4, 84, 84}, opt(torch::kUInt8));
+    b.obs["eps"] = torch::empty({T, B, 1}, opt(torch::kFloat32));
+    b.obs["legal_move"] = torch::empty({T, B, A}, opt(torch::kFloat32));
+    b.action["a"] = torch::empty({T, B}, opt(torch::kInt64));
+    b.reward = torch::empty({T, B}, opt(torch::kFloat32));
+    b.terminal = torch::empty({T, B}, opt(torch::kBool));
+    b.bootstrap = torch::empty({T, B}, opt(torch::kFloat32));
+    b.h0["h0"] = torch::empty({1, B, 512}, opt(torch::kFloat32));
+    b.h0["c0"] = torch::empty({1, B, 512}, opt(torch::kFloat32));
+    b.seqLen = torch::empty({B}, opt(torch::kFloat32));
+    auto weight = torch::empty({B}, opt(torch::kFloat32));
+    void* rows[10] = {b.obs["s"].data_ptr(), b.obs["eps"].data_ptr(), b.obs["legal_move"].data_ptr(),
+                      b.action["a"].data_ptr(), b.reward.data_ptr(), b.terminal.data_ptr(), b.bootstrap.data_ptr(),
+                      b.h0["h0"].data_ptr(), b.h0["c0"].data_ptr(), b.seqLen.data_ptr()};
+    check(rela_replay_sample(h_, batchsize, rows, weight.data_ptr<float>(), torchCurrentStream(device_)),
+          "RNNPrioritizedReplay.sample");
+    const int want = parseDevice(device);
+    if (want != device_) {
+      const auto target = want < 0 ? torch::Device(torch::kCPU) : torch::Device(torch::kCUDA, (c10::DeviceIndex)want);
+      auto mv = [&](torch::Tensor& t) { t = t.to(target); };
+      for (auto* d : {&b.obs, &b.action, &b.h0})
+        for (auto& kv : *d) mv(kv.second);
+      mv(b.reward);
+      mv(b.terminal);
+      mv(b.bootstrap);
+      mv(b.seqLen);
+      mv(weight);
+    }
+    return std::make_tuple(std::move(b), weight);
+  }
+
+  void updatePriority(const torch::Tensor& priority) {
+    if (!h_) throw std::runtime_error("RNNPrioritizedReplay.update_priority: nothing was sampled");
+    if (priority.dim() != 1) throw std::invalid_argument("update_priority expects a 1-D tensor");
+    auto p = priority.detach().to(torch::kFloat32).contiguous();
+    if (p.is_cuda()) {
+      if (p.device().index() != device_) p = p.to(torch::Device(torch::kCUDA, (c10::DeviceIndex)device_));
+      check(rela_replay_update_priority(h_, (int)p.numel(), p.data_ptr<float>(), 1, torchCurrentStream(device_)),
+            "RNNPrioritizedReplay.update_priority");
+      keep_ = p;
+    } else {
+      check(rela_replay_update_priority(h_, (int)p.numel(), p.data_ptr<float>(), 0, nullptr),
+            "RNNPrioritizedReplay.update_priority");
+    }
+  }
+
+ private:
+  const int capacity_, seed_;
+  const float alpha_, beta_;
+  const int prefetch_;
+  std::mutex m_;
+  rela_replay* h_ = nullptr;
+  int device_ = -1, numAction_ = 0, T_ = 0;
+  torch::Tensor keep_;
 };
 
 // =====================================================================================
@@ -407,7 +522,11 @@ class DQNActor : public Actor {
     constsValid_ = true;
     auto sc = s.contiguous();
     auto lease = locker_->getModel();
-    const int rc = rela_apex_actor_act(h_, lease.online, sc.data_ptr<uint8_t>(), epsPtr, legalPtr,
+    if (lease.kind != ModelLocker::kFF) {
+      locker_->releaseModel(lease.id);
+      throw std::runtime_error("DQNActor needs an AtariFFNet-shaped agent in its ModelLocker");
+    }
+    const int rc = rela_apex_actor_act(h_, static_cast<const rela_ffnet*>(lease.online), sc.data_ptr<uint8_t>(), epsPtr, legalPtr,
                                        action_.data_ptr<int64_t>(), nullptr, stream_);
     locker_->releaseModel(lease.id);
     check(rc, "DQNActor.act");
@@ -425,7 +544,8 @@ class DQNActor : public Actor {
     auto lease = locker_->getModel();
     const int rc = rela_apex_actor_post_step(h_, reward_.data_ptr<float>(),
                                              reinterpret_cast<const uint8_t*>(terminal_.data_ptr<bool>()), 0,
-                                             lease.online, lease.target, 0, nullptr, stream_);
+                                             static_cast<const rela_ffnet*>(lease.online),
+                                             static_cast<const rela_ffnet*>(lease.target), 0, nullptr, stream_);
     locker_->releaseModel(lease.id);
     check(rc, "DQNActor.postStep");
   }
@@ -441,18 +561,104 @@ class DQNActor : public Actor {
   bool constsValid_ = false;
 };
 
+// =====================================================================================
+// R2D2Actor (rela/r2d2_actor.h:189-353)
+// =====================================================================================
 class R2D2Actor : public Actor {
  public:
-  R2D2Actor(std::shared_ptr<ModelLocker>, int, int, float, int, int, std::shared_ptr<RNNPrioritizedReplay>) {
-    throw std::runtime_error("R2D2Actor: the R2D2 path is not implemented in this build yet");
+  R2D2Actor(std::shared_ptr<ModelLocker> locker, int multiStep, int batchsize, float gamma, int seqLen, int burnin,
+            std::shared_ptr<RNNPrioritizedReplay> replay)
+      : batchsize_(batchsize), multiStep_(multiStep), gamma_(gamma), seqLen_(seqLen), burnin_(burnin),
+        locker_(std::move(locker)), replay_(std::move(replay)) {
+    if (burnin_ > seqLen_ || multiStep_ > seqLen_)  // r2d2_actor.h:25-26
+      throw std::invalid_argument("R2D2Actor needs burn_in <= seq_len and multi_step <= seq_len");
   }
-  explicit R2D2Actor(std::shared_ptr<ModelLocker>) {
-    throw std::runtime_error("R2D2Actor: the R2D2 path is not implemented in this build yet");
+
+  // evaluation mode (r2d2_actor.h:208-215)
+  explicit R2D2Actor(std::shared_ptr<ModelLocker> locker)
+      : batchsize_(1), multiStep_(1), gamma_(1.f), seqLen_(1), burnin_(0), locker_(std::move(locker)),
+        replay_(nullptr) {}
+
+  ~R2D2Actor() override {
+    rela_r2d2_actor_destroy(h_);
+    if (stream_) rela_stream_destroy(stream_, locker_->deviceIndex);
   }
-  int numAct() const { return 0; }
-  TensorDict act(TensorDict&) override { return {}; }
-  void setRewardAndTerminal(torch::Tensor&, torch::Tensor&) override {}
-  void postStep() override {}
+
+  int numAct() const { return h_ ? (int)rela_r2d2_actor_num_act(h_) : 0; }
+
+  TensorDict act(TensorDict& obs) override {
+    const auto& s = obs.at("s");
+    const auto& legal = obs.at("legal_move");
+    const auto& eps = obs.at("eps");
+    if (s.size(0) != batchsize_ || s.numel() != (int64_t)batchsize_ * kObsBytes || s.dtype() != torch::kUInt8)
+      throw std::runtime_error("R2D2Actor.act: obs['s'] must be uint8 [batchsize,4,84,84]");
+    const int A = (int)legal.size(1);
+    if (!h_) {
+      static std::atomic<uint64_t> counter{0};
+      const int T = burnin_ + seqLen_ + multiStep_;
+      rela_replay* rep = replay_ ? replay_->handle(locker_->deviceIndex, A, T) : nullptr;
+      check(rela_stream_create(&stream_, locker_->deviceIndex), "rela_stream_create");
+      check(rela_r2d2_actor_create(&h_, batchsize_, batchsize_, A, multiStep_, gamma_, seqLen_, burnin_,
+                                   locker_->eta(), rep, 0xD1B54A32D192ED03ull * (++counter), locker_->deviceIndex),
+            "rela_r2d2_actor_create");
+      action_ = torch::zeros({batchsize_}, torch::kInt64);
+      if (torch::cuda::is_available()) action_ = action_.pin_memory();
+      epsHost_ = torch::zeros({batchsize_}, torch::kFloat32);
+      legalHost_ = torch::zeros({batchsize_, A}, torch::kFloat32);
+    }
+    const float* epsPtr = nullptr;
+    const float* legalPtr = nullptr;
+    auto e = eps.reshape({batchsize_}).to(torch::kFloat32).contiguous();
+    if (!constsValid_ || std::memcmp(e.data_ptr(), epsHost_.data_ptr(), e.nbytes()) != 0) {
+      epsHost_.copy_(e);
+      epsPtr = epsHost_.data_ptr<float>();
+    }
+    auto l = legal.to(torch::kFloat32).contiguous();
+    if (!constsValid_ || std::memcmp(l.data_ptr(), legalHost_.data_ptr(), l.nbytes()) != 0) {
+      legalHost_.copy_(l);
+      legalPtr = legalHost_.data_ptr<float>();
+    }
+    constsValid_ = true;
+    auto sc = s.contiguous();
+    auto lease = locker_->getModel();
+    if (lease.kind != ModelLocker::kLSTM) {
+      locker_->releaseModel(lease.id);
+      throw std::runtime_error("R2D2Actor needs an AtariLSTMNet-shaped agent in its ModelLocker");
+    }
+    const int rc = rela_r2d2_actor_act(h_, static_cast<const rela_lstmnet*>(lease.online), sc.data_ptr<uint8_t>(),
+                                       epsPtr, legalPtr, action_.data_ptr<int64_t>(), nullptr, stream_);
+    locker_->releaseModel(lease.id);
+    check(rc, "R2D2Actor.act");
+    return TensorDict{{"a", action_}};
+  }
+
+  void setRewardAndTerminal(torch::Tensor& r, torch::Tensor& t) override {
+    if (!replay_) throw std::runtime_error("R2D2Actor: evaluation actor has no replay");
+    reward_ = r.to(torch::kFloat32).contiguous();
+    terminal_ = t.to(torch::kBool).contiguous();
+  }
+
+  void postStep() override {
+    if (!replay_) throw std::runtime_error("R2D2Actor: evaluation actor has no replay");
+    auto lease = locker_->getModel();
+    const int rc = rela_r2d2_actor_post_step(h_, reward_.data_ptr<float>(),
+                                             reinterpret_cast<const uint8_t*>(terminal_.data_ptr<bool>()),
+                                             static_cast<const rela_lstmnet*>(lease.online),
+                                             static_cast<const rela_lstmnet*>(lease.target), 0, nullptr, stream_);
+    locker_->releaseModel(lease.id);
+    check(rc, "R2D2Actor.postStep");
+  }
+
+ private:
+  const int batchsize_, multiStep_;
+  const float gamma_;
+  const int seqLen_, burnin_;
+  std::shared_ptr<ModelLocker> locker_;
+  std::shared_ptr<RNNPrioritizedReplay> replay_;
+  rela_r2d2_actor* h_ = nullptr;
+  void* stream_ = nullptr;
+  torch::Tensor action_, epsHost_, legalHost_, reward_, terminal_;
+  bool constsValid_ = false;
 };
 
 // =====================================================================================
@@ -602,7 +808,9 @@ PYBIND11_MODULE(rela, m) {
   py::class_<RNNPrioritizedReplay, std::shared_ptr<RNNPrioritizedReplay>>(m, "RNNPrioritizedReplay")
       .def(py::init<int, int, float, float, int>())
       .def("size", &RNNPrioritizedReplay::size)
-      .def("num_add", &RNNPrioritizedReplay::numAdd);
+      .def("num_add", &RNNPrioritizedReplay::numAdd)
+      .def("sample", &RNNPrioritizedReplay::sample)
+      .def("update_priority", &RNNPrioritizedReplay::updatePriority);
 
   py::class_<Env, std::shared_ptr<Env>>(m, "Env");
 

@@ -77,3 +77,80 @@ def load_agent_params(agent, cfg=CFG):
             sd[prefix + k] = torch.from_numpy(v)
     agent.load_state_dict(sd)
     return agent
+
+
+# ---------------------------------------------------------------------------------------------
+# R2D2: same lock-step idea with sequences.  Blocks are 1..2K sequences, so "ring full" is not an
+# exact size; the actor is considered parked when size() has not moved for a while.
+# ---------------------------------------------------------------------------------------------
+CFG_R2D2 = dict(K=2, multi_step=3, gamma=0.997, seq_len=6, burn_in=2, eta=0.9, capacity=16, alpha=1.0, beta=1.0,
+                seed=11, episode_len=14, num_action=6, rounds=5, batch=4, online_seed=3003, target_seed=4004,
+                env_seed=700)
+
+
+def _wait_parked(replay, min_size, quiet=1.0, timeout=180.0):
+    t0 = time.time()
+    last, since = -1, time.time()
+    while True:
+        cur = replay.num_add()
+        if cur != last:
+            last, since = cur, time.time()
+        elif replay.size() >= min_size and time.time() - since > quiet:
+            return
+        if time.time() - t0 > timeout:
+            raise TimeoutError("actor never parked (size %d)" % replay.size())
+        time.sleep(0.01)
+
+
+def run_lockstep_r2d2(rela, synth_atari, agent, act_device, sample_device, cfg=CFG_R2D2):
+    replay = rela.RNNPrioritizedReplay(cfg["capacity"], cfg["seed"], cfg["alpha"], cfg["beta"], 0)
+    locker = rela.ModelLocker([agent], act_device)
+    actor = rela.R2D2Actor(locker, cfg["multi_step"], cfg["K"], cfg["gamma"], cfg["seq_len"], cfg["burn_in"], replay)
+    vec = rela.VectorEnv()
+    games = []
+    for g in range(cfg["K"]):
+        game = synth_atari.SyntheticAtariEnv(cfg["env_seed"] + g, 0.0, cfg["num_action"], cfg["episode_len"])
+        games.append(game)
+        vec.append(game)
+    ctx = rela.Context()
+    ctx.push_env_thread(rela.BasicThreadLoop(actor, vec, False))
+    ctx.start()
+    rounds = []
+    for r in range(cfg["rounds"]):
+        _wait_parked(replay, cfg["batch"])
+        batch, w = replay.sample(cfg["batch"], sample_device)
+        _wait_parked(replay, cfg["batch"])  # the parked block lands before the priorities change
+        s = batch.obs["s"].cpu().numpy().astype(np.int64)  # [T,B,4,84,84]
+        T, B = s.shape[:2]
+        rounds.append(dict(
+            s_sum=s.reshape(T, B, -1).sum(2).T.tolist(),
+            a=batch.action["a"].cpu().T.tolist(), reward=batch.reward.cpu().T.tolist(),
+            terminal=batch.terminal.cpu().long().T.tolist(), bootstrap=batch.bootstrap.cpu().T.tolist(),
+            eps_sum=batch.obs["eps"].cpu().sum().item(), legal_sum=batch.obs["legal_move"].cpu().sum(2).T.tolist(),
+            seq_len=batch.seq_len.cpu().tolist(),
+            h0_abs=batch.h0["h0"].cpu().abs().sum(2).reshape(-1).double().tolist(),
+            c0_abs=batch.h0["c0"].cpu().abs().sum(2).reshape(-1).double().tolist(),
+            weight=w.cpu().double().tolist(), num_add=replay.num_add(), size=replay.size()))
+        replay.update_priority(torch.linspace(0.5, 2.0, cfg["batch"]) * (1 + 0.25 * r))
+    ctx.terminate()
+    ctx.resume()
+    t0 = time.time()
+    while not ctx.terminated():
+        if replay.size() >= cfg["batch"]:
+            batch, w = replay.sample(cfg["batch"], sample_device)
+            replay.update_priority(torch.ones(cfg["batch"]))
+        time.sleep(0.005)
+        if time.time() - t0 > 180:
+            raise TimeoutError("context did not terminate")
+    return rounds
+
+
+def load_lstm_agent_params(agent, cfg=CFG_R2D2):
+    from synth import synth_lstm_params
+
+    sd = {}
+    for prefix, seed in (("online_net.", cfg["online_seed"]), ("target_net.", cfg["target_seed"])):
+        for k, v in synth_lstm_params(cfg["num_action"], seed).items():
+            sd[prefix + k] = torch.from_numpy(v)
+    agent.load_state_dict(sd)
+    return agent

@@ -249,8 +249,40 @@ print("RESULT" + json.dumps(rounds))
     save("e2e_lockstep_apex", [], json.loads(line[len("RESULT"):]), cfg=CFG)
 
 
+def e2e_r2d2_cases():
+    """The REAL reference's R2D2 path end to end (H6-shimmed module, see oracle/Makefile)."""
+    code = r"""
+import json, sys, types
+sys.dont_write_bytecode = True
+sys.modules.setdefault("tensorboardX", types.ModuleType("tensorboardX"))
+sys.modules["tensorboardX"].SummaryWriter = object
+sys.path[:0] = [%r, %r, %r, "/root/reference/pyrela"]
+import torch
+torch.set_num_threads(1)
+import rela, synth_atari
+assert "_ref/h6" in rela.__file__
+from r2d2 import R2D2Agent
+from net import AtariLSTMNet
+from e2e_lockstep import CFG_R2D2 as C, run_lockstep_r2d2, load_lstm_agent_params
+agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, C["num_action"]), "cpu", C["multi_step"], C["gamma"], C["eta"],
+                  C["seq_len"], C["burn_in"], 0)
+load_lstm_agent_params(agent)
+rounds = run_lockstep_r2d2(rela, synth_atari, agent, "cpu", "cpu")
+print("RESULT" + json.dumps(rounds))
+""" % (os.path.join(REFBIN, "h6"), REFBIN, os.path.dirname(HERE))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    if out.returncode != 0:
+        print(out.stdout[-2000:], out.stderr[-4000:])
+        raise SystemExit(1)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1]
+    from e2e_lockstep import CFG_R2D2
+    save("e2e_lockstep_r2d2", [], json.loads(line[len("RESULT"):]), cfg=CFG_R2D2)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["replay", "nstep", "ffnet", "e2e", "r2d2buf", "r2d2agg"]
+    which = sys.argv[1:] or ["replay", "nstep", "ffnet", "e2e", "r2d2buf", "r2d2agg", "e2e_r2d2"]
+    if "e2e_r2d2" in which:
+        e2e_r2d2_cases()
     if "r2d2buf" in which:
         r2d2buf_cases()
     if "r2d2agg" in which:

@@ -57,3 +57,30 @@ def test_training_entry_point_runs(mods, capsys):
     assert "Speed: train: " in out and "buffer_add: " in out
     assert len(hist) == 2 and all(np.isfinite(h["loss"]) for h in hist)
     assert hist[-1]["act"] > 0 and hist[-1]["buffer_add"] > 0
+
+
+def test_lockstep_r2d2_matches_reference(mods):
+    """R2D2 rows (T2, A4, A5, N2 of SURVEY 8a) end to end: R2D2Actor + RNNPrioritizedReplay of this
+    repo against the REAL reference (H6-shimmed build, CPU TorchScript LSTM agent), same lock-step
+    protocol.  Sequences, actions, n-step rewards, terminals, lengths exact; stored recurrent state
+    to 1e-4; IS weights (functions of the aggregated TD priorities) to 1e-3."""
+    from e2e_lockstep import CFG_R2D2, load_lstm_agent_params, run_lockstep_r2d2
+    from rela_amd.pyrela.net import AtariLSTMNet
+    from rela_amd.pyrela.r2d2 import R2D2Agent
+
+    rela, synth = mods
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_lockstep_r2d2.json")))
+    C = CFG_R2D2
+    assert gold["cfg"] == C
+    agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, C["num_action"]), "cpu", C["multi_step"], C["gamma"], C["eta"],
+                      C["seq_len"], C["burn_in"], 0)
+    load_lstm_agent_params(agent)
+    rounds = run_lockstep_r2d2(rela, synth, agent, "cuda:0", "cuda:0")
+    assert len(rounds) == len(gold["expect"])
+    for r, (got, exp) in enumerate(zip(rounds, gold["expect"])):
+        for key in ("s_sum", "a", "terminal", "bootstrap", "legal_sum", "seq_len", "num_add", "size", "eps_sum"):
+            assert got[key] == exp[key], (r, key)
+        assert np.array_equal(np.float32(got["reward"]), np.float32(exp["reward"])), r
+        np.testing.assert_allclose(got["h0_abs"], exp["h0_abs"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(got["c0_abs"], exp["c0_abs"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(got["weight"], exp["weight"], rtol=1e-3, err_msg="IS weights, round %d" % r)

@@ -1,7 +1,7 @@
 """CPU-side checks of the pybind module `rela` (drop-in surface of rela/pybind.cc:19-108) and of
 the second native module `synth_atari` that plugs a C++ Env into it.  No GPU needed: only
 host logic (class surface, Env ABI across modules, VectorEnv batching, Context lifecycle,
-ModelLocker('cpu') bookkeeping, loud failures for the not-yet-built R2D2 names)."""
+ModelLocker('cpu') bookkeeping, loud failures where a GPU would be required)."""
 import os
 import sys
 
@@ -86,7 +86,7 @@ def test_context_lifecycle_without_threads(mods):
     assert c.terminated()
 
 
-def test_model_locker_cpu_and_r2d2_guards(mods):
+def test_model_locker_cpu_and_actor_guards(mods):
     rela, _ = mods
     from rela_amd.pyrela.apex import ApexAgent
     from rela_amd.pyrela.net import AtariFFNet
@@ -98,10 +98,14 @@ def test_model_locker_cpu_and_r2d2_guards(mods):
         a.online_net.fc_v.bias.add_(1.0)
     locker.update_model(a)  # cpu locker keeps the Python replicas in sync (model_locker.h:31)
     assert torch.equal(b.online_net.fc_v.bias, a.online_net.fc_v.bias)
-    with pytest.raises(RuntimeError, match="not implemented"):
-        rela.RNNPrioritizedReplay(8, 1, 0.9, 0.6, 0)
-    with pytest.raises(RuntimeError, match="not implemented"):
-        rela.R2D2Actor(locker)
+    rr = rela.RNNPrioritizedReplay(8, 1, 0.9, 0.6, 0)
+    assert rr.size() == 0 and rr.num_add() == 0
+    with pytest.raises(RuntimeError):
+        rr.sample(2, "cpu")  # empty
+    with pytest.raises(ValueError):
+        rela.R2D2Actor(locker, 3, 4, 0.997, 2, 4, rr)  # burn_in > seq_len (r2d2_actor.h:25)
+    ev = rela.R2D2Actor(locker)  # evaluation ctor constructs (r2d2_actor.h:208-215)
+    assert ev.num_act() == 0 and not hasattr(ev, "act")  # actors are opaque to Python upstream too
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError):
             rela.ModelLocker([a], "cuda:0")  # no silent CPU fallback

@@ -1,0 +1,65 @@
+"""GPU tests of the sequence features of the replay C ABI: three-phase append (begin / write /
+commit, prioritized_replay.h:43-78) and the time-major gather of RNNTransition::makeBatch
+(types.cc:140-182)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_three_phase_append_and_time_major_gather():
+    import torch
+
+    from gpu_util import cur_stream
+    from oracle_lib import OracleReplay
+    from rela_amd import _capi as capi
+
+    T, E = 5, 48  # 5 steps of 48 bytes per slot in field 0; field 1 is a plain 16-byte row
+    h = C.c_void_p()
+    capi.check(capi.lib.rela_replay_create(C.byref(h), 16, 3, 1.0, 1.0, 0, 0), "create")
+    rb = (C.c_int64 * 2)(T * E, 16)
+    st = (C.c_int32 * 2)(T, 1)
+    capi.check(capi.lib.rela_replay_set_schema_seq(h, 2, rb, st), "schema")
+    oracle = OracleReplay(16, 3, 1.0, 1.0)
+    rng = np.random.default_rng(0)
+    seqs = rng.integers(0, 256, (12, T, E), dtype=np.uint8)
+    plain = rng.integers(0, 256, (12, 16), dtype=np.uint8)
+    d_seq, d_plain = torch.from_numpy(seqs).cuda(), torch.from_numpy(plain).cuda()
+    prio = rng.uniform(0.1, 2, 12).astype(np.float32)
+    d_prio = torch.from_numpy(prio).cuda()
+    # block 1: 5 slots written out of order and piecewise, visible only after commit
+    slot = C.c_int()
+    capi.check(capi.lib.rela_replay_begin_add(h, 5, 0, C.byref(slot)), "begin")
+    assert slot.value == 0 and capi.lib.rela_replay_size(h) == 0
+    for off in (3, 0, 4, 1, 2):
+        rows = (C.c_void_p * 2)(d_seq[off].data_ptr(), d_plain[off].data_ptr())
+        capi.check(capi.lib.rela_replay_write_rows(h, slot.value, off, 1, rows, cur_stream()), "write")
+    assert capi.lib.rela_replay_size(h) == 0  # safeSize_: nothing committed yet
+    capi.check(capi.lib.rela_replay_commit_add(h, slot.value, 5, C.c_void_p(d_prio.data_ptr()), cur_stream()), "commit")
+    assert capi.lib.rela_replay_size(h) == 5 and capi.lib.rela_replay_num_add(h) == 5
+    assert oracle.add(np.arange(5), prio[:5]) == 0
+    # block 2 through the one-shot add
+    rows = (C.c_void_p * 2)(d_seq[5:].data_ptr(), d_plain[5:].data_ptr())
+    capi.check(capi.lib.rela_replay_add(h, 7, rows, C.c_void_p(d_prio[5:].data_ptr()), 0, cur_stream()), "add")
+    assert oracle.add(np.arange(5, 12), prio[5:]) == 0
+    B = 6
+    out_seq = torch.empty((T, B, E), dtype=torch.uint8, device="cuda")
+    out_plain = torch.empty((B, 16), dtype=torch.uint8, device="cuda")
+    w = torch.empty(B, device="cuda")
+    outs = (C.c_void_p * 2)(out_seq.data_ptr(), out_plain.data_ptr())
+    capi.check(capi.lib.rela_replay_sample(h, B, outs, C.c_void_p(w.data_ptr()), cur_stream()), "sample")
+    rc, ids, tags, ow = oracle.sample(B)
+    assert rc == 0
+    st_ = capi.ReplayState()
+    ids_dev = np.zeros(B, np.int32)
+    capi.check(capi.lib.rela_replay_debug_state(h, C.byref(st_), ids_dev.ctypes.data_as(C.c_void_p), None, None), "dbg")
+    np.testing.assert_array_equal(ids_dev, ids)
+    assert st_.sum == oracle.state()["sum"]
+    got = out_seq.cpu().numpy()
+    for b in range(B):
+        np.testing.assert_array_equal(got[:, b], seqs[ids[b]])  # out[t][b] = slot_b[t]
+    np.testing.assert_array_equal(out_plain.cpu().numpy(), plain[ids])
+    np.testing.assert_allclose(w.cpu().numpy(), ow, rtol=4e-7)
+    capi.lib.rela_replay_destroy(h)
