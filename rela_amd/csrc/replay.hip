@@ -153,12 +153,15 @@ __global__ void replay_targets(const uint32_t* __restrict__ draws, int batch, Re
   }
 }
 
-__global__ void replay_search(SeqView v, const double* __restrict__ eff, int batch, int32_t* __restrict__ ids,
-                              float* __restrict__ raw_w, uint8_t* __restrict__ evicted,
-                              ReplayDevState* __restrict__ st) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per stratum (seq_find_wave): the 512 searches of a batch spread over the chip
+__global__ __launch_bounds__(64) void replay_search(SeqView v, const double* __restrict__ eff, int batch,
+                                                    int32_t* __restrict__ ids, float* __restrict__ raw_w,
+                                                    uint8_t* __restrict__ evicted,
+                                                    ReplayDevState* __restrict__ st) {
+  const int i = blockIdx.x;
   if (i >= batch) return;
-  const SeqHit h = seq_find(v, eff[i]);
+  const SeqHit h = seq_find_wave(v, eff[i]);
+  if ((threadIdx.x & 63) != 0) return;
   int64_t k = h.k;
   if (!h.found) {  // :297-302 (the reference aborts here)
     st->err = RELA_ESCAN;
@@ -176,10 +179,12 @@ __global__ __launch_bounds__(kThreads) void replay_pop(SeqView v, int n_pop, uin
                                                        ReplayDevState* __restrict__ st) {
   const int tid = blockIdx.x * kThreads + threadIdx.x;
   for (int k = tid; k < n_pop; k += gridDim.x * kThreads) evicted[seq_phys(v, k)] = 1;
-  if (tid == 0) {
-    const double diff = -seq_prefix(v, n_pop);
-    st->last_pop = diff;
-    st->sum += diff;
+  if (blockIdx.x == 0 && threadIdx.x < 64) {  // wavefront 0 evaluates the exact prefix cooperatively
+    const double diff = -seq_prefix_wave(v, n_pop);
+    if (threadIdx.x == 0) {
+      st->last_pop = diff;
+      st->sum += diff;
+    }
   }
 }
 
@@ -503,7 +508,7 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
   }
   {
     ProfScope prof("replay_search", r->stream);
-    hipLaunchKernelGGL(replay_search, dim3(ceil_div(batch, 64)), dim3(64), 0, r->stream, v, r->d_eff, batch,
+    hipLaunchKernelGGL(replay_search, dim3(batch), dim3(64), 0, r->stream, v, r->d_eff, batch,
                        r->d_ids, r->d_raw_w, r->d_evicted, r->d_state);
   }
   // pop storage if full :311-315: `size` is re-read as size_ (reserved blocks included), and the

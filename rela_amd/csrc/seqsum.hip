@@ -154,31 +154,57 @@ __global__ void seq_l3_tables(const SeqTab* __restrict__ T2, int n2, SeqTab* __r
   T3[j] = t;
 }
 
-// One lane walks the level-3 nodes in order carrying the exact accumulator.
-__global__ void seq_chain(const float* __restrict__ w, int64_t ring, int64_t head, int64_t size,
-                          const SeqTab* __restrict__ T1, const SeqTab* __restrict__ T2,
-                          const SeqTab* __restrict__ T3, int n3, double* __restrict__ A3) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const SeqRingAt at{w, ring, head, size};
+// One WAVEFRONT walks the level-3 nodes in order carrying the exact accumulator: 64 level-3
+// tables are fetched per load and tried through lane broadcasts; a node whose table cannot be
+// applied (a binade crossing) is walked cooperatively at the finer levels.
+__global__ __launch_bounds__(64) void seq_chain(const float* __restrict__ w, int64_t ring, int64_t head,
+                                                int64_t size, const SeqTab* __restrict__ T1,
+                                                const SeqTab* __restrict__ T2, const SeqTab* __restrict__ T3,
+                                                int n3, double* __restrict__ A3) {
+  const int lane = threadIdx.x & 63;
+  SeqView v;
+  v.w = w;
+  v.ring = ring;
+  v.head = head;
+  v.size = size;
+  v.T1 = T1;
+  v.T2 = T2;
+  v.A3 = A3;
+  v.n3 = n3;
   double A = 0;
-  for (int j = 0; j < n3; ++j) {
-    A3[j] = A;
-    int64_t kend = (int64_t)(j + 1) * kL3;
-    if (kend > size) kend = size;
-    A = seq_walk(A, (int64_t)j * kL3, kend, (double)INFINITY, T1, T2, T3, at).A;
+  for (int base = 0; base < n3; base += 64) {
+    SeqTab mine = seq_tab_invalid();
+    if (base + lane < n3) mine = T3[base + lane];
+    const int cnt = (n3 - base < 64) ? n3 - base : 64;
+    for (int c = 0; c < cnt; ++c) {
+      const int j = base + c;
+      if (lane == 0) A3[j] = A;
+      const SeqTab t3 = seq_tab_bcast(mine, c);
+      double n;
+      if (seq_apply(t3, A, &n)) {  // level-3 tables are zero padded: always safe to apply
+        A = n;
+        continue;
+      }
+      int64_t kend = (int64_t)(j + 1) * kL3;
+      if (kend > size) kend = size;
+      A = seq_walk_wave(v, A, (int64_t)j * kL3, kend, (double)INFINITY, true).A;
+    }
   }
-  A3[n3] = A;
+  if (lane == 0) A3[n3] = A;
 }
 
-__global__ void seq_search_kernel(SeqView v, const double* __restrict__ targets, int nt,
-                                  int64_t* __restrict__ out_k, double* __restrict__ out_A,
-                                  float* __restrict__ out_w) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one wavefront per target
+__global__ __launch_bounds__(64) void seq_search_kernel(SeqView v, const double* __restrict__ targets, int nt,
+                                                        int64_t* __restrict__ out_k, double* __restrict__ out_A,
+                                                        float* __restrict__ out_w) {
+  const int i = blockIdx.x;
   if (i >= nt) return;
-  const SeqHit h = seq_find(v, targets[i]);
-  out_k[i] = h.found ? h.k : -1;
-  out_A[i] = h.A;
-  out_w[i] = h.w;
+  const SeqHit h = seq_find_wave(v, targets[i]);
+  if ((threadIdx.x & 63) == 0) {
+    out_k[i] = h.found ? h.k : -1;
+    out_A[i] = h.A;
+    out_w[i] = h.w;
+  }
 }
 
 }  // namespace
@@ -280,7 +306,7 @@ extern "C" int rela_seqscan_search(const float* ring_dev, int64_t ring, int64_t 
   RELA_HIP(hipMalloc(&d_w, sizeof(float) * n));
   if (nt > 0) {
     RELA_HIP(hipMemcpyAsync(d_t, targets_host, sizeof(double) * nt, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(seq_search_kernel, dim3(ceil_div(nt, 64)), dim3(64), 0, stream, v, d_t, nt, d_k, d_A, d_w);
+    hipLaunchKernelGGL(seq_search_kernel, dim3(nt), dim3(64), 0, stream, v, d_t, nt, d_k, d_A, d_w);
     RELA_LAUNCH_CHECK();
     RELA_HIP(hipMemcpyAsync(out_index, d_k, sizeof(int64_t) * nt, hipMemcpyDeviceToHost, stream));
     RELA_HIP(hipMemcpyAsync(out_acc, d_A, sizeof(double) * nt, hipMemcpyDeviceToHost, stream));

@@ -65,6 +65,107 @@ __device__ inline double seq_prefix(const SeqView& v, int64_t k) {
                   SeqRingAt{v.w, v.ring, v.head, v.size}).A;
 }
 
+// ---- wave-cooperative walk -------------------------------------------------------------
+// Same arithmetic as seq_walk (seqsum_core.h), executed by all 64 lanes of a wavefront with
+// identical scalar state: sibling tables (16 x 24 B) and native weights (64 x 4 B) are fetched
+// by one coalesced load each and consumed through lane broadcasts, so a search costs ~3 memory
+// round trips instead of ~100 dependent ones.  Every lane must call these with the same
+// arguments; every lane gets the same result.
+__device__ __forceinline__ SeqTab seq_tab_bcast(const SeqTab& mine, int src) {
+  SeqTab t;
+  t.d[0] = __shfl(mine.d[0], src, 64);
+  t.d[1] = __shfl(mine.d[1], src, 64);
+  t.e = __shfl(mine.e, src, 64);
+  t.par = __shfl(mine.par, src, 64);
+  return t;
+}
+
+// Walks [k0, kend) inside ONE level-3 node (k0 is that node's first index).  pad_ok: tables may
+// be applied even when their span runs past kend (true for searches up to `size`, where the
+// tables were built with zero padding; false when kend is an arbitrary prefix end).
+__device__ inline SeqHit seq_walk_wave(const SeqView& v, double A0, int64_t k0, int64_t kend, double target,
+                                       bool pad_ok) {
+  const int lane = threadIdx.x & 63;
+  const SeqRingAt at{v.w, v.ring, v.head, v.size};
+  SeqHit h;
+  double A = A0;
+  int64_t k = k0;
+  const int64_t n2 = (v.size + kL2 - 1) / kL2, n1 = n2 * kFan;
+  SeqTab my2 = seq_tab_invalid();
+  {
+    const int64_t i2 = k0 / kL2 + lane;
+    if (lane < kFan && i2 < n2) my2 = v.T2[i2];
+  }
+  for (int c2 = 0; c2 < kFan && k < kend; ++c2) {
+    double n;
+    const SeqTab t2 = seq_tab_bcast(my2, c2);
+    if ((pad_ok || k + kL2 <= kend) && seq_apply(t2, A, &n) && n < target) {
+      A = n;
+      k += kL2;
+      continue;
+    }
+    SeqTab my1 = seq_tab_invalid();
+    {
+      const int64_t i1 = k / kL1 + lane;
+      if (lane < kFan && i1 < n1) my1 = v.T1[i1];
+    }
+    const int64_t end2 = (k + kL2 < kend) ? k + kL2 : kend;
+    for (int c1 = 0; c1 < kFan && k < end2; ++c1) {
+      const SeqTab t1 = seq_tab_bcast(my1, c1);
+      if ((pad_ok || k + kL1 <= kend) && seq_apply(t1, A, &n) && n < target) {
+        A = n;
+        k += kL1;
+        continue;
+      }
+      const float wl = at(k + lane);  // 64 weights, one coalesced load (0 beyond size)
+      const int cnt = (int)((k + kL1 <= kend) ? kL1 : (kend - k));
+      for (int e = 0; e < cnt; ++e) {
+        const float we = __shfl(wl, e, 64);
+        A += (double)we;
+        if (A >= target) {
+          h.k = k + e;
+          h.A = A;
+          h.w = we;
+          h.found = true;
+          return h;
+        }
+      }
+      k += cnt;
+    }
+  }
+  h.k = kend;
+  h.A = A;
+  h.w = 0.f;
+  h.found = false;
+  return h;
+}
+
+// wave-cooperative versions of seq_find / seq_prefix
+__device__ inline SeqHit seq_find_wave(const SeqView& v, double target) {
+  int lo = 0, hi = v.n3;  // smallest j with A3[j+1] >= target (uniform across the wave)
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (v.A3[mid + 1] >= target) hi = mid; else lo = mid + 1;
+  }
+  if (lo >= v.n3) {
+    SeqHit h;
+    h.k = v.size;
+    h.A = v.A3[v.n3];
+    h.w = 0.f;
+    h.found = false;
+    return h;
+  }
+  int64_t kend = (int64_t)(lo + 1) * kL3;
+  if (kend > v.size) kend = v.size;
+  return seq_walk_wave(v, v.A3[lo], (int64_t)lo * kL3, kend, target, true);
+}
+
+__device__ inline double seq_prefix_wave(const SeqView& v, int64_t k) {
+  int j = (int)(k / kL3);
+  if (j >= v.n3) return v.A3[v.n3];
+  return seq_walk_wave(v, v.A3[j], (int64_t)j * kL3, k, (double)INFINITY, false).A;
+}
+
 // ---- host side -----------------------------------------------------------------------
 struct SeqIndex {
   double* bsum2 = nullptr;  // [n2cap]     plain f64 sums of level-2 nodes (guesses only)

@@ -6,7 +6,7 @@ re-published every --actor_sync_freq updates, the target net every --num_update_
 Differences, all on purpose:
   * envs are synthetic (create_env.py); --game only names the run; evaluation is out of scope;
   * the priority stays on the GPU between loss() and update_priority() (no per-step host sync);
-  * --algo r2d2 is rejected until the R2D2 rows are built.
+  * one replay partition per actor GPU: several --act_device values need one process each.
 """
 import argparse
 import os
@@ -20,7 +20,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 
 from rela_amd.pyrela import create_env, utils  # noqa: E402
 from rela_amd.pyrela.apex import ApexAgent  # noqa: E402
-from rela_amd.pyrela.net import AtariFFNet  # noqa: E402
+from rela_amd.pyrela.net import AtariFFNet, AtariLSTMNet  # noqa: E402
+from rela_amd.pyrela.r2d2 import R2D2Agent  # noqa: E402
 
 rela = create_env.rela
 
@@ -29,7 +30,11 @@ def parse_args(argv=None):
     p = argparse.ArgumentParser(description="Ape-X on synthetic Atari-shaped envs (MI355X)")
     p.add_argument("--save_dir", type=str, default="exps/exp1")
     p.add_argument("--multi_step", type=int, default=3)
-    p.add_argument("--algo", type=str, default="apex")
+    p.add_argument("--algo", type=str, default="apex", help="apex/r2d2")
+    p.add_argument("--seq_burn_in", type=int, default=40)
+    p.add_argument("--seq_len", type=int, default=80)
+    p.add_argument("--eta", type=float, default=0.9)
+    p.add_argument("--same_hid", type=int, default=0)
     p.add_argument("--game", type=str, default="synthetic")
     p.add_argument("--seed", type=int, default=10002)
     p.add_argument("--max_frame", type=int, default=108000)
@@ -58,26 +63,37 @@ def parse_args(argv=None):
 
 
 def train(args, on_epoch=None):
-    if args.algo != "apex":
-        raise SystemExit("--algo %s: only the Ape-X path is built (R2D2 rows are next)" % args.algo)
+    if args.algo not in ("apex", "r2d2"):
+        raise SystemExit("--algo must be apex or r2d2")
     torch.manual_seed(args.seed + 2)
     torch.cuda.manual_seed(args.seed + 3)
     pprint.pprint(vars(args))
 
     num_action = create_env.get_num_action(args.game)
-    agent = ApexAgent(lambda: AtariFFNet(num_action), args.multi_step, args.gamma).to(args.train_device)
-    optim = torch.optim.RMSprop(agent.online_net.parameters(), lr=args.lr, eps=args.eps)
+    if args.algo == "r2d2":  # pyrela/main.py:98-109,123-126
+        agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, num_action), args.train_device, args.multi_step, args.gamma,
+                          args.eta, args.seq_len, args.seq_burn_in, args.same_hid).to(args.train_device)
+        optim = torch.optim.Adam(agent.online_net.parameters(), lr=args.lr, eps=args.eps)
+        replay_class = rela.RNNPrioritizedReplay
+    else:  # :110-122
+        agent = ApexAgent(lambda: AtariFFNet(num_action), args.multi_step, args.gamma).to(args.train_device)
+        optim = torch.optim.RMSprop(agent.online_net.parameters(), lr=args.lr, eps=args.eps)
+        replay_class = rela.FFPrioritizedReplay
 
     act_devices = args.act_device.split(",")
     if len(act_devices) != 1:
         raise SystemExit("one replay partition per actor GPU: launch one process per act device (DESIGN.md §6)")
     lockers = [rela.ModelLocker([agent, agent, agent], d) for d in act_devices]  # 3 weight versions per device
 
-    replay_buffer = rela.FFPrioritizedReplay(args.replay_buffer_size, args.seed, args.priority_exponent,
-                                             args.importance_exponent, args.prefetch)
+    replay_buffer = replay_class(args.replay_buffer_size, args.seed, args.priority_exponent,
+                                 args.importance_exponent, args.prefetch)
     explore_eps = utils.generate_eps(args.act_base_eps, args.act_eps_alpha, args.num_thread * args.num_game_per_thread)
-    make_actor = lambda i: rela.DQNActor(lockers[i % len(lockers)], args.multi_step, args.num_game_per_thread,
-                                         args.gamma, replay_buffer)
+    if args.algo == "r2d2":
+        make_actor = lambda i: rela.R2D2Actor(lockers[i % len(lockers)], args.multi_step, args.num_game_per_thread,
+                                              args.gamma, args.seq_len, args.seq_burn_in, replay_buffer)
+    else:
+        make_actor = lambda i: rela.DQNActor(lockers[i % len(lockers)], args.multi_step, args.num_game_per_thread,
+                                             args.gamma, replay_buffer)
     print("creating train env")
     context, games, actors = create_env.create_train_env(args.seed, explore_eps, args.episode_len, args.num_thread,
                                                          args.num_game_per_thread, make_actor)

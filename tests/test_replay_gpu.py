@@ -161,6 +161,33 @@ def test_random_scenario_vs_oracle(cap, batch, block, rounds, kind):
     g.close()
 
 
+def test_update_with_heavy_duplicates():
+    """update() (prioritized_replay.h:105-119) when almost every sampled id is the same slot: the
+    i-th occurrence must see the weight written by the previous occurrence.  Regression test for a
+    shared-memory race in replay_update (duplicate scan vs. last-occurrence flags)."""
+    from gpu_util import GpuReplay
+    from oracle_lib import OracleReplay
+
+    rng = np.random.default_rng(9)
+    for trial in range(20):
+        g, o = GpuReplay(64, 5 + trial, 1.0, 0.4), OracleReplay(64, 5 + trial, 1.0, 0.4)
+        p = rng.uniform(1e-4, 1e-3, 48).astype(np.float32)
+        p[rng.integers(0, 48, 2)] = 50.0  # two slots soak up nearly all strata
+        assert g.add_tags(np.arange(48), p) == 0 and o.add(np.arange(48), p) == 0
+        for r in range(3):
+            rc, ids, _, _ = o.sample(512)
+            assert rc == 0
+            rc, _, _ = g.sample(512)
+            assert rc == 0
+            np.testing.assert_array_equal(g.state(512)["ids"], ids)
+            assert len(set(ids.tolist())) < 40
+            newp = rng.uniform(0.5, 60, 512).astype(np.float32)
+            assert o.update(newp) == 0 and g.update(newp, on_device=bool(r % 2)) == 0
+            assert g.state()["sum"] == o.state()["sum"], (trial, r)
+            np.testing.assert_array_equal(g.weights()[0], o.weights())
+        g.close()
+
+
 def test_protocol_errors():
     from gpu_util import GpuReplay
     from rela_amd import _capi as capi
