@@ -59,9 +59,19 @@ struct ConvCfg {
   static constexpr int RPW = (RT + RG - 1) / RG;
   static constexpr int K = CIN * KH * KW;
   static constexpr int KS = K / 4;
+  // LDS image of one f32 sample: pixel stride PIX floats, row stride ROW, sample stride SAMP, padded
+  // so that the dword address of output position p (flattened over the samples of the block) is
+  // 2*p + const (mod 32): the 16 rows x 2 k-lanes of a ds_read_b32 group then hit 32 distinct banks.
+  //   STRIDE*PIX = 2 (mod 32);  STRIDE*ROW = 2*OW (mod 32);  SAMP = 2*OH*OW (mod 32)
   static constexpr int PIX = U8 ? 0 : (CIN + (STRIDE == 2 ? 1 : 2));  // floats per LDS pixel
+  static constexpr int ROW_RAW = IW * PIX;
+  static constexpr int ROW_NEED = STRIDE == 2 ? OW : 2 * OW;            // ROW mod (STRIDE == 2 ? 16 : 32)
+  static constexpr int ROW_MOD = STRIDE == 2 ? 16 : 32;
+  static constexpr int ROW = U8 ? 0 : ROW_RAW + ((ROW_NEED - ROW_RAW % ROW_MOD) % ROW_MOD + ROW_MOD) % ROW_MOD;
+  static constexpr int SAMP_RAW = IH * ROW;
+  static constexpr int SAMP = U8 ? 0 : SAMP_RAW + ((2 * OH * OW - SAMP_RAW) % 32 + 32) % 32;
   static constexpr int IN_ELEMS = CIN * IH * IW;                        // per sample
-  static constexpr int LDS_BYTES = U8 ? S * IN_ELEMS : S * IH * IW * PIX * 4;
+  static constexpr int LDS_BYTES = U8 ? S * IN_ELEMS : S * SAMP * 4;
 };
 
 using Conv2 = ConvCfg<32, 20, 20, 4, 4, 2, 9, 9, 64, 2, false>;
@@ -90,7 +100,9 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const void* __restrict__ i
     for (int i = tid; i < C::S * per; i += kThreads) {
       const float4 v = (i < ns * per) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       const int pixel = i / cq_n, cq = i - pixel * cq_n;
-      float* d = dst + pixel * C::PIX + cq * 4;
+      const int smp = pixel / (C::IH * C::IW), pin = pixel - smp * (C::IH * C::IW);
+      const int y = pin / C::IW, x = pin - y * C::IW;
+      float* d = dst + smp * C::SAMP + y * C::ROW + x * C::PIX + cq * 4;
       d[0] = v.x;
       d[1] = v.y;
       d[2] = v.z;
@@ -113,7 +125,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const void* __restrict__ i
     if constexpr (C::U8)
       abase[t] = s * C::IN_ELEMS + oy * C::STRIDE * C::IW + ox * C::STRIDE + kk;
     else
-      abase[t] = ((s * C::IH * C::IW + oy * C::STRIDE * C::IW + ox * C::STRIDE) * C::PIX + kk) * 4;
+      abase[t] = (s * C::SAMP + oy * C::STRIDE * C::ROW + ox * C::STRIDE * C::PIX + kk) * 4;
   }
 
   f32x4 acc[C::RPW];
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const void* __restrict__ i
 #pragma unroll
         for (int cq = 0; cq < C::CIN / 4; ++cq) {
           const int ks = (kh * C::KW + kw) * (C::CIN / 4) + cq;
-          const int koff = ((kh * C::IW + kw) * C::PIX + cq * 4) * 4;
+          const int koff = (kh * C::ROW + kw * C::PIX + cq * 4) * 4;
           const float b = bptr[(size_t)ks * 64];
 #pragma unroll
           for (int t = 0; t < C::RPW; ++t) {

@@ -131,15 +131,14 @@ __global__ __launch_bounds__(kThreads) void replay_gather_rows(const uint8_t* __
 // canonical = float(u32)/2^32 clamped below 1 (oracle/mt19937.c restates it).
 // The reference scans once for all targets and never moves backwards, so the effective
 // target of sample i is max(rand_0..rand_i); a non-positive target means "first acc > 0".
-__global__ void replay_targets(const uint32_t* __restrict__ draws, int batch, ReplayDevState* __restrict__ st,
-                               float* __restrict__ targets, double* __restrict__ eff) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(1024) void replay_targets(const uint32_t* __restrict__ draws, int batch,
+                                                       ReplayDevState* __restrict__ st, float* __restrict__ targets,
+                                                       double* __restrict__ eff) {
+  __shared__ double run[kMaxBatch];
   const float sum = (float)st->sum;
-  st->sum_f = sum;
   const float segment = sum / (float)batch;
   const float cap = sum - 0.2f;
-  double run = 4.9406564584124654e-324;  // denorm_min: acc >= it  <=>  acc > 0
-  for (int i = 0; i < batch; ++i) {
+  for (int i = threadIdx.x; i < batch; i += blockDim.x) {
     float c = (float)draws[i] * 2.3283064365386963e-10f;  // exact scaling by 2^-32
     if (c >= 1.0f) c = 0.99999994f;
     const float u = c * segment + 0.0f;
@@ -147,10 +146,22 @@ __global__ void replay_targets(const uint32_t* __restrict__ draws, int batch, Re
     float r = u + off;
     r = (r < cap) ? r : cap;  // std::min(sum - 0.2f, rand)
     targets[i] = r;
-    const double rd = (double)r;
-    if (rd > run) run = rd;
-    eff[i] = run;
+    // denorm_min: acc >= it  <=>  acc > 0
+    run[i] = fmax((double)r, 4.9406564584124654e-324);
   }
+  __syncthreads();
+  // inclusive prefix maximum (Hillis-Steele in LDS; batch <= 4096)
+  for (int off = 1; off < batch; off <<= 1) {
+    double v[kMaxBatch / 1024];
+    int c = 0;
+    for (int i = threadIdx.x; i < batch; i += blockDim.x, ++c) v[c] = (i >= off) ? fmax(run[i], run[i - off]) : run[i];
+    __syncthreads();
+    c = 0;
+    for (int i = threadIdx.x; i < batch; i += blockDim.x, ++c) run[i] = v[c];
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < batch; i += blockDim.x) eff[i] = run[i];
+  if (threadIdx.x == 0) st->sum_f = sum;
 }
 
 // one wavefront per stratum (seq_find_wave): the 512 searches of a batch spread over the chip
@@ -235,19 +246,15 @@ __global__ __launch_bounds__(1024) void replay_update(const float* __restrict__ 
     float d = 0.f;
     bool last = true;
     if (!evicted[id]) {
+      // no early exits: every lane reads the same sid[j] (an LDS broadcast), the loop pipelines
       int prev = -1;
-      for (int j = i - 1; j >= 0; --j)
-        if (sid[j] == id) {
-          prev = j;
-          break;
-        }
+      for (int j = 0; j < n; ++j) {
+        const bool same = sid[j] == id;
+        prev = (same && j < i) ? j : prev;
+        last = (same && j > i) ? false : last;
+      }
       const float old = prev >= 0 ? neww[prev] : w[id];
       d = neww[i] - old;  // float - float :113
-      for (int j = i + 1; j < n; ++j)
-        if (sid[j] == id) {
-          last = false;
-          break;
-        }
     } else {
       last = false;
     }
@@ -503,7 +510,7 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
   if (rc != RELA_OK) return rc;
   {
     ProfScope prof("replay_targets", r->stream);
-    hipLaunchKernelGGL(replay_targets, dim3(1), dim3(64), 0, r->stream, r->d_draws, batch, r->d_state,
+    hipLaunchKernelGGL(replay_targets, dim3(1), dim3(1024), 0, r->stream, r->d_draws, batch, r->d_state,
                        r->d_targets, r->d_eff);
   }
   {

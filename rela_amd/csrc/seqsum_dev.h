@@ -71,12 +71,23 @@ __device__ inline double seq_prefix(const SeqView& v, int64_t k) {
 // by one coalesced load each and consumed through lane broadcasts, so a search costs ~3 memory
 // round trips instead of ~100 dependent ones.  Every lane must call these with the same
 // arguments; every lane gets the same result.
+// `src` is wave-uniform: v_readlane_b32 (a few cycles) instead of ds_bpermute_b32 (an LDS round trip)
+__device__ __forceinline__ int rl_i(int x, int src) { return __builtin_amdgcn_readlane(x, src); }
+__device__ __forceinline__ float rl_f(float x, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src));
+}
+__device__ __forceinline__ double rl_d(double x, int src) {
+  const long long b = __double_as_longlong(x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 __device__ __forceinline__ SeqTab seq_tab_bcast(const SeqTab& mine, int src) {
   SeqTab t;
-  t.d[0] = __shfl(mine.d[0], src, 64);
-  t.d[1] = __shfl(mine.d[1], src, 64);
-  t.e = __shfl(mine.e, src, 64);
-  t.par = __shfl(mine.par, src, 64);
+  t.d[0] = rl_d(mine.d[0], src);
+  t.d[1] = rl_d(mine.d[1], src);
+  t.e = rl_i(mine.e, src);
+  t.par = rl_i(mine.par, src);
   return t;
 }
 
@@ -120,7 +131,7 @@ __device__ inline SeqHit seq_walk_wave(const SeqView& v, double A0, int64_t k0, 
       const float wl = at(k + lane);  // 64 weights, one coalesced load (0 beyond size)
       const int cnt = (int)((k + kL1 <= kend) ? kL1 : (kend - k));
       for (int e = 0; e < cnt; ++e) {
-        const float we = __shfl(wl, e, 64);
+        const float we = rl_f(wl, e);
         A += (double)we;
         if (A >= target) {
           h.k = k + e;
