@@ -25,6 +25,8 @@
 // accumulation: every product is exact and the result is fp32-accurate, while the layer drops
 // from MFMA-bound to HBM-bound (28 KB in + 51 KB out per sample).  The /255 of net.py:46 is
 // folded into conv1's weights at load time.
+#include <cstdlib>
+
 #include "common.h"
 #include "prof.h"
 
@@ -74,8 +76,11 @@ struct ConvCfg {
   static constexpr int LDS_BYTES = U8 ? S * IN_ELEMS : S * SAMP * 4;
 };
 
-using Conv2 = ConvCfg<32, 20, 20, 4, 4, 2, 9, 9, 64, 2, false>;
-using Conv3 = ConvCfg<64, 9, 9, 3, 3, 1, 7, 7, 64, 4, false>;
+// Samples per block: conv2 keeps ONE sample resident (53 KB of LDS -> 3 blocks per CU, so one block's
+// staging phase overlaps the others' MFMA phase; measured 458 -> 388 us per 6400 against S = 2 despite
+// 81 -> 96 row padding); conv3 keeps four (S = 2 measured the same).
+using Conv2 = ConvCfg<32, 20, 20, 4, 4, 2, 9, 9, 64, 1, false>;
+using Conv3 = ConvCfg<64, 9, 9, 3, 3, 1, 7, 7, 64, 3, false>;
 
 template <class C>
 __global__ __launch_bounds__(kThreads) void conv_mfma(const void* __restrict__ in_, const float* __restrict__ Bfrag,
@@ -394,13 +399,22 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma(const float* __restrict__ 
 
   load_chunk(0);
   store_chunk(0);
+  // B fragments stream from L2 one K-chunk AHEAD of their use (register double buffer), so the
+  // MFMAs of a chunk never wait on the fragment loads issued in the same chunk
+  float bnext[G::KC / 4];
+#pragma unroll
+  for (int j = 0; j < G::KC / 4; ++j) bnext[j] = bptr[(size_t)j * 64];
   __syncthreads();
   for (int ch = 0; ch < G::NCH; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < G::NCH) load_chunk(ch + 1);
     float bfr[G::KC / 4];
 #pragma unroll
-    for (int j = 0; j < G::KC / 4; ++j) bfr[j] = bptr[(size_t)(ch * (G::KC / 4) + j) * 64];
+    for (int j = 0; j < G::KC / 4; ++j) bfr[j] = bnext[j];
+    if (ch + 1 < G::NCH) {
+#pragma unroll
+      for (int j = 0; j < G::KC / 4; ++j) bnext[j] = bptr[(size_t)((ch + 1) * (G::KC / 4) + j) * 64];
+    }
 #pragma unroll
     for (int j = 0; j < G::KC / 4; ++j) {
 #pragma unroll
