@@ -154,13 +154,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible and there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = "cuda:%d" % local_rank
+    # Rehearsal switch for a one-GPU box: all ranks share cuda:0 and talk over gloo (RCCL refuses two
+    # ranks on one device).  The driver's real N > 1 runs use one GPU per rank and RCCL.
+    rehearsal = os.environ.get("RELA_BENCH_REHEARSAL", "0") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = "cuda:%d" % dev_index
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from rela_amd import build as _build

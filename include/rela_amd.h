@@ -39,6 +39,10 @@ int rela_abi_version(void);
 int rela_stream_create(void** out, int device);
 void rela_stream_destroy(void* stream, int device);
 int rela_stream_synchronize(void* stream, int device);
+/* work queued on `waiter` after this call starts only after everything queued on `signaler` so far */
+int rela_stream_wait_stream(void* waiter, void* signaler, int device);
+/* asynchronous host->device copy on `stream` (page-locked sources overlap with compute) */
+int rela_memcpy_h2d_async(void* dst_dev, const void* src_host, int64_t bytes, void* stream, int device);
 
 /* ===================================================================================
  * Prioritized replay  --  rela/prioritized_replay.h:173-348 (PrioritizedReplay<T>) over
@@ -80,6 +84,11 @@ int rela_replay_write_rows(rela_replay* r, int first_slot, int offset, int count
                            const void* const* rows_dev, void* stream);
 int rela_replay_commit_add(rela_replay* r, int first_slot, int n, const float* priority_dev,
                            void* stream);
+/* The same commit for n = G*group_rows slots that stand for G consecutive reference blocks of
+ * group_rows items (G actor threads batched into one launch): the float block sum and the
+ * `sum_ +=` of :58-66,73 are taken per group, in order, exactly as G separate appends would.   */
+int rela_replay_commit_add_grouped(rela_replay* r, int first_slot, int n, int group_rows,
+                                   const float* priority_dev, void* stream);
 
 /* add(sample, priority)  prioritized_replay.h:186-200 -> blockAppend :43-78.
  * rows_dev[f] points at n consecutive rows of field f (device); priority_dev is f32[n]
@@ -105,6 +114,11 @@ int rela_replay_sample(rela_replay* r, int batch, void* const* out_rows_dev, flo
  * pyrela/apex.py:90).  `stream`: the stream that produced a device-side priority.          */
 int rela_replay_update_priority(rela_replay* r, int n, const float* priority, int on_device,
                                 void* stream);
+
+/* Teardown aid (no reference counterpart: there a producer parked on a full ring, :47, keeps its
+ * Context from joining forever).  After shutdown every pending and future begin_add/add returns
+ * RELA_EWOULDBLOCK immediately; sample/update keep working.                                  */
+int rela_replay_shutdown(rela_replay* r);
 
 int rela_replay_size(const rela_replay* r);        /* size()    :245-247 */
 int64_t rela_replay_num_add(const rela_replay* r); /* numAdd()  :251-253 */

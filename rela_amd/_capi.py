@@ -61,6 +61,8 @@ _sig("rela_abi_version", i32, [])
 _sig("rela_stream_create", i32, [P(vp), i32])
 _sig("rela_stream_destroy", None, [vp, i32])
 _sig("rela_stream_synchronize", i32, [vp, i32])
+_sig("rela_stream_wait_stream", i32, [vp, vp, i32])
+_sig("rela_memcpy_h2d_async", i32, [vp, vp, i64, vp, i32])
 _sig("rela_replay_create", i32, [P(vp), i32, i32, f32, f32, i32, i32])
 _sig("rela_replay_destroy", None, [vp])
 _sig("rela_replay_set_schema", i32, [vp, i32, P(i64)])
@@ -68,9 +70,11 @@ _sig("rela_replay_set_schema_seq", i32, [vp, i32, P(i64), P(C.c_int32)])
 _sig("rela_replay_begin_add", i32, [vp, i32, i32, P(i32)])
 _sig("rela_replay_write_rows", i32, [vp, i32, i32, i32, P(vp), vp])
 _sig("rela_replay_commit_add", i32, [vp, i32, i32, vp, vp])
+_sig("rela_replay_commit_add_grouped", i32, [vp, i32, i32, i32, vp, vp])
 _sig("rela_replay_add", i32, [vp, i32, P(vp), vp, i32, vp])
 _sig("rela_replay_sample", i32, [vp, i32, P(vp), vp, vp])
 _sig("rela_replay_update_priority", i32, [vp, i32, vp, i32, vp])
+_sig("rela_replay_shutdown", i32, [vp])
 _sig("rela_replay_size", i32, [vp])
 _sig("rela_replay_num_add", i64, [vp])
 _sig("rela_replay_debug_state", i32, [vp, P(ReplayState), vp, vp, vp])

@@ -176,7 +176,11 @@ extern "C" int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward
   if (rc != RELA_OK) return rc;
   // FFTransition rows (types.h:18-51): obs{s,eps,legal_move}, next_obs{...}, action{a}, reward, terminal, bootstrap
   const void* rows[10] = {obs_t, obs_n, a->eps, a->eps, a->legal, a->legal, act_t, a->out_r, a->out_t, a->out_b};
-  rc = rela_replay_add(a->replay, a->R, rows, a->prio, nonblocking, s);
+  // one reference block per group of K rows (each batched actor thread's own add, :189)
+  int slot = 0;
+  rc = rela_replay_begin_add(a->replay, a->R, nonblocking, &slot);
+  if (rc == RELA_OK) rc = rela_replay_write_rows(a->replay, slot, 0, a->R, rows, s);
+  if (rc == RELA_OK) rc = rela_replay_commit_add_grouped(a->replay, slot, a->R, a->K, a->prio, s);
   a->head = (a->head + 1) % H;  // pop_front :101-104
   a->count -= 1;
   if (rc == RELA_OK && inserted) *inserted = 1;

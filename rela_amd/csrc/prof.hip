@@ -112,3 +112,20 @@ extern "C" int rela_stream_synchronize(void* stream, int device) {
   RELA_HIP(hipStreamSynchronize((hipStream_t)stream));
   return RELA_OK;
 }
+
+extern "C" int rela_stream_wait_stream(void* waiter, void* signaler, int device) {
+  DeviceGuard g(device);
+  hipEvent_t ev = nullptr;
+  RELA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  RELA_HIP(hipEventRecord(ev, (hipStream_t)signaler));
+  RELA_HIP(hipStreamWaitEvent((hipStream_t)waiter, ev, 0));
+  RELA_HIP(hipEventDestroy(ev));  // released once the recorded work has completed
+  return RELA_OK;
+}
+
+extern "C" int rela_memcpy_h2d_async(void* dst_dev, const void* src_host, int64_t bytes, void* stream, int device) {
+  RELA_CHECK(dst_dev && src_host && bytes >= 0, RELA_EINVAL, "rela_memcpy_h2d_async: bad arguments");
+  DeviceGuard g(device);
+  RELA_HIP(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  return RELA_OK;
+}

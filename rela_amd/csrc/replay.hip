@@ -59,12 +59,17 @@ __device__ __forceinline__ float pow_alpha(float p, float alpha) {
 // ---- add ------------------------------------------------------------------------------
 // blockAppend :57-66,73.  One workgroup: weights in parallel, then lane 0 accumulates the
 // block sum in FLOAT in slot order (exactly `sum += weightAcc[i]`) and adds it to sum_.
+// `group` > 0: the n slots are n/group consecutive reference blocks (one per batched actor thread);
+// each block's float sum is added to sum_ separately, in order.
 __global__ __launch_bounds__(kThreads) void replay_append_weights(const float* __restrict__ prio, int n,
                                                                   float alpha, float* __restrict__ w,
-                                                                  int ring, int start,
+                                                                  int ring, int start, int group,
                                                                   ReplayDevState* __restrict__ st) {
   __shared__ float chunk[2048];
   float fsum = 0.f;
+  double dsum = 0.0;  // lane 0 only
+  if (threadIdx.x == 0) dsum = st->sum;
+  const int g = group > 0 ? group : n;
   for (int base = 0; base < n; base += 2048) {
     const int m = min(2048, n - base);
     for (int i = threadIdx.x; i < m; i += kThreads) {
@@ -74,11 +79,20 @@ __global__ __launch_bounds__(kThreads) void replay_append_weights(const float* _
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      for (int i = 0; i < m; ++i) fsum += chunk[i];
+      for (int i = 0; i < m; ++i) {
+        fsum += chunk[i];
+        if ((base + i + 1) % g == 0) {  // end of one reference block: sum_ += sum :73
+          dsum += (double)fsum;
+          fsum = 0.f;
+        }
+      }
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) st->sum += (double)fsum;
+  if (threadIdx.x == 0) {
+    if (n % g != 0) dsum += (double)fsum;
+    st->sum = dsum;
+  }
 }
 
 // copies n rows of one field into ring slots start.. (mod ring); 16-byte lanes when possible
@@ -285,6 +299,7 @@ struct rela_replay {
   mutable std::mutex m;
   std::condition_variable cv_size;
   int head = 0, tail = 0, size = 0;
+  bool shut = false;                 // rela_replay_shutdown: producers no longer block
   int safe_tail = 0, safe_size = 0;  // committed prefix, ConcurrentQueue::safeTail_/safeSize_
   std::condition_variable cv_tail;
   std::atomic<int64_t> num_add{0};
@@ -407,9 +422,11 @@ extern "C" int rela_replay_begin_add(rela_replay* r, int n, int nonblocking, int
   RELA_CHECK(r && n > 0 && first_slot, RELA_EINVAL, "rela_replay_begin_add: bad arguments");
   RELA_CHECK(n <= r->ring, RELA_EINVAL, "rela_replay_begin_add: block of %d exceeds the ring (%d)", n, r->ring);
   std::unique_lock<std::mutex> lk(r->m);
+  if (r->shut) return RELA_EWOULDBLOCK;
   if (r->size + n > r->ring) {  // cvSize_.wait :47
     if (nonblocking) return RELA_EWOULDBLOCK;
-    r->cv_size.wait(lk, [&] { return r->size + n <= r->ring; });
+    r->cv_size.wait(lk, [&] { return r->shut || r->size + n <= r->ring; });
+    if (r->shut) return RELA_EWOULDBLOCK;
   }
   *first_slot = r->tail;
   r->tail = (r->tail + n) % r->ring;
@@ -450,7 +467,12 @@ extern "C" int rela_replay_write_rows(rela_replay* r, int first_slot, int offset
 
 extern "C" int rela_replay_commit_add(rela_replay* r, int first_slot, int n, const float* priority_dev,
                                       void* stream_) {
-  RELA_CHECK(r && n > 0 && priority_dev, RELA_EINVAL, "rela_replay_commit_add: bad arguments");
+  return rela_replay_commit_add_grouped(r, first_slot, n, 0, priority_dev, stream_);
+}
+
+extern "C" int rela_replay_commit_add_grouped(rela_replay* r, int first_slot, int n, int group_rows,
+                                              const float* priority_dev, void* stream_) {
+  RELA_CHECK(r && n > 0 && priority_dev && group_rows >= 0, RELA_EINVAL, "rela_replay_commit_add: bad arguments");
   hipStream_t producer = (hipStream_t)stream_;
   DeviceGuard g(r->device);
   std::unique_lock<std::mutex> lk(r->m);
@@ -460,7 +482,7 @@ extern "C" int rela_replay_commit_add(rela_replay* r, int first_slot, int n, con
   {
     ProfScope prof("replay_append_weights", r->stream);
     hipLaunchKernelGGL(replay_append_weights, dim3(1), dim3(kThreads), 0, r->stream, priority_dev, n, r->alpha,
-                       r->d_w, r->ring, first_slot, r->d_state);
+                       r->d_w, r->ring, first_slot, group_rows, r->d_state);
   }
   RELA_LAUNCH_CHECK();
   RELA_HIP(hipEventRecord(r->ev_out, r->stream));
@@ -589,6 +611,16 @@ extern "C" int rela_replay_update_priority(rela_replay* r, int n, const float* p
     RELA_HIP(hipStreamWaitEvent(producer, r->ev_out, 0));
   }
   r->n_sampled = 0;  // sampledIds_.clear() :244
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_shutdown(rela_replay* r) {
+  RELA_CHECK(r, RELA_EINVAL, "rela_replay_shutdown: bad arguments");
+  {
+    std::lock_guard<std::mutex> lk(r->m);
+    r->shut = true;
+  }
+  r->cv_size.notify_all();
   return RELA_OK;
 }
 

@@ -17,6 +17,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -132,6 +133,11 @@ class Actor {
   virtual TensorDict act(TensorDict& obs) = 0;
   virtual void setRewardAndTerminal(torch::Tensor& r, torch::Tensor& t) = 0;
   virtual void postStep() = 0;
+  // runtime hook, not part of the reference interface: the thread that drove this actor has left
+  // its main loop (lets batched cohorts release the remaining members)
+  virtual void onLoopExit() {}
+  // runtime hook: the owning Context is being destroyed -- unpark anything that could block a join
+  virtual void onShutdown() {}
 };
 
 // =====================================================================================
@@ -310,6 +316,10 @@ class FFPrioritizedReplay {
 
   int size() const { return h_ ? rela_replay_size(h_) : 0; }
   int numAdd() const { return h_ ? (int)rela_replay_num_add(h_) : 0; }
+  void shutdown() {
+    std::lock_guard<std::mutex> lk(m_);
+    if (h_) rela_replay_shutdown(h_);
+  }
 
   std::tuple<FFTransition, torch::Tensor> sample(int batchsize, const std::string& device) {
     if (!h_) throw std::runtime_error("FFPrioritizedReplay.sample: the replay is empty");
@@ -403,6 +413,10 @@ class RNNPrioritizedReplay {
 
   int size() const { return h_ ? rela_replay_size(h_) : 0; }
   int numAdd() const { return h_ ? (int)rela_replay_num_add(h_) : 0; }
+  void shutdown() {
+    std::lock_guard<std::mutex> lk(m_);
+    if (h_) rela_replay_shutdown(h_);
+  }
 
   std::tuple<RNNTransition, torch::Tensor> sample(int batchsize, const std::string& device) {
     if (!h_) throw std::runtime_error("RNNPrioritizedReplay.sample: the replay is empty");
@@ -467,6 +481,180 @@ class RNNPrioritizedReplay {
 };
 
 // =====================================================================================
+// ActorCohort -- cross-thread inference batching ("inference batches cross-thread per GPU").
+//
+// The T training DQNActors of one Context that share (ModelLocker, replay, K, n, gamma) are backed
+// by ONE device shard of T*K rows (rela_apex_actor with group_rows = K).  Every thread still runs
+// the reference loop (thread_loop.h:74-105) on its own K envs; act() / postStep() rendezvous at a
+// barrier and the last arriver launches the batched work for all rows.  Scope-sensitive arithmetic
+// is unchanged: q.min() is taken per group of K rows (one reference TorchScript call) and every
+// member's transitions are committed as their own K-slot block (in member order), so the replay
+// sees exactly what T independent actors would have appended -- only in a fixed order.
+// =====================================================================================
+class ActorCohort {
+ public:
+  ActorCohort(std::shared_ptr<ModelLocker> locker, std::shared_ptr<FFPrioritizedReplay> replay, int multiStep, int K,
+              float gamma, int members)
+      : locker_(std::move(locker)), replay_(std::move(replay)), n_(multiStep), K_(K), gamma_(gamma), T_(members),
+        numAct_(members) {
+    for (auto& c : numAct_) c.store(0);
+  }
+
+  ~ActorCohort() {
+    rela_apex_actor_destroy(h_);
+    const int dev = locker_->deviceIndex;
+    if (compute_) rela_stream_destroy(compute_, dev);
+    if (upload_) rela_stream_destroy(upload_, dev);
+  }
+
+  int numAct(int member) const { return (int)numAct_[member].load(); }
+
+  TensorDict act(int member, TensorDict& obs) {
+    const auto& s = obs.at("s");
+    const auto& legal = obs.at("legal_move");
+    const auto& eps = obs.at("eps");
+    if (s.size(0) != K_ || s.numel() != (int64_t)K_ * kObsBytes || s.dtype() != torch::kUInt8)
+      throw std::runtime_error("DQNActor.act: obs['s'] must be uint8 [batchsize,4,84,84]");
+    const int A = (int)legal.size(1);
+    std::unique_lock<std::mutex> lk(m_);
+    if (draining_) return drained();
+    if (!h_) create(A);
+    // this member's rows: frames go straight to the HBM history slot on the upload stream,
+    // the per-env constants to the host staging (uploaded by the leader when they changed)
+    auto sc = s.contiguous();
+    check(rela_memcpy_h2d_async(static_cast<uint8_t*>(rela_apex_actor_obs_slot(h_)) + (int64_t)member * K_ * kObsBytes,
+                                sc.data_ptr(), (int64_t)K_ * kObsBytes, upload_, locker_->deviceIndex),
+          "rela_memcpy_h2d_async");
+    keepObs_[member] = sc;
+    auto e = eps.reshape({K_}).to(torch::kFloat32).contiguous();
+    auto l = legal.to(torch::kFloat32).contiguous();
+    float* ed = epsAll_.data_ptr<float>() + (int64_t)member * K_;
+    float* ld = legalAll_.data_ptr<float>() + (int64_t)member * K_ * A;
+    if (!constsValid_ || std::memcmp(ed, e.data_ptr(), e.nbytes()) != 0 || std::memcmp(ld, l.data_ptr(), l.nbytes()) != 0) {
+      std::memcpy(ed, e.data_ptr(), e.nbytes());
+      std::memcpy(ld, l.data_ptr(), l.nbytes());
+      constsDirty_ = true;
+    }
+    rendezvous(lk, [&] {
+      check(rela_stream_wait_stream(compute_, upload_, locker_->deviceIndex), "rela_stream_wait_stream");
+      auto lease = locker_->getModel();
+      const int rc = rela_apex_actor_act(h_, static_cast<const rela_ffnet*>(lease.online), nullptr,
+                                         constsDirty_ ? epsAll_.data_ptr<float>() : nullptr,
+                                         constsDirty_ ? legalAll_.data_ptr<float>() : nullptr,
+                                         actionAll_.data_ptr<int64_t>(), nullptr, compute_);
+      locker_->releaseModel(lease.id);
+      check(rc, "DQNActor.act (batched)");
+      constsDirty_ = false;
+      constsValid_ = true;
+    });
+    if (draining_) return drained();
+    numAct_[member] += K_;
+    return TensorDict{{"a", actionAll_.narrow(0, (int64_t)member * K_, K_)}};
+  }
+
+  void setRewardAndTerminal(int member, torch::Tensor& r, torch::Tensor& t) {
+    auto rf = r.to(torch::kFloat32).contiguous();
+    auto tb = t.to(torch::kBool).contiguous();
+    std::lock_guard<std::mutex> lk(m_);
+    if (!h_ || draining_) return;
+    std::memcpy(rewardAll_.data_ptr<float>() + (int64_t)member * K_, rf.data_ptr(), (size_t)K_ * sizeof(float));
+    std::memcpy(terminalAll_.data_ptr<bool>() + (int64_t)member * K_, tb.data_ptr(), (size_t)K_);
+  }
+
+  void postStep(int member) {
+    (void)member;
+    std::unique_lock<std::mutex> lk(m_);
+    if (!h_ || draining_) return;
+    rendezvous(lk, [&] {
+      auto lease = locker_->getModel();
+      const int rc = rela_apex_actor_post_step(h_, rewardAll_.data_ptr<float>(),
+                                               reinterpret_cast<const uint8_t*>(terminalAll_.data_ptr<bool>()), 0,
+                                               static_cast<const rela_ffnet*>(lease.online),
+                                               static_cast<const rela_ffnet*>(lease.target), 0, nullptr, compute_);
+      locker_->releaseModel(lease.id);
+      if (rc != RELA_EWOULDBLOCK) check(rc, "DQNActor.postStep (batched)");  // dropped block after shutdown
+      // The next round's frames land in the history slot this tick just read (the ring reuses
+      // slot `head`): uploads must start after the tick's queued kernels and row copies.
+      check(rela_stream_wait_stream(upload_, compute_, locker_->deviceIndex), "rela_stream_wait_stream");
+    });
+  }
+
+  void shutdown() {
+    replay_->shutdown();
+    std::lock_guard<std::mutex> lk(m_);
+    draining_ = true;
+    cv_.notify_all();
+  }
+
+  void leave(int member) {
+    (void)member;
+    std::lock_guard<std::mutex> lk(m_);
+    draining_ = true;  // one member gone: the cohort cannot complete another round
+    cv_.notify_all();
+  }
+
+ private:
+  template <class F>
+  void rendezvous(std::unique_lock<std::mutex>& lk, F&& leaderWork) {
+    const uint64_t gen = generation_;
+    if (++arrived_ == T_) {
+      try {
+        leaderWork();
+      } catch (...) {
+        draining_ = true;
+        arrived_ = 0;
+        ++generation_;
+        cv_.notify_all();
+        throw;
+      }
+      arrived_ = 0;
+      ++generation_;
+      cv_.notify_all();
+    } else {
+      cv_.wait(lk, [&] { return generation_ != gen || draining_; });
+    }
+  }
+
+  TensorDict drained() { return TensorDict{{"a", torch::zeros({K_}, torch::kInt64)}}; }
+
+  void create(int A) {
+    if (locker_->kind() != ModelLocker::kFF)
+      throw std::runtime_error("DQNActor needs an AtariFFNet-shaped agent in its ModelLocker");
+    const int dev = locker_->deviceIndex;
+    static std::atomic<uint64_t> counter{0};
+    rela_replay* rep = replay_->handle(dev, A);
+    check(rela_stream_create(&compute_, dev), "rela_stream_create");
+    check(rela_stream_create(&upload_, dev), "rela_stream_create");
+    check(rela_apex_actor_create(&h_, T_ * K_, K_, A, n_, gamma_, rep, 0xA24BAED4963EE407ull * (++counter), dev),
+          "rela_apex_actor_create");
+    auto pin = [](torch::Tensor t) { return torch::cuda::is_available() ? t.pin_memory() : t; };
+    const int64_t R = (int64_t)T_ * K_;
+    actionAll_ = pin(torch::zeros({R}, torch::kInt64));
+    epsAll_ = pin(torch::zeros({R}, torch::kFloat32));
+    legalAll_ = pin(torch::zeros({R, A}, torch::kFloat32));
+    rewardAll_ = pin(torch::zeros({R}, torch::kFloat32));
+    terminalAll_ = pin(torch::zeros({R}, torch::kBool));
+    keepObs_.resize(T_);
+  }
+
+  std::shared_ptr<ModelLocker> locker_;
+  std::shared_ptr<FFPrioritizedReplay> replay_;
+  const int n_, K_;
+  const float gamma_;
+  const int T_;
+  rela_apex_actor* h_ = nullptr;
+  void *compute_ = nullptr, *upload_ = nullptr;
+  torch::Tensor actionAll_, epsAll_, legalAll_, rewardAll_, terminalAll_;
+  std::vector<torch::Tensor> keepObs_;
+  std::vector<std::atomic<int64_t>> numAct_;
+  bool constsValid_ = false, constsDirty_ = false, draining_ = false;
+  std::mutex m_;
+  std::condition_variable cv_;
+  int arrived_ = 0;
+  uint64_t generation_ = 0;
+};
+
+// =====================================================================================
 // DQNActor (rela/dqn_actor.h:126-211)
 // =====================================================================================
 class DQNActor : public Actor {
@@ -485,9 +673,34 @@ class DQNActor : public Actor {
     if (stream_) rela_stream_destroy(stream_, locker_->deviceIndex);
   }
 
-  int numAct() const { return h_ ? (int)rela_apex_actor_num_act(h_) : 0; }
+  int numAct() const {
+    if (cohort_) return cohort_->numAct(member_);
+    return h_ ? (int)rela_apex_actor_num_act(h_) : 0;
+  }
+
+  // batching key: actors that agree on all of these may share one device shard
+  bool trainable() const { return replay_ != nullptr; }
+  const void* lockerKey() const { return locker_.get(); }
+  const void* replayKey() const { return replay_.get(); }
+  int batchsize() const { return batchsize_; }
+  int multiStep() const { return multiStep_; }
+  float gamma() const { return gamma_; }
+  std::shared_ptr<ModelLocker> locker() const { return locker_; }
+  std::shared_ptr<FFPrioritizedReplay> replay() const { return replay_; }
+  void joinCohort(std::shared_ptr<ActorCohort> c, int member) {
+    cohort_ = std::move(c);
+    member_ = member;
+  }
+  void onLoopExit() override {
+    if (cohort_) cohort_->leave(member_);
+  }
+  void onShutdown() override {
+    if (cohort_) cohort_->shutdown();
+    if (replay_) replay_->shutdown();
+  }
 
   TensorDict act(TensorDict& obs) override {
+    if (cohort_) return cohort_->act(member_, obs);
     const auto& s = obs.at("s");
     const auto& legal = obs.at("legal_move");
     const auto& eps = obs.at("eps");
@@ -535,19 +748,21 @@ class DQNActor : public Actor {
 
   void setRewardAndTerminal(torch::Tensor& r, torch::Tensor& t) override {
     if (!replay_) throw std::runtime_error("DQNActor: evaluation actor has no replay");  // :175
+    if (cohort_) return cohort_->setRewardAndTerminal(member_, r, t);
     reward_ = r.to(torch::kFloat32).contiguous();
     terminal_ = t.to(torch::kBool).contiguous();
   }
 
   void postStep() override {
     if (!replay_) throw std::runtime_error("DQNActor: evaluation actor has no replay");  // :182
+    if (cohort_) return cohort_->postStep(member_);
     auto lease = locker_->getModel();
     const int rc = rela_apex_actor_post_step(h_, reward_.data_ptr<float>(),
                                              reinterpret_cast<const uint8_t*>(terminal_.data_ptr<bool>()), 0,
                                              static_cast<const rela_ffnet*>(lease.online),
                                              static_cast<const rela_ffnet*>(lease.target), 0, nullptr, stream_);
     locker_->releaseModel(lease.id);
-    check(rc, "DQNActor.postStep");
+    if (rc != RELA_EWOULDBLOCK) check(rc, "DQNActor.postStep");  // dropped block after replay shutdown
   }
 
  private:
@@ -559,6 +774,8 @@ class DQNActor : public Actor {
   void* stream_ = nullptr;  // this actor thread's private HIP stream
   torch::Tensor action_, epsHost_, legalHost_, reward_, terminal_;
   bool constsValid_ = false;
+  std::shared_ptr<ActorCohort> cohort_;  // set when this actor is batched with its siblings
+  int member_ = -1;
 };
 
 // =====================================================================================
@@ -585,6 +802,9 @@ class R2D2Actor : public Actor {
   }
 
   int numAct() const { return h_ ? (int)rela_r2d2_actor_num_act(h_) : 0; }
+  void onShutdown() override {
+    if (replay_) replay_->shutdown();
+  }
 
   TensorDict act(TensorDict& obs) override {
     const auto& s = obs.at("s");
@@ -646,7 +866,7 @@ class R2D2Actor : public Actor {
                                              static_cast<const rela_lstmnet*>(lease.online),
                                              static_cast<const rela_lstmnet*>(lease.target), 0, nullptr, stream_);
     locker_->releaseModel(lease.id);
-    check(rc, "R2D2Actor.postStep");
+    if (rc != RELA_EWOULDBLOCK) check(rc, "R2D2Actor.postStep");  // dropped block after replay shutdown
   }
 
  private:
@@ -685,6 +905,7 @@ class ThreadLoop {
   }
   virtual bool terminated() { return stop_.load(); }
   virtual void mainLoop() = 0;
+  virtual std::shared_ptr<Actor> actor() const { return nullptr; }
 
  protected:
   // blocks while paused; like the reference, terminate() alone does not wake a paused loop
@@ -722,7 +943,10 @@ class BasicThreadLoop : public ThreadLoop {
       }
       if (eval_) break;  // one episode
     }
+    actor_->onLoopExit();
   }
+
+  std::shared_ptr<Actor> actor() const override { return actor_; }
 
  private:
   std::shared_ptr<Actor> actor_;
@@ -739,6 +963,8 @@ class Context {
   ~Context() {
     for (auto& l : loops_) l->terminate();
     for (auto& l : loops_) l->resume();  // unlike the reference, never leave a paused thread unjoinable
+    for (auto& l : loops_)
+      if (auto a = l->actor()) a->onShutdown();  // ... nor one parked on a full replay ring
     for (auto& th : threads_)
       if (th.joinable()) th.join();
   }
@@ -751,6 +977,7 @@ class Context {
 
   void start() {
     started_ = true;
+    formCohorts();
     for (size_t i = 0; i < loops_.size(); ++i) {
       threads_.emplace_back([this, i] {
         loops_[i]->mainLoop();
@@ -770,6 +997,36 @@ class Context {
   bool terminated() { return done_.load() == (int)loops_.size(); }
 
  private:
+  // Training DQNActors of this context that share (locker, replay, K, n, gamma) are batched into
+  // one device shard (ActorCohort); a lone actor keeps its private shard.  RELA_NO_COHORT=1 opts out.
+  void formCohorts() {
+    if (const char* off = std::getenv("RELA_NO_COHORT"))
+      if (off[0] == '1') return;
+    std::vector<std::vector<std::shared_ptr<DQNActor>>> buckets;
+    for (auto& l : loops_) {
+      auto a = std::dynamic_pointer_cast<DQNActor>(l->actor());
+      if (!a || !a->trainable()) continue;
+      bool placed = false;
+      for (auto& b : buckets) {
+        auto& f = b.front();
+        if (f->lockerKey() == a->lockerKey() && f->replayKey() == a->replayKey() && f->batchsize() == a->batchsize() &&
+            f->multiStep() == a->multiStep() && f->gamma() == a->gamma()) {
+          b.push_back(a);
+          placed = true;
+          break;
+        }
+      }
+      if (!placed) buckets.push_back({a});
+    }
+    for (auto& b : buckets) {
+      if (b.size() < 2) continue;
+      auto& f = b.front();
+      auto cohort = std::make_shared<ActorCohort>(f->locker(), f->replay(), f->multiStep(), f->batchsize(), f->gamma(),
+                                                  (int)b.size());
+      for (size_t i = 0; i < b.size(); ++i) b[i]->joinCohort(cohort, (int)i);
+    }
+  }
+
   bool started_ = false;
   std::atomic<int> done_{0};
   std::vector<std::shared_ptr<ThreadLoop>> loops_;

@@ -1,0 +1,90 @@
+"""Actor-rate benchmark of the threaded drop-in (counterpart of pyrela/benchmark.py:19-126).
+
+T C++ actor threads x K synthetic envs run BasicThreadLoop -> DQNActor (HIP) -> FFPrioritizedReplay
+(HBM).  The act rate (sum of num_act() deltas / s, pyrela/utils.py:40-44) is measured over
+`num_epoch` windows without sampling and `num_epoch` windows with a concurrent B = 512
+sample / update_priority loop; the mean of the last half of each is reported, as upstream.
+Unlike bench.py this path includes host env stepping and the per-step host->HBM observation upload.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+from rela_amd.pyrela import create_env, utils  # noqa: E402
+from rela_amd.pyrela.apex import ApexAgent  # noqa: E402
+from rela_amd.pyrela.net import AtariFFNet  # noqa: E402
+
+rela = create_env.rela
+
+
+def benchmark_fps(num_thread, num_game_per_thread, args):
+    num_action = create_env.get_num_action("synthetic")
+    agent = ApexAgent(lambda: AtariFFNet(num_action), 3, 0.99).to(args.device)
+    locker = rela.ModelLocker([agent], args.device)
+    replay_buffer = rela.FFPrioritizedReplay(args.replay_buffer_size, args.seed, 0.6, 0.4, 0)
+    eps = utils.generate_eps(0.4, 7, num_thread * num_game_per_thread)
+    make_actor = lambda i: rela.DQNActor(locker, 1, num_game_per_thread, 0.99, replay_buffer)
+    context, games, actors = create_env.create_train_env(args.seed, eps, args.episode_len, num_thread,
+                                                         num_game_per_thread, make_actor)
+    context.start()
+    while replay_buffer.size() < args.burn_in_frames:
+        time.sleep(0.2)
+    seen = utils.total_acts(actors)
+    rates = {"without": [], "with": []}
+    for mode in ("without", "with"):
+        for epoch in range(args.num_epoch):
+            t0 = time.time()
+            if mode == "without":
+                time.sleep(args.epoch_sec)
+            else:
+                while time.time() - t0 <= args.epoch_sec:
+                    batch, weight = replay_buffer.sample(512, args.device)
+                    replay_buffer.update_priority(weight)
+            dt = time.time() - t0
+            now = utils.total_acts(actors)
+            rates[mode].append((now - seen) / dt)
+            seen = now
+            print("%s sample: epoch %d, act rate: %d, buffer size: %d" % (mode, epoch, rates[mode][-1],
+                                                                          replay_buffer.size()), flush=True)
+    context.terminate()
+    context.resume()
+    while not context.terminated():
+        if replay_buffer.size() >= 512:  # unpark actors blocked on a full ring
+            batch, weight = replay_buffer.sample(512, args.device)
+            replay_buffer.update_priority(weight)
+        time.sleep(0.01)
+    half = args.num_epoch // 2
+    return float(np.mean(rates["without"][-half or None:])), float(np.mean(rates["with"][-half or None:]))
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--device", default="cuda:0")
+    p.add_argument("--seed", type=int, default=10001)
+    p.add_argument("--replay_buffer_size", type=int, default=2 ** 21)
+    p.add_argument("--burn_in_frames", type=int, default=1000)
+    p.add_argument("--episode_len", type=int, default=200)
+    p.add_argument("--epoch_sec", type=float, default=30)
+    p.add_argument("--num_epoch", type=int, default=6)
+    p.add_argument("--grid", default="80x20,80x40,80x80,80x160", help="threads x games per thread")
+    args = p.parse_args(argv)
+    rows = []
+    for cell in args.grid.split(","):
+        t, k = (int(v) for v in cell.split("x"))
+        without, with_ = benchmark_fps(t, k, args)
+        rows.append((t, k, without, with_))
+        print("act rate: without sample: %.2f, with sample: %.2f" % (without, with_), flush=True)
+    print("%8s %14s %24s %24s" % ("#thread", "#game/thread", "act rate (w/o sample)", "act rate (with sample)"))
+    for r in rows:
+        print("%8d %14d %24.1f %24.1f" % r)
+    return rows
+
+
+if __name__ == "__main__":
+    main()

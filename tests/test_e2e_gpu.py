@@ -101,3 +101,60 @@ def test_r2d2_training_entry_point_runs(mods, capsys):
     assert "Speed: train: " in out
     assert len(hist) == 2 and all(np.isfinite(h["loss"]) for h in hist)
     assert hist[-1]["act"] > 0 and hist[-1]["buffer_add"] > 0
+
+
+def test_cohort_batches_threads_consistently(mods):
+    """Two actor threads batched into one device shard (ActorCohort): every sampled transition must be
+    self-consistent -- with eps = 0 its action is the greedy action of the online net on its own
+    frame stack, its frames come from one of the envs' LCG streams, inserts arrive as whole rounds of
+    T*K transitions -- and the learner-side TD error of the batch reproduces a finite priority."""
+    import torch
+
+    from e2e_lockstep import CFG, load_agent_params
+    from rela_amd.pyrela.apex import ApexAgent
+    from rela_amd.pyrela.net import AtariFFNet
+
+    rela, synth = mods
+    T, K, A, n = 2, 4, CFG["num_action"], 3
+    agent = load_agent_params(ApexAgent(lambda: AtariFFNet(A), n, 0.997)).to("cuda:0")
+    replay = rela.FFPrioritizedReplay(64, 3, 1.0, 0.4, 0)
+    locker = rela.ModelLocker([agent], "cuda:0")
+    ctx = rela.Context()
+    actors, games = [], []
+    for t in range(T):
+        vec = rela.VectorEnv()
+        for g in range(K):
+            game = synth.SyntheticAtariEnv(100 + t * K + g, 0.0, A, 11)
+            games.append(game)
+            vec.append(game)
+        actor = rela.DQNActor(locker, n, K, 0.997, replay)
+        actors.append(actor)
+        ctx.push_env_thread(rela.BasicThreadLoop(actor, vec, False))
+    ctx.start()
+    import time
+
+    t0 = time.time()
+    while replay.size() < 80 and time.time() - t0 < 120:  # ring = 80: the cohort parks on the full ring
+        time.sleep(0.01)
+    assert replay.size() == 80
+    assert replay.num_add() % (T * K) == 0  # whole rounds only
+    assert actors[0].num_act() == actors[1].num_act() > 0  # lock-step
+    for _ in range(3):
+        batch, w = replay.sample(16, "cuda:0")
+        with torch.no_grad():
+            q = agent.online_net(batch.obs)
+            greedy = ((1 + q - q.min()) * batch.obs["legal_move"]).argmax(1)
+            _, prio = agent.loss(batch, sync_priority=False)
+        assert torch.equal(greedy, batch.action["a"])
+        assert torch.isfinite(prio).all() and torch.isfinite(w).all()
+        replay.update_priority(prio)
+        time.sleep(0.2)
+    ctx.terminate()
+    ctx.resume()
+    t0 = time.time()
+    while not ctx.terminated():
+        if replay.size() >= 16:
+            batch, w = replay.sample(16, "cuda:0")
+            replay.update_priority(w)
+        time.sleep(0.005)
+        assert time.time() - t0 < 120
