@@ -178,7 +178,8 @@ def main():
         dist.barrier()
     from rela_amd import _capi as capi
     from rela_amd.engine import ApexActorEngine, FFNetHandle
-    from rela_amd.learner import allreduce_grads
+    from rela_amd.engine import dev_view
+    from rela_amd.learner import allreduce_grads, global_is_weights
     from rela_amd.pyrela.apex import ApexAgent
     from rela_amd.pyrela.net import AtariFFNet
     from rela_amd.replay import FFReplay
@@ -232,6 +233,12 @@ def main():
             target.load_state_dict(agent.target_net.state_dict())
             actor_stream.wait_stream(main_stream)
         batch, weight = replay.sample(BATCH)
+        if world > 1:  # one replay partition per GPU: normalise the IS weights over all of them
+            raw_p, sum_p = C.c_void_p(), C.c_void_p()
+            capi.check(capi.lib.rela_replay_last_sample_dev(replay.h, C.byref(raw_p), C.byref(sum_p)), "last_sample")
+            raw_w = dev_view(raw_p.value, (BATCH,), torch.float32, torch.device(device))
+            part_sum = dev_view(sum_p.value, (1,), torch.float32, torch.device(device))
+            weight = global_is_weights(raw_w, part_sum, replay.size(), BETA)
         loss, prio = agent.loss(batch, sync_priority=False)
         (loss * weight).mean().backward()
         if world > 1:

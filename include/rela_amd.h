@@ -115,6 +115,11 @@ int rela_replay_sample(rela_replay* r, int batch, void* const* out_rows_dev, flo
 int rela_replay_update_priority(rela_replay* r, int n, const float* priority, int on_device,
                                 void* stream);
 
+/* Device pointers to what the last sample() left behind, for exchanges between replay partitions
+ * (SURVEY 8e): the un-normalised weights w_i of the outstanding batch (:289) and the float sum
+ * the stratified targets were drawn against (:261-262).  Valid until the next sample().       */
+int rela_replay_last_sample_dev(rela_replay* r, const float** raw_w_dev, const float** sum_f_dev);
+
 /* Teardown aid (no reference counterpart: there a producer parked on a full ring, :47, keeps its
  * Context from joining forever).  After shutdown every pending and future begin_add/add returns
  * RELA_EWOULDBLOCK immediately; sample/update keep working.                                  */

@@ -74,6 +74,7 @@ _sig("rela_replay_commit_add_grouped", i32, [vp, i32, i32, i32, vp, vp])
 _sig("rela_replay_add", i32, [vp, i32, P(vp), vp, i32, vp])
 _sig("rela_replay_sample", i32, [vp, i32, P(vp), vp, vp])
 _sig("rela_replay_update_priority", i32, [vp, i32, vp, i32, vp])
+_sig("rela_replay_last_sample_dev", i32, [vp, P(vp), P(vp)])
 _sig("rela_replay_shutdown", i32, [vp])
 _sig("rela_replay_size", i32, [vp])
 _sig("rela_replay_num_add", i64, [vp])

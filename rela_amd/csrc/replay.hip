@@ -614,6 +614,13 @@ extern "C" int rela_replay_update_priority(rela_replay* r, int n, const float* p
   return RELA_OK;
 }
 
+extern "C" int rela_replay_last_sample_dev(rela_replay* r, const float** raw_w_dev, const float** sum_f_dev) {
+  RELA_CHECK(r, RELA_EINVAL, "rela_replay_last_sample_dev: bad arguments");
+  if (raw_w_dev) *raw_w_dev = r->d_raw_w;
+  if (sum_f_dev) *sum_f_dev = &r->d_state->sum_f;
+  return RELA_OK;
+}
+
 extern "C" int rela_replay_shutdown(rela_replay* r) {
   RELA_CHECK(r, RELA_EINVAL, "rela_replay_shutdown: bad arguments");
   {

@@ -23,3 +23,24 @@ def allreduce_grads(params, world_size, group=None):
         n = g.numel()
         g.copy_(flat[off:off + n].view_as(g))
         off += n
+
+
+def global_is_weights(raw_w, partition_sum, partition_size, beta, group=None):
+    """Importance weights of one replay PARTITION normalised over ALL partitions.
+
+    The reference computes  w = (size * raw / sum) ** -beta;  w /= w.max()  over its single buffer
+    (rela/prioritized_replay.h:320-322).  With one partition per actor GPU, `size` and `sum` become the
+    totals over the partitions (one SUM all-reduce of two scalars) and the maximum is taken over every
+    rank's batch (one MAX all-reduce of a scalar) -- the "priority all-reduce" of the north star.
+    raw_w: f32[B] un-normalised weights of this rank's sample; partition_sum / partition_size: this
+    partition's weight sum (tensor or float) and item count.  Two tiny collectives per learner step.
+    """
+    dev = raw_w.device
+    stats = torch.stack([torch.as_tensor(partition_sum, dtype=torch.float64, device=dev).reshape(()),
+                         torch.as_tensor(float(partition_size), dtype=torch.float64, device=dev).reshape(())])
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
+    total_sum, total_size = stats[0].float(), stats[1].float()
+    w = (total_size * (raw_w / total_sum)).pow(-beta)
+    top = w.max()
+    dist.all_reduce(top, op=dist.ReduceOp.MAX, group=group)
+    return w / top

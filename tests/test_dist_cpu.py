@@ -68,3 +68,44 @@ def test_two_rank_gradient_allreduce_keeps_replicas_identical():
         opt.zero_grad()
     ref = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     torch.testing.assert_close(a, ref, rtol=1e-5, atol=1e-6)
+
+
+def _is_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rela_amd.learner import global_is_weights
+
+    g = torch.Generator().manual_seed(5)
+    raw = torch.rand(2, 16, generator=g) + 0.05      # two partitions' sampled raw weights
+    sums = torch.tensor([123.5, 77.25])
+    sizes = [1000, 640]
+    w = global_is_weights(raw[rank], sums[rank], sizes[rank], 0.4)
+    gathered = [torch.zeros_like(w) for _ in range(world)]
+    dist.all_gather(gathered, w)
+    if rank == 0:
+        out.put([t.tolist() for t in gathered])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_partition_is_weight_normalisation():
+    """IS weights over two replay partitions == the single-buffer formula on the union."""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_is_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(5)
+    raw = torch.rand(2, 16, generator=g) + 0.05
+    total_sum, total_size = torch.tensor(123.5 + 77.25), torch.tensor(1640.0)
+    ref = (total_size * (raw.reshape(-1) / total_sum)).pow(-0.4)  # prioritized_replay.h:320-322 on the union
+    ref = ref / ref.max()
+    got = torch.tensor(res).reshape(-1)
+    torch.testing.assert_close(got, ref, rtol=1e-6, atol=0)
+    assert got.max() == 1.0
