@@ -1,0 +1,26 @@
+"""Evaluation on the `rela` module (counterpart of pyrela/eval.py:9-36): `num_thread` single-env
+eval threads (BasicThreadLoop(actor, env, True): one episode each, no replay, thread_loop.h:66-71,
+92-103) driven by evaluation actors (DQNActor(locker) / R2D2Actor(locker)) with eps = 0; returns the
+mean episode reward.  The locker must live on a cuda device (this engine has no CPU actor path)."""
+import time
+
+import numpy as np
+
+from rela_amd.pyrela import create_env
+
+rela = create_env.rela
+
+
+def evaluate(num_thread, model_locker, actor_cls, seed, episode_len, eval_eps=0.0):
+    context = rela.Context()
+    games = []
+    for i in range(num_thread):
+        game = create_env.create_game(seed + i, eval_eps, episode_len)
+        games.append(game)
+        env = rela.VectorEnv()
+        env.append(game)
+        context.push_env_thread(rela.BasicThreadLoop(actor_cls(model_locker), env, True))
+    context.start()
+    while not context.terminated():
+        time.sleep(0.05)
+    return float(np.mean([g.get_episode_reward() for g in games]))

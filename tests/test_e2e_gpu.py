@@ -158,3 +158,25 @@ def test_cohort_batches_threads_consistently(mods):
             replay.update_priority(w)
         time.sleep(0.005)
         assert time.time() - t0 < 120
+
+
+def test_eval_path_runs_one_episode_per_thread(mods):
+    """BasicThreadLoop(eval=True) semantics (thread_loop.h:66-71,92-103): exactly one env, one episode,
+    no replay traffic; evaluation actors act greedily (eps = 0) and the context terminates by itself."""
+    from e2e_lockstep import CFG, load_agent_params
+    from rela_amd.pyrela.apex import ApexAgent
+    from rela_amd.pyrela.eval import evaluate
+    from rela_amd.pyrela.net import AtariFFNet
+
+    rela, synth = mods
+    agent = load_agent_params(ApexAgent(lambda: AtariFFNet(CFG["num_action"]), 3, 0.997))
+    locker = rela.ModelLocker([agent], "cuda:0")
+    score = evaluate(3, locker, rela.DQNActor, 77, 25)
+    assert -25.0 <= score <= 25.0
+    again = evaluate(3, locker, rela.DQNActor, 77, 25)
+    assert again == score  # greedy + seeded envs: deterministic
+    with pytest.raises(ValueError):
+        v = rela.VectorEnv()
+        v.append(synth.SyntheticAtariEnv(1, 0.0, 18, 5))
+        v.append(synth.SyntheticAtariEnv(2, 0.0, 18, 5))
+        rela.BasicThreadLoop(rela.DQNActor(locker), v, True)  # eval loops drive exactly one env
