@@ -74,6 +74,7 @@ struct ConvCfg {
   static constexpr int SAMP = U8 ? 0 : SAMP_RAW + ((2 * OH * OW - SAMP_RAW) % 32 + 32) % 32;
   static constexpr int IN_ELEMS = CIN * IH * IW;                        // per sample
   static constexpr int LDS_BYTES = U8 ? S * IN_ELEMS : S * SAMP * 4;
+  static constexpr bool BSTAT = !U8 && K / 4 <= 128;  // weight column tile fits the register budget
 };
 
 // Samples per block: conv2 keeps ONE sample resident (53 KB of LDS -> 3 blocks per CU, so one block's
@@ -96,22 +97,45 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const void* __restrict__ i
     const uint4* src = reinterpret_cast<const uint4*>(static_cast<const uint8_t*>(in_) + (size_t)n0 * C::IN_ELEMS);
     uint4* dst = reinterpret_cast<uint4*>(smem);
     constexpr int per = C::IN_ELEMS / 16;
-    for (int i = tid; i < C::S * per; i += kThreads) dst[i] = (i < ns * per) ? src[i] : make_uint4(0, 0, 0, 0);
+    // all loads of the tile in flight before the first LDS write (one HBM round trip, not IT)
+    constexpr int IT = (C::S * per + kThreads - 1) / kThreads;
+    uint4 v[IT];
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      const int i = tid + j * kThreads;
+      v[j] = (i < ns * per) ? src[i] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      const int i = tid + j * kThreads;
+      if (i < C::S * per) dst[i] = v[j];
+    }
   } else {
     const float4* src = reinterpret_cast<const float4*>(static_cast<const float*>(in_) + (size_t)n0 * C::IN_ELEMS);
     float* dst = reinterpret_cast<float*>(smem);
     constexpr int cq_n = C::CIN / 4;
     constexpr int per = C::IN_ELEMS / 4;
-    for (int i = tid; i < C::S * per; i += kThreads) {
-      const float4 v = (i < ns * per) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const int pixel = i / cq_n, cq = i - pixel * cq_n;
-      const int smp = pixel / (C::IH * C::IW), pin = pixel - smp * (C::IH * C::IW);
-      const int y = pin / C::IW, x = pin - y * C::IW;
-      float* d = dst + smp * C::SAMP + y * C::ROW + x * C::PIX + cq * 4;
-      d[0] = v.x;
-      d[1] = v.y;
-      d[2] = v.z;
-      d[3] = v.w;
+    // all loads of the tile in flight before the first LDS write (one HBM round trip, not IT)
+    constexpr int IT = (C::S * per + kThreads - 1) / kThreads;
+    float4 v[IT];
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      const int i = tid + j * kThreads;
+      v[j] = (i < ns * per) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      const int i = tid + j * kThreads;
+      if (i < C::S * per) {
+        const int pixel = i / cq_n, cq = i - pixel * cq_n;
+        const int smp = pixel / (C::IH * C::IW), pin = pixel - smp * (C::IH * C::IW);
+        const int y = pin / C::IW, x = pin - y * C::IW;
+        float* d = dst + smp * C::SAMP + y * C::ROW + x * C::PIX + cq * 4;
+        d[0] = v[j].x;
+        d[1] = v[j].y;
+        d[2] = v[j].z;
+        d[3] = v[j].w;
+      }
     }
   }
   __syncthreads();
@@ -158,21 +182,30 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const void* __restrict__ i
       }
     }
   } else {
-    // k = (kh, kw, c), c fastest: one k-step = 4 consecutive channels of one input pixel
-    for (int kh = 0; kh < C::KH; ++kh) {
-      for (int kw = 0; kw < C::KW; ++kw) {
+    // k = (kh, kw, c), c fastest: one k-step = 4 consecutive channels of one input pixel.
+    // The B fragments of one (kh, kw) chunk are fetched (L2) a whole chunk ahead of their use.
+    constexpr int CQ = C::CIN / 4, NCH = C::KH * C::KW;
+    float bcur[CQ], bnext[CQ];
 #pragma unroll
-        for (int cq = 0; cq < C::CIN / 4; ++cq) {
-          const int ks = (kh * C::KW + kw) * (C::CIN / 4) + cq;
-          const int koff = (kh * C::ROW + kw * C::PIX + cq * 4) * 4;
-          const float b = bptr[(size_t)ks * 64];
+    for (int cq = 0; cq < CQ; ++cq) bcur[cq] = bptr[(size_t)cq * 64];
 #pragma unroll
-          for (int t = 0; t < C::RPW; ++t) {
-            const float a = *reinterpret_cast<const float*>(smem + abase[t] + koff);
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[t], 0, 0, 0);
-          }
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int kh = ch / C::KW, kw = ch - kh * C::KW;
+      if (ch + 1 < NCH) {
+#pragma unroll
+        for (int cq = 0; cq < CQ; ++cq) bnext[cq] = bptr[(size_t)((ch + 1) * CQ + cq) * 64];
+      }
+#pragma unroll
+      for (int cq = 0; cq < CQ; ++cq) {
+        const int koff = (kh * C::ROW + kw * C::PIX + cq * 4) * 4;
+#pragma unroll
+        for (int t = 0; t < C::RPW; ++t) {
+          const float a = *reinterpret_cast<const float*>(smem + abase[t] + koff);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bcur[cq], acc[t], 0, 0, 0);
         }
       }
+#pragma unroll
+      for (int cq = 0; cq < CQ; ++cq) bcur[cq] = bnext[cq];
     }
   }
 
@@ -192,6 +225,152 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const void* __restrict__ i
       }
     }
   }
+}
+
+// ---- B-stationary persistent variant for large batches -------------------------------------
+// Ablation of conv_mfma at N = 6400 (conv2: 372 us with, 306 us without the per-k-step B-fragment
+// loads) shows the weight fetches, not the LDS reads or the tile staging, stall the MFMA stream.
+// One column tile of the weights is K x 16 floats = KS registers per lane (128 / 144), so here
+// every wave keeps ITS column tile in registers for the whole launch and the block (one per CU,
+// 2 waves per SIMD) walks over its share of the samples with a double-buffered LDS input tile:
+// the global loads of group g+1 are issued before the k-loop of group g and written to the other
+// buffer halfway through it.  The k-loop then touches only LDS (A) and registers (B).
+constexpr int kNumCU = 256;
+
+template <class C>
+__global__ __launch_bounds__(kThreads) void conv_mfma_bstat(const float* __restrict__ in,
+                                                            const float* __restrict__ Bfrag,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ out, int N) {
+  static_assert(!C::U8, "f32 channel-last input only");
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int ct = wave % C::CT, rg = wave / C::CT;
+  const int li = lane & 15, kk = lane >> 4;
+  const int ngroups = (N + C::S - 1) / C::S;
+
+  float breg[C::KS];
+  {
+    const float* bptr = Bfrag + (size_t)ct * C::KS * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) breg[ks] = bptr[(size_t)ks * 64];
+  }
+
+  int abase[C::RPW];
+#pragma unroll
+  for (int t = 0; t < C::RPW; ++t) {
+    const int m = (rg + t * C::RG) * 16 + li;
+    const int mm = (m < C::M) ? m : 0;
+    const int sm = mm / C::P, pos = mm - sm * C::P;
+    const int oy = pos / C::OW, ox = pos - oy * C::OW;
+    abase[t] = (sm * C::SAMP + oy * C::STRIDE * C::ROW + ox * C::STRIDE * C::PIX + kk) * 4;
+  }
+  const int col = ct * 16 + li;
+  const float bv = bias[col];
+
+  // staging in two phases of IT2 float4 per thread (keeps the live set below 256 registers)
+  constexpr int cq_n = C::CIN / 4;
+  constexpr int per = C::IN_ELEMS / 4;
+  constexpr int IT = (C::S * per + kThreads - 1) / kThreads;
+  constexpr int IT2 = (IT + 1) / 2;
+  float4 v[IT2];
+  auto stage_load = [&](int g, int phase) {
+    const int n0 = g * C::S;
+    const int ns = min(C::S, N - n0);
+    const float4* src = reinterpret_cast<const float4*>(in + (size_t)n0 * C::IN_ELEMS);
+#pragma unroll
+    for (int j = 0; j < IT2; ++j) {
+      const int i = tid + (phase * IT2 + j) * kThreads;
+      v[j] = (i < ns * per) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage_store = [&](int buf, int phase) {
+    float* dst = reinterpret_cast<float*>(smem + buf * C::LDS_BYTES);
+#pragma unroll
+    for (int j = 0; j < IT2; ++j) {
+      const int i = tid + (phase * IT2 + j) * kThreads;
+      if (i < C::S * per) {
+        const int pixel = i / cq_n, cq = i - pixel * cq_n;
+        const int sm = pixel / (C::IH * C::IW), pin = pixel - sm * (C::IH * C::IW);
+        const int y = pin / C::IW, x = pin - y * C::IW;
+        float* d = dst + sm * C::SAMP + y * C::ROW + x * C::PIX + cq * 4;
+        d[0] = v[j].x;
+        d[1] = v[j].y;
+        d[2] = v[j].z;
+        d[3] = v[j].w;
+      }
+    }
+  };
+
+  int g = blockIdx.x;
+  if (g >= ngroups) return;
+  stage_load(g, 0);
+  stage_store(0, 0);
+  stage_load(g, 1);
+  stage_store(0, 1);
+  __syncthreads();
+  int buf = 0;
+  constexpr int CQ = C::CIN / 4, NCH = C::KH * C::KW;
+  for (; g < ngroups; g += gridDim.x) {
+    const bool has_next = g + (int)gridDim.x < ngroups;
+    if (has_next) stage_load(g + gridDim.x, 0);
+    const uint8_t* tile = smem + buf * C::LDS_BYTES;
+    f32x4 acc[C::RPW];
+#pragma unroll
+    for (int t = 0; t < C::RPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int kh = ch / C::KW, kw = ch - kh * C::KW;
+#pragma unroll
+      for (int cq = 0; cq < CQ; ++cq) {
+        const int koff = (kh * C::ROW + kw * C::PIX + cq * 4) * 4;
+#pragma unroll
+        for (int t = 0; t < C::RPW; ++t) {
+          const float a = *reinterpret_cast<const float*>(tile + abase[t] + koff);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, breg[ch * CQ + cq], acc[t], 0, 0, 0);
+        }
+      }
+      // the other buffer was last read one group ago (barrier since): fill it while this group computes
+      if (has_next) {
+        if (ch == NCH / 3) {
+          stage_store(buf ^ 1, 0);
+          stage_load(g + gridDim.x, 1);
+        } else if (ch == (2 * NCH) / 3) {
+          stage_store(buf ^ 1, 1);
+        }
+      }
+    }
+    const int n0 = g * C::S;
+    const int mlim = min(C::S, N - n0) * C::P;
+#pragma unroll
+    for (int t = 0; t < C::RPW; ++t) {
+      const int rt = rg + t * C::RG;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = rt * 16 + kk * 4 + r;
+        if (m < mlim) {
+          const float o = acc[t][r] + bv;
+          out[((size_t)n0 * C::P + m) * C::OC + col] = o > 0.f ? o : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+// Picks the B-stationary kernel once every CU gets at least two sample groups.  conv3 stays on
+// conv_mfma: its 144 + 20 accumulator registers spill under the 256-register budget and with one
+// block per CU the 2134 groups of N = 6400 quantise to 9 rounds (measured 259 us against 227 us).
+template <class C>
+void launch_conv(const float* in, const float* Bfrag, const float* bias, float* out, int N, hipStream_t s) {
+  const int ngroups = ceil_div(N, C::S);
+  if (C::BSTAT && ngroups >= 2 * kNumCU)
+    hipLaunchKernelGGL(conv_mfma_bstat<C>, dim3(kNumCU), dim3(kThreads), 2 * C::LDS_BYTES, s, in, Bfrag, bias, out, N);
+  else
+    hipLaunchKernelGGL(conv_mfma<C>, dim3(ngroups), dim3(kThreads), C::LDS_BYTES, s, (const void*)in, Bfrag, bias,
+                       out, N);
 }
 
 // ---- conv1 on bf16 MFMA, exact-weight split ------------------------------------------------
@@ -227,7 +406,19 @@ __global__ __launch_bounds__(kThreads) void conv1_bf16x3(const uint8_t* __restri
     const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)n0 * C::IN_ELEMS);
     uint4* dst = reinterpret_cast<uint4*>(smem);
     constexpr int per = C::IN_ELEMS / 16;
-    for (int i = tid; i < C::S * per; i += kThreads) dst[i] = (i < ns * per) ? src[i] : make_uint4(0, 0, 0, 0);
+    // all loads of the tile in flight before the first LDS write (one HBM round trip, not IT)
+    constexpr int IT = (C::S * per + kThreads - 1) / kThreads;
+    uint4 v[IT];
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      const int i = tid + j * kThreads;
+      v[j] = (i < ns * per) ? src[i] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+      const int i = tid + j * kThreads;
+      if (i < C::S * per) dst[i] = v[j];
+    }
   }
   __syncthreads();
 
@@ -590,6 +781,10 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv2::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv3>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv3::LDS_BYTES));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bstat<Conv2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Conv2::LDS_BYTES));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bstat<Conv3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Conv3::LDS_BYTES));
   *out = n;
   return RELA_OK;
 }
@@ -684,13 +879,11 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
   }
   {
     ProfScope prof("conv2_mfma", s);
-    hipLaunchKernelGGL(conv_mfma<Conv2>, dim3(ceil_div(N, Conv2::S)), dim3(kThreads), Conv2::LDS_BYTES, s,
-                       (const void*)a1, d.B2, d.b2, a2, N);
+    launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
   }
   {
     ProfScope prof("conv3_mfma", s);
-    hipLaunchKernelGGL(conv_mfma<Conv3>, dim3(ceil_div(N, Conv3::S)), dim3(kThreads), Conv3::LDS_BYTES, s,
-                       (const void*)a2, d.B3, d.b3, a3, N);
+    launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
   }
   {
     ProfScope prof("fc_mfma", s);
@@ -758,6 +951,10 @@ extern "C" int rela_lstmnet_create(rela_lstmnet** out, int num_action, int devic
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv2::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv3>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv3::LDS_BYTES));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bstat<Conv2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Conv2::LDS_BYTES));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_bstat<Conv3>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * Conv3::LDS_BYTES));
   *out = n;
   return RELA_OK;
 }
@@ -854,13 +1051,11 @@ extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_
   }
   {
     ProfScope prof("conv2_mfma", s);
-    hipLaunchKernelGGL(conv_mfma<Conv2>, dim3(ceil_div(N, Conv2::S)), dim3(kThreads), Conv2::LDS_BYTES, s,
-                       (const void*)a1, d.B2, d.b2, a2, N);
+    launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
   }
   {
     ProfScope prof("conv3_mfma", s);
-    hipLaunchKernelGGL(conv_mfma<Conv3>, dim3(ceil_div(N, Conv3::S)), dim3(kThreads), Conv3::LDS_BYTES, s,
-                       (const void*)a2, d.B3, d.b3, a3, N);
+    launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
   }
   {
     ProfScope prof("lstm_gates_mfma", s);

@@ -65,34 +65,65 @@ __global__ __launch_bounds__(kThreads) void replay_append_weights(const float* _
                                                                   float alpha, float* __restrict__ w,
                                                                   int ring, int start, int group,
                                                                   ReplayDevState* __restrict__ st) {
-  __shared__ float chunk[2048];
-  float fsum = 0.f;
-  double dsum = 0.0;  // lane 0 only
+  // One reference block = `group` rows: float sum in row order, then sum_ += (double)sum (:64-73).
+  // Blocks are independent until the double accumulation, so one thread sums one block and
+  // thread 0 folds the block sums in order; a block longer than the LDS chunk stays serial.
+  constexpr int kCap = 4096;
+  __shared__ float chunk[kCap];
+  __shared__ float gsum[kCap];
+  double dsum = 0.0;  // thread 0 only
   if (threadIdx.x == 0) dsum = st->sum;
   const int g = group > 0 ? group : n;
-  for (int base = 0; base < n; base += 2048) {
-    const int m = min(2048, n - base);
-    for (int i = threadIdx.x; i < m; i += kThreads) {
-      const float v = pow_alpha(prio[base + i], alpha);
-      chunk[i] = v;
-      w[(int)(((int64_t)start + base + i) % ring)] = v;
+  if (g <= kCap) {
+    const int cs = (kCap / g) * g;
+    for (int base = 0; base < n; base += cs) {
+      const int m = min(cs, n - base);
+      for (int i = threadIdx.x; i < m; i += kThreads) {
+        const float v = pow_alpha(prio[base + i], alpha);
+        chunk[i] = v;
+        w[(int)(((int64_t)start + base + i) % ring)] = v;
+      }
+      __syncthreads();
+      const int ng = (m + g - 1) / g;  // a trailing partial block counts as a block
+      for (int j = threadIdx.x; j < ng; j += kThreads) {
+        const int lo = j * g, hi = min(lo + g, m);
+        float f = 0.f;
+        for (int i = lo; i < hi; ++i) f += chunk[i];
+        gsum[j] = f;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0)
+        for (int j = 0; j < ng; ++j) dsum += (double)gsum[j];
+      __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int i = 0; i < m; ++i) {
-        fsum += chunk[i];
-        if ((base + i + 1) % g == 0) {  // end of one reference block: sum_ += sum :73
-          dsum += (double)fsum;
-          fsum = 0.f;
+  } else {
+    float fsum = 0.f;
+    for (int base = 0; base < n; base += kCap) {
+      const int m = min(kCap, n - base);
+      for (int i = threadIdx.x; i < m; i += kThreads) {
+        const float v = pow_alpha(prio[base + i], alpha);
+        chunk[i] = v;
+        w[(int)(((int64_t)start + base + i) % ring)] = v;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int i = 0;
+        while (i < m) {
+          const int to_boundary = g - (base + i) % g;  // rows left in the current block
+          const int end = min(m, i + to_boundary);
+#pragma unroll 8
+          for (; i < end; ++i) fsum += chunk[i];
+          if ((base + i) % g == 0) {
+            dsum += (double)fsum;
+            fsum = 0.f;
+          }
         }
       }
+      __syncthreads();
     }
-    __syncthreads();
+    if (threadIdx.x == 0 && n % g != 0) dsum += (double)fsum;
   }
-  if (threadIdx.x == 0) {
-    if (n % g != 0) dsum += (double)fsum;
-    st->sum = dsum;
-  }
+  if (threadIdx.x == 0) st->sum = dsum;
 }
 
 // copies n rows of one field into ring slots start.. (mod ring); 16-byte lanes when possible

@@ -51,7 +51,8 @@ class FFNetHandle:
             self.h = None
 
     def __del__(self):
-        self.close()
+        if capi is not None and getattr(capi, "lib", None) is not None:  # module globals die first at exit
+            self.close()
 
 
 class _DevMem:
@@ -95,7 +96,8 @@ class ApexActorEngine:
             self.h = None
 
     def __del__(self):
-        self.close()
+        if capi is not None and getattr(capi, "lib", None) is not None:  # module globals die first at exit
+            self.close()
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

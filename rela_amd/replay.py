@@ -45,7 +45,8 @@ class FFReplay:
             self.h = None
 
     def __del__(self):
-        self.close()
+        if capi is not None and getattr(capi, "lib", None) is not None:  # module globals die first at exit
+            self.close()
 
     def size(self):
         return capi.lib.rela_replay_size(self.h)

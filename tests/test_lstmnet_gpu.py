@@ -49,7 +49,7 @@ class GpuLstmNet:
         self.capi.lib.rela_lstmnet_destroy(self.h)
 
 
-@pytest.mark.parametrize("N,A", [(1, 18), (5, 6), (80, 18), (131, 18)])
+@pytest.mark.parametrize("N,A", [(1, 18), (5, 6), (80, 18), (131, 18), (1537, 18)])
 def test_lstm_step_vs_torch(N, A):
     import torch
 
