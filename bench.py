@@ -248,12 +248,17 @@ def main():
         optim.zero_grad(set_to_none=True)
         replay.update_priority(prio)
 
+    # diagnosis only (RELA_BENCH_ONLY=actor|learner): time one side alone; the JSON line says so
+    ONLY = os.environ.get("RELA_BENCH_ONLY", "")
+
     def one_step():
         # The learner samples the replay as the previous tick left it and runs next to this tick
         # (had the tick been queued first, `sample` would sit behind the tick's `add` on the replay
         # stream and the two would serialise).  Join at the end: one step = one tick + one update.
-        learner_step()
-        actor_tick()
+        if ONLY != "actor":
+            learner_step()
+        if ONLY != "learner":
+            actor_tick()
         main_stream.wait_stream(actor_stream)
 
     # fill the ring to capacity (untimed): real ticks for the history, then bulk inserts
@@ -338,8 +343,12 @@ def main():
                        "parallelism": "replicas%d+grad-allreduce" % world if world > 1 else "single"},
             "grad_steps_per_s": args.steps / dt, "train_samples_per_s": args.steps * BATCH * world / dt,
             "buffer_add_per_s": adds / dt,
+            **({"diagnostic_only": ONLY} if ONLY else {}),
+            # act + compute_priority's online(obs), target(next_obs); online(next_obs) is act's own
+            # forward (same weights, same batch) and is reused bit-identically -> 3, else 4
+            "forwards_per_tick": fwd_cnt / args.steps if ONLY != "learner" else 0,
             "forward_ms_per_6400": fwd_ms / max(fwd_cnt, 1),
-            "forward_tflops": sum(FLOP.values()) * ROWS / (fwd_ms / max(fwd_cnt, 1) * 1e-3) / 1e12,
+            "forward_tflops": sum(FLOP.values()) * ROWS / (max(fwd_ms, 1e-9) / max(fwd_cnt, 1) * 1e-3) / 1e12,
             "replay_sample_scan_ms": scan_ms / args.steps,
             "kernels_ms_per_step": {k: v["total_ms"] / args.steps for k, v in sorted(prof.items())},
             "roofline": roof,

@@ -182,6 +182,9 @@ void rela_ffnet_destroy(rela_ffnet* net);
 int rela_ffnet_load(rela_ffnet* net, const rela_ffnet_params* params, int params_on_device,
                     void* stream);
 int rela_ffnet_num_action(const rela_ffnet* net);
+/* number of completed rela_ffnet_load calls: (net, version) names one set of weights, which lets a
+ * caller reuse a forward it already ran on the same input (rela_apex_actor_post_step does) */
+uint64_t rela_ffnet_version(const rela_ffnet* net);
 /* bytes of scratch rela_ffnet_forward needs for a batch of n */
 int64_t rela_ffnet_workspace_bytes(const rela_ffnet* net, int n);
 

@@ -35,6 +35,10 @@ struct rela_apex_actor {
   uint8_t* out_t = nullptr;
   void* ws = nullptr;
   int64_t ws_bytes = 0;
+  // weights and history slot the Q-values in q[0] (written by act) belong to
+  const rela_ffnet* q_net = nullptr;
+  uint64_t q_version = 0;
+  int q_slot = -1;
 };
 
 namespace {
@@ -132,6 +136,9 @@ extern "C" int rela_apex_actor_act(rela_apex_actor* a, const rela_ffnet* online,
   rc = rela_apex_act_from_q(a->R, a->A, a->K, a->q, a->legal, a->eps, a->seed, a->act_calls * (uint64_t)a->R, act, s);
   if (rc != RELA_OK) return rc;
   a->act_calls += 1;
+  a->q_net = online;
+  a->q_version = rela_ffnet_version(online);
+  a->q_slot = slot;
   a->cur = slot;
   a->num_act += a->R;  // :169
   if (action_dev_out) *action_dev_out = act;
@@ -166,12 +173,19 @@ extern "C" int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward
   const size_t QA = (size_t)a->R * a->A;
   rc = rela_ffnet_forward(online, a->R, obs_t, a->legal, a->q + QA, a->ws, a->ws_bytes, s);  // apex.py:38
   if (rc != RELA_OK) return rc;
-  rc = rela_ffnet_forward(online, a->R, obs_n, a->legal, a->q + 2 * QA, a->ws, a->ws_bytes, s);  // :41
-  if (rc != RELA_OK) return rc;
+  // greedy_act(next_obs) :41 -- next_obs is the observation act() just ran the online net on
+  // (dqn_actor.h:161, history.back() :84).  With the same weights (no load since) and the same
+  // legal mask and batch, that forward is bit-identical to the one act() left in q[0]: reuse it.
+  const float* q_online_n = a->q;
+  if (!(a->q_net == online && a->q_version == rela_ffnet_version(online) && a->q_slot == last)) {
+    rc = rela_ffnet_forward(online, a->R, obs_n, a->legal, a->q + 2 * QA, a->ws, a->ws_bytes, s);
+    if (rc != RELA_OK) return rc;
+    q_online_n = a->q + 2 * QA;
+  }
   rc = rela_ffnet_forward(target, a->R, obs_n, a->legal, a->q + 3 * QA, a->ws, a->ws_bytes, s);  // :42
   if (rc != RELA_OK) return rc;
   const int64_t* act_t = a->act + (size_t)first * a->R;
-  rc = rela_apex_td_from_q(a->R, a->A, a->K, a->q + QA, a->q + 2 * QA, a->q + 3 * QA, a->legal, act_t, a->out_r,
+  rc = rela_apex_td_from_q(a->R, a->A, a->K, a->q + QA, q_online_n, a->q + 3 * QA, a->legal, act_t, a->out_r,
                            a->out_b, a->gamma_n, nullptr, a->prio, s);
   if (rc != RELA_OK) return rc;
   // FFTransition rows (types.h:18-51): obs{s,eps,legal_move}, next_obs{...}, action{a}, reward, terminal, bootstrap

@@ -536,7 +536,7 @@ struct GemmCfg {
   static constexpr int VPT = BM * KC / 4 / kThreads;  // float4 per thread per chunk
 };
 
-using GemmFc = GemmCfg<3136, 512, 128, kEpiBiasRelu>;
+using GemmFc = GemmCfg<3136, 512, 64, kEpiBiasRelu>;
 using GemmHeads = GemmCfg<512, 32, 128, kEpiBias>;
 // LSTM gates: [x(3136) | h(512)] x [3648][2048]; columns permuted to 4*unit + gate (i,f,g,o) so the
 // four gates of a hidden unit sit in four adjacent lanes of one accumulator tile.
@@ -744,6 +744,7 @@ struct rela_ffnet {
   int num_action = 0;
   FFNetDev d;
   bool loaded = false;
+  uint64_t version = 0;  // bumped by every load
 };
 
 namespace {
@@ -799,6 +800,7 @@ extern "C" void rela_ffnet_destroy(rela_ffnet* n) {
 }
 
 extern "C" int rela_ffnet_num_action(const rela_ffnet* n) { return n ? n->num_action : 0; }
+extern "C" uint64_t rela_ffnet_version(const rela_ffnet* n) { return n ? n->version : 0; }
 
 extern "C" int64_t rela_ffnet_workspace_bytes(const rela_ffnet* n, int batch) {
   (void)n;
@@ -854,6 +856,7 @@ extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on
     (void)hipFree(tmp);
   }
   n->loaded = true;
+  n->version += 1;
   return RELA_OK;
 }
 

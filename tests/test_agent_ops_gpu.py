@@ -135,3 +135,55 @@ def test_eps_greedy_statistics():
     assert (acts[0] != acts[1]).any()  # different Philox offsets -> different draws
     hist = np.bincount(acts[0][acts[0] != greedy], minlength=A)[legal[0] == 1]
     assert hist.min() > 0.5 * hist.mean()
+
+
+def test_post_step_reuses_act_forward_bit_identically():
+    """post_step skips the online forward on next_obs when act() already ran it with the same
+    weights (dqn_actor.h:161 and apex.py:41 evaluate the same network on the same batch).  A twin
+    actor whose weights are re-loaded (same values, new version) before every post_step must take
+    the recompute path and end with bit-identical priorities and replay weights."""
+    import torch
+
+    from rela_amd import _capi as capi
+    from rela_amd.engine import ApexActorEngine, FFNetHandle
+    from rela_amd.replay import FFReplay
+    from synth import synth_obs, synth_params
+
+    A, R, K, n = 6, 16, 8, 3
+    params = {k: torch.from_numpy(v) for k, v in synth_params(A, 5).items()}
+    tparams = {k: torch.from_numpy(v) for k, v in synth_params(A, 6).items()}
+    eps = np.linspace(0.0, 0.4, R).astype(np.float32)
+    runs = []
+    for reload_between in (False, True):
+        online, target = FFNetHandle(A, "cuda:0"), FFNetHandle(A, "cuda:0")
+        online.load_state_dict(params)
+        target.load_state_dict(tparams)
+        replay = FFReplay(256, 3, 0.6, 0.4, 0, A, "cuda:0")
+        eng = ApexActorEngine(R, K, A, n, 0.99, replay, eps, "cuda:0", seed=11)
+        eng.legal.fill_(1.0)
+        prios, acts = [], []
+        for t in range(n + 4):
+            eng.next_obs_slot().copy_(torch.from_numpy(synth_obs(R, 100 + t)).cuda())
+            acts.append(eng.act(online).cpu().numpy().copy())
+            v0 = capi.lib.rela_ffnet_version(online.h)
+            if reload_between:
+                online.load_state_dict(params)
+                assert capi.lib.rela_ffnet_version(online.h) == v0 + 1
+            rew = torch.full((R,), 0.25 * t, device="cuda")
+            term = torch.zeros(R, dtype=torch.uint8, device="cuda")
+            if eng.post_step(rew, term, online, target):
+                prios.append(eng.prio.cpu().numpy().copy())
+        torch.cuda.synchronize()
+        ring = replay.debug_state()["ring"]
+        w, ev = np.zeros(ring, np.float32), np.zeros(ring, np.uint8)
+        capi.check(capi.lib.rela_replay_debug_weights(replay.h, w.ctypes.data_as(C.c_void_p),
+                                                      ev.ctypes.data_as(C.c_void_p)), "debug_weights")
+        runs.append((np.array(acts), np.array(prios), w, replay.size()))
+        eng.close()
+        replay.close()
+        online.close()
+        target.close()
+    assert runs[0][3] == runs[1][3] == 4 * R
+    assert np.array_equal(runs[0][0], runs[1][0])
+    assert np.array_equal(runs[0][1].view(np.uint32), runs[1][1].view(np.uint32))
+    assert np.array_equal(runs[0][2].view(np.uint32), runs[1][2].view(np.uint32))
