@@ -262,7 +262,9 @@ void rela_apex_actor_destroy(rela_apex_actor* a);
 /* Device address ([rows][4][84][84] u8) the env layer may write the NEXT observation batch into
  * directly (then pass obs_host = NULL to act).                                              */
 void* rela_apex_actor_obs_slot(rela_apex_actor* a);
-/* Device addresses of the per-env constants; eps f32[rows], legal f32[rows][A].             */
+/* Device addresses of the CURRENT obs["eps"] f32[rows] and obs["legal_move"] f32[rows][A]; act()
+ * snapshots them into the history slot of the step, so a transition's obs side carries the values
+ * of time t-n and its next_obs side those of time t (dqn_actor.h:84-90).                      */
 float* rela_apex_actor_eps_dev(rela_apex_actor* a);
 float* rela_apex_actor_legal_dev(rela_apex_actor* a);
 

@@ -28,8 +28,10 @@ struct rela_apex_actor {
   int64_t* act = nullptr;   // [n+1][R]
   float* rew = nullptr;     // [n+1][R]
   uint8_t* term = nullptr;  // [n+1][R]
-  float* eps = nullptr;     // [R]
+  float* eps = nullptr;     // [R]      current values (callers may write them on the device) ...
   float* legal = nullptr;   // [R][A]
+  float* eps_hist = nullptr;    // [n+1][R]     ... snapshotted per history slot by act(), because the
+  float* legal_hist = nullptr;  // [n+1][R][A]  transition's obs side carries those of time t-n (:84-90)
   float* q = nullptr;       // [4][R][A]
   float *out_r = nullptr, *out_b = nullptr, *prio = nullptr;
   uint8_t* out_t = nullptr;
@@ -75,6 +77,8 @@ extern "C" int rela_apex_actor_create(rela_apex_actor** out, int rows, int group
   RELA_HIP(hipMalloc(&a->term, H * R));
   RELA_HIP(hipMalloc(&a->eps, R * sizeof(float)));
   RELA_HIP(hipMalloc(&a->legal, R * A * sizeof(float)));
+  RELA_HIP(hipMalloc(&a->eps_hist, H * R * sizeof(float)));
+  RELA_HIP(hipMalloc(&a->legal_hist, H * R * A * sizeof(float)));
   RELA_HIP(hipMalloc(&a->q, 4 * R * A * sizeof(float)));
   RELA_HIP(hipMalloc(&a->out_r, R * sizeof(float)));
   RELA_HIP(hipMalloc(&a->out_b, R * sizeof(float)));
@@ -99,7 +103,8 @@ extern "C" void rela_apex_actor_destroy(rela_apex_actor* a) {
   if (!a) return;
   DeviceGuard g(a->device);
   (void)hipDeviceSynchronize();
-  void* ps[] = {a->obs, a->act, a->rew, a->term, a->eps, a->legal, a->q, a->out_r, a->out_b, a->prio, a->out_t, a->ws};
+  void* ps[] = {a->obs, a->act, a->rew, a->term, a->eps, a->legal, a->q, a->out_r, a->out_b, a->prio, a->out_t, a->ws,
+                a->eps_hist, a->legal_hist};
   for (void* p : ps) (void)hipFree(p);
   delete a;
 }
@@ -130,10 +135,14 @@ extern "C" int rela_apex_actor_act(rela_apex_actor* a, const rela_ffnet* online,
   if (eps_host) RELA_HIP(hipMemcpyAsync(a->eps, eps_host, (size_t)a->R * sizeof(float), hipMemcpyHostToDevice, s));
   if (legal_host)
     RELA_HIP(hipMemcpyAsync(a->legal, legal_host, (size_t)a->R * a->A * sizeof(float), hipMemcpyHostToDevice, s));
-  int rc = rela_ffnet_forward(online, a->R, obs, a->legal, a->q, a->ws, a->ws_bytes, s);
+  float* eps_s = a->eps_hist + (size_t)slot * a->R;
+  float* legal_s = a->legal_hist + (size_t)slot * a->R * a->A;
+  RELA_HIP(hipMemcpyAsync(eps_s, a->eps, (size_t)a->R * sizeof(float), hipMemcpyDeviceToDevice, s));
+  RELA_HIP(hipMemcpyAsync(legal_s, a->legal, (size_t)a->R * a->A * sizeof(float), hipMemcpyDeviceToDevice, s));
+  int rc = rela_ffnet_forward(online, a->R, obs, legal_s, a->q, a->ws, a->ws_bytes, s);
   if (rc != RELA_OK) return rc;
   int64_t* act = a->act + (size_t)slot * a->R;
-  rc = rela_apex_act_from_q(a->R, a->A, a->K, a->q, a->legal, a->eps, a->seed, a->act_calls * (uint64_t)a->R, act, s);
+  rc = rela_apex_act_from_q(a->R, a->A, a->K, a->q, legal_s, eps_s, a->seed, a->act_calls * (uint64_t)a->R, act, s);
   if (rc != RELA_OK) return rc;
   a->act_calls += 1;
   a->q_net = online;
@@ -171,25 +180,29 @@ extern "C" int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward
   const uint8_t* obs_t = a->obs + (size_t)first * a->R * kObs;
   const uint8_t* obs_n = a->obs + (size_t)last * a->R * kObs;
   const size_t QA = (size_t)a->R * a->A;
-  rc = rela_ffnet_forward(online, a->R, obs_t, a->legal, a->q + QA, a->ws, a->ws_bytes, s);  // apex.py:38
+  const float* legal_t = a->legal_hist + (size_t)first * a->R * a->A;
+  const float* legal_n = a->legal_hist + (size_t)last * a->R * a->A;
+  const float* eps_t = a->eps_hist + (size_t)first * a->R;
+  const float* eps_n = a->eps_hist + (size_t)last * a->R;
+  rc = rela_ffnet_forward(online, a->R, obs_t, legal_t, a->q + QA, a->ws, a->ws_bytes, s);  // apex.py:38
   if (rc != RELA_OK) return rc;
   // greedy_act(next_obs) :41 -- next_obs is the observation act() just ran the online net on
   // (dqn_actor.h:161, history.back() :84).  With the same weights (no load since) and the same
   // legal mask and batch, that forward is bit-identical to the one act() left in q[0]: reuse it.
   const float* q_online_n = a->q;
   if (!(a->q_net == online && a->q_version == rela_ffnet_version(online) && a->q_slot == last)) {
-    rc = rela_ffnet_forward(online, a->R, obs_n, a->legal, a->q + 2 * QA, a->ws, a->ws_bytes, s);
+    rc = rela_ffnet_forward(online, a->R, obs_n, legal_n, a->q + 2 * QA, a->ws, a->ws_bytes, s);
     if (rc != RELA_OK) return rc;
     q_online_n = a->q + 2 * QA;
   }
-  rc = rela_ffnet_forward(target, a->R, obs_n, a->legal, a->q + 3 * QA, a->ws, a->ws_bytes, s);  // :42
+  rc = rela_ffnet_forward(target, a->R, obs_n, legal_n, a->q + 3 * QA, a->ws, a->ws_bytes, s);  // :42
   if (rc != RELA_OK) return rc;
   const int64_t* act_t = a->act + (size_t)first * a->R;
-  rc = rela_apex_td_from_q(a->R, a->A, a->K, a->q + QA, q_online_n, a->q + 3 * QA, a->legal, act_t, a->out_r,
+  rc = rela_apex_td_from_q(a->R, a->A, a->K, a->q + QA, q_online_n, a->q + 3 * QA, legal_n, act_t, a->out_r,
                            a->out_b, a->gamma_n, nullptr, a->prio, s);
   if (rc != RELA_OK) return rc;
   // FFTransition rows (types.h:18-51): obs{s,eps,legal_move}, next_obs{...}, action{a}, reward, terminal, bootstrap
-  const void* rows[10] = {obs_t, obs_n, a->eps, a->eps, a->legal, a->legal, act_t, a->out_r, a->out_t, a->out_b};
+  const void* rows[10] = {obs_t, obs_n, eps_t, eps_n, legal_t, legal_n, act_t, a->out_r, a->out_t, a->out_b};
   // one reference block per group of K rows (each batched actor thread's own add, :189)
   int slot = 0;
   rc = rela_replay_begin_add(a->replay, a->R, nonblocking, &slot);

@@ -187,3 +187,88 @@ def test_post_step_reuses_act_forward_bit_identically():
     assert np.array_equal(runs[0][0], runs[1][0])
     assert np.array_equal(runs[0][1].view(np.uint32), runs[1][1].view(np.uint32))
     assert np.array_equal(runs[0][2].view(np.uint32), runs[1][2].view(np.uint32))
+
+
+def test_transition_carries_eps_and_legal_of_its_own_time_step():
+    """obs["eps"] / obs["legal_move"] change from step to step: the stored transition must hold the
+    values of time t-n on its obs side and of time t on its next_obs side (the reference pushes the
+    whole obs dict into the n-step history, dqn_actor.h:23-29,84-90), and the priority must equal
+    a plain fp32 PyTorch evaluation of apex.py:30-45 with those per-time masks."""
+    import torch
+    import torch.nn.functional as F
+
+    from rela_amd.engine import ApexActorEngine, FFNetHandle
+    from rela_amd.replay import FFReplay
+    from synth import synth_params
+
+    A, R, n, gamma = 6, 8, 2, 0.9
+    p_on, p_tg = synth_params(A, 21), synth_params(A, 22)
+    online, target = FFNetHandle(A, "cuda:0"), FFNetHandle(A, "cuda:0")
+    online.load_state_dict({k: torch.from_numpy(v) for k, v in p_on.items()})
+    target.load_state_dict({k: torch.from_numpy(v) for k, v in p_tg.items()})
+    replay = FFReplay(64, 3, 1.0, 0.4, 0, A, "cuda:0")
+    eng = ApexActorEngine(R, R, A, n, gamma, replay, np.zeros(R, np.float32), "cuda:0", seed=5)
+    rng = np.random.default_rng(0)
+
+    def net(p, s, legal):
+        t = {k: torch.from_numpy(v).cuda() for k, v in p.items()}
+        x = s.float() / 255.0
+        x = F.relu(F.conv2d(x, t["net.0.weight"], t["net.0.bias"], stride=4))
+        x = F.relu(F.conv2d(x, t["net.2.weight"], t["net.2.bias"], stride=2))
+        x = F.relu(F.conv2d(x, t["net.4.weight"], t["net.4.bias"], stride=1))
+        h = F.relu(F.linear(x.reshape(s.shape[0], 3136), t["linear.0.weight"], t["linear.0.bias"]))
+        v, a = F.linear(h, t["fc_v.weight"], t["fc_v.bias"]), F.linear(h, t["fc_a.weight"], t["fc_a.bias"]) * legal
+        return v + a - a.mean(1, keepdim=True)
+
+    T = n + 3
+    obs, legal, eps, acts, rews = [], [], [], [], []
+    popped = []
+    for t in range(T):
+        o = torch.from_numpy(rng.integers(0, 256, (R, 4, 84, 84), dtype=np.uint8)).cuda()
+        lg = (rng.uniform(size=(R, A)) < 0.7).astype(np.float32)
+        lg[:, t % A] = 1.0  # at least one legal move
+        lg = torch.from_numpy(lg).cuda()
+        e = torch.full((R, 1), 0.0, device="cuda") + 0.001 * t  # eps tiny: value recorded, acts stay greedy mostly
+        obs.append(o), legal.append(lg), eps.append(e)
+        eng.next_obs_slot().copy_(o)
+        eng.legal.copy_(lg)
+        eng.eps.copy_(e)
+        acts.append(eng.act(online).clone())
+        r = torch.from_numpy(rng.uniform(-1, 1, R).astype(np.float32)).cuda()
+        rews.append(r)
+        if eng.post_step(r, torch.zeros(R, dtype=torch.uint8, device="cuda"), online, target):
+            popped.append((t - n, eng.prio.clone()))
+    torch.cuda.synchronize()
+    assert [t0 for t0, _ in popped] == list(range(T - n))
+    with torch.no_grad():
+        for t0, prio in popped:
+            t1 = t0 + n
+            ret = sum((gamma ** i) * rews[t0 + i] for i in range(n))
+            q_on = net(p_on, obs[t0], legal[t0]).gather(1, acts[t0].unsqueeze(1)).squeeze(1)
+            qn = net(p_on, obs[t1], legal[t1])
+            next_a = ((1 + qn - qn.min()) * legal[t1]).argmax(1)
+            boot = net(p_tg, obs[t1], legal[t1]).gather(1, next_a.unsqueeze(1)).squeeze(1)
+            ref = (ret + (gamma ** n) * boot - q_on).abs()
+            np.testing.assert_allclose(prio.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-4)
+    # stored rows: alpha = 1 so the ring weight is the priority; sample everything a few times
+    seen = set()
+    for _ in range(40):
+        batch, w = replay.sample(8)
+        s0 = batch.obs["s"].cpu().numpy()
+        for i in range(8):
+            hits = [t0 for t0 in range(T - n) for r in range(R) if np.array_equal(s0[i], obs[t0][r].cpu().numpy())]
+            assert hits, "sampled row is not one of the inserted observations"
+            t0 = hits[0]
+            r = [r for r in range(R) if np.array_equal(s0[i], obs[t0][r].cpu().numpy())][0]
+            assert np.array_equal(batch.obs["legal_move"][i].cpu().numpy(), legal[t0][r].cpu().numpy())
+            assert np.array_equal(batch.next_obs["legal_move"][i].cpu().numpy(), legal[t0 + n][r].cpu().numpy())
+            assert np.array_equal(batch.obs["eps"][i].cpu().numpy(), eps[t0][r].cpu().numpy())
+            assert np.array_equal(batch.next_obs["eps"][i].cpu().numpy(), eps[t0 + n][r].cpu().numpy())
+            assert np.array_equal(batch.next_obs["s"][i].cpu().numpy(), obs[t0 + n][r].cpu().numpy())
+            seen.add((t0, r))
+        replay.update_priority(w.clone())
+    assert len(seen) > R
+    eng.close()
+    replay.close()
+    online.close()
+    target.close()
