@@ -215,7 +215,12 @@ def main():
     # the learner step stays on torch's default stream; they meet only through the replay, whose
     # private stream serialises insert / sample / update in commit order.
     actor_stream = torch.cuda.Stream(device=device)
-    main_stream = torch.cuda.current_stream(device)
+    # the learner's ~170 short eager kernels go to a HIGH-priority stream so they are not queued
+    # behind the tick's chip-filling kernels; RELA_BENCH_PRIO=0 keeps the default stream
+    if os.environ.get("RELA_BENCH_PRIO", "1") == "1":
+        main_stream = torch.cuda.Stream(device=device, priority=-1)
+    else:
+        main_stream = torch.cuda.current_stream(device)
 
     def actor_tick():
         i = step_idx[0] % n_pool
@@ -223,7 +228,7 @@ def main():
             engine.act(online)
             engine.post_step(reward_pool[i], term_pool[i], online, target, nonblocking=True)
 
-    def learner_step():
+    def learner_sample():
         k = step_idx[0]
         if k % 2500 == 0:
             agent.sync_target_with_online()
@@ -239,6 +244,9 @@ def main():
             raw_w = dev_view(raw_p.value, (BATCH,), torch.float32, torch.device(device))
             part_sum = dev_view(sum_p.value, (1,), torch.float32, torch.device(device))
             weight = global_is_weights(raw_w, part_sum, replay.size(), BETA)
+        return batch, weight
+
+    def learner_update(batch, weight):
         loss, prio = agent.loss(batch, sync_priority=False)
         (loss * weight).mean().backward()
         if world > 1:
@@ -252,14 +260,21 @@ def main():
     ONLY = os.environ.get("RELA_BENCH_ONLY", "")
 
     def one_step():
-        # The learner samples the replay as the previous tick left it and runs next to this tick
-        # (had the tick been queued first, `sample` would sit behind the tick's `add` on the replay
-        # stream and the two would serialise).  Join at the end: one step = one tick + one update.
-        if ONLY != "actor":
-            learner_step()
-        if ONLY != "learner":
-            actor_tick()
-        main_stream.wait_stream(actor_stream)
+        # One step = one learner update + one actor tick, sharing the GPU.  Order of the host calls:
+        #  1. sample      -- a handful of launches; sees the replay as the previous tick left it (had
+        #                    the tick been queued first, `sample` would sit behind the tick's `add` on
+        #                    the replay's in-order stream)
+        #  2. actor tick  -- a dozen launches on actor_stream, ~3 ms of GPU work
+        #  3. loss / backward / optimiser / update_priority -- ~150 eager PyTorch launches whose
+        #                    host-side cost now overlaps the tick's GPU work instead of preceding it
+        with torch.cuda.stream(main_stream):
+            if ONLY != "actor":
+                batch, weight = learner_sample()
+            if ONLY != "learner":
+                actor_tick()
+            if ONLY != "actor":
+                learner_update(batch, weight)
+            main_stream.wait_stream(actor_stream)
 
     # fill the ring to capacity (untimed): real ticks for the history, then bulk inserts
     for _ in range(MULTI_STEP + 1):

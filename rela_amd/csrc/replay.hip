@@ -373,7 +373,11 @@ extern "C" int rela_replay_create(rela_replay** out, int capacity, int seed, flo
   r->beta = beta;
   r->prefetch = prefetch;
   r->rng.seed(seed);  // :183
-  RELA_HIP(hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+  {  // replay operations are short and sit on the critical path of actors AND learner: highest priority
+    int least = 0, greatest = 0;
+    RELA_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    RELA_HIP(hipStreamCreateWithPriority(&r->stream, hipStreamNonBlocking, greatest));
+  }
   RELA_HIP(hipEventCreateWithFlags(&r->ev_in, hipEventDisableTiming));
   RELA_HIP(hipEventCreateWithFlags(&r->ev_out, hipEventDisableTiming));
   RELA_HIP(hipMalloc(&r->d_w, sizeof(float) * (size_t)r->ring));
