@@ -325,6 +325,47 @@ const float* rela_r2d2_actor_hidden_dev(const rela_r2d2_actor* a, int which);
 const float* rela_r2d2_actor_last_priority_dev(const rela_r2d2_actor* a);
 
 /* ===================================================================================
+ * Ape-X learner step  --  pyrela/main.py:206-251 with ApexAgent.loss (pyrela/apex.py:80-91):
+ * td_err -> smooth_l1 * IS weight -> mean -> backward -> clip_grad_norm_ -> optimiser.
+ * Replaces PyTorch autograd for AtariFFNet (net.py:8-55).  Parameters, gradients and optimiser
+ * state live in one flat device buffer in rela_ffnet_params order (each tensor in state_dict
+ * layout, segments padded to 4 floats).
+ * =================================================================================== */
+typedef struct rela_apex_learner rela_apex_learner;
+
+/* optimizer: 0 = torch.optim.RMSprop(lr, eps) (main.py:120, alpha 0.99, no momentum),
+ *            1 = torch.optim.Adam(lr, eps) (betas 0.9/0.999).  grad_clip = max_norm of
+ * clip_grad_norm_ (main.py:233).  gamma ** multi_step scales the bootstrap (apex.py:44).      */
+int rela_apex_learner_create(rela_apex_learner** out, int num_action, int max_batch, int multi_step,
+                             float gamma, int optimizer, float lr, float eps, float grad_clip,
+                             int device);
+void rela_apex_learner_destroy(rela_apex_learner* l);
+/* load_state_dict for online_net and target_net (target == NULL: copy of online); resets the
+ * optimiser state                                                                            */
+int rela_apex_learner_load(rela_apex_learner* l, const rela_ffnet_params* online,
+                           const rela_ffnet_params* target, int params_on_device, void* stream);
+/* ApexAgent.sync_target_with_online  apex.py:26-27 */
+int rela_apex_learner_sync_target(rela_apex_learner* l, void* stream);
+/* loss + backward on one sampled batch.  rows_dev: the ten FFTransition fields in the order
+ * rela_replay_sample fills them; weight_dev f32[batch] = the IS weights.  Leaves the gradient of
+ * mean(smooth_l1(td_err) * weight) in the flat gradient buffer, |td_err| in priority_dev
+ * (apex.py:88-90, feed it to rela_replay_update_priority) and the loss in loss_dev (may be NULL). */
+int rela_apex_learner_backward(rela_apex_learner* l, int batch, const void* const* rows_dev,
+                               const float* weight_dev, float* priority_dev, float* loss_dev,
+                               void* stream);
+/* clip_grad_norm_ + optimiser step on the flat buffers, then re-packs the kernel-layout weights.
+ * Data-parallel learners all-reduce the gradient buffer between backward and apply.          */
+int rela_apex_learner_apply(rela_apex_learner* l, void* stream);
+/* device views: parameters (online / target) and gradients as state_dict-layout tensors, e.g.
+ * to publish new weights to the actors' nets with rela_ffnet_load(net, &p, 1, stream)        */
+int rela_apex_learner_params(rela_apex_learner* l, rela_ffnet_params* online_out,
+                             rela_ffnet_params* target_out);
+int rela_apex_learner_grads(rela_apex_learner* l, rela_ffnet_params* grads_out);
+int rela_apex_learner_flat(rela_apex_learner* l, float** params_dev, float** grads_dev, int64_t* count);
+/* f32[2] on the device: total gradient norm before clipping, clip coefficient of the last apply */
+const float* rela_apex_learner_stats_dev(const rela_apex_learner* l);
+
+/* ===================================================================================
  * Live per-kernel timing (HIP events on the launch stream) for bench.py's roofline line.
  * No reference counterpart: the reference times sections with torch.cuda.synchronize()
  * (pyrela/common_utils/stopwatch.py:17-54).

@@ -115,6 +115,16 @@ _sig("rela_r2d2_actor_post_step", i32, [vp, vp, vp, vp, vp, i32, P(i32), vp])
 _sig("rela_r2d2_actor_num_act", i64, [vp])
 _sig("rela_r2d2_actor_hidden_dev", vp, [vp, i32])
 _sig("rela_r2d2_actor_last_priority_dev", vp, [vp])
+_sig("rela_apex_learner_create", i32, [P(vp), i32, i32, i32, f32, i32, f32, f32, f32, i32])
+_sig("rela_apex_learner_destroy", None, [vp])
+_sig("rela_apex_learner_load", i32, [vp, P(FFNetParams), P(FFNetParams), i32, vp])
+_sig("rela_apex_learner_sync_target", i32, [vp, vp])
+_sig("rela_apex_learner_backward", i32, [vp, i32, P(vp), vp, vp, vp, vp])
+_sig("rela_apex_learner_apply", i32, [vp, vp])
+_sig("rela_apex_learner_params", i32, [vp, P(FFNetParams), P(FFNetParams)])
+_sig("rela_apex_learner_grads", i32, [vp, P(FFNetParams)])
+_sig("rela_apex_learner_flat", i32, [vp, P(vp), P(vp), P(i64)])
+_sig("rela_apex_learner_stats_dev", vp, [vp])
 _sig("rela_prof_enable", i32, [i32])
 _sig("rela_prof_summary_json", i32, [C.c_char_p, i64])
 

@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "ffnet_layout.h"
 #include "prof.h"
 
 namespace rela_amd {
@@ -747,10 +748,6 @@ struct rela_ffnet {
   uint64_t version = 0;  // bumped by every load
 };
 
-namespace {
-constexpr int64_t kA1 = 400 * 32, kA2 = 81 * 64, kA3 = 49 * 64, kH = 512, kHA = 32;
-constexpr int64_t kWsFloatsPerSample = kA1 + kA2 + kA3 + kH + kHA;
-}  // namespace
 
 extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
   RELA_CHECK(out && num_action >= 1 && num_action <= 31, RELA_EINVAL,

@@ -1,0 +1,30 @@
+// Workspace layout of rela_ffnet_forward (csrc/ffnet.hip), shared with the learner's backward pass
+// (csrc/learner.hip), which reads the activations the forward left there.
+//   a1 [N][20*20][32]  relu(conv1)   channel-last
+//   a2 [N][ 9* 9][64]  relu(conv2)
+//   a3 [N][ 7* 7][64]  relu(conv3)   (= fc input, k = pos*64 + c)
+//   h  [N][512]        relu(fc)
+//   ha [N][32]         heads: columns 0..A-1 = fc_a, column 31 = fc_v
+#pragma once
+#include <cstdint>
+
+namespace rela_amd {
+
+constexpr int64_t kA1 = 400 * 32, kA2 = 81 * 64, kA3 = 49 * 64, kH = 512, kHA = 32;
+constexpr int64_t kWsFloatsPerSample = kA1 + kA2 + kA3 + kH + kHA;
+
+struct FFNetWs {
+  float *a1, *a2, *a3, *h, *ha;
+};
+
+inline FFNetWs ffnet_ws(void* ws, int N) {
+  FFNetWs w;
+  w.a1 = static_cast<float*>(ws);
+  w.a2 = w.a1 + kA1 * N;
+  w.a3 = w.a2 + kA2 * N;
+  w.h = w.a3 + kA3 * N;
+  w.ha = w.h + kH * N;
+  return w;
+}
+
+}  // namespace rela_amd

@@ -44,3 +44,158 @@ def global_is_weights(raw_w, partition_sum, partition_size, beta, group=None):
     top = w.max()
     dist.all_reduce(top, op=dist.ReduceOp.MAX, group=group)
     return w / top
+
+
+class HipApexLearner:
+    """The Ape-X learner step in HIP (rela_apex_learner_*, csrc/learner.hip): the counterpart of
+    `loss, priority = agent.loss(batch); (loss * weight).mean().backward(); clip_grad_norm_;
+    optim.step()` of pyrela/main.py:226-239 for ApexAgent + AtariFFNet, without PyTorch autograd.
+
+        learner = HipApexLearner.from_agent(agent, batch, lr=6.25e-5, eps=1.5e-4)
+        batch, weight = replay.sample(B)            # rela_amd.replay.FFReplay
+        loss, priority = learner.step(batch, weight)
+        replay.update_priority(priority)
+        learner.publish(actor_net)                  # every actor_sync_freq steps (ModelLocker.update_model)
+    """
+
+    KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
+            "linear.0.weight", "linear.0.bias", "fc_v.weight", "fc_v.bias", "fc_a.weight", "fc_a.bias")
+    SHAPES = lambda A: ((32, 4, 8, 8), (32,), (64, 32, 4, 4), (64,), (64, 64, 3, 3), (64,), (512, 3136), (512,),  # noqa: E731
+                        (1, 512), (1,), (A, 512), (A,))
+    FIELDS = ("s", "next_s", "eps", "next_eps", "legal_move", "next_legal_move", "a", "reward", "terminal",
+              "bootstrap")
+
+    def __init__(self, num_action, max_batch, multi_step, gamma, optimizer="rmsprop", lr=6.25e-5, eps=1.5e-4,
+                 grad_clip=40.0, device="cuda:0"):
+        import ctypes as C
+
+        from . import _capi as capi
+
+        self._C, self._capi = C, capi
+        self.device = torch.device(device)
+        self.num_action, self.max_batch = num_action, max_batch
+        h = C.c_void_p()
+        capi.check(capi.lib.rela_apex_learner_create(C.byref(h), num_action, max_batch, multi_step, gamma,
+                                                     {"rmsprop": 0, "adam": 1}[optimizer], lr, eps, grad_clip,
+                                                     self.device.index or 0), "rela_apex_learner_create")
+        self.h = h
+        self._prio = torch.empty(max_batch, dtype=torch.float32, device=self.device)
+        self._loss = torch.empty(1, dtype=torch.float32, device=self.device)
+
+    @classmethod
+    def from_agent(cls, agent, max_batch, **kw):
+        """agent: pyrela ApexAgent (online_net / target_net AtariFFNet, multi_step, gamma)."""
+        dev = next(agent.online_net.parameters()).device
+        num_action = agent.online_net.fc_a.weight.shape[0]
+        self = cls(num_action, max_batch, agent.multi_step, agent.gamma, device=str(dev), **kw)
+        self.load_state_dicts(agent.online_net.state_dict(), agent.target_net.state_dict())
+        return self
+
+    def _stream(self):
+        return self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _params(self, sd, keep):
+        p = self._capi.FFNetParams()
+        for (field, _), key in zip(self._capi.FFNetParams._fields_, self.KEYS):
+            t = sd[key].detach().to(self.device, torch.float32).contiguous()
+            keep.append(t)
+            setattr(p, field, t.data_ptr())
+        return p
+
+    def load_state_dicts(self, online_sd, target_sd=None):
+        C, capi = self._C, self._capi
+        keep = []
+        po = self._params(online_sd, keep)
+        pt = self._params(target_sd, keep) if target_sd is not None else None
+        capi.check(capi.lib.rela_apex_learner_load(self.h, C.byref(po), C.byref(pt) if pt is not None else None, 1,
+                                                   self._stream()), "rela_apex_learner_load")
+        torch.cuda.current_stream(self.device).synchronize()  # sources may be temporaries
+
+    def sync_target_with_online(self):
+        self._capi.check(self._capi.lib.rela_apex_learner_sync_target(self.h, self._stream()), "sync_target")
+
+    def _views(self, which):
+        from .engine import dev_view
+
+        C, capi = self._C, self._capi
+        p = capi.FFNetParams()
+        if which == "grads":
+            capi.check(capi.lib.rela_apex_learner_grads(self.h, C.byref(p)), "rela_apex_learner_grads")
+        elif which == "online":
+            capi.check(capi.lib.rela_apex_learner_params(self.h, C.byref(p), None), "rela_apex_learner_params")
+        else:
+            capi.check(capi.lib.rela_apex_learner_params(self.h, None, C.byref(p)), "rela_apex_learner_params")
+        shapes = HipApexLearner.SHAPES(self.num_action)
+        return {key: dev_view(getattr(p, field), shape, torch.float32, self.device)
+                for (field, _), key, shape in zip(capi.FFNetParams._fields_, self.KEYS, shapes)}, p
+
+    def state_dict(self, which="online"):
+        """Zero-copy views of the flat parameter buffer as a state_dict ("online" | "target" | "grads")."""
+        return self._views(which)[0]
+
+    def flat(self):
+        """(params, grads) as flat f32 views -- the all-reduce bucket of data-parallel learners."""
+        from .engine import dev_view
+
+        C, capi = self._C, self._capi
+        pp, gp, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        capi.check(capi.lib.rela_apex_learner_flat(self.h, C.byref(pp), C.byref(gp), C.byref(n)), "flat")
+        return (dev_view(pp.value, (n.value,), torch.float32, self.device),
+                dev_view(gp.value, (n.value,), torch.float32, self.device))
+
+    def stats(self):
+        """cuda f32[2]: gradient norm before clipping, clip coefficient of the last apply()."""
+        from .engine import dev_view
+
+        return dev_view(self._capi.lib.rela_apex_learner_stats_dev(self.h), (2,), torch.float32, self.device)
+
+    def backward(self, batch, weight):
+        """batch: the namespace FFReplay.sample returns (or any object with obs / next_obs / action /
+        reward / terminal / bootstrap of cuda tensors); weight: cuda f32[B].  -> (loss[1], priority[B])."""
+        C, capi = self._C, self._capi
+        B = weight.numel()
+        t = {"s": batch.obs["s"], "next_s": batch.next_obs["s"], "eps": batch.obs["eps"],
+             "next_eps": batch.next_obs["eps"], "legal_move": batch.obs["legal_move"],
+             "next_legal_move": batch.next_obs["legal_move"], "a": batch.action["a"], "reward": batch.reward,
+             "terminal": batch.terminal, "bootstrap": batch.bootstrap}
+        keep = [t[f].contiguous() for f in self.FIELDS]
+        w = weight.detach().float().contiguous()
+        rows = (C.c_void_p * 10)(*[x.data_ptr() for x in keep])
+        self._keep = (keep, w)
+        capi.check(capi.lib.rela_apex_learner_backward(self.h, B, rows, C.c_void_p(w.data_ptr()),
+                                                       C.c_void_p(self._prio.data_ptr()),
+                                                       C.c_void_p(self._loss.data_ptr()), self._stream()),
+                   "rela_apex_learner_backward")
+        return self._loss, self._prio[:B]
+
+    def apply(self):
+        self._capi.check(self._capi.lib.rela_apex_learner_apply(self.h, self._stream()), "rela_apex_learner_apply")
+
+    def step(self, batch, weight, world_size=1, group=None):
+        loss, prio = self.backward(batch, weight)
+        if world_size > 1:  # replicated learners: one flat SUM all-reduce, then the mean
+            g = self.flat()[1]
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+            g.div_(world_size)
+        self.apply()
+        return loss, prio
+
+    def publish(self, online_handle, target_handle=None):
+        """ModelLocker.update_model for device nets: repack the current weights into actor-side
+        FFNetHandle objects (rela_ffnet_load from device pointers, no host copy)."""
+        C, capi = self._C, self._capi
+        _, po = self._views("online")
+        capi.check(capi.lib.rela_ffnet_load(online_handle.h, C.byref(po), 1, self._stream()), "rela_ffnet_load")
+        if target_handle is not None:
+            _, pt = self._views("target")
+            capi.check(capi.lib.rela_ffnet_load(target_handle.h, C.byref(pt), 1, self._stream()), "rela_ffnet_load")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._capi.lib.rela_apex_learner_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        capi = getattr(self, "_capi", None)
+        if capi is not None and getattr(capi, "lib", None) is not None:
+            self.close()
