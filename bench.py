@@ -179,7 +179,7 @@ def main():
     from rela_amd import _capi as capi
     from rela_amd.engine import ApexActorEngine, FFNetHandle
     from rela_amd.engine import dev_view
-    from rela_amd.learner import allreduce_grads, global_is_weights
+    from rela_amd.learner import HipApexLearner, allreduce_grads, global_is_weights
     from rela_amd.pyrela.apex import ApexAgent
     from rela_amd.pyrela.net import AtariFFNet
     from rela_amd.replay import FFReplay
@@ -190,6 +190,11 @@ def main():
         for p in agent.parameters():
             dist.broadcast(p.data, 0)
     optim = torch.optim.RMSprop(agent.online_net.parameters(), lr=6.25e-5, eps=1.5e-4)
+    # learner step: hand-written HIP (csrc/learner.hip) by default; RELA_BENCH_LEARNER=torch runs the
+    # same step through PyTorch autograd (pyrela/main.py:226-239 verbatim) for comparison
+    LEARNER = os.environ.get("RELA_BENCH_LEARNER", "hip")
+    hip_learner = HipApexLearner.from_agent(agent, BATCH, lr=6.25e-5, eps=1.5e-4, grad_clip=40.0) \
+        if LEARNER == "hip" else None
     online, target = FFNetHandle(NUM_ACTION, device), FFNetHandle(NUM_ACTION, device)
     online.load_state_dict(agent.online_net.state_dict())
     target.load_state_dict(agent.target_net.state_dict())
@@ -231,11 +236,17 @@ def main():
     def learner_sample():
         k = step_idx[0]
         if k % 2500 == 0:
-            agent.sync_target_with_online()
+            if hip_learner is not None:
+                hip_learner.sync_target_with_online()
+            else:
+                agent.sync_target_with_online()
         if k % 20 == 0:  # ModelLocker.update_model, main.py:213-215 (waits for in-flight actor work)
             main_stream.wait_stream(actor_stream)
-            online.load_state_dict(agent.online_net.state_dict())
-            target.load_state_dict(agent.target_net.state_dict())
+            if hip_learner is not None:
+                hip_learner.publish(online, target)
+            else:
+                online.load_state_dict(agent.online_net.state_dict())
+                target.load_state_dict(agent.target_net.state_dict())
             actor_stream.wait_stream(main_stream)
         batch, weight = replay.sample(BATCH)
         if world > 1:  # one replay partition per GPU: normalise the IS weights over all of them
@@ -247,6 +258,10 @@ def main():
         return batch, weight
 
     def learner_update(batch, weight):
+        if hip_learner is not None:
+            loss, prio = hip_learner.step(batch, weight, world_size=world)
+            replay.update_priority(prio)
+            return
         loss, prio = agent.loss(batch, sync_priority=False)
         (loss * weight).mean().backward()
         if world > 1:
@@ -358,6 +373,7 @@ def main():
                        "parallelism": "replicas%d+grad-allreduce" % world if world > 1 else "single"},
             "grad_steps_per_s": args.steps / dt, "train_samples_per_s": args.steps * BATCH * world / dt,
             "buffer_add_per_s": adds / dt,
+            "learner": "hip (csrc/learner.hip)" if hip_learner is not None else "torch autograd",
             **({"diagnostic_only": ONLY} if ONLY else {}),
             # act + compute_priority's online(obs), target(next_obs); online(next_obs) is act's own
             # forward (same weights, same batch) and is reused bit-identically -> 3, else 4

@@ -29,6 +29,7 @@
 
 #include "common.h"
 #include "ffnet_layout.h"
+#include "gemm_lds.h"
 #include "prof.h"
 
 namespace rela_amd {
@@ -41,6 +42,7 @@ struct FFNetDev {
   float *B2 = nullptr, *b2 = nullptr;  // conv2 frags [4][128][64], bias[64]
   float *B3 = nullptr, *b3 = nullptr;  // conv3 frags [4][144][64], bias[64]
   float *Bf = nullptr, *bf = nullptr;  // fc    frags [32][784][64], bias[512]
+  float* BfT = nullptr;                // fc    weights [3136 (k = pos*64+c)][512] for the small-batch split-K path
   float *Bh = nullptr, *bh = nullptr;  // heads frags [2][128][64], bias[32]  (cols 0..A-1 = fc_a, col 31 = fc_v)
 };
 
@@ -670,6 +672,54 @@ __global__ void dueling_kernel(const float* __restrict__ ha, const float* __rest
 }
 
 // ---- weight packing (load_state_dict time) ------------------------------------------------
+// ---- fc forward for small batches --------------------------------------------------------------
+// Below kFcSplitBelow rows gemm_mfma<GemmFc> launches fewer than 128 blocks, each walking all 98
+// K-chunks (123 us at N = 512, the same at N = 80).  There the product runs as a split-K instance of
+// gemm_lds (gemm_lds.h) over ~256 blocks; fc_reduce sums the partial tiles in a fixed order and
+// applies bias + ReLU.  The partial tiles live in the caller's workspace behind `ha`.
+constexpr int kFcSplitBelow = 2048;
+constexpr int64_t kFcPartFloats = (int64_t)4096 * 512;  // splits * N <= 32 * 128
+inline int fc_splits(int N) {
+  const int rb = ceil_div(N, 128);
+  const int sp = 32 / rb;
+  return sp < 1 ? 1 : sp;
+}
+
+using TileFcSmall = gemm::TileCfg<128, 64, 4, 2, false>;
+struct ProbFcFwd : gemm::ProbBase {
+  const float *a3, *wt;  // a3 [N][3136] (k = pos*64+c), wt [3136][512]
+  float* part;           // [splits][N][512]
+  __device__ float4 loadA(int m, int k) const {
+    return m < M ? *reinterpret_cast<const float4*>(a3 + (size_t)m * 3136 + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __device__ float4 loadB(int k, int n) const { return *reinterpret_cast<const float4*>(wt + (size_t)k * 512 + n); }
+  __device__ void store(int z, int m, int n, float v) const { part[((size_t)z * M + m) * 512 + n] = v; }
+};
+
+__global__ void fc_reduce(const float* __restrict__ part, int splits, int N, const float* __restrict__ bias,
+                          float* __restrict__ h) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of h
+  if (idx >= N * 128) return;
+  const int n4 = (idx & 127) * 4;
+  const size_t off = (size_t)(idx >> 7) * 512 + n4;
+  float4 s = *reinterpret_cast<const float4*>(bias + n4);
+  for (int z = 0; z < splits; ++z) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (size_t)z * N * 512 + off);
+    s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+  }
+  *reinterpret_cast<float4*>(h + off) =
+      make_float4(s.x > 0.f ? s.x : 0.f, s.y > 0.f ? s.y : 0.f, s.z > 0.f ? s.z : 0.f, s.w > 0.f ? s.w : 0.f);
+}
+
+// wt[k = pos*64 + c][u] = linear.0.weight[u][c*49 + pos]   (net.py:49 flattens channel-first)
+__global__ void pack_fc_t(const float* __restrict__ w, float* __restrict__ wt) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 3136 * 512) return;
+  const int k = idx >> 9, u = idx & 511;
+  const int c = k & 63, pos = k >> 6;
+  wt[idx] = w[(size_t)u * 3136 + c * 49 + pos];
+}
+
 enum PackMode { kPackConv1 = 0, kPackConv2 = 1, kPackConv3 = 2, kPackFc = 3, kPackHeads = 4, kPackLstm = 5 };
 
 __global__ void pack_frags(int mode, const float* __restrict__ w, const float* __restrict__ w2, int num_action,
@@ -740,12 +790,19 @@ __global__ void pack_head_bias(const float* __restrict__ ab, const float* __rest
 
 using namespace rela_amd;
 
+namespace {
+const char* const kProfActor[6] = {"conv1_bf16x3", "conv2_mfma", "conv3_mfma", "fc_mfma", "heads_mfma", "dueling"};
+const char* const kProfLearner[6] = {"learner_fwd_conv1", "learner_fwd_conv2", "learner_fwd_conv3",
+                                     "learner_fwd_fc",    "learner_fwd_heads", "learner_fwd_dueling"};
+}  // namespace
+
 struct rela_ffnet {
   int device = 0;
   int num_action = 0;
   FFNetDev d;
   bool loaded = false;
   uint64_t version = 0;  // bumped by every load
+  const char* const* prof_names = nullptr;  // per-kernel timing labels (actor-side by default)
 };
 
 
@@ -769,6 +826,7 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
   RELA_HIP(hipMalloc(&d.B3, sizeof(float) * 4 * 144 * 64));
   RELA_HIP(hipMalloc(&d.b3, sizeof(float) * 64));
   RELA_HIP(hipMalloc(&d.Bf, sizeof(float) * 32 * 784 * 64));
+  RELA_HIP(hipMalloc(&d.BfT, sizeof(float) * 3136 * 512));
   RELA_HIP(hipMalloc(&d.bf, sizeof(float) * 512));
   RELA_HIP(hipMalloc(&d.Bh, sizeof(float) * 2 * 128 * 64));
   RELA_HIP(hipMalloc(&d.bh, sizeof(float) * 32));
@@ -791,17 +849,22 @@ extern "C" void rela_ffnet_destroy(rela_ffnet* n) {
   if (!n) return;
   DeviceGuard g(n->device);
   (void)hipDeviceSynchronize();
-  void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bf, n->d.bf, n->d.Bh, n->d.bh};
+  void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bf, n->d.bf, n->d.Bh, n->d.bh,
+                n->d.BfT};
   for (void* p : ps) (void)hipFree(p);
   delete n;
 }
 
 extern "C" int rela_ffnet_num_action(const rela_ffnet* n) { return n ? n->num_action : 0; }
+namespace rela_amd {
+void ffnet_label_as_learner(rela_ffnet* n) { n->prof_names = kProfLearner; }
+}  // namespace rela_amd
 extern "C" uint64_t rela_ffnet_version(const rela_ffnet* n) { return n ? n->version : 0; }
 
 extern "C" int64_t rela_ffnet_workspace_bytes(const rela_ffnet* n, int batch) {
   (void)n;
-  return (int64_t)sizeof(float) * kWsFloatsPerSample * (batch > 0 ? batch : 0) + 256;
+  const int64_t b = batch > 0 ? batch : 0;
+  return (int64_t)sizeof(float) * (kWsFloatsPerSample * b + (b < kFcSplitBelow ? kFcPartFloats : 0)) + 256;
 }
 
 extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on_device, void* stream_) {
@@ -841,6 +904,7 @@ extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on
   pack(kPackConv2, dv[2], nullptr, n->d.B2, 4, 128);
   pack(kPackConv3, dv[4], nullptr, n->d.B3, 4, 144);
   pack(kPackFc, dv[6], nullptr, n->d.Bf, 32, 784);
+  hipLaunchKernelGGL(pack_fc_t, dim3(ceil_div(3136 * 512, 256)), dim3(256), 0, s, dv[6], n->d.BfT);
   pack(kPackHeads, dv[10], dv[8], n->d.Bh, 2, 128);
   RELA_HIP(hipMemcpyAsync(n->d.b1, dv[1], sizeof(float) * 32, hipMemcpyDeviceToDevice, s));
   RELA_HIP(hipMemcpyAsync(n->d.b2, dv[3], sizeof(float) * 64, hipMemcpyDeviceToDevice, s));
@@ -872,33 +936,44 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
   float* h = a3 + kA3 * N;
   float* ha = h + kH * N;
   const FFNetDev& d = n->d;
+  const char* const* names = n->prof_names ? n->prof_names : kProfActor;
   {
-    ProfScope prof("conv1_bf16x3", s);
+    ProfScope prof(names[0], s);
     hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
                        d.B1, d.b1, a1, N);
   }
   {
-    ProfScope prof("conv2_mfma", s);
+    ProfScope prof(names[1], s);
     launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
   }
   {
-    ProfScope prof("conv3_mfma", s);
+    ProfScope prof(names[2], s);
     launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
   }
-  {
-    ProfScope prof("fc_mfma", s);
+  if (N < kFcSplitBelow) {
+    const int splits = fc_splits(N);
+    float* part = ha + kHA * N;
+    part += (64 - ((part - static_cast<float*>(ws)) & 63)) & 63;  // 256-byte aligned (float4 loads)
+    ProbFcFwd p{};
+    p.M = N, p.N = 512, p.K = 3136;
+    p.a3 = a3, p.wt = d.BfT, p.part = part;
+    gemm::launch_gemm<TileFcSmall>(p, splits, s, names[3]);
+    hipLaunchKernelGGL(fc_reduce, dim3(ceil_div(N * 128, 256)), dim3(256), 0, s, (const float*)part, splits, N,
+                       (const float*)d.bf, h);
+  } else {
+    ProfScope prof(names[3], s);
     hipLaunchKernelGGL(gemm_mfma<GemmFc>, dim3(GemmFc::CT / GemmFc::CTB, ceil_div(N, GemmFc::BM)), dim3(kThreads), 0, s,
                        (const float*)a3, (const float*)nullptr, (const float*)d.Bf, (const float*)d.bf, h,
                        (const float*)nullptr, (float*)nullptr, N);
   }
   {
-    ProfScope prof("heads_mfma", s);
+    ProfScope prof(names[4], s);
     hipLaunchKernelGGL(gemm_mfma<GemmHeads>, dim3(GemmHeads::CT / GemmHeads::CTB, ceil_div(N, GemmHeads::BM)),
                        dim3(kThreads), 0, s, (const float*)h, (const float*)nullptr, (const float*)d.Bh,
                        (const float*)d.bh, ha, (const float*)nullptr, (float*)nullptr, N);
   }
   {
-    ProfScope prof("dueling", s);
+    ProfScope prof(names[5], s);
     hipLaunchKernelGGL(dueling_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, (const float*)ha, legal_dev, q_dev,
                        (float*)nullptr, N, n->num_action);
   }

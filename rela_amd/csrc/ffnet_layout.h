@@ -28,3 +28,9 @@ inline FFNetWs ffnet_ws(void* ws, int N) {
 }
 
 }  // namespace rela_amd
+
+struct rela_ffnet;
+namespace rela_amd {
+// per-kernel timing labels "learner_fwd_*" instead of the actor-side names (prof.h)
+void ffnet_label_as_learner(rela_ffnet* n);
+}  // namespace rela_amd

@@ -30,156 +30,19 @@
 
 #include "common.h"
 #include "ffnet_layout.h"
+#include "gemm_lds.h"
 #include "prof.h"
 
 namespace rela_amd {
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int kLT = 512;  // 8 wavefronts
-constexpr int BK = 32;    // K chunk staged per barrier (8 MFMA k-steps)
-
-__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-// ---- generic LDS-tiled MFMA GEMM:  C[M][N] = sum_k A(m,k) * B(k,n) ---------------------------
-// A arrives either k-contiguous (AMC = false: loadA(m, k) -> A[m][k..k+3]) or m-contiguous
-// (AMC = true: loadA(k, m) -> A[m..m+3][k], the transposed operand of a weight gradient);
-// B is always n-contiguous: loadB(k, n) -> B[k][n..n+3].  Loaders return zeros out of range.
-template <int BM_, int BN_, int WM_, int WN_, bool AMC_>
-struct TileCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
-  static constexpr bool AMC = AMC_;
-  static_assert(WM * WN == 8, "8 wavefronts per block");
-  static constexpr int TM = BM / 16 / WM, TN = BN / 16 / WN;  // 16x16 tiles per wave
-  static_assert(TM >= 1 && TN >= 1, "tile too small for the wave grid");
-  // leading dimensions = 16 (mod 32) floats, or k+2: a fragment read (16 rows x 4 k) touches
-  // every bank exactly twice, the minimum for 64 lanes
-  static constexpr int LDA = AMC ? BM + 16 : BK + 2;
-  static constexpr int A_FLOATS = AMC ? BK * LDA : BM * LDA;
-  static constexpr int LDB = BN + 16;
-  static constexpr int B_FLOATS = BK * LDB;
-  static constexpr int A_V4 = BM * BK / 4, B_V4 = BN * BK / 4;
-  static constexpr int A_IT = (A_V4 + kLT - 1) / kLT, B_IT = (B_V4 + kLT - 1) / kLT;
-};
-
-template <class T, class P>
-__global__ __launch_bounds__(kLT) void gemm_lds(const P p) {
-  __shared__ __attribute__((aligned(16))) float sA[2][T::A_FLOATS];
-  __shared__ __attribute__((aligned(16))) float sB[2][T::B_FLOATS];
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, kk = lane >> 4;
-  const int wm = wave / T::WN, wn = wave % T::WN;
-  const int m0 = blockIdx.y * T::BM, n0 = blockIdx.x * T::BN;
-  const int nch = (p.K + BK - 1) / BK;
-  const int c0 = blockIdx.z * p.kslice;
-  const int c1 = min(nch, c0 + p.kslice);
-
-  float4 ra[T::A_IT], rb[T::B_IT];
-  auto gload = [&](int ch) {
-    const int k0 = ch * BK;
-#pragma unroll
-    for (int j = 0; j < T::A_IT; ++j) {
-      const int idx = tid + j * kLT;
-      if (idx < T::A_V4) {
-        if constexpr (T::AMC) {
-          const int kr = idx / (T::BM / 4), q = idx % (T::BM / 4);
-          ra[j] = p.loadA(k0 + kr, m0 + 4 * q);
-        } else {
-          const int r = idx >> 3, q = idx & 7;
-          ra[j] = p.loadA(m0 + r, k0 + 4 * q);
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < T::B_IT; ++j) {
-      const int idx = tid + j * kLT;
-      if (idx < T::B_V4) {
-        const int kr = idx / (T::BN / 4), q = idx % (T::BN / 4);
-        rb[j] = p.loadB(k0 + kr, n0 + 4 * q);
-      }
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < T::A_IT; ++j) {
-      const int idx = tid + j * kLT;
-      if (idx < T::A_V4) {
-        if constexpr (T::AMC) {
-          const int kr = idx / (T::BM / 4), q = idx % (T::BM / 4);
-          *reinterpret_cast<float4*>(&sA[buf][kr * T::LDA + 4 * q]) = ra[j];
-        } else {
-          const int r = idx >> 3, q = idx & 7;
-          float* d = &sA[buf][r * T::LDA + 4 * q];
-          *reinterpret_cast<float2*>(d) = make_float2(ra[j].x, ra[j].y);
-          *reinterpret_cast<float2*>(d + 2) = make_float2(ra[j].z, ra[j].w);
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < T::B_IT; ++j) {
-      const int idx = tid + j * kLT;
-      if (idx < T::B_V4) {
-        const int kr = idx / (T::BN / 4), q = idx % (T::BN / 4);
-        *reinterpret_cast<float4*>(&sB[buf][kr * T::LDB + 4 * q]) = rb[j];
-      }
-    }
-  };
-
-  f32x4 acc[T::TM][T::TN];
-#pragma unroll
-  for (int t = 0; t < T::TM; ++t)
-#pragma unroll
-    for (int u = 0; u < T::TN; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  if (c0 < c1) {
-    gload(c0);
-    sstore(0);
-  }
-  __syncthreads();
-  for (int ch = c0; ch < c1; ++ch) {
-    const int buf = (ch - c0) & 1;
-    if (ch + 1 < c1) gload(ch + 1);
-#pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
-      float a[T::TM], b[T::TN];
-#pragma unroll
-      for (int t = 0; t < T::TM; ++t) {
-        const int row = (wm * T::TM + t) * 16 + li;
-        a[t] = T::AMC ? sA[buf][(4 * ks + kk) * T::LDA + row] : sA[buf][row * T::LDA + 4 * ks + kk];
-      }
-#pragma unroll
-      for (int u = 0; u < T::TN; ++u) b[u] = sB[buf][(4 * ks + kk) * T::LDB + (wn * T::TN + u) * 16 + li];
-#pragma unroll
-      for (int t = 0; t < T::TM; ++t)
-#pragma unroll
-        for (int u = 0; u < T::TN; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[u], acc[t][u], 0, 0, 0);
-    }
-    if (ch + 1 < c1) sstore(buf ^ 1);
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int t = 0; t < T::TM; ++t)
-#pragma unroll
-    for (int u = 0; u < T::TN; ++u)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + (wm * T::TM + t) * 16 + kk * 4 + r;
-        const int n = n0 + (wn * T::TN + u) * 16 + li;
-        if (m < p.M && n < p.N) p.store(blockIdx.z, m, n, acc[t][u][r]);
-      }
-}
+using namespace gemm;
 
 using TileDgrad = TileCfg<128, 64, 4, 2, false>;  // M = batch rows, A k-contiguous
 using TileWfc = TileCfg<128, 64, 4, 2, true>;     // fc weight gradient (M = 512 units)
 using TileW64 = TileCfg<64, 64, 2, 4, true>;      // conv2 / conv3 weight gradients (M = 64 channels)
 using TileW32 = TileCfg<32, 64, 2, 4, true>;      // conv1 / head weight gradients (M = 32)
 
-struct ProbBase {
-  int M, N, K, kslice;
-};
 
 // d_h[b][u] = relu'(h) * sum_k d_ha[b][k] * Wh[k][u]      Wh rows: 0..A-1 = fc_a.weight, 31 = fc_v.weight
 struct ProbHeadDgrad : ProbBase {
@@ -283,13 +146,6 @@ struct ProbW1 : ProbBase {
   __device__ void store(int z, int m, int n, float v) const { part[((size_t)z * M + m) * N + n] = v; }
 };
 
-template <class T, class P>
-void launch_gemm(P p, int splits, hipStream_t s, const char* name) {
-  const int nch = ceil_div(p.K, BK);
-  p.kslice = ceil_div(nch, splits);
-  ProfScope prof(name, s);
-  hipLaunchKernelGGL((gemm_lds<T, P>), dim3(ceil_div(p.N, T::BN), ceil_div(p.M, T::BM), splits), dim3(kLT), 0, s, p);
-}
 
 // ---- col2im (gather form) with the ReLU mask of the layer below ------------------------------
 // d_a2[b][y][x][c] = relu'(a2) * sum_{kh,kw} col3[(b, (y-kh)*7 + x-kw)][(kh*3+kw)*64 + c]
@@ -359,21 +215,29 @@ __global__ void reduce_splits(const float* __restrict__ part, int splits, int M,
 }
 
 // ---- column sums (bias gradients): two deterministic stages ----------------------------------
-constexpr int kColsumBlocks = 64;
+constexpr int kColsumBlocks = 256;
+// src [rows][C], C in {32, 64, 512}: a thread owns one float4 of columns and every L-th row of the
+// block's row slice (coalesced 16-byte loads), LDS reduction over the L row lanes
 __global__ __launch_bounds__(kLT) void colsum_partial(const float* __restrict__ src, int64_t rows, int C,
                                                       float* __restrict__ part) {
-  __shared__ float sm[kLT];
-  const int L = kLT / C;  // row lanes per column (C in {32, 64, 512})
-  const int col = threadIdx.x % C, rl = threadIdx.x / C;
+  __shared__ float4 sm[kLT];
+  const int G = C / 4, L = kLT / G;
+  const int cg = threadIdx.x % G, rl = threadIdx.x / G;
   const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
-  float s = 0.f;
-  for (int64_t r = r0 + rl; r < r1; r += L) s += src[r * C + col];
+  float4 s = zero4();
+  for (int64_t r = r0 + rl; r < r1; r += L) {
+    const float4 v = ld4(src + r * C + cg * 4);
+    s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+  }
   sm[threadIdx.x] = s;
   __syncthreads();
   if (rl == 0) {
-    for (int l = 1; l < L; ++l) s += sm[col + l * C];
-    part[(size_t)blockIdx.x * C + col] = s;
+    for (int l = 1; l < L; ++l) {
+      const float4 v = sm[cg + l * G];
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * C + cg * 4) = s;
   }
 }
 __global__ void colsum_final(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
@@ -593,6 +457,8 @@ extern "C" int rela_apex_learner_create(rela_apex_learner** out, int num_action,
   if (rc != RELA_OK) return rc;
   rc = rela_ffnet_create(&l->target, num_action, device);
   if (rc != RELA_OK) return rc;
+  ffnet_label_as_learner(l->online);
+  ffnet_label_as_learner(l->target);
   RELA_HIP(hipMalloc(&l->w2p, sizeof(float) * 64 * 512));
   RELA_HIP(hipMalloc(&l->w3p, sizeof(float) * 64 * 576));
   RELA_HIP(hipMalloc(&l->wfcp, sizeof(float) * 512 * 3136));
