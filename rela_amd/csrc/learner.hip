@@ -240,12 +240,22 @@ __global__ __launch_bounds__(kLT) void colsum_partial(const float* __restrict__ 
     *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * C + cg * 4) = s;
   }
 }
-__global__ void colsum_final(const float* __restrict__ part, int nblk, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * C + c];
-  out[c] = s;
+// one block per float4 of columns: thread b holds partial b, fixed-shape tree reduction in LDS
+__global__ __launch_bounds__(kColsumBlocks) void colsum_final(const float* __restrict__ part, int C,
+                                                              float* __restrict__ out) {
+  __shared__ float4 sm[kColsumBlocks];
+  const int cg = blockIdx.x;
+  sm[threadIdx.x] = ld4(part + (size_t)threadIdx.x * C + cg * 4);
+  __syncthreads();
+  for (int o = kColsumBlocks / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const float4 v = sm[threadIdx.x + o];
+      float4& d = sm[threadIdx.x];
+      d.x += v.x, d.y += v.y, d.z += v.z, d.w += v.w;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *reinterpret_cast<float4*>(out + cg * 4) = sm[0];
 }
 __global__ void head_bias_grad(const float* __restrict__ s32, int A, float* __restrict__ g_a_b,
                                float* __restrict__ g_v_b) {
@@ -603,8 +613,7 @@ extern "C" int rela_apex_learner_backward(rela_apex_learner* l, int batch, const
   auto colsum = [&](const float* src, int64_t rows, int C, float* out) {
     ProfScope prof("learner_colsum", s);
     hipLaunchKernelGGL(colsum_partial, dim3(kColsumBlocks), dim3(kLT), 0, s, src, rows, C, l->cpart);
-    hipLaunchKernelGGL(colsum_final, dim3(ceil_div(C, 256)), dim3(256), 0, s, (const float*)l->cpart, kColsumBlocks,
-                       C, out);
+    hipLaunchKernelGGL(colsum_final, dim3(C / 4), dim3(kColsumBlocks), 0, s, (const float*)l->cpart, C, out);
   };
 
   // heads: d_h, dWh, db
