@@ -59,6 +59,8 @@ def parse_args(argv=None):
     p.add_argument("--act_eps_alpha", type=float, default=7)
     p.add_argument("--act_device", type=str, default="cuda:0")
     p.add_argument("--actor_sync_freq", type=int, default=20)
+    p.add_argument("--hip_learner", type=int, default=1,
+                   help="apex: run loss/backward/clip/RMSprop through csrc/learner.hip instead of autograd")
     return p.parse_args(argv)
 
 
@@ -79,6 +81,12 @@ def train(args, on_epoch=None):
         agent = ApexAgent(lambda: AtariFFNet(num_action), args.multi_step, args.gamma).to(args.train_device)
         optim = torch.optim.RMSprop(agent.online_net.parameters(), lr=args.lr, eps=args.eps)
         replay_class = rela.FFPrioritizedReplay
+    learner = None
+    if args.algo == "apex" and getattr(args, "hip_learner", 1):
+        from rela_amd.learner import HipApexLearner
+
+        learner = HipApexLearner.from_agent(agent, args.batchsize, lr=args.lr, eps=args.eps,
+                                            grad_clip=args.grad_clip)
 
     act_devices = args.act_device.split(",")
     if len(act_devices) != 1:
@@ -111,17 +119,27 @@ def train(args, on_epoch=None):
         for batch_idx in range(args.epoch_len):
             num_update = batch_idx + epoch * args.epoch_len
             if num_update % args.num_update_between_sync == 0:
-                agent.sync_target_with_online()
+                if learner is not None:
+                    learner.sync_target_with_online()
+                else:
+                    agent.sync_target_with_online()
             if num_update % args.actor_sync_freq == 0:
+                if learner is not None:  # ModelLocker reads the Python model: hand it the current weights
+                    agent.online_net.load_state_dict(learner.state_dict("online"))
+                    agent.target_net.load_state_dict(learner.state_dict("target"))
                 for locker in lockers:
                     locker.update_model(agent)
             batch, weight = replay_buffer.sample(args.batchsize, args.train_device)
-            loss, priority = agent.loss(batch, sync_priority=False)
-            loss = (loss * weight).mean()
-            loss.backward()
-            torch.nn.utils.clip_grad_norm_(agent.online_net.parameters(), args.grad_clip)
-            optim.step()
-            optim.zero_grad()
+            if learner is not None:
+                loss, priority = learner.step(batch, weight)
+                loss = loss[0].clone()
+            else:
+                loss, priority = agent.loss(batch, sync_priority=False)
+                loss = (loss * weight).mean()
+                loss.backward()
+                torch.nn.utils.clip_grad_norm_(agent.online_net.parameters(), args.grad_clip)
+                optim.step()
+                optim.zero_grad()
             replay_buffer.update_priority(priority)
             loss_sum += loss.detach()
         torch.cuda.synchronize()

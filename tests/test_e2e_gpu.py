@@ -43,15 +43,17 @@ def test_lockstep_matches_reference(mods):
         np.testing.assert_allclose(got["weight"], exp["weight"], rtol=1e-4, err_msg="IS weights, round %d" % r)
 
 
-def test_training_entry_point_runs(mods, capsys):
+@pytest.mark.parametrize("hip_learner", [1, 0])
+def test_training_entry_point_runs(mods, capsys, hip_learner):
     """pyrela-style main loop on 2 threads x 8 envs for two tiny epochs: actors insert from C++
-    threads while the learner samples / steps / updates; rates are printed in the reference's
-    `Speed:` format and the loss is finite."""
+    threads while the learner samples / steps / updates (hand-written HIP learner step, or PyTorch
+    autograd as in the reference); rates are printed in the reference's `Speed:` format and the
+    loss is finite."""
     from rela_amd.pyrela import main as entry
 
     args = entry.parse_args(["--num_thread", "2", "--num_game_per_thread", "8", "--batchsize", "32", "--epoch_len", "20",
                              "--num_epoch", "2", "--burn_in_frames", "64", "--replay_buffer_size", "512",
-                             "--episode_len", "25", "--actor_sync_freq", "5"])
+                             "--episode_len", "25", "--actor_sync_freq", "5", "--hip_learner", str(hip_learner)])
     hist = entry.train(args)
     out = capsys.readouterr().out
     assert "Speed: train: " in out and "buffer_add: " in out
