@@ -339,6 +339,24 @@ def main():
     buf = C.create_string_buffer(1 << 16)
     capi.check(capi.lib.rela_prof_summary_json(buf, len(buf)), "rela_prof_summary_json")
     prof = json.loads(buf.value.decode())
+
+    # Reference-style accounting next to the headline (N = 1 only, untimed by the driver): the same
+    # step with the act-forward reuse switched off, i.e. all 4 forwards of the reference per env-step.
+    ms_4fwd = None
+    if world == 1 and not ONLY:
+        engine.set_reuse(False)
+        k4 = max(5, args.steps // 3)
+        for _ in range(2):
+            one_step()
+            step_idx[0] += 1
+        sync_all()
+        t4 = time.perf_counter()
+        for _ in range(k4):
+            one_step()
+            step_idx[0] += 1
+        sync_all()
+        ms_4fwd = (time.perf_counter() - t4) / k4 * 1e3
+        engine.set_reuse(True)
     st = replay.debug_state()
     assert st["dev_error"] == 0, "replay reported device error %d" % st["dev_error"]
 
@@ -378,6 +396,8 @@ def main():
             # act + compute_priority's online(obs), target(next_obs); online(next_obs) is act's own
             # forward (same weights, same batch) and is reused bit-identically -> 3, else 4
             "forwards_per_tick": fwd_cnt / args.steps if ONLY != "learner" else 0,
+            "no_reuse": None if ms_4fwd is None else {
+                "forwards_per_tick": 4, "ms_per_step": ms_4fwd, "env_steps_per_s": ROWS / (ms_4fwd * 1e-3)},
             "forward_ms_per_6400": fwd_ms / max(fwd_cnt, 1),
             "forward_tflops": sum(FLOP.values()) * ROWS / (max(fwd_ms, 1e-9) / max(fwd_cnt, 1) * 1e-3) / 1e12,
             "replay_sample_scan_ms": scan_ms / args.steps,

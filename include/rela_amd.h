@@ -287,6 +287,9 @@ int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward, const uin
                               int nonblocking, int* inserted, void* stream);
 
 int64_t rela_apex_actor_num_act(const rela_apex_actor* a); /* numAct()  dqn_actor.h:149-151 */
+/* post_step evaluates online(next_obs) only if act() did not already do so with the same weights
+ * (bit-identical, see post_step); on = 0 always recomputes, i.e. the reference's 4 forwards per step */
+int rela_apex_actor_set_reuse(rela_apex_actor* a, int on);
 /* diagnostic: device pointers of the last Q table of act() and of the last priorities       */
 const float* rela_apex_actor_last_q_dev(const rela_apex_actor* a);
 const float* rela_apex_actor_last_priority_dev(const rela_apex_actor* a);

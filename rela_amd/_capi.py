@@ -105,6 +105,7 @@ _sig("rela_apex_actor_legal_dev", vp, [vp])
 _sig("rela_apex_actor_act", i32, [vp, vp, vp, vp, vp, vp, P(vp), vp])
 _sig("rela_apex_actor_post_step", i32, [vp, vp, vp, i32, vp, vp, i32, P(i32), vp])
 _sig("rela_apex_actor_num_act", i64, [vp])
+_sig("rela_apex_actor_set_reuse", i32, [vp, i32])
 _sig("rela_apex_actor_last_q_dev", vp, [vp])
 _sig("rela_apex_actor_last_priority_dev", vp, [vp])
 _sig("rela_r2d2_actor_create", i32, [P(vp), i32, i32, i32, i32, f32, i32, i32, f64, vp, u64, i32])

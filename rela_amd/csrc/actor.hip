@@ -41,6 +41,7 @@ struct rela_apex_actor {
   const rela_ffnet* q_net = nullptr;
   uint64_t q_version = 0;
   int q_slot = -1;
+  bool reuse_act_forward = true;
 };
 
 namespace {
@@ -113,6 +114,11 @@ static inline int next_slot(const rela_apex_actor* a) { return (a->head + a->cou
 
 extern "C" void* rela_apex_actor_obs_slot(rela_apex_actor* a) {
   return a ? a->obs + (size_t)next_slot(a) * a->R * kObs : nullptr;
+}
+extern "C" int rela_apex_actor_set_reuse(rela_apex_actor* a, int on) {
+  RELA_CHECK(a, RELA_EINVAL, "rela_apex_actor_set_reuse: bad arguments");
+  a->reuse_act_forward = on != 0;
+  return RELA_OK;
 }
 extern "C" float* rela_apex_actor_eps_dev(rela_apex_actor* a) { return a ? a->eps : nullptr; }
 extern "C" float* rela_apex_actor_legal_dev(rela_apex_actor* a) { return a ? a->legal : nullptr; }
@@ -190,7 +196,8 @@ extern "C" int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward
   // (dqn_actor.h:161, history.back() :84).  With the same weights (no load since) and the same
   // legal mask and batch, that forward is bit-identical to the one act() left in q[0]: reuse it.
   const float* q_online_n = a->q;
-  if (!(a->q_net == online && a->q_version == rela_ffnet_version(online) && a->q_slot == last)) {
+  if (!(a->reuse_act_forward && a->q_net == online && a->q_version == rela_ffnet_version(online) &&
+        a->q_slot == last)) {
     rc = rela_ffnet_forward(online, a->R, obs_n, legal_n, a->q + 2 * QA, a->ws, a->ws_bytes, s);
     if (rc != RELA_OK) return rc;
     q_online_n = a->q + 2 * QA;

@@ -106,6 +106,10 @@ class ApexActorEngine:
     def num_act(self):
         return capi.lib.rela_apex_actor_num_act(self.h)
 
+    def set_reuse(self, on):
+        """on=False: post_step always recomputes online(next_obs) (the reference's 4 forwards per step)."""
+        capi.check(capi.lib.rela_apex_actor_set_reuse(self.h, int(bool(on))), "rela_apex_actor_set_reuse")
+
     def next_obs_slot(self):
         """The HBM slot the env layer writes the next observation batch into ([R,4,84,84] u8)."""
         ptr = capi.lib.rela_apex_actor_obs_slot(self.h)

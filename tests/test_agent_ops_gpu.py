@@ -154,19 +154,21 @@ def test_post_step_reuses_act_forward_bit_identically():
     tparams = {k: torch.from_numpy(v) for k, v in synth_params(A, 6).items()}
     eps = np.linspace(0.0, 0.4, R).astype(np.float32)
     runs = []
-    for reload_between in (False, True):
+    for reload_between in (False, True, "switch"):
         online, target = FFNetHandle(A, "cuda:0"), FFNetHandle(A, "cuda:0")
         online.load_state_dict(params)
         target.load_state_dict(tparams)
         replay = FFReplay(256, 3, 0.6, 0.4, 0, A, "cuda:0")
         eng = ApexActorEngine(R, K, A, n, 0.99, replay, eps, "cuda:0", seed=11)
         eng.legal.fill_(1.0)
+        if reload_between == "switch":
+            eng.set_reuse(False)
         prios, acts = [], []
         for t in range(n + 4):
             eng.next_obs_slot().copy_(torch.from_numpy(synth_obs(R, 100 + t)).cuda())
             acts.append(eng.act(online).cpu().numpy().copy())
             v0 = capi.lib.rela_ffnet_version(online.h)
-            if reload_between:
+            if reload_between is True:
                 online.load_state_dict(params)
                 assert capi.lib.rela_ffnet_version(online.h) == v0 + 1
             rew = torch.full((R,), 0.25 * t, device="cuda")
@@ -183,10 +185,11 @@ def test_post_step_reuses_act_forward_bit_identically():
         replay.close()
         online.close()
         target.close()
-    assert runs[0][3] == runs[1][3] == 4 * R
-    assert np.array_equal(runs[0][0], runs[1][0])
-    assert np.array_equal(runs[0][1].view(np.uint32), runs[1][1].view(np.uint32))
-    assert np.array_equal(runs[0][2].view(np.uint32), runs[1][2].view(np.uint32))
+    for other in runs[1:]:
+        assert runs[0][3] == other[3] == 4 * R
+        assert np.array_equal(runs[0][0], other[0])
+        assert np.array_equal(runs[0][1].view(np.uint32), other[1].view(np.uint32))
+        assert np.array_equal(runs[0][2].view(np.uint32), other[2].view(np.uint32))
 
 
 def test_transition_carries_eps_and_legal_of_its_own_time_step():
