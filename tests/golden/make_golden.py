@@ -181,6 +181,68 @@ def ffnet_cases():
              priority=prio.numpy().astype(np.float64).tolist(), td_err=err.numpy().astype(np.float64).tolist())
 
 
+def learner_cases():
+    """One learner step of the REAL reference on CPU (pyrela/main.py:226-239 with pyrela/apex.py):
+    loss -> (loss * weight).mean().backward() -> clip_grad_norm_ -> RMSprop.step.  Gradients and
+    updated parameters are recorded as per-tensor norms / sums plus 48 sampled entries."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference/pyrela")
+    import types
+
+    import torch
+    from apex import ApexAgent  # noqa: the reference's own modules
+    from net import AtariFFNet
+
+    torch.set_num_threads(4)
+    for name, A, B, clip in [("learner_apex_A18_B32", 18, 32, 0.5), ("learner_apex_A6_B8_noclip", 6, 8, 40.0)]:
+        multi_step, gamma, lr, eps = 3, 0.997, 1e-3, 1.5e-4
+        agent = ApexAgent(lambda: AtariFFNet(A), multi_step, gamma)
+        on, tg = synth_params(A, 3003), synth_params(A, 4004)
+        agent.online_net.load_state_dict({k: torch.from_numpy(v) for k, v in on.items()})
+        agent.target_net.load_state_dict({k: torch.from_numpy(v) for k, v in tg.items()})
+        s, ns = synth_obs(B, 41), synth_obs(B, 42)
+        rng = np.random.default_rng(43)
+        legal = (rng.uniform(size=(B, A)) < 0.8).astype(np.float32)
+        nlegal = (rng.uniform(size=(B, A)) < 0.8).astype(np.float32)
+        legal[:, 0] = 1.0
+        nlegal[:, 1] = 1.0
+        action = np.array([rng.choice(np.flatnonzero(legal[i])) for i in range(B)], np.int64)
+        reward = rng.normal(0.0, 1.5, B).astype(np.float32)  # some |td| > 1: both Huber branches
+        bootstrap = (rng.uniform(size=B) < 0.8).astype(np.float32)
+        weight = rng.uniform(0.1, 1.0, B).astype(np.float32)
+        batch = types.SimpleNamespace(
+            obs={"s": torch.from_numpy(s), "legal_move": torch.from_numpy(legal), "eps": torch.zeros(B, 1)},
+            next_obs={"s": torch.from_numpy(ns), "legal_move": torch.from_numpy(nlegal), "eps": torch.zeros(B, 1)},
+            action={"a": torch.from_numpy(action)}, reward=torch.from_numpy(reward),
+            terminal=torch.zeros(B, dtype=torch.bool), bootstrap=torch.from_numpy(bootstrap))
+        params = list(agent.online_net.parameters())
+        optim = torch.optim.RMSprop(params, lr=lr, eps=eps)  # main.py:120
+        loss, priority = agent.loss(batch)                    # main.py:226
+        loss = (loss * torch.from_numpy(weight)).mean()       # :228
+        loss.backward()                                       # :229
+        named = dict(agent.online_net.named_parameters())
+        pick = {k: np.random.default_rng(7).integers(0, v.numel(), 48) for k, v in named.items()}
+
+        def digest(get):
+            out = {}
+            for k, v in named.items():
+                t = get(v).detach().double().reshape(-1)
+                out[k] = {"l2": float(t.norm()), "sum": float(t.sum()), "absmax": float(t.abs().max()),
+                          "idx": pick[k].tolist(), "val": t[torch.from_numpy(pick[k])].tolist()}
+            return out
+
+        grads = digest(lambda v: v.grad)
+        g_norm = torch.nn.utils.clip_grad_norm_(params, clip)  # :233
+        optim.step()                                           # :238
+        after = digest(lambda v: v)
+        save(name, [], [], num_action=A, B=B, multi_step=multi_step, gamma=gamma, lr=lr, eps=eps, grad_clip=clip,
+             online_seed=3003, target_seed=4004, obs_seed=41, next_obs_seed=42,
+             legal=legal.tolist(), next_legal=nlegal.tolist(), action=action.tolist(), reward=reward.tolist(),
+             bootstrap=bootstrap.tolist(), weight=weight.tolist(), loss=float(loss),
+             priority=priority.numpy().astype(np.float64).tolist(), grad_norm=float(g_norm), grads=grads,
+             params_after=after)
+
+
 def r2d2buf_cases():
     """R2D2TransitionBuffer traces: episodes shorter than the window, full windows with carry-over,
     terminals inside the carried region, overlapping carry (burn+n > seq), burn_in = 0."""
@@ -295,3 +357,5 @@ if __name__ == "__main__":
         nstep_cases()
     if "ffnet" in which:
         ffnet_cases()
+    if "learner" in which:
+        learner_cases()

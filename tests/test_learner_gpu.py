@@ -1,10 +1,16 @@
 """GPU parity of the hand-written Ape-X learner step (csrc/learner.hip, through the C ABI) against
 PyTorch autograd on the same batch: loss, priorities, every gradient tensor, and the parameters
 after clip_grad_norm_ + RMSprop / Adam steps (pyrela/main.py:226-239, pyrela/apex.py:30-91)."""
+import glob
+import json
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 RTOL, ATOL = 2e-3, 2e-5  # fp32 sums of up to 2e5 terms in different orders (split-K vs MIOpen)
 
@@ -168,3 +174,52 @@ def test_learner_errors():
     assert capi.lib.rela_apex_learner_create(C.byref(h), 6, 32, 3, 0.99, 0, 1e-4, 1e-4, 40.0, 0) == capi.OK
     assert capi.lib.rela_apex_learner_apply(h, None) == capi.ESTATE  # never loaded
     capi.lib.rela_apex_learner_destroy(h)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "learner_*.json"))), ids=os.path.basename)
+def test_learner_step_matches_the_reference_golden(path):
+    """One learner step against vectors recorded from the REAL reference on CPU
+    (tests/golden/make_golden.py learner_cases: pyrela/apex.py loss -> backward -> clip_grad_norm_ ->
+    RMSprop.step of pyrela/main.py:226-239): loss, priorities, gradient norm, and for every parameter
+    tensor its gradient / updated value (l2 norm, sum, 48 sampled entries)."""
+    import torch
+    from types import SimpleNamespace
+
+    from rela_amd.learner import HipApexLearner
+    from synth import synth_obs, synth_params
+
+    g = json.load(open(path))
+    A, B = g["num_action"], g["B"]
+    dev = "cuda:0"
+    learner = HipApexLearner(A, B, g["multi_step"], g["gamma"], lr=g["lr"], eps=g["eps"], grad_clip=g["grad_clip"],
+                             device=dev)
+    to = lambda sd: {k: torch.from_numpy(v).to(dev) for k, v in sd.items()}
+    learner.load_state_dicts(to(synth_params(A, g["online_seed"])), to(synth_params(A, g["target_seed"])))
+    f32 = lambda x: torch.tensor(x, dtype=torch.float32, device=dev)
+    batch = SimpleNamespace(
+        obs={"s": torch.from_numpy(synth_obs(B, g["obs_seed"])).to(dev), "eps": torch.zeros(B, 1, device=dev),
+             "legal_move": f32(g["legal"])},
+        next_obs={"s": torch.from_numpy(synth_obs(B, g["next_obs_seed"])).to(dev),
+                  "eps": torch.zeros(B, 1, device=dev), "legal_move": f32(g["next_legal"])},
+        action={"a": torch.tensor(g["action"], dtype=torch.int64, device=dev)}, reward=f32(g["reward"]),
+        terminal=torch.zeros(B, dtype=torch.bool, device=dev), bootstrap=f32(g["bootstrap"]))
+    loss, prio = learner.backward(batch, f32(g["weight"]))
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(prio.cpu().numpy(), np.array(g["priority"]), rtol=1e-4, atol=1e-4)
+
+    def check(views, gold, tol_scale, what):
+        for key, rec in gold.items():
+            t = views[key].double().reshape(-1).cpu()
+            scale = rec["absmax"] + 1e-12
+            np.testing.assert_allclose(float(t.norm()), rec["l2"], rtol=2e-3, atol=tol_scale * scale,
+                                       err_msg="%s l2 %s" % (what, key))
+            np.testing.assert_allclose(t[torch.tensor(rec["idx"])].numpy(), np.array(rec["val"]), rtol=2e-3,
+                                       atol=tol_scale * scale, err_msg="%s %s" % (what, key))
+
+    check(learner.state_dict("grads"), g["grads"], 2e-3, "grad")
+    learner.apply()
+    st = learner.stats().cpu().numpy()
+    np.testing.assert_allclose(st[0], g["grad_norm"], rtol=1e-3)
+    # one RMSprop step moves a weight by at most lr / sqrt(1 - alpha) = 10 lr
+    check(learner.state_dict("online"), g["params_after"], 0.02 * 10 * g["lr"] / 1.0, "param")
+    learner.close()
