@@ -199,3 +199,43 @@ class HipApexLearner:
         capi = getattr(self, "_capi", None)
         if capi is not None and getattr(capi, "lib", None) is not None:
             self.close()
+
+
+# ---- weight publish to actor-only ranks (SURVEY 8e: C3 / C4 layouts) ------------------------------
+FFNET_KEYS = HipApexLearner.KEYS
+
+
+def ffnet_flat_layout(num_action):
+    """[(state_dict key, shape, offset)] and the total length of the flat f32 parameter buffer of
+    csrc/learner.hip: rela_ffnet_params order, every segment padded to a multiple of 4 floats."""
+    out, off = [], 0
+    for key, shape in zip(FFNET_KEYS, HipApexLearner.SHAPES(num_action)):
+        n = 1
+        for d in shape:
+            n *= d
+        out.append((key, shape, off))
+        off += (n + 3) // 4 * 4
+    return out, off
+
+
+def broadcast_weights(flat, src=0, group=None):
+    """ModelLocker.update_model across processes: ONE broadcast of the flat parameter buffer
+    (6.8 MB for AtariFFNet) from the learner rank to the actor ranks (RCCL over xGMI on GPUs)."""
+    dist.broadcast(flat, src=src, group=group)
+    return flat
+
+
+def load_net_from_flat(net_handle, flat, num_action):
+    """Repack an actor-side FFNetHandle from a flat parameter buffer resident on its GPU."""
+    import ctypes as C
+
+    from . import _capi as capi
+
+    layout, total = ffnet_flat_layout(num_action)
+    assert flat.is_cuda and flat.dtype == torch.float32 and flat.numel() == total and flat.is_contiguous()
+    p = capi.FFNetParams()
+    for (field, _), (_, _, off) in zip(capi.FFNetParams._fields_, layout):
+        setattr(p, field, flat.data_ptr() + 4 * off)
+    stream = C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)
+    capi.check(capi.lib.rela_ffnet_load(net_handle.h, C.byref(p), 1, stream), "rela_ffnet_load")
+    net_handle._keep = [flat]

@@ -109,3 +109,47 @@ def test_two_partition_is_weight_normalisation():
     got = torch.tensor(res).reshape(-1)
     torch.testing.assert_close(got, ref, rtol=1e-6, atol=0)
     assert got.max() == 1.0
+
+
+def _publish_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rela_amd.learner import broadcast_weights, ffnet_flat_layout
+
+    layout, total = ffnet_flat_layout(18)
+    flat = torch.arange(total, dtype=torch.float32) if rank == 0 else torch.zeros(total)
+    broadcast_weights(flat, src=0)  # learner rank 0 -> actor rank 1
+    key, shape, off = layout[6]  # linear.0.weight
+    n = shape[0] * shape[1]
+    if rank == 1:
+        out.put((bool(torch.equal(flat, torch.arange(total, dtype=torch.float32))), key, list(shape), off,
+                 flat[off:off + n].view(shape)[3, 5].item(), total))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_weight_publish_layout_and_broadcast():
+    """The flat parameter buffer of csrc/learner.hip (rela_ffnet_params order, segments padded to 4
+    floats) broadcast from the learner rank to an actor-only rank."""
+    from rela_amd.learner import ffnet_flat_layout
+
+    layout, total = ffnet_flat_layout(18)
+    assert [k for k, _, _ in layout][:2] == ["net.0.weight", "net.0.bias"]
+    assert all(off % 4 == 0 for _, _, off in layout) and total % 4 == 0
+    # 1,693,875 parameters at A = 18 (SURVEY 8), + padding of fc_v.bias (1 -> 4) and fc_a.bias (18 -> 20)
+    assert total == 1693875 + 3 + 2
+    offs = {k: off for k, _, off in layout}
+    assert offs["net.2.weight"] == 8192 + 32 and offs["fc_a.weight"] == offs["fc_v.bias"] + 4
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_publish_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    same, key, shape, off, val, tot = out.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert same and key == "linear.0.weight" and shape == [512, 3136] and tot == total
+    assert val == float(off + 3 * 3136 + 5)

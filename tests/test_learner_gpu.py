@@ -223,3 +223,45 @@ def test_learner_step_matches_the_reference_golden(path):
     # one RMSprop step moves a weight by at most lr / sqrt(1 - alpha) = 10 lr
     check(learner.state_dict("online"), g["params_after"], 0.02 * 10 * g["lr"] / 1.0, "param")
     learner.close()
+
+
+def test_actor_net_loaded_from_flat_buffer_matches_publish():
+    """load_net_from_flat (what an actor-only rank does after broadcast_weights) gives the same
+    forward as HipApexLearner.publish, and the Python layout equals the library's."""
+    import torch
+
+    from rela_amd import _capi as capi
+    from rela_amd.engine import FFNetHandle
+    from rela_amd.learner import HipApexLearner, ffnet_flat_layout, load_net_from_flat
+    from synth import synth_obs, synth_params
+    import ctypes as C
+
+    A, N = 18, 40
+    learner = HipApexLearner(A, 32, 3, 0.99)
+    learner.load_state_dicts({k: torch.from_numpy(v).cuda() for k, v in synth_params(A, 9).items()})
+    flat_p, _ = learner.flat()
+    layout, total = ffnet_flat_layout(A)
+    assert flat_p.numel() == total
+    sd = learner.state_dict("online")
+    for key, shape, off in layout:
+        assert sd[key].data_ptr() == flat_p.data_ptr() + 4 * off and tuple(sd[key].shape) == tuple(shape)
+    received = flat_p.clone()  # stands for the broadcast destination on another rank
+    a, b = FFNetHandle(A, "cuda:0"), FFNetHandle(A, "cuda:0")
+    learner.publish(a)
+    load_net_from_flat(b, received, A)
+    s = torch.from_numpy(synth_obs(N, 3)).cuda()
+    legal = torch.ones(N, A, device="cuda")
+    nb = capi.lib.rela_ffnet_workspace_bytes(a.h, N)
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    qs = []
+    for net in (a, b):
+        q = torch.empty(N, A, device="cuda")
+        capi.check(capi.lib.rela_ffnet_forward(net.h, N, C.c_void_p(s.data_ptr()), C.c_void_p(legal.data_ptr()),
+                                               C.c_void_p(q.data_ptr()), C.c_void_p(ws.data_ptr()), nb,
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)), "fwd")
+        qs.append(q)
+    torch.cuda.synchronize()
+    assert torch.equal(qs[0], qs[1])
+    a.close()
+    b.close()
+    learner.close()
