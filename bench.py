@@ -376,6 +376,17 @@ def main():
                     "traffic": None, "avg_launch_ms": avg_ms, "launches": rec["count"]}
         if roof["achieved"] is not None:
             roof["frac"] = roof["achieved"] / roof["peak"]
+        # HBM bytes per launch of that kernel from the committed PMC passes (separate rocprofv3 --pmc
+        # runs of the isolated forward at the same N, tools/final_evidence.sh + tools/pmc_table.py)
+        try:
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                             "r01_traffic.json")))
+            rec_t = tj["kernels"].get(name)
+            if rec_t is not None:
+                roof["traffic"] = rec_t["read_bytes"] + rec_t["write_bytes"]
+                roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+        except (OSError, ValueError, KeyError):
+            pass
         fwd_ms = sum(prof[k]["total_ms"] for k in FLOP if k in prof)
         fwd_cnt = prof.get("conv1_bf16x3", {"count": 1})["count"]
         scan_ms = sum(v["total_ms"] for k, v in prof.items() if k.startswith("seq_") or k in (

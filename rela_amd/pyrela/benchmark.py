@@ -40,18 +40,21 @@ def benchmark_fps(num_thread, num_game_per_thread, args):
     for mode in ("without", "with"):
         for epoch in range(args.num_epoch):
             t0 = time.time()
+            n_sample = 0
             if mode == "without":
                 time.sleep(args.epoch_sec)
             else:
                 while time.time() - t0 <= args.epoch_sec:
                     batch, weight = replay_buffer.sample(512, args.device)
                     replay_buffer.update_priority(weight)
+                    n_sample += 1
+                torch.cuda.synchronize()  # the loop only enqueues: count what the GPU finished
             dt = time.time() - t0
             now = utils.total_acts(actors)
             rates[mode].append((now - seen) / dt)
             seen = now
-            print("%s sample: epoch %d, act rate: %d, buffer size: %d" % (mode, epoch, rates[mode][-1],
-                                                                          replay_buffer.size()), flush=True)
+            print("%s sample: epoch %d, act rate: %d, buffer size: %d, sample rate: %d/s" % (
+                mode, epoch, rates[mode][-1], replay_buffer.size(), n_sample / dt), flush=True)
     context.terminate()
     context.resume()
     while not context.terminated():

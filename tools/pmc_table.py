@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 PMC passes of tools/final_evidence.sh into the table of profiles/README.md and
+into profiles/r01_traffic.json (HBM bytes per launch, which bench.py reports as roofline.traffic).
+
+  python tools/pmc_table.py gpurun_out/final profiles/r01_traffic.json
+
+Corrections as MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is
+doubled for wide coalesced reads on gfx950; clock = GRBM_GUI_ACTIVE / 8 XCDs / duration;
+MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 1024 SIMDs)."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def short(n):
+    m = re.search(r"conv_mfma_bstat<.*?ConvCfg<(\d+)", n)
+    if m:
+        return "conv2_mfma" if m.group(1) == "32" else "conv3_mfma"
+    m = re.search(r"ConvCfg<(\d+)", n)
+    if m:
+        return "conv2_mfma" if m.group(1) == "32" else "conv3_mfma"
+    m = re.search(r"gemm_mfma<.*?GemmCfg<(\d+), (\d+)", n)
+    if m:
+        return {"3136_512": "fc_mfma", "512_32": "heads_mfma"}.get("%s_%s" % m.groups(), "gemm_%s_%s" % m.groups())
+    m = re.search(r"::(\w+)[<(]", n)
+    return m.group(1) if m else n[:40]
+
+
+def main(root, out_json):
+    res = {}
+    for name in ("pmc_sq", "pmc_fetch", "pmc_write"):
+        tr = list(csv.DictReader(open(glob.glob("%s/%s/*/*_kernel_trace.csv" % (root, name))[0])))
+        dur = collections.defaultdict(list)
+        for r in tr:
+            dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        for r in csv.DictReader(open(glob.glob("%s/%s/*/*_counter_collection.csv" % (root, name))[0])):
+            res.setdefault(short(r["Kernel_Name"]), {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        if name == "pmc_sq":
+            for k, v in dur.items():
+                res.setdefault(k, {})["us"] = [x / 1e3 for x in v]
+    keep = ("conv1_bf16x3", "conv2_mfma", "conv3_mfma", "fc_mfma", "heads_mfma", "replay_scatter_rows",
+            "replay_gather_rows", "seq_chain", "replay_search", "replay_append_weights")
+    traffic = {}
+    print("| kernel | us | GHz | MFMA busy | HBM read MB | HBM write MB | LDS bank-conflict cycles |")
+    print("|---|---|---|---|---|---|---|")
+    for k in keep:
+        d = res.get(k)
+        if not d or "us" not in d or "GRBM_GUI_ACTIVE" not in d:
+            continue
+        avg = lambda c: sum(d[c]) / len(d[c]) if c in d else float("nan")
+        us, cyc = avg("us"), avg("GRBM_GUI_ACTIVE") / 8
+        rd, wr = 2 * avg("FETCH_SIZE") * 1024, avg("WRITE_SIZE") * 1024
+        traffic[k] = {"read_bytes": rd, "write_bytes": wr, "launch_us": us}
+        print("| %s | %.1f | %.2f | %.1f %% | %.1f | %.1f | %.0f |" % (
+            k, us, cyc / us / 1e3, 100 * avg("SQ_VALU_MFMA_BUSY_CYCLES") / (cyc * 1024), rd / 1e6, wr / 1e6,
+            avg("SQ_LDS_BANK_CONFLICT")))
+    if out_json:
+        json.dump({"source": "rocprofv3 --pmc passes of tools/profile_forward.py (N = 6400), see tools/pmc_table.py",
+                   "kernels": traffic}, open(out_json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
