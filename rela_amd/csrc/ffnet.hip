@@ -366,6 +366,9 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_bstat(const float* __restr
 // Picks the B-stationary kernel once every CU gets at least two sample groups.  conv3 stays on
 // conv_mfma: its 144 + 20 accumulator registers spill under the 256-register budget and with one
 // block per CU the 2134 groups of N = 6400 quantise to 9 rounds (measured 259 us against 227 us).
+// Splitting K over two wave groups (72 weight registers + 40 accumulators per wave, halves summed
+// through LDS) removes the spills of the hot loop but measured 318 us: with one block per CU two
+// waves per SIMD do not hide the LDS latency of ten row tiles.  Tried and dropped in round 1.
 template <class C>
 void launch_conv(const float* in, const float* Bfrag, const float* bias, float* out, int N, hipStream_t s) {
   const int ngroups = ceil_div(N, C::S);
