@@ -82,6 +82,12 @@ int rela_replay_set_schema_seq(rela_replay* r, int nfields, const int64_t* row_b
 int rela_replay_begin_add(rela_replay* r, int n, int nonblocking, int* first_slot);
 int rela_replay_write_rows(rela_replay* r, int first_slot, int offset, int count,
                            const void* const* rows_dev, void* stream);
+/* write, gathered: row i of the call comes from source row src_index_dev[f][i] of field f's base
+ * array (row pitch = the field's row_bytes) and goes to reserved slot first_slot + dst_offset_dev[i].
+ * One launch per field for any number of rows (the R2D2 actor emits all sequences of a pop so). */
+int rela_replay_write_rows_gather(rela_replay* r, int first_slot, int count,
+                                  const int32_t* dst_offset_dev, const void* const* bases_dev,
+                                  const int32_t* const* src_index_dev, void* stream);
 int rela_replay_commit_add(rela_replay* r, int first_slot, int n, const float* priority_dev,
                            void* stream);
 /* The same commit for n = G*group_rows slots that stand for G consecutive reference blocks of

@@ -69,6 +69,7 @@ _sig("rela_replay_set_schema", i32, [vp, i32, P(i64)])
 _sig("rela_replay_set_schema_seq", i32, [vp, i32, P(i64), P(C.c_int32)])
 _sig("rela_replay_begin_add", i32, [vp, i32, i32, P(i32)])
 _sig("rela_replay_write_rows", i32, [vp, i32, i32, i32, P(vp), vp])
+_sig("rela_replay_write_rows_gather", i32, [vp, i32, i32, vp, P(vp), P(vp), vp])
 _sig("rela_replay_commit_add", i32, [vp, i32, i32, vp, vp])
 _sig("rela_replay_commit_add_grouped", i32, [vp, i32, i32, i32, vp, vp])
 _sig("rela_replay_add", i32, [vp, i32, P(vp), vp, i32, vp])

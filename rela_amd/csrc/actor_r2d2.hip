@@ -201,6 +201,7 @@ struct rela_r2d2_actor {
   Windows w{};
   float *prow = nullptr, *lens = nullptr, *agg = nullptr;  // [2R][seq], [2R], [2R]
   int32_t *d_slot = nullptr, *d_ranges = nullptr, *d_emits = nullptr, *d_envs = nullptr;
+  int32_t* d_gather = nullptr;  // [2][2R]: destination offsets q and source envs of one emission batch
   uint8_t* d_flags = nullptr;
   void* ws = nullptr;
   int64_t ws_bytes = 0;
@@ -292,6 +293,7 @@ extern "C" int rela_r2d2_actor_create(rela_r2d2_actor** out, int rows, int group
   RELA_ALLOC(a->d_flags, R);
   RELA_ALLOC(a->d_ranges, 2 * R * 4 * sizeof(int32_t));
   RELA_ALLOC(a->d_emits, 2 * R * 3 * sizeof(int32_t));
+  RELA_ALLOC(a->d_gather, 2 * R * 2 * sizeof(int32_t));
   RELA_ALLOC(a->d_envs, R * sizeof(int32_t));
 #undef RELA_ALLOC
   a->ws_bytes = rela_lstmnet_workspace_bytes(nullptr, rows);
@@ -313,7 +315,7 @@ extern "C" void rela_r2d2_actor_destroy(rela_r2d2_actor* a) {
   void* ps[] = {a->obs,   a->act,    a->rew,    a->term,      a->hist_h, a->hist_c, a->hid_h,  a->hid_c,  a->tmp_h,
                 a->tmp_c, a->eps,    a->legal,  a->q,         a->out_r,  a->out_b,  a->prio_step, a->out_t, a->w.s,
                 a->w.eps, a->w.legal, a->w.a,   a->w.reward,  a->w.term, a->w.boot, a->w.prio, a->w.h0,   a->w.c0,
-                a->w.nh0, a->w.nc0,  a->prow,   a->lens,      a->agg,    a->d_slot, a->d_flags, a->d_ranges, a->d_emits,
+                a->w.nh0, a->w.nc0,  a->prow,   a->lens,      a->agg,    a->d_slot, a->d_flags, a->d_ranges, a->d_emits, a->d_gather,
                 a->d_envs, a->ws};
   for (void* p : ps) (void)hipFree(p);
   delete a->book;
@@ -455,15 +457,28 @@ extern "C" int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward
     rc = rela_replay_begin_add(a->replay, nseq, nonblocking, &slot0);
     if (rc == RELA_OK) {
       const Windows& w = a->w;
-      auto emit_rows = [&](int q, int env) -> int {
-        const size_t e = (size_t)env, T = (size_t)a->T;
-        const void* rows[10] = {w.s + e * T * kObs, w.eps + e * T,      w.legal + e * T * a->A, w.a + e * T,
-                                w.reward + e * T,   w.term + e * T,     w.boot + e * T,         w.h0 + e * kHid,
-                                w.c0 + e * kHid,    a->lens + q};
-        return rela_replay_write_rows(a->replay, slot0, q, 1, rows, s);
+      // all sequences of one kind leave in ONE gathered write per field: destination offset q, source
+      // row = the env's window (lens is indexed by q itself)
+      auto emit_batch = [&](bool second) -> int {
+        std::vector<int32_t> qs, envs;
+        for (int q = 0; q < nseq; ++q)
+          if ((plan.emits[q].second != 0) == second) {
+            qs.push_back(q);
+            envs.push_back(plan.emits[q].env);
+          }
+        const int cnt = (int)qs.size();
+        if (cnt == 0) return RELA_OK;
+        int32_t* d_q = a->d_gather + (second ? 2 * (size_t)a->R : 0);
+        int32_t* d_e = d_q + cnt;
+        std::vector<int32_t> both(qs);
+        both.insert(both.end(), envs.begin(), envs.end());
+        // pageable source: the call returns only after the staging copy, so `both` may die
+        RELA_HIP(hipMemcpyAsync(d_q, both.data(), both.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        const void* bases[10] = {w.s, w.eps, w.legal, w.a, w.reward, w.term, w.boot, w.h0, w.c0, a->lens};
+        const int32_t* idx[10] = {d_e, d_e, d_e, d_e, d_e, d_e, d_e, d_e, d_e, d_q};
+        return rela_replay_write_rows_gather(a->replay, slot0, cnt, d_q, bases, idx, s);
       };
-      for (int q = 0; q < nseq && rc == RELA_OK; ++q)
-        if (!plan.emits[q].second) rc = emit_rows(q, plan.emits[q].env);
+      rc = emit_batch(false);
       if (rc == RELA_OK && !plan.carry_env.empty()) {
         RELA_HIP(hipMemcpyAsync(a->d_envs, plan.carry_env.data(), plan.carry_env.size() * sizeof(int32_t),
                                 hipMemcpyHostToDevice, s));
@@ -471,8 +486,7 @@ extern "C" int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward
         RELA_LAUNCH_CHECK();
         rc = upload_ranges(a, plan.carry_pad, s);
       }
-      for (int q = 0; q < nseq && rc == RELA_OK; ++q)
-        if (plan.emits[q].second) rc = emit_rows(q, plan.emits[q].env);
+      if (rc == RELA_OK) rc = emit_batch(true);
       if (rc == RELA_OK) rc = rela_replay_commit_add(a->replay, slot0, nseq, a->agg, s);
       if (rc == RELA_OK && n_sequences) *n_sequences = nseq;
     } else if (rc == RELA_EWOULDBLOCK) {

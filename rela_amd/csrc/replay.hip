@@ -147,6 +147,29 @@ __global__ __launch_bounds__(kThreads) void replay_scatter_rows(const uint8_t* _
   }
 }
 
+// indexed form: row r comes from source row src_idx[r] and goes to slot start + dst_off[r]
+__global__ __launch_bounds__(kThreads) void replay_scatter_rows_indexed(const uint8_t* __restrict__ src,
+                                                                        const int32_t* __restrict__ src_idx,
+                                                                        const int32_t* __restrict__ dst_off,
+                                                                        uint8_t* __restrict__ dst, int64_t row_bytes,
+                                                                        int n, int ring, int start, int vec16) {
+  for (int row = blockIdx.y; row < n; row += gridDim.y) {
+    const int slot = (int)(((int64_t)start + dst_off[row]) % ring);
+    const uint8_t* s = src + (int64_t)src_idx[row] * row_bytes;
+    uint8_t* d = dst + (int64_t)slot * row_bytes;
+    if (vec16) {
+      const int64_t nv = row_bytes >> 4;
+      const uint4* s4 = reinterpret_cast<const uint4*>(s);
+      uint4* d4 = reinterpret_cast<uint4*>(d);
+      for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kThreads)
+        d4[i] = s4[i];
+    } else {
+      for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < row_bytes; i += (int64_t)gridDim.x * kThreads)
+        d[i] = s[i];
+    }
+  }
+}
+
 // gathers batch rows of one field: out[i] = field[ids[i]]   (makeBatch, types.cc:8-46)
 // `steps` > 1: the row is a sequence of `steps` sub-rows and the output is time-major,
 // out[t][b] = slot_b[t]  (RNNTransition::makeBatch, types.cc:140-182)
@@ -492,6 +515,36 @@ extern "C" int rela_replay_write_rows(rela_replay* r, int first_slot, int offset
       ProfScope prof("replay_scatter_rows", r->stream);
       hipLaunchKernelGGL(replay_scatter_rows, dim3(gx, std::min(count, 32768)), dim3(kThreads), 0, r->stream,
                          (const uint8_t*)rows_dev[f], r->d_fields[f], rb, count, r->ring, start, v16);
+    }
+  }
+  RELA_LAUNCH_CHECK();
+  RELA_HIP(hipEventRecord(r->ev_out, r->stream));
+  RELA_HIP(hipStreamWaitEvent(producer, r->ev_out, 0));
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_write_rows_gather(rela_replay* r, int first_slot, int count,
+                                             const int32_t* dst_offset_dev, const void* const* bases_dev,
+                                             const int32_t* const* src_index_dev, void* stream_) {
+  RELA_CHECK(r && count > 0 && first_slot >= 0 && first_slot < r->ring && dst_offset_dev && bases_dev && src_index_dev,
+             RELA_EINVAL, "rela_replay_write_rows_gather: bad arguments");
+  hipStream_t producer = (hipStream_t)stream_;
+  DeviceGuard g(r->device);
+  std::lock_guard<std::mutex> lk(r->m);
+  RELA_HIP(hipEventRecord(r->ev_in, producer));
+  RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
+  for (size_t f = 0; f < r->d_fields.size(); ++f) {
+    if (!bases_dev[f]) continue;
+    RELA_CHECK(src_index_dev[f], RELA_EINVAL, "rela_replay_write_rows_gather: field %d has no source index", (int)f);
+    const int64_t rb = r->row_bytes[f];
+    const int v16 = vec16_ok(bases_dev[f], r->d_fields[f], rb);
+    const int64_t units = v16 ? (rb >> 4) : rb;
+    int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (units + kThreads - 1) / kThreads), 64);
+    {
+      ProfScope prof("replay_scatter_rows", r->stream);
+      hipLaunchKernelGGL(replay_scatter_rows_indexed, dim3(gx, std::min(count, 32768)), dim3(kThreads), 0, r->stream,
+                         (const uint8_t*)bases_dev[f], src_index_dev[f], dst_offset_dev, r->d_fields[f], rb, count,
+                         r->ring, first_slot, v16);
     }
   }
   RELA_LAUNCH_CHECK();
