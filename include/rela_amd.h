@@ -238,6 +238,7 @@ void rela_lstmnet_destroy(rela_lstmnet* net);
 int rela_lstmnet_load(rela_lstmnet* net, const rela_lstmnet_params* params, int params_on_device,
                       void* stream);
 int rela_lstmnet_num_action(const rela_lstmnet* net);
+uint64_t rela_lstmnet_version(const rela_lstmnet* net); /* as rela_ffnet_version */
 int64_t rela_lstmnet_workspace_bytes(const rela_lstmnet* net, int n);
 
 /* One time step for n rows: what AtariLSTMNet.act (net.py:110-124) and .forward with seq = 1
@@ -329,6 +330,9 @@ int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward_host,
                               const rela_lstmnet* target, int nonblocking, int* n_sequences,
                               void* stream);
 int64_t rela_r2d2_actor_num_act(const rela_r2d2_actor* a);
+/* as rela_apex_actor_set_reuse: online_net.act(next_obs, next_hid) of compute_priority (r2d2.py:91) is the
+ * step act() just ran; it is recomputed only if the weights changed in between (or on = 0)       */
+int rela_r2d2_actor_set_reuse(rela_r2d2_actor* a, int on);
 /* diagnostics: current recurrent state (which = 0: h, 1: c) f32[rows,512]; last step priorities */
 const float* rela_r2d2_actor_hidden_dev(const rela_r2d2_actor* a, int which);
 const float* rela_r2d2_actor_last_priority_dev(const rela_r2d2_actor* a);

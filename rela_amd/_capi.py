@@ -94,6 +94,7 @@ _sig("rela_lstmnet_create", i32, [P(vp), i32, i32])
 _sig("rela_lstmnet_destroy", None, [vp])
 _sig("rela_lstmnet_load", i32, [vp, P(LSTMNetParams), i32, vp])
 _sig("rela_lstmnet_num_action", i32, [vp])
+_sig("rela_lstmnet_version", C.c_uint64, [vp])
 _sig("rela_lstmnet_workspace_bytes", i64, [vp, i32])
 _sig("rela_lstmnet_step", i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp])
 _sig("rela_apex_act_from_q", i32, [i32, i32, i32, vp, vp, vp, u64, u64, vp, vp])
@@ -115,6 +116,7 @@ _sig("rela_r2d2_actor_obs_slot", vp, [vp])
 _sig("rela_r2d2_actor_act", i32, [vp, vp, vp, vp, vp, vp, P(vp), vp])
 _sig("rela_r2d2_actor_post_step", i32, [vp, vp, vp, vp, vp, i32, P(i32), vp])
 _sig("rela_r2d2_actor_num_act", i64, [vp])
+_sig("rela_r2d2_actor_set_reuse", i32, [vp, i32])
 _sig("rela_r2d2_actor_hidden_dev", vp, [vp, i32])
 _sig("rela_r2d2_actor_last_priority_dev", vp, [vp])
 _sig("rela_apex_learner_create", i32, [P(vp), i32, i32, i32, f32, i32, f32, f32, f32, i32])

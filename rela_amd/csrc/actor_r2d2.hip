@@ -194,8 +194,14 @@ struct rela_r2d2_actor {
   uint8_t* term = nullptr;
   float *hist_h = nullptr, *hist_c = nullptr;  // [n+1][R][512]
   float *hid_h = nullptr, *hid_c = nullptr, *tmp_h = nullptr, *tmp_c = nullptr;  // [R][512]
-  float *eps = nullptr, *legal = nullptr;
+  float *eps = nullptr, *legal = nullptr;          // current values (uploaded / written by the caller)
+  float *eps_hist = nullptr, *legal_hist = nullptr;  // [n+1][R], [n+1][R][A]: snapshots per history slot
   float* q = nullptr;  // [4][R][A]: adv(act), q_online, adv_next, q_target
+  // weights and history slot the advantages in q[0] (written by act) belong to
+  const rela_lstmnet* q_net = nullptr;
+  uint64_t q_version = 0;
+  int q_slot = -1;
+  bool reuse_act_step = true;
   float *out_r = nullptr, *out_b = nullptr, *prio_step = nullptr;
   uint8_t* out_t = nullptr;
   Windows w{};
@@ -263,6 +269,8 @@ extern "C" int rela_r2d2_actor_create(rela_r2d2_actor** out, int rows, int group
   RELA_ALLOC(a->tmp_c, R * kHid * sizeof(float));
   RELA_ALLOC(a->eps, R * sizeof(float));
   RELA_ALLOC(a->legal, R * A * sizeof(float));
+  RELA_ALLOC(a->eps_hist, H * R * sizeof(float));
+  RELA_ALLOC(a->legal_hist, H * R * A * sizeof(float));
   RELA_ALLOC(a->q, 4 * R * A * sizeof(float));
   RELA_ALLOC(a->out_r, R * sizeof(float));
   RELA_ALLOC(a->out_b, R * sizeof(float));
@@ -313,7 +321,7 @@ extern "C" void rela_r2d2_actor_destroy(rela_r2d2_actor* a) {
   DeviceGuard g(a->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {a->obs,   a->act,    a->rew,    a->term,      a->hist_h, a->hist_c, a->hid_h,  a->hid_c,  a->tmp_h,
-                a->tmp_c, a->eps,    a->legal,  a->q,         a->out_r,  a->out_b,  a->prio_step, a->out_t, a->w.s,
+                a->tmp_c, a->eps,    a->legal,  a->eps_hist, a->legal_hist, a->q,         a->out_r,  a->out_b,  a->prio_step, a->out_t, a->w.s,
                 a->w.eps, a->w.legal, a->w.a,   a->w.reward,  a->w.term, a->w.boot, a->w.prio, a->w.h0,   a->w.c0,
                 a->w.nh0, a->w.nc0,  a->prow,   a->lens,      a->agg,    a->d_slot, a->d_flags, a->d_ranges, a->d_emits, a->d_gather,
                 a->d_envs, a->ws};
@@ -326,6 +334,11 @@ static inline int next_slot(const rela_r2d2_actor* a) { return (a->head + a->cou
 
 extern "C" void* rela_r2d2_actor_obs_slot(rela_r2d2_actor* a) {
   return a ? a->obs + (size_t)next_slot(a) * a->R * kObs : nullptr;
+}
+extern "C" int rela_r2d2_actor_set_reuse(rela_r2d2_actor* a, int on) {
+  RELA_CHECK(a, RELA_EINVAL, "rela_r2d2_actor_set_reuse: bad arguments");
+  a->reuse_act_step = on != 0;
+  return RELA_OK;
 }
 extern "C" int64_t rela_r2d2_actor_num_act(const rela_r2d2_actor* a) { return a ? a->num_act.load() : 0; }
 extern "C" const float* rela_r2d2_actor_hidden_dev(const rela_r2d2_actor* a, int which) {
@@ -351,14 +364,21 @@ extern "C" int rela_r2d2_actor_act(rela_r2d2_actor* a, const rela_lstmnet* onlin
   // historyHidden_.push_back(hidden_) :226-228
   RELA_HIP(hipMemcpyAsync(a->hist_h + (size_t)slot * R * kHid, a->hid_h, HB, hipMemcpyDeviceToDevice, s));
   RELA_HIP(hipMemcpyAsync(a->hist_c + (size_t)slot * R * kHid, a->hid_c, HB, hipMemcpyDeviceToDevice, s));
-  int rc = rela_lstmnet_step(online, a->R, obs, a->legal, a->hid_h, a->hid_c, a->tmp_h, a->tmp_c, nullptr, a->q, a->ws,
+  float* eps_s = a->eps_hist + (size_t)slot * R;
+  float* legal_s = a->legal_hist + (size_t)slot * R * a->A;
+  RELA_HIP(hipMemcpyAsync(eps_s, a->eps, R * sizeof(float), hipMemcpyDeviceToDevice, s));
+  RELA_HIP(hipMemcpyAsync(legal_s, a->legal, R * a->A * sizeof(float), hipMemcpyDeviceToDevice, s));
+  int rc = rela_lstmnet_step(online, a->R, obs, legal_s, a->hid_h, a->hid_c, a->tmp_h, a->tmp_c, nullptr, a->q, a->ws,
                              a->ws_bytes, s);
   if (rc != RELA_OK) return rc;
   std::swap(a->hid_h, a->tmp_h);  // hidden_ <- new state :241
   std::swap(a->hid_c, a->tmp_c);
   int64_t* act = a->act + (size_t)slot * R;
-  rc = rela_apex_act_from_q(a->R, a->A, a->K, a->q, a->legal, a->eps, a->seed, a->act_calls * (uint64_t)a->R, act, s);
+  rc = rela_apex_act_from_q(a->R, a->A, a->K, a->q, legal_s, eps_s, a->seed, a->act_calls * (uint64_t)a->R, act, s);
   if (rc != RELA_OK) return rc;
+  a->q_net = online;
+  a->q_version = rela_lstmnet_version(online);
+  a->q_slot = slot;
   a->act_calls += 1;
   a->cur = slot;
   a->num_act += a->R;
@@ -416,18 +436,27 @@ extern "C" int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward
   const float *h_t = a->hist_h + (size_t)first * R * kHid, *c_t = a->hist_c + (size_t)first * R * kHid;
   const float *h_n = a->hist_h + (size_t)last * R * kHid, *c_n = a->hist_c + (size_t)last * R * kHid;
   const size_t QA = R * a->A;
+  const float* legal_t = a->legal_hist + (size_t)first * R * a->A;
+  const float* legal_n = a->legal_hist + (size_t)last * R * a->A;
+  const float* eps_t = a->eps_hist + (size_t)first * R;
   // compute_priority  r2d2.py:76-100
-  rc = rela_lstmnet_step(online, a->R, obs_t, a->legal, h_t, c_t, a->tmp_h, a->tmp_c, a->q + QA, nullptr, a->ws,
+  rc = rela_lstmnet_step(online, a->R, obs_t, legal_t, h_t, c_t, a->tmp_h, a->tmp_c, a->q + QA, nullptr, a->ws,
                          a->ws_bytes, s);  // online_net(obs, hid) :89
   if (rc != RELA_OK) return rc;
-  rc = rela_lstmnet_step(online, a->R, obs_n, a->legal, h_n, c_n, a->tmp_h, a->tmp_c, nullptr, a->q + 2 * QA, a->ws,
-                         a->ws_bytes, s);  // online_net.act(next_obs, next_hid) :91
-  if (rc != RELA_OK) return rc;
-  rc = rela_lstmnet_step(target, a->R, obs_n, a->legal, h_n, c_n, a->tmp_h, a->tmp_c, a->q + 3 * QA, nullptr, a->ws,
+  // online_net.act(next_obs, next_hid) :91 is the very step act() ran on this tick (same frames, same
+  // recurrent state, same legal mask): with unchanged weights its advantages in q[0] are reused
+  const float* adv_next = a->q;
+  if (!(a->reuse_act_step && a->q_net == online && a->q_version == rela_lstmnet_version(online) && a->q_slot == last)) {
+    rc = rela_lstmnet_step(online, a->R, obs_n, legal_n, h_n, c_n, a->tmp_h, a->tmp_c, nullptr, a->q + 2 * QA, a->ws,
+                           a->ws_bytes, s);
+    if (rc != RELA_OK) return rc;
+    adv_next = a->q + 2 * QA;
+  }
+  rc = rela_lstmnet_step(target, a->R, obs_n, legal_n, h_n, c_n, a->tmp_h, a->tmp_c, a->q + 3 * QA, nullptr, a->ws,
                          a->ws_bytes, s);  // target_net(next_obs, next_hid, next_action) :93
   if (rc != RELA_OK) return rc;
   const int64_t* act_t = a->act + (size_t)first * R;
-  rc = rela_apex_td_from_q(a->R, a->A, a->K, a->q + QA, a->q + 2 * QA, a->q + 3 * QA, a->legal, act_t, a->out_r, a->out_b,
+  rc = rela_apex_td_from_q(a->R, a->A, a->K, a->q + QA, adv_next, a->q + 3 * QA, legal_n, act_t, a->out_r, a->out_b,
                            a->gamma_n, nullptr, a->prio_step, s);
   if (rc != RELA_OK) return rc;
 
@@ -438,7 +467,7 @@ extern "C" int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward
   if (rc != RELA_OK) return rc;
   RELA_HIP(hipMemcpyAsync(a->d_slot, plan.write_slot.data(), R * sizeof(int32_t), hipMemcpyHostToDevice, s));
   RELA_HIP(hipMemcpyAsync(a->d_flags, plan.flags.data(), R, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(r2d2_write_step, dim3(a->R), dim3(kT), 0, s, a->w, a->d_slot, a->d_flags, obs_t, a->eps, a->legal,
+  hipLaunchKernelGGL(r2d2_write_step, dim3(a->R), dim3(kT), 0, s, a->w, a->d_slot, a->d_flags, obs_t, eps_t, legal_t,
                      act_t, a->out_r, a->out_t, a->out_b, a->prio_step, h_t, c_t);
   RELA_LAUNCH_CHECK();
   rc = upload_ranges(a, plan.tail_pad, s);

@@ -994,6 +994,7 @@ struct rela_lstmnet {
   float* Bl = nullptr;   // lstm frags [128][912][64]
   float* bl = nullptr;   // b_ih + b_hh, permuted [2048]
   bool loaded = false;
+  uint64_t version = 0;  // bumped by every load
 };
 
 namespace {
@@ -1047,6 +1048,7 @@ extern "C" void rela_lstmnet_destroy(rela_lstmnet* n) {
 }
 
 extern "C" int rela_lstmnet_num_action(const rela_lstmnet* n) { return n ? n->num_action : 0; }
+extern "C" uint64_t rela_lstmnet_version(const rela_lstmnet* n) { return n ? n->version : 0; }
 
 extern "C" int64_t rela_lstmnet_workspace_bytes(const rela_lstmnet* n, int batch) {
   (void)n;
@@ -1102,6 +1104,7 @@ extern "C" int rela_lstmnet_load(rela_lstmnet* n, const rela_lstmnet_params* p, 
     (void)hipFree(tmp);
   }
   n->loaded = true;
+  n->version += 1;
   return RELA_OK;
 }
 
