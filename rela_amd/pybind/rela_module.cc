@@ -500,8 +500,17 @@ class ActorCohort {
     for (auto& c : numAct_) c.store(0);
   }
 
+  // R2D2 flavour: the members are R2D2Actors, the shard is a rela_r2d2_actor (r2d2_actor.h:189-353)
+  ActorCohort(std::shared_ptr<ModelLocker> locker, std::shared_ptr<RNNPrioritizedReplay> replay, int multiStep, int K,
+              float gamma, int seqLen, int burnin, int members)
+      : locker_(std::move(locker)), rnnReplay_(std::move(replay)), lstm_(true), seqLen_(seqLen), burnin_(burnin),
+        n_(multiStep), K_(K), gamma_(gamma), T_(members), numAct_(members) {
+    for (auto& c : numAct_) c.store(0);
+  }
+
   ~ActorCohort() {
     rela_apex_actor_destroy(h_);
+    rela_r2d2_actor_destroy(hr_);
     const int dev = locker_->deviceIndex;
     if (compute_) rela_stream_destroy(compute_, dev);
     if (upload_) rela_stream_destroy(upload_, dev);
@@ -518,11 +527,12 @@ class ActorCohort {
     const int A = (int)legal.size(1);
     std::unique_lock<std::mutex> lk(m_);
     if (draining_) return drained();
-    if (!h_) create(A);
+    if (!created_) create(A);
     // this member's rows: frames go straight to the HBM history slot on the upload stream,
     // the per-env constants to the host staging (uploaded by the leader when they changed)
     auto sc = s.contiguous();
-    check(rela_memcpy_h2d_async(static_cast<uint8_t*>(rela_apex_actor_obs_slot(h_)) + (int64_t)member * K_ * kObsBytes,
+    void* slot = lstm_ ? rela_r2d2_actor_obs_slot(hr_) : rela_apex_actor_obs_slot(h_);
+    check(rela_memcpy_h2d_async(static_cast<uint8_t*>(slot) + (int64_t)member * K_ * kObsBytes,
                                 sc.data_ptr(), (int64_t)K_ * kObsBytes, upload_, locker_->deviceIndex),
           "rela_memcpy_h2d_async");
     keepObs_[member] = sc;
@@ -538,12 +548,14 @@ class ActorCohort {
     rendezvous(lk, [&] {
       check(rela_stream_wait_stream(compute_, upload_, locker_->deviceIndex), "rela_stream_wait_stream");
       auto lease = locker_->getModel();
-      const int rc = rela_apex_actor_act(h_, static_cast<const rela_ffnet*>(lease.online), nullptr,
-                                         constsDirty_ ? epsAll_.data_ptr<float>() : nullptr,
-                                         constsDirty_ ? legalAll_.data_ptr<float>() : nullptr,
-                                         actionAll_.data_ptr<int64_t>(), nullptr, compute_);
+      const float* e = constsDirty_ ? epsAll_.data_ptr<float>() : nullptr;
+      const float* l = constsDirty_ ? legalAll_.data_ptr<float>() : nullptr;
+      const int rc = lstm_ ? rela_r2d2_actor_act(hr_, static_cast<const rela_lstmnet*>(lease.online), nullptr, e, l,
+                                                 actionAll_.data_ptr<int64_t>(), nullptr, compute_)
+                           : rela_apex_actor_act(h_, static_cast<const rela_ffnet*>(lease.online), nullptr, e, l,
+                                                 actionAll_.data_ptr<int64_t>(), nullptr, compute_);
       locker_->releaseModel(lease.id);
-      check(rc, "DQNActor.act (batched)");
+      check(rc, lstm_ ? "R2D2Actor.act (batched)" : "DQNActor.act (batched)");
       constsDirty_ = false;
       constsValid_ = true;
     });
@@ -556,7 +568,7 @@ class ActorCohort {
     auto rf = r.to(torch::kFloat32).contiguous();
     auto tb = t.to(torch::kBool).contiguous();
     std::lock_guard<std::mutex> lk(m_);
-    if (!h_ || draining_) return;
+    if (!created_ || draining_) return;
     std::memcpy(rewardAll_.data_ptr<float>() + (int64_t)member * K_, rf.data_ptr(), (size_t)K_ * sizeof(float));
     std::memcpy(terminalAll_.data_ptr<bool>() + (int64_t)member * K_, tb.data_ptr(), (size_t)K_);
   }
@@ -564,15 +576,19 @@ class ActorCohort {
   void postStep(int member) {
     (void)member;
     std::unique_lock<std::mutex> lk(m_);
-    if (!h_ || draining_) return;
+    if (!created_ || draining_) return;
     rendezvous(lk, [&] {
       auto lease = locker_->getModel();
-      const int rc = rela_apex_actor_post_step(h_, rewardAll_.data_ptr<float>(),
-                                               reinterpret_cast<const uint8_t*>(terminalAll_.data_ptr<bool>()), 0,
-                                               static_cast<const rela_ffnet*>(lease.online),
-                                               static_cast<const rela_ffnet*>(lease.target), 0, nullptr, compute_);
+      const uint8_t* term = reinterpret_cast<const uint8_t*>(terminalAll_.data_ptr<bool>());
+      const int rc =
+          lstm_ ? rela_r2d2_actor_post_step(hr_, rewardAll_.data_ptr<float>(), term,
+                                            static_cast<const rela_lstmnet*>(lease.online),
+                                            static_cast<const rela_lstmnet*>(lease.target), 0, nullptr, compute_)
+                : rela_apex_actor_post_step(h_, rewardAll_.data_ptr<float>(), term, 0,
+                                            static_cast<const rela_ffnet*>(lease.online),
+                                            static_cast<const rela_ffnet*>(lease.target), 0, nullptr, compute_);
       locker_->releaseModel(lease.id);
-      if (rc != RELA_EWOULDBLOCK) check(rc, "DQNActor.postStep (batched)");  // dropped block after shutdown
+      if (rc != RELA_EWOULDBLOCK) check(rc, "postStep (batched)");  // dropped block after shutdown
       // The next round's frames land in the history slot this tick just read (the ring reuses
       // slot `head`): uploads must start after the tick's queued kernels and row copies.
       check(rela_stream_wait_stream(upload_, compute_, locker_->deviceIndex), "rela_stream_wait_stream");
@@ -580,7 +596,10 @@ class ActorCohort {
   }
 
   void shutdown() {
-    replay_->shutdown();
+    if (lstm_)
+      rnnReplay_->shutdown();
+    else
+      replay_->shutdown();
     std::lock_guard<std::mutex> lk(m_);
     draining_ = true;
     cv_.notify_all();
@@ -618,15 +637,27 @@ class ActorCohort {
   TensorDict drained() { return TensorDict{{"a", torch::zeros({K_}, torch::kInt64)}}; }
 
   void create(int A) {
-    if (locker_->kind() != ModelLocker::kFF)
-      throw std::runtime_error("DQNActor needs an AtariFFNet-shaped agent in its ModelLocker");
+    if (locker_->kind() != (lstm_ ? ModelLocker::kLSTM : ModelLocker::kFF))
+      throw std::runtime_error(lstm_ ? "R2D2Actor needs an AtariLSTMNet-shaped agent in its ModelLocker"
+                                     : "DQNActor needs an AtariFFNet-shaped agent in its ModelLocker");
     const int dev = locker_->deviceIndex;
     static std::atomic<uint64_t> counter{0};
-    rela_replay* rep = replay_->handle(dev, A);
     check(rela_stream_create(&compute_, dev), "rela_stream_create");
     check(rela_stream_create(&upload_, dev), "rela_stream_create");
-    check(rela_apex_actor_create(&h_, T_ * K_, K_, A, n_, gamma_, rep, 0xA24BAED4963EE407ull * (++counter), dev),
-          "rela_apex_actor_create");
+    if (lstm_) {
+      // one pop of the shard commits the sequences of all members as ONE block, in row (= member)
+      // order; the reference would issue one block per thread (only the float block-sum grouping of
+      // sum_ differs, far below the fp tolerance of the priorities themselves)
+      rela_replay* rep = rnnReplay_->handle(dev, A, burnin_ + seqLen_ + n_);
+      check(rela_r2d2_actor_create(&hr_, T_ * K_, K_, A, n_, gamma_, seqLen_, burnin_, locker_->eta(), rep,
+                                   0xC2B2AE3D27D4EB4Full * (++counter), dev),
+            "rela_r2d2_actor_create");
+    } else {
+      rela_replay* rep = replay_->handle(dev, A);
+      check(rela_apex_actor_create(&h_, T_ * K_, K_, A, n_, gamma_, rep, 0xA24BAED4963EE407ull * (++counter), dev),
+            "rela_apex_actor_create");
+    }
+    created_ = true;
     auto pin = [](torch::Tensor t) { return torch::cuda::is_available() ? t.pin_memory() : t; };
     const int64_t R = (int64_t)T_ * K_;
     actionAll_ = pin(torch::zeros({R}, torch::kInt64));
@@ -639,10 +670,15 @@ class ActorCohort {
 
   std::shared_ptr<ModelLocker> locker_;
   std::shared_ptr<FFPrioritizedReplay> replay_;
+  std::shared_ptr<RNNPrioritizedReplay> rnnReplay_;
+  const bool lstm_ = false;
+  const int seqLen_ = 0, burnin_ = 0;
   const int n_, K_;
   const float gamma_;
   const int T_;
   rela_apex_actor* h_ = nullptr;
+  rela_r2d2_actor* hr_ = nullptr;
+  bool created_ = false;
   void *compute_ = nullptr, *upload_ = nullptr;
   torch::Tensor actionAll_, epsAll_, legalAll_, rewardAll_, terminalAll_;
   std::vector<torch::Tensor> keepObs_;
@@ -801,12 +837,35 @@ class R2D2Actor : public Actor {
     if (stream_) rela_stream_destroy(stream_, locker_->deviceIndex);
   }
 
-  int numAct() const { return h_ ? (int)rela_r2d2_actor_num_act(h_) : 0; }
+  int numAct() const {
+    if (cohort_) return cohort_->numAct(member_);
+    return h_ ? (int)rela_r2d2_actor_num_act(h_) : 0;
+  }
+  // batching key: actors that agree on all of these may share one device shard
+  bool trainable() const { return replay_ != nullptr; }
+  const void* lockerKey() const { return locker_.get(); }
+  const void* replayKey() const { return replay_.get(); }
+  int batchsize() const { return batchsize_; }
+  int multiStep() const { return multiStep_; }
+  float gamma() const { return gamma_; }
+  int seqLen() const { return seqLen_; }
+  int burnin() const { return burnin_; }
+  std::shared_ptr<ModelLocker> locker() const { return locker_; }
+  std::shared_ptr<RNNPrioritizedReplay> replay() const { return replay_; }
+  void joinCohort(std::shared_ptr<ActorCohort> c, int member) {
+    cohort_ = std::move(c);
+    member_ = member;
+  }
+  void onLoopExit() override {
+    if (cohort_) cohort_->leave(member_);
+  }
   void onShutdown() override {
+    if (cohort_) cohort_->shutdown();
     if (replay_) replay_->shutdown();
   }
 
   TensorDict act(TensorDict& obs) override {
+    if (cohort_) return cohort_->act(member_, obs);
     const auto& s = obs.at("s");
     const auto& legal = obs.at("legal_move");
     const auto& eps = obs.at("eps");
@@ -854,12 +913,14 @@ class R2D2Actor : public Actor {
 
   void setRewardAndTerminal(torch::Tensor& r, torch::Tensor& t) override {
     if (!replay_) throw std::runtime_error("R2D2Actor: evaluation actor has no replay");
+    if (cohort_) return cohort_->setRewardAndTerminal(member_, r, t);
     reward_ = r.to(torch::kFloat32).contiguous();
     terminal_ = t.to(torch::kBool).contiguous();
   }
 
   void postStep() override {
     if (!replay_) throw std::runtime_error("R2D2Actor: evaluation actor has no replay");
+    if (cohort_) return cohort_->postStep(member_);
     auto lease = locker_->getModel();
     const int rc = rela_r2d2_actor_post_step(h_, reward_.data_ptr<float>(),
                                              reinterpret_cast<const uint8_t*>(terminal_.data_ptr<bool>()),
@@ -879,6 +940,8 @@ class R2D2Actor : public Actor {
   void* stream_ = nullptr;
   torch::Tensor action_, epsHost_, legalHost_, reward_, terminal_;
   bool constsValid_ = false;
+  std::shared_ptr<ActorCohort> cohort_;  // set when this actor is batched with its siblings
+  int member_ = -1;
 };
 
 // =====================================================================================
@@ -997,20 +1060,18 @@ class Context {
   bool terminated() { return done_.load() == (int)loops_.size(); }
 
  private:
-  // Training DQNActors of this context that share (locker, replay, K, n, gamma) are batched into
-  // one device shard (ActorCohort); a lone actor keeps its private shard.  RELA_NO_COHORT=1 opts out.
-  void formCohorts() {
-    if (const char* off = std::getenv("RELA_NO_COHORT"))
-      if (off[0] == '1') return;
-    std::vector<std::vector<std::shared_ptr<DQNActor>>> buckets;
+  // Training DQNActors (R2D2Actors) of this context that share (locker, replay, K, n, gamma[, seq_len,
+  // burn_in]) are batched into one device shard (ActorCohort); a lone actor keeps its private shard.
+  // RELA_NO_COHORT=1 opts out.
+  template <class ActorT, class Same, class Make>
+  void formCohortsOf(Same same, Make make) {
+    std::vector<std::vector<std::shared_ptr<ActorT>>> buckets;
     for (auto& l : loops_) {
-      auto a = std::dynamic_pointer_cast<DQNActor>(l->actor());
+      auto a = std::dynamic_pointer_cast<ActorT>(l->actor());
       if (!a || !a->trainable()) continue;
       bool placed = false;
       for (auto& b : buckets) {
-        auto& f = b.front();
-        if (f->lockerKey() == a->lockerKey() && f->replayKey() == a->replayKey() && f->batchsize() == a->batchsize() &&
-            f->multiStep() == a->multiStep() && f->gamma() == a->gamma()) {
+        if (same(*b.front(), *a)) {
           b.push_back(a);
           placed = true;
           break;
@@ -1020,11 +1081,32 @@ class Context {
     }
     for (auto& b : buckets) {
       if (b.size() < 2) continue;
-      auto& f = b.front();
-      auto cohort = std::make_shared<ActorCohort>(f->locker(), f->replay(), f->multiStep(), f->batchsize(), f->gamma(),
-                                                  (int)b.size());
+      auto cohort = make(*b.front(), (int)b.size());
       for (size_t i = 0; i < b.size(); ++i) b[i]->joinCohort(cohort, (int)i);
     }
+  }
+
+  void formCohorts() {
+    if (const char* off = std::getenv("RELA_NO_COHORT"))
+      if (off[0] == '1') return;
+    formCohortsOf<DQNActor>(
+        [](const DQNActor& f, const DQNActor& a) {
+          return f.lockerKey() == a.lockerKey() && f.replayKey() == a.replayKey() && f.batchsize() == a.batchsize() &&
+                 f.multiStep() == a.multiStep() && f.gamma() == a.gamma();
+        },
+        [](const DQNActor& f, int members) {
+          return std::make_shared<ActorCohort>(f.locker(), f.replay(), f.multiStep(), f.batchsize(), f.gamma(), members);
+        });
+    formCohortsOf<R2D2Actor>(
+        [](const R2D2Actor& f, const R2D2Actor& a) {
+          return f.lockerKey() == a.lockerKey() && f.replayKey() == a.replayKey() && f.batchsize() == a.batchsize() &&
+                 f.multiStep() == a.multiStep() && f.gamma() == a.gamma() && f.seqLen() == a.seqLen() &&
+                 f.burnin() == a.burnin();
+        },
+        [](const R2D2Actor& f, int members) {
+          return std::make_shared<ActorCohort>(f.locker(), f.replay(), f.multiStep(), f.batchsize(), f.gamma(),
+                                               f.seqLen(), f.burnin(), members);
+        });
   }
 
   bool started_ = false;

@@ -182,3 +182,69 @@ def test_eval_path_runs_one_episode_per_thread(mods):
         v.append(synth.SyntheticAtariEnv(1, 0.0, 18, 5))
         v.append(synth.SyntheticAtariEnv(2, 0.0, 18, 5))
         rela.BasicThreadLoop(rela.DQNActor(locker), v, True)  # eval loops drive exactly one env
+
+
+def test_r2d2_cohort_batches_threads_consistently(mods):
+    """Two R2D2Actor threads batched into one device shard (ActorCohort, LSTM flavour): the threads run
+    in lock-step, and every sampled sequence is self-consistent -- unrolling the PyTorch AtariLSTMNet
+    from the stored h0 over the stored frames reproduces the stored (greedy, eps = 0) actions at every
+    valid step, i.e. each env kept its own recurrent state and window inside the shared shard."""
+    import time
+
+    import torch
+
+    from e2e_lockstep import CFG_R2D2, load_lstm_agent_params
+    from rela_amd.pyrela.net import AtariLSTMNet
+    from rela_amd.pyrela.r2d2 import R2D2Agent
+
+    rela, synth = mods
+    C = CFG_R2D2
+    T, K, A = 2, 4, C["num_action"]
+    seq_len, burn, n = 8, 4, 3
+    agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, A), "cpu", n, C["gamma"], C["eta"], seq_len, burn, 0)
+    load_lstm_agent_params(agent)
+    gpu_agent = R2D2Agent.clone(agent, "cuda:0")
+    replay = rela.RNNPrioritizedReplay(32, 3, 0.9, 0.6, 0)
+    locker = rela.ModelLocker([agent], "cuda:0")
+    ctx = rela.Context()
+    actors = []
+    for t in range(T):
+        vec = rela.VectorEnv()
+        for g in range(K):
+            vec.append(synth.SyntheticAtariEnv(300 + t * K + g, 0.0, A, 23))
+        actor = rela.R2D2Actor(locker, n, K, C["gamma"], seq_len, burn, replay)
+        actors.append(actor)
+        ctx.push_env_thread(rela.BasicThreadLoop(actor, vec, False))
+    ctx.start()
+    t0 = time.time()
+    while replay.size() < 24 and time.time() - t0 < 120:
+        time.sleep(0.01)
+    assert replay.size() >= 24
+    assert actors[0].num_act() == actors[1].num_act() > 0  # lock-step: one shard, one tick for both threads
+    B = 6
+    for _ in range(3):
+        batch, w = replay.sample(B, "cuda:0")
+        s = batch.obs["s"]                      # [T, B, 4, 84, 84]
+        legal = batch.obs["legal_move"]         # [T, B, A]
+        with torch.no_grad():
+            o, _ = gpu_agent.online_net.unroll_rnn({"s": s}, {"h0": batch.h0["h0"], "c0": batch.h0["c0"]})
+            adv = gpu_agent.online_net.fc_a(o)
+            greedy = ((1 + adv - adv.min()) * legal).argmax(2)
+        a = batch.action["a"]
+        L = batch.seq_len.long()
+        assert (L >= 1).all() and (L <= burn + seq_len).all()
+        for b in range(B):
+            lb = int(L[b])
+            assert torch.equal(greedy[:lb, b].cpu(), a[:lb, b].cpu()), "sequence %d deviates from its own unroll" % b
+        assert torch.isfinite(w).all()
+        replay.update_priority(torch.ones(B))
+        time.sleep(0.1)
+    ctx.terminate()
+    ctx.resume()
+    t0 = time.time()
+    while not ctx.terminated():
+        if replay.size() >= B:
+            batch, w = replay.sample(B, "cuda:0")
+            replay.update_priority(torch.ones(B))
+        time.sleep(0.005)
+        assert time.time() - t0 < 120
