@@ -379,6 +379,16 @@ void launch_conv(const float* in, const float* Bfrag, const float* bias, float* 
                        out, N);
 }
 
+// gemm_mfma block height: makespan estimate = rounds over the CUs x rows per block; 112-row blocks win
+// when they save a round (fc at N = 6400: 232 blocks in one round instead of 400 in two)
+inline bool prefer_bm112(int N, int colgroups, int bm_default) {
+  auto cost = [&](int bm) {
+    const int64_t blocks = (int64_t)ceil_div(N, bm) * colgroups;
+    return ((blocks + kNumCU - 1) / kNumCU) * bm;
+  };
+  return cost(112) < cost(bm_default);
+}
+
 // ---- conv1 on bf16 MFMA, exact-weight split ------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -539,14 +549,19 @@ struct GemmCfg {
   static constexpr int NCH = K / KC;
   static constexpr int KS = K / 4;
   static constexpr int LDA = 34;
-  static constexpr int VPT = BM * KC / 4 / kThreads;  // float4 per thread per chunk
+  static constexpr int V4 = BM * KC / 4;                       // float4 per chunk
+  static constexpr int VPT = (V4 + kThreads - 1) / kThreads;  // per thread (the last one may be partial)
 };
 
+// Block height is picked per launch (launch_gemm_rows below): 400 half-height fc blocks at N = 6400 sit
+// two-deep on 144 CUs and one-deep on 112; 232 blocks of 112 rows fill one round.
 using GemmFc = GemmCfg<3136, 512, 64, kEpiBiasRelu>;
+using GemmFc112 = GemmCfg<3136, 512, 112, kEpiBiasRelu>;
 using GemmHeads = GemmCfg<512, 32, 128, kEpiBias>;
 // LSTM gates: [x(3136) | h(512)] x [3648][2048]; columns permuted to 4*unit + gate (i,f,g,o) so the
 // four gates of a hidden unit sit in four adjacent lanes of one accumulator tile.
 using GemmLstm = GemmCfg<3648, 2048, 128, kEpiLstmCell, 3136>;
+using GemmLstm112 = GemmCfg<3648, 2048, 112, kEpiLstmCell, 3136>;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -569,6 +584,7 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma(const float* __restrict__ 
 #pragma unroll
     for (int v = 0; v < G::VPT; ++v) {
       const int idx = tid + v * kThreads;
+      if (G::V4 % kThreads != 0 && idx >= G::V4) break;
       const int r = idx >> 3, q = idx & 7;  // KC/4 == 8 float4 per row
       const int row = row0 + r;
       const int k = ch * G::KC + q * 4;
@@ -581,6 +597,7 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma(const float* __restrict__ 
 #pragma unroll
     for (int v = 0; v < G::VPT; ++v) {
       const int idx = tid + v * kThreads;
+      if (G::V4 % kThreads != 0 && idx >= G::V4) break;
       const int r = idx >> 3, q = idx & 7;
       float* d = &sA[buf][r * G::LDA + q * 4];
       *reinterpret_cast<float2*>(d) = make_float2(stage[v].x, stage[v].y);
@@ -965,9 +982,14 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
                        (const float*)d.bf, h);
   } else {
     ProfScope prof(names[3], s);
-    hipLaunchKernelGGL(gemm_mfma<GemmFc>, dim3(GemmFc::CT / GemmFc::CTB, ceil_div(N, GemmFc::BM)), dim3(kThreads), 0, s,
-                       (const float*)a3, (const float*)nullptr, (const float*)d.Bf, (const float*)d.bf, h,
-                       (const float*)nullptr, (float*)nullptr, N);
+    if (prefer_bm112(N, GemmFc::CT / GemmFc::CTB, GemmFc::BM))
+      hipLaunchKernelGGL(gemm_mfma<GemmFc112>, dim3(GemmFc112::CT / GemmFc112::CTB, ceil_div(N, GemmFc112::BM)),
+                         dim3(kThreads), 0, s, (const float*)a3, (const float*)nullptr, (const float*)d.Bf,
+                         (const float*)d.bf, h, (const float*)nullptr, (float*)nullptr, N);
+    else
+      hipLaunchKernelGGL(gemm_mfma<GemmFc>, dim3(GemmFc::CT / GemmFc::CTB, ceil_div(N, GemmFc::BM)), dim3(kThreads), 0,
+                         s, (const float*)a3, (const float*)nullptr, (const float*)d.Bf, (const float*)d.bf, h,
+                         (const float*)nullptr, (float*)nullptr, N);
   }
   {
     ProfScope prof(names[4], s);
@@ -1140,9 +1162,14 @@ extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_
   }
   {
     ProfScope prof("lstm_gates_mfma", s);
-    hipLaunchKernelGGL(gemm_mfma<GemmLstm>, dim3(GemmLstm::CT / GemmLstm::CTB, ceil_div(N, GemmLstm::BM)),
-                       dim3(kThreads), 0, s, (const float*)a3, h_in, (const float*)n->Bl, (const float*)n->bl, h_out,
-                       c_in, c_out, N);
+    if (prefer_bm112(N, GemmLstm::CT / GemmLstm::CTB, GemmLstm::BM))
+      hipLaunchKernelGGL(gemm_mfma<GemmLstm112>, dim3(GemmLstm112::CT / GemmLstm112::CTB, ceil_div(N, GemmLstm112::BM)),
+                         dim3(kThreads), 0, s, (const float*)a3, h_in, (const float*)n->Bl, (const float*)n->bl, h_out,
+                         c_in, c_out, N);
+    else
+      hipLaunchKernelGGL(gemm_mfma<GemmLstm>, dim3(GemmLstm::CT / GemmLstm::CTB, ceil_div(N, GemmLstm::BM)),
+                         dim3(kThreads), 0, s, (const float*)a3, h_in, (const float*)n->Bl, (const float*)n->bl, h_out,
+                         c_in, c_out, N);
   }
   if (q_dev || adv_dev) {
     {
