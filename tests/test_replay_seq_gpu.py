@@ -63,3 +63,67 @@ def test_three_phase_append_and_time_major_gather():
     np.testing.assert_array_equal(out_plain.cpu().numpy(), plain[ids])
     np.testing.assert_allclose(w.cpu().numpy(), ow, rtol=4e-7)
     capi.lib.rela_replay_destroy(h)
+
+
+def test_gathered_row_write_matches_per_row_writes():
+    """rela_replay_write_rows_gather (one launch per field for any number of rows, arbitrary source
+    rows and destination offsets, wrap-around of the ring) stores exactly what per-row
+    rela_replay_write_rows calls store."""
+    import torch
+
+    from gpu_util import cur_stream
+    from rela_amd import _capi as capi
+
+    T, E = 4, 32
+    rng = np.random.default_rng(1)
+    src_seq = torch.from_numpy(rng.integers(0, 256, (20, T * E), dtype=np.uint8)).cuda()   # 20 candidate rows
+    src_plain = torch.from_numpy(rng.integers(0, 256, (20, 12), dtype=np.uint8)).cuda()    # not 16-byte rows
+    prio = torch.from_numpy(rng.uniform(0.1, 2, 16).astype(np.float32)).cuda()
+    results = []
+    for gathered in (False, True):
+        h = C.c_void_p()
+        capi.check(capi.lib.rela_replay_create(C.byref(h), 8, 3, 1.0, 1.0, 0, 0), "create")  # ring = 10
+        rb = (C.c_int64 * 2)(T * E, 12)
+        st = (C.c_int32 * 2)(T, 1)
+        capi.check(capi.lib.rela_replay_set_schema_seq(h, 2, rb, st), "schema")
+        slot = C.c_int()
+        # first block fills 7 of the 10 ring slots, second block (after a sample pops nothing) wraps around
+        for blk, (n, pick_seq, pick_plain) in enumerate([(7, [3, 19, 0, 7, 7, 12, 5], [1, 2, 3, 4, 5, 6, 0])]):
+            capi.check(capi.lib.rela_replay_begin_add(h, n, 0, C.byref(slot)), "begin")
+            order = [4, 0, 6, 2, 1, 5, 3]  # destination offsets in scrambled order
+            if gathered:
+                dst = torch.tensor(order, dtype=torch.int32).cuda()
+                i_seq = torch.tensor([pick_seq[o] for o in order], dtype=torch.int32).cuda()
+                i_plain = torch.tensor([pick_plain[o] for o in order], dtype=torch.int32).cuda()
+                bases = (C.c_void_p * 2)(src_seq.data_ptr(), src_plain.data_ptr())
+                idx = (C.c_void_p * 2)(i_seq.data_ptr(), i_plain.data_ptr())
+                capi.check(capi.lib.rela_replay_write_rows_gather(h, slot.value, n, C.c_void_p(dst.data_ptr()), bases,
+                                                                  idx, cur_stream()), "gather")
+            else:
+                for o in order:
+                    rows = (C.c_void_p * 2)(src_seq[pick_seq[o]].data_ptr(), src_plain[pick_plain[o]].data_ptr())
+                    capi.check(capi.lib.rela_replay_write_rows(h, slot.value, o, 1, rows, cur_stream()), "write")
+            capi.check(capi.lib.rela_replay_commit_add(h, slot.value, n, C.c_void_p(prio.data_ptr()), cur_stream()),
+                       "commit")
+        B = 8
+        out_seq = torch.empty((T, B, E), dtype=torch.uint8, device="cuda")
+        out_plain = torch.empty((B, 12), dtype=torch.uint8, device="cuda")
+        w = torch.empty(B, device="cuda")
+        outs = (C.c_void_p * 2)(out_seq.data_ptr(), out_plain.data_ptr())
+        capi.check(capi.lib.rela_replay_sample(h, B, outs, C.c_void_p(w.data_ptr()), cur_stream()), "sample")
+        torch.cuda.synchronize()
+        st_ = capi.ReplayState()
+        ids = np.zeros(B, np.int32)
+        capi.check(capi.lib.rela_replay_debug_state(h, C.byref(st_), ids.ctypes.data_as(C.c_void_p), None, None), "dbg")
+        results.append((ids.copy(), out_seq.cpu().numpy().copy(), out_plain.cpu().numpy().copy(), w.cpu().numpy().copy()))
+        # the stored rows are the picked source rows
+        seq_np, plain_np = src_seq.cpu().numpy(), src_plain.cpu().numpy()
+        for b in range(B):
+            q = int(ids[b])  # slot == destination offset (first block starts at slot 0)
+            assert np.array_equal(out_seq.cpu().numpy()[:, b, :].reshape(-1), seq_np[[3, 19, 0, 7, 7, 12, 5][q]])
+            assert np.array_equal(out_plain.cpu().numpy()[b], plain_np[[1, 2, 3, 4, 5, 6, 0][q]])
+        capi.lib.rela_replay_update_priority(h, B, C.c_void_p(w.data_ptr()), 1, cur_stream())
+        torch.cuda.synchronize()
+        capi.lib.rela_replay_destroy(h)
+    for a, b in zip(results[0], results[1]):
+        assert np.array_equal(a, b)
