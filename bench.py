@@ -58,6 +58,30 @@ def generate_eps(base_eps, alpha, num_actor):
     return [base_eps ** (1 + i / (num_actor - 1) * alpha) for i in range(num_actor)]
 
 
+def cpu_baseline_reference(seconds=12.0):
+    """The REAL reference's CPU-thread actor path (oracle/_ref/rela*.so, compiled from the reference's
+    sources where they exist; only the built module travels) timed on this box's host cores by
+    oracle/ref_actor_bench.py in a child process.  None if the prebuilt module is absent or fails."""
+    import glob
+
+    if not glob.glob(os.path.join(ROOT, "oracle", "_ref", "rela*.so")):
+        return None
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_actor_bench.py"), "--threads", str(cores),
+                              "--games", "20", "--seconds", str(seconds), "--warmup", "4", "--num_action",
+                              str(NUM_ACTION)], env=env, capture_output=True, text=True, timeout=180)
+        rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    except Exception:  # noqa: BLE001  (any failure -> fall back to the port)
+        return None
+    return {"value": rec["env_steps_per_s"], "unit": "env-steps/s", "cores": cores, "kind": "reference",
+            "sample": "the reference's own C++ actor threads (oracle/_ref/rela, g++ -O2) with a CPU TorchScript Ape-X "
+                      "agent: %d threads x %d synthetic envs, OMP_NUM_THREADS=1, A=%d, n=3, %.1f s window after 4 s "
+                      "warm-up, light B=32 sampler evicting the overflow (pyrela/benchmark.py protocol)"
+                      % (rec["threads"], rec["games"], rec["num_action"], rec["seconds"])}
+
+
 def cpu_baseline(budget_s=15.0):
     """The oracle (plain-C port of the same path) timed on this box's host cores: one actor tick
     (act + n-step + TD priority + replay insert) over a bounded number of envs."""
@@ -416,7 +440,11 @@ def main():
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            port = cpu_baseline()
+            ref = cpu_baseline_reference()
+            out["cpu_baseline"] = ref if ref is not None else port
+            if ref is not None:
+                out["cpu_baseline"]["port"] = {k: port[k] for k in ("value", "cores", "sample")}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
