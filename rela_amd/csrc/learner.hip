@@ -605,10 +605,8 @@ extern "C" int rela_apex_learner_backward(rela_apex_learner* l, int batch, const
 
   const FFNetWs w = ffnet_ws(l->ws_on, Bn);
   const rela_ffnet_params P = params_at(l, l->P);
-  const rela_ffnet_params G = params_at(l, l->G);
-  float* Gm[12];
+  float* Gm[12];  // gradient tensors in rela_ffnet_params order
   for (int i = 0; i < 12; ++i) Gm[i] = l->G + l->off[i];
-  (void)G;
 
   auto colsum = [&](const float* src, int64_t rows, int C, float* out) {
     ProfScope prof("learner_colsum", s);
