@@ -384,6 +384,9 @@ const float* rela_apex_learner_stats_dev(const rela_apex_learner* l);
  * (pyrela/common_utils/stopwatch.py:17-54).
  * =================================================================================== */
 int rela_prof_enable(int on);
+/* time only the named kernels (comma-separated; NULL or "" = all): keeps the events' own cost out
+ * of a timed region that only needs the dominant kernel                                        */
+int rela_prof_set_filter(const char* names);
 /* synchronises the device; writes {"kernel":{"count":n,"total_ms":t},...} and clears */
 int rela_prof_summary_json(char* out, int64_t cap);
 

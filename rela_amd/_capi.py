@@ -130,6 +130,7 @@ _sig("rela_apex_learner_grads", i32, [vp, P(FFNetParams)])
 _sig("rela_apex_learner_flat", i32, [vp, P(vp), P(vp), P(i64)])
 _sig("rela_apex_learner_stats_dev", vp, [vp])
 _sig("rela_prof_enable", i32, [i32])
+_sig("rela_prof_set_filter", i32, [C.c_char_p])
 _sig("rela_prof_summary_json", i32, [C.c_char_p, i64])
 
 
