@@ -287,6 +287,83 @@ def r2d2agg_cases():
     save("r2d2_aggregate", [], out)
 
 
+def _r2d2_batch(seed, A, B, seq, burn, n):
+    """Deterministic RNNTransition-shaped batch ([T,B,...], types.cc:140-182) with consistent padding:
+    sequence b has seq_len L_b; its train-part terminals are 1 from step L_b - burn - 1 on
+    (r2d2.py:169-173 asserts exactly this); sequence 0 starts an episode (dummy burn-in)."""
+    import types
+
+    import torch
+
+    T = burn + seq + n
+    rng = np.random.default_rng(seed)
+    s = synth_obs(T * B, seed + 1).reshape(T, B, 4, 84, 84)
+    legal = (rng.uniform(size=(T, B, A)) < 0.85).astype(np.float32)
+    legal[:, :, 0] = 1.0
+    lens = np.array([burn + seq, burn + 3, burn + seq - 1][:B], np.float32)
+    term = np.zeros((T, B), np.float32)
+    for b in range(B):
+        first = burn + int(lens[b]) - burn - 1
+        if lens[b] < burn + seq:
+            term[first:, b] = 1.0
+    term[:burn, 0] = 1.0  # padLike'd burn-in of an episode start (r2d2_actor.h:55-66)
+    boot = (1.0 - np.maximum.reduce([np.roll(term, -k, 0) for k in range(n)])).astype(np.float32)
+    boot[T - n:] = 0.0
+    action = np.zeros((T, B), np.int64)
+    for t in range(T):
+        for b in range(B):
+            action[t, b] = rng.choice(np.flatnonzero(legal[t, b]))
+    reward = rng.normal(0, 1.2, (T, B)).astype(np.float32)
+    h0 = rng.normal(0, 0.3, (1, B, 512)).astype(np.float32)
+    c0 = rng.normal(0, 0.3, (1, B, 512)).astype(np.float32)
+    weight = rng.uniform(0.2, 1.0, B).astype(np.float32)
+    tt = torch.from_numpy
+    batch = types.SimpleNamespace(
+        obs={"s": tt(s), "legal_move": tt(legal), "eps": torch.zeros(T, B, 1)}, h0={"h0": tt(h0), "c0": tt(c0)},
+        action={"a": tt(action)}, reward=tt(reward), terminal=tt(term).bool(), bootstrap=tt(boot), seq_len=tt(lens))
+    meta = dict(legal=legal.tolist(), action=action.tolist(), reward=reward.tolist(), terminal=term.tolist(),
+                bootstrap=boot.tolist(), seq_len=lens.tolist(), weight=weight.tolist(), obs_seed=seed + 1,
+                h0=[f2h(v) for v in h0.reshape(-1)], c0=[f2h(v) for v in c0.reshape(-1)])
+    return batch, tt(weight), meta
+
+
+def r2d2loss_cases():
+    """R2D2Agent.loss of the REAL reference (pyrela/r2d2.py:122-206) + the backward of
+    (loss * weight).mean() (pyrela/main.py:226-229) on one small batch, CPU."""
+    import types
+
+    sys.dont_write_bytecode = True
+    sys.modules.setdefault("tensorboardX", types.ModuleType("tensorboardX"))
+    sys.modules["tensorboardX"].SummaryWriter = object
+    sys.path.insert(0, "/root/reference/pyrela")
+    import torch
+    from net import AtariLSTMNet
+    from r2d2 import R2D2Agent
+    from synth import synth_lstm_params
+
+    torch.set_num_threads(4)
+    A, B, seq, burn, n, gamma, eta = 6, 3, 6, 2, 2, 0.997, 0.9
+    agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, A), "cpu", n, gamma, eta, seq, burn, 0)
+    sd = {}
+    for prefix, seed in (("online_net.", 5005), ("target_net.", 6006)):
+        for k, v in synth_lstm_params(A, seed).items():
+            sd[prefix + k] = torch.from_numpy(v)
+    agent.load_state_dict(sd)
+    batch, weight, meta = _r2d2_batch(51, A, B, seq, burn, n)
+    loss, priority = agent.loss(batch)
+    (loss * weight).mean().backward()
+    named = dict(agent.online_net.named_parameters())
+    grads = {}
+    for k, v in named.items():
+        t = v.grad.detach().double().reshape(-1)
+        idx = np.random.default_rng(7).integers(0, t.numel(), 32)
+        grads[k] = {"l2": float(t.norm()), "absmax": float(t.abs().max()), "idx": idx.tolist(),
+                    "val": t[torch.from_numpy(idx)].tolist()}
+    save("r2d2_loss_A6_B3", [], [], num_action=A, B=B, seq_len=seq, burn_in=burn, multi_step=n, gamma=gamma, eta=eta,
+         online_seed=5005, target_seed=6006, batch=meta, loss=loss.detach().double().tolist(),
+         priority=priority.double().tolist(), grads=grads)
+
+
 def e2e_cases():
     """The REAL reference end to end: its pybind module (oracle/_ref/rela*.so), its TorchScript
     ApexAgent on the CPU, our synthetic env compiled against its rela/env.h."""
@@ -359,3 +436,5 @@ if __name__ == "__main__":
         ffnet_cases()
     if "learner" in which:
         learner_cases()
+    if "r2d2loss" in which:
+        r2d2loss_cases()

@@ -98,3 +98,52 @@ def test_aggregate_priority_matches_reference():
         lib.oracle_r2d2_aggregate(len(lens), case["seq_len"], case["burn_in"], case["eta"], vp(prio), vp(lens), vp(out))
         ref = np.array([h2f(v) for v in case["agg"]], np.float32)
         np.testing.assert_allclose(out, ref, rtol=2e-7, atol=0)  # torch sums pairwise; the oracle left to right
+
+
+def test_r2d2_learner_loss_matches_reference_golden():
+    """rela_amd/pyrela/r2d2.py (R2D2Agent.td_err / loss / aggregate_priority, the learner side of SURVEY
+    rows N2/G2) against vectors recorded from the REAL reference's R2D2Agent on CPU
+    (tests/golden/make_golden.py r2d2loss: loss per sequence, aggregated priority, and the gradients of
+    (loss * weight).mean() w.r.t. every online parameter), including a padded short sequence and a
+    sequence that starts an episode (zeroed state after the dummy burn-in)."""
+    import sys
+    from types import SimpleNamespace
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from rela_amd.pyrela.net import AtariLSTMNet
+    from rela_amd.pyrela.r2d2 import R2D2Agent
+    from synth import synth_lstm_params, synth_obs
+
+    g = json.load(open(os.path.join(GOLD, "r2d2_loss_A6_B3.json")))
+    A, B, seq, burn, n = g["num_action"], g["B"], g["seq_len"], g["burn_in"], g["multi_step"]
+    T = burn + seq + n
+    torch.set_num_threads(4)
+    agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, A), "cpu", n, g["gamma"], g["eta"], seq, burn, 0)
+    sd = {}
+    for prefix, seed in (("online_net.", g["online_seed"]), ("target_net.", g["target_seed"])):
+        for k, v in synth_lstm_params(A, seed).items():
+            sd[prefix + k] = torch.from_numpy(v)
+    agent.load_state_dict(sd)
+    m = g["batch"]
+    f32 = lambda x: torch.tensor(x, dtype=torch.float32)
+    hid = lambda key: torch.tensor([h2f(v) for v in m[key]], dtype=torch.float32).reshape(1, B, 512)
+    batch = SimpleNamespace(
+        obs={"s": torch.from_numpy(synth_obs(T * B, m["obs_seed"]).reshape(T, B, 4, 84, 84)),
+             "legal_move": f32(m["legal"]), "eps": torch.zeros(T, B, 1)},
+        h0={"h0": hid("h0"), "c0": hid("c0")}, action={"a": torch.tensor(m["action"], dtype=torch.int64)},
+        reward=f32(m["reward"]), terminal=f32(m["terminal"]).bool(), bootstrap=f32(m["bootstrap"]),
+        seq_len=f32(m["seq_len"]))
+    loss, prio = agent.loss(batch)
+    np.testing.assert_allclose(loss.detach().numpy(), np.array(g["loss"]), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(prio.numpy(), np.array(g["priority"]), rtol=1e-4, atol=1e-5)
+    (loss * f32(m["weight"])).mean().backward()
+    named = dict(agent.online_net.named_parameters())
+    assert set(named) == set(g["grads"])
+    for key, rec in g["grads"].items():
+        t = named[key].grad.detach().double().reshape(-1)
+        scale = rec["absmax"] + 1e-12
+        np.testing.assert_allclose(float(t.norm()), rec["l2"], rtol=1e-3, atol=1e-4 * scale, err_msg=key)
+        np.testing.assert_allclose(t[torch.tensor(rec["idx"])].numpy(), np.array(rec["val"]), rtol=1e-3,
+                                   atol=1e-3 * scale, err_msg=key)
