@@ -457,6 +457,13 @@ def main():
             "kernels_ms_per_step_note": "untimed pass of %d steps with every kernel timed; the timed region times "
                                         "only conv1/conv2/conv3/fc (roofline)" % k_all,
             "roofline": roof,
+            # the HBM-bound side of the path: the replay insert copies obs and next_obs rows (read + write)
+            "roofline_hbm": (lambda ms: None if ms <= 0 else {
+                "kernel": "replay_scatter_rows", "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
+                "achieved": ROWS * 2 * 28224 * 2 / (ms * 1e-3) / 1e9,
+                "frac": ROWS * 2 * 28224 * 2 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "algorithmic_bytes_per_step": ROWS * 2 * 28224 * 2, "ms_per_step": ms})(
+                    prof_all.get("replay_scatter_rows", {"total_ms": 0.0})["total_ms"] / k_all),
         }
         if world == 1 and not args.no_cpu_baseline:
             port = cpu_baseline()

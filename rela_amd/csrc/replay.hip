@@ -147,6 +147,40 @@ __global__ __launch_bounds__(kThreads) void replay_scatter_rows(const uint8_t* _
   }
 }
 
+// Fields whose rows are a few bytes (eps, legal_move, a, reward, terminal, bootstrap: 4..72 B) are moved
+// by ONE launch for all of them: a thread owns one row and walks the small fields (1 MB in total per
+// 6,400-row block; what mattered was eight launches per insert / per sample, not the bytes).
+constexpr int kSmallRowBytes = 256;
+constexpr int kMaxSmallFields = 12;
+struct SmallFields {
+  const uint8_t* src[kMaxSmallFields];
+  uint8_t* dst[kMaxSmallFields];
+  int32_t row_bytes[kMaxSmallFields];
+  int32_t n;
+};
+__device__ __forceinline__ void copy_small(uint8_t* __restrict__ d, const uint8_t* __restrict__ s, int nbytes) {
+  if (((nbytes | (int)(uintptr_t)d | (int)(uintptr_t)s) & 3) == 0) {
+    for (int i = 0; i < nbytes; i += 4) *reinterpret_cast<uint32_t*>(d + i) = *reinterpret_cast<const uint32_t*>(s + i);
+  } else {
+    for (int i = 0; i < nbytes; ++i) d[i] = s[i];
+  }
+}
+__global__ void replay_scatter_small(SmallFields t, int n, int ring, int start) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const int64_t slot = ((int64_t)start + row) % ring;
+  for (int f = 0; f < t.n; ++f)
+    copy_small(t.dst[f] + slot * t.row_bytes[f], t.src[f] + (int64_t)row * t.row_bytes[f], t.row_bytes[f]);
+}
+// src = ring fields, dst = batch outputs: out[b] = field[ids[b]]
+__global__ void replay_gather_small(SmallFields t, const int32_t* __restrict__ ids, int batch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const int64_t slot = ids[b];
+  for (int f = 0; f < t.n; ++f)
+    copy_small(t.dst[f] + (int64_t)b * t.row_bytes[f], t.src[f] + slot * t.row_bytes[f], t.row_bytes[f]);
+}
+
 // indexed form: row r comes from source row src_idx[r] and goes to slot start + dst_off[r]
 __global__ __launch_bounds__(kThreads) void replay_scatter_rows_indexed(const uint8_t* __restrict__ src,
                                                                         const int32_t* __restrict__ src_idx,
@@ -505,9 +539,17 @@ extern "C" int rela_replay_write_rows(rela_replay* r, int first_slot, int offset
   // continue only after its rows were consumed
   RELA_HIP(hipEventRecord(r->ev_in, producer));
   RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
+  SmallFields small{};
   for (size_t f = 0; f < r->d_fields.size(); ++f) {
     if (!rows_dev[f]) continue;
     const int64_t rb = r->row_bytes[f];
+    if (rb <= kSmallRowBytes && small.n < kMaxSmallFields) {
+      small.src[small.n] = (const uint8_t*)rows_dev[f];
+      small.dst[small.n] = r->d_fields[f];
+      small.row_bytes[small.n] = (int32_t)rb;
+      small.n += 1;
+      continue;
+    }
     const int v16 = vec16_ok(rows_dev[f], r->d_fields[f], rb);
     const int64_t units = v16 ? (rb >> 4) : rb;
     int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (units + kThreads - 1) / kThreads), 64);
@@ -516,6 +558,11 @@ extern "C" int rela_replay_write_rows(rela_replay* r, int first_slot, int offset
       hipLaunchKernelGGL(replay_scatter_rows, dim3(gx, std::min(count, 32768)), dim3(kThreads), 0, r->stream,
                          (const uint8_t*)rows_dev[f], r->d_fields[f], rb, count, r->ring, start, v16);
     }
+  }
+  if (small.n > 0) {
+    ProfScope prof("replay_scatter_small", r->stream);
+    hipLaunchKernelGGL(replay_scatter_small, dim3(ceil_div(count, 256)), dim3(256), 0, r->stream, small, count, r->ring,
+                       start);
   }
   RELA_LAUNCH_CHECK();
   RELA_HIP(hipEventRecord(r->ev_out, r->stream));
@@ -648,10 +695,18 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
                        r->d_state, out_weight_dev);
   }
   if (out_rows_dev) {
+    SmallFields small{};
     for (size_t f = 0; f < r->d_fields.size(); ++f) {
       if (!out_rows_dev[f]) continue;
       const int64_t rb = r->row_bytes[f];
       const int st = r->steps[f];
+      if (st == 1 && rb <= kSmallRowBytes && small.n < kMaxSmallFields) {
+        small.src[small.n] = r->d_fields[f];
+        small.dst[small.n] = (uint8_t*)out_rows_dev[f];
+        small.row_bytes[small.n] = (int32_t)rb;
+        small.n += 1;
+        continue;
+      }
       const int64_t sub = rb / st;
       const int v16 = vec16_ok(out_rows_dev[f], r->d_fields[f], sub) && (rb % 16 == 0);
       const int64_t units = v16 ? (sub >> 4) : sub;
@@ -661,6 +716,11 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
         hipLaunchKernelGGL(replay_gather_rows, dim3(gx, batch * st), dim3(kThreads), 0, r->stream, r->d_fields[f],
                            r->d_ids, (uint8_t*)out_rows_dev[f], rb, st, batch, v16);
       }
+    }
+    if (small.n > 0) {
+      ProfScope prof("replay_gather_small", r->stream);
+      hipLaunchKernelGGL(replay_gather_small, dim3(ceil_div(batch, 256)), dim3(256), 0, r->stream, small,
+                         (const int32_t*)r->d_ids, batch);
     }
   }
   RELA_LAUNCH_CHECK();
