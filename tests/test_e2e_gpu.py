@@ -248,3 +248,30 @@ def test_r2d2_cohort_batches_threads_consistently(mods):
             replay.update_priority(torch.ones(B))
         time.sleep(0.005)
         assert time.time() - t0 < 120
+
+
+def test_r2d2_eval_path_runs_one_episode_per_thread(mods):
+    """The evaluation constructor R2D2Actor(locker) (r2d2_actor.h:208-215): batch 1, no replay, recurrent
+    state carried over the episode; scores are deterministic at eps = 0."""
+    import torch
+
+    from rela_amd.pyrela import create_env
+    from rela_amd.pyrela.eval import evaluate
+    from rela_amd.pyrela.net import AtariLSTMNet
+    from rela_amd.pyrela.r2d2 import R2D2Agent
+    from synth import synth_lstm_params
+
+    rela, synth = mods
+    A = create_env.get_num_action("synthetic")  # the eval env factory's action count
+    agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, A), "cpu", 3, 0.997, 0.9, 8, 4, 0)
+    sd = {}
+    for prefix, seed in (("online_net.", 31), ("target_net.", 32)):
+        for k, v in synth_lstm_params(A, seed).items():
+            sd[prefix + k] = torch.from_numpy(v)
+    agent.load_state_dict(sd)
+    locker = rela.ModelLocker([agent], "cuda:0")
+    score = evaluate(3, locker, rela.R2D2Actor, seed=9, episode_len=17, eval_eps=0.0)
+    assert -17.0 <= score <= 17.0
+    assert evaluate(3, locker, rela.R2D2Actor, seed=9, episode_len=17, eval_eps=0.0) == score
+    ev = rela.R2D2Actor(locker)
+    assert ev.num_act() == 0
