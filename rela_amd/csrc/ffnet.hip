@@ -461,6 +461,8 @@ __global__ __launch_bounds__(kThreads) void conv1_bf16x3(const uint8_t* __restri
   // Tried in round 1 without gain (157 us either way): a register double buffer for the weight fragments
   // (146 VGPRs: loses the second block per CU, 206 us) and staging them per k-step through LDS.  The kernel
   // moves 511 MB per 6,400 samples (3.2 TB/s), most of it the f32 output in 64-byte partial rows.
+  // A persistent weight-stationary form (96 weight registers + 52 accumulators per wave, double-buffered
+  // u8 tile) spills under the 256-register budget and measured 357-431 us.
 #pragma unroll 1
   for (int ks = 0; ks < C::KS; ++ks) {
     const int koff = (ks >> 1) * 84 * 84 + (ks & 1) * 4 * 84;
