@@ -131,6 +131,10 @@ int rela_replay_last_sample_dev(rela_replay* r, const float** raw_w_dev, const f
  * RELA_EWOULDBLOCK immediately; sample/update keep working.                                  */
 int rela_replay_shutdown(rela_replay* r);
 
+/* capacity and ring size (int(1.25 * capacity), :181).  sample() evicts down to `capacity`, so a
+ * blocking append of more than ring - capacity rows can never be satisfied: producers of large blocks
+ * (the batched actor shards) insert in pieces of at most that many rows.                        */
+int rela_replay_limits(const rela_replay* r, int* capacity, int* ring);
 int rela_replay_size(const rela_replay* r);        /* size()    :245-247 */
 int64_t rela_replay_num_add(const rela_replay* r); /* numAdd()  :251-253 */
 

@@ -210,13 +210,34 @@ extern "C" int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward
   if (rc != RELA_OK) return rc;
   // FFTransition rows (types.h:18-51): obs{s,eps,legal_move}, next_obs{...}, action{a}, reward, terminal, bootstrap
   const void* rows[10] = {obs_t, obs_n, eps_t, eps_n, legal_t, legal_n, act_t, a->out_r, a->out_t, a->out_b};
-  // one reference block per group of K rows (each batched actor thread's own add, :189)
-  int slot = 0;
-  rc = rela_replay_begin_add(a->replay, a->R, nonblocking, &slot);
-  if (rc == RELA_OK) rc = rela_replay_write_rows(a->replay, slot, 0, a->R, rows, s);
-  if (rc == RELA_OK) rc = rela_replay_commit_add_grouped(a->replay, slot, a->R, a->K, a->prio, s);
+  // One reference block per group of K rows (each batched actor thread's own add, :189).  The whole shard
+  // is reserved at once when that can always be satisfied; a blocking append of more than ring - capacity
+  // rows never can (sample() evicts down to capacity only), so a shard that large goes in pieces of whole
+  // K-groups -- which is exactly what the reference's separate actor threads would issue.
+  int cap = 0, ring = 0;
+  rc = rela_replay_limits(a->replay, &cap, &ring);
+  if (rc != RELA_OK) return rc;
+  const int fit = ((ring - cap) / a->K) * a->K;
+  const int piece = a->R <= ring - cap ? a->R : (fit > a->K ? fit : a->K);
+  const int64_t rb[10] = {kObs, kObs, 4, 4, 4 * a->A, 4 * a->A, 8, 4, 1, 4};
+  int dropped = 0;
+  for (int off = 0; off < a->R; off += piece) {
+    const int cnt = a->R - off < piece ? a->R - off : piece;
+    const void* prow[10];
+    for (int f = 0; f < 10; ++f) prow[f] = static_cast<const uint8_t*>(rows[f]) + (int64_t)off * rb[f];
+    int slot = 0;
+    rc = rela_replay_begin_add(a->replay, cnt, nonblocking, &slot);
+    if (rc == RELA_EWOULDBLOCK) {
+      dropped = 1;
+      continue;
+    }
+    if (rc == RELA_OK) rc = rela_replay_write_rows(a->replay, slot, 0, cnt, prow, s);
+    if (rc == RELA_OK) rc = rela_replay_commit_add_grouped(a->replay, slot, cnt, a->K, a->prio + off, s);
+    if (rc != RELA_OK) break;
+  }
   a->head = (a->head + 1) % H;  // pop_front :101-104
   a->count -= 1;
+  if (rc == RELA_OK && dropped) rc = RELA_EWOULDBLOCK;
   if (rc == RELA_OK && inserted) *inserted = 1;
   return rc;
 }

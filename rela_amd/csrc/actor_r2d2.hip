@@ -207,7 +207,7 @@ struct rela_r2d2_actor {
   Windows w{};
   float *prow = nullptr, *lens = nullptr, *agg = nullptr;  // [2R][seq], [2R], [2R]
   int32_t *d_slot = nullptr, *d_ranges = nullptr, *d_emits = nullptr, *d_envs = nullptr;
-  int32_t* d_gather = nullptr;  // [2][2R]: destination offsets q and source envs of one emission batch
+  int32_t* d_gather = nullptr;  // [2][3R]: destination offsets, source envs and emit indices of one batch
   uint8_t* d_flags = nullptr;
   void* ws = nullptr;
   int64_t ws_bytes = 0;
@@ -301,7 +301,7 @@ extern "C" int rela_r2d2_actor_create(rela_r2d2_actor** out, int rows, int group
   RELA_ALLOC(a->d_flags, R);
   RELA_ALLOC(a->d_ranges, 2 * R * 4 * sizeof(int32_t));
   RELA_ALLOC(a->d_emits, 2 * R * 3 * sizeof(int32_t));
-  RELA_ALLOC(a->d_gather, 2 * R * 2 * sizeof(int32_t));
+  RELA_ALLOC(a->d_gather, 2 * R * 3 * sizeof(int32_t));
   RELA_ALLOC(a->d_envs, R * sizeof(int32_t));
 #undef RELA_ALLOC
   a->ws_bytes = rela_lstmnet_workspace_bytes(nullptr, rows);
@@ -482,53 +482,77 @@ extern "C" int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward
     hipLaunchKernelGGL(r2d2_aggregate, dim3(ceil_div(nseq, 64)), dim3(64), 0, s, a->prow, a->lens, nseq, a->seq, a->burn,
                        a->eta, a->one_minus_eta, a->agg);
     RELA_LAUNCH_CHECK();
-    int slot0 = 0;
-    rc = rela_replay_begin_add(a->replay, nseq, nonblocking, &slot0);
-    if (rc == RELA_OK) {
-      const Windows& w = a->w;
-      // all sequences of one kind leave in ONE gathered write per field: destination offset q, source
+    // A pop of a large shard can exceed what a blocking append can ever get (ring - capacity slots:
+    // sample() evicts down to capacity only).  The pop therefore goes in pieces of at most that many
+    // sequences, cut at env boundaries (an env's second, short sequence directly follows its first):
+    // reserve, write the first sequences, carry those envs' windows, write their second sequences, commit.
+    int cap = 0, ring = 0;
+    rc = rela_replay_limits(a->replay, &cap, &ring);
+    if (rc != RELA_OK) return rc;
+    const int max_block = ring - cap > 1 ? ring - cap : 1;
+    const Windows& w = a->w;
+    int inserted = 0, dropped = 0;
+    size_t ci = 0, pi = 0;  // cursors into carry_env / carry_pad (both ascending in env)
+    for (int q0 = 0; q0 < nseq && rc == RELA_OK;) {
+      int q1 = nseq - q0 <= max_block ? nseq : q0 + max_block;
+      if (q1 < nseq && plan.emits[q1].second) q1 = (q1 - 1 > q0) ? q1 - 1 : q1 + 1;  // keep a pair together
+      const int cnt = q1 - q0;
+      const int env_hi = plan.emits[q1 - 1].env;
+      std::vector<int32_t> carry;
+      while (ci < plan.carry_env.size() && plan.carry_env[ci] <= env_hi) carry.push_back(plan.carry_env[ci++]);
+      std::vector<SeqRange> pads;
+      while (pi < plan.carry_pad.size() && plan.carry_pad[pi].env <= env_hi) pads.push_back(plan.carry_pad[pi++]);
+      auto carry_piece = [&]() -> int {
+        if (carry.empty()) return RELA_OK;
+        RELA_HIP(hipMemcpyAsync(a->d_envs, carry.data(), carry.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(r2d2_carry, dim3((unsigned)carry.size()), dim3(kT), 0, s, a->w, a->d_envs);
+        RELA_LAUNCH_CHECK();
+        return upload_ranges(a, pads, s);
+      };
+      int slot0 = 0;
+      rc = rela_replay_begin_add(a->replay, cnt, nonblocking, &slot0);
+      if (rc == RELA_EWOULDBLOCK) {
+        // dropped piece: the windows must still advance exactly as if it had been stored
+        dropped = 1;
+        rc = carry_piece();
+        q0 = q1;
+        continue;
+      }
+      if (rc != RELA_OK) break;
+      // all sequences of one kind leave in ONE gathered write per field: destination offset q - q0, source
       // row = the env's window (lens is indexed by q itself)
       auto emit_batch = [&](bool second) -> int {
-        std::vector<int32_t> qs, envs;
-        for (int q = 0; q < nseq; ++q)
+        std::vector<int32_t> dst, envs, qs;
+        for (int q = q0; q < q1; ++q)
           if ((plan.emits[q].second != 0) == second) {
-            qs.push_back(q);
+            dst.push_back(q - q0);
             envs.push_back(plan.emits[q].env);
+            qs.push_back(q);
           }
-        const int cnt = (int)qs.size();
-        if (cnt == 0) return RELA_OK;
-        int32_t* d_q = a->d_gather + (second ? 2 * (size_t)a->R : 0);
-        int32_t* d_e = d_q + cnt;
-        std::vector<int32_t> both(qs);
-        both.insert(both.end(), envs.begin(), envs.end());
-        // pageable source: the call returns only after the staging copy, so `both` may die
-        RELA_HIP(hipMemcpyAsync(d_q, both.data(), both.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        const int m = (int)dst.size();
+        if (m == 0) return RELA_OK;
+        int32_t* d_dst = a->d_gather + (second ? 3 * (size_t)a->R : 0);
+        int32_t* d_env = d_dst + m;
+        int32_t* d_q = d_env + m;
+        std::vector<int32_t> all(dst);
+        all.insert(all.end(), envs.begin(), envs.end());
+        all.insert(all.end(), qs.begin(), qs.end());
+        // pageable source: the call returns only after the staging copy, so `all` may die
+        RELA_HIP(hipMemcpyAsync(d_dst, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
         const void* bases[10] = {w.s, w.eps, w.legal, w.a, w.reward, w.term, w.boot, w.h0, w.c0, a->lens};
-        const int32_t* idx[10] = {d_e, d_e, d_e, d_e, d_e, d_e, d_e, d_e, d_e, d_q};
-        return rela_replay_write_rows_gather(a->replay, slot0, cnt, d_q, bases, idx, s);
+        const int32_t* idx[10] = {d_env, d_env, d_env, d_env, d_env, d_env, d_env, d_env, d_env, d_q};
+        return rela_replay_write_rows_gather(a->replay, slot0, m, d_dst, bases, idx, s);
       };
       rc = emit_batch(false);
-      if (rc == RELA_OK && !plan.carry_env.empty()) {
-        RELA_HIP(hipMemcpyAsync(a->d_envs, plan.carry_env.data(), plan.carry_env.size() * sizeof(int32_t),
-                                hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(r2d2_carry, dim3((unsigned)plan.carry_env.size()), dim3(kT), 0, s, a->w, a->d_envs);
-        RELA_LAUNCH_CHECK();
-        rc = upload_ranges(a, plan.carry_pad, s);
-      }
+      if (rc == RELA_OK) rc = carry_piece();
       if (rc == RELA_OK) rc = emit_batch(true);
-      if (rc == RELA_OK) rc = rela_replay_commit_add(a->replay, slot0, nseq, a->agg, s);
-      if (rc == RELA_OK && n_sequences) *n_sequences = nseq;
-    } else if (rc == RELA_EWOULDBLOCK) {
-      // dropped block: the windows must still advance exactly as if it had been stored
-      if (!plan.carry_env.empty()) {
-        RELA_HIP(hipMemcpyAsync(a->d_envs, plan.carry_env.data(), plan.carry_env.size() * sizeof(int32_t),
-                                hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(r2d2_carry, dim3((unsigned)plan.carry_env.size()), dim3(kT), 0, s, a->w, a->d_envs);
-        RELA_LAUNCH_CHECK();
-        int rc2 = upload_ranges(a, plan.carry_pad, s);
-        if (rc2 != RELA_OK) return rc2;
-      }
+      if (rc == RELA_OK) rc = rela_replay_commit_add(a->replay, slot0, cnt, a->agg + q0, s);
+      if (rc == RELA_OK) inserted += cnt;
+      q0 = q1;
     }
+    if (rc != RELA_OK) return rc;
+    if (n_sequences) *n_sequences = inserted;
+    if (dropped) rc = RELA_EWOULDBLOCK;
     if (rc != RELA_OK && rc != RELA_EWOULDBLOCK) return rc;
   }
   a->head = (a->head + 1) % H;  // multiStepBuffer_ / historyHidden_ pop_front :283-286

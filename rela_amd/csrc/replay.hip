@@ -787,6 +787,13 @@ extern "C" int rela_replay_size(const rela_replay* r) {
 
 extern "C" int64_t rela_replay_num_add(const rela_replay* r) { return r ? r->num_add.load() : 0; }
 
+extern "C" int rela_replay_limits(const rela_replay* r, int* capacity, int* ring) {
+  RELA_CHECK(r, RELA_EINVAL, "rela_replay_limits: bad arguments");
+  if (capacity) *capacity = r->capacity;
+  if (ring) *ring = r->ring;
+  return RELA_OK;
+}
+
 extern "C" int rela_replay_debug_state(rela_replay* r, rela_replay_state* out, int32_t* ids_host, float* raw_w_host,
                                        float* targets_host) {
   RELA_CHECK(r && out, RELA_EINVAL, "rela_replay_debug_state: bad arguments");

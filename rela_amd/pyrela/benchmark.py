@@ -18,18 +18,27 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 
 from rela_amd.pyrela import create_env, utils  # noqa: E402
 from rela_amd.pyrela.apex import ApexAgent  # noqa: E402
-from rela_amd.pyrela.net import AtariFFNet  # noqa: E402
+from rela_amd.pyrela.net import AtariFFNet, AtariLSTMNet  # noqa: E402
+from rela_amd.pyrela.r2d2 import R2D2Agent  # noqa: E402
 
 rela = create_env.rela
 
 
 def benchmark_fps(num_thread, num_game_per_thread, args):
     num_action = create_env.get_num_action("synthetic")
-    agent = ApexAgent(lambda: AtariFFNet(num_action), 3, 0.99).to(args.device)
-    locker = rela.ModelLocker([agent], args.device)
-    replay_buffer = rela.FFPrioritizedReplay(args.replay_buffer_size, args.seed, 0.6, 0.4, 0)
     eps = utils.generate_eps(0.4, 7, num_thread * num_game_per_thread)
-    make_actor = lambda i: rela.DQNActor(locker, 1, num_game_per_thread, 0.99, replay_buffer)
+    if args.algo == "r2d2":  # not in the reference's benchmark.py; same protocol on the R2D2 classes
+        agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, num_action), "cpu", 3, 0.997, 0.9, args.seq_len, args.seq_burn_in, 0)
+        locker = rela.ModelLocker([agent], args.device)
+        replay_buffer = rela.RNNPrioritizedReplay(args.replay_buffer_size, args.seed, 0.9, 0.6, 0)
+        make_actor = lambda i: rela.R2D2Actor(locker, 3, num_game_per_thread, 0.997, args.seq_len, args.seq_burn_in,
+                                              replay_buffer)
+    else:
+        agent = ApexAgent(lambda: AtariFFNet(num_action), 3, 0.99).to(args.device)
+        locker = rela.ModelLocker([agent], args.device)
+        replay_buffer = rela.FFPrioritizedReplay(args.replay_buffer_size, args.seed, 0.6, 0.4, 0)
+        make_actor = lambda i: rela.DQNActor(locker, 1, num_game_per_thread, 0.99, replay_buffer)
+    batch = 64 if args.algo == "r2d2" else 512
     context, games, actors = create_env.create_train_env(args.seed, eps, args.episode_len, num_thread,
                                                          num_game_per_thread, make_actor)
     context.start()
@@ -45,7 +54,7 @@ def benchmark_fps(num_thread, num_game_per_thread, args):
                 time.sleep(args.epoch_sec)
             else:
                 while time.time() - t0 <= args.epoch_sec:
-                    batch, weight = replay_buffer.sample(512, args.device)
+                    _, weight = replay_buffer.sample(batch, args.device)
                     replay_buffer.update_priority(weight)
                     n_sample += 1
                 torch.cuda.synchronize()  # the loop only enqueues: count what the GPU finished
@@ -57,9 +66,12 @@ def benchmark_fps(num_thread, num_game_per_thread, args):
                 mode, epoch, rates[mode][-1], replay_buffer.size(), n_sample / dt), flush=True)
     context.terminate()
     context.resume()
+    t_drain = time.time()
     while not context.terminated():
-        if replay_buffer.size() >= 512:  # unpark actors blocked on a full ring
-            batch, weight = replay_buffer.sample(512, args.device)
+        if time.time() - t_drain > 120:
+            raise RuntimeError("actor threads did not terminate within 120 s (replay size %d)" % replay_buffer.size())
+        if replay_buffer.size() >= batch:  # unpark actors blocked on a full ring
+            _, weight = replay_buffer.sample(batch, args.device)
             replay_buffer.update_priority(weight)
         time.sleep(0.01)
     half = args.num_epoch // 2
@@ -69,6 +81,9 @@ def benchmark_fps(num_thread, num_game_per_thread, args):
 def main(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--device", default="cuda:0")
+    p.add_argument("--algo", default="apex", help="apex (the reference's benchmark) | r2d2")
+    p.add_argument("--seq_len", type=int, default=80)
+    p.add_argument("--seq_burn_in", type=int, default=40)
     p.add_argument("--seed", type=int, default=10001)
     p.add_argument("--replay_buffer_size", type=int, default=2 ** 21)
     p.add_argument("--burn_in_frames", type=int, default=1000)

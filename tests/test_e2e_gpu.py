@@ -275,3 +275,86 @@ def test_r2d2_eval_path_runs_one_episode_per_thread(mods):
     assert evaluate(3, locker, rela.R2D2Actor, seed=9, episode_len=17, eval_eps=0.0) == score
     ev = rela.R2D2Actor(locker)
     assert ev.num_act() == 0
+
+
+def _run_small_replay(rela, ctx, replay, actors, batch, target_adds, make_priority):
+    """Samples / updates until `target_adds` insertions happened; fails instead of hanging."""
+    import time
+
+    ctx.start()
+    t0 = time.time()
+    while replay.num_add() < target_adds:
+        if replay.size() >= batch:
+            _, w = replay.sample(batch, "cuda:0")
+            replay.update_priority(make_priority(w))
+        time.sleep(0.002)
+        assert time.time() - t0 < 120, "no progress: %d adds, size %d" % (replay.num_add(), replay.size())
+    lockstep = len({a.num_act() for a in actors}) == 1
+    ctx.terminate()
+    ctx.resume()
+    t0 = time.time()
+    while not ctx.terminated():
+        if replay.size() >= batch:
+            _, w = replay.sample(batch, "cuda:0")
+            replay.update_priority(make_priority(w))
+        time.sleep(0.002)
+        assert time.time() - t0 < 120
+    return lockstep
+
+
+def test_cohort_shard_larger_than_ring_slack_inserts_in_pieces(mods):
+    """A batched shard of T*K = 8 rows on a replay whose ring leaves only ring - capacity = 4 free slots
+    once full: one blocking append of 8 rows could never be satisfied (sampling evicts down to capacity
+    only); the shard must insert K-group pieces, as the reference's separate threads would."""
+    import torch
+
+    from e2e_lockstep import CFG, load_agent_params
+    from rela_amd.pyrela.apex import ApexAgent
+    from rela_amd.pyrela.net import AtariFFNet
+
+    rela, synth = mods
+    T, K, A, n = 2, 4, CFG["num_action"], 3
+    agent = load_agent_params(ApexAgent(lambda: AtariFFNet(A), n, 0.997)).to("cuda:0")
+    replay = rela.FFPrioritizedReplay(16, 3, 1.0, 0.4, 0)  # ring 20
+    locker = rela.ModelLocker([agent], "cuda:0")
+    ctx = rela.Context()
+    actors = []
+    for t in range(T):
+        vec = rela.VectorEnv()
+        for g in range(K):
+            vec.append(synth.SyntheticAtariEnv(500 + t * K + g, 0.0, A, 11))
+        actor = rela.DQNActor(locker, n, K, 0.997, replay)
+        actors.append(actor)
+        ctx.push_env_thread(rela.BasicThreadLoop(actor, vec, False))
+    _run_small_replay(rela, ctx, replay, actors, 4, 240, lambda w: torch.ones_like(w))
+    assert replay.num_add() >= 240 and replay.num_add() % K == 0
+
+
+def test_r2d2_cohort_pop_larger_than_ring_slack_inserts_in_pieces(mods):
+    """The same for sequences: 8 envs in one shard, replay capacity 8 (ring 10, 2 free slots once full);
+    pops of up to 8 sequences go in pieces cut at env boundaries."""
+    import torch
+
+    from e2e_lockstep import CFG_R2D2, load_lstm_agent_params
+    from rela_amd.pyrela.net import AtariLSTMNet
+    from rela_amd.pyrela.r2d2 import R2D2Agent
+
+    rela, synth = mods
+    C = CFG_R2D2
+    T, K, A = 2, 4, C["num_action"]
+    seq_len, burn, n = 6, 2, 3
+    agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, A), "cpu", n, C["gamma"], C["eta"], seq_len, burn, 0)
+    load_lstm_agent_params(agent)
+    replay = rela.RNNPrioritizedReplay(8, 3, 0.9, 0.6, 0)  # ring 10
+    locker = rela.ModelLocker([agent], "cuda:0")
+    ctx = rela.Context()
+    actors = []
+    for t in range(T):
+        vec = rela.VectorEnv()
+        for g in range(K):
+            vec.append(synth.SyntheticAtariEnv(600 + t * K + g, 0.0, A, 9 + g))  # staggered episode ends
+        actor = rela.R2D2Actor(locker, n, K, C["gamma"], seq_len, burn, replay)
+        actors.append(actor)
+        ctx.push_env_thread(rela.BasicThreadLoop(actor, vec, False))
+    _run_small_replay(rela, ctx, replay, actors, 2, 120, lambda w: torch.ones_like(w).cpu())
+    assert replay.num_add() >= 120
