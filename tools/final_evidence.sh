@@ -8,6 +8,7 @@
 #   prof_bench/              rocprofv3 --kernel-trace --stats of bench.py
 #   forward_small_n.log      per-kernel forward timings at N = 80 / 512 / 6400
 #   threaded_benchmark.log   rela_amd/pyrela/benchmark.py, 64 threads x 100 envs, replay 2^21
+#   threaded_benchmark_r2d2.log  the same driver with --algo r2d2, 32 threads x 100 envs
 #   r2d2_actor_tick.json     tools/time_r2d2_tick.py, 3200 envs, seq 80 / burn 40 / n 3
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -39,6 +40,8 @@ for n in 80 512 6400; do TAG=N=$n N=$n timeout -k 10 120 python tools/time_forwa
 cat $O/forward_small_n.log
 timeout -k 10 400 python rela_amd/pyrela/benchmark.py --grid 64x100 --epoch_sec 1.5 --num_epoch 4 --replay_buffer_size 2097152 --burn_in_frames 20000 > $O/threaded_benchmark.log 2>&1 || { tail -5 $O/threaded_benchmark.log; exit 9; }
 tail -4 $O/threaded_benchmark.log
+timeout -k 10 300 python rela_amd/pyrela/benchmark.py --algo r2d2 --grid 32x100 --epoch_sec 2 --num_epoch 4 --replay_buffer_size 8192 --burn_in_frames 200 --episode_len 400 > $O/threaded_benchmark_r2d2.log 2>&1 || { tail -5 $O/threaded_benchmark_r2d2.log; exit 11; }
+tail -3 $O/threaded_benchmark_r2d2.log
 ROWS=3200 TICKS=260 timeout -k 10 300 python tools/time_r2d2_tick.py 2> $O/r2d2_actor_tick.err | tail -1 > $O/r2d2_actor_tick.json || exit 10
 cut -c1-300 $O/r2d2_actor_tick.json
 find $O -name "*.csv" -size +8M -delete
