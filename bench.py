@@ -10,16 +10,23 @@ alpha = 0.6, beta = 0.4, learner batch 512 (pyrela/main.py:28-65 defaults).
 
 One STEP = what the reference does per env-step of every actor thread plus one learner update:
   actor tick over 6,400 envs  (rela/thread_loop.h:74-105 -> rela/dqn_actor.h:153-203)
-      act: 1 trunk forward + eps-greedy; post_step: n-step return, TD priority (3 trunk
-      forwards: online(s_t), online(s_t+n), target(s_t+n)), replay insert of 6,400 transitions
+      act: 1 trunk forward + eps-greedy; post_step: n-step return, TD priority from online(s_t),
+      online(s_t+n), target(s_t+n), replay insert of 6,400 transitions.
+      online(s_t+n) is the forward act() just ran on the same observation with the same weights
+      (dqn_actor.h:84,161 + apex.py:41): it is reused bit-identically instead of recomputed, so a tick
+      runs 3 trunk forwards (4 on a tick that straddles a weight publish).  `forwards_per_tick` reports
+      what ran, and `no_reuse` carries the same step measured with the reuse switched off (all 4
+      forwards of the reference).  Nothing else is cached or skipped.
   learner step                (pyrela/main.py:206-251)
       replay.sample(512) [exact sequential-sum scan + gather] -> ApexAgent.loss -> backward
-      -> clip 40 -> RMSprop -> update_priority; actor weights re-published every 20 steps,
-      target net every 2,500.
-Nothing is cached or skipped: all four forwards run every tick (no reuse of act-time Q-values).
+      -> clip 40 -> RMSprop -> update_priority, hand-written HIP (csrc/learner.hip; RELA_BENCH_LEARNER=torch
+      runs PyTorch autograd instead); actor weights re-published every 20 steps, target net every 2,500.
 
 Prints ONE JSON line (rank 0).  `value` = env-steps/s summed over ranks.  Extra keys carry the
-learner rate, the live roofline of the dominant kernel and the CPU baseline (oracle port).
+learner rate, the live roofline of the dominant kernel (HIP events around the heavy forward kernels
+inside the timed region; the full per-kernel table comes from an untimed pass), the HBM-side roofline
+of the replay insert, and the CPU baseline (the reference's own CPU-thread actor path from
+oracle/_ref when present, else the oracle's plain-C port).
 """
 import argparse
 import ctypes as C
