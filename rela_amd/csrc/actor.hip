@@ -4,7 +4,8 @@
 // DQNActor (rela/dqn_actor.h:126-211) and MultiStepTransitionBuffer (:15-124):
 //   act        push (obs, action) :23-29,153-171      -> 1 trunk forward + eps-greedy
 //   post_step  push (r, t) :31-40; canPop :46-48; popTransition :58-106; computePriority :193-203
-//              (3 trunk forwards, apex.py:30-45); replay add :189
+//              (online(s_t), online(s_t+n), target(s_t+n), apex.py:30-45; online(s_t+n) is act()'s own
+//              forward and is reused when the weights are unchanged); replay add :189
 // The deque of :120-123 is a ring of multi_step+1 slots in HBM; "pop_front" is a head increment.
 #include <atomic>
 #include <cmath>

@@ -7,7 +7,8 @@ BasicThreadLoop::mainLoop (rela/thread_loop.h:74-105) makes DQNActor do:
 
   act       (dqn_actor.h:153-171)  Q(obs) -> eps-greedy action                    1 trunk forward
   post_step (dqn_actor.h:181-203)  n-step pop (:58-106) -> TD priority (apex.py:68-78)
-                                   -> replay add (prioritized_replay.h:186-200)   3 trunk forwards
+                                   -> replay add (prioritized_replay.h:186-200)   2 trunk forwards (+1 if the weights
+                                                                                  changed since act(): the third is act's own)
 
 The observation history (n+1 frame stacks per env) lives in HBM, so obs_t / obs_{t+n} are never
 re-uploaded for the priority pass and the replay insert is a device-to-device row copy.
