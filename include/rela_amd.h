@@ -96,6 +96,12 @@ int rela_replay_commit_add(rela_replay* r, int first_slot, int n, const float* p
 int rela_replay_commit_add_grouped(rela_replay* r, int first_slot, int n, int group_rows,
                                    const float* priority_dev, void* stream);
 
+/* Releases a reservation whose producer failed between begin and commit (no reference counterpart:
+ * there an exception on an actor thread ends the process, rela/context.h:39-46).  The n slots are
+ * committed in order with ZERO weight: safe_tail advances so that later blocks can commit, sum_ is
+ * unchanged and a zero-weight slot can never be drawn (:286).                                  */
+int rela_replay_abort_add(rela_replay* r, int first_slot, int n);
+
 /* add(sample, priority)  prioritized_replay.h:186-200 -> blockAppend :43-78.
  * rows_dev[f] points at n consecutive rows of field f (device); priority_dev is f32[n]
  * (device).  Weights are pow(priority, alpha) (:188).  Blocks while the ring cannot take n

@@ -72,6 +72,7 @@ _sig("rela_replay_write_rows", i32, [vp, i32, i32, i32, P(vp), vp])
 _sig("rela_replay_write_rows_gather", i32, [vp, i32, i32, vp, P(vp), P(vp), vp])
 _sig("rela_replay_commit_add", i32, [vp, i32, i32, vp, vp])
 _sig("rela_replay_commit_add_grouped", i32, [vp, i32, i32, i32, vp, vp])
+_sig("rela_replay_abort_add", i32, [vp, i32, i32])
 _sig("rela_replay_add", i32, [vp, i32, P(vp), vp, i32, vp])
 _sig("rela_replay_sample", i32, [vp, i32, P(vp), vp, vp])
 _sig("rela_replay_update_priority", i32, [vp, i32, vp, i32, vp])

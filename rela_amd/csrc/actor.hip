@@ -232,9 +232,13 @@ extern "C" int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward
       dropped = 1;
       continue;
     }
-    if (rc == RELA_OK) rc = rela_replay_write_rows(a->replay, slot, 0, cnt, prow, s);
-    if (rc == RELA_OK) rc = rela_replay_commit_add_grouped(a->replay, slot, cnt, a->K, a->prio + off, s);
     if (rc != RELA_OK) break;
+    rc = rela_replay_write_rows(a->replay, slot, 0, cnt, prow, s);
+    if (rc == RELA_OK) rc = rela_replay_commit_add_grouped(a->replay, slot, cnt, a->K, a->prio + off, s);
+    if (rc != RELA_OK) {  // release the reservation so later blocks of other producers can still commit
+      (void)rela_replay_abort_add(a->replay, slot, cnt);
+      break;
+    }
   }
   a->head = (a->head + 1) % H;  // pop_front :101-104
   a->count -= 1;

@@ -214,6 +214,7 @@ struct rela_r2d2_actor {
   std::vector<uint8_t> h_term;  // [n+1][R] host copy: the bookkeeping needs the flags
   SeqBook* book = nullptr;
   SeqPlan plan;
+  HostStage stage;  // pinned staging of the per-tick index plans (one segment per post_step)
 };
 
 extern "C" int rela_r2d2_actor_create(rela_r2d2_actor** out, int rows, int group_rows, int num_action, int multi_step,
@@ -311,6 +312,10 @@ extern "C" int rela_r2d2_actor_create(rela_r2d2_actor** out, int rows, int group
     RELA_HIP(hipMemcpy(a->legal, ones.data(), R * A * sizeof(float), hipMemcpyHostToDevice));
   }
   a->h_term.assign(H * R, 0);
+  {
+    const int rc = a->stage.init(R * 320 + 4096);
+    RELA_CHECK(rc == RELA_OK, rc, "rela_r2d2_actor_create: pinned staging buffer");
+  }
   a->book = new SeqBook(rows, multi_step, seq_len, burn_in);
   *out = a;
   return RELA_OK;
@@ -326,6 +331,7 @@ extern "C" void rela_r2d2_actor_destroy(rela_r2d2_actor* a) {
                 a->w.nh0, a->w.nc0,  a->prow,   a->lens,      a->agg,    a->d_slot, a->d_flags, a->d_ranges, a->d_emits, a->d_gather,
                 a->d_envs, a->ws};
   for (void* p : ps) (void)hipFree(p);
+  a->stage.destroy();
   delete a->book;
   delete a;
 }
@@ -399,11 +405,10 @@ int upload_ranges(rela_r2d2_actor* a, const std::vector<SeqRange>& rs, hipStream
     flat.insert(flat.end(), {r.env, r.begin, r.end, r.zero_prio});
     maxlen = std::max(maxlen, r.end - r.begin);
   }
-  RELA_HIP(hipMemcpyAsync(a->d_ranges, flat.data(), flat.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  RELA_HIP(a->stage.h2d(a->d_ranges, flat.data(), flat.size() * sizeof(int32_t), s));
   hipLaunchKernelGGL(r2d2_pad, dim3((unsigned)rs.size(), (unsigned)maxlen), dim3(kT), 0, s, a->w, a->d_ranges);
   RELA_LAUNCH_CHECK();
-  // the staging vector dies here: hipMemcpyAsync from pageable memory has already staged it
-  return RELA_OK;
+  return RELA_OK;  // `flat` may die: the upload reads the pinned copy
 }
 }  // namespace
 
@@ -419,8 +424,14 @@ extern "C" int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward
   if (n_sequences) *n_sequences = 0;
   const size_t R = (size_t)a->R;
   const int H = a->n + 1;
-  RELA_HIP(hipMemcpyAsync(a->rew + (size_t)a->cur * R, reward_host, R * sizeof(float), hipMemcpyHostToDevice, s));
-  RELA_HIP(hipMemcpyAsync(a->term + (size_t)a->cur * R, terminal_host, R, hipMemcpyHostToDevice, s));
+  struct StageCall {  // one pinned segment per call, released (event) on every return path
+    HostStage& st;
+    hipStream_t s;
+    StageCall(HostStage& st_, hipStream_t s_) : st(st_), s(s_) { st.begin(); }
+    ~StageCall() { st.end(s); }
+  } stage_call(a->stage, s);
+  RELA_HIP(a->stage.h2d(a->rew + (size_t)a->cur * R, reward_host, R * sizeof(float), s));
+  RELA_HIP(a->stage.h2d(a->term + (size_t)a->cur * R, terminal_host, R, s));
   memcpy(&a->h_term[(size_t)a->cur * R], terminal_host, R);
   hipLaunchKernelGGL(r2d2_reset_hidden, dim3(a->R), dim3(128), 0, s, a->term + (size_t)a->cur * R, a->R, a->hid_h,
                      a->hid_c);
@@ -465,8 +476,8 @@ extern "C" int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward
   a->book->step(&a->h_term[(size_t)first * R], &plan);
   rc = upload_ranges(a, plan.front_pad, s);
   if (rc != RELA_OK) return rc;
-  RELA_HIP(hipMemcpyAsync(a->d_slot, plan.write_slot.data(), R * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  RELA_HIP(hipMemcpyAsync(a->d_flags, plan.flags.data(), R, hipMemcpyHostToDevice, s));
+  RELA_HIP(a->stage.h2d(a->d_slot, plan.write_slot.data(), R * sizeof(int32_t), s));
+  RELA_HIP(a->stage.h2d(a->d_flags, plan.flags.data(), R, s));
   hipLaunchKernelGGL(r2d2_write_step, dim3(a->R), dim3(kT), 0, s, a->w, a->d_slot, a->d_flags, obs_t, eps_t, legal_t,
                      act_t, a->out_r, a->out_t, a->out_b, a->prio_step, h_t, c_t);
   RELA_LAUNCH_CHECK();
@@ -477,7 +488,7 @@ extern "C" int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward
     const int nseq = (int)plan.emits.size();
     std::vector<int32_t> em;
     for (const auto& e : plan.emits) em.insert(em.end(), {e.env, e.len, e.second});
-    RELA_HIP(hipMemcpyAsync(a->d_emits, em.data(), em.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    RELA_HIP(a->stage.h2d(a->d_emits, em.data(), em.size() * sizeof(int32_t), s));
     hipLaunchKernelGGL(r2d2_collect, dim3(nseq), dim3(128), 0, s, a->w, a->d_emits, nseq, a->prow, a->lens);
     hipLaunchKernelGGL(r2d2_aggregate, dim3(ceil_div(nseq, 64)), dim3(64), 0, s, a->prow, a->lens, nseq, a->seq, a->burn,
                        a->eta, a->one_minus_eta, a->agg);
@@ -504,7 +515,7 @@ extern "C" int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward
       while (pi < plan.carry_pad.size() && plan.carry_pad[pi].env <= env_hi) pads.push_back(plan.carry_pad[pi++]);
       auto carry_piece = [&]() -> int {
         if (carry.empty()) return RELA_OK;
-        RELA_HIP(hipMemcpyAsync(a->d_envs, carry.data(), carry.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        RELA_HIP(a->stage.h2d(a->d_envs, carry.data(), carry.size() * sizeof(int32_t), s));
         hipLaunchKernelGGL(r2d2_carry, dim3((unsigned)carry.size()), dim3(kT), 0, s, a->w, a->d_envs);
         RELA_LAUNCH_CHECK();
         return upload_ranges(a, pads, s);
@@ -537,8 +548,7 @@ extern "C" int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward
         std::vector<int32_t> all(dst);
         all.insert(all.end(), envs.begin(), envs.end());
         all.insert(all.end(), qs.begin(), qs.end());
-        // pageable source: the call returns only after the staging copy, so `all` may die
-        RELA_HIP(hipMemcpyAsync(d_dst, all.data(), all.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        RELA_HIP(a->stage.h2d(d_dst, all.data(), all.size() * sizeof(int32_t), s));  // pinned copy: `all` may die
         const void* bases[10] = {w.s, w.eps, w.legal, w.a, w.reward, w.term, w.boot, w.h0, w.c0, a->lens};
         const int32_t* idx[10] = {d_env, d_env, d_env, d_env, d_env, d_env, d_env, d_env, d_env, d_q};
         return rela_replay_write_rows_gather(a->replay, slot0, m, d_dst, bases, idx, s);
@@ -548,6 +558,7 @@ extern "C" int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward
       if (rc == RELA_OK) rc = emit_batch(true);
       if (rc == RELA_OK) rc = rela_replay_commit_add(a->replay, slot0, cnt, a->agg + q0, s);
       if (rc == RELA_OK) inserted += cnt;
+      else (void)rela_replay_abort_add(a->replay, slot0, cnt);  // never leave a reservation uncommitted
       q0 = q1;
     }
     if (rc != RELA_OK) return rc;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "../../include/rela_amd.h"
 
@@ -42,6 +43,68 @@ struct DeviceGuard {
   }
   ~DeviceGuard() {
     if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+
+// Page-locked staging for the small host->device uploads of the hot path (index plans, RNG draws,
+// host-side priorities).  hipMemcpyAsync from pageable memory is only lifetime-safe because the
+// runtime happens to stage it synchronously, and that staging drains the stream from the host; here
+// the source is copied into a pinned arena first, so the upload is truly asynchronous and the caller's
+// buffer may die at once.  The arena is a ring of kSeg segments: one segment per API call
+// (begin ... end), reused only after the event recorded at its end() has completed.
+struct HostStage {
+  static constexpr int kSeg = 4;
+  uint8_t* base = nullptr;
+  size_t seg_bytes = 0, off = 0;
+  hipEvent_t ev[kSeg] = {};
+  bool pending[kSeg] = {};
+  int cur = 0;
+  bool open = false;
+
+  int init(size_t bytes_per_call) {
+    seg_bytes = (bytes_per_call + 255) & ~(size_t)255;
+    if (hipHostMalloc(reinterpret_cast<void**>(&base), seg_bytes * kSeg, hipHostMallocDefault) != hipSuccess) {
+      base = nullptr;
+      return RELA_ENOMEM;
+    }
+    for (int i = 0; i < kSeg; ++i)
+      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return RELA_ENODEV;
+    return RELA_OK;
+  }
+  void destroy() {
+    for (int i = 0; i < kSeg; ++i)
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+    if (base) (void)hipHostFree(base);
+    base = nullptr;
+  }
+  void begin() {
+    cur = (cur + 1) % kSeg;
+    if (pending[cur]) {
+      (void)hipEventSynchronize(ev[cur]);
+      pending[cur] = false;
+    }
+    off = 0;
+    open = true;
+  }
+  // upload `bytes` from src to dst_dev on stream s (asynchronous when the segment has room)
+  hipError_t h2d(void* dst_dev, const void* src, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    const size_t need = (bytes + 15) & ~(size_t)15;
+    if (!open || base == nullptr || off + need > seg_bytes) {  // fallback: still lifetime-safe
+      hipError_t e = hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyHostToDevice, s);
+      if (e != hipSuccess) return e;
+      return hipStreamSynchronize(s);
+    }
+    uint8_t* p = base + (size_t)cur * seg_bytes + off;
+    memcpy(p, src, bytes);
+    off += need;
+    return hipMemcpyAsync(dst_dev, p, bytes, hipMemcpyHostToDevice, s);
+  }
+  void end(hipStream_t s) {
+    if (!open) return;
+    if (off > 0 && hipEventRecord(ev[cur], s) == hipSuccess) pending[cur] = true;
+    open = false;
   }
 };
 

@@ -211,19 +211,22 @@ __global__ __launch_bounds__(kThreads) void replay_gather_rows(const uint8_t* __
                                                                const int32_t* __restrict__ ids,
                                                                uint8_t* __restrict__ out, int64_t slot_bytes,
                                                                int steps, int batch, int vec16) {
-  const int b = blockIdx.y % batch, t = blockIdx.y / batch;
   const int64_t row_bytes = slot_bytes / steps;
-  const uint8_t* s = field + (int64_t)ids[b] * slot_bytes + (int64_t)t * row_bytes;
-  uint8_t* d = out + ((int64_t)t * batch + b) * row_bytes;
-  if (vec16) {
-    const int64_t nv = row_bytes >> 4;
-    const uint4* s4 = reinterpret_cast<const uint4*>(s);
-    uint4* d4 = reinterpret_cast<uint4*>(d);
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kThreads)
-      d4[i] = s4[i];
-  } else {
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < row_bytes; i += (int64_t)gridDim.x * kThreads)
-      d[i] = s[i];
+  // grid.y is capped (65,535 limit; batch * steps = 62,976 already at B = 512, T = 123): stride over (t, b)
+  for (int y = blockIdx.y; y < batch * steps; y += gridDim.y) {
+    const int b = y % batch, t = y / batch;
+    const uint8_t* s = field + (int64_t)ids[b] * slot_bytes + (int64_t)t * row_bytes;
+    uint8_t* d = out + ((int64_t)t * batch + b) * row_bytes;
+    if (vec16) {
+      const int64_t nv = row_bytes >> 4;
+      const uint4* s4 = reinterpret_cast<const uint4*>(s);
+      uint4* d4 = reinterpret_cast<uint4*>(d);
+      for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kThreads)
+        d4[i] = s4[i];
+    } else {
+      for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < row_bytes; i += (int64_t)gridDim.x * kThreads)
+        d[i] = s[i];
+    }
   }
 }
 
@@ -407,6 +410,7 @@ struct rela_replay {
   std::vector<int32_t> steps;  // sub-rows per slot (1 = plain field)
   std::vector<uint8_t*> d_fields;
   SeqIndex ix;
+  HostStage stage;  // pinned staging of the RNG draws / host-side priorities (guarded by m)
 };
 
 extern "C" const char* rela_last_error(void) { return g_err; }
@@ -451,6 +455,8 @@ extern "C" int rela_replay_create(rela_replay** out, int capacity, int seed, flo
   RELA_HIP(hipMemsetAsync(r->d_state, 0, sizeof(ReplayDevState), r->stream));
   int rc = seq_index_alloc(&r->ix, r->ring);
   if (rc != RELA_OK) return rc;
+  rc = r->stage.init(sizeof(uint32_t) * kMaxBatch);
+  RELA_CHECK(rc == RELA_OK, rc, "rela_replay_create: pinned staging buffer");
   RELA_HIP(hipStreamSynchronize(r->stream));
   *out = r;
   return RELA_OK;
@@ -462,6 +468,7 @@ extern "C" void rela_replay_destroy(rela_replay* r) {
   (void)hipStreamSynchronize(r->stream);
   for (auto* p : r->d_fields) (void)hipFree(p);
   seq_index_free(&r->ix);
+  r->stage.destroy();
   (void)hipFree(r->d_w);
   (void)hipFree(r->d_evicted);
   (void)hipFree(r->d_state);
@@ -611,7 +618,8 @@ extern "C" int rela_replay_commit_add_grouped(rela_replay* r, int first_slot, in
   hipStream_t producer = (hipStream_t)stream_;
   DeviceGuard g(r->device);
   std::unique_lock<std::mutex> lk(r->m);
-  r->cv_tail.wait(lk, [&] { return r->safe_tail == first_slot; });  // in-order commit :69
+  r->cv_tail.wait(lk, [&] { return r->shut || r->safe_tail == first_slot; });  // in-order commit :69
+  if (r->safe_tail != first_slot) return RELA_EWOULDBLOCK;  // shut down while an earlier block never committed
   RELA_HIP(hipEventRecord(r->ev_in, producer));
   RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
   {
@@ -630,6 +638,26 @@ extern "C" int rela_replay_commit_add_grouped(rela_replay* r, int first_slot, in
   return RELA_OK;
 }
 
+// Releases a reservation whose producer failed between begin_add and commit (no reference counterpart:
+// there an exception on an actor thread ends the process).  The block is committed in order with ZERO
+// weights: safe_tail advances so later blocks can commit, sum_ is unchanged, and a zero-weight slot can
+// never be the first index whose running sum reaches a positive target (:286), i.e. it is never sampled.
+extern "C" int rela_replay_abort_add(rela_replay* r, int first_slot, int n) {
+  RELA_CHECK(r && n > 0 && first_slot >= 0 && first_slot < r->ring, RELA_EINVAL, "rela_replay_abort_add: bad arguments");
+  DeviceGuard g(r->device);
+  std::unique_lock<std::mutex> lk(r->m);
+  r->cv_tail.wait(lk, [&] { return r->shut || r->safe_tail == first_slot; });
+  if (r->safe_tail != first_slot) return RELA_EWOULDBLOCK;
+  const int first_part = std::min(n, r->ring - first_slot);
+  RELA_HIP(hipMemsetAsync(r->d_w + first_slot, 0, sizeof(float) * (size_t)first_part, r->stream));
+  if (n > first_part) RELA_HIP(hipMemsetAsync(r->d_w, 0, sizeof(float) * (size_t)(n - first_part), r->stream));
+  r->safe_tail = (first_slot + n) % r->ring;
+  r->safe_size += n;
+  lk.unlock();
+  r->cv_tail.notify_all();
+  return RELA_OK;
+}
+
 extern "C" int rela_replay_add(rela_replay* r, int n, const void* const* rows_dev, const float* priority_dev,
                                int nonblocking, void* stream_) {
   RELA_CHECK(r && n > 0 && priority_dev, RELA_EINVAL, "rela_replay_add: bad arguments");
@@ -639,7 +667,10 @@ extern "C" int rela_replay_add(rela_replay* r, int n, const void* const* rows_de
   if (rc != RELA_OK) return rc;
   if (!r->d_fields.empty()) {
     rc = rela_replay_write_rows(r, slot, 0, n, rows_dev, stream_);
-    if (rc != RELA_OK) return rc;
+    if (rc != RELA_OK) {
+      (void)rela_replay_abort_add(r, slot, n);
+      return rc;
+    }
   }
   return rela_replay_commit_add(r, slot, n, priority_dev, stream_);
 }
@@ -660,7 +691,10 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
   // outputs belong to the consumer: do not overwrite them before its queued work is done
   RELA_HIP(hipEventRecord(r->ev_in, consumer));
   RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
-  RELA_HIP(hipMemcpyAsync(r->d_draws, draws.data(), sizeof(uint32_t) * batch, hipMemcpyHostToDevice, r->stream));
+  r->stage.begin();
+  const hipError_t up = r->stage.h2d(r->d_draws, draws.data(), sizeof(uint32_t) * batch, r->stream);
+  r->stage.end(r->stream);
+  RELA_HIP(up);
   const int size = r->safe_size;  // storage_ [0, safeSize) is static during the scan :261-263
   SeqView v;
   int rc = seq_index_build(r->ix, r->d_w, r->ring, r->head, size, r->stream, &v);
@@ -691,7 +725,7 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
   }
   {
     ProfScope prof("replay_is_weights", r->stream);
-    hipLaunchKernelGGL(replay_is_weights, dim3(1), dim3(1024), 0, r->stream, r->d_raw_w, batch, (float)size, r->beta,
+    hipLaunchKernelGGL(replay_is_weights, dim3(1), dim3(1024), 0, r->stream, r->d_raw_w, batch, (float)full_size, r->beta,
                        r->d_state, out_weight_dev);
   }
   if (out_rows_dev) {
@@ -713,7 +747,7 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
       int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (units + kThreads - 1) / kThreads), 64);
       {
         ProfScope prof("replay_gather_rows", r->stream);
-        hipLaunchKernelGGL(replay_gather_rows, dim3(gx, batch * st), dim3(kThreads), 0, r->stream, r->d_fields[f],
+        hipLaunchKernelGGL(replay_gather_rows, dim3(gx, std::min(batch * st, 32768)), dim3(kThreads), 0, r->stream, r->d_fields[f],
                            r->d_ids, (uint8_t*)out_rows_dev[f], rb, st, batch, v16);
       }
     }
@@ -745,7 +779,10 @@ extern "C" int rela_replay_update_priority(rela_replay* r, int n, const float* p
     RELA_HIP(hipEventRecord(r->ev_in, producer));
     RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
   } else {
-    RELA_HIP(hipMemcpyAsync(r->d_prio, priority, sizeof(float) * n, hipMemcpyHostToDevice, r->stream));
+    r->stage.begin();
+    const hipError_t up = r->stage.h2d(r->d_prio, priority, sizeof(float) * n, r->stream);
+    r->stage.end(r->stream);
+    RELA_HIP(up);
     p = r->d_prio;
   }
   {
@@ -776,6 +813,7 @@ extern "C" int rela_replay_shutdown(rela_replay* r) {
     r->shut = true;
   }
   r->cv_size.notify_all();
+  r->cv_tail.notify_all();
   return RELA_OK;
 }
 

@@ -19,6 +19,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <mutex>
 #include <stdexcept>
 #include <thread>
@@ -1043,7 +1044,23 @@ class Context {
     formCohorts();
     for (size_t i = 0; i < loops_.size(); ++i) {
       threads_.emplace_back([this, i] {
-        loops_[i]->mainLoop();
+        // The reference lets an exception on an actor thread reach std::terminate (rela/context.h:39-46).
+        // Here the first one is kept and re-raised on the Python thread by terminated(); the loop counts
+        // as done, its cohort is told (the siblings drain instead of waiting at the barrier forever) and
+        // every other loop is asked to stop, so the learner fails with a traceback instead of an abort.
+        try {
+          loops_[i]->mainLoop();
+        } catch (...) {
+          {
+            std::lock_guard<std::mutex> lk(errM_);
+            if (!error_) error_ = std::current_exception();
+          }
+          try {
+            if (auto a = loops_[i]->actor()) a->onLoopExit();
+          } catch (...) {
+          }
+          for (auto& l : loops_) l->terminate();
+        }
         ++done_;
       });
     }
@@ -1057,7 +1074,17 @@ class Context {
   void terminate() {
     for (auto& l : loops_) l->terminate();
   }
-  bool terminated() { return done_.load() == (int)loops_.size(); }
+  bool terminated() {
+    {
+      std::lock_guard<std::mutex> lk(errM_);
+      if (error_) {
+        std::exception_ptr e = error_;
+        error_ = nullptr;  // raised once; afterwards terminated() reports the joined state
+        std::rethrow_exception(e);
+      }
+    }
+    return done_.load() == (int)loops_.size();
+  }
 
  private:
   // Training DQNActors (R2D2Actors) of this context that share (locker, replay, K, n, gamma[, seq_len,
@@ -1110,6 +1137,8 @@ class Context {
   }
 
   bool started_ = false;
+  std::mutex errM_;
+  std::exception_ptr error_;  // first exception thrown on an actor thread
   std::atomic<int> done_{0};
   std::vector<std::shared_ptr<ThreadLoop>> loops_;
   std::vector<std::thread> threads_;

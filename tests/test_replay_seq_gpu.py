@@ -127,3 +127,132 @@ def test_gathered_row_write_matches_per_row_writes():
         capi.lib.rela_replay_destroy(h)
     for a, b in zip(results[0], results[1]):
         assert np.array_equal(a, b)
+
+
+def test_abort_releases_a_reservation():
+    """A block reserved by begin_add whose producer fails must not wedge the ring: after
+    rela_replay_abort_add the blocks behind it commit, the aborted slots carry zero weight, are never
+    drawn, and sum_ ignores them."""
+    import torch
+
+    from gpu_util import cur_stream
+    from rela_amd import _capi as capi
+
+    h = C.c_void_p()
+    capi.check(capi.lib.rela_replay_create(C.byref(h), 32, 3, 1.0, 1.0, 0, 0), "create")
+    rb = (C.c_int64 * 1)(8)
+    capi.check(capi.lib.rela_replay_set_schema(h, 1, rb), "schema")
+    tags = torch.arange(24, dtype=torch.int64, device="cuda")
+    prio = torch.ones(24, device="cuda")
+    s0, s1 = C.c_int(), C.c_int()
+    capi.check(capi.lib.rela_replay_begin_add(h, 8, 0, C.byref(s0)), "begin")
+    capi.check(capi.lib.rela_replay_begin_add(h, 8, 0, C.byref(s1)), "begin")
+    rows = (C.c_void_p * 1)(tags[8:].data_ptr())
+    capi.check(capi.lib.rela_replay_write_rows(h, s1.value, 0, 8, rows, cur_stream()), "write")
+    capi.check(capi.lib.rela_replay_abort_add(h, s0.value, 8), "abort")  # the first producer gives up
+    capi.check(capi.lib.rela_replay_commit_add(h, s1.value, 8, C.c_void_p(prio.data_ptr()), cur_stream()), "commit")
+    assert capi.lib.rela_replay_size(h) == 16 and capi.lib.rela_replay_num_add(h) == 8
+    out = torch.empty(16, dtype=torch.int64, device="cuda")
+    w = torch.empty(16, device="cuda")
+    outs = (C.c_void_p * 1)(out.data_ptr())
+    capi.check(capi.lib.rela_replay_sample(h, 16, outs, C.c_void_p(w.data_ptr()), cur_stream()), "sample")
+    st = capi.ReplayState()
+    ids = np.zeros(16, np.int32)
+    capi.check(capi.lib.rela_replay_debug_state(h, C.byref(st), ids.ctypes.data_as(C.c_void_p), None, None), "dbg")
+    assert st.dev_error == 0 and st.sum == 8.0
+    assert ids.min() >= 8 and sorted(set(out.cpu().tolist())) == list(range(8, 16))
+    capi.lib.rela_replay_destroy(h)
+
+
+def test_shutdown_releases_a_commit_waiting_for_its_turn():
+    """rela_replay_shutdown wakes a commit that waits behind a block that will never commit."""
+    import threading
+
+    import torch
+
+    from gpu_util import cur_stream
+    from rela_amd import _capi as capi
+
+    h = C.c_void_p()
+    capi.check(capi.lib.rela_replay_create(C.byref(h), 32, 3, 1.0, 1.0, 0, 0), "create")
+    s0, s1 = C.c_int(), C.c_int()
+    capi.check(capi.lib.rela_replay_begin_add(h, 4, 0, C.byref(s0)), "begin")
+    capi.check(capi.lib.rela_replay_begin_add(h, 4, 0, C.byref(s1)), "begin")
+    prio = torch.ones(4, device="cuda")
+    stream = cur_stream()
+    rc = []
+    th = threading.Thread(target=lambda: rc.append(capi.lib.rela_replay_commit_add(
+        h, s1.value, 4, C.c_void_p(prio.data_ptr()), stream)))
+    th.start()
+    th.join(0.3)
+    assert th.is_alive()  # parked behind the uncommitted first block (in-order commit, :69)
+    capi.check(capi.lib.rela_replay_shutdown(h), "shutdown")
+    th.join(10)
+    assert not th.is_alive() and rc == [capi.EWOULDBLOCK]
+    capi.lib.rela_replay_destroy(h)
+
+
+def test_is_weights_use_size_including_reservations():
+    """prioritized_replay.h:312,321: the IS weights use size_ (reserved, uncommitted blocks included), not
+    the committed size the scan ran over.  beta = 1 makes the weights exact: w_i = 1/(size * w_i/sum) / max."""
+    import torch
+
+    from gpu_util import cur_stream
+    from rela_amd import _capi as capi
+
+    outs_w = []
+    for reserve in (0, 5):
+        h = C.c_void_p()
+        capi.check(capi.lib.rela_replay_create(C.byref(h), 64, 3, 1.0, 0.5, 0, 0), "create")
+        prio = torch.arange(1, 17, device="cuda", dtype=torch.float32)
+        capi.check(capi.lib.rela_replay_add(h, 16, None, C.c_void_p(prio.data_ptr()), 0, cur_stream()), "add")
+        slot = C.c_int()
+        if reserve:
+            capi.check(capi.lib.rela_replay_begin_add(h, reserve, 0, C.byref(slot)), "begin")
+        w = torch.empty(8, device="cuda")
+        capi.check(capi.lib.rela_replay_sample(h, 8, None, C.c_void_p(w.data_ptr()), cur_stream()), "sample")
+        st = capi.ReplayState()
+        raw = np.zeros(8, np.float32)
+        capi.check(capi.lib.rela_replay_debug_state(h, C.byref(st), None, raw.ctypes.data_as(C.c_void_p), None), "dbg")
+        size = np.float32(16 + reserve)
+        q = (raw / np.float32(st.sum)).astype(np.float32)
+        exp = np.power((size * q).astype(np.float32), np.float32(-0.5)).astype(np.float32)
+        exp = exp / exp.max()
+        np.testing.assert_allclose(w.cpu().numpy(), exp, rtol=3e-7)
+        outs_w.append(w.cpu().numpy())
+        if reserve:
+            capi.check(capi.lib.rela_replay_abort_add(h, slot.value, reserve), "abort")
+        capi.lib.rela_replay_destroy(h)
+    # normalised by the maximum, the factor size^-beta cancels: both runs agree to rounding
+    np.testing.assert_allclose(outs_w[0], outs_w[1], rtol=3e-7)
+
+
+def test_time_major_gather_beyond_65535_rows():
+    """batch * steps > 65,535 (the grid.y limit): B = 1100 sequences of T = 64 steps in one sample."""
+    import torch
+
+    from gpu_util import cur_stream
+    from rela_amd import _capi as capi
+
+    T, E, N, B = 64, 16, 1200, 1100
+    h = C.c_void_p()
+    capi.check(capi.lib.rela_replay_create(C.byref(h), 2048, 3, 1.0, 1.0, 0, 0), "create")
+    rb = (C.c_int64 * 1)(T * E)
+    st = (C.c_int32 * 1)(T)
+    capi.check(capi.lib.rela_replay_set_schema_seq(h, 1, rb, st), "schema")
+    rng = np.random.default_rng(5)
+    seqs = rng.integers(0, 256, (N, T, E), dtype=np.uint8)
+    d_seq = torch.from_numpy(seqs).cuda()
+    prio = torch.ones(N, device="cuda")
+    rows = (C.c_void_p * 1)(d_seq.data_ptr())
+    capi.check(capi.lib.rela_replay_add(h, N, rows, C.c_void_p(prio.data_ptr()), 0, cur_stream()), "add")
+    out = torch.zeros((T, B, E), dtype=torch.uint8, device="cuda")
+    w = torch.empty(B, device="cuda")
+    outs = (C.c_void_p * 1)(out.data_ptr())
+    capi.check(capi.lib.rela_replay_sample(h, B, outs, C.c_void_p(w.data_ptr()), cur_stream()), "sample")
+    st_ = capi.ReplayState()
+    ids = np.zeros(B, np.int32)
+    capi.check(capi.lib.rela_replay_debug_state(h, C.byref(st_), ids.ctypes.data_as(C.c_void_p), None, None), "dbg")
+    assert st_.dev_error == 0
+    np.testing.assert_array_equal(out.cpu().numpy(), seqs[ids].transpose(1, 0, 2))
+    capi.lib.rela_replay_destroy(h)
