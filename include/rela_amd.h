@@ -157,6 +157,8 @@ typedef struct {
 int rela_replay_debug_state(rela_replay* r, rela_replay_state* out, int32_t* ids_host,
                             float* raw_w_host, float* targets_host);
 int rela_replay_debug_weights(rela_replay* r, float* weights_host, uint8_t* evicted_host);
+/* raw rows [slot, slot+count) of one field (physical slots, no wrap) -> host; synchronises */
+int rela_replay_debug_read_rows(rela_replay* r, int field, int slot, int count, void* rows_host);
 
 /* The scan primitive on its own: for nt targets (f64, host, ascending not required) over the
  * logical range [head, head+size) of a device weight ring, the first index whose

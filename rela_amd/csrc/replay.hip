@@ -870,3 +870,16 @@ extern "C" int rela_replay_debug_weights(rela_replay* r, float* weights_host, ui
   RELA_HIP(hipStreamSynchronize(r->stream));
   return RELA_OK;
 }
+
+extern "C" int rela_replay_debug_read_rows(rela_replay* r, int field, int slot, int count, void* rows_host) {
+  RELA_CHECK(r && rows_host && field >= 0 && field < (int)r->d_fields.size() && slot >= 0 && count >= 0 &&
+                 slot + count <= r->ring,
+             RELA_EINVAL, "rela_replay_debug_read_rows: bad arguments");
+  DeviceGuard g(r->device);
+  std::lock_guard<std::mutex> lk(r->m);
+  const size_t rb = (size_t)r->row_bytes[field];
+  RELA_HIP(hipMemcpyAsync(rows_host, r->d_fields[field] + (size_t)slot * rb, rb * (size_t)count, hipMemcpyDeviceToHost,
+                          r->stream));
+  RELA_HIP(hipStreamSynchronize(r->stream));
+  return RELA_OK;
+}

@@ -102,14 +102,26 @@ def _wait_parked(replay, min_size, quiet=1.0, timeout=180.0):
         time.sleep(0.01)
 
 
-def run_lockstep_r2d2(rela, synth_atari, agent, act_device, sample_device, cfg=CFG_R2D2):
+# BASELINE config C4's sequence shape (pyrela/scripts/ref_run_r2d2.sh:12-18: seq 80 / burn-in 40 / n 3, window of
+# 123 slots = 3.47 MB of frames per sequence).  The four envs cover: an episode shorter than the window
+# (50 steps), a terminal inside the carried region (step 120 lands in slot 80 of the second window,
+# r2d2_actor.h:119-142 -> a second, short sequence), several carries in a row (260) and a window that
+# never sees a terminal (1000).  `quiet` = seconds without an add before the actor counts as parked
+# (the reference's CPU actor needs ~2 s for the 80 steps between two pops).
+CFG_R2D2_C4 = dict(K=4, multi_step=3, gamma=0.997, seq_len=80, burn_in=40, eta=0.9, capacity=16, alpha=1.0, beta=1.0,
+                   seed=13, episode_len=0, episode_lens=[50, 121, 260, 1000], num_action=6, rounds=4, batch=4,
+                   online_seed=3003, target_seed=4004, env_seed=760)
+
+
+def run_lockstep_r2d2(rela, synth_atari, agent, act_device, sample_device, cfg=CFG_R2D2, quiet=1.0):
     replay = rela.RNNPrioritizedReplay(cfg["capacity"], cfg["seed"], cfg["alpha"], cfg["beta"], 0)
     locker = rela.ModelLocker([agent], act_device)
     actor = rela.R2D2Actor(locker, cfg["multi_step"], cfg["K"], cfg["gamma"], cfg["seq_len"], cfg["burn_in"], replay)
     vec = rela.VectorEnv()
     games = []
     for g in range(cfg["K"]):
-        game = synth_atari.SyntheticAtariEnv(cfg["env_seed"] + g, 0.0, cfg["num_action"], cfg["episode_len"])
+        ep_len = cfg["episode_lens"][g] if cfg.get("episode_lens") else cfg["episode_len"]
+        game = synth_atari.SyntheticAtariEnv(cfg["env_seed"] + g, 0.0, cfg["num_action"], ep_len)
         games.append(game)
         vec.append(game)
     ctx = rela.Context()
@@ -117,9 +129,9 @@ def run_lockstep_r2d2(rela, synth_atari, agent, act_device, sample_device, cfg=C
     ctx.start()
     rounds = []
     for r in range(cfg["rounds"]):
-        _wait_parked(replay, cfg["batch"])
+        _wait_parked(replay, cfg["batch"], quiet=quiet, timeout=180.0 + 40 * quiet)
         batch, w = replay.sample(cfg["batch"], sample_device)
-        _wait_parked(replay, cfg["batch"])  # the parked block lands before the priorities change
+        _wait_parked(replay, cfg["batch"], quiet=quiet, timeout=180.0 + 40 * quiet)  # the parked block lands first
         s = batch.obs["s"].cpu().numpy().astype(np.int64)  # [T,B,4,84,84]
         T, B = s.shape[:2]
         rounds.append(dict(

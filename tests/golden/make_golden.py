@@ -388,7 +388,7 @@ print("RESULT" + json.dumps(rounds))
     save("e2e_lockstep_apex", [], json.loads(line[len("RESULT"):]), cfg=CFG)
 
 
-def e2e_r2d2_cases():
+def e2e_r2d2_cases(cfg_name="CFG_R2D2", out_name="e2e_lockstep_r2d2", quiet=1.0):
     """The REAL reference's R2D2 path end to end (H6-shimmed module, see oracle/Makefile)."""
     code = r"""
 import json, sys, types
@@ -402,26 +402,28 @@ import rela, synth_atari
 assert "_ref/h6" in rela.__file__
 from r2d2 import R2D2Agent
 from net import AtariLSTMNet
-from e2e_lockstep import CFG_R2D2 as C, run_lockstep_r2d2, load_lstm_agent_params
+from e2e_lockstep import %s as C, run_lockstep_r2d2, load_lstm_agent_params
 agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, C["num_action"]), "cpu", C["multi_step"], C["gamma"], C["eta"],
                   C["seq_len"], C["burn_in"], 0)
-load_lstm_agent_params(agent)
-rounds = run_lockstep_r2d2(rela, synth_atari, agent, "cpu", "cpu")
+load_lstm_agent_params(agent, C)
+rounds = run_lockstep_r2d2(rela, synth_atari, agent, "cpu", "cpu", C, quiet=%r)
 print("RESULT" + json.dumps(rounds))
-""" % (os.path.join(REFBIN, "h6"), REFBIN, os.path.dirname(HERE))
+""" % (os.path.join(REFBIN, "h6"), REFBIN, os.path.dirname(HERE), cfg_name, quiet)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     if out.returncode != 0:
         print(out.stdout[-2000:], out.stderr[-4000:])
         raise SystemExit(1)
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1]
-    from e2e_lockstep import CFG_R2D2
-    save("e2e_lockstep_r2d2", [], json.loads(line[len("RESULT"):]), cfg=CFG_R2D2)
+    import e2e_lockstep
+    save(out_name, [], json.loads(line[len("RESULT"):]), cfg=getattr(e2e_lockstep, cfg_name))
 
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["replay", "nstep", "ffnet", "e2e", "r2d2buf", "r2d2agg", "e2e_r2d2"]
     if "e2e_r2d2" in which:
         e2e_r2d2_cases()
+    if "e2e_r2d2_c4" in which:  # BASELINE config C4's window shape (seq 80 / burn-in 40 / n 3); ~5 minutes
+        e2e_r2d2_cases("CFG_R2D2_C4", "e2e_lockstep_r2d2_c4", quiet=12.0)
     if "r2d2buf" in which:
         r2d2buf_cases()
     if "r2d2agg" in which:

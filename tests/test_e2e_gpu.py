@@ -88,6 +88,35 @@ def test_lockstep_r2d2_matches_reference(mods):
         np.testing.assert_allclose(got["weight"], exp["weight"], rtol=1e-3, err_msg="IS weights, round %d" % r)
 
 
+def test_lockstep_r2d2_c4_shape_matches_reference(mods):
+    """The same lock-step protocol at BASELINE config C4's window shape (seq 80 / burn-in 40 / n 3, 123 slots,
+    3.47 MB per sequence; pyrela/scripts/ref_run_r2d2.sh:12-18) against the REAL reference: episodes shorter
+    than the window, a terminal inside the carried region, consecutive carries, recurrent state captured at
+    window index 80, and the time-major gather of [123, B, 4, 84, 84] batches."""
+    from e2e_lockstep import CFG_R2D2_C4 as C, load_lstm_agent_params, run_lockstep_r2d2
+    from rela_amd.pyrela.net import AtariLSTMNet
+    from rela_amd.pyrela.r2d2 import R2D2Agent
+
+    rela, synth = mods
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_lockstep_r2d2_c4.json")))
+    assert gold["cfg"] == C
+    agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, C["num_action"]), "cpu", C["multi_step"], C["gamma"], C["eta"],
+                      C["seq_len"], C["burn_in"], 0)
+    load_lstm_agent_params(agent, C)
+    rounds = run_lockstep_r2d2(rela, synth, agent, "cuda:0", "cuda:0", C, quiet=3.0)
+    assert len(rounds) == len(gold["expect"])
+    lens = set()
+    for r, (got, exp) in enumerate(zip(rounds, gold["expect"])):
+        for key in ("s_sum", "a", "terminal", "bootstrap", "legal_sum", "seq_len", "num_add", "size", "eps_sum"):
+            assert got[key] == exp[key], (r, key)
+        assert np.array_equal(np.float32(got["reward"]), np.float32(exp["reward"])), r
+        np.testing.assert_allclose(got["h0_abs"], exp["h0_abs"], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(got["c0_abs"], exp["c0_abs"], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(got["weight"], exp["weight"], rtol=2e-3, err_msg="IS weights, round %d" % r)
+        lens.update(exp["seq_len"])
+    assert max(lens) == C["burn_in"] + C["seq_len"] and min(lens) < max(lens)  # full and short sequences were sampled
+
+
 def test_r2d2_training_entry_point_runs(mods, capsys):
     """--algo r2d2 on 2 threads x 4 envs: sequences (seq 8 / burn 4 / n 3) flow from C++ actor threads
     through RNNPrioritizedReplay into the R2D2Agent learner (burn-in unroll, Adam, aggregate priority)."""

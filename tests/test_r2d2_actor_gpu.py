@@ -97,3 +97,119 @@ def test_post_step_reuses_the_act_step_bit_identically():
         assert np.array_equal(base[0], other[0])
         assert np.array_equal(base[1].view(np.uint32), other[1].view(np.uint32)), mode
         assert np.array_equal(base[2].view(np.uint32), other[2].view(np.uint32)), mode
+
+
+def test_device_windows_at_c4_shape_match_the_oracle_buffer():
+    """BASELINE config C4's window shape (seq 80 / burn-in 40 / n 3: 123 slots, 3.47 MB of frames per
+    sequence) on the device: every sequence the R2D2 actor shard appends to the replay -- slot contents,
+    front / tail padding, carry-over, second short sequence after a terminal in the carried region, length,
+    aggregated priority -- against the oracle's R2D2TransitionBuffer (oracle/r2d2_oracle.c, pinned to traces
+    of the real rela::R2D2TransitionBuffer incl. r2d2buf_k1_n3_s80_b40.json) fed the same per-step
+    terminals and the device's own per-step priorities.  Frames carry their (env, step) tag in the first
+    four bytes, so a misplaced row of the 3.47 MB windows cannot go unnoticed."""
+    import torch
+
+    from oracle_lib import h2f, load
+    from rela_amd import _capi as capi
+    from rela_amd.engine import dev_view
+    from synth import synth_obs
+    from test_oracle_r2d2 import OracleR2D2Buf, bind
+
+    R, K, A, n, seq, burn, gamma, eta = 3, 3, 6, 3, 80, 40, 0.997, 0.9
+    T = burn + seq + n
+    steps = 520
+    online, _k1 = _net(capi, A, 1)
+    target, _k2 = _net(capi, A, 2)
+    replay = C.c_void_p()
+    capi.check(capi.lib.rela_replay_create(C.byref(replay), 64, 7, 1.0, 0.6, 0, 0), "rela_replay_create")
+    rb = (C.c_int64 * 10)(T * 28224, T * 4, T * 4 * A, T * 8, T * 4, T, T * 4, 2048, 2048, 4)
+    st = (C.c_int32 * 10)(T, T, T, T, T, T, T, 1, 1, 1)
+    capi.check(capi.lib.rela_replay_set_schema_seq(replay, 10, rb, st), "schema")
+    actor = C.c_void_p()
+    capi.check(capi.lib.rela_r2d2_actor_create(C.byref(actor), R, K, A, n, gamma, seq, burn, eta, replay, 3, 0), "create")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(80)
+    # terminals: env 0 ends after 50 steps (episode shorter than the window), then at step 50 + 121 (terminal
+    # inside the carried region of its second window); env 1 never before step 300; env 2 random
+    term_all = np.zeros((steps, R), np.uint8)
+    term_all[49, 0] = term_all[170, 0] = term_all[400, 0] = 1
+    term_all[300, 1] = 1
+    term_all[:, 2] = rng.uniform(size=steps) < 0.012
+    rew_all = rng.integers(-1, 2, (steps, R)).astype(np.float32)
+    acts = np.zeros((steps, R), np.int64)
+    lib = bind(load())
+    obuf = OracleR2D2Buf(R, n, seq, burn)
+    n_r, n_b, n_t = (np.zeros((steps, R), np.float32), np.zeros((steps, R), np.float32), np.zeros((steps, R), np.uint8))
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    checked, kinds, tail = 0, set(), 0
+    base = synth_obs(R, 4242)
+    for t in range(steps):
+        obs = base.copy()
+        tagv = (np.arange(R) + t * 100).astype(np.uint32)
+        obs.reshape(R, -1)[:, :4] = tagv.view(np.uint8).reshape(R, 4)
+        obs.reshape(R, -1)[:, 4:64] = rng.integers(0, 256, (R, 60), dtype=np.uint8)  # the net must see fresh frames
+        eps = np.zeros(R, np.float32)
+        legal = np.ones((R, A), np.float32)
+        act = np.zeros(R, np.int64)
+        capi.check(capi.lib.rela_r2d2_actor_act(actor, online, vp(obs), vp(eps), vp(legal), vp(act), None, stream), "act")
+        acts[t] = act
+        ns = C.c_int(0)
+        capi.check(capi.lib.rela_r2d2_actor_post_step(actor, vp(rew_all[t]), vp(term_all[t]), online, target, 0,
+                                                      C.byref(ns), stream), "post_step")
+        if t < n:
+            assert ns.value == 0
+            continue
+        s = t - n  # the transition popped from the n-step buffer on this tick (dqn_actor.h:58-106)
+        lib.oracle_nstep_pop(n, R, C.c_float(gamma), rew_all[s:s + n + 1].ctypes.data_as(C.POINTER(C.c_float)),
+                             term_all[s:s + n + 1].ctypes.data_as(C.POINTER(C.c_uint8)),
+                             n_r[s].ctypes.data_as(C.POINTER(C.c_float)), n_b[s].ctypes.data_as(C.POINTER(C.c_float)),
+                             n_t[s].ctypes.data_as(C.POINTER(C.c_uint8)))
+        torch.cuda.synchronize()
+        p = dev_view(capi.lib.rela_r2d2_actor_last_priority_dev(actor), (R,), torch.float32,
+                     torch.device("cuda:0")).cpu().numpy().copy()
+        can = obuf.push(n_t[s], p)
+        assert can == (ns.value > 0), (t, can, ns.value)
+        if not can:
+            continue
+        exp = obuf.pop()
+        assert len(exp) == ns.value
+        q = len(exp)
+        fr = np.zeros((q, T * 28224), np.uint8)
+        a_ = np.zeros((q, T), np.int64)
+        r_, b_ = np.zeros((q, T), np.float32), np.zeros((q, T), np.float32)
+        t_ = np.zeros((q, T), np.uint8)
+        ln = np.zeros(q, np.float32)
+        for f, arr in ((0, fr), (3, a_), (4, r_), (5, t_), (6, b_), (9, ln)):
+            capi.check(capi.lib.rela_replay_debug_read_rows(replay, f, tail, q, vp(arr)), "read_rows")
+        st_ = capi.ReplayState()
+        capi.check(capi.lib.rela_replay_debug_state(replay, C.byref(st_), None, None, None), "state")
+        w = np.zeros(st_.ring, np.float32)
+        capi.check(capi.lib.rela_replay_debug_weights(replay, vp(w), None), "weights")
+        for i, e in enumerate(exp):
+            env = e["env"]
+            real = np.array(e["reward"], np.float32) > 0  # the oracle tags real slots with reward = step + 0.5
+            step_of = (np.array(e["reward"], np.float32) - 0.5).astype(np.int64)
+            got_tag = fr[i].reshape(T, 28224)[:, :4].copy().view(np.uint32).reshape(T)
+            for j in range(T):
+                if real[j]:
+                    sj = int(step_of[j])
+                    assert got_tag[j] == env + 100 * sj, (t, i, j)
+                    assert a_[i, j] == acts[sj, env] and t_[i, j] == n_t[sj, env]
+                    assert r_[i, j] == n_r[sj, env] and b_[i, j] == n_b[sj, env]
+                else:  # padLike (types.cc:69-80): zeros, terminal = 1
+                    assert got_tag[j] == 0 and not fr[i].reshape(T, 28224)[j].any()
+                    assert a_[i, j] == 0 and r_[i, j] == 0 and b_[i, j] == 0 and t_[i, j] == 1
+            assert e["terminal"] == t_[i].tolist()
+            assert ln[i] == e["len"]
+            prow = np.array([h2f(v) for v in e["prio"]], np.float32)[None]
+            agg = np.zeros(1, np.float32)
+            lib.oracle_r2d2_aggregate(1, seq, burn, C.c_float(eta), vp(prow), vp(np.array([e["len"]], np.float32)), vp(agg))
+            np.testing.assert_allclose(w[tail + i], agg[0], rtol=2e-6)
+            kinds.add("short" if e["len"] < burn + seq else "full")
+            checked += 1
+        tail += q
+    assert checked >= 12 and kinds == {"short", "full"} and tail < 64
+    capi.lib.rela_r2d2_actor_destroy(actor)
+    capi.lib.rela_replay_destroy(replay)
+    capi.lib.rela_lstmnet_destroy(online)
+    capi.lib.rela_lstmnet_destroy(target)
