@@ -65,28 +65,43 @@ def generate_eps(base_eps, alpha, num_actor):
     return [base_eps ** (1 + i / (num_actor - 1) * alpha) for i in range(num_actor)]
 
 
-def cpu_baseline_reference(seconds=12.0):
+def cpu_baseline_reference():
     """The REAL reference's CPU-thread actor path (oracle/_ref/rela*.so, compiled from the reference's
     sources where they exist; only the built module travels) timed on this box's host cores by
-    oracle/ref_actor_bench.py in a child process.  None if the prebuilt module is absent or fails."""
+    oracle/ref_actor_bench.py in a child process: first at the headline's shape (80 threads x 80 envs, the
+    threads oversubscribing the cores as the reference's README does with 80 threads on 40 cores), then
+    with one thread per core x 20 envs (its best shape on few cores, reported as `best_shape`).
+    None if the prebuilt module is absent or fails."""
     import glob
 
     if not glob.glob(os.path.join(ROOT, "oracle", "_ref", "rela*.so")):
         return None
     cores = min(len(os.sched_getaffinity(0)), 16)
     env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+
+    def run(threads, games, seconds, warmup):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_actor_bench.py"), "--threads",
+                              str(threads), "--games", str(games), "--seconds", str(seconds), "--warmup", str(warmup),
+                              "--num_action", str(NUM_ACTION)], env=env, capture_output=True, text=True, timeout=240)
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+
     try:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_actor_bench.py"), "--threads", str(cores),
-                              "--games", "20", "--seconds", str(seconds), "--warmup", "4", "--num_action",
-                              str(NUM_ACTION)], env=env, capture_output=True, text=True, timeout=180)
-        rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        rec = run(T_THREADS, K_GAMES, 14.0, 6.0)
     except Exception:  # noqa: BLE001  (any failure -> fall back to the port)
         return None
-    return {"value": rec["env_steps_per_s"], "unit": "env-steps/s", "cores": cores, "kind": "reference",
-            "sample": "the reference's own C++ actor threads (oracle/_ref/rela, g++ -O2) with a CPU TorchScript Ape-X "
-                      "agent: %d threads x %d synthetic envs, OMP_NUM_THREADS=1, A=%d, n=3, %.1f s window after 4 s "
-                      "warm-up, light B=32 sampler evicting the overflow (pyrela/benchmark.py protocol)"
-                      % (rec["threads"], rec["games"], rec["num_action"], rec["seconds"])}
+    res = {"value": rec["env_steps_per_s"], "unit": "env-steps/s", "cores": cores, "kind": "reference",
+           "sample": "the reference's own C++ actor threads (oracle/_ref/rela, g++ -O2) with a CPU TorchScript Ape-X "
+                     "agent at the headline's shape: %d threads x %d synthetic envs on %d host cores, OMP_NUM_THREADS=1, "
+                     "A=%d, n=3, %.1f s window after 6 s warm-up, light B=32 sampler evicting the overflow "
+                     "(pyrela/benchmark.py protocol)"
+                     % (rec["threads"], rec["games"], cores, rec["num_action"], rec["seconds"])}
+    try:
+        best = run(cores, 20, 10.0, 4.0)
+        res["best_shape"] = {"value": best["env_steps_per_s"], "threads": best["threads"], "games": best["games"],
+                             "seconds": best["seconds"]}
+    except Exception:  # noqa: BLE001
+        pass
+    return res
 
 
 def cpu_baseline(budget_s=15.0):
@@ -174,8 +189,9 @@ def cpu_baseline(budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    # default window: 600 steps of ~3.5 ms = ~2 s of timed work (r01's 20-step window was 72 ms)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replay-cap", type=int, default=REPLAY_CAP)
     args = ap.parse_args()
@@ -200,6 +216,11 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    # ONE learner batch of 512 per step for the whole job (pyrela/main.py:221): with G replay partitions every
+    # rank draws B/G from its own partition, the gradients are averaged over the ranks and the
+    # importance weights are normalised over all partitions.
+    assert BATCH % world == 0, "the learner batch (%d) must split evenly over %d ranks" % (BATCH, world)
+    B_LOCAL = BATCH // world
 
     from rela_amd import build as _build
 
@@ -224,7 +245,7 @@ def main():
     # learner step: hand-written HIP (csrc/learner.hip) by default; RELA_BENCH_LEARNER=torch runs the
     # same step through PyTorch autograd (pyrela/main.py:226-239 verbatim) for comparison
     LEARNER = os.environ.get("RELA_BENCH_LEARNER", "hip")
-    hip_learner = HipApexLearner.from_agent(agent, BATCH, lr=6.25e-5, eps=1.5e-4, grad_clip=40.0) \
+    hip_learner = HipApexLearner.from_agent(agent, B_LOCAL, lr=6.25e-5, eps=1.5e-4, grad_clip=40.0) \
         if LEARNER == "hip" else None
     online, target = FFNetHandle(NUM_ACTION, device), FFNetHandle(NUM_ACTION, device)
     online.load_state_dict(agent.online_net.state_dict())
@@ -279,11 +300,11 @@ def main():
                 online.load_state_dict(agent.online_net.state_dict())
                 target.load_state_dict(agent.target_net.state_dict())
             actor_stream.wait_stream(main_stream)
-        batch, weight = replay.sample(BATCH)
+        batch, weight = replay.sample(B_LOCAL)
         if world > 1:  # one replay partition per GPU: normalise the IS weights over all of them
             raw_p, sum_p = C.c_void_p(), C.c_void_p()
             capi.check(capi.lib.rela_replay_last_sample_dev(replay.h, C.byref(raw_p), C.byref(sum_p)), "last_sample")
-            raw_w = dev_view(raw_p.value, (BATCH,), torch.float32, torch.device(device))
+            raw_w = dev_view(raw_p.value, (B_LOCAL,), torch.float32, torch.device(device))
             part_sum = dev_view(sum_p.value, (1,), torch.float32, torch.device(device))
             weight = global_is_weights(raw_w, part_sum, replay.size(), BETA)
         return batch, weight
@@ -388,20 +409,26 @@ def main():
 
     # Reference-style accounting next to the headline (N = 1 only, untimed by the driver): the same
     # step with the act-forward reuse switched off, i.e. all 4 forwards of the reference per env-step.
+    # A second timed region of exactly the same K steps, bracketed the same way (barrier + synchronize on
+    # both sides, MAX over ranks), with the reuse switched off: SURVEY 8d's unit of work, 4 forwards per env-step.
     ms_4fwd = None
-    if world == 1 and not ONLY:
+    if not ONLY:
         engine.set_reuse(False)
-        k4 = max(5, args.steps // 3)
-        for _ in range(2):
+        for _ in range(min(args.warmup, 3)):
             one_step()
             step_idx[0] += 1
         sync_all()
         t4 = time.perf_counter()
-        for _ in range(k4):
+        for _ in range(args.steps):
             one_step()
             step_idx[0] += 1
         sync_all()
-        ms_4fwd = (time.perf_counter() - t4) / k4 * 1e3
+        dt4 = time.perf_counter() - t4
+        if world > 1:
+            t = torch.tensor([dt4], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt4 = float(t.item())
+        ms_4fwd = dt4 / args.steps * 1e3
         engine.set_reuse(True)
     st = replay.debug_state()
     assert st["dev_error"] == 0, "replay reported device error %d" % st["dev_error"]
@@ -424,17 +451,19 @@ def main():
                     "traffic": None, "avg_launch_ms": avg_ms, "launches": rec["count"]}
         if roof["achieved"] is not None:
             roof["frac"] = roof["achieved"] / roof["peak"]
-        # HBM bytes per launch of that kernel from the committed PMC passes (separate rocprofv3 --pmc
-        # runs of the isolated forward at the same N, tools/final_evidence.sh + tools/pmc_table.py)
-        try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                             "r01_traffic.json")))
-            rec_t = tj["kernels"].get(name)
-            if rec_t is not None:
-                roof["traffic"] = rec_t["read_bytes"] + rec_t["write_bytes"]
-                roof["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-        except (OSError, ValueError, KeyError):
-            pass
+        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the
+        # figure comes from the committed PMC passes of the isolated forward at the same N (separate
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, tools/final_evidence.sh + tools/pmc_table.py); newest round first
+        for tname in ("r02_traffic.json", "r01_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
+                rec_t = tj["kernels"].get(name)
+                if rec_t is not None:
+                    roof["traffic"] = rec_t["read_bytes"] + rec_t["write_bytes"]
+                    roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, not this run)" % tname
+                    break
+            except (OSError, ValueError, KeyError):
+                continue
         fwd_ms = sum(prof[k]["total_ms"] for k in FLOP if k in prof)
         fwd_cnt = prof.get("conv1_bf16x3", {"count": 1})["count"]
         scan_ms = sum(v["total_ms"] for k, v in prof_all.items() if k.startswith("seq_") or k in (
@@ -445,10 +474,14 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Ape-X DQN, 80 threads x 80 games (6400 envs) per GPU, actor+learner on one "
-                                   "MI355X, replay 2^20 device-resident, A=18, n=3, learner batch 512 per GPU",
+                                   "MI355X, replay 2^20 per GPU device-resident, A=18, n=3, ONE learner batch of 512 per "
+                                   "step for the whole job (B/G sampled per replay partition); device-resident static "
+                                   "frames: no env stepping and no H2D inside the timed region",
                        "envs_per_gpu": ROWS, "replay_capacity": args.replay_cap, "learner_batch": BATCH,
-                       "parallelism": "replicas%d+grad-allreduce" % world if world > 1 else "single"},
-            "grad_steps_per_s": args.steps / dt, "train_samples_per_s": args.steps * BATCH * world / dt,
+                       "learner_batch_per_gpu": B_LOCAL,
+                       "parallelism": ("actor-shards%d+replay-partitions+grad-allreduce" % world) if world > 1
+                       else "single"},
+            "grad_steps_per_s": args.steps / dt, "train_samples_per_s": args.steps * BATCH / dt,
             "buffer_add_per_s": adds / dt,
             "learner": "hip (csrc/learner.hip)" if hip_learner is not None else "torch autograd",
             **({"diagnostic_only": ONLY} if ONLY else {}),
@@ -456,7 +489,10 @@ def main():
             # forward (same weights, same batch) and is reused bit-identically -> 3, else 4
             "forwards_per_tick": fwd_cnt / args.steps if ONLY != "learner" else 0,
             "no_reuse": None if ms_4fwd is None else {
-                "forwards_per_tick": 4, "ms_per_step": ms_4fwd, "env_steps_per_s": ROWS / (ms_4fwd * 1e-3)},
+                "forwards_per_tick": 4, "steps": args.steps, "ms_per_step": ms_4fwd,
+                "env_steps_per_s": ROWS * world / (ms_4fwd * 1e-3),
+                "note": "second timed region of the same K steps with the act-forward reuse off: the reference's "
+                        "4 trunk forwards per env-step (SURVEY 8d: 74.8 MFLOP)"},
             "forward_ms_per_6400": fwd_ms / max(fwd_cnt, 1),
             "forward_tflops": sum(FLOP.values()) * ROWS / (max(fwd_ms, 1e-9) / max(fwd_cnt, 1) * 1e-3) / 1e12,
             "replay_sample_scan_ms": scan_ms / k_all,
@@ -464,8 +500,17 @@ def main():
             "kernels_ms_per_step_note": "untimed pass of %d steps with every kernel timed; the timed region times "
                                         "only conv1/conv2/conv3/fc (roofline)" % k_all,
             "roofline": roof,
-            # the HBM-bound side of the path: the replay insert copies obs and next_obs rows (read + write)
-            "roofline_hbm": (lambda ms: None if ms <= 0 else {
+            # the HBM-bound side of the path.  (i) the sample call, SURVEY 8d: 4*N + B*56,448 algorithmic bytes
+            # (the reference's linear scan over the N live weights + the gather of the batch rows) over the
+            # summed launch time of ALL kernels of one rela_replay_sample; (ii) the insert's row copies.
+            "roofline_hbm": (lambda ms, nbytes: None if ms <= 0 else {
+                "kernel": "rela_replay_sample (seq_* + replay_targets/search/pop/is_weights/gather_*)", "bound": "hbm",
+                "unit": "GB/s", "peak": PEAK_HBM_GBS, "achieved": nbytes / (ms * 1e-3) / 1e9,
+                "frac": nbytes / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_call": nbytes,
+                "ms_per_call": ms, "scan_ms": scan_ms / k_all})(
+                    (scan_ms + sum(v["total_ms"] for k, v in prof_all.items() if k.startswith("replay_gather"))) / k_all,
+                    4 * st["safe_size"] + B_LOCAL * 56448),
+            "roofline_hbm_insert": (lambda ms: None if ms <= 0 else {
                 "kernel": "replay_scatter_rows", "bound": "hbm", "unit": "GB/s", "peak": PEAK_HBM_GBS,
                 "achieved": ROWS * 2 * 28224 * 2 / (ms * 1e-3) / 1e9,
                 "frac": ROWS * 2 * 28224 * 2 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,

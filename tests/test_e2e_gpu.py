@@ -387,3 +387,30 @@ def test_r2d2_cohort_pop_larger_than_ring_slack_inserts_in_pieces(mods):
         ctx.push_env_thread(rela.BasicThreadLoop(actor, vec, False))
     _run_small_replay(rela, ctx, replay, actors, 2, 120, lambda w: torch.ones_like(w).cpu())
     assert replay.num_add() >= 120
+
+
+@pytest.mark.parametrize("algo", ["apex", "r2d2"])
+def test_benchmark_driver_tiny_grid(mods, capsys, algo):
+    """rela_amd/pyrela/benchmark.py (counterpart of pyrela/benchmark.py:19-126, the script that DEFINES the
+    env-steps/s metric) on a tiny grid: both phases run, the per-epoch lines and the summary
+    line have the reference's format, and actors keep acting next to the unthrottled sampler."""
+    import re
+
+    from rela_amd.pyrela import benchmark
+
+    argv = ["--grid", "2x4,3x2", "--epoch_sec", "0.6", "--num_epoch", "2", "--episode_len", "30"]
+    if algo == "r2d2":
+        argv += ["--algo", "r2d2", "--seq_len", "8", "--seq_burn_in", "4", "--replay_buffer_size", "128",
+                 "--burn_in_frames", "70"]
+    else:
+        argv += ["--replay_buffer_size", "2048", "--burn_in_frames", "600"]
+    rows = benchmark.main(argv)
+    out = capsys.readouterr().out
+    assert [(r[0], r[1]) for r in rows] == [(2, 4), (3, 2)]
+    per_epoch = re.findall(r"^(without|with) sample: epoch (\d+), act rate: (\d+), buffer size: (\d+)", out, re.M)
+    assert len(per_epoch) == 2 * 2 * 2  # 2 cells x 2 phases x 2 epochs
+    summary = re.findall(r"^act rate: without sample: ([0-9.]+), with sample: ([0-9.]+)$", out, re.M)
+    assert len(summary) == 2
+    for (t, k, without, with_), (sw, sws) in zip(rows, summary):
+        assert abs(float(sw) - without) < 0.01 and abs(float(sws) - with_) < 0.01
+        assert without > 0 and with_ > 0
