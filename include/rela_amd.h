@@ -391,6 +391,40 @@ int rela_apex_learner_flat(rela_apex_learner* l, float** params_dev, float** gra
 const float* rela_apex_learner_stats_dev(const rela_apex_learner* l);
 
 /* ===================================================================================
+ * R2D2 learner step  --  pyrela/main.py:206-251 with R2D2Agent.loss (pyrela/r2d2.py:189-206):
+ * td_err (:122-187: burn-in unroll without gradient, state zeroed where terminal[burn_in-1], training
+ * unroll of online and target AtariLSTMNet (pyrela/net.py:127-163), per-step target with Q_target[t+n],
+ * pad mask) -> smooth_l1 summed over the sequence * IS weight -> mean -> backward through the heads,
+ * the LSTM (BPTT over seq_len + multi_step steps) and the conv trunk -> clip_grad_norm_ -> Adam
+ * (main.py:124-126).  Replaces PyTorch autograd.  Flat buffers in rela_lstmnet_params order.
+ * =================================================================================== */
+typedef struct rela_r2d2_learner rela_r2d2_learner;
+
+/* optimizer: 0 = RMSprop, 1 = Adam (the reference's choice for R2D2, main.py:124); eta = mixing weight of
+ * aggregate_priority (r2d2.py:103-120); max_batch <= 1024 sequences of burn_in + seq_len + multi_step steps */
+int rela_r2d2_learner_create(rela_r2d2_learner** out, int num_action, int max_batch, int multi_step,
+                             float gamma, int seq_len, int burn_in, double eta, int optimizer, float lr,
+                             float eps, float grad_clip, int device);
+void rela_r2d2_learner_destroy(rela_r2d2_learner* l);
+int rela_r2d2_learner_load(rela_r2d2_learner* l, const rela_lstmnet_params* online,
+                           const rela_lstmnet_params* target, int params_on_device, void* stream);
+int rela_r2d2_learner_sync_target(rela_r2d2_learner* l, void* stream); /* r2d2.py:54-55 */
+/* loss + backward on one sampled batch.  rows_dev: the ten RNNTransition fields, time-major, in the order of
+ * the sequence schema (s, eps, legal_move, a, reward, terminal, bootstrap, h0, c0, seq_len) as
+ * rela_replay_sample fills them; weight_dev f32[batch].  Leaves the gradient of mean(loss * weight) in the flat
+ * gradient buffer, the aggregated priority (r2d2.py:205) in priority_dev f32[batch], mean(loss * weight) in
+ * loss_dev (may be NULL) and the per-sequence Huber sums (r2d2.py:203) in loss_seq_dev (may be NULL).       */
+int rela_r2d2_learner_backward(rela_r2d2_learner* l, int batch, const void* const* rows_dev,
+                               const float* weight_dev, float* priority_dev, float* loss_dev,
+                               float* loss_seq_dev, void* stream);
+int rela_r2d2_learner_apply(rela_r2d2_learner* l, void* stream); /* clip + optimiser + repack */
+int rela_r2d2_learner_params(rela_r2d2_learner* l, rela_lstmnet_params* online_out,
+                             rela_lstmnet_params* target_out);
+int rela_r2d2_learner_grads(rela_r2d2_learner* l, rela_lstmnet_params* grads_out);
+int rela_r2d2_learner_flat(rela_r2d2_learner* l, float** params_dev, float** grads_dev, int64_t* count);
+const float* rela_r2d2_learner_stats_dev(const rela_r2d2_learner* l); /* grad norm, clip coefficient */
+
+/* ===================================================================================
  * Live per-kernel timing (HIP events on the launch stream) for bench.py's roofline line.
  * No reference counterpart: the reference times sections with torch.cuda.synchronize()
  * (pyrela/common_utils/stopwatch.py:17-54).

@@ -1192,3 +1192,44 @@ extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_
   RELA_LAUNCH_CHECK();
   return RELA_OK;
 }
+
+// ---- internal entry points for the R2D2 learner (csrc/learner_r2d2.hip) -------------------------
+// conv trunk only: frames u8[N][4][84][84] -> a1 / a2 / a3 (channel-last, ffnet_layout.h)
+namespace rela_amd {
+int lstmnet_trunk(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, hipStream_t s,
+                  const char* const* names) {
+  RELA_CHECK(n && n->loaded, RELA_ESTATE, "lstmnet_trunk: parameters were never loaded");
+  RELA_CHECK(N >= 1 && s_dev && a1 && a2 && a3, RELA_EINVAL, "lstmnet_trunk: bad arguments");
+  const FFNetDev& d = n->d;
+  {
+    ProfScope prof(names[0], s);
+    hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
+                       d.b1, a1, N);
+  }
+  {
+    ProfScope prof(names[1], s);
+    launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
+  }
+  {
+    ProfScope prof(names[2], s);
+    launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
+  }
+  RELA_LAUNCH_CHECK();
+  return RELA_OK;
+}
+
+// dueling heads on rows of LSTM outputs: o f32[N][512] -> ha [N][32] (cols 0..A-1 = fc_a, col 31 = fc_v) and q [N][A]
+int lstmnet_heads(const rela_lstmnet* n, int N, const float* o, const float* legal, float* ha, float* q, hipStream_t s,
+                  const char* name) {
+  RELA_CHECK(n && n->loaded, RELA_ESTATE, "lstmnet_heads: parameters were never loaded");
+  const FFNetDev& d = n->d;
+  ProfScope prof(name, s);
+  hipLaunchKernelGGL(gemm_mfma<GemmHeads>, dim3(GemmHeads::CT / GemmHeads::CTB, ceil_div(N, GemmHeads::BM)),
+                     dim3(kThreads), 0, s, o, (const float*)nullptr, (const float*)d.Bh, (const float*)d.bh, ha,
+                     (const float*)nullptr, (float*)nullptr, N);
+  hipLaunchKernelGGL(dueling_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, (const float*)ha, legal, q,
+                     (float*)nullptr, N, n->num_action);
+  RELA_LAUNCH_CHECK();
+  return RELA_OK;
+}
+}  // namespace rela_amd

@@ -6,6 +6,8 @@
 //   h  [N][512]        relu(fc)
 //   ha [N][32]         heads: columns 0..A-1 = fc_a, column 31 = fc_v
 #pragma once
+#include <hip/hip_runtime.h>
+
 #include <cstdint>
 
 namespace rela_amd {
@@ -33,4 +35,15 @@ struct rela_ffnet;
 namespace rela_amd {
 // per-kernel timing labels "learner_fwd_*" instead of the actor-side names (prof.h)
 void ffnet_label_as_learner(rela_ffnet* n);
+}  // namespace rela_amd
+
+struct rela_lstmnet;
+namespace rela_amd {
+// internal (not part of the C ABI): the conv trunk and the dueling heads of an AtariLSTMNet on their own,
+// for the R2D2 learner, which batches the trunk over all T*B frames of a sequence batch and runs the
+// recurrent part itself.  names: three per-kernel timing labels.
+int lstmnet_trunk(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, hipStream_t s,
+                  const char* const* names);
+int lstmnet_heads(const rela_lstmnet* n, int N, const float* o, const float* legal, float* ha, float* q, hipStream_t s,
+                  const char* name);
 }  // namespace rela_amd

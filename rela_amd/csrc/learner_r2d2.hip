@@ -1,0 +1,677 @@
+// R2D2 learner step on the device: pyrela/main.py:206-251 with R2D2Agent.loss (pyrela/r2d2.py:189-206),
+// td_err (:122-187) and AtariLSTMNet.unroll_rnn / forward (pyrela/net.py:127-163), without PyTorch autograd
+// (SURVEY 8a G2 / K15, 8f-2):
+//
+//   forward   per net (target first, then online; one set of trunk buffers):
+//               conv trunk over ALL T*B frames of the batch at once (T = burn_in + seq_len + multi_step)
+//               GX = a3 x W_ih^T + (b_ih + b_hh) for all T*B rows in ONE GEMM            (K = 3136)
+//               T recurrent steps: gates_t = GX_t + h_{t-1} x W_hh^T (split-K GEMM, K = 512) -> LSTM cell
+//               (torch gate order i,f,g,o); the burn-in steps carry no gradient (:144-147) and the state
+//               after them is zeroed where terminal[burn_in-1] (dummy burn-in at an episode start, :149-154)
+//               dueling heads + Q over the seq_len + multi_step training steps
+//   td        batch-global q.min() of the online Q (net.py:160), greedy action, Q_online[a], Q_target[greedy],
+//             target_i = r_i + bootstrap_i * gamma^n * Q_target[i + n], pad mask i >= seq_len_b - burn_in (:169-183),
+//             Huber summed over the sequence (:197-203), eta-mixed priority (:103-120)
+//   backward  d(mean(loss * w)) through the heads, BPTT over the seq_len + multi_step training steps
+//             (dh_{t-1} = dgates_t x W_hh, split-K), then batched over all training rows:
+//             dW_hh = DG^T x H_prev, dW_ih = DG^T x a3, d_a3 = DG x W_ih (ReLU mask) and the shared conv-trunk
+//             backward of learner_common.h.  Every contraction is an instance of gemm_lds (f32 MFMA).
+//   update    clip_grad_norm_ + Adam (pyrela/main.py:124-126,233-238) on flat buffers in state_dict order.
+#include "learner_common.h"
+
+using namespace rela_amd;
+
+namespace rela_amd {
+namespace {
+
+constexpr int kHid = 512, kGates = 2048, kFeat = 3136;
+constexpr int kRecSplitF = 4;  // split-K of the recurrent forward GEMM (K = 512)
+constexpr int kRecSplitB = 8;  // split-K of the recurrent backward GEMM (K = 2048)
+
+using TileRows = TileCfg<128, 64, 4, 2, false>;  // M = many rows, A k-contiguous
+using TileRec = TileCfg<64, 64, 2, 4, false>;    // M = batch rows of one time step
+using TileWg = TileCfg<128, 64, 4, 2, true>;     // weight gradients, M = 2048 gate rows
+using TileW32r = TileCfg<32, 64, 2, 4, true>;    // head weight gradients (M = 32)
+
+// GX[r][g] = bias[g] + sum_k a3[r][k] * wihT[k][g]
+struct ProbGateX : ProbBase {
+  const float *a3, *wihT, *bias;
+  float* gx;
+  __device__ float4 loadA(int m, int k) const { return m < M ? ld4(a3 + (size_t)m * kFeat + k) : zero4(); }
+  __device__ float4 loadB(int k, int n) const { return ld4(wihT + (size_t)k * kGates + n); }
+  __device__ void store(int, int m, int n, float v) const { gx[(size_t)m * kGates + n] = v + bias[n]; }
+};
+// part[z][b][g] = sum_{k in slice z} h[b][k] * whhT[k][g]
+struct ProbRecFwd : ProbBase {
+  const float *h, *whhT;
+  float* part;
+  __device__ float4 loadA(int m, int k) const { return m < M ? ld4(h + (size_t)m * kHid + k) : zero4(); }
+  __device__ float4 loadB(int k, int n) const { return ld4(whhT + (size_t)k * kGates + n); }
+  __device__ void store(int z, int m, int n, float v) const { part[((size_t)z * M + m) * kGates + n] = v; }
+};
+// part[z][b][k] = sum_{g in slice z} dg[b][g] * whh[g][k]
+struct ProbRecBwd : ProbBase {
+  const float *dg, *whh;
+  float* part;
+  __device__ float4 loadA(int m, int k) const { return m < M ? ld4(dg + (size_t)m * kGates + k) : zero4(); }
+  __device__ float4 loadB(int k, int n) const { return ld4(whh + (size_t)k * kHid + n); }
+  __device__ void store(int z, int m, int n, float v) const { part[((size_t)z * M + m) * kHid + n] = v; }
+};
+// dW_hh[g][k] = sum_r dg[r][g] * hprev[r][k]
+struct ProbWhh : ProbBase {
+  const float *dg, *hprev;
+  float* out;
+  __device__ float4 loadA(int r, int m) const { return r < K ? ld4(dg + (size_t)r * kGates + m) : zero4(); }
+  __device__ float4 loadB(int r, int n) const { return r < K ? ld4(hprev + (size_t)r * kHid + n) : zero4(); }
+  __device__ void store(int, int m, int n, float v) const { out[(size_t)m * kHid + n] = v; }
+};
+// dW_ih[g][c*49+pos] = sum_r dg[r][g] * a3[r][pos*64+c]     (written in state_dict order, net.py:105-106)
+struct ProbWih : ProbBase {
+  const float *dg, *a3;
+  float* out;
+  __device__ float4 loadA(int r, int m) const { return r < K ? ld4(dg + (size_t)r * kGates + m) : zero4(); }
+  __device__ float4 loadB(int r, int n) const { return r < K ? ld4(a3 + (size_t)r * kFeat + n) : zero4(); }
+  __device__ void store(int, int m, int n, float v) const {
+    const int pos = n >> 6, c = n & 63;
+    out[(size_t)m * kFeat + c * 49 + pos] = v;
+  }
+};
+// d_a3[r][j] = relu'(a3) * sum_g dg[r][g] * wihp[g][j]      j = pos*64 + c
+struct ProbIhDgrad : ProbBase {
+  const float *dg, *wihp, *a3;
+  float* d_a3;
+  __device__ float4 loadA(int m, int k) const { return m < M ? ld4(dg + (size_t)m * kGates + k) : zero4(); }
+  __device__ float4 loadB(int k, int n) const { return ld4(wihp + (size_t)k * kFeat + n); }
+  __device__ void store(int, int m, int n, float v) const {
+    const size_t i = (size_t)m * kFeat + n;
+    d_a3[i] = a3[i] > 0.f ? v : 0.f;
+  }
+};
+// d_o[r][u] = sum_k d_ha[r][k] * Wh[k][u]      Wh rows: 0..A-1 = fc_a.weight, 31 = fc_v.weight (no ReLU on o)
+struct ProbHeadDgradSeq : ProbBase {
+  const float *d_ha, *a_w, *v_w;
+  float* d_o;
+  int A;
+  __device__ float4 loadA(int m, int k) const { return m < M ? ld4(d_ha + (size_t)m * 32 + k) : zero4(); }
+  __device__ float4 loadB(int k, int n) const {
+    if (k < A) return ld4(a_w + (size_t)k * kHid + n);
+    if (k == 31) return ld4(v_w + n);
+    return zero4();
+  }
+  __device__ void store(int, int m, int n, float v) const { d_o[(size_t)m * kHid + n] = v; }
+};
+
+// ---- weight copies in the orders the GEMM loaders read ------------------------------------------
+// wihT[k = pos*64+c][g] and wihp[g][k = pos*64+c]  <-  weight_ih_l0[g][c*49+pos]; whhT[k][g] <- weight_hh_l0[g][k]
+__global__ void pack_lstm_learner(const float* __restrict__ wih, const float* __restrict__ whh,
+                                  const float* __restrict__ bih, const float* __restrict__ bhh,
+                                  float* __restrict__ wihT, float* __restrict__ wihp, float* __restrict__ whhT,
+                                  float* __restrict__ bsum) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < (int64_t)kGates * kFeat) {
+    const int g = (int)(idx / kFeat), k = (int)(idx - (int64_t)g * kFeat);
+    const int c = k & 63, pos = k >> 6;
+    const float v = wih[(size_t)g * kFeat + c * 49 + pos];
+    if (wihp) wihp[idx] = v;
+    wihT[(size_t)k * kGates + g] = v;
+  }
+  if (idx < (int64_t)kGates * kHid) {
+    const int g = (int)(idx / kHid), k = (int)(idx - (int64_t)g * kHid);
+    whhT[(size_t)k * kGates + g] = whh[idx];
+  }
+  if (idx < kGates) bsum[idx] = bih[idx] + bhh[idx];
+}
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// one LSTM time step for Bn rows: pre-activations = gx (x-part + bias) + sum of the split-K partials of
+// h_{t-1} x W_hh^T; torch cell (gate order i,f,g,o).  save != 0 leaves the ACTIVATED gates in gx.
+__global__ void lstm_cell_fwd(float* __restrict__ gx, const float* __restrict__ part, int nsplit, int Bn,
+                              const float* __restrict__ c_prev, float* __restrict__ c_out, float* __restrict__ h_out,
+                              int save) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Bn * kHid) return;
+  const int b = idx / kHid, u = idx - b * kHid;
+  float pre[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const size_t o = (size_t)b * kGates + q * kHid + u;
+    float v = gx[o];
+    for (int z = 0; z < nsplit; ++z) v += part[(size_t)z * Bn * kGates + o];
+    pre[q] = v;
+  }
+  const float gi = sigm(pre[0]), gf = sigm(pre[1]), gg = tanhf(pre[2]), go = sigm(pre[3]);
+  const float c = gf * c_prev[idx] + gi * gg;
+  c_out[idx] = c;
+  h_out[idx] = go * tanhf(c);
+  if (save) {
+    float* row = gx + (size_t)b * kGates + u;
+    row[0] = gi, row[kHid] = gf, row[2 * kHid] = gg, row[3 * kHid] = go;
+  }
+}
+
+// hid *= 1 - terminal[burn_in - 1]   (r2d2.py:149-154)
+__global__ void zero_hidden_where_terminal(const uint8_t* __restrict__ term, int Bn, float* __restrict__ h,
+                                           float* __restrict__ c) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Bn * kHid) return;
+  if (term[idx / kHid]) h[idx] = 0.f, c[idx] = 0.f;
+}
+
+// BPTT of one step.  ga: activated gates of the step (overwritten by the pre-activation gradients),
+// d_o: gradient from the heads, dh partials: dgates_{t+1} x W_hh (nsplit = 0 at the last step).
+__global__ void lstm_cell_bwd(float* __restrict__ ga, const float* __restrict__ d_o, const float* __restrict__ dh_part,
+                              int nsplit, int Bn, const float* __restrict__ c_now, const float* __restrict__ c_prev,
+                              float* __restrict__ dc_rec) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Bn * kHid) return;
+  const int b = idx / kHid, u = idx - b * kHid;
+  float dh = d_o[idx];
+  for (int z = 0; z < nsplit; ++z) dh += dh_part[(size_t)z * Bn * kHid + idx];
+  float* row = ga + (size_t)b * kGates + u;
+  const float gi = row[0], gf = row[kHid], gg = row[2 * kHid], go = row[3 * kHid];
+  const float tc = tanhf(c_now[idx]);
+  const float dc = dc_rec[idx] + dh * go * (1.0f - tc * tc);
+  row[0] = dc * gg * gi * (1.0f - gi);
+  row[kHid] = dc * c_prev[idx] * gf * (1.0f - gf);
+  row[2 * kHid] = dc * gi * (1.0f - gg * gg);
+  row[3 * kHid] = dh * tc * go * (1.0f - go);
+  dc_rec[idx] = dc * gf;
+}
+
+// q.min() over the whole [Tt, B, A] tensor (net.py:160)
+__global__ __launch_bounds__(1024) void q_min_all(const float* __restrict__ q, int64_t n, float* __restrict__ out) {
+  __shared__ float red[1024];
+  float m = INFINITY;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) m = fminf(m, q[i]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0];
+}
+
+// per training row r = (t, b): greedy action of the online net, Q_online[a_r], Q_target[greedy_r]
+__global__ void seq_select(const float* __restrict__ q_on, const float* __restrict__ q_tg,
+                           const float* __restrict__ legal, const int64_t* __restrict__ act,
+                           const float* __restrict__ qmin, int rows, int A, float* __restrict__ qa_on,
+                           float* __restrict__ qa_tg) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float mn = qmin[0];
+  const float* qo = q_on + (size_t)r * A;
+  const float* lg = legal + (size_t)r * A;
+  int best = 0;
+  float bv = -INFINITY;
+  for (int j = 0; j < A; ++j) {
+    const float v = (1.0f + qo[j] - mn) * lg[j];
+    if (v > bv) bv = v, best = j;  // first maximum, as torch.argmax
+  }
+  qa_on[r] = qo[(int)act[r]];
+  qa_tg[r] = q_tg[(size_t)r * A + best];
+}
+
+// per sequence b: err_i = (r_i + boot_i * gamma^n * Qt[i+n] - Qo[i]) * (1 - pad_i), Huber sum, eta-mixed
+// priority, and d(mean_b(loss_b * w_b)) / dQo[i]; one thread per sequence (B <= 1024), one block.
+__global__ __launch_bounds__(1024) void seq_td_loss(const float* __restrict__ qa_on, const float* __restrict__ qa_tg,
+                                                    const float* __restrict__ reward, const float* __restrict__ boot,
+                                                    const float* __restrict__ seq_len, const float* __restrict__ w,
+                                                    int Bn, int seq, int burn, int nstep, float gamma_n, float eta,
+                                                    float one_minus_eta, float* __restrict__ dqa,
+                                                    float* __restrict__ prio, float* __restrict__ loss_seq,
+                                                    float* __restrict__ loss_out) {
+  __shared__ float red[1024];
+  const int b = threadIdx.x;
+  float lw = 0.f;
+  if (b < Bn) {
+    const float len = seq_len[b];
+    const float inv_b = 1.0f / (float)Bn;
+    float lsum = 0.f, psum = 0.f, pmax = 0.f;  // |err| * mask >= 0, so the maximum over the row starts at 0
+    for (int i = 0; i < seq + nstep; ++i) {
+      const size_t r = (size_t)i * Bn + b;  // training rows are time-major
+      float g = 0.f;
+      if (i < seq) {
+        const float target = reward[r] + boot[r] * (gamma_n * qa_tg[(size_t)(i + nstep) * Bn + b]);
+        const bool pad = (float)i >= len - (float)burn;  // should_padding :175
+        const float e = pad ? 0.f : target - qa_on[r];
+        const float ae = fabsf(e);
+        lsum += ae < 1.0f ? 0.5f * e * e : ae - 0.5f;
+        const float pm = ((float)i < len) ? ae : 0.f;  // aggregate_priority mask :113-115
+        psum += pm;
+        pmax = fmaxf(pmax, pm);
+        // err = target - Qo:  d mean(loss * w) / d Qo[i] = -w * clamp(err, -1, 1) / B
+        g = pad ? 0.f : -(w[b] * fminf(fmaxf(e, -1.0f), 1.0f)) * inv_b;
+      }
+      dqa[r] = g;
+    }
+    loss_seq[b] = lsum;
+    prio[b] = eta * pmax + one_minus_eta * (psum / (len - (float)burn));
+    lw = lsum * w[b];
+  }
+  red[threadIdx.x] = lw;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[0] = red[0] / (float)Bn;
+}
+
+// gradient through the dueling head  q = v + a*legal - mean_A(a*legal)  (net.py:93-99), per training row
+__global__ void seq_head_grad(const float* __restrict__ dqa, const int64_t* __restrict__ act,
+                              const float* __restrict__ legal, int rows, int A, float* __restrict__ d_ha) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * 32) return;
+  const int r = idx >> 5, k = idx & 31;
+  const float g = dqa[r];
+  float v = 0.f;
+  if (k < A) v = legal[(size_t)r * A + k] * (g * ((k == (int)act[r] ? 1.0f : 0.0f) - 1.0f / (float)A));
+  if (k == 31) v = g;
+  d_ha[idx] = v;
+}
+
+}  // namespace
+}  // namespace rela_amd
+
+// flat parameter layout: rela_lstmnet_params order, every segment padded to 4 floats
+struct rela_r2d2_learner {
+  int device = 0;
+  int A = 0, Bmax = 0, seq = 0, burn = 0, n = 0, T = 0;
+  float gamma_n = 0.f, eta = 0.f, one_minus_eta = 0.f;
+  OptimState opt;
+  int64_t off[15] = {0};  // segment offsets, off[14] = total
+  float *P = nullptr, *PT = nullptr, *G = nullptr, *S1 = nullptr, *S2 = nullptr;
+  rela_lstmnet *online = nullptr, *target = nullptr;
+  float *w2p = nullptr, *w3p = nullptr;                               // conv dgrad operand copies (online)
+  float *wihT[2] = {nullptr, nullptr}, *whhT[2] = {nullptr, nullptr}, *bsum[2] = {nullptr, nullptr};  // [online, target]
+  float* wihp = nullptr;                                              // online W_ih in k order (dgrad)
+  float *a1 = nullptr, *a2 = nullptr, *a3 = nullptr;                  // trunk activations of T*B frames
+  float* gx = nullptr;                                                // [T*B][2048]: GX -> activated gates -> dgates
+  float *Hs[2] = {nullptr, nullptr}, *Cs[2] = {nullptr, nullptr};     // [(T+1)*B][512] per net
+  float* rec_part = nullptr;                                          // split-K partials of the recurrent GEMMs
+  float *ha = nullptr, *q_on = nullptr, *q_tg = nullptr;              // heads of the training rows
+  float *qmin = nullptr, *qa_on = nullptr, *qa_tg = nullptr, *dqa = nullptr, *d_ha = nullptr, *d_o = nullptr;
+  float *dc_rec = nullptr;
+  float *d_a3 = nullptr, *d_a2 = nullptr, *d_a1 = nullptr, *col = nullptr, *part = nullptr, *cpart = nullptr,
+        *s32 = nullptr;
+  double* npart = nullptr;
+  float *norm = nullptr, *loss = nullptr, *loss_seq = nullptr;
+  bool loaded = false;
+};
+
+namespace {
+const int64_t* seg_counts(int A, int64_t cnt[14]) {
+  const int64_t c[14] = {32 * 256, 32, 64 * 512, 64, 64 * 576, 64, (int64_t)kGates * kFeat, (int64_t)kGates * kHid,
+                         kGates, kGates, 512, 1, (int64_t)A * 512, A};
+  for (int i = 0; i < 14; ++i) cnt[i] = c[i];
+  return cnt;
+}
+
+rela_lstmnet_params lparams_at(const rela_r2d2_learner* l, float* base) {
+  rela_lstmnet_params p;
+  const float** f = reinterpret_cast<const float**>(&p);
+  for (int i = 0; i < 14; ++i) f[i] = base + l->off[i];
+  return p;
+}
+
+int repack_r2d2(rela_r2d2_learner* l, bool online, bool target, hipStream_t s) {
+  const int64_t total = (int64_t)kGates * kFeat;
+  if (online) {
+    const rela_lstmnet_params p = lparams_at(l, l->P);
+    int rc = rela_lstmnet_load(l->online, &p, 1, s);
+    if (rc != RELA_OK) return rc;
+    hipLaunchKernelGGL(permute_weights, dim3(ceil_div(64 * 512, 256)), dim3(256), 0, s, kPermConv2, p.conv2_w, l->w2p,
+                       64 * 512);
+    hipLaunchKernelGGL(permute_weights, dim3(ceil_div(64 * 576, 256)), dim3(256), 0, s, kPermConv3, p.conv3_w, l->w3p,
+                       64 * 576);
+    hipLaunchKernelGGL(pack_lstm_learner, dim3(ceil_div(total, 256)), dim3(256), 0, s, p.w_ih, p.w_hh, p.b_ih, p.b_hh,
+                       l->wihT[0], l->wihp, l->whhT[0], l->bsum[0]);
+    RELA_LAUNCH_CHECK();
+  }
+  if (target) {
+    const rela_lstmnet_params p = lparams_at(l, l->PT);
+    int rc = rela_lstmnet_load(l->target, &p, 1, s);
+    if (rc != RELA_OK) return rc;
+    hipLaunchKernelGGL(pack_lstm_learner, dim3(ceil_div(total, 256)), dim3(256), 0, s, p.w_ih, p.w_hh, p.b_ih, p.b_hh,
+                       l->wihT[1], (float*)nullptr, l->whhT[1], l->bsum[1]);
+    RELA_LAUNCH_CHECK();
+  }
+  return RELA_OK;
+}
+
+const char* const kTrunkNames[3] = {"learner_fwd_conv1", "learner_fwd_conv2", "learner_fwd_conv3"};
+
+// forward of one net over the whole batch; leaves H / C of every step in Hs[which] / Cs[which], the activated
+// gates of the training steps in l->gx (save = true) and the dueling Q of the training rows in q_out.
+int forward_net(rela_r2d2_learner* l, int which, int Bn, const uint8_t* obs, const float* legal_train,
+                const uint8_t* term, const float* h0, const float* c0, bool save, float* q_out, hipStream_t s) {
+  const rela_lstmnet* net = which == 0 ? l->online : l->target;
+  const int T = l->T, burn = l->burn, rowsAll = T * Bn, Tt = T - burn;
+  int rc = lstmnet_trunk(net, rowsAll, obs, l->a1, l->a2, l->a3, s, kTrunkNames);
+  if (rc != RELA_OK) return rc;
+  {
+    ProbGateX p{};
+    p.M = rowsAll, p.N = kGates, p.K = kFeat;
+    p.a3 = l->a3, p.wihT = l->wihT[which], p.bias = l->bsum[which], p.gx = l->gx;
+    launch_gemm<TileRows>(p, 1, s, "learner_lstm_gates_x");
+  }
+  float *H = l->Hs[which], *Cc = l->Cs[which];
+  const size_t blk = (size_t)Bn * kHid;
+  RELA_HIP(hipMemcpyAsync(H, h0, blk * sizeof(float), hipMemcpyDeviceToDevice, s));
+  RELA_HIP(hipMemcpyAsync(Cc, c0, blk * sizeof(float), hipMemcpyDeviceToDevice, s));
+  const int cell_grid = ceil_div((int64_t)Bn * kHid, 256);
+  for (int t = 0; t < T; ++t) {
+    if (t == burn && burn > 0) {  // state after the burn-in: zero it where the burn-in was a dummy
+      hipLaunchKernelGGL(zero_hidden_where_terminal, dim3(cell_grid), dim3(256), 0, s, term + (size_t)(burn - 1) * Bn,
+                         Bn, H + t * blk, Cc + t * blk);
+    }
+    ProbRecFwd p{};
+    p.M = Bn, p.N = kGates, p.K = kHid;
+    p.h = H + t * blk, p.whhT = l->whhT[which], p.part = l->rec_part;
+    launch_gemm<TileRec>(p, kRecSplitF, s, "learner_lstm_rec_fwd");
+    ProfScope prof("learner_lstm_cell", s);
+    hipLaunchKernelGGL(lstm_cell_fwd, dim3(cell_grid), dim3(256), 0, s, l->gx + (size_t)t * Bn * kGates,
+                       (const float*)l->rec_part, kRecSplitF, Bn, (const float*)(Cc + t * blk), Cc + (t + 1) * blk,
+                       H + (t + 1) * blk, (save && t >= burn) ? 1 : 0);
+  }
+  RELA_LAUNCH_CHECK();
+  // heads over the training steps: o_t = H[t+1], t in [burn, T)
+  return lstmnet_heads(net, Tt * Bn, H + (size_t)(burn + 1) * blk, legal_train, l->ha, q_out, s, "learner_fwd_heads");
+}
+}  // namespace
+
+extern "C" int rela_r2d2_learner_create(rela_r2d2_learner** out, int num_action, int max_batch, int multi_step,
+                                        float gamma, int seq_len, int burn_in, double eta, int optimizer, float lr,
+                                        float eps, float grad_clip, int device) {
+  RELA_CHECK(out && num_action >= 1 && num_action <= 31 && max_batch >= 1 && max_batch <= 1024 && multi_step >= 1 &&
+                 seq_len >= 1 && burn_in >= 0 && (optimizer == 0 || optimizer == 1),
+             RELA_EINVAL, "rela_r2d2_learner_create: bad arguments (A=%d batch=%d n=%d seq=%d burn=%d optimizer=%d)",
+             num_action, max_batch, multi_step, seq_len, burn_in, optimizer);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    set_last_error("rela_r2d2_learner_create: HIP device %d not available (%d visible); there is no CPU path", device,
+                   ndev);
+    return RELA_ENODEV;
+  }
+  DeviceGuard g(device);
+  auto* l = new rela_r2d2_learner();
+  l->device = device;
+  l->A = num_action, l->Bmax = max_batch, l->seq = seq_len, l->burn = burn_in, l->n = multi_step;
+  l->T = burn_in + seq_len + multi_step;
+  l->gamma_n = (float)pow((double)gamma, (double)multi_step);  // r2d2.py:165
+  l->eta = (float)eta;
+  l->one_minus_eta = (float)(1.0 - eta);  // TorchScript folds (1.0 - self.eta) in double, r2d2.py:119
+  l->opt.optimizer = optimizer, l->opt.lr = lr, l->opt.eps = eps, l->opt.clip = grad_clip;
+  int64_t cnt[14];
+  seg_counts(num_action, cnt);
+  for (int i = 0; i < 14; ++i) l->off[i + 1] = l->off[i] + (cnt[i] + 3) / 4 * 4;
+  const size_t nb = sizeof(float) * (size_t)l->off[14];
+  const size_t B = (size_t)max_batch, A = (size_t)num_action, T = (size_t)l->T, Tt = T - burn_in;
+  const size_t rowsAll = T * B, rowsTr = Tt * B;
+  auto alloc = [&](float** p, size_t floats, bool zero) -> int {
+    RELA_HIP(hipMalloc(p, sizeof(float) * floats));
+    if (zero) RELA_HIP(hipMemset(*p, 0, sizeof(float) * floats));
+    return RELA_OK;
+  };
+#define R2_ALLOC(ptr, floats, zero)               \
+  do {                                            \
+    int _rc = alloc(&(ptr), (floats), (zero));    \
+    if (_rc != RELA_OK) return _rc;               \
+  } while (0)
+  R2_ALLOC(l->P, l->off[14], true);
+  R2_ALLOC(l->PT, l->off[14], true);
+  R2_ALLOC(l->G, l->off[14], true);
+  R2_ALLOC(l->S1, l->off[14], true);
+  R2_ALLOC(l->S2, l->off[14], true);
+  (void)nb;
+  int rc = rela_lstmnet_create(&l->online, num_action, device);
+  if (rc != RELA_OK) return rc;
+  rc = rela_lstmnet_create(&l->target, num_action, device);
+  if (rc != RELA_OK) return rc;
+  R2_ALLOC(l->w2p, 64 * 512, false);
+  R2_ALLOC(l->w3p, 64 * 576, false);
+  for (int w = 0; w < 2; ++w) {
+    R2_ALLOC(l->wihT[w], (size_t)kGates * kFeat, false);
+    R2_ALLOC(l->whhT[w], (size_t)kGates * kHid, false);
+    R2_ALLOC(l->bsum[w], kGates, false);
+    R2_ALLOC(l->Hs[w], (T + 1) * B * kHid, true);
+    R2_ALLOC(l->Cs[w], (T + 1) * B * kHid, true);
+  }
+  R2_ALLOC(l->wihp, (size_t)kGates * kFeat, false);
+  R2_ALLOC(l->a1, rowsAll * kA1, false);
+  R2_ALLOC(l->a2, rowsAll * kA2, false);
+  R2_ALLOC(l->a3, rowsAll * kA3, false);
+  R2_ALLOC(l->gx, rowsAll * kGates, false);
+  {
+    const size_t f = (size_t)kRecSplitF * B * kGates, b = (size_t)kRecSplitB * B * kHid;
+    R2_ALLOC(l->rec_part, f > b ? f : b, false);
+  }
+  R2_ALLOC(l->ha, rowsTr * 32, false);
+  R2_ALLOC(l->q_on, rowsTr * A, false);
+  R2_ALLOC(l->q_tg, rowsTr * A, false);
+  R2_ALLOC(l->qmin, 4, false);
+  R2_ALLOC(l->qa_on, rowsTr, false);
+  R2_ALLOC(l->qa_tg, rowsTr, false);
+  R2_ALLOC(l->dqa, rowsTr, false);
+  R2_ALLOC(l->d_ha, rowsTr * 32, false);
+  R2_ALLOC(l->d_o, rowsTr * kHid, false);
+  R2_ALLOC(l->dc_rec, B * kHid, false);
+  R2_ALLOC(l->d_a3, rowsTr * kA3, false);
+  R2_ALLOC(l->d_a2, rowsTr * kA2, false);
+  R2_ALLOC(l->d_a1, rowsTr * kA1, false);
+  R2_ALLOC(l->col, trunk_col_floats(rowsTr), false);
+  R2_ALLOC(l->part, kTrunkPartFloats, false);
+  R2_ALLOC(l->cpart, (size_t)kColsumBlocks * kGates, false);
+  R2_ALLOC(l->s32, 32, false);
+  R2_ALLOC(l->norm, 2, true);
+  R2_ALLOC(l->loss, 1, true);
+  R2_ALLOC(l->loss_seq, B, true);
+#undef R2_ALLOC
+  RELA_HIP(hipMalloc(&l->npart, sizeof(double) * kNormBlocks));
+  *out = l;
+  return RELA_OK;
+}
+
+extern "C" void rela_r2d2_learner_destroy(rela_r2d2_learner* l) {
+  if (!l) return;
+  DeviceGuard g(l->device);
+  (void)hipDeviceSynchronize();
+  void* ps[] = {l->P,      l->PT,     l->G,       l->S1,      l->S2,      l->w2p,     l->w3p,   l->wihT[0], l->wihT[1],
+                l->whhT[0], l->whhT[1], l->bsum[0], l->bsum[1], l->Hs[0],   l->Hs[1],   l->Cs[0], l->Cs[1],   l->wihp,
+                l->a1,    l->a2,      l->a3,      l->gx,      l->rec_part, l->ha,   l->q_on,    l->q_tg,
+                l->qmin,   l->qa_on,  l->qa_tg,   l->dqa,     l->d_ha,    l->d_o,     l->dc_rec, l->d_a3,   l->d_a2,
+                l->d_a1,   l->col,    l->part,    l->cpart,   l->s32,     l->npart,   l->norm,  l->loss,    l->loss_seq};
+  for (void* p : ps) (void)hipFree(p);
+  rela_lstmnet_destroy(l->online);
+  rela_lstmnet_destroy(l->target);
+  delete l;
+}
+
+extern "C" int rela_r2d2_learner_load(rela_r2d2_learner* l, const rela_lstmnet_params* online,
+                                      const rela_lstmnet_params* target, int on_device, void* stream_) {
+  RELA_CHECK(l && online, RELA_EINVAL, "rela_r2d2_learner_load: bad arguments");
+  hipStream_t s = (hipStream_t)stream_;
+  DeviceGuard g(l->device);
+  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  const float* const* fo = reinterpret_cast<const float* const*>(online);
+  const float* const* ft = reinterpret_cast<const float* const*>(target ? target : online);
+  int64_t cnt[14];
+  seg_counts(l->A, cnt);
+  for (int i = 0; i < 14; ++i) {
+    RELA_CHECK(fo[i] && ft[i], RELA_EINVAL, "rela_r2d2_learner_load: parameter %d is NULL", i);
+    RELA_HIP(hipMemcpyAsync(l->P + l->off[i], fo[i], sizeof(float) * cnt[i], kind, s));
+    RELA_HIP(hipMemcpyAsync(l->PT + l->off[i], ft[i], sizeof(float) * cnt[i], kind, s));
+  }
+  if (!on_device) RELA_HIP(hipStreamSynchronize(s));  // the host buffers may go away
+  const size_t nb = sizeof(float) * (size_t)l->off[14];
+  RELA_HIP(hipMemsetAsync(l->S1, 0, nb, s));
+  RELA_HIP(hipMemsetAsync(l->S2, 0, nb, s));
+  l->opt.adam_t = 0;
+  int rc = repack_r2d2(l, true, true, s);
+  if (rc != RELA_OK) return rc;
+  l->loaded = true;
+  return RELA_OK;
+}
+
+extern "C" int rela_r2d2_learner_sync_target(rela_r2d2_learner* l, void* stream_) {
+  RELA_CHECK(l && l->loaded, RELA_ESTATE, "rela_r2d2_learner_sync_target: parameters were never loaded");
+  hipStream_t s = (hipStream_t)stream_;
+  DeviceGuard g(l->device);
+  RELA_HIP(hipMemcpyAsync(l->PT, l->P, sizeof(float) * (size_t)l->off[14], hipMemcpyDeviceToDevice, s));
+  return repack_r2d2(l, false, true, s);
+}
+
+extern "C" int rela_r2d2_learner_params(rela_r2d2_learner* l, rela_lstmnet_params* online_out,
+                                        rela_lstmnet_params* target_out) {
+  RELA_CHECK(l, RELA_EINVAL, "rela_r2d2_learner_params: bad arguments");
+  if (online_out) *online_out = lparams_at(l, l->P);
+  if (target_out) *target_out = lparams_at(l, l->PT);
+  return RELA_OK;
+}
+
+extern "C" int rela_r2d2_learner_grads(rela_r2d2_learner* l, rela_lstmnet_params* grads_out) {
+  RELA_CHECK(l && grads_out, RELA_EINVAL, "rela_r2d2_learner_grads: bad arguments");
+  *grads_out = lparams_at(l, l->G);
+  return RELA_OK;
+}
+
+extern "C" int rela_r2d2_learner_flat(rela_r2d2_learner* l, float** params_dev, float** grads_dev, int64_t* count) {
+  RELA_CHECK(l, RELA_EINVAL, "rela_r2d2_learner_flat: bad arguments");
+  if (params_dev) *params_dev = l->P;
+  if (grads_dev) *grads_dev = l->G;
+  if (count) *count = l->off[14];
+  return RELA_OK;
+}
+
+extern "C" const float* rela_r2d2_learner_stats_dev(const rela_r2d2_learner* l) { return l ? l->norm : nullptr; }
+
+extern "C" int rela_r2d2_learner_backward(rela_r2d2_learner* l, int batch, const void* const* rows_dev,
+                                          const float* weight_dev, float* priority_dev, float* loss_dev,
+                                          float* loss_seq_dev, void* stream_) {
+  RELA_CHECK(l && l->loaded, RELA_ESTATE, "rela_r2d2_learner_backward: parameters were never loaded");
+  RELA_CHECK(batch >= 1 && batch <= l->Bmax && rows_dev && weight_dev && priority_dev, RELA_EINVAL,
+             "rela_r2d2_learner_backward: bad arguments (batch %d, max %d)", batch, l->Bmax);
+  hipStream_t s = (hipStream_t)stream_;
+  DeviceGuard g(l->device);
+  const int Bn = batch, A = l->A, T = l->T, burn = l->burn, Tt = T - burn, rowsTr = Tt * Bn;
+  // RNNTransition batch, time-major (types.cc:140-182), in the order of the 10-field sequence schema
+  const uint8_t* obs = static_cast<const uint8_t*>(rows_dev[0]);     // [T][B][4][84][84]
+  const float* legal = static_cast<const float*>(rows_dev[2]);       // [T][B][A]
+  const int64_t* act = static_cast<const int64_t*>(rows_dev[3]);     // [T][B]
+  const float* reward = static_cast<const float*>(rows_dev[4]);      // [T][B]
+  const uint8_t* term = static_cast<const uint8_t*>(rows_dev[5]);    // [T][B]
+  const float* boot = static_cast<const float*>(rows_dev[6]);        // [T][B]
+  const float* h0 = static_cast<const float*>(rows_dev[7]);          // [1][B][512]
+  const float* c0 = static_cast<const float*>(rows_dev[8]);
+  const float* seq_len = static_cast<const float*>(rows_dev[9]);     // [B]
+  RELA_CHECK(obs && legal && act && reward && term && boot && h0 && c0 && seq_len, RELA_EINVAL,
+             "rela_r2d2_learner_backward: a batch field is NULL");
+  const size_t tr0 = (size_t)burn * Bn;  // first training row
+  const float* legal_tr = legal + tr0 * A;
+  const int64_t* act_tr = act + tr0;
+  // target net first (no gradient, :158-159), then the online net, whose activations stay for the backward pass
+  int rc = forward_net(l, 1, Bn, obs, legal_tr, term, h0, c0, false, l->q_tg, s);
+  if (rc != RELA_OK) return rc;
+  rc = forward_net(l, 0, Bn, obs, legal_tr, term, h0, c0, true, l->q_on, s);
+  if (rc != RELA_OK) return rc;
+  {
+    ProfScope prof("learner_seq_td", s);
+    hipLaunchKernelGGL(q_min_all, dim3(1), dim3(1024), 0, s, (const float*)l->q_on, (int64_t)rowsTr * A, l->qmin);
+    hipLaunchKernelGGL(seq_select, dim3(ceil_div(rowsTr, 256)), dim3(256), 0, s, (const float*)l->q_on,
+                       (const float*)l->q_tg, legal_tr, act_tr, (const float*)l->qmin, rowsTr, A, l->qa_on, l->qa_tg);
+    hipLaunchKernelGGL(seq_td_loss, dim3(1), dim3(1024), 0, s, (const float*)l->qa_on, (const float*)l->qa_tg,
+                       reward + tr0, boot + tr0, seq_len, weight_dev, Bn, l->seq, burn, l->n, l->gamma_n, l->eta,
+                       l->one_minus_eta, l->dqa, priority_dev, l->loss_seq, l->loss);
+    hipLaunchKernelGGL(seq_head_grad, dim3(ceil_div((int64_t)rowsTr * 32, 256)), dim3(256), 0, s, (const float*)l->dqa,
+                       act_tr, legal_tr, rowsTr, A, l->d_ha);
+  }
+  if (loss_dev) RELA_HIP(hipMemcpyAsync(loss_dev, l->loss, sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (loss_seq_dev)
+    RELA_HIP(hipMemcpyAsync(loss_seq_dev, l->loss_seq, sizeof(float) * Bn, hipMemcpyDeviceToDevice, s));
+
+  const rela_lstmnet_params P = lparams_at(l, l->P);
+  float* Gm[14];  // gradient tensors in rela_lstmnet_params order
+  for (int i = 0; i < 14; ++i) Gm[i] = l->G + l->off[i];
+  const size_t blk = (size_t)Bn * kHid;
+  float *H = l->Hs[0], *Cc = l->Cs[0];
+  const float* o_tr = H + (size_t)(burn + 1) * blk;  // LSTM outputs of the training steps
+  // heads: d_o, dW, db
+  {
+    ProbHeadDgradSeq p{};
+    p.M = rowsTr, p.N = kHid, p.K = 32;
+    p.d_ha = l->d_ha, p.a_w = P.a_w, p.v_w = P.v_w, p.d_o = l->d_o, p.A = A;
+    launch_gemm<TileRows>(p, 1, s, "learner_dgrad_heads");
+  }
+  {
+    ProbHeadWgrad p{};
+    p.M = 32, p.N = kHid, p.K = rowsTr;
+    p.d_ha = l->d_ha, p.h = o_tr, p.g_a_w = Gm[12], p.g_v_w = Gm[10], p.A = A;
+    launch_gemm<TileW32r>(p, 1, s, "learner_wgrad_heads");
+  }
+  colsum_launch(l->d_ha, rowsTr, 32, l->cpart, l->s32, s);
+  hipLaunchKernelGGL(head_bias_grad, dim3(1), dim3(32), 0, s, (const float*)l->s32, A, Gm[13], Gm[11]);
+  // BPTT over the training steps, newest first; the activated gates in gx become the gate gradients in place
+  RELA_HIP(hipMemsetAsync(l->dc_rec, 0, blk * sizeof(float), s));
+  const int cell_grid = ceil_div((int64_t)Bn * kHid, 256);
+  float* ga_tr = l->gx + tr0 * kGates;
+  for (int t = Tt - 1; t >= 0; --t) {
+    const int gs = burn + t;  // global step
+    {
+      ProfScope prof("learner_lstm_cell_bwd", s);
+      hipLaunchKernelGGL(lstm_cell_bwd, dim3(cell_grid), dim3(256), 0, s, ga_tr + (size_t)t * Bn * kGates,
+                         (const float*)(l->d_o + (size_t)t * blk), (const float*)l->rec_part,
+                         t == Tt - 1 ? 0 : kRecSplitB, Bn, (const float*)(Cc + (size_t)(gs + 1) * blk),
+                         (const float*)(Cc + (size_t)gs * blk), l->dc_rec);
+    }
+    if (t > 0) {  // the state entering the first training step comes from the burn-in: no gradient (:144-147)
+      ProbRecBwd p{};
+      p.M = Bn, p.N = kHid, p.K = kGates;
+      p.dg = ga_tr + (size_t)t * Bn * kGates, p.whh = P.w_hh, p.part = l->rec_part;
+      launch_gemm<TileRec>(p, kRecSplitB, s, "learner_lstm_rec_bwd");
+    }
+  }
+  const float* DG = ga_tr;                          // [rowsTr][2048]
+  const float* hprev = H + (size_t)burn * blk;      // h_{t-1} of training step t = H[burn + t]
+  const float* a3_tr = l->a3 + tr0 * kA3;
+  {
+    ProbWhh p{};
+    p.M = kGates, p.N = kHid, p.K = rowsTr;
+    p.dg = DG, p.hprev = hprev, p.out = Gm[7];
+    launch_gemm<TileWg>(p, 1, s, "learner_wgrad_lstm_hh");
+  }
+  {
+    ProbWih p{};
+    p.M = kGates, p.N = kFeat, p.K = rowsTr;
+    p.dg = DG, p.a3 = a3_tr, p.out = Gm[6];
+    launch_gemm<TileWg>(p, 1, s, "learner_wgrad_lstm_ih");
+  }
+  colsum_launch(DG, rowsTr, kGates, l->cpart, Gm[8], s);  // bias_ih_l0 and bias_hh_l0 see the same gradient
+  RELA_HIP(hipMemcpyAsync(Gm[9], Gm[8], sizeof(float) * kGates, hipMemcpyDeviceToDevice, s));
+  {
+    ProbIhDgrad p{};
+    p.M = rowsTr, p.N = kFeat, p.K = kGates;
+    p.dg = DG, p.wihp = l->wihp, p.a3 = a3_tr, p.d_a3 = l->d_a3;
+    launch_gemm<TileRows>(p, 1, s, "learner_dgrad_lstm_ih");
+  }
+  {
+    TrunkBwd t{};
+    t.Bn = rowsTr, t.obs = obs + tr0 * 28224, t.a1 = l->a1 + tr0 * kA1, t.a2 = l->a2 + tr0 * kA2, t.d_a3 = l->d_a3;
+    t.d_a2 = l->d_a2, t.d_a1 = l->d_a1, t.col = l->col, t.part = l->part, t.cpart = l->cpart;
+    t.w2p = l->w2p, t.w3p = l->w3p;
+    t.g_c1w = Gm[0], t.g_c1b = Gm[1], t.g_c2w = Gm[2], t.g_c2b = Gm[3], t.g_c3w = Gm[4], t.g_c3b = Gm[5];
+    trunk_backward(t, s);
+  }
+  RELA_LAUNCH_CHECK();
+  return RELA_OK;
+}
+
+extern "C" int rela_r2d2_learner_apply(rela_r2d2_learner* l, void* stream_) {
+  RELA_CHECK(l && l->loaded, RELA_ESTATE, "rela_r2d2_learner_apply: parameters were never loaded");
+  hipStream_t s = (hipStream_t)stream_;
+  DeviceGuard g(l->device);
+  optimizer_apply(l->opt, l->P, l->G, l->S1, l->S2, l->off[14], l->npart, l->norm, s);
+  RELA_LAUNCH_CHECK();
+  return repack_r2d2(l, true, false, s);
+}

@@ -201,6 +201,154 @@ class HipApexLearner:
             self.close()
 
 
+class HipR2D2Learner:
+    """The R2D2 learner step in HIP (rela_r2d2_learner_*, csrc/learner_r2d2.hip): the counterpart of
+    `loss, priority = agent.loss(batch); (loss * weight).mean().backward(); clip_grad_norm_; optim.step()`
+    of pyrela/main.py:226-239 for R2D2Agent + AtariLSTMNet (pyrela/r2d2.py:122-206, net.py:127-163), without
+    PyTorch autograd: burn-in unroll, training unroll of online and target nets, sequence TD error, BPTT, Adam.
+
+        learner = HipR2D2Learner.from_agent(agent, batch, lr=..., eps=...)
+        batch, weight = replay.sample(B, device)          # rela.RNNPrioritizedReplay
+        loss, priority = learner.step(batch, weight)
+        replay.update_priority(priority)
+    """
+
+    KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
+            "lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0", "fc_v.weight", "fc_v.bias",
+            "fc_a.weight", "fc_a.bias")
+    SHAPES = lambda A: ((32, 4, 8, 8), (32,), (64, 32, 4, 4), (64,), (64, 64, 3, 3), (64,), (2048, 3136), (2048, 512),  # noqa: E731
+                        (2048,), (2048,), (1, 512), (1,), (A, 512), (A,))
+
+    def __init__(self, num_action, max_batch, multi_step, gamma, seq_len, burn_in, eta, optimizer="adam", lr=6.25e-5,
+                 eps=1.5e-4, grad_clip=40.0, device="cuda:0"):
+        import ctypes as C
+
+        from . import _capi as capi
+
+        self._C, self._capi = C, capi
+        self.device = torch.device(device)
+        self.num_action, self.max_batch = num_action, max_batch
+        self.seq_len, self.burn_in, self.multi_step = seq_len, burn_in, multi_step
+        h = C.c_void_p()
+        capi.check(capi.lib.rela_r2d2_learner_create(C.byref(h), num_action, max_batch, multi_step, gamma, seq_len,
+                                                     burn_in, float(eta), {"rmsprop": 0, "adam": 1}[optimizer], lr, eps,
+                                                     grad_clip, self.device.index or 0), "rela_r2d2_learner_create")
+        self.h = h
+        self._prio = torch.empty(max_batch, dtype=torch.float32, device=self.device)
+        self._loss = torch.empty(1, dtype=torch.float32, device=self.device)
+        self._loss_seq = torch.empty(max_batch, dtype=torch.float32, device=self.device)
+
+    @classmethod
+    def from_agent(cls, agent, max_batch, **kw):
+        """agent: pyrela R2D2Agent (online_net / target_net AtariLSTMNet, multi_step, gamma, eta, seq_len, burn_in)."""
+        dev = next(agent.online_net.parameters()).device
+        num_action = agent.online_net.fc_a.weight.shape[0]
+        self = cls(num_action, max_batch, agent.multi_step, agent.gamma, agent.seq_len, agent.burn_in, agent.eta,
+                   device=str(dev), **kw)
+        self.load_state_dicts(agent.online_net.state_dict(), agent.target_net.state_dict())
+        return self
+
+    def _stream(self):
+        return self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _params(self, sd, keep):
+        p = self._capi.LSTMNetParams()
+        for (field, _), key in zip(self._capi.LSTMNetParams._fields_, self.KEYS):
+            t = sd[key].detach().to(self.device, torch.float32).contiguous()
+            keep.append(t)
+            setattr(p, field, t.data_ptr())
+        return p
+
+    def load_state_dicts(self, online_sd, target_sd=None):
+        C, capi = self._C, self._capi
+        keep = []
+        po = self._params(online_sd, keep)
+        pt = self._params(target_sd, keep) if target_sd is not None else None
+        capi.check(capi.lib.rela_r2d2_learner_load(self.h, C.byref(po), C.byref(pt) if pt is not None else None, 1,
+                                                   self._stream()), "rela_r2d2_learner_load")
+        torch.cuda.current_stream(self.device).synchronize()  # sources may be temporaries
+
+    def sync_target_with_online(self):
+        self._capi.check(self._capi.lib.rela_r2d2_learner_sync_target(self.h, self._stream()), "sync_target")
+
+    def state_dict(self, which="online"):
+        """Zero-copy views of the flat buffers as a state_dict ("online" | "target" | "grads")."""
+        from .engine import dev_view
+
+        C, capi = self._C, self._capi
+        p = capi.LSTMNetParams()
+        if which == "grads":
+            capi.check(capi.lib.rela_r2d2_learner_grads(self.h, C.byref(p)), "rela_r2d2_learner_grads")
+        elif which == "online":
+            capi.check(capi.lib.rela_r2d2_learner_params(self.h, C.byref(p), None), "rela_r2d2_learner_params")
+        else:
+            capi.check(capi.lib.rela_r2d2_learner_params(self.h, None, C.byref(p)), "rela_r2d2_learner_params")
+        shapes = HipR2D2Learner.SHAPES(self.num_action)
+        return {key: dev_view(getattr(p, field), shape, torch.float32, self.device)
+                for (field, _), key, shape in zip(capi.LSTMNetParams._fields_, self.KEYS, shapes)}
+
+    def flat(self):
+        """(params, grads) as flat f32 views -- the all-reduce bucket of data-parallel learners (30 MB)."""
+        from .engine import dev_view
+
+        C, capi = self._C, self._capi
+        pp, gp, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        capi.check(capi.lib.rela_r2d2_learner_flat(self.h, C.byref(pp), C.byref(gp), C.byref(n)), "flat")
+        return (dev_view(pp.value, (n.value,), torch.float32, self.device),
+                dev_view(gp.value, (n.value,), torch.float32, self.device))
+
+    def stats(self):
+        from .engine import dev_view
+
+        return dev_view(self._capi.lib.rela_r2d2_learner_stats_dev(self.h), (2,), torch.float32, self.device)
+
+    def backward(self, batch, weight):
+        """batch: RNNTransition-shaped (time-major [T, B, ...] cuda tensors: obs{s, eps, legal_move}, h0{h0, c0},
+        action{a}, reward, terminal, bootstrap, seq_len); weight: cuda f32[B].
+        -> (mean(loss * weight)[1], aggregated priority[B], per-sequence loss[B])."""
+        C, capi = self._C, self._capi
+        B = weight.numel()
+        dev = self.device
+        fields = [batch.obs["s"], batch.obs["eps"].float(), batch.obs["legal_move"].float(), batch.action["a"],
+                  batch.reward.float(), batch.terminal.to(torch.uint8), batch.bootstrap.float(), batch.h0["h0"].float(),
+                  batch.h0["c0"].float(), batch.seq_len.float()]
+        keep = [f.to(dev).contiguous() for f in fields]
+        T = self.burn_in + self.seq_len + self.multi_step
+        assert keep[0].dtype == torch.uint8 and keep[0].shape[:2] == (T, B), (keep[0].shape, T, B)
+        assert keep[3].dtype == torch.int64
+        w = weight.detach().to(dev).float().contiguous()
+        rows = (C.c_void_p * 10)(*[x.data_ptr() for x in keep])
+        self._keep = (keep, w)
+        capi.check(capi.lib.rela_r2d2_learner_backward(self.h, B, rows, C.c_void_p(w.data_ptr()),
+                                                       C.c_void_p(self._prio.data_ptr()),
+                                                       C.c_void_p(self._loss.data_ptr()),
+                                                       C.c_void_p(self._loss_seq.data_ptr()), self._stream()),
+                   "rela_r2d2_learner_backward")
+        return self._loss, self._prio[:B], self._loss_seq[:B]
+
+    def apply(self):
+        self._capi.check(self._capi.lib.rela_r2d2_learner_apply(self.h, self._stream()), "rela_r2d2_learner_apply")
+
+    def step(self, batch, weight, world_size=1, group=None):
+        loss, prio, _ = self.backward(batch, weight)
+        if world_size > 1:
+            g = self.flat()[1]
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+            g.div_(world_size)
+        self.apply()
+        return loss, prio
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._capi.lib.rela_r2d2_learner_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        capi = getattr(self, "_capi", None)
+        if capi is not None and getattr(capi, "lib", None) is not None:
+            self.close()
+
+
 # ---- weight publish to actor-only ranks (SURVEY 8e: C3 / C4 layouts) ------------------------------
 FFNET_KEYS = HipApexLearner.KEYS
 

@@ -60,7 +60,8 @@ def parse_args(argv=None):
     p.add_argument("--act_device", type=str, default="cuda:0")
     p.add_argument("--actor_sync_freq", type=int, default=20)
     p.add_argument("--hip_learner", type=int, default=1,
-                   help="apex: run loss/backward/clip/RMSprop through csrc/learner.hip instead of autograd")
+                   help="run loss / backward / clip / optimiser through the hand-written HIP learner step "
+                        "(csrc/learner.hip for apex, csrc/learner_r2d2.hip for r2d2) instead of PyTorch autograd")
     return p.parse_args(argv)
 
 
@@ -82,11 +83,11 @@ def train(args, on_epoch=None):
         optim = torch.optim.RMSprop(agent.online_net.parameters(), lr=args.lr, eps=args.eps)
         replay_class = rela.FFPrioritizedReplay
     learner = None
-    if args.algo == "apex" and getattr(args, "hip_learner", 1):
-        from rela_amd.learner import HipApexLearner
+    if getattr(args, "hip_learner", 1):  # hand-written HIP learner step (csrc/learner.hip, csrc/learner_r2d2.hip)
+        from rela_amd.learner import HipApexLearner, HipR2D2Learner
 
-        learner = HipApexLearner.from_agent(agent, args.batchsize, lr=args.lr, eps=args.eps,
-                                            grad_clip=args.grad_clip)
+        cls = HipR2D2Learner if args.algo == "r2d2" else HipApexLearner
+        learner = cls.from_agent(agent, args.batchsize, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip)
 
     act_devices = args.act_device.split(",")
     if len(act_devices) != 1:

@@ -117,16 +117,18 @@ def test_lockstep_r2d2_c4_shape_matches_reference(mods):
     assert max(lens) == C["burn_in"] + C["seq_len"] and min(lens) < max(lens)  # full and short sequences were sampled
 
 
-def test_r2d2_training_entry_point_runs(mods, capsys):
+@pytest.mark.parametrize("hip_learner", [1, 0])
+def test_r2d2_training_entry_point_runs(mods, capsys, hip_learner):
     """--algo r2d2 on 2 threads x 4 envs: sequences (seq 8 / burn 4 / n 3) flow from C++ actor threads
-    through RNNPrioritizedReplay into the R2D2Agent learner (burn-in unroll, Adam, aggregate priority)."""
+    through RNNPrioritizedReplay into the R2D2 learner step (burn-in unroll, BPTT, Adam, aggregate priority):
+    hand-written HIP (csrc/learner_r2d2.hip) or PyTorch autograd as in the reference."""
     from rela_amd.pyrela import main as entry
 
     args = entry.parse_args(["--algo", "r2d2", "--num_thread", "2", "--num_game_per_thread", "4", "--batchsize", "8",
                              "--epoch_len", "6", "--num_epoch", "2", "--burn_in_frames", "16",
                              "--replay_buffer_size", "64", "--episode_len", "30", "--actor_sync_freq", "3",
                              "--seq_len", "8", "--seq_burn_in", "4", "--priority_exponent", "0.9",
-                             "--importance_exponent", "0.6"])
+                             "--importance_exponent", "0.6", "--hip_learner", str(hip_learner)])
     hist = entry.train(args)
     out = capsys.readouterr().out
     assert "Speed: train: " in out
@@ -398,12 +400,13 @@ def test_benchmark_driver_tiny_grid(mods, capsys, algo):
 
     from rela_amd.pyrela import benchmark
 
-    argv = ["--grid", "2x4,3x2", "--epoch_sec", "0.6", "--num_epoch", "2", "--episode_len", "30"]
+    # the replay must not fill during the phase WITHOUT a sampler (back-pressure would park the actors, H10)
+    argv = ["--grid", "2x4,3x2", "--epoch_sec", "0.5", "--num_epoch", "2", "--episode_len", "30"]
     if algo == "r2d2":
-        argv += ["--algo", "r2d2", "--seq_len", "8", "--seq_burn_in", "4", "--replay_buffer_size", "128",
+        argv += ["--algo", "r2d2", "--seq_len", "8", "--seq_burn_in", "4", "--replay_buffer_size", "8192",
                  "--burn_in_frames", "70"]
     else:
-        argv += ["--replay_buffer_size", "2048", "--burn_in_frames", "600"]
+        argv += ["--replay_buffer_size", "65536", "--burn_in_frames", "600"]
     rows = benchmark.main(argv)
     out = capsys.readouterr().out
     assert [(r[0], r[1]) for r in rows] == [(2, 4), (3, 2)]

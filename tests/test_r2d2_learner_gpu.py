@@ -1,0 +1,210 @@
+"""R2D2 learner step on the device.
+
+  1. rela_amd/pyrela/r2d2.py on PyTorch-ROCm autograd ON THE GPU against vectors recorded from the REAL
+     reference's R2D2Agent on CPU (tests/golden/r2d2_loss_A6_B3.json: loss per sequence, aggregated priority,
+     gradients of (loss * weight).mean() w.r.t. every online parameter).
+  2. the hand-written HIP step (csrc/learner_r2d2.hip via rela_amd.learner.HipR2D2Learner) against the same
+     reference vectors: loss / priority 1e-4, every gradient tensor 2e-3.
+  3. the HIP step against PyTorch autograd on the device at BASELINE config C4's learner shape
+     (B = 64, T = 40 + 80 + 3 = 123, A = 18): every gradient tensor 2e-3 relative to its largest entry.
+  4. clip_grad_norm_ + Adam arithmetic and a 2-step trajectory against torch.optim.Adam.
+"""
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _agent(A, n, gamma, eta, seq, burn, on_seed, tg_seed, device):
+    import torch
+
+    from rela_amd.pyrela.net import AtariLSTMNet
+    from rela_amd.pyrela.r2d2 import R2D2Agent
+    from synth import synth_lstm_params
+
+    agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, A), "cpu", n, gamma, eta, seq, burn, 0)
+    sd = {}
+    for prefix, seed in (("online_net.", on_seed), ("target_net.", tg_seed)):
+        for k, v in synth_lstm_params(A, seed).items():
+            sd[prefix + k] = torch.from_numpy(v)
+    agent.load_state_dict(sd)
+    return agent.to(device)
+
+
+def _golden_batch(g, device):
+    import torch
+
+    from oracle_lib import h2f
+    from synth import synth_obs
+
+    B, seq, burn, n = g["B"], g["seq_len"], g["burn_in"], g["multi_step"]
+    T = burn + seq + n
+    m = g["batch"]
+    f32 = lambda x: torch.tensor(x, dtype=torch.float32, device=device)
+    hid = lambda key: torch.tensor([h2f(v) for v in m[key]], dtype=torch.float32, device=device).reshape(1, B, 512)
+    batch = SimpleNamespace(
+        obs={"s": torch.from_numpy(synth_obs(T * B, m["obs_seed"]).reshape(T, B, 4, 84, 84)).to(device),
+             "legal_move": f32(m["legal"]), "eps": torch.zeros(T, B, 1, device=device)},
+        h0={"h0": hid("h0"), "c0": hid("c0")}, action={"a": torch.tensor(m["action"], dtype=torch.int64, device=device)},
+        reward=f32(m["reward"]), terminal=f32(m["terminal"]).bool(), bootstrap=f32(m["bootstrap"]),
+        seq_len=f32(m["seq_len"]))
+    return batch, f32(m["weight"])
+
+
+def _check_grads_vs_golden(named_grads, g):
+    import torch
+
+    assert set(named_grads) == set(g["grads"])
+    for key, rec in g["grads"].items():
+        t = named_grads[key].detach().double().reshape(-1).cpu()
+        scale = rec["absmax"] + 1e-12
+        np.testing.assert_allclose(float(t.norm()), rec["l2"], rtol=2e-3, atol=1e-4 * scale, err_msg=key)
+        np.testing.assert_allclose(t[torch.tensor(rec["idx"])].numpy(), np.array(rec["val"]), rtol=2e-3,
+                                   atol=2e-3 * scale, err_msg=key)
+
+
+def test_pytorch_r2d2_loss_on_gpu_matches_reference_golden():
+    import torch
+
+    g = json.load(open(os.path.join(GOLD, "r2d2_loss_A6_B3.json")))
+    torch.backends.cudnn.allow_tf32 = False
+    agent = _agent(g["num_action"], g["multi_step"], g["gamma"], g["eta"], g["seq_len"], g["burn_in"], g["online_seed"],
+                   g["target_seed"], "cuda:0")
+    batch, weight = _golden_batch(g, "cuda:0")
+    loss, prio = agent.loss(batch)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), np.array(g["loss"]), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(prio.cpu().numpy(), np.array(g["priority"]), rtol=1e-4, atol=1e-5)
+    (loss * weight).mean().backward()
+    _check_grads_vs_golden({k: v.grad for k, v in agent.online_net.named_parameters()}, g)
+
+
+def test_hip_r2d2_learner_matches_reference_golden():
+    """Loss per sequence, aggregated priority and every gradient tensor of the hand-written step against the
+    REAL reference (padded short sequence, dummy burn-in with zeroed state, illegal actions)."""
+    import torch
+
+    from rela_amd.learner import HipR2D2Learner
+
+    g = json.load(open(os.path.join(GOLD, "r2d2_loss_A6_B3.json")))
+    agent = _agent(g["num_action"], g["multi_step"], g["gamma"], g["eta"], g["seq_len"], g["burn_in"], g["online_seed"],
+                   g["target_seed"], "cuda:0")
+    learner = HipR2D2Learner.from_agent(agent, g["B"], grad_clip=1e9)
+    batch, weight = _golden_batch(g, "cuda:0")
+    loss, prio, loss_seq = learner.backward(batch, weight)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(loss_seq.cpu().numpy(), np.array(g["loss"]), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(prio.cpu().numpy(), np.array(g["priority"]), rtol=1e-4, atol=1e-5)
+    exp_total = float((np.array(g["loss"]) * np.array(g["batch"]["weight"])).mean())
+    np.testing.assert_allclose(float(loss.cpu()[0]), exp_total, rtol=1e-4)
+    _check_grads_vs_golden(learner.state_dict("grads"), g)
+    learner.close()
+
+
+def _random_batch(rng, A, B, seq, burn, n, device):
+    """RNNTransition-shaped batch with consistent padding (as tests/golden/make_golden.py:_r2d2_batch)."""
+    import torch
+
+    T = burn + seq + n
+    s = torch.randint(0, 256, (T, B, 4, 84, 84), dtype=torch.uint8, device=device)
+    legal = (rng.uniform(size=(T, B, A)) < 0.85).astype(np.float32)
+    legal[:, :, 0] = 1.0
+    lens = rng.integers(burn + 2, burn + seq + 1, B).astype(np.float32)
+    lens[0] = burn + seq
+    term = np.zeros((T, B), np.float32)
+    for b in range(B):
+        if lens[b] < burn + seq:
+            term[int(lens[b]) - 1:, b] = 1.0
+    start = rng.uniform(size=B) < 0.25  # sequences that start an episode: padLike'd burn-in (terminal = 1)
+    term[:burn, start] = 1.0
+    boot = (1.0 - np.maximum.reduce([np.roll(term, -k, 0) for k in range(n)])).astype(np.float32)
+    boot[T - n:] = 0.0
+    action = np.zeros((T, B), np.int64)
+    for t in range(T):
+        for b in range(B):
+            action[t, b] = rng.choice(np.flatnonzero(legal[t, b]))
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    batch = SimpleNamespace(
+        obs={"s": s, "legal_move": tt(legal), "eps": torch.zeros(T, B, 1, device=device)},
+        h0={"h0": tt(rng.normal(0, 0.3, (1, B, 512)).astype(np.float32)),
+            "c0": tt(rng.normal(0, 0.3, (1, B, 512)).astype(np.float32))},
+        action={"a": tt(action)}, reward=tt(rng.normal(0, 1.2, (T, B)).astype(np.float32)), terminal=tt(term).bool(),
+        bootstrap=tt(boot), seq_len=tt(lens))
+    return batch, tt(rng.uniform(0.2, 1.0, B).astype(np.float32))
+
+
+@pytest.mark.parametrize("A,B,seq,burn,n", [(18, 64, 80, 40, 3), (6, 5, 7, 0, 2), (18, 33, 12, 6, 3)])
+def test_hip_r2d2_learner_matches_autograd(A, B, seq, burn, n):
+    """C4's learner shape (B = 64, seq 80 / burn-in 40 / n 3 -> 7,872 frames, 83 BPTT steps), a batch without
+    burn-in and a ragged batch: loss, priorities and every gradient tensor against PyTorch autograd of
+    rela_amd/pyrela/r2d2.py on the same device."""
+    import torch
+
+    from rela_amd.learner import HipR2D2Learner
+
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    rng = np.random.default_rng(A * 1000 + B)
+    agent = _agent(A, n, 0.997, 0.9, seq, burn, 71, 72, "cuda:0")
+    batch, weight = _random_batch(rng, A, B, seq, burn, n, "cuda:0")
+    learner = HipR2D2Learner.from_agent(agent, B, grad_clip=1e9)
+    loss, prio, loss_seq = learner.backward(batch, weight)
+    torch.cuda.synchronize()
+    ref_loss, ref_prio = agent.loss(batch, sync_priority=False)
+    (ref_loss * weight).mean().backward()
+    np.testing.assert_allclose(loss_seq.cpu().numpy(), ref_loss.detach().cpu().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(prio.cpu().numpy(), ref_prio.cpu().numpy(), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(float(loss.cpu()[0]), float((ref_loss * weight).mean()), rtol=2e-4)
+    grads = learner.state_dict("grads")
+    for key, p in agent.online_net.named_parameters():
+        ref = p.grad.detach()
+        scale = float(ref.abs().max()) + 1e-12
+        err = float((grads[key] - ref).abs().max())
+        assert err <= 2e-3 * scale, (key, err, scale)
+    learner.close()
+
+
+def test_hip_r2d2_learner_adam_step_and_trajectory():
+    """clip_grad_norm_(40) + Adam(lr, eps) (pyrela/main.py:124-126,233-238) on the flat buffers, two
+    consecutive steps on fresh batches, against torch.optim.Adam driven by autograd."""
+    import torch
+
+    from rela_amd.learner import HipR2D2Learner
+
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    A, B, seq, burn, n = 6, 8, 10, 4, 3
+    rng = np.random.default_rng(5)
+    agent = _agent(A, n, 0.997, 0.9, seq, burn, 81, 82, "cuda:0")
+    lr, eps, clip = 1e-3, 1.5e-4, 0.5  # a clip small enough to bite
+    learner = HipR2D2Learner.from_agent(agent, B, lr=lr, eps=eps, grad_clip=clip)
+    optim = torch.optim.Adam(agent.online_net.parameters(), lr=lr, eps=eps)
+    for step in range(2):
+        batch, weight = _random_batch(rng, A, B, seq, burn, n, "cuda:0")
+        learner.step(batch, weight)
+        loss, _ = agent.loss(batch, sync_priority=False)
+        (loss * weight).mean().backward()
+        norm = torch.nn.utils.clip_grad_norm_(agent.online_net.parameters(), clip)
+        optim.step()
+        optim.zero_grad()
+        torch.cuda.synchronize()
+        st = learner.stats().cpu().numpy()
+        np.testing.assert_allclose(st[0], float(norm), rtol=2e-3)
+        assert st[1] < 1.0
+        sd = learner.state_dict("online")
+        for key, p in agent.online_net.named_parameters():
+            # an Adam step moves every weight by ~lr; compare the UPDATE, not the weight
+            np.testing.assert_allclose(sd[key].cpu().numpy(), p.detach().cpu().numpy(), rtol=0, atol=0.05 * lr,
+                                       err_msg="%s after step %d" % (key, step))
+    learner.sync_target_with_online()
+    torch.cuda.synchronize()
+    tg = learner.state_dict("target")
+    on = learner.state_dict("online")
+    for key in on:
+        assert torch.equal(tg[key], on[key])
+    learner.close()
