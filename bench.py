@@ -186,6 +186,169 @@ def cpu_baseline(budget_s=15.0):
                       % (n_env, K_GAMES, cores, dt)}
 
 
+# ---- R2D2 (BASELINE config C4's shapes on one GPU per rank) ------------------------------------------
+R2_ROWS, R2_K = 3200, 80            # 40 actor threads x 80 envs per GPU
+R2_SEQ, R2_BURN, R2_ETA = 80, 40, 0.9  # pyrela/scripts/ref_run_r2d2.sh:12-18
+R2_BATCH, R2_ALPHA, R2_BETA = 64, 0.9, 0.6
+R2_REPLAY_CAP = 8192                # sequences of 123 steps x 28,224 B = 3.47 MB each (ring 10,240: 35.5 GB)
+R2_EPISODE = 400
+FLOP_LSTM_GATES = 2 * 3648 * 2048   # [x | h] x W per env-step of one LSTM step
+
+
+def bench_r2d2(args, world, rank, device):
+    """One STEP = one R2D2 actor tick over 3,200 envs (act: trunk + LSTM step + eps-greedy; post_step: n-step
+    return, per-step priority from online(s_t, h_t) / target(s_t+n, h_t+n) [online.act(s_t+n) is act's own step,
+    reused], sequence windows, eta-aggregated priority, insert of the finished sequences) + one learner update
+    (sample 64 sequences of 123 steps -> R2D2Agent.loss -> BPTT -> clip -> Adam -> update_priority, hand-written
+    HIP, csrc/learner_r2d2.hip).  Frames are device-resident; rewards / terminals come from the host because the
+    window bookkeeping branches on them (rela/r2d2_actor.h:29-87)."""
+    import torch.distributed as dist
+
+    from rela_amd import _capi as capi
+    from rela_amd.engine import LSTMNetHandle, R2D2ActorEngine
+    from rela_amd.learner import HipR2D2Learner
+    from rela_amd.pyrela.net import AtariLSTMNet
+    from rela_amd.pyrela.r2d2 import R2D2Agent
+    from rela_amd.replay import RNNReplay
+
+    assert R2_BATCH % world == 0
+    B_LOCAL = R2_BATCH // world
+    T = R2_BURN + R2_SEQ + MULTI_STEP
+    torch.manual_seed(SEED + 2 + rank)
+    agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, NUM_ACTION), "cpu", MULTI_STEP, GAMMA, R2_ETA, R2_SEQ, R2_BURN,
+                      0).to(device)
+    if world > 1:
+        for p in agent.parameters():
+            dist.broadcast(p.data, 0)
+    learner = HipR2D2Learner.from_agent(agent, B_LOCAL, lr=6.25e-5, eps=1.5e-4, grad_clip=40.0)
+    online, target = LSTMNetHandle(NUM_ACTION, device), LSTMNetHandle(NUM_ACTION, device)
+    online.load_state_dict(agent.online_net.state_dict())
+    target.load_state_dict(agent.target_net.state_dict())
+    replay = RNNReplay(args.replay_cap, SEED + rank, R2_ALPHA, R2_BETA, 0, NUM_ACTION, T, device)
+    eps_all = generate_eps(0.4, 7, R2_ROWS * world)
+    engine = R2D2ActorEngine(R2_ROWS, R2_K, NUM_ACTION, MULTI_STEP, GAMMA, R2_SEQ, R2_BURN, R2_ETA, replay,
+                             eps_all[rank * R2_ROWS:(rank + 1) * R2_ROWS], device, seed=SEED + rank)
+    g = torch.Generator(device=device)
+    g.manual_seed(SEED + 7 + rank)
+    rng = np.random.default_rng(SEED + rank)
+    reward = rng.integers(-1, 2, R2_ROWS).astype(np.float32)
+    phase = rng.integers(0, R2_EPISODE, R2_ROWS)
+    actor_stream = torch.cuda.Stream(device=device)
+    main_stream = torch.cuda.Stream(device=device, priority=-1)
+    tick_idx, step_idx = [0], [0]
+
+    def actor_tick():
+        k = tick_idx[0]
+        if k <= MULTI_STEP:  # the n+1 history slots get their static synthetic frames on the first pass
+            engine.next_obs_slot().copy_(torch.randint(0, 256, (R2_ROWS, 4, 84, 84), dtype=torch.uint8, device=device,
+                                                       generator=g))
+            actor_stream.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(actor_stream):
+            engine.act(online)
+            term = ((k + phase) % R2_EPISODE == R2_EPISODE - 1).astype(np.uint8)
+            engine.post_step(reward, term, online, target, nonblocking=True)
+        tick_idx[0] += 1
+
+    def one_step():
+        with torch.cuda.stream(main_stream):
+            k = step_idx[0]
+            if k % 2500 == 0:
+                learner.sync_target_with_online()
+            if k % 20 == 0:
+                main_stream.wait_stream(actor_stream)
+                learner.publish(online, target)
+                actor_stream.wait_stream(main_stream)
+            batch, weight = replay.sample(B_LOCAL)
+            actor_tick()
+            loss, prio = learner.step(batch, weight, world_size=world)
+            replay.update_priority(prio)
+            main_stream.wait_stream(actor_stream)
+        step_idx[0] += 1
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    while replay.size() < 4 * R2_BATCH:  # untimed: actors alone until the replay can serve batches
+        actor_tick()
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        one_step()
+    sync_all()
+    capi.lib.rela_prof_set_filter(b"lstm_gates_mfma,conv1_bf16x3,conv2_mfma,conv3_mfma")
+    capi.lib.rela_prof_enable(1)
+    add0 = replay.num_add()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    capi.lib.rela_prof_enable(0)
+    adds = replay.num_add() - add0
+    if world > 1:
+        t = torch.tensor([dt, float(adds)], device=device, dtype=torch.float64)
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+        dt, adds = float(t[0]), float(t[1])
+    buf = C.create_string_buffer(1 << 16)
+    capi.check(capi.lib.rela_prof_summary_json(buf, len(buf)), "rela_prof_summary_json")
+    prof = json.loads(buf.value.decode())
+    capi.lib.rela_prof_set_filter(None)
+    capi.lib.rela_prof_enable(1)
+    k_all = max(5, args.steps // 10)
+    for _ in range(k_all):
+        one_step()
+    sync_all()
+    capi.lib.rela_prof_enable(0)
+    capi.check(capi.lib.rela_prof_summary_json(buf, len(buf)), "rela_prof_summary_json")
+    prof_all = json.loads(buf.value.decode())
+    st = replay.debug_state()
+    assert st["dev_error"] == 0
+    if rank == 0:
+        rec = prof.get("lstm_gates_mfma", {"total_ms": 0.0, "count": 1})
+        avg_ms = rec["total_ms"] / max(rec["count"], 1)
+        flops = FLOP_LSTM_GATES * R2_ROWS
+        ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else None
+        sample_ms = sum(v["total_ms"] for k, v in prof_all.items() if k.startswith("seq_") or k.startswith("replay_gather")
+                        or k in ("replay_targets", "replay_search", "replay_pop", "replay_is_weights")) / k_all
+        sample_bytes = 4 * st["safe_size"] + B_LOCAL * sum(replay.row_bytes)
+        learner_ms = sum(v["total_ms"] for k, v in prof_all.items() if k.startswith("learner_")) / k_all
+        out = {
+            "metric": "env-steps/s (R2D2 Atari 84x84x4, seq 80 / burn-in 40 / n 3, actor tick + learner grad-step)",
+            "value": R2_ROWS * world * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "R2D2 LSTM (BASELINE config C4's shapes), 40 threads x 80 games (3200 envs) per GPU, "
+                                   "actor + learner on one MI355X, sequence replay of %d x 3.47 MB device-resident, A=18, "
+                                   "seq 80 / burn-in 40 / n 3, ONE learner batch of 64 sequences per step for the whole "
+                                   "job; device-resident static frames, rewards / terminals from the host"
+                                   % args.replay_cap,
+                       "envs_per_gpu": R2_ROWS, "replay_capacity": args.replay_cap, "learner_batch": R2_BATCH,
+                       "learner_batch_per_gpu": B_LOCAL, "parallelism": "single" if world == 1 else
+                       "actor-shards%d+replay-partitions+grad-allreduce" % world},
+            "grad_steps_per_s": args.steps / dt, "train_samples_per_s": args.steps * R2_BATCH / dt,
+            "buffer_add_per_s": adds / dt, "learner": "hip (csrc/learner_r2d2.hip)",
+            "learner_kernel_ms_per_step": learner_ms,
+            # SURVEY 8d: R2D2 grad-step (B = 64) ~ 0.80 TFLOP algorithmic
+            "learner_tflops": 0.80 * (B_LOCAL / 64.0) / (learner_ms * 1e-3) if learner_ms > 0 else None,
+            "kernels_ms_per_step": {k: v["total_ms"] / k_all for k, v in sorted(prof_all.items())},
+            "roofline": {"kernel": "lstm_gates_mfma", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": None if ach is None else ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches": rec["count"], "algorithmic_flop_per_launch": flops},
+            "roofline_hbm": None if sample_ms <= 0 else {
+                "kernel": "rela_replay_sample (scan + time-major gather of 64 x 3.47 MB)", "bound": "hbm", "unit": "GB/s",
+                "peak": PEAK_HBM_GBS, "achieved": sample_bytes / (sample_ms * 1e-3) / 1e9,
+                "frac": sample_bytes / (sample_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "algorithmic_bytes_per_call": sample_bytes, "ms_per_call": sample_ms},
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,8 +356,12 @@ def main():
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--replay-cap", type=int, default=REPLAY_CAP)
+    ap.add_argument("--replay-cap", type=int, default=None)
+    ap.add_argument("--algo", default="apex", help="apex (BASELINE.json's metric, the default) | r2d2 (config C4's "
+                                                   "sequence shape: seq 80 / burn-in 40 / n 3, 3200 envs, B = 64)")
     args = ap.parse_args()
+    if args.replay_cap is None:
+        args.replay_cap = REPLAY_CAP if args.algo == "apex" else R2_REPLAY_CAP
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -228,6 +395,8 @@ def main():
         _build.build_native()
     if world > 1:
         dist.barrier()
+    if args.algo == "r2d2":
+        return bench_r2d2(args, world, rank, device)
     from rela_amd import _capi as capi
     from rela_amd.engine import ApexActorEngine, FFNetHandle
     from rela_amd.engine import dev_view

@@ -132,3 +132,100 @@ class ApexActorEngine:
         if rc != capi.EWOULDBLOCK:
             capi.check(rc, "rela_apex_actor_post_step")
         return bool(ins.value)
+
+
+class LSTMNetHandle:
+    """One immutable device copy of AtariLSTMNet parameters in kernel layout (rela_lstmnet_*)."""
+
+    KEYS = ("net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
+            "lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0", "fc_v.weight", "fc_v.bias",
+            "fc_a.weight", "fc_a.bias")
+
+    def __init__(self, num_action, device="cuda:0"):
+        self.device = torch.device(device)
+        self.num_action = num_action
+        h = C.c_void_p()
+        capi.check(capi.lib.rela_lstmnet_create(C.byref(h), num_action, self.device.index or 0), "rela_lstmnet_create")
+        self.h = h
+
+    def load_state_dict(self, sd, prefix=""):
+        p = capi.LSTMNetParams()
+        keep = []
+        for (field, _), key in zip(capi.LSTMNetParams._fields_, self.KEYS):
+            t = sd[prefix + key].detach().to(self.device, torch.float32).contiguous()
+            keep.append(t)
+            setattr(p, field, t.data_ptr())
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        capi.check(capi.lib.rela_lstmnet_load(self.h, C.byref(p), 1, stream), "rela_lstmnet_load")
+        self._keep = keep
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib.rela_lstmnet_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        if capi is not None and getattr(capi, "lib", None) is not None:
+            self.close()
+
+
+class R2D2ActorEngine:
+    """Thin Python handle on the native R2D2 actor shard (rela_r2d2_actor_*, csrc/actor_r2d2.hip): `rows` envs in
+    groups of K with their n-step rings, recurrent state and sequence windows in HBM."""
+
+    def __init__(self, rows, group_rows, num_action, multi_step, gamma, seq_len, burn_in, eta, replay, eps,
+                 device="cuda:0", seed=1):
+        self.R, self.K, self.A = rows, group_rows, num_action
+        self.device = torch.device(device)
+        self.replay = replay
+        h = C.c_void_p()
+        capi.check(capi.lib.rela_r2d2_actor_create(C.byref(h), rows, group_rows, num_action, multi_step, gamma, seq_len,
+                                                   burn_in, float(eta), replay.h if replay is not None else None, seed,
+                                                   self.device.index or 0), "rela_r2d2_actor_create")
+        self.h = h
+        self._eps = torch.as_tensor(eps, dtype=torch.float32).reshape(rows).contiguous()
+        self._legal = torch.ones((rows, num_action), dtype=torch.float32)
+        self._first = True
+
+    def close(self):
+        if getattr(self, "h", None):
+            capi.lib.rela_r2d2_actor_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        if capi is not None and getattr(capi, "lib", None) is not None:
+            self.close()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @property
+    def num_act(self):
+        return capi.lib.rela_r2d2_actor_num_act(self.h)
+
+    def set_reuse(self, on):
+        capi.check(capi.lib.rela_r2d2_actor_set_reuse(self.h, int(bool(on))), "rela_r2d2_actor_set_reuse")
+
+    def next_obs_slot(self):
+        return dev_view(capi.lib.rela_r2d2_actor_obs_slot(self.h), (self.R, 4, 84, 84), torch.uint8, self.device)
+
+    def act(self, online):
+        """R2D2Actor::act on the observation already resident in next_obs_slot(); cuda i64[R]."""
+        out = C.c_void_p()
+        e = C.c_void_p(self._eps.data_ptr()) if self._first else None
+        l = C.c_void_p(self._legal.data_ptr()) if self._first else None
+        capi.check(capi.lib.rela_r2d2_actor_act(self.h, online.h, None, e, l, None, C.byref(out), self._stream()),
+                   "rela_r2d2_actor_act")
+        self._first = False
+        return dev_view(out.value, (self.R,), torch.int64, self.device)
+
+    def post_step(self, reward_host, terminal_host, online, target, nonblocking=False):
+        """setRewardAndTerminal + postStep; reward f32[R] / terminal u8[R] are HOST numpy arrays (the window
+        bookkeeping branches on the terminal flags).  -> sequences appended by this call."""
+        n = C.c_int(0)
+        rc = capi.lib.rela_r2d2_actor_post_step(self.h, reward_host.ctypes.data_as(C.c_void_p),
+                                                terminal_host.ctypes.data_as(C.c_void_p), online.h, target.h,
+                                                int(nonblocking), C.byref(n), self._stream())
+        if rc != capi.EWOULDBLOCK:
+            capi.check(rc, "rela_r2d2_actor_post_step")
+        return n.value

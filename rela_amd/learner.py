@@ -338,6 +338,16 @@ class HipR2D2Learner:
         self.apply()
         return loss, prio
 
+    def publish(self, online_handle, target_handle=None):
+        """ModelLocker.update_model for device nets: repack the current weights into actor-side LSTMNetHandle
+        objects (rela_lstmnet_load from device pointers, no host copy)."""
+        C, capi = self._C, self._capi
+        po, pt = capi.LSTMNetParams(), capi.LSTMNetParams()
+        capi.check(capi.lib.rela_r2d2_learner_params(self.h, C.byref(po), C.byref(pt)), "rela_r2d2_learner_params")
+        capi.check(capi.lib.rela_lstmnet_load(online_handle.h, C.byref(po), 1, self._stream()), "rela_lstmnet_load")
+        if target_handle is not None:
+            capi.check(capi.lib.rela_lstmnet_load(target_handle.h, C.byref(pt), 1, self._stream()), "rela_lstmnet_load")
+
     def close(self):
         if getattr(self, "h", None):
             self._capi.lib.rela_r2d2_learner_destroy(self.h)

@@ -104,3 +104,57 @@ class FFReplay:
         st = capi.ReplayState()
         capi.check(capi.lib.rela_replay_debug_state(self.h, C.byref(st), None, None, None), "rela_replay_debug_state")
         return {k: getattr(st, k) for k, _ in capi.ReplayState._fields_}
+
+
+class RNNReplay:
+    """RNNPrioritizedReplay(capacity, seed, alpha, beta, prefetch) over RNNTransition records
+    (rela/types.h:53-73): one slot = one sequence of T = burn_in + seq_len + multi_step steps; `sample`
+    returns the time-major batch RNNTransition::makeBatch builds (rela/types.cc:140-182): per-step fields
+    [T, B, ...], h0 / c0 [1, B, 512], seq_len [B]."""
+
+    FIELDS = ("s", "eps", "legal_move", "a", "reward", "terminal", "bootstrap", "h0", "c0", "seq_len")
+
+    def __init__(self, capacity, seed, alpha, beta, prefetch, num_action, steps, device="cuda:0"):
+        self.device = torch.device(device)
+        self.num_action, self.T = num_action, steps
+        h = C.c_void_p()
+        capi.check(capi.lib.rela_replay_create(C.byref(h), capacity, seed, alpha, beta, prefetch,
+                                               self.device.index or 0), "rela_replay_create")
+        self.h = h
+        A, T = num_action, steps
+        self.row_bytes = [T * OBS_BYTES, T * 4, T * 4 * A, T * 8, T * 4, T, T * 4, 2048, 2048, 4]
+        rb = (C.c_int64 * 10)(*self.row_bytes)
+        st = (C.c_int32 * 10)(T, T, T, T, T, T, T, 1, 1, 1)
+        capi.check(capi.lib.rela_replay_set_schema_seq(h, 10, rb, st), "rela_replay_set_schema_seq")
+        self._out = {}
+        self._keep = None
+
+    close = FFReplay.close
+    __del__ = FFReplay.__del__
+    size = FFReplay.size
+    num_add = FFReplay.num_add
+    update_priority = FFReplay.update_priority
+    debug_state = FFReplay.debug_state
+
+    def _buffers(self, batch):
+        if batch not in self._out:
+            dev, A, T = self.device, self.num_action, self.T
+            mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+            self._out[batch] = dict(
+                s=mk((T, batch, 4, 84, 84), torch.uint8), eps=mk((T, batch, 1), torch.float32),
+                legal_move=mk((T, batch, A), torch.float32), a=mk((T, batch), torch.int64),
+                reward=mk((T, batch), torch.float32), terminal=mk((T, batch), torch.bool),
+                bootstrap=mk((T, batch), torch.float32), h0=mk((1, batch, 512), torch.float32),
+                c0=mk((1, batch, 512), torch.float32), seq_len=mk((batch,), torch.float32),
+                weight=mk((batch,), torch.float32))
+        return self._out[batch]
+
+    def sample(self, batchsize, device=None, gather=True):
+        b = self._buffers(batchsize)
+        rows = (C.c_void_p * len(self.FIELDS))(*[b[f].data_ptr() for f in self.FIELDS]) if gather else None
+        capi.check(capi.lib.rela_replay_sample(self.h, batchsize, rows, C.c_void_p(b["weight"].data_ptr()),
+                                               _stream_ptr(self.device)), "rela_replay_sample")
+        batch = SimpleNamespace(obs={"s": b["s"], "eps": b["eps"], "legal_move": b["legal_move"]},
+                                h0={"h0": b["h0"], "c0": b["c0"]}, action={"a": b["a"]}, reward=b["reward"],
+                                terminal=b["terminal"], bootstrap=b["bootstrap"], seq_len=b["seq_len"])
+        return batch, b["weight"]
