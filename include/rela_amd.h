@@ -168,6 +168,11 @@ int rela_seqscan_search(const float* ring_dev, int64_t ring, int64_t head, int64
                         const double* targets_host, int nt, int64_t* out_index, double* out_acc,
                         float* out_w, double* out_total, void* stream);
 
+/* Test hook of the scan index (csrc/seqsum.hip): 0 = normal; 1 = binade guesses perturbed, 2 = every guess
+ * invalid, 3 = crossing records split one element late.  The guesses only decide how much work the exact
+ * evaluation skips, so every result must be bit-identical in all modes (tests/test_replay_gpu.py).      */
+int rela_seqscan_debug_perturb(int mode);
+
 /* ===================================================================================
  * n-step return  --  MultiStepTransitionBuffer::popTransition, rela/dqn_actor.h:58-106.
  * reward_hist / terminal_hist are [multi_step+1][K] device arrays holding the deque of

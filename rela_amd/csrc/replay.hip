@@ -38,13 +38,6 @@ void set_last_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-struct ReplayDevState {
-  double sum;       // ConcurrentQueue::sum_
-  float sum_f;      // sum_ narrowed at the last sample_ (:261-262)
-  int32_t err;      // sticky device-side error
-  double last_pop;  // diff of the last blockPop (diagnostic)
-};
-
 namespace {
 
 constexpr int kMaxBatch = 4096;
@@ -172,15 +165,6 @@ __global__ void replay_scatter_small(SmallFields t, int n, int ring, int start) 
   for (int f = 0; f < t.n; ++f)
     copy_small(t.dst[f] + slot * t.row_bytes[f], t.src[f] + (int64_t)row * t.row_bytes[f], t.row_bytes[f]);
 }
-// src = ring fields, dst = batch outputs: out[b] = field[ids[b]]
-__global__ void replay_gather_small(SmallFields t, const int32_t* __restrict__ ids, int batch) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= batch) return;
-  const int64_t slot = ids[b];
-  for (int f = 0; f < t.n; ++f)
-    copy_small(t.dst[f] + (int64_t)b * t.row_bytes[f], t.src[f] + slot * t.row_bytes[f], t.row_bytes[f]);
-}
-
 // indexed form: row r comes from source row src_idx[r] and goes to slot start + dst_off[r]
 __global__ __launch_bounds__(kThreads) void replay_scatter_rows_indexed(const uint8_t* __restrict__ src,
                                                                         const int32_t* __restrict__ src_idx,
@@ -204,78 +188,29 @@ __global__ __launch_bounds__(kThreads) void replay_scatter_rows_indexed(const ui
   }
 }
 
-// gathers batch rows of one field: out[i] = field[ids[i]]   (makeBatch, types.cc:8-46)
-// `steps` > 1: the row is a sequence of `steps` sub-rows and the output is time-major,
-// out[t][b] = slot_b[t]  (RNNTransition::makeBatch, types.cc:140-182)
-__global__ __launch_bounds__(kThreads) void replay_gather_rows(const uint8_t* __restrict__ field,
-                                                               const int32_t* __restrict__ ids,
-                                                               uint8_t* __restrict__ out, int64_t slot_bytes,
-                                                               int steps, int batch, int vec16) {
-  const int64_t row_bytes = slot_bytes / steps;
-  // grid.y is capped (65,535 limit; batch * steps = 62,976 already at B = 512, T = 123): stride over (t, b)
-  for (int y = blockIdx.y; y < batch * steps; y += gridDim.y) {
-    const int b = y % batch, t = y / batch;
-    const uint8_t* s = field + (int64_t)ids[b] * slot_bytes + (int64_t)t * row_bytes;
-    uint8_t* d = out + ((int64_t)t * batch + b) * row_bytes;
-    if (vec16) {
-      const int64_t nv = row_bytes >> 4;
-      const uint4* s4 = reinterpret_cast<const uint4*>(s);
-      uint4* d4 = reinterpret_cast<uint4*>(d);
-      for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kThreads)
-        d4[i] = s4[i];
-    } else {
-      for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < row_bytes; i += (int64_t)gridDim.x * kThreads)
-        d[i] = s[i];
-    }
-  }
-}
-
 // ---- sample ---------------------------------------------------------------------------
-// Stratified targets :261-280 from the raw mt19937 draws.  libstdc++'s
-// uniform_real_distribution<float>(0, segment) is canonical*(segment-0)+0 with
-// canonical = float(u32)/2^32 clamped below 1 (oracle/mt19937.c restates it).
-// The reference scans once for all targets and never moves backwards, so the effective
-// target of sample i is max(rand_0..rand_i); a non-positive target means "first acc > 0".
-__global__ __launch_bounds__(1024) void replay_targets(const uint32_t* __restrict__ draws, int batch,
-                                                       ReplayDevState* __restrict__ st, float* __restrict__ targets,
-                                                       double* __restrict__ eff) {
-  __shared__ double run[kMaxBatch];
-  const float sum = (float)st->sum;
-  const float segment = sum / (float)batch;
-  const float cap = sum - 0.2f;
-  for (int i = threadIdx.x; i < batch; i += blockDim.x) {
-    float c = (float)draws[i] * 2.3283064365386963e-10f;  // exact scaling by 2^-32
-    if (c >= 1.0f) c = 0.99999994f;
-    const float u = c * segment + 0.0f;
-    const float off = (float)i * segment;
-    float r = u + off;
-    r = (r < cap) ? r : cap;  // std::min(sum - 0.2f, rand)
-    targets[i] = r;
-    // denorm_min: acc >= it  <=>  acc > 0
-    run[i] = fmax((double)r, 4.9406564584124654e-324);
-  }
-  __syncthreads();
-  // inclusive prefix maximum (Hillis-Steele in LDS; batch <= 4096)
-  for (int off = 1; off < batch; off <<= 1) {
-    double v[kMaxBatch / 1024];
-    int c = 0;
-    for (int i = threadIdx.x; i < batch; i += blockDim.x, ++c) v[c] = (i >= off) ? fmax(run[i], run[i - off]) : run[i];
-    __syncthreads();
-    c = 0;
-    for (int i = threadIdx.x; i < batch; i += blockDim.x, ++c) run[i] = v[c];
-    __syncthreads();
-  }
-  for (int i = threadIdx.x; i < batch; i += blockDim.x) eff[i] = run[i];
-  if (threadIdx.x == 0) st->sum_f = sum;
-}
-
-// one wavefront per stratum (seq_find_wave): the 512 searches of a batch spread over the chip
+// The stratified targets (:261-280) are computed by the chain kernel of the scan index (seqsum.hip).
+// Blocks [0, batch): one wavefront per stratum (seq_find_wave: three coalesced loads over the exact prefix
+// arrays + at most 64 native adds).  Blocks >= batch: blockPop :84-103 -- the evicted range is the first n_pop
+// logical slots of the range the scan just indexed, and `diff -= w` from zero is the negated sequential
+// prefix (RNE is symmetric); the first of them evaluates that prefix exactly.
 __global__ __launch_bounds__(64) void replay_search(SeqView v, const double* __restrict__ eff, int batch,
                                                     int32_t* __restrict__ ids, float* __restrict__ raw_w,
-                                                    uint8_t* __restrict__ evicted,
-                                                    ReplayDevState* __restrict__ st) {
+                                                    uint8_t* __restrict__ evicted, ReplayDevState* __restrict__ st,
+                                                    int n_pop) {
   const int i = blockIdx.x;
-  if (i >= batch) return;
+  if (i >= batch) {
+    const int pb = i - batch, npb = gridDim.x - batch;
+    for (int k = pb * 64 + (threadIdx.x & 63); k < n_pop; k += npb * 64) evicted[seq_phys(v, k)] = 1;
+    if (pb == 0) {
+      const double diff = -seq_prefix_wave(v, n_pop);
+      if ((threadIdx.x & 63) == 0) {
+        st->last_pop = diff;
+        st->sum += diff;
+      }
+    }
+    return;
+  }
   const SeqHit h = seq_find_wave(v, eff[i]);
   if ((threadIdx.x & 63) != 0) return;
   int64_t k = h.k;
@@ -286,29 +221,51 @@ __global__ __launch_bounds__(64) void replay_search(SeqView v, const double* __r
   const int64_t p = seq_phys(v, k);
   ids[i] = (int32_t)p;
   raw_w[i] = h.found ? h.w : 0.f;
-  evicted[p] = 0;  // getElementAndMark :124-128
+  // getElementAndMark :124-128 clears the flag; a slot that is popped right after (:311-315) ends up evicted,
+  // and the pop blocks of this launch set that flag
+  if (k >= n_pop) evicted[p] = 0;
 }
 
-// blockPop :84-103.  The evicted range is the first n_pop logical slots of the range the scan
-// just indexed, and `diff -= w` from zero is the negated sequential prefix (RNE is symmetric).
-__global__ __launch_bounds__(kThreads) void replay_pop(SeqView v, int n_pop, uint8_t* __restrict__ evicted,
-                                                       ReplayDevState* __restrict__ st) {
-  const int tid = blockIdx.x * kThreads + threadIdx.x;
-  for (int k = tid; k < n_pop; k += gridDim.x * kThreads) evicted[seq_phys(v, k)] = 1;
-  if (blockIdx.x == 0 && threadIdx.x < 64) {  // wavefront 0 evaluates the exact prefix cooperatively
-    const double diff = -seq_prefix_wave(v, n_pop);
-    if (threadIdx.x == 0) {
-      st->last_pop = diff;
-      st->sum += diff;
+// Block 0: IS weights :320-322 (w/sum -> pow(size*w, -beta) -> /= max).  Block f + 1: gather of small field f
+// (eps, legal_move, a, reward, terminal, bootstrap ...) of the batch, out[b] = field[ids[b]] -- four
+// independent (row, word) items in flight per thread.  One launch for all of it.
+__global__ __launch_bounds__(1024) void replay_finish(const float* __restrict__ raw_w, int batch, float size_f,
+                                                      float beta, const ReplayDevState* __restrict__ st,
+                                                      float* __restrict__ out, SmallFields t,
+                                                      const int32_t* __restrict__ ids) {
+  if (blockIdx.x > 0) {
+    const int f = blockIdx.x - 1;
+    const int rb = t.row_bytes[f];
+    if ((rb & 3) == 0 && (((uintptr_t)t.dst[f] | (uintptr_t)t.src[f]) & 3) == 0) {
+      const int words = rb >> 2, total = batch * words;
+      const uint32_t* __restrict__ src = reinterpret_cast<const uint32_t*>(t.src[f]);
+      uint32_t* __restrict__ dst = reinterpret_cast<uint32_t*>(t.dst[f]);
+      for (int base = threadIdx.x; base < total; base += 4 * blockDim.x) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * blockDim.x;
+          if (idx < total) {
+            const int row = idx / words;
+            v[u] = src[(int64_t)ids[row] * words + (idx - row * words)];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * blockDim.x;
+          if (idx < total) dst[idx] = v[u];
+        }
+      }
+    } else {
+      const uint8_t* __restrict__ src = t.src[f];
+      uint8_t* __restrict__ dst = t.dst[f];
+      for (int idx = threadIdx.x; idx < batch * rb; idx += blockDim.x) {
+        const int row = idx / rb;
+        dst[idx] = src[(int64_t)ids[row] * rb + (idx - row * rb)];
+      }
     }
+    return;
   }
-}
-
-// IS weights :320-322: w/sum -> pow(size*w, -beta) -> /= max     (one workgroup)
-__global__ __launch_bounds__(1024) void replay_is_weights(const float* __restrict__ raw_w, int batch,
-                                                          float size_f, float beta,
-                                                          const ReplayDevState* __restrict__ st,
-                                                          float* __restrict__ out) {
   __shared__ float red[1024];
   const float sum = st->sum_f;
   float mx = -INFINITY;
@@ -329,6 +286,39 @@ __global__ __launch_bounds__(1024) void replay_is_weights(const float* __restric
   for (int i = threadIdx.x; i < batch; i += blockDim.x) out[i] = out[i] / mx;
 }
 
+// gathers batch rows of every LARGE field in one launch (blockIdx.z = field): out[i] = field[ids[i]]
+// (makeBatch, types.cc:8-46); `steps` > 1: the row is a sequence of `steps` sub-rows and the output is
+// time-major, out[t][b] = slot_b[t]  (RNNTransition::makeBatch, types.cc:140-182)
+constexpr int kMaxBigFields = 12;
+struct BigFields {
+  const uint8_t* field[kMaxBigFields];
+  uint8_t* out[kMaxBigFields];
+  int64_t slot_bytes[kMaxBigFields];
+  int32_t steps[kMaxBigFields];
+  int32_t vec16[kMaxBigFields];
+};
+__global__ __launch_bounds__(kThreads) void replay_gather_big(BigFields t, const int32_t* __restrict__ ids, int batch) {
+  const int f = blockIdx.z;
+  const int steps = t.steps[f];
+  const int64_t row_bytes = t.slot_bytes[f] / steps;
+  // grid.y is capped (65,535 limit; batch * steps = 62,976 already at B = 512, T = 123): stride over (t, b)
+  for (int y = blockIdx.y; y < batch * steps; y += gridDim.y) {
+    const int b = y % batch, ts = y / batch;
+    const uint8_t* s = t.field[f] + (int64_t)ids[b] * t.slot_bytes[f] + (int64_t)ts * row_bytes;
+    uint8_t* d = t.out[f] + ((int64_t)ts * batch + b) * row_bytes;
+    if (t.vec16[f]) {
+      const int64_t nv = row_bytes >> 4;
+      const uint4* s4 = reinterpret_cast<const uint4*>(s);
+      uint4* d4 = reinterpret_cast<uint4*>(d);
+      for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kThreads)
+        d4[i] = s4[i];
+    } else {
+      for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < row_bytes; i += (int64_t)gridDim.x * kThreads)
+        d[i] = s[i];
+    }
+  }
+}
+
 // ---- update ---------------------------------------------------------------------------
 // update :105-119 for the outstanding batch.  Sequential semantics with duplicate ids: the
 // i-th occurrence sees the weight written by the previous occurrence.  One workgroup:
@@ -339,24 +329,33 @@ __global__ __launch_bounds__(1024) void replay_update(const float* __restrict__ 
                                                       float* __restrict__ w, ReplayDevState* __restrict__ st) {
   __shared__ float neww[kMaxBatch];
   __shared__ float dlt[kMaxBatch];
-  __shared__ int32_t sid[kMaxBatch];
+  __shared__ __attribute__((aligned(16))) int32_t sid[kMaxBatch];
   __shared__ uint8_t is_last[kMaxBatch];  // separate from sid[]: other lanes are still scanning sid[]
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     neww[i] = pow_alpha(prio[i], alpha);
     sid[i] = ids[i];
   }
+  const int n4 = (n + 3) & ~3;
+  for (int i = n + threadIdx.x; i < n4; i += blockDim.x) sid[i] = -1;  // padding of the last int4
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int id = sid[i];
     float d = 0.f;
     bool last = true;
     if (!evicted[id]) {
-      // no early exits: every lane reads the same sid[j] (an LDS broadcast), the loop pipelines
+      // no early exits: every lane reads the same four ids per LDS access (a broadcast), the loop pipelines
       int prev = -1;
-      for (int j = 0; j < n; ++j) {
-        const bool same = sid[j] == id;
-        prev = (same && j < i) ? j : prev;
-        last = (same && j > i) ? false : last;
+      const int4* s4 = reinterpret_cast<const int4*>(sid);
+      for (int j4 = 0; j4 < n4 / 4; ++j4) {
+        const int4 q = s4[j4];
+        const int j = j4 * 4;
+        const int qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool same = qq[u] == id;
+          prev = (same && j + u < i) ? j + u : prev;
+          last = (same && j + u > i) ? false : last;
+        }
       }
       const float old = prev >= 0 ? neww[prev] : w[id];
       d = neww[i] - old;  // float - float :113
@@ -370,10 +369,17 @@ __global__ __launch_bounds__(1024) void replay_update(const float* __restrict__ 
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += blockDim.x)
     if (is_last[i]) w[sid[i]] = neww[i];
-  if (threadIdx.x == 0) {
+  // diff += (double)dlt[i] in order (:113-116): a dependent f64 chain.  One wavefront keeps 64 values per
+  // register and feeds the chain through lane broadcasts instead of one LDS round trip per element.
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
     double diff = 0;
-    for (int i = 0; i < n; ++i) diff += (double)dlt[i];  // evicted ids contribute +0.0f (a no-op)
-    st->sum += diff;
+    for (int base = 0; base < n; base += 64) {
+      const float mine = base + lane < n ? dlt[base + lane] : 0.f;  // evicted ids contribute +0.0f (a no-op)
+      const int cnt = n - base < 64 ? n - base : 64;
+      for (int e = 0; e < cnt; ++e) diff += (double)rl_f(mine, e);
+    }
+    if (lane == 0) st->sum += diff;
   }
 }
 
@@ -697,39 +703,30 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
   RELA_HIP(up);
   const int size = r->safe_size;  // storage_ [0, safeSize) is static during the scan :261-263
   SeqView v;
-  int rc = seq_index_build(r->ix, r->d_w, r->ring, r->head, size, r->stream, &v);
+  SeqTargetsJob tj;
+  tj.draws = r->d_draws, tj.batch = batch, tj.state = r->d_state, tj.targets = r->d_targets, tj.eff = r->d_eff;
+  int rc = seq_index_build(r->ix, r->d_w, r->ring, r->head, size, r->stream, &v, &tj);
   if (rc != RELA_OK) return rc;
-  {
-    ProfScope prof("replay_targets", r->stream);
-    hipLaunchKernelGGL(replay_targets, dim3(1), dim3(1024), 0, r->stream, r->d_draws, batch, r->d_state,
-                       r->d_targets, r->d_eff);
-  }
-  {
-    ProfScope prof("replay_search", r->stream);
-    hipLaunchKernelGGL(replay_search, dim3(batch), dim3(64), 0, r->stream, v, r->d_eff, batch,
-                       r->d_ids, r->d_raw_w, r->d_evicted, r->d_state);
-  }
   // pop storage if full :311-315: `size` is re-read as size_ (reserved blocks included), and the
   // IS weights below use that value (:312,321).  Only committed slots can be evicted.
   const int full_size = r->size;
   const int n_pop = full_size > r->capacity ? std::min(full_size - r->capacity, size) : 0;
+  {
+    const int pop_blocks = n_pop > 0 ? std::min(ceil_div(n_pop, 256), 128) : 0;
+    ProfScope prof("replay_search", r->stream);
+    hipLaunchKernelGGL(replay_search, dim3(batch + pop_blocks), dim3(64), 0, r->stream, v, r->d_eff, batch,
+                       r->d_ids, r->d_raw_w, r->d_evicted, r->d_state, n_pop);
+  }
   if (n_pop > 0) {
-    {
-      ProfScope prof("replay_pop", r->stream);
-      hipLaunchKernelGGL(replay_pop, dim3(std::min(ceil_div(n_pop, kThreads), 256)), dim3(kThreads), 0, r->stream, v,
-                         n_pop, r->d_evicted, r->d_state);
-    }
     r->head = (r->head + n_pop) % r->ring;
     r->size -= n_pop;
     r->safe_size -= n_pop;
   }
-  {
-    ProfScope prof("replay_is_weights", r->stream);
-    hipLaunchKernelGGL(replay_is_weights, dim3(1), dim3(1024), 0, r->stream, r->d_raw_w, batch, (float)full_size, r->beta,
-                       r->d_state, out_weight_dev);
-  }
+  SmallFields small{};
+  BigFields big{};
+  int nbig = 0, max_y = 1;
+  int64_t max_units = 1;
   if (out_rows_dev) {
-    SmallFields small{};
     for (size_t f = 0; f < r->d_fields.size(); ++f) {
       if (!out_rows_dev[f]) continue;
       const int64_t rb = r->row_bytes[f];
@@ -741,21 +738,30 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
         small.n += 1;
         continue;
       }
+      RELA_CHECK(nbig < kMaxBigFields, RELA_EINVAL, "rela_replay_sample: more than %d large fields", kMaxBigFields);
       const int64_t sub = rb / st;
       const int v16 = vec16_ok(out_rows_dev[f], r->d_fields[f], sub) && (rb % 16 == 0);
-      const int64_t units = v16 ? (sub >> 4) : sub;
-      int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (units + kThreads - 1) / kThreads), 64);
-      {
-        ProfScope prof("replay_gather_rows", r->stream);
-        hipLaunchKernelGGL(replay_gather_rows, dim3(gx, std::min(batch * st, 32768)), dim3(kThreads), 0, r->stream, r->d_fields[f],
-                           r->d_ids, (uint8_t*)out_rows_dev[f], rb, st, batch, v16);
-      }
+      big.field[nbig] = r->d_fields[f];
+      big.out[nbig] = (uint8_t*)out_rows_dev[f];
+      big.slot_bytes[nbig] = rb;
+      big.steps[nbig] = st;
+      big.vec16[nbig] = v16;
+      max_units = std::max<int64_t>(max_units, v16 ? (sub >> 4) : sub);
+      max_y = std::max(max_y, batch * st);
+      nbig += 1;
     }
-    if (small.n > 0) {
-      ProfScope prof("replay_gather_small", r->stream);
-      hipLaunchKernelGGL(replay_gather_small, dim3(ceil_div(batch, 256)), dim3(256), 0, r->stream, small,
-                         (const int32_t*)r->d_ids, batch);
-    }
+  }
+  {
+    ProfScope prof("replay_finish", r->stream);
+    hipLaunchKernelGGL(replay_finish, dim3(1 + small.n), dim3(1024), 0, r->stream, (const float*)r->d_raw_w, batch,
+                       (float)full_size, r->beta, (const ReplayDevState*)r->d_state, out_weight_dev, small,
+                       (const int32_t*)r->d_ids);
+  }
+  if (nbig > 0) {
+    const int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (max_units + kThreads - 1) / kThreads), 64);
+    ProfScope prof("replay_gather_rows", r->stream);
+    hipLaunchKernelGGL(replay_gather_big, dim3(gx, std::min(max_y, 32768), nbig), dim3(kThreads), 0, r->stream, big,
+                       (const int32_t*)r->d_ids, batch);
   }
   RELA_LAUNCH_CHECK();
   RELA_HIP(hipEventRecord(r->ev_out, r->stream));

@@ -42,6 +42,8 @@ constexpr int kL3 = kL2 * kFan;      // 16384
 
 constexpr int kTabInvalid = -1;  // never applicable
 constexpr int kTabAny = -2;      // all-zero node: identity in every binade
+constexpr int kTabExact = -3;    // d[0] = the exact accumulator entering the node, d[1] = leaving it: written by
+                                 // the chain for crossing nodes once both are known; applies iff A == d[0]
 
 // Transfer table of one node.  d[p] is the exact increment (already scaled by u, exact
 // in f64) for incoming parity p; par bit p is the parity of that increment in units of u.
@@ -174,7 +176,7 @@ RELA_HD SeqTab seq_tab_invalid() {
 // Compose two tables (L then R).  kTabAny is the identity; a binade mismatch or an
 // increment beyond 2^53 ulps (never applicable anyway) yields an invalid table.
 RELA_HD SeqTab seq_compose(const SeqTab& L, const SeqTab& R) {
-  if (L.e == kTabInvalid || R.e == kTabInvalid) return seq_tab_invalid();
+  if (L.e == kTabInvalid || R.e == kTabInvalid || L.e == kTabExact || R.e == kTabExact) return seq_tab_invalid();
   if (L.e == kTabAny) return R;
   if (R.e == kTabAny) return L;
   if (L.e != R.e) return seq_tab_invalid();
@@ -198,6 +200,11 @@ RELA_HD bool seq_apply(const SeqTab& t, double A, double* out) {
     return true;
   }
   if (t.e == kTabInvalid) return false;
+  if (t.e == kTabExact) {
+    if (dbits(A) != dbits(t.d[0])) return false;
+    *out = t.d[1];
+    return true;
+  }
   const uint64_t ab = dbits(A);
   if ((int)((ab >> 52) & 0x7ff) != t.e) return false;
   const double n = A + t.d[ab & 1];

@@ -1,5 +1,12 @@
 // seqsum_dev.h -- device-side view of a built sequential-sum index (see seqsum_core.h) and the
 // host entry points that build it.  Shared by seqsum.hip and replay.hip.
+//
+// The index gives the EXACT value of the reference's running sum (rela/prioritized_replay.h:304-306)
+// before every level-2 node (1024 weights): A2[i] = acc before logical element 1024*i, and A3 for the
+// level-3 nodes.  A search for a stratified target is two coalesced loads over the monotone arrays A3 / A2,
+// one coalesced load of the 16 level-1 transfer tables of the level-2 node it lands in (applied in order,
+// each application verified), and at most 64 native adds inside one level-1 node; a prefix (blockPop's
+// diff, :85-95) walks the same way.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -8,14 +15,20 @@
 
 namespace rela_amd {
 
-// Everything a kernel needs to evaluate the reference's running sum
-// (rela/prioritized_replay.h:304-306) at any logical index of the ring.
+// device-resident scalars of one replay (replay.hip); the chain kernel reads `sum` for the stratified targets
+struct ReplayDevState {
+  double sum;       // ConcurrentQueue::sum_
+  float sum_f;      // sum_ narrowed at the last sample_ (:261-262)
+  int32_t err;      // sticky device-side error
+  double last_pop;  // diff of the last blockPop (diagnostic)
+};
+
 struct SeqView {
   const float* w;  // weight ring (device)
   int64_t ring, head, size;
-  const SeqTab* T1;
-  const SeqTab* T2;
-  const double* A3;  // exact accumulator before each level-3 node; A3[n3] = total
+  const SeqTab* T1;  // [16*n2] level-1 transfer tables (zero padded to whole level-2 nodes)
+  const double* A2;  // [16*n3 + 1]  exact accumulator before each level-2 node (zero padded past size)
+  const double* A3;  // [n3 + 1]     ... before each level-3 node; A3[n3] = total
   int n3;
 };
 
@@ -35,42 +48,6 @@ __device__ __forceinline__ int64_t seq_phys(const SeqView& v, int64_t k) {
   return p >= v.ring ? p - v.ring : p;
 }
 
-// first logical index whose inclusive sequential prefix reaches `target` (> 0)
-__device__ inline SeqHit seq_find(const SeqView& v, double target) {
-  int lo = 0, hi = v.n3;  // smallest j with A3[j+1] >= target
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (v.A3[mid + 1] >= target) hi = mid; else lo = mid + 1;
-  }
-  if (lo >= v.n3) {
-    SeqHit h;
-    h.k = v.size;
-    h.A = v.A3[v.n3];
-    h.w = 0.f;
-    h.found = false;
-    return h;
-  }
-  int64_t kend = (int64_t)(lo + 1) * kL3;
-  if (kend > v.size) kend = v.size;
-  return seq_walk(v.A3[lo], (int64_t)lo * kL3, kend, target, v.T1, v.T2, (const SeqTab*)nullptr,
-                  SeqRingAt{v.w, v.ring, v.head, v.size});
-}
-
-// exact sequential sum of the first k weights (k <= size)
-__device__ inline double seq_prefix(const SeqView& v, int64_t k) {
-  int j = (int)(k / kL3);
-  if (j > v.n3) j = v.n3;
-  if (j == v.n3) return v.A3[v.n3];
-  return seq_walk(v.A3[j], (int64_t)j * kL3, k, (double)INFINITY, v.T1, v.T2, (const SeqTab*)nullptr,
-                  SeqRingAt{v.w, v.ring, v.head, v.size}).A;
-}
-
-// ---- wave-cooperative walk -------------------------------------------------------------
-// Same arithmetic as seq_walk (seqsum_core.h), executed by all 64 lanes of a wavefront with
-// identical scalar state: sibling tables (16 x 24 B) and native weights (64 x 4 B) are fetched
-// by one coalesced load each and consumed through lane broadcasts, so a search costs ~3 memory
-// round trips instead of ~100 dependent ones.  Every lane must call these with the same
-// arguments; every lane gets the same result.
 // `src` is wave-uniform: v_readlane_b32 (a few cycles) instead of ds_bpermute_b32 (an LDS round trip)
 __device__ __forceinline__ int rl_i(int x, int src) { return __builtin_amdgcn_readlane(x, src); }
 __device__ __forceinline__ float rl_f(float x, int src) {
@@ -91,59 +68,53 @@ __device__ __forceinline__ SeqTab seq_tab_bcast(const SeqTab& mine, int src) {
   return t;
 }
 
-// Walks [k0, kend) inside ONE level-3 node (k0 is that node's first index).  pad_ok: tables may
-// be applied even when their span runs past kend (true for searches up to `size`, where the
-// tables were built with zero padding; false when kend is an arbitrary prefix end).
-__device__ inline SeqHit seq_walk_wave(const SeqView& v, double A0, int64_t k0, int64_t kend, double target,
-                                       bool pad_ok) {
+// Native walk of the 64 weights of level-1 node u held one per lane (wl), from the exact accumulator A
+// (wave-uniform): stops at the first element whose inclusive sum reaches `target`, or after `cnt` elements.
+__device__ __forceinline__ SeqHit seq_native_wave(float wl, double A, int64_t k0, int cnt, double target) {
+  SeqHit h;
+  for (int e = 0; e < cnt; ++e) {
+    const float we = rl_f(wl, e);
+    A += (double)we;
+    if (A >= target) {
+      h.k = k0 + e;
+      h.A = A;
+      h.w = we;
+      h.found = true;
+      return h;
+    }
+  }
+  h.k = k0 + cnt;
+  h.A = A;
+  h.w = 0.f;
+  h.found = false;
+  return h;
+}
+
+// Walks the level-2 node i2 from its exact start value: the 16 level-1 tables arrive in ONE coalesced load and
+// are applied through lane broadcasts (verified; a table that cannot be applied, or that would pass `target`,
+// is walked natively).  Stops at the first element whose inclusive sum reaches `target`, or at element kend.
+__device__ inline SeqHit seq_walk_l2_wave(const SeqView& v, int64_t i2, double A, int64_t kend, double target) {
   const int lane = threadIdx.x & 63;
   const SeqRingAt at{v.w, v.ring, v.head, v.size};
-  SeqHit h;
-  double A = A0;
-  int64_t k = k0;
-  const int64_t n2 = (v.size + kL2 - 1) / kL2, n1 = n2 * kFan;
-  SeqTab my2 = seq_tab_invalid();
-  {
-    const int64_t i2 = k0 / kL2 + lane;
-    if (lane < kFan && i2 < n2) my2 = v.T2[i2];
-  }
-  for (int c2 = 0; c2 < kFan && k < kend; ++c2) {
+  SeqTab mine = seq_tab_any();
+  if (lane < kFan) mine = v.T1[i2 * kFan + lane];
+  int64_t k = i2 * kL2;
+  for (int c = 0; c < kFan && k < kend; ++c) {
+    const SeqTab t1 = seq_tab_bcast(mine, c);
     double n;
-    const SeqTab t2 = seq_tab_bcast(my2, c2);
-    if ((pad_ok || k + kL2 <= kend) && seq_apply(t2, A, &n) && n < target) {
+    if (k + kL1 <= kend && seq_apply(t1, A, &n) && n < target) {
       A = n;
-      k += kL2;
+      k += kL1;
       continue;
     }
-    SeqTab my1 = seq_tab_invalid();
-    {
-      const int64_t i1 = k / kL1 + lane;
-      if (lane < kFan && i1 < n1) my1 = v.T1[i1];
-    }
-    const int64_t end2 = (k + kL2 < kend) ? k + kL2 : kend;
-    for (int c1 = 0; c1 < kFan && k < end2; ++c1) {
-      const SeqTab t1 = seq_tab_bcast(my1, c1);
-      if ((pad_ok || k + kL1 <= kend) && seq_apply(t1, A, &n) && n < target) {
-        A = n;
-        k += kL1;
-        continue;
-      }
-      const float wl = at(k + lane);  // 64 weights, one coalesced load (0 beyond size)
-      const int cnt = (int)((k + kL1 <= kend) ? kL1 : (kend - k));
-      for (int e = 0; e < cnt; ++e) {
-        const float we = rl_f(wl, e);
-        A += (double)we;
-        if (A >= target) {
-          h.k = k + e;
-          h.A = A;
-          h.w = we;
-          h.found = true;
-          return h;
-        }
-      }
-      k += cnt;
-    }
+    const float wl = at(k + lane);  // 64 weights, one coalesced load (0 beyond size)
+    const int cnt = (int)((k + kL1 <= kend) ? kL1 : (kend - k));
+    const SeqHit h = seq_native_wave(wl, A, k, cnt, target);
+    if (h.found) return h;
+    A = h.A;
+    k += cnt;
   }
+  SeqHit h;
   h.k = kend;
   h.A = A;
   h.w = 0.f;
@@ -151,14 +122,18 @@ __device__ inline SeqHit seq_walk_wave(const SeqView& v, double A0, int64_t k0, 
   return h;
 }
 
-// wave-cooperative versions of seq_find / seq_prefix
+// Wave-cooperative search: first logical index whose inclusive sequential prefix reaches `target` (> 0).
+// Every lane must call with the same arguments; every lane gets the same result.
 __device__ inline SeqHit seq_find_wave(const SeqView& v, double target) {
-  int lo = 0, hi = v.n3;  // smallest j with A3[j+1] >= target (uniform across the wave)
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (v.A3[mid + 1] >= target) hi = mid; else lo = mid + 1;
+  const int lane = threadIdx.x & 63;
+  // level 3: j = number of level-3 nodes whose END value is still below the target
+  int j = 0;
+  for (int base = 0; base < v.n3; base += 64) {
+    const int i = base + lane;
+    const bool below = i < v.n3 && v.A3[i + 1] < target;
+    j += __popcll(__ballot(below));
   }
-  if (lo >= v.n3) {
+  if (j >= v.n3) {  // never reached (:297-302, the reference aborts here)
     SeqHit h;
     h.k = v.size;
     h.A = v.A3[v.n3];
@@ -166,33 +141,64 @@ __device__ inline SeqHit seq_find_wave(const SeqView& v, double target) {
     h.found = false;
     return h;
   }
-  int64_t kend = (int64_t)(lo + 1) * kL3;
+  // level 2: 16 children (the array is padded to whole level-3 nodes)
+  const bool b2 = lane < kFan && v.A2[(int64_t)j * kFan + 1 + lane] < target;
+  const int64_t i2 = (int64_t)j * kFan + __popcll(__ballot(b2));
+  int64_t kend = (i2 + 1) * kL2;
   if (kend > v.size) kend = v.size;
-  return seq_walk_wave(v, v.A3[lo], (int64_t)lo * kL3, kend, target, true);
+  return seq_walk_l2_wave(v, i2, v.A2[i2], kend, target);
 }
 
+// exact sequential sum of the first k weights (k <= size), wave-cooperative
 __device__ inline double seq_prefix_wave(const SeqView& v, int64_t k) {
-  int j = (int)(k / kL3);
-  if (j >= v.n3) return v.A3[v.n3];
-  return seq_walk_wave(v, v.A3[j], (int64_t)j * kL3, k, (double)INFINITY, false).A;
+  if (k >= v.size) return v.A3[v.n3];
+  const int64_t i2 = k / kL2;
+  return seq_walk_l2_wave(v, i2, v.A2[i2], k, (double)INFINITY).A;
 }
 
 // ---- host side -----------------------------------------------------------------------
+// A level-1 node whose binade guess is invalid (the running sum crosses a power of two inside it) is a
+// "crossing node".  The tables kernel records it with a speculative split at the crossing element m:
+// B = transfer table of elements [0, m) in the binade before, C = table of (m, 64) in the binade after.
+// The chain applies B, adds w[m] natively and applies C, each step verified; any failed check falls back
+// to 64 native adds, so the split only decides how much work is skipped.
+struct SeqRec {
+  int32_t node;  // level-1 node index
+  int32_t kind;  // 0 = split (B, wm, C), 1 = walk natively
+  int32_t m;
+  float wm;
+  SeqTab B, C;
+};
+constexpr int kMaxRec = 256;
+
 struct SeqIndex {
-  double* bsum2 = nullptr;  // [n2cap]     plain f64 sums of level-2 nodes (guesses only)
-  double* S0 = nullptr;     // [n2cap + 1] their exclusive prefix
+  double* s2 = nullptr;     // [n2cap]       plain f64 sums of level-2 nodes (binade guesses only)
+  double* s1 = nullptr;     // [n2cap * 16]  plain f64 sums of level-1 nodes
   SeqTab* T1 = nullptr;     // [n2cap * 16]
   SeqTab* T2 = nullptr;     // [n2cap]
   SeqTab* T3 = nullptr;     // [n3cap]
   double* A3 = nullptr;     // [n3cap + 1]
+  double* A2 = nullptr;     // [n3cap * 16 + 1]
+  SeqRec* rec = nullptr;    // [kMaxRec]
+  int32_t* ctl = nullptr;   // [0] number of crossing records, [1] count of fallback runs (diagnostic)
   int n2cap = 0, n3cap = 0;
+};
+
+// Optional second job of the chain kernel (it is a single workgroup with idle lanes): the stratified
+// targets of a sample (prioritized_replay.h:261-280).  batch = 0: none.
+struct SeqTargetsJob {
+  const uint32_t* draws = nullptr;  // raw mt19937 outputs, one per sample
+  int batch = 0;
+  ReplayDevState* state = nullptr;  // sum -> sum_f
+  float* targets = nullptr;  // [batch] clamped targets (diagnostic)
+  double* eff = nullptr;     // [batch] effective (prefix-max) targets
 };
 
 int seq_index_alloc(SeqIndex* ix, int64_t max_elems);
 void seq_index_free(SeqIndex* ix);
-// Queues the build (5 small kernels) for the live range [head, head+size) on `stream` and
-// fills `view` (plain struct, pass by value to kernels queued on the same stream afterwards).
-int seq_index_build(const SeqIndex& ix, const float* ring_dev, int64_t ring, int64_t head,
-                    int64_t size, hipStream_t stream, SeqView* view);
+// Queues the build (3 kernels) for the live range [head, head+size) on `stream` and fills `view`
+// (plain struct, pass by value to kernels queued on the same stream afterwards).
+int seq_index_build(const SeqIndex& ix, const float* ring_dev, int64_t ring, int64_t head, int64_t size,
+                    hipStream_t stream, SeqView* view, const SeqTargetsJob* targets = nullptr);
 
 }  // namespace rela_amd

@@ -159,7 +159,7 @@ def test_hip_r2d2_learner_matches_autograd(A, B, seq, burn, n):
     (ref_loss * weight).mean().backward()
     np.testing.assert_allclose(loss_seq.cpu().numpy(), ref_loss.detach().cpu().numpy(), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(prio.cpu().numpy(), ref_prio.cpu().numpy(), rtol=2e-4, atol=2e-4)
-    np.testing.assert_allclose(float(loss.cpu()[0]), float((ref_loss * weight).mean()), rtol=2e-4)
+    np.testing.assert_allclose(float(loss.cpu()[0]), float((ref_loss * weight).mean().detach()), rtol=2e-4)
     grads = learner.state_dict("grads")
     for key, p in agent.online_net.named_parameters():
         ref = p.grad.detach()

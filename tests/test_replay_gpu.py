@@ -108,6 +108,18 @@ def test_golden_device_pow(path):
             assert abs(got["sum"] - ref) <= 1e-6 * abs(ref) + 1e-6
 
 
+@pytest.fixture(params=[0, 1, 2, 3], ids=["guess", "perturbed", "all-native", "late-split"])
+def scan_mode(request):
+    """The binade guesses of the scan index only decide how much work its exact evaluation skips: mode 1 moves
+    every third guess by a binade (failed gap -> legacy walk), mode 2 invalidates all (record overflow -> native
+    walk), mode 3 splits crossing records one element late (failed record checks).  Results may not change."""
+    from rela_amd import _capi as capi
+
+    capi.lib.rela_seqscan_debug_perturb(request.param)
+    yield request.param
+    capi.lib.rela_seqscan_debug_perturb(0)
+
+
 SCENARIOS = [
     # capacity, batch, block, rounds, kind
     (1000, 64, 80, 60, "uniform"),
@@ -118,7 +130,7 @@ SCENARIOS = [
 
 
 @pytest.mark.parametrize("cap,batch,block,rounds,kind", SCENARIOS)
-def test_random_scenario_vs_oracle(cap, batch, block, rounds, kind):
+def test_random_scenario_vs_oracle(cap, batch, block, rounds, kind, scan_mode):
     """Interleaved add / sample / update against the CPU oracle with identical inputs
     (alpha = 1 so both sides store the same weights); everything compared exactly."""
     from gpu_util import GpuReplay
@@ -209,7 +221,7 @@ def test_protocol_errors():
 @pytest.mark.parametrize("kind", ["uniform", "lognormal", "logwide", "sparse", "ties", "pow06", "denorm",
                                   "giant_first", "leading_zeros"])
 @pytest.mark.parametrize("n", [1, 64, 1000, 16384, 16385, 70000])
-def test_seqscan_bit_exact(kind, n):
+def test_seqscan_bit_exact(kind, n, scan_mode):
     """rela_seqscan_search vs the oracle's sequential f64 scan (prioritized_replay.h:266-308)."""
     from gpu_util import dev, seqscan
     from test_seqsum_host import gen, oracle_scan, seq_total
@@ -233,7 +245,8 @@ def test_seqscan_bit_exact(kind, n):
             assert k[i] == exp_idx[i] and A[i] == exp_acc[i] and w[i] == logical[exp_idx[i]]
 
 
-def test_seqscan_full_ring_2p20():
+@pytest.mark.parametrize("kind", ["pow06", "lognormal", "sparse"])
+def test_seqscan_full_ring_2p20(kind, scan_mode):
     """BASELINE config C2: ring = int(1.25 * 2^20) = 1,310,720 live weights, B = 512 strata.
     The sequential oracle still runs in well under a second at this size, so compare fully."""
     from gpu_util import dev, seqscan
@@ -241,7 +254,7 @@ def test_seqscan_full_ring_2p20():
 
     rng = np.random.default_rng(2020)
     n = 1310720
-    logical = gen("pow06", n, rng)
+    logical = gen(kind, n, rng)
     total = seq_total(logical)
     seg = total / 512
     targets = (rng.uniform(0, seg, 512) + np.arange(512) * seg).astype(np.float32)
