@@ -131,6 +131,8 @@ int rela_replay_update_priority(rela_replay* r, int n, const float* priority, in
  * (SURVEY 8e): the un-normalised weights w_i of the outstanding batch (:289) and the float sum
  * the stratified targets were drawn against (:261-262).  Valid until the next sample().       */
 int rela_replay_last_sample_dev(rela_replay* r, const float** raw_w_dev, const float** sum_f_dev);
+/* the size the last sample()'s IS weights used (:312,321: size_ re-read before the pop, reservations included) */
+int rela_replay_last_sample_size(const rela_replay* r);
 
 /* Teardown aid (no reference counterpart: there a producer parked on a full ring, :47, keeps its
  * Context from joining forever).  After shutdown every pending and future begin_add/add returns

@@ -77,6 +77,7 @@ _sig("rela_replay_add", i32, [vp, i32, P(vp), vp, i32, vp])
 _sig("rela_replay_sample", i32, [vp, i32, P(vp), vp, vp])
 _sig("rela_replay_update_priority", i32, [vp, i32, vp, i32, vp])
 _sig("rela_replay_last_sample_dev", i32, [vp, P(vp), P(vp)])
+_sig("rela_replay_last_sample_size", i32, [vp])
 _sig("rela_replay_shutdown", i32, [vp])
 _sig("rela_replay_limits", i32, [vp, P(i32), P(i32)])
 _sig("rela_replay_size", i32, [vp])

@@ -401,6 +401,7 @@ struct rela_replay {
   std::condition_variable cv_tail;
   std::atomic<int64_t> num_add{0};
   int n_sampled = 0;
+  int last_full_size = 0;  // size_ as re-read by the last sample_ (:312), the N of its IS weights
   hipStream_t stream = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr;
   float* d_w = nullptr;
@@ -710,6 +711,7 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
   // pop storage if full :311-315: `size` is re-read as size_ (reserved blocks included), and the
   // IS weights below use that value (:312,321).  Only committed slots can be evicted.
   const int full_size = r->size;
+  r->last_full_size = full_size;
   const int n_pop = full_size > r->capacity ? std::min(full_size - r->capacity, size) : 0;
   {
     const int pop_blocks = n_pop > 0 ? std::min(ceil_div(n_pop, 256), 128) : 0;
@@ -811,6 +813,8 @@ extern "C" int rela_replay_last_sample_dev(rela_replay* r, const float** raw_w_d
   if (sum_f_dev) *sum_f_dev = &r->d_state->sum_f;
   return RELA_OK;
 }
+
+extern "C" int rela_replay_last_sample_size(const rela_replay* r) { return r ? r->last_full_size : 0; }
 
 extern "C" int rela_replay_shutdown(rela_replay* r) {
   RELA_CHECK(r, RELA_EINVAL, "rela_replay_shutdown: bad arguments");

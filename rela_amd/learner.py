@@ -143,6 +143,16 @@ class HipApexLearner:
         return (dev_view(pp.value, (n.value,), torch.float32, self.device),
                 dev_view(gp.value, (n.value,), torch.float32, self.device))
 
+    def flat_target(self):
+        """The target net's flat parameter buffer (same layout as flat()[0]) -- what a publish sends along."""
+        from .engine import dev_view
+
+        C, capi = self._C, self._capi
+        p, n = capi.FFNetParams(), C.c_int64()
+        capi.check(capi.lib.rela_apex_learner_params(self.h, None, C.byref(p)), "rela_apex_learner_params")
+        capi.check(capi.lib.rela_apex_learner_flat(self.h, None, None, C.byref(n)), "flat")
+        return dev_view(p.conv1_w, (n.value,), torch.float32, self.device)  # conv1_w sits at offset 0
+
     def stats(self):
         """cuda f32[2]: gradient norm before clipping, clip coefficient of the last apply()."""
         from .engine import dev_view

@@ -287,6 +287,21 @@ class ModelLocker {
   std::condition_variable cv_;
 };
 
+// Not in the reference's surface: what a replay PARTITION contributes to the importance weights of a batch
+// drawn over several partitions -- the un-normalised weights w_i of the last sample, the float
+// sum they were drawn against and the size its weights used (prioritized_replay.h:289,261,312).
+static std::tuple<torch::Tensor, torch::Tensor, int> lastSampleRaw(rela_replay* h, int device, int n) {
+  if (!h || n <= 0) throw std::runtime_error("last_sample_raw: nothing was sampled");
+  const float* raw = nullptr;
+  const float* sum = nullptr;
+  check(rela_replay_last_sample_dev(h, &raw, &sum), "rela_replay_last_sample_dev");
+  auto opt = torch::TensorOptions().dtype(torch::kFloat32).device(torch::Device(torch::kCUDA, (c10::DeviceIndex)device));
+  // the replay's stream wrote them; sample() already made torch's current stream wait for that work
+  auto w = torch::from_blob(const_cast<float*>(raw), {n}, opt).clone();
+  auto s = torch::from_blob(const_cast<float*>(sum), {1}, opt).clone();
+  return std::make_tuple(w, s, rela_replay_last_sample_size(h));
+}
+
 // =====================================================================================
 // FFPrioritizedReplay (rela/prioritized_replay.h:173-348 as bound in pybind.cc:37-47)
 // =====================================================================================
@@ -346,6 +361,7 @@ class FFPrioritizedReplay {
                       b.bootstrap.data_ptr()};
     check(rela_replay_sample(h_, batchsize, rows, weight.data_ptr<float>(), torchCurrentStream(device_)),
           "FFPrioritizedReplay.sample");
+    lastBatch_ = batchsize;
     const int want = parseDevice(device);
     if (want != device_) {  // learner on another GPU (or the cpu): move the batch, types.cc:34-43
       const auto target = want < 0 ? torch::Device(torch::kCPU) : torch::Device(torch::kCUDA, (c10::DeviceIndex)want);
@@ -359,6 +375,8 @@ class FFPrioritizedReplay {
     }
     return std::make_tuple(std::move(b), weight);
   }
+
+  std::tuple<torch::Tensor, torch::Tensor, int> lastSampleRaw_() { return lastSampleRaw(h_, device_, lastBatch_); }
 
   void updatePriority(const torch::Tensor& priority) {
     if (!h_) throw std::runtime_error("FFPrioritizedReplay.update_priority: nothing was sampled");
@@ -382,6 +400,7 @@ class FFPrioritizedReplay {
   std::mutex m_;
   rela_replay* h_ = nullptr;
   int device_ = -1, numAction_ = 0;
+  int lastBatch_ = 0;
   torch::Tensor keep_;
 };
 
@@ -1171,7 +1190,8 @@ PYBIND11_MODULE(rela, m) {
       .def("size", &FFPrioritizedReplay::size)
       .def("num_add", &FFPrioritizedReplay::numAdd)
       .def("sample", &FFPrioritizedReplay::sample)
-      .def("update_priority", &FFPrioritizedReplay::updatePriority);
+      .def("update_priority", &FFPrioritizedReplay::updatePriority)
+      .def("last_sample_raw", &FFPrioritizedReplay::lastSampleRaw_);  // partition exchange only
 
   py::class_<RNNPrioritizedReplay, std::shared_ptr<RNNPrioritizedReplay>>(m, "RNNPrioritizedReplay")
       .def(py::init<int, int, float, float, int>())

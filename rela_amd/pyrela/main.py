@@ -90,8 +90,8 @@ def train(args, on_epoch=None):
         learner = cls.from_agent(agent, args.batchsize, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip)
 
     act_devices = args.act_device.split(",")
-    if len(act_devices) != 1:
-        raise SystemExit("one replay partition per actor GPU: launch one process per act device (DESIGN.md §6)")
+    if len(act_devices) != 1:  # the caller should have gone through train_multi (see __main__)
+        raise SystemExit("several --act_device values: use rela_amd.pyrela.main.train_multi (one process per GPU)")
     lockers = [rela.ModelLocker([agent, agent, agent], d) for d in act_devices]  # 3 weight versions per device
 
     replay_buffer = replay_class(args.replay_buffer_size, args.seed, args.priority_exponent,
@@ -163,5 +163,160 @@ def train(args, on_epoch=None):
     return history
 
 
+# ---- the reference's multi-GPU layout (pyrela/main.py:131-166), one process per GPU -------------------------
+def _exchange_backend(args):
+    """RCCL when every rank has its own GPU; gloo with host-side exchange buffers when ranks share a card
+    (the one-GPU rehearsal: RCCL refuses two ranks on one device)."""
+    devs = [args.train_device] + args.act_device.split(",")
+    shared = len(set(devs)) < len(devs)
+    return ("gloo", "cpu") if shared else ("nccl", None)
+
+
+class _RelaFFPartition:
+    """the `rela` module's FFPrioritizedReplay as a partition of rela_amd.parallel"""
+
+    def __init__(self, replay, device):
+        self.replay, self.device = replay, device
+
+    def sample(self, n):
+        b, _ = self.replay.sample(n, self.device)
+        raw_w, part_sum, size = self.replay.last_sample_raw()
+        fields = {"s": b.obs["s"], "next_s": b.next_obs["s"], "eps": b.obs["eps"], "next_eps": b.next_obs["eps"],
+                  "legal_move": b.obs["legal_move"], "next_legal_move": b.next_obs["legal_move"], "a": b.action["a"],
+                  "reward": b.reward, "terminal": b.terminal.to(torch.uint8), "bootstrap": b.bootstrap}
+        return fields, raw_w, part_sum, size
+
+    def update_priority(self, p):
+        self.replay.update_priority(p.to(self.device))
+
+
+def _multi_worker(rank, world, args, port, results):
+    import torch.distributed as dist
+
+    from rela_amd.learner import HipApexLearner, ffnet_flat_layout
+    from rela_amd.parallel import PartitionedReplay, PartitionServer, ff_batch_namespace, ff_field_specs
+
+    act_devices = args.act_device.split(",")
+    G = len(act_devices)
+    backend, exch = _exchange_backend(args)
+    my_device = args.train_device if rank == 0 else act_devices[rank - 1]
+    torch.cuda.set_device(torch.device(my_device))
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(my_device))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    exch_device = exch or my_device
+    torch.manual_seed(args.seed + 2)  # identical initial weights on every rank
+    num_action = create_env.get_num_action(args.game)
+    agent = ApexAgent(lambda: AtariFFNet(num_action), args.multi_step, args.gamma).to(my_device)
+    specs = ff_field_specs(num_action)
+    layout, total = ffnet_flat_layout(num_action)
+    assert args.batchsize % G == 0 and args.num_thread % G == 0
+    if rank == 0:
+        learner = HipApexLearner.from_agent(agent, args.batchsize, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip)
+        replay = PartitionedReplay(specs, args.batchsize, args.importance_exponent, exch_device)
+        history = []
+        for epoch in range(args.num_epoch):
+            t0 = time.time()
+            loss_sum = torch.zeros((), device=my_device)
+            for batch_idx in range(args.epoch_len):
+                num_update = batch_idx + epoch * args.epoch_len
+                if num_update % args.num_update_between_sync == 0:
+                    learner.sync_target_with_online()
+                if num_update % args.actor_sync_freq == 0:  # ONE broadcast per flat buffer instead of load_state_dict
+                    replay.publish(learner.flat()[0].to(exch_device), learner.flat_target().to(exch_device))
+                fields, weight = replay.sample()
+                batch = ff_batch_namespace({k: v.to(my_device) for k, v in fields.items()})
+                loss, priority = learner.step(batch, weight.to(my_device))
+                replay.update_priority(priority)
+                loss_sum += loss[0]
+            torch.cuda.synchronize()
+            dt = time.time() - t0
+            history.append(dict(epoch=epoch, seconds=dt, train=args.epoch_len * args.batchsize / dt,
+                                loss=float(loss_sum) / args.epoch_len))
+            print("epoch: %d, time: %.1fs, loss: %.5f, train: %.1f samples/s" % (
+                epoch, dt, history[-1]["loss"], history[-1]["train"]), flush=True)
+        replay.stop()
+        counts = torch.zeros(2, dtype=torch.float64, device=exch_device)
+        dist.all_reduce(counts)
+        results.put(dict(history=history, act=float(counts[0]), buffer_add=float(counts[1])))
+    else:
+        g = rank - 1
+        locker = rela.ModelLocker([agent, agent, agent], my_device)
+        part = rela.FFPrioritizedReplay(args.replay_buffer_size // G, args.seed + g, args.priority_exponent,
+                                        args.importance_exponent, args.prefetch)
+        eps_all = utils.generate_eps(args.act_base_eps, args.act_eps_alpha, args.num_thread * args.num_game_per_thread)
+        # the reference deals thread t to device t % G (main.py:155,166): this rank runs those threads
+        threads = [t for t in range(args.num_thread) if t % G == g]
+        K = args.num_game_per_thread
+        eps = [e for t in threads for e in eps_all[t * K:(t + 1) * K]]
+        make_actor = lambda i: rela.DQNActor(locker, args.multi_step, K, args.gamma, part)
+        context, games, actors = create_env.create_train_env(args.seed + 7919 * g, eps, args.episode_len, len(threads), K,
+                                                             make_actor)
+        context.start()
+        while part.size() < max(args.burn_in_frames // G, args.batchsize // G):
+            time.sleep(0.05)
+
+        def on_weights(on_flat, tg_flat):
+            sd = {}
+            for prefix, flat in (("online_net.", on_flat), ("target_net.", tg_flat)):
+                for key, shape, off in layout:
+                    n = 1
+                    for d in shape:
+                        n *= d
+                    sd[prefix + key] = flat[off:off + n].view(shape)
+            agent.load_state_dict(sd)
+            locker.update_model(agent)
+
+        srv = PartitionServer(_RelaFFPartition(part, my_device), specs, args.batchsize, args.importance_exponent,
+                              exch_device, flat_sizes=(total, total), on_weights=on_weights)
+        srv.serve_forever()
+        counts = torch.tensor([float(utils.total_acts(actors)), float(part.num_add())], dtype=torch.float64,
+                              device=exch_device)
+        dist.all_reduce(counts)
+        context.terminate()
+        context.resume()
+        t0 = time.time()
+        while not context.terminated() and time.time() - t0 < 60:
+            if part.size() >= args.batchsize // G:
+                _, w = part.sample(args.batchsize // G, my_device)
+                part.update_priority(w)
+            time.sleep(0.01)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def train_multi(args):
+    """--act_device cuda:1,cuda:2,...: one actor process per act device, each with its replay partition, plus
+    the learner process on --train_device (rela_amd/parallel.py).  Processes are spawned BEFORE any GPU call."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    if args.algo != "apex":
+        raise SystemExit("train_multi: --algo apex only (the R2D2 exchange uses the same classes with rnn_field_specs)")
+    G = len(args.act_device.split(","))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    results = ctx.Queue()
+    procs = [ctx.Process(target=_multi_worker, args=(r, G + 1, args, port, results)) for r in range(G + 1)]
+    for p in procs:
+        p.start()
+    res = results.get(timeout=3600)
+    for p in procs:
+        p.join(timeout=120)
+        if p.exitcode != 0:
+            raise SystemExit("rank process exited with %s" % p.exitcode)
+    return res
+
+
 if __name__ == "__main__":
-    train(parse_args())
+    _args = parse_args()
+    if len(_args.act_device.split(",")) > 1 or _args.act_device != _args.train_device:
+        print(train_multi(_args))
+    else:
+        train(_args)

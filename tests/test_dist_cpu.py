@@ -153,3 +153,136 @@ def test_flat_weight_publish_layout_and_broadcast():
         assert p.exitcode == 0
     assert same and key == "linear.0.weight" and shape == [512, 3136] and tot == total
     assert val == float(off + 3 * 3136 + 5)
+
+
+# ---- C3 / C4 layout: learner rank + actor ranks with replay partitions (rela_amd/parallel.py) ----------
+_EX = dict(cap=64, batch=16, beta=0.4, alpha=1.0, rounds=3, blocks=6, block=12)
+
+
+def _feed(oracle, seed):
+    """the insertion stream of one partition: `blocks` blocks of `block` tagged rows"""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    for b in range(_EX["blocks"]):
+        tags = np.arange(b * _EX["block"], (b + 1) * _EX["block"]) + 1000 * seed
+        assert oracle.add(tags, rng.uniform(0.05, 2.0, _EX["block"]).astype(np.float32)) == 0
+
+
+class _OraclePartition:
+    """A replay partition for the CPU exchange tests, built on the oracle (test infrastructure): rows are the
+    int64 tag and a float payload derived from it."""
+
+    def __init__(self, seed):
+        import sys
+
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from oracle_lib import OracleReplay
+
+        self.o = OracleReplay(_EX["cap"], seed, _EX["alpha"], _EX["beta"])
+        _feed(self.o, seed)
+
+    def sample(self, n):
+        import numpy as np
+
+        st = self.o.state()
+        rc, ids, tags, w = self.o.sample(n)
+        assert rc == 0
+        fields = {"tag": torch.from_numpy(tags.copy()),
+                  "payload": torch.from_numpy(np.stack([tags * 0.5, tags * 0.25, tags + 1.0], 1).astype(np.float32))}
+        return fields, torch.from_numpy(self.o.last_raw_w(n)), float(np.float32(st["sum"])), st["size"]
+
+    def update_priority(self, p):
+        assert self.o.update(p.numpy()) == 0
+
+
+def _exchange_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rela_amd.learner import ffnet_flat_layout
+    from rela_amd.parallel import FieldSpec, PartitionedReplay, PartitionServer
+
+    specs = [FieldSpec("tag", (), torch.int64), FieldSpec("payload", (3,), torch.float32)]
+    _, total = ffnet_flat_layout(18)  # the flat buffers HipApexLearner publishes (online, target)
+    if rank == 0:
+        rep = PartitionedReplay(specs, _EX["batch"], _EX["beta"], "cpu")
+        rounds = []
+        for r in range(_EX["rounds"]):
+            fields, w = rep.sample()
+            try:
+                rep.sample()
+                raise SystemExit("second sample without update was accepted")
+            except AssertionError:
+                pass
+            prio = (fields["tag"] % 7).float() * 0.3 + 0.1 + r
+            rounds.append(dict(tag=fields["tag"].tolist(), payload=fields["payload"].tolist(), w=w.tolist(),
+                               prio=prio.tolist()))
+            rep.update_priority(prio)
+            if r == 1:
+                rep.publish(torch.arange(total, dtype=torch.float32), torch.arange(total, dtype=torch.float32) * 2)
+        rep.stop()
+        out.put(("learner", rounds))
+    else:
+        got = []
+        srv = PartitionServer(_OraclePartition(rank), specs, _EX["batch"], _EX["beta"], "cpu", flat_sizes=(total, total),
+                              on_weights=lambda on, tg: got.append((float(on[12345]), float(tg[12345]), on.numel())))
+        srv.serve_forever()
+        out.put(("actor", rank, srv.partition.o.state()["sum"], srv.served, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_partitioned_replay_exchange_over_three_ranks():
+    """Learner rank + two actor ranks (gloo): B/G sampling per partition, row gather, IS weights normalised
+    over both partitions, priority scatter and the flat weight publish.  Each partition must behave exactly
+    like a reference PrioritizedReplay(capacity/G, seed_g) fed the same stream and asked for B/G (SURVEY 8e's
+    parity definition): the test replays both partitions locally on the oracle and compares everything."""
+    import numpy as np
+
+    from oracle_lib import OracleReplay
+
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 3, port, out)) for r in range(3)]
+    for p in procs:
+        p.start()
+    msgs = [out.get(timeout=180) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rounds = [m for m in msgs if m[0] == "learner"][0][1]
+    actors = {m[1]: m for m in msgs if m[0] == "actor"}
+    mirrors = {g: OracleReplay(_EX["cap"], g, _EX["alpha"], _EX["beta"]) for g in (1, 2)}
+    for g, o in mirrors.items():
+        _feed(o, g)
+    bl = _EX["batch"] // 2
+    for r, rec in enumerate(rounds):
+        raw, sums, sizes, tags = [], [], [], []
+        for g in (1, 2):
+            st = mirrors[g].state()
+            rc, ids, t, _ = mirrors[g].sample(bl)
+            assert rc == 0
+            raw.append(mirrors[g].last_raw_w(bl))
+            sums.append(np.float32(st["sum"]))
+            sizes.append(st["size"])
+            tags.append(t)
+        exp_tags = np.concatenate(tags)
+        assert rec["tag"] == exp_tags.tolist(), "round %d: rows are not the partitions' own B/G samples" % r
+        np.testing.assert_array_equal(np.array(rec["payload"], np.float32),
+                                      np.stack([exp_tags * 0.5, exp_tags * 0.25, exp_tags + 1.0], 1).astype(np.float32))
+        # prioritized_replay.h:320-322 over the union: N and sum are the totals, the maximum is global
+        tot_sum, tot_n = np.float64(sums[0]) + np.float64(sums[1]), float(sizes[0] + sizes[1])
+        w = (np.float32(tot_n) * (np.concatenate(raw) / np.float32(tot_sum))) ** np.float32(-_EX["beta"])
+        np.testing.assert_allclose(np.array(rec["w"], np.float32), w / w.max(), rtol=2e-6)
+        assert max(rec["w"]) == 1.0
+        prio = np.array(rec["prio"], np.float32)
+        for i, g in enumerate((1, 2)):  # the scatter hands every partition ITS chunk of the priorities
+            assert mirrors[g].update(prio[i * bl:(i + 1) * bl]) == 0
+    for g in (1, 2):
+        _, _, final_sum, served, got = actors[g]
+        assert served == _EX["rounds"] and final_sum == mirrors[g].state()["sum"]
+        from rela_amd.learner import ffnet_flat_layout
+
+        assert got == [(12345.0, 24690.0, ffnet_flat_layout(18)[1])]

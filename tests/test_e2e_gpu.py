@@ -417,3 +417,25 @@ def test_benchmark_driver_tiny_grid(mods, capsys, algo):
     for (t, k, without, with_), (sw, sws) in zip(rows, summary):
         assert abs(float(sw) - without) < 0.01 and abs(float(sws) - with_) < 0.01
         assert without > 0 and with_ > 0
+
+
+def test_multi_process_layout_rehearsal_on_one_gpu():
+    """The reference's multi-GPU layout (pyrela/main.py:131-166: act devices next to one learner device) as
+    one process per GPU (rela_amd/pyrela/main.py:train_multi, rela_amd/parallel.py), rehearsed with all three
+    ranks on cuda:0 over gloo: two actor processes with their replay partitions and C++ actor threads, one
+    learner process sampling B/G from each, gathering the rows, scattering the priorities and publishing the
+    flat weights.  (On a multi-GPU node the same code runs over RCCL; that needs more than this one card.)"""
+    import ast
+    import subprocess
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "rela_amd", "pyrela", "main.py"), "--train_device", "cuda:0",
+           "--act_device", "cuda:0,cuda:0", "--num_thread", "4", "--num_game_per_thread", "4", "--batchsize", "32",
+           "--epoch_len", "10", "--num_epoch", "2", "--burn_in_frames", "64", "--replay_buffer_size", "1024",
+           "--episode_len", "25", "--actor_sync_freq", "5"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    last = [l for l in out.stdout.splitlines() if l.startswith("{'history'")][-1]
+    res = ast.literal_eval(last)
+    assert len(res["history"]) == 2 and all(np.isfinite(h["loss"]) for h in res["history"])
+    assert res["act"] > 0 and res["buffer_add"] > 0

@@ -306,3 +306,72 @@ def test_full_size_properties():
     expect = float(np.sum(wts[live].astype(np.float64)))  # small integers: exact in any order
     assert g.state()["sum"] == expect
     g.close()
+
+
+def test_partitions_match_reference_replays_of_capacity_over_g():
+    """SURVEY 8e's parity definition under sharding: partition g is bit-identical to a reference
+    PrioritizedReplay(capacity / G, seed_g) fed the same insertion stream and asked for B / G; the importance
+    weights of the whole batch are the single-buffer formula (prioritized_replay.h:320-322) with N and sum
+    taken over all partitions and one global maximum (what rela_amd.parallel exchanges between ranks)."""
+    import ctypes as C
+
+    import torch
+
+    from gpu_util import GpuReplay
+    from oracle_lib import OracleReplay
+    from rela_amd import _capi as capi
+    from test_seqsum_host import gen
+
+    G, cap, B, beta = 4, 4096, 512, 0.4
+    rng = np.random.default_rng(44)
+    parts = [(GpuReplay(cap // G, 10002 + g, 1.0, beta), OracleReplay(cap // G, 10002 + g, 1.0, beta)) for g in range(G)]
+    tag = 0
+    for rnd in range(6):
+        for g, (dev, ora) in enumerate(parts):
+            for _ in range(3):  # every partition is fed by its own actors: different streams
+                p = gen("pow06", 80, rng)
+                tags = np.arange(tag, tag + 80)
+                tag += 80
+                assert (dev.add_tags(tags, p) == 0) == (ora.add(tags, p) == 0)
+        raws, sums, sizes, ws = [], [], [], []
+        for g, (dev, ora) in enumerate(parts):
+            pre = ora.state()
+            rc, ids, otags, ow = ora.sample(B // G)
+            assert rc == 0
+            rc, outs, w = dev.sample(B // G)
+            assert rc == 0
+            st = dev.state(B // G)
+            np.testing.assert_array_equal(st["ids"], ids)
+            np.testing.assert_array_equal(tags_of(outs), otags)
+            np.testing.assert_array_equal(st["raw_w"], ora.last_raw_w(B // G))
+            assert capi.lib.rela_replay_last_sample_size(dev.h) == pre["size"]
+            raw_p, sum_p = C.c_void_p(), C.c_void_p()
+            capi.check(capi.lib.rela_replay_last_sample_dev(dev.h, C.byref(raw_p), C.byref(sum_p)), "last_sample")
+            sum_f = np.zeros(1, np.float32)
+            torch.cuda.synchronize()
+            from rela_amd.engine import dev_view
+
+            sum_f[0] = float(dev_view(sum_p.value, (1,), torch.float32, torch.device("cuda:0")).cpu()[0])
+            assert sum_f[0] == np.float32(pre["sum"])
+            raws.append(st["raw_w"])
+            sums.append(sum_f[0])
+            sizes.append(pre["size"])
+            ws.append(w.cpu().numpy())
+        tot_sum = np.float32(np.sum(np.array(sums, np.float64)))
+        tot_n = np.float32(sum(sizes))
+        raw = np.concatenate(raws)
+        glob = (tot_n * (raw / tot_sum)) ** np.float32(-beta)
+        glob = glob / glob.max()
+        # every partition's own weights follow the same formula with ITS N / sum / max; re-normalising them by the
+        # ratios reproduces the global weights (what global_is_weights computes from the raw weights)
+        for g in range(G):
+            loc = (np.float32(sizes[g]) * (raws[g] / sums[g])) ** np.float32(-beta)
+            np.testing.assert_allclose(ws[g], loc / loc.max(), rtol=4e-7)
+        assert glob.max() == 1.0 and (glob > 0).all()
+        newp = gen("pow06", B, rng)
+        for g, (dev, ora) in enumerate(parts):
+            chunk = newp[g * (B // G):(g + 1) * (B // G)]
+            assert dev.update(chunk, on_device=bool(g % 2)) == 0 and ora.update(chunk) == 0
+            assert dev.state()["sum"] == ora.state()["sum"]
+    for dev, _ in parts:
+        dev.close()
