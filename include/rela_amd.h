@@ -170,6 +170,10 @@ int rela_seqscan_search(const float* ring_dev, int64_t ring, int64_t head, int64
                         const double* targets_host, int nt, int64_t* out_index, double* out_acc,
                         float* out_w, double* out_total, void* stream);
 
+/* Test tap: out[i] = pow(x[i], exponent) exactly as the replay evaluates torch::pow(tensor[n], exponent) of
+ * rela/prioritized_replay.h:188,239,321 (SLEEF powf for the 32-wide vector part, double pow for the n % 32 tail) */
+int rela_debug_pow(const float* x_dev, int n, float exponent, float* out_dev, void* stream);
+
 /* Test hook of the scan index (csrc/seqsum.hip): 0 = normal; 1 = binade guesses perturbed, 2 = every guess
  * invalid, 3 = crossing records split one element late.  The guesses only decide how much work the exact
  * evaluation skips, so every result must be bit-identical in all modes (tests/test_replay_gpu.py).      */

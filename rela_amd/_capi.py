@@ -86,6 +86,7 @@ _sig("rela_replay_debug_state", i32, [vp, P(ReplayState), vp, vp, vp])
 _sig("rela_replay_debug_weights", i32, [vp, vp, vp])
 _sig("rela_replay_debug_read_rows", i32, [vp, i32, i32, i32, vp])
 _sig("rela_seqscan_search", i32, [vp, i64, i64, i64, vp, i32, vp, vp, vp, P(f64), vp])
+_sig("rela_debug_pow", i32, [vp, i32, f32, vp, vp])
 _sig("rela_seqscan_debug_perturb", i32, [i32])
 _sig("rela_nstep_return", i32, [i32, i32, f32, i32, vp, vp, vp, vp, vp, vp])
 _sig("rela_ffnet_create", i32, [P(vp), i32, i32])

@@ -27,6 +27,7 @@
 #include "common.h"
 #include "prof.h"
 #include "seqsum_dev.h"
+#include "sleef_powf_core.h"
 
 namespace rela_amd {
 
@@ -43,10 +44,24 @@ namespace {
 constexpr int kMaxBatch = 4096;
 constexpr int kThreads = 256;
 
-__device__ __forceinline__ float pow_alpha(float p, float alpha) {
-  // ATen copies for exponent 1 (the reference's own test uses alpha = 1,
-  // rela/tests/test_prioritized_replay.cc:19); otherwise powf (SLEEF there, ocml here).
-  return alpha == 1.0f ? p : powf(p, alpha);
+// torch::pow(tensor, exponent) as ATen's CPU kernel evaluates it for a float tensor of n elements and a
+// float exponent held in a double Scalar (rela/prioritized_replay.h:188,239,321): the vectorised loop takes
+// 2 * Vec::size() = 32 floats per iteration through SLEEF's powf (u10) with the exponent as float; the
+// remaining n % 32 elements go through the scalar lambda, std::pow(float, double) -> double pow, rounded to
+// float.  Exponent 1 is a copy.  pos = index inside that tensor, n_ref = its length.
+__device__ __forceinline__ float pow_aten(float p, float ex, int pos, int n_ref) {
+  if (ex == 1.0f) return p;
+  // exponents ATen evaluates without pow (pow_tensor_scalar_optimized_kernel); beta = 1 gives the reciprocal.
+  // (+-0.5 go through ATen's vectorised sqrt, which is not the IEEE square root in the last bit on every input:
+  // the device uses the IEEE one; no BASELINE config uses those exponents and they are not pinned.)
+  if (ex == -1.0f) return __fdiv_rn(1.0f, p);
+  if (ex == 0.5f) return __fsqrt_rn(p);
+  if (ex == 2.0f) return __fmul_rn(p, p);
+  if (ex == 3.0f) return __fmul_rn(__fmul_rn(p, p), p);
+  if (ex == -0.5f) return __fdiv_rn(1.0f, __fsqrt_rn(p));
+  if (ex == -2.0f) return __fdiv_rn(1.0f, __fmul_rn(p, p));
+  if (pos < n_ref - (n_ref & 31)) return sleef::powf_u10(p, ex);
+  return (float)pow((double)p, (double)ex);
 }
 
 // ---- add ------------------------------------------------------------------------------
@@ -72,7 +87,9 @@ __global__ __launch_bounds__(kThreads) void replay_append_weights(const float* _
     for (int base = 0; base < n; base += cs) {
       const int m = min(cs, n - base);
       for (int i = threadIdx.x; i < m; i += kThreads) {
-        const float v = pow_alpha(prio[base + i], alpha);
+        const int gi = (base + i) / g;                       // reference block of this row
+        const int glen = min(g, n - gi * g);                 // its length (the last one may be partial)
+        const float v = pow_aten(prio[base + i], alpha, (base + i) - gi * g, glen);
         chunk[i] = v;
         w[(int)(((int64_t)start + base + i) % ring)] = v;
       }
@@ -94,7 +111,9 @@ __global__ __launch_bounds__(kThreads) void replay_append_weights(const float* _
     for (int base = 0; base < n; base += kCap) {
       const int m = min(kCap, n - base);
       for (int i = threadIdx.x; i < m; i += kThreads) {
-        const float v = pow_alpha(prio[base + i], alpha);
+        const int gi = (base + i) / g;
+        const int glen = min(g, n - gi * g);
+        const float v = pow_aten(prio[base + i], alpha, (base + i) - gi * g, glen);
         chunk[i] = v;
         w[(int)(((int64_t)start + base + i) % ring)] = v;
       }
@@ -272,7 +291,7 @@ __global__ __launch_bounds__(1024) void replay_finish(const float* __restrict__ 
   for (int i = threadIdx.x; i < batch; i += blockDim.x) {
     const float q = raw_w[i] / sum;
     const float s = size_f * q;
-    const float p = (beta == 1.0f) ? 1.0f / s : powf(s, -beta);
+    const float p = pow_aten(s, -beta, i, batch);  // torch::pow(size * weights, -beta_) :321
     out[i] = p;
     mx = fmaxf(mx, p);
   }
@@ -332,7 +351,7 @@ __global__ __launch_bounds__(1024) void replay_update(const float* __restrict__ 
   __shared__ __attribute__((aligned(16))) int32_t sid[kMaxBatch];
   __shared__ uint8_t is_last[kMaxBatch];  // separate from sid[]: other lanes are still scanning sid[]
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    neww[i] = pow_alpha(prio[i], alpha);
+    neww[i] = pow_aten(prio[i], alpha, i, n);  // torch::pow(priority, alpha_) over the batch :239
     sid[i] = ids[i];
   }
   const int n4 = (n + 3) & ~3;
@@ -891,5 +910,23 @@ extern "C" int rela_replay_debug_read_rows(rela_replay* r, int field, int slot, 
   RELA_HIP(hipMemcpyAsync(rows_host, r->d_fields[field] + (size_t)slot * rb, rb * (size_t)count, hipMemcpyDeviceToHost,
                           r->stream));
   RELA_HIP(hipStreamSynchronize(r->stream));
+  return RELA_OK;
+}
+
+// Test tap: out[i] = torch::pow(x, exponent)[i] as the replay evaluates it for a tensor of n elements.
+namespace rela_amd {
+namespace {
+__global__ void debug_pow_kernel(const float* __restrict__ x, int n, float ex, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = pow_aten(x[i], ex, i, n);
+}
+}  // namespace
+}  // namespace rela_amd
+extern "C" int rela_debug_pow(const float* x_dev, int n, float exponent, float* out_dev, void* stream_) {
+  RELA_CHECK(x_dev && out_dev && n >= 0, RELA_EINVAL, "rela_debug_pow: bad arguments");
+  if (n > 0)
+    hipLaunchKernelGGL(debug_pow_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream_, x_dev, n, exponent,
+                       out_dev);
+  RELA_LAUNCH_CHECK();
   return RELA_OK;
 }

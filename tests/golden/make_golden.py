@@ -364,6 +364,29 @@ def r2d2loss_cases():
          priority=priority.double().tolist(), grads=grads)
 
 
+def powf_cases():
+    """torch.pow(tensor, exponent) of the ATen build in this container (the op behind the reference's
+    `torch::pow(priority, alpha_)`, rela/prioritized_replay.h:188,239,321): tensors of several lengths so that
+    both the 32-wide SLEEF part and the scalar n % 32 tail are recorded; values as hex floats."""
+    import torch
+
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(77)
+    out = []
+    for ex in (0.6, 0.9, -0.4, -0.6, 0.4, -1.0):  # 0.5 is ATen's own vectorised sqrt, not pow: not pinned
+        for n in (80, 512, 31, 33, 200, 8):
+            kinds = [np.abs(rng.normal(0, 1, n)) + 1e-6, np.exp(rng.uniform(np.log(1e-12), np.log(1e6), n)),
+                     rng.uniform(0, 4, n)]
+            for x in kinds:
+                x = x.astype(np.float32)
+                if n >= 80:  # the values around the [0.75, 1.5) mantissa split of logk, and exact powers of two
+                    x[:6] = np.array([1.5, np.nextafter(np.float32(1.5), np.float32(0)), np.nextafter(np.float32(1.5), np.float32(9)), 0.75, 1.0, 2.0], np.float32)
+                    x[-3:] = np.array([0.0, 1.0, 3.0], np.float32)
+                y = torch.pow(torch.from_numpy(x), float(np.float32(ex))).numpy()
+                out.append(dict(exponent=f2h(ex), n=n, x=[f2h(v) for v in x], y=[f2h(v) for v in y]))
+    save("aten_powf_vectors", [], out)
+
+
 def e2e_cases():
     """The REAL reference end to end: its pybind module (oracle/_ref/rela*.so), its TorchScript
     ApexAgent on the CPU, our synthetic env compiled against its rela/env.h."""
@@ -440,3 +463,5 @@ if __name__ == "__main__":
         learner_cases()
     if "r2d2loss" in which:
         r2d2loss_cases()
+    if "powf" in which:
+        powf_cases()

@@ -76,9 +76,11 @@ def check_state(exp, st):
 @pytest.mark.parametrize("path", cases("replay_"), ids=os.path.basename)
 def test_golden_bookkeeping_bit_exact(path):
     """From the weights onward everything is exact: alpha==1 scripts run as recorded, alpha!=1
-    scripts are fed the weights the reference stored (its SLEEF powf) with alpha=1."""
+    scripts are fed the weights the reference stored with alpha=1.  The importance weights are exact too:
+    torch::pow(size * weights, -beta) is evaluated as ATen's CPU kernel does (SLEEF powf for the 32-wide part
+    of the tensor, double pow for the n % 32 tail, reciprocal for beta = 1)."""
     case = json.load(open(path))
-    alpha, beta = h2f(case["script"][0].split()[3]), h2f(case["script"][0].split()[4])
+    alpha = h2f(case["script"][0].split()[3])
     for kind, exp, got in run_golden(case, feed_stored_weights=(alpha != 1.0)):
         if kind == "state":
             check_state(exp, got)
@@ -86,26 +88,45 @@ def test_golden_bookkeeping_bit_exact(path):
         assert got["ids"].tolist() == exp["ids"]
         assert got["tags"].tolist() == exp["tags"]
         check_state(exp, got["state"])
-        ref_w = np.array([h2f(h) for h in exp["w"]], np.float32)
-        if beta == 1.0:
-            assert [f2h(x) for x in got["w"]] == exp["w"]
-        else:
-            np.testing.assert_allclose(got["w"], ref_w, rtol=4e-7, atol=0)
+        assert [f2h(x) for x in got["w"]] == exp["w"]
 
 
 @pytest.mark.parametrize("path", [p for p in cases("replay_") if "_a06" in p], ids=os.path.basename)
 def test_golden_device_pow(path):
-    """alpha != 1 end to end with the device powf: ids/tags still equal the reference's on the
-    recorded scripts (a last-bit powf difference moves an id only if a target lands within
-    that bit of a boundary); the f64 sum agrees to f32 round-off."""
+    """alpha != 1 end to end with the device's restatement of ATen's pow (rela/prioritized_replay.h:188,239 ->
+    SLEEF Sleef_powf_u10 for the vector lanes, double pow for the tail lanes of each K-element add): the
+    stored weights, the f64 running sum, the sampled ids and the importance weights all equal the reference's
+    bit for bit."""
     case = json.load(open(path))
     for kind, exp, got in run_golden(case, feed_stored_weights=False):
         if kind == "sample":
             assert got["ids"].tolist() == exp["ids"]
             assert got["tags"].tolist() == exp["tags"]
+            check_state(exp, got["state"])
+            assert [f2h(x) for x in got["w"]] == exp["w"]
         else:
-            ref = struct.unpack(">d", bytes.fromhex(exp["sum"]))[0]
-            assert abs(got["sum"] - ref) <= 1e-6 * abs(ref) + 1e-6
+            check_state(exp, got)
+
+
+def test_device_pow_matches_aten_vectors():
+    """rela_debug_pow (the pow the replay kernels use) against vectors recorded from the real ATen op
+    (tests/golden/aten_powf_vectors.json, tests/golden/make_golden.py powf): every element, bit for bit --
+    32-wide SLEEF part and scalar tail of each tensor length."""
+    import torch
+
+    from gpu_util import cur_stream, dev, ptr
+    from rela_amd import _capi as capi
+
+    cases_ = json.load(open(os.path.join(GOLD, "aten_powf_vectors.json")))["expect"]
+    total = 0
+    for c in cases_:
+        x = np.array([h2f(v) for v in c["x"]], np.float32)
+        d_x = dev(x)
+        d_y = torch.empty(len(x), device="cuda")
+        capi.check(capi.lib.rela_debug_pow(ptr(d_x), len(x), h2f(c["exponent"]), ptr(d_y), cur_stream()), "rela_debug_pow")
+        assert [f2h(v) for v in d_y.cpu().numpy()] == c["y"], (c["exponent"], c["n"])
+        total += len(x)
+    assert total > 15000
 
 
 @pytest.fixture(params=[0, 1, 2, 3], ids=["guess", "perturbed", "all-native", "late-split"])
