@@ -357,6 +357,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replay-cap", type=int, default=None)
+    ap.add_argument("--dedup", default=None, choices=[None, "stack", "plane"],
+                    help="frame-stack de-duplication in the replay (SURVEY 8f-3): stack = 28,224 B per env-step, plane = "
+                         "7,056 B (the frames of this bench are static, so only the byte traffic is representative); "
+                         "default: s and next_s stored in full (56,448 B), as in round 1's headline")
     ap.add_argument("--algo", default="apex", help="apex (BASELINE.json's metric, the default) | r2d2 (config C4's "
                                                    "sequence shape: seq 80 / burn-in 40 / n 3, 3200 envs, B = 64)")
     args = ap.parse_args()
@@ -420,7 +424,8 @@ def main():
     online.load_state_dict(agent.online_net.state_dict())
     target.load_state_dict(agent.target_net.state_dict())
 
-    replay = FFReplay(args.replay_cap, SEED + rank, ALPHA, BETA, 0, NUM_ACTION, device)
+    replay = FFReplay(args.replay_cap, SEED + rank, ALPHA, BETA, 0, NUM_ACTION, device, dedup=args.dedup,
+                      guard_units=(MULTI_STEP + 8) * ROWS)
     eps_all = generate_eps(0.4, 7, ROWS * world)
     eps = eps_all[rank * ROWS:(rank + 1) * ROWS]
     engine = ApexActorEngine(ROWS, K_GAMES, NUM_ACTION, MULTI_STEP, GAMMA, replay, eps, device, seed=SEED + rank)
@@ -520,6 +525,9 @@ def main():
     z_a = torch.zeros(ROWS, dtype=torch.int64, device=device)
     z_f = torch.zeros(ROWS, device=device)
     z_b = torch.zeros(ROWS, dtype=torch.uint8, device=device)
+    while args.dedup and replay.size() + ROWS <= args.replay_cap:  # de-duplicated rows enter through the shard
+        actor_tick()
+        step_idx[0] += 1
     while replay.size() + ROWS <= args.replay_cap:
         prio.uniform_(0.01, 2.0, generator=g)
         obs_a, obs_b = engine.obs_hist[0], engine.obs_hist[1]
@@ -647,7 +655,8 @@ def main():
                                    "step for the whole job (B/G sampled per replay partition); device-resident static "
                                    "frames: no env stepping and no H2D inside the timed region",
                        "envs_per_gpu": ROWS, "replay_capacity": args.replay_cap, "learner_batch": BATCH,
-                       "learner_batch_per_gpu": B_LOCAL,
+                       "learner_batch_per_gpu": B_LOCAL, "replay_dedup": args.dedup,
+                       "replay_frame_bytes_per_transition": {None: 56448, "stack": 28224, "plane": 7056}[args.dedup],
                        "parallelism": ("actor-shards%d+replay-partitions+grad-allreduce" % world) if world > 1
                        else "single"},
             "grad_steps_per_s": args.steps / dt, "train_samples_per_s": args.steps * BATCH / dt,

@@ -72,6 +72,28 @@ int rela_replay_set_schema(rela_replay* r, int nfields, const int64_t* row_bytes
 int rela_replay_set_schema_seq(rela_replay* r, int nfields, const int64_t* row_bytes,
                                const int32_t* steps);
 
+/* Frame-stack de-duplication.  The reference's transitions are VIEWS: obs of one transition and
+ * next_obs of an earlier one share storage (rela/types.cc:48-67), and an Atari observation is a sliding stack of
+ * four 84x84 planes of which one is new per step (atari/game_state.h:53-82).  With this schema the two stack
+ * fields (field_a, field_b, each units_per_stack * unit_bytes long from the caller's point of view) are kept as
+ * units_per_stack int32 references into ONE ring of units (unit = a whole stack, units_per_stack 1: 28,224 B per
+ * env-step instead of 56,448; or unit = one plane, units_per_stack 4: 7,056 B); sample() rebuilds the full
+ * stacks in its gather, so the learner sees exactly the batch it would get without de-duplication.  The ring
+ * holds int(1.25 * capacity) + guard_units units: guard = the units a producer stores ahead of the transitions
+ * that use them ((multi_step + 1 [+ 3 planes]) * rows).  Producers: reserve units (blocks like begin_add while
+ * a live slot still refers to the unit that would be overwritten), write them, pass the references as the
+ * rows of the two stack fields, and declare the smallest sequence number a block refers to before commit. */
+int rela_replay_set_schema_dedup(rela_replay* r, int nfields, const int64_t* row_bytes, int field_a,
+                                 int field_b, int64_t unit_bytes, int units_per_stack, int64_t guard_units);
+/* first_seq: monotone sequence number of the first unit; first_index (may be NULL): its ring index, the
+ * value a reference holds (index of unit q = (first_index + q) mod capacity, see rela_replay_dedup_info) */
+int rela_replay_units_reserve(rela_replay* r, int count, int nonblocking, int64_t* first_seq, int32_t* first_index);
+/* copies count units from src_dev (unit q at src_dev + q * src_pitch) into the reserved range */
+int rela_replay_units_write(rela_replay* r, int64_t first_seq, int count, const void* src_dev, int64_t src_pitch,
+                            void* stream);
+int rela_replay_set_block_min_unit(rela_replay* r, int first_slot, int n, int64_t min_seq);
+int rela_replay_dedup_info(const rela_replay* r, int* units_per_stack, int64_t* unit_bytes, int64_t* unit_capacity);
+
 /* blockAppend in its three phases (prioritized_replay.h:43-78), for producers that assemble a
  * block piecewise (the R2D2 actor emits several sequences per pop):
  *   begin  :46-56  reserve n slots (blocks while the ring is full unless nonblocking)
@@ -316,6 +338,13 @@ int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward, const uin
                               int on_device, const rela_ffnet* online, const rela_ffnet* target,
                               int nonblocking, int* inserted, void* stream);
 
+/* Frame-stack de-duplication on the way in: the replay must have been given
+ * rela_replay_set_schema_dedup with the same units_per_stack.  1: every stack enters the unit ring once (obs of
+ * one transition and next_obs of another are the same stack, rela/types.cc:48-67) -- valid for any env.
+ * 4: one NEW 84x84 plane per env-step; valid only for envs that stack frames as GameState::computeFeature does
+ * (atari/game_state.h:53-82: slide by one plane per step, first frame of an episode repeated four times).
+ * Call once, before the first act().                                                              */
+int rela_apex_actor_set_dedup(rela_apex_actor* a, int units_per_stack);
 int64_t rela_apex_actor_num_act(const rela_apex_actor* a); /* numAct()  dqn_actor.h:149-151 */
 /* post_step evaluates online(next_obs) only if act() did not already do so with the same weights
  * (bit-identical, see post_step); on = 0 always recomputes, i.e. the reference's 4 forwards per step */

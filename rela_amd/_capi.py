@@ -67,6 +67,11 @@ _sig("rela_replay_create", i32, [P(vp), i32, i32, f32, f32, i32, i32])
 _sig("rela_replay_destroy", None, [vp])
 _sig("rela_replay_set_schema", i32, [vp, i32, P(i64)])
 _sig("rela_replay_set_schema_seq", i32, [vp, i32, P(i64), P(C.c_int32)])
+_sig("rela_replay_set_schema_dedup", i32, [vp, i32, P(i64), i32, i32, i64, i32, i64])
+_sig("rela_replay_units_reserve", i32, [vp, i32, i32, P(i64), P(C.c_int32)])
+_sig("rela_replay_units_write", i32, [vp, i64, i32, vp, i64, vp])
+_sig("rela_replay_set_block_min_unit", i32, [vp, i32, i32, i64])
+_sig("rela_replay_dedup_info", i32, [vp, P(i32), P(i64), P(i64)])
 _sig("rela_replay_begin_add", i32, [vp, i32, i32, P(i32)])
 _sig("rela_replay_write_rows", i32, [vp, i32, i32, i32, P(vp), vp])
 _sig("rela_replay_write_rows_gather", i32, [vp, i32, i32, vp, P(vp), P(vp), vp])
@@ -112,6 +117,7 @@ _sig("rela_apex_actor_eps_dev", vp, [vp])
 _sig("rela_apex_actor_legal_dev", vp, [vp])
 _sig("rela_apex_actor_act", i32, [vp, vp, vp, vp, vp, vp, P(vp), vp])
 _sig("rela_apex_actor_post_step", i32, [vp, vp, vp, i32, vp, vp, i32, P(i32), vp])
+_sig("rela_apex_actor_set_dedup", i32, [vp, i32])
 _sig("rela_apex_actor_num_act", i64, [vp])
 _sig("rela_apex_actor_set_reuse", i32, [vp, i32])
 _sig("rela_apex_actor_last_q_dev", vp, [vp])

@@ -43,10 +43,47 @@ struct rela_apex_actor {
   uint64_t q_version = 0;
   int q_slot = -1;
   bool reuse_act_forward = true;
+  // frame-stack de-duplication (rela_apex_actor_set_dedup; replay side: rela_replay_set_schema_dedup)
+  int dd_ups = 0;                    // 0 = off, 1 = one unit per stack, 4 = one unit per 84x84 plane
+  int64_t dd_cap = 0;                // units in the replay's ring
+  int32_t* ref_hist = nullptr;       // [n+1][R][ups] unit indices of every history slot's stack
+  std::vector<uint8_t> refs_valid;   // [n+1] the slot's units were stored
+  std::vector<int64_t> tick_seq;     // first unit sequence number of the last kTickWin ticks (ring by tick)
+  int64_t tick = 0, key_tick = -1;   // ticks stored so far; tick of the last keyframe (all planes stored)
 };
 
 namespace {
 constexpr int64_t kObs = 4 * 84 * 84;
+constexpr int64_t kPlane = 84 * 84;
+constexpr int kTickWin = 64;
+
+// references of the stack just acted on (history slot `cur`), per row:
+//   ups == 1            : the stack's own unit
+//   ups == 4, keyframe  : its four planes (stored together)
+//   ups == 4, otherwise : an episode start repeats the new plane four times (GameState::computeFeature,
+//                         atari/game_state.h:66-70); any other step slides the previous stack by one plane (:71-74)
+__global__ void dedup_make_refs(int32_t* __restrict__ cur, const int32_t* __restrict__ prev,
+                                const uint8_t* __restrict__ prev_term, int R, int ups, int keyframe, int32_t first_idx,
+                                int64_t cap) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= R) return;
+  if (ups == 1) {
+    cur[row] = (int32_t)(((int64_t)first_idx + row) % cap);
+    return;
+  }
+  int32_t* c = cur + (size_t)row * 4;
+  if (keyframe) {
+    for (int k = 0; k < 4; ++k) c[k] = (int32_t)(((int64_t)first_idx + 4 * row + k) % cap);
+    return;
+  }
+  const int32_t fresh = (int32_t)(((int64_t)first_idx + row) % cap);
+  if (prev_term[row]) {
+    c[0] = c[1] = c[2] = c[3] = fresh;
+  } else {
+    const int32_t* p = prev + (size_t)row * 4;
+    c[0] = p[1], c[1] = p[2], c[2] = p[3], c[3] = fresh;
+  }
+}
 }
 
 extern "C" int rela_apex_actor_create(rela_apex_actor** out, int rows, int group_rows, int num_action, int multi_step,
@@ -106,7 +143,7 @@ extern "C" void rela_apex_actor_destroy(rela_apex_actor* a) {
   DeviceGuard g(a->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {a->obs, a->act, a->rew, a->term, a->eps, a->legal, a->q, a->out_r, a->out_b, a->prio, a->out_t, a->ws,
-                a->eps_hist, a->legal_hist};
+                a->eps_hist, a->legal_hist, a->ref_hist};
   for (void* p : ps) (void)hipFree(p);
   delete a;
 }
@@ -119,6 +156,26 @@ extern "C" void* rela_apex_actor_obs_slot(rela_apex_actor* a) {
 extern "C" int rela_apex_actor_set_reuse(rela_apex_actor* a, int on) {
   RELA_CHECK(a, RELA_EINVAL, "rela_apex_actor_set_reuse: bad arguments");
   a->reuse_act_forward = on != 0;
+  return RELA_OK;
+}
+extern "C" int rela_apex_actor_set_dedup(rela_apex_actor* a, int units_per_stack) {
+  RELA_CHECK(a && a->replay && (units_per_stack == 1 || units_per_stack == 4), RELA_EINVAL,
+             "rela_apex_actor_set_dedup: needs a replay and 1 (stack units) or 4 (plane units)");
+  RELA_CHECK(a->count == 0 && a->tick == 0 && a->dd_ups == 0, RELA_ESTATE, "rela_apex_actor_set_dedup: call it once, before the first act()");
+  int ups = 0;
+  int64_t ub = 0, cap = 0;
+  int rc = rela_replay_dedup_info(a->replay, &ups, &ub, &cap);
+  if (rc != RELA_OK) return rc;
+  RELA_CHECK(ups == units_per_stack && ub * ups == kObs, RELA_EINVAL,
+             "rela_apex_actor_set_dedup: the replay's schema has %d units of %lld bytes per stack", ups, (long long)ub);
+  DeviceGuard g(a->device);
+  const size_t H = (size_t)a->n + 1;
+  RELA_HIP(hipMalloc(&a->ref_hist, H * (size_t)a->R * ups * sizeof(int32_t)));
+  RELA_HIP(hipMemset(a->ref_hist, 0, H * (size_t)a->R * ups * sizeof(int32_t)));
+  a->dd_ups = ups;
+  a->dd_cap = cap;
+  a->refs_valid.assign(H, 0);
+  a->tick_seq.assign(kTickWin, 0);
   return RELA_OK;
 }
 extern "C" float* rela_apex_actor_eps_dev(rela_apex_actor* a) { return a ? a->eps : nullptr; }
@@ -177,13 +234,56 @@ extern "C" int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward
   const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   RELA_HIP(hipMemcpyAsync(a->rew + (size_t)a->cur * a->R, reward, (size_t)a->R * sizeof(float), kind, s));
   RELA_HIP(hipMemcpyAsync(a->term + (size_t)a->cur * a->R, terminal, (size_t)a->R, kind, s));
+  const int H = a->n + 1;
+  if (a->dd_ups > 0) {
+    // de-duplicated replay: the stack acted on this tick enters the unit ring ONCE (one plane, or the whole
+    // stack); transitions refer to it (as next_obs now, as obs n ticks from now)
+    const int cur = a->cur, prev = (cur + H - 1) % H;
+    const bool prev_ok = a->tick > 0 && a->refs_valid[prev];
+    const int keyframe = (a->dd_ups == 4 && !prev_ok) ? 1 : 0;
+    const int count = (a->dd_ups == 4 && keyframe) ? 4 * a->R : a->R;
+    int64_t seq = 0;
+    int32_t idx = 0;
+    int rc = rela_replay_units_reserve(a->replay, count, nonblocking, &seq, &idx);
+    if (rc == RELA_EWOULDBLOCK) {
+      a->refs_valid[cur] = 0;  // ring full and non-blocking: this stack is not stored, its transitions are dropped
+    } else {
+      if (rc != RELA_OK) return rc;
+      const uint8_t* stack = a->obs + (size_t)cur * a->R * kObs;
+      if (a->dd_ups == 1) rc = rela_replay_units_write(a->replay, seq, count, stack, kObs, s);
+      else if (keyframe) rc = rela_replay_units_write(a->replay, seq, count, stack, kPlane, s);
+      else rc = rela_replay_units_write(a->replay, seq, count, stack + 3 * kPlane, kObs, s);  // the newest plane
+      if (rc != RELA_OK) return rc;
+      hipLaunchKernelGGL(dedup_make_refs, dim3(ceil_div(a->R, 256)), dim3(256), 0, s,
+                         a->ref_hist + (size_t)cur * a->R * a->dd_ups, a->ref_hist + (size_t)prev * a->R * a->dd_ups,
+                         a->term + (size_t)prev * a->R, a->R, a->dd_ups, keyframe, idx, a->dd_cap);
+      RELA_LAUNCH_CHECK();
+      a->refs_valid[cur] = 1;
+      if (keyframe || a->dd_ups == 1) a->key_tick = a->tick;
+      a->tick_seq[(size_t)(a->tick % kTickWin)] = seq;
+    }
+    a->tick += 1;
+  }
   a->cur = -1;
   a->count += 1;
   if (a->count < a->n + 1) return RELA_OK;  // canPop :46-48
-  const int H = a->n + 1;
   const int first = a->head, last = (a->head + a->n) % H;
   int rc = rela_nstep_return(a->n, a->R, a->gamma, first, a->rew, a->term, a->out_r, a->out_b, a->out_t, s);
   if (rc != RELA_OK) return rc;
+  // de-duplication: both stacks of the transition must be in the unit ring; the oldest unit it refers to is
+  // the first plane of obs_t, stored at most 3 ticks before tick t = (tick - 1) - n (never before a keyframe)
+  bool dd_drop = false;
+  int64_t dd_min_seq = 0;
+  if (a->dd_ups > 0) {
+    dd_drop = !(a->refs_valid[first] && a->refs_valid[last]);
+    int64_t t_first = a->tick - 1 - a->n;
+    int64_t oldest = a->dd_ups == 4 ? t_first - 3 : t_first;
+    if (oldest < 0) oldest = 0;
+    // a keyframe at or before t_first bounds the chain; a later one cannot happen while refs stay valid
+    if (a->key_tick >= 0 && a->key_tick <= t_first && oldest < a->key_tick) oldest = a->key_tick;
+    if (a->tick - oldest >= kTickWin) oldest = a->tick - kTickWin + 1;
+    dd_min_seq = a->tick_seq[(size_t)(oldest % kTickWin)];
+  }
   const uint8_t* obs_t = a->obs + (size_t)first * a->R * kObs;
   const uint8_t* obs_n = a->obs + (size_t)last * a->R * kObs;
   const size_t QA = (size_t)a->R * a->A;
@@ -211,6 +311,10 @@ extern "C" int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward
   if (rc != RELA_OK) return rc;
   // FFTransition rows (types.h:18-51): obs{s,eps,legal_move}, next_obs{...}, action{a}, reward, terminal, bootstrap
   const void* rows[10] = {obs_t, obs_n, eps_t, eps_n, legal_t, legal_n, act_t, a->out_r, a->out_t, a->out_b};
+  if (a->dd_ups > 0) {
+    rows[0] = a->ref_hist + (size_t)first * a->R * a->dd_ups;
+    rows[1] = a->ref_hist + (size_t)last * a->R * a->dd_ups;
+  }
   // One reference block per group of K rows (each batched actor thread's own add, :189).  The whole shard
   // is reserved at once when that can always be satisfied; a blocking append of more than ring - capacity
   // rows never can (sample() evicts down to capacity only), so a shard that large goes in pieces of whole
@@ -220,9 +324,10 @@ extern "C" int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward
   if (rc != RELA_OK) return rc;
   const int fit = ((ring - cap) / a->K) * a->K;
   const int piece = a->R <= ring - cap ? a->R : (fit > a->K ? fit : a->K);
-  const int64_t rb[10] = {kObs, kObs, 4, 4, 4 * a->A, 4 * a->A, 8, 4, 1, 4};
-  int dropped = 0;
-  for (int off = 0; off < a->R; off += piece) {
+  const int64_t stack_rb = a->dd_ups > 0 ? (int64_t)sizeof(int32_t) * a->dd_ups : kObs;
+  const int64_t rb[10] = {stack_rb, stack_rb, 4, 4, 4 * a->A, 4 * a->A, 8, 4, 1, 4};
+  int dropped = dd_drop ? 1 : 0;
+  for (int off = 0; off < a->R && !dd_drop; off += piece) {
     const int cnt = a->R - off < piece ? a->R - off : piece;
     const void* prow[10];
     for (int f = 0; f < 10; ++f) prow[f] = static_cast<const uint8_t*>(rows[f]) + (int64_t)off * rb[f];
@@ -233,6 +338,7 @@ extern "C" int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward
       continue;
     }
     if (rc != RELA_OK) break;
+    if (a->dd_ups > 0) (void)rela_replay_set_block_min_unit(a->replay, slot, cnt, dd_min_seq);
     rc = rela_replay_write_rows(a->replay, slot, 0, cnt, prow, s);
     if (rc == RELA_OK) rc = rela_replay_commit_add_grouped(a->replay, slot, cnt, a->K, a->prio + off, s);
     if (rc != RELA_OK) {  // release the reservation so later blocks of other producers can still commit

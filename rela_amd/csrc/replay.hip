@@ -308,6 +308,34 @@ __global__ __launch_bounds__(1024) void replay_finish(const float* __restrict__ 
 // gathers batch rows of every LARGE field in one launch (blockIdx.z = field): out[i] = field[ids[i]]
 // (makeBatch, types.cc:8-46); `steps` > 1: the row is a sequence of `steps` sub-rows and the output is
 // time-major, out[t][b] = slot_b[t]  (RNNTransition::makeBatch, types.cc:140-182)
+// De-duplicated stack field: out[b] = the `ups` units refs[ids[b]][0..ups) point to (the stack
+// GameState::computeFeature built on the way in, atari/game_state.h:53-82, is rebuilt on the way out).
+__global__ __launch_bounds__(kThreads) void replay_gather_dedup(const int32_t* __restrict__ refs,
+                                                               const int32_t* __restrict__ ids,
+                                                               const uint8_t* __restrict__ units, int64_t unit_bytes,
+                                                               int ups, uint8_t* __restrict__ out, int batch) {
+  for (int y = blockIdx.y; y < batch * ups; y += gridDim.y) {
+    const int b = y / ups, k = y - b * ups;
+    const int64_t u = refs[(int64_t)ids[b] * ups + k];
+    const uint4* s4 = reinterpret_cast<const uint4*>(units + u * unit_bytes);
+    uint4* d4 = reinterpret_cast<uint4*>(out + ((int64_t)b * ups + k) * unit_bytes);
+    const int64_t nv = unit_bytes >> 4;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kThreads) d4[i] = s4[i];
+  }
+}
+
+// copies `count` units from a pitched source into the unit ring at sequence first_seq..
+__global__ __launch_bounds__(kThreads) void replay_units_write(const uint8_t* __restrict__ src, int64_t pitch,
+                                                              uint8_t* __restrict__ units, int64_t unit_bytes,
+                                                              int64_t cap, int64_t first_seq, int count) {
+  for (int row = blockIdx.y; row < count; row += gridDim.y) {
+    const uint4* s4 = reinterpret_cast<const uint4*>(src + (int64_t)row * pitch);
+    uint4* d4 = reinterpret_cast<uint4*>(units + ((first_seq + row) % cap) * unit_bytes);
+    const int64_t nv = unit_bytes >> 4;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < nv; i += (int64_t)gridDim.x * kThreads) d4[i] = s4[i];
+  }
+}
+
 constexpr int kMaxBigFields = 12;
 struct BigFields {
   const uint8_t* field[kMaxBigFields];
@@ -437,6 +465,14 @@ struct rela_replay {
   std::vector<uint8_t*> d_fields;
   SeqIndex ix;
   HostStage stage;  // pinned staging of the RNG draws / host-side priorities (guarded by m)
+  // frame-stack de-duplication (rela_replay_set_schema_dedup): the two stack fields hold int32 references
+  // into a ring of UNITS (one 84x84 plane, or one 4-plane stack) addressed by a monotone sequence number
+  int dd_ups = 0;                 // units per stack (0 = de-duplication off)
+  int64_t dd_unit_bytes = 0, dd_cap = 0;
+  uint8_t* d_units = nullptr;     // [dd_cap][dd_unit_bytes]
+  int dd_field[2] = {-1, -1};
+  int64_t dd_next_seq = 0;        // sequence number of the next unit
+  std::vector<int64_t> dd_slot_min;  // [ring] smallest unit sequence a slot refers to (host; guarded by m)
 };
 
 extern "C" const char* rela_last_error(void) { return g_err; }
@@ -495,6 +531,7 @@ extern "C" void rela_replay_destroy(rela_replay* r) {
   for (auto* p : r->d_fields) (void)hipFree(p);
   seq_index_free(&r->ix);
   r->stage.destroy();
+  (void)hipFree(r->d_units);
   (void)hipFree(r->d_w);
   (void)hipFree(r->d_evicted);
   (void)hipFree(r->d_state);
@@ -539,6 +576,96 @@ extern "C" int rela_replay_set_schema_seq(rela_replay* r, int nfields, const int
   return RELA_OK;
 }
 
+// ---- frame-stack de-duplication ------------------------------------------------------
+extern "C" int rela_replay_set_schema_dedup(rela_replay* r, int nfields, const int64_t* row_bytes, int field_a,
+                                            int field_b, int64_t unit_bytes, int units_per_stack,
+                                            int64_t guard_units) {
+  RELA_CHECK(r && nfields >= 2 && row_bytes && field_a >= 0 && field_b >= 0 && field_a < nfields && field_b < nfields &&
+                 field_a != field_b && unit_bytes > 0 && unit_bytes % 16 == 0 && units_per_stack >= 1 &&
+                 units_per_stack <= 16 && guard_units >= 0,
+             RELA_EINVAL, "rela_replay_set_schema_dedup: bad arguments");
+  RELA_CHECK(row_bytes[field_a] == unit_bytes * units_per_stack && row_bytes[field_b] == row_bytes[field_a], RELA_EINVAL,
+             "rela_replay_set_schema_dedup: the stack fields must be units_per_stack * unit_bytes long");
+  std::vector<int64_t> rb(row_bytes, row_bytes + nfields);
+  rb[field_a] = rb[field_b] = (int64_t)sizeof(int32_t) * units_per_stack;  // references instead of frames
+  int rc = rela_replay_set_schema_seq(r, nfields, rb.data(), nullptr);
+  if (rc != RELA_OK) return rc;
+  DeviceGuard g(r->device);
+  std::lock_guard<std::mutex> lk(r->m);
+  r->dd_ups = units_per_stack;
+  r->dd_unit_bytes = unit_bytes;
+  r->dd_cap = (int64_t)r->ring + guard_units;
+  RELA_CHECK(r->dd_cap < ((int64_t)1 << 31), RELA_EINVAL, "rela_replay_set_schema_dedup: unit ring too large");
+  r->dd_field[0] = field_a;
+  r->dd_field[1] = field_b;
+  RELA_HIP(hipMalloc(&r->d_units, (size_t)r->dd_cap * (size_t)unit_bytes));
+  r->dd_slot_min.assign((size_t)r->ring, 0);
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_units_reserve(rela_replay* r, int count, int nonblocking, int64_t* first_seq,
+                                         int32_t* first_index) {
+  RELA_CHECK(r && r->dd_ups > 0 && count > 0 && first_seq, RELA_EINVAL, "rela_replay_units_reserve: bad arguments");
+  RELA_CHECK(count <= r->dd_cap, RELA_EINVAL, "rela_replay_units_reserve: %d units exceed the unit ring", count);
+  std::unique_lock<std::mutex> lk(r->m);
+  // a unit may be overwritten only when no live (or reserved) slot refers to it: FIFO order makes the slot at
+  // `head` the one with the smallest reference
+  auto fits = [&] {
+    const int64_t oldest = r->size > 0 ? r->dd_slot_min[(size_t)r->head] : r->dd_next_seq;
+    return r->dd_next_seq + count - oldest <= r->dd_cap;
+  };
+  if (r->shut) return RELA_EWOULDBLOCK;
+  if (!fits()) {
+    if (nonblocking) return RELA_EWOULDBLOCK;
+    r->cv_size.wait(lk, [&] { return r->shut || fits(); });
+    if (r->shut) return RELA_EWOULDBLOCK;
+  }
+  *first_seq = r->dd_next_seq;
+  if (first_index) *first_index = (int32_t)(r->dd_next_seq % r->dd_cap);
+  r->dd_next_seq += count;
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_units_write(rela_replay* r, int64_t first_seq, int count, const void* src_dev,
+                                       int64_t src_pitch, void* stream_) {
+  RELA_CHECK(r && r->dd_ups > 0 && count > 0 && src_dev && src_pitch >= r->dd_unit_bytes && src_pitch % 16 == 0 &&
+                 first_seq >= 0 && first_seq + count <= r->dd_next_seq && ((uintptr_t)src_dev & 15) == 0,
+             RELA_EINVAL, "rela_replay_units_write: bad arguments");
+  hipStream_t producer = (hipStream_t)stream_;
+  DeviceGuard g(r->device);
+  std::lock_guard<std::mutex> lk(r->m);
+  RELA_HIP(hipEventRecord(r->ev_in, producer));
+  RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
+  {
+    const int64_t nv = r->dd_unit_bytes >> 4;
+    const int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (nv + kThreads - 1) / kThreads), 64);
+    ProfScope prof("replay_scatter_rows", r->stream);
+    hipLaunchKernelGGL(replay_units_write, dim3(gx, std::min(count, 32768)), dim3(kThreads), 0, r->stream,
+                       (const uint8_t*)src_dev, src_pitch, r->d_units, r->dd_unit_bytes, r->dd_cap, first_seq, count);
+  }
+  RELA_LAUNCH_CHECK();
+  RELA_HIP(hipEventRecord(r->ev_out, r->stream));
+  RELA_HIP(hipStreamWaitEvent(producer, r->ev_out, 0));
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_set_block_min_unit(rela_replay* r, int first_slot, int n, int64_t min_seq) {
+  RELA_CHECK(r && r->dd_ups > 0 && n > 0 && first_slot >= 0 && first_slot < r->ring && n <= r->ring, RELA_EINVAL,
+             "rela_replay_set_block_min_unit: bad arguments");
+  std::lock_guard<std::mutex> lk(r->m);
+  for (int i = 0; i < n; ++i) r->dd_slot_min[(size_t)((first_slot + i) % r->ring)] = min_seq;
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_dedup_info(const rela_replay* r, int* units_per_stack, int64_t* unit_bytes,
+                                      int64_t* unit_capacity) {
+  RELA_CHECK(r, RELA_EINVAL, "rela_replay_dedup_info: bad arguments");
+  if (units_per_stack) *units_per_stack = r->dd_ups;
+  if (unit_bytes) *unit_bytes = r->dd_unit_bytes;
+  if (unit_capacity) *unit_capacity = r->dd_cap;
+  return RELA_OK;
+}
+
 static inline int vec16_ok(const void* a, const void* b, int64_t row_bytes) {
   return ((row_bytes & 15) == 0) && (((uintptr_t)a & 15) == 0) && (((uintptr_t)b & 15) == 0);
 }
@@ -554,6 +681,10 @@ extern "C" int rela_replay_begin_add(rela_replay* r, int n, int nonblocking, int
     if (r->shut) return RELA_EWOULDBLOCK;
   }
   *first_slot = r->tail;
+  if (r->dd_ups > 0) {  // until the producer declares it (set_block_min_unit): nothing older than the guard window
+    const int64_t lo = r->dd_next_seq - (r->dd_cap - r->ring);
+    for (int i = 0; i < n; ++i) r->dd_slot_min[(size_t)((r->tail + i) % r->ring)] = lo;
+  }
   r->tail = (r->tail + n) % r->ring;
   r->size += n;
   return RELA_OK;
@@ -752,6 +883,7 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
       if (!out_rows_dev[f]) continue;
       const int64_t rb = r->row_bytes[f];
       const int st = r->steps[f];
+      if (r->dd_ups > 0 && ((int)f == r->dd_field[0] || (int)f == r->dd_field[1])) continue;  // rebuilt below
       if (st == 1 && rb <= kSmallRowBytes && small.n < kMaxSmallFields) {
         small.src[small.n] = r->d_fields[f];
         small.dst[small.n] = (uint8_t*)out_rows_dev[f];
@@ -777,6 +909,19 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
     hipLaunchKernelGGL(replay_finish, dim3(1 + small.n), dim3(1024), 0, r->stream, (const float*)r->d_raw_w, batch,
                        (float)full_size, r->beta, (const ReplayDevState*)r->d_state, out_weight_dev, small,
                        (const int32_t*)r->d_ids);
+  }
+  if (out_rows_dev && r->dd_ups > 0) {
+    for (int q = 0; q < 2; ++q) {
+      const int f = r->dd_field[q];
+      if (!out_rows_dev[f]) continue;
+      RELA_CHECK(((uintptr_t)out_rows_dev[f] & 15) == 0, RELA_EINVAL, "rela_replay_sample: unaligned stack output");
+      const int64_t nv = r->dd_unit_bytes >> 4;
+      const int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (nv + kThreads - 1) / kThreads), 64);
+      ProfScope prof("replay_gather_rows", r->stream);
+      hipLaunchKernelGGL(replay_gather_dedup, dim3(gx, std::min(batch * r->dd_ups, 32768)), dim3(kThreads), 0, r->stream,
+                         (const int32_t*)r->d_fields[f], (const int32_t*)r->d_ids, (const uint8_t*)r->d_units,
+                         r->dd_unit_bytes, r->dd_ups, (uint8_t*)out_rows_dev[f], batch);
+    }
   }
   if (nbig > 0) {
     const int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (max_units + kThreads - 1) / kThreads), 64);

@@ -81,6 +81,9 @@ class ApexActorEngine:
                                                    replay.h if replay is not None else None, seed,
                                                    self.device.index or 0), "rela_apex_actor_create")
         self.h = h
+        if replay is not None and getattr(replay, "dedup", None):  # frame-stack de-duplication on the way in
+            capi.check(capi.lib.rela_apex_actor_set_dedup(h, {"stack": 1, "plane": 4}[replay.dedup]),
+                       "rela_apex_actor_set_dedup")
         dev = self.device
         base = capi.lib.rela_apex_actor_obs_slot(h)  # head = count = 0 -> slot 0 = base of the history
         self.obs_hist = dev_view(base, (multi_step + 1, rows, 4, 84, 84), torch.uint8, dev)

@@ -22,6 +22,7 @@
 #include <exception>
 #include <mutex>
 #include <stdexcept>
+#include <string>
 #include <thread>
 
 #include "rela/env.h"
@@ -319,7 +320,18 @@ class FFPrioritizedReplay {
       check(rela_replay_create(&h_, capacity_, seed_, alpha_, beta_, prefetch_, device), "rela_replay_create");
       const int64_t A = numAction;
       const int64_t rb[10] = {kObsBytes, kObsBytes, 4, 4, 4 * A, 4 * A, 8, 4, 1, 4};
-      check(rela_replay_set_schema(h_, 10, rb), "rela_replay_set_schema");
+      // RELA_REPLAY_DEDUP=stack|plane: frame-stack de-duplication (include/rela_amd.h).  "stack" is
+      // valid for any env (what the reference's shared tensor views do); "plane" needs an env that slides its
+      // stack by one frame per step as atari/game_state.h:53-82 does.
+      const char* dd = std::getenv("RELA_REPLAY_DEDUP");
+      const int ups = dd && std::string(dd) == "stack" ? 1 : (dd && std::string(dd) == "plane" ? 4 : 0);
+      if (ups > 0) {
+        const char* gd = std::getenv("RELA_REPLAY_DEDUP_GUARD");
+        const int64_t guard = gd ? std::atoll(gd) : 131072;  // units stored ahead of their transitions
+        check(rela_replay_set_schema_dedup(h_, 10, rb, 0, 1, kObsBytes / ups, ups, guard), "rela_replay_set_schema_dedup");
+      } else {
+        check(rela_replay_set_schema(h_, 10, rb), "rela_replay_set_schema");
+      }
       device_ = device;
       numAction_ = numAction;
     } else if (device != device_ || numAction != numAction_) {
@@ -500,6 +512,14 @@ class RNNPrioritizedReplay {
   torch::Tensor keep_;
 };
 
+// the actor side of a de-duplicating replay (RELA_REPLAY_DEDUP, see FFPrioritizedReplay::handle)
+static void enableDedup(rela_apex_actor* a, rela_replay* rep) {
+  if (!rep) return;
+  int ups = 0;
+  check(rela_replay_dedup_info(rep, &ups, nullptr, nullptr), "rela_replay_dedup_info");
+  if (ups > 0) check(rela_apex_actor_set_dedup(a, ups), "rela_apex_actor_set_dedup");
+}
+
 // =====================================================================================
 // ActorCohort -- cross-thread inference batching ("inference batches cross-thread per GPU").
 //
@@ -676,6 +696,7 @@ class ActorCohort {
       rela_replay* rep = replay_->handle(dev, A);
       check(rela_apex_actor_create(&h_, T_ * K_, K_, A, n_, gamma_, rep, 0xA24BAED4963EE407ull * (++counter), dev),
             "rela_apex_actor_create");
+      enableDedup(h_, rep);
     }
     created_ = true;
     auto pin = [](torch::Tensor t) { return torch::cuda::is_available() ? t.pin_memory() : t; };
@@ -770,6 +791,7 @@ class DQNActor : public Actor {
       check(rela_apex_actor_create(&h_, batchsize_, batchsize_, A, multiStep_, gamma_, rep,
                                    0x9E3779B97F4A7C15ull * (++counter), locker_->deviceIndex),
             "rela_apex_actor_create");
+      enableDedup(h_, rep);
       action_ = torch::zeros({batchsize_}, torch::kInt64);
       if (torch::cuda::is_available()) action_ = action_.pin_memory();
       epsHost_ = torch::zeros({batchsize_}, torch::kFloat32);

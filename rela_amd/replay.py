@@ -25,7 +25,12 @@ class FFReplay:
     FIELDS = ("s", "next_s", "eps", "next_eps", "legal_move", "next_legal_move", "a", "reward", "terminal",
               "bootstrap")
 
-    def __init__(self, capacity, seed, alpha, beta, prefetch, num_action, device="cuda:0"):
+    def __init__(self, capacity, seed, alpha, beta, prefetch, num_action, device="cuda:0", dedup=None,
+                 guard_units=0):
+        """dedup: None (s and next_s stored in full, 2 x 28,224 B per transition), "stack" (every stack stored once:
+        28,224 B per env-step) or "plane" (one new 84x84 plane per env-step: 7,056 B; only for envs that slide their
+        frame stack like atari/game_state.h:53-82).  guard_units: the units producers store ahead of the transitions
+        that use them, (multi_step + 8) * rows of all producers is always enough."""
         self.device = torch.device(device)
         self.num_action = num_action
         h = C.c_void_p()
@@ -35,7 +40,13 @@ class FFReplay:
         A = num_action
         self.row_bytes = [OBS_BYTES, OBS_BYTES, 4, 4, 4 * A, 4 * A, 8, 4, 1, 4]
         rb = (C.c_int64 * len(self.row_bytes))(*self.row_bytes)
-        capi.check(capi.lib.rela_replay_set_schema(h, len(self.row_bytes), rb), "rela_replay_set_schema")
+        self.dedup = dedup
+        if dedup is None:
+            capi.check(capi.lib.rela_replay_set_schema(h, len(self.row_bytes), rb), "rela_replay_set_schema")
+        else:
+            ups = {"stack": 1, "plane": 4}[dedup]
+            capi.check(capi.lib.rela_replay_set_schema_dedup(h, len(self.row_bytes), rb, 0, 1, OBS_BYTES // ups, ups,
+                                                             int(guard_units)), "rela_replay_set_schema_dedup")
         self._out = {}
         self._keep = None
 

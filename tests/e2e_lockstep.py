@@ -23,6 +23,11 @@ def _wait(cond, what, timeout=120.0):
         time.sleep(0.002)
 
 
+# the same run with an Atari-like env: ONE new plane per step, sliding stack, first frame of an episode repeated
+# four times (atari/game_state.h:53-82) -- the stream a plane-level de-duplicating replay is valid for
+CFG_SLIDING = dict(CFG, sliding=True, env_seed=950, rounds=8)
+
+
 def run_lockstep(rela, synth_atari, agent, act_device, sample_device, cfg=CFG):
     """agent: an ApexAgent-shaped module whose state_dict carries online_net.* / target_net.*."""
     ring = int(1.25 * cfg["capacity"])
@@ -32,7 +37,10 @@ def run_lockstep(rela, synth_atari, agent, act_device, sample_device, cfg=CFG):
     vec = rela.VectorEnv()
     games = []
     for g in range(cfg["K"]):
-        game = synth_atari.SyntheticAtariEnv(cfg["env_seed"] + g, 0.0, cfg["num_action"], cfg["episode_len"])
+        if cfg.get("sliding"):
+            game = synth_atari.SyntheticAtariEnv(cfg["env_seed"] + g, 0.0, cfg["num_action"], cfg["episode_len"], True)
+        else:
+            game = synth_atari.SyntheticAtariEnv(cfg["env_seed"] + g, 0.0, cfg["num_action"], cfg["episode_len"])
         games.append(game)
         vec.append(game)
     ctx = rela.Context()
@@ -48,6 +56,7 @@ def run_lockstep(rela, synth_atari, agent, act_device, sample_device, cfg=CFG):
         rounds.append(dict(
             s_sum=s.reshape(len(s), -1).sum(1).tolist(), s_head=s.reshape(len(s), -1)[:, :4].tolist(),
             next_s_sum=ns.reshape(len(ns), -1).sum(1).tolist(),
+            s_planes=s.reshape(len(s), 4, -1).sum(2).tolist(), next_s_planes=ns.reshape(len(ns), 4, -1).sum(2).tolist(),
             a=batch.action["a"].cpu().tolist(), reward=batch.reward.cpu().tolist(),
             terminal=[int(x) for x in batch.terminal.cpu().tolist()], bootstrap=batch.bootstrap.cpu().tolist(),
             eps=batch.obs["eps"].cpu().reshape(-1).tolist(),

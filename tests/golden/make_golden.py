@@ -387,7 +387,7 @@ def powf_cases():
     save("aten_powf_vectors", [], out)
 
 
-def e2e_cases():
+def e2e_cases(cfg_name="CFG", out_name="e2e_lockstep_apex"):
     """The REAL reference end to end: its pybind module (oracle/_ref/rela*.so), its TorchScript
     ApexAgent on the CPU, our synthetic env compiled against its rela/env.h."""
     code = r"""
@@ -400,15 +400,15 @@ import rela, synth_atari
 assert "_ref" in rela.__file__
 from apex import ApexAgent
 from net import AtariFFNet
-from e2e_lockstep import CFG, run_lockstep, load_agent_params
-agent = load_agent_params(ApexAgent(lambda: AtariFFNet(CFG["num_action"]), CFG["multi_step"], CFG["gamma"]))
-rounds = run_lockstep(rela, synth_atari, agent, "cpu", "cpu")
+from e2e_lockstep import %s as CFG, run_lockstep, load_agent_params
+agent = load_agent_params(ApexAgent(lambda: AtariFFNet(CFG["num_action"]), CFG["multi_step"], CFG["gamma"]), CFG)
+rounds = run_lockstep(rela, synth_atari, agent, "cpu", "cpu", CFG)
 print("RESULT" + json.dumps(rounds))
-""" % (REFBIN, os.path.dirname(HERE))
+""" % (REFBIN, os.path.dirname(HERE), cfg_name)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True)
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1]
-    from e2e_lockstep import CFG
-    save("e2e_lockstep_apex", [], json.loads(line[len("RESULT"):]), cfg=CFG)
+    import e2e_lockstep
+    save(out_name, [], json.loads(line[len("RESULT"):]), cfg=getattr(e2e_lockstep, cfg_name))
 
 
 def e2e_r2d2_cases(cfg_name="CFG_R2D2", out_name="e2e_lockstep_r2d2", quiet=1.0):
@@ -453,6 +453,8 @@ if __name__ == "__main__":
         r2d2agg_cases()
     if "e2e" in which:
         e2e_cases()
+    if "e2e_sliding" in which:  # Atari-like sliding frame stacks (for the de-duplicating replay)
+        e2e_cases("CFG_SLIDING", "e2e_lockstep_apex_sliding")
     if "replay" in which:
         replay_cases()
     if "nstep" in which:

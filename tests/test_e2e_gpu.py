@@ -25,7 +25,35 @@ def mods():
     return rela, synth_atari
 
 
-def test_lockstep_matches_reference(mods):
+def _check_apex_rounds(rounds, gold):
+    assert len(rounds) == len(gold["expect"])
+    for r, (got, exp) in enumerate(zip(rounds, gold["expect"])):
+        for key in ("s_sum", "s_head", "next_s_sum", "s_planes", "next_s_planes", "a", "terminal", "bootstrap", "eps",
+                    "legal_sum", "num_add"):
+            assert got[key] == exp[key], (r, key)
+        assert np.array_equal(np.float32(got["reward"]), np.float32(exp["reward"])), r  # n-step return: exact
+        np.testing.assert_allclose(got["weight"], exp["weight"], rtol=1e-4, err_msg="IS weights, round %d" % r)
+
+
+@pytest.fixture
+def dedup_env():
+    """RELA_REPLAY_DEDUP for the duration of one test (read when the replay partition is created)."""
+    def set_(mode):
+        if mode:
+            os.environ["RELA_REPLAY_DEDUP"] = mode
+            os.environ["RELA_REPLAY_DEDUP_GUARD"] = "512"
+        else:
+            os.environ.pop("RELA_REPLAY_DEDUP", None)
+    yield set_
+    os.environ.pop("RELA_REPLAY_DEDUP", None)
+    os.environ.pop("RELA_REPLAY_DEDUP_GUARD", None)
+
+
+@pytest.mark.parametrize("dedup", [None, "stack"])
+def test_lockstep_matches_reference(mods, dedup_env, dedup):
+    """dedup = "stack": the replay keeps every observation stack once (obs of one transition = next_obs of
+    another, as the reference's tensor views share storage, rela/types.cc:48-67); the sampled batches must be the
+    same rows the REAL reference returned (SURVEY 8f-3's parity definition)."""
     from e2e_lockstep import CFG, load_agent_params, run_lockstep
     from rela_amd.pyrela.apex import ApexAgent
     from rela_amd.pyrela.net import AtariFFNet
@@ -33,14 +61,27 @@ def test_lockstep_matches_reference(mods):
     rela, synth = mods
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_lockstep_apex.json")))
     assert gold["cfg"] == CFG
+    dedup_env(dedup)
     agent = load_agent_params(ApexAgent(lambda: AtariFFNet(CFG["num_action"]), CFG["multi_step"], CFG["gamma"]))
-    rounds = run_lockstep(rela, synth, agent, "cuda:0", "cuda:0")
-    assert len(rounds) == len(gold["expect"])
-    for r, (got, exp) in enumerate(zip(rounds, gold["expect"])):
-        for key in ("s_sum", "s_head", "next_s_sum", "a", "terminal", "bootstrap", "eps", "legal_sum", "num_add"):
-            assert got[key] == exp[key], (r, key)
-        assert np.array_equal(np.float32(got["reward"]), np.float32(exp["reward"])), r  # n-step return: exact
-        np.testing.assert_allclose(got["weight"], exp["weight"], rtol=1e-4, err_msg="IS weights, round %d" % r)
+    _check_apex_rounds(run_lockstep(rela, synth, agent, "cuda:0", "cuda:0"), gold)
+
+
+@pytest.mark.parametrize("dedup", [None, "stack", "plane"])
+def test_lockstep_sliding_env_matches_reference(mods, dedup_env, dedup):
+    """An Atari-like env (one new 84x84 plane per step, sliding stack, first frame of an episode repeated four
+    times: atari/game_state.h:53-82) driven through the REAL reference gave tests/golden/e2e_lockstep_apex_sliding.json.
+    With dedup = "plane" the replay stores 7,056 B per env-step instead of 56,448 B and rebuilds the stacks in its
+    gather: every sampled frame stack (per-plane sums), action, reward, flag and weight must equal the reference's."""
+    from e2e_lockstep import CFG_SLIDING as C, load_agent_params, run_lockstep
+    from rela_amd.pyrela.apex import ApexAgent
+    from rela_amd.pyrela.net import AtariFFNet
+
+    rela, synth = mods
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_lockstep_apex_sliding.json")))
+    assert gold["cfg"] == C
+    dedup_env(dedup)
+    agent = load_agent_params(ApexAgent(lambda: AtariFFNet(C["num_action"]), C["multi_step"], C["gamma"]), C)
+    _check_apex_rounds(run_lockstep(rela, synth, agent, "cuda:0", "cuda:0", C), gold)
 
 
 @pytest.mark.parametrize("hip_learner", [1, 0])
