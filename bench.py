@@ -55,6 +55,11 @@ SEED = 10002
 FLOP = {"conv1_bf16x3": 2 * 400 * 32 * 256, "conv2_mfma": 2 * 81 * 64 * 512, "conv3_mfma": 2 * 49 * 64 * 576,
         "fc_mfma": 2 * 3136 * 512, "heads_mfma": 2 * 512 * 19}
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
+# algorithmic HBM bytes per sample-forward of each kernel: input tensor + output tensor (activations are 4 B per
+# element in both precision modes: f32, or bf16 hi + lo), u8 frames in, f32 h out
+BYTES_PER_SAMPLE = {"conv1_bf16x3": 28224 + 400 * 32 * 4, "conv2_mfma": 400 * 32 * 4 + 81 * 64 * 4,
+                    "conv3_mfma": 81 * 64 * 4 + 49 * 64 * 4, "fc_mfma": 49 * 64 * 4 + 512 * 4, "heads_mfma": 512 * 4 + 32 * 4}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -361,6 +366,10 @@ def main():
                     help="frame-stack de-duplication in the replay (SURVEY 8f-3): stack = 28,224 B per env-step, plane = "
                          "7,056 B (the frames of this bench are static, so only the byte traffic is representative); "
                          "default: s and next_s stored in full (56,448 B), as in round 1's headline")
+    ap.add_argument("--precision", default="bf16x2", choices=["f32", "bf16x2"],
+                    help="arithmetic of the actors' conv2 / conv3 / fc: bf16x2 = split-bf16 MFMA (hi + lo bf16 operands, "
+                         "three products, f32 accumulation; Q within 1e-6 of the f32 path in tests/test_ffnet_gpu.py, stated "
+                         "tolerance 1e-4), f32 = exact f32 MFMA (the parity mode, round 1's headline)")
     ap.add_argument("--algo", default="apex", help="apex (BASELINE.json's metric, the default) | r2d2 (config C4's "
                                                    "sequence shape: seq 80 / burn-in 40 / n 3, 3200 envs, B = 64)")
     args = ap.parse_args()
@@ -423,6 +432,8 @@ def main():
     online, target = FFNetHandle(NUM_ACTION, device), FFNetHandle(NUM_ACTION, device)
     online.load_state_dict(agent.online_net.state_dict())
     target.load_state_dict(agent.target_net.state_dict())
+    online.set_precision(args.precision)
+    target.set_precision(args.precision)
 
     replay = FFReplay(args.replay_cap, SEED + rank, ALPHA, BETA, 0, NUM_ACTION, device, dedup=args.dedup,
                       guard_units=(MULTI_STEP + 8) * ROWS)
@@ -618,11 +629,26 @@ def main():
         name, rec = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
         avg_ms = rec["total_ms"] / rec["count"]
         if name in FLOP:
+            # Both rooflines of the dominant kernel; `bound` = the one it sits closer to.  MFMA: algorithmic FLOPs
+            # (2 * MACs) over the dense peak of the instruction the kernel issues -- f32 mode:
+            # v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s; bf16x2 mode: v_mfma_f32_16x16x32_bf16, 2,500 TFLOP/s, of which
+            # the three products per algorithmic product leave 833 (conv1 runs its exact 3-piece split in both
+            # modes).  HBM: algorithmic bytes (input + output tensors, 4 B per activation) over 8 TB/s.
             flops = FLOP[name] * ROWS
-            roof = {"kernel": name, "bound": "mfma", "achieved": flops / (avg_ms * 1e-3) / 1e12,
-                    "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "traffic": None,
-                    "avg_launch_ms": avg_ms, "launches": rec["count"],
-                    "algorithmic_flop_per_launch": flops}
+            split3 = args.precision == "bf16x2" or name == "conv1_bf16x3"
+            peak_mfma = PEAK_BF16_MFMA_TFLOPS / 3.0 if split3 else PEAK_F32_MFMA_TFLOPS
+            nbytes = BYTES_PER_SAMPLE[name] * ROWS
+            mfma = {"achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": peak_mfma, "unit": "TFLOP/s",
+                    "algorithmic_flop_per_launch": flops,
+                    "instruction": "v_mfma_f32_16x16x32_bf16 x3 (hi/lo split)" if split3 else "v_mfma_f32_16x16x4_f32"}
+            mfma["frac"] = mfma["achieved"] / peak_mfma
+            hbm = {"achieved": nbytes / (avg_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                   "algorithmic_bytes_per_launch": nbytes}
+            hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
+            pick = mfma if mfma["frac"] >= hbm["frac"] else hbm
+            roof = {"kernel": name, "bound": "mfma" if pick is mfma else "hbm", "achieved": pick["achieved"],
+                    "peak": pick["peak"], "unit": pick["unit"], "traffic": None, "avg_launch_ms": avg_ms,
+                    "launches": rec["count"], "mfma": mfma, "hbm": hbm}
         else:
             roof = {"kernel": name, "bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "traffic": None, "avg_launch_ms": avg_ms, "launches": rec["count"]}
@@ -649,13 +675,16 @@ def main():
             "metric": "env-steps/s (Ape-X Atari 84x84x4, actor tick + learner grad-step)",
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else "f32 results from split-bf16 MFMA (bf16 hi+lo operands, 3 products, "
+                                                           "f32 accumulate; |dQ| < 1e-6 vs the f32 path)",
+            "data": "synthetic",
             "config": {"workload": "Ape-X DQN, 80 threads x 80 games (6400 envs) per GPU, actor+learner on one "
                                    "MI355X, replay 2^20 per GPU device-resident, A=18, n=3, ONE learner batch of 512 per "
                                    "step for the whole job (B/G sampled per replay partition); device-resident static "
                                    "frames: no env stepping and no H2D inside the timed region",
                        "envs_per_gpu": ROWS, "replay_capacity": args.replay_cap, "learner_batch": BATCH,
-                       "learner_batch_per_gpu": B_LOCAL, "replay_dedup": args.dedup,
+                       "learner_batch_per_gpu": B_LOCAL, "replay_dedup": args.dedup, "actor_precision": args.precision,
                        "replay_frame_bytes_per_transition": {None: 56448, "stack": 28224, "plane": 7056}[args.dedup],
                        "parallelism": ("actor-shards%d+replay-partitions+grad-allreduce" % world) if world > 1
                        else "single"},

@@ -236,6 +236,14 @@ int rela_ffnet_num_action(const rela_ffnet* net);
 /* number of completed rela_ffnet_load calls: (net, version) names one set of weights, which lets a
  * caller reuse a forward it already ran on the same input (rela_apex_actor_post_step does) */
 uint64_t rela_ffnet_version(const rela_ffnet* net);
+/* Arithmetic of conv2 / conv3 / fc in rela_ffnet_forward.  0 (default, the parity mode): v_mfma_f32_16x16x4_f32,
+ * bit-for-bit an f32 fmaf chain.  1: split-bf16 on v_mfma_f32_16x16x32_bf16 -- every activation and weight is
+ * carried as hi + lo bf16 (16 mantissa bits) and a product is a_lo*b_hi + a_hi*b_lo + a_hi*b_hi with f32
+ * accumulation: ~2^-16 relative error per product instead of 2^-24, 5.3x less matrix-core time.  Stated
+ * tolerance: Q-values within 1e-4 (abs + rel) of the f32 path and of the reference goldens
+ * (tests/test_ffnet_gpu.py reports the greedy-action agreement).  conv1 and the heads are exact in both. */
+int rela_ffnet_set_precision(rela_ffnet* net, int mode);
+int rela_ffnet_precision(const rela_ffnet* net);
 /* bytes of scratch rela_ffnet_forward needs for a batch of n */
 int64_t rela_ffnet_workspace_bytes(const rela_ffnet* net, int n);
 

@@ -44,6 +44,8 @@ struct FFNetDev {
   float *Bf = nullptr, *bf = nullptr;  // fc    frags [32][784][64], bias[512]
   float* BfT = nullptr;                // fc    weights [3136 (k = pos*64+c)][512] for the small-batch split-K path
   float *Bh = nullptr, *bh = nullptr;  // heads frags [2][128][64], bias[32]  (cols 0..A-1 = fc_a, col 31 = fc_v)
+  // split-bf16 fast path: [ct][ks][hi, lo][lane] x 8 bf16 (see "Split-bf16" below)
+  uint4 *B2f = nullptr, *B3f = nullptr, *Bff = nullptr;
 };
 
 namespace {
@@ -409,6 +411,10 @@ __device__ __forceinline__ uint4 u8x8_to_bf16x8(uint32_t d0, uint32_t d1) {
   return make_uint4(pk(d0, 0), pk(d0, 2), pk(d1, 0), pk(d1, 2));
 }
 
+__device__ __forceinline__ void split_store(uint8_t* rec, int C, int col, float v, bool valid);
+
+// SPLIT: the output goes out as split-bf16 pixel records (fast path below) instead of f32
+template <bool SPLIT>
 __global__ __launch_bounds__(kThreads) void conv1_bf16x3(const uint8_t* __restrict__ in,
                                                          const uint4* __restrict__ Bfrag,
                                                          const float* __restrict__ bias, float* __restrict__ out,
@@ -498,8 +504,11 @@ __global__ __launch_bounds__(kThreads) void conv1_bf16x3(const uint8_t* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = rt * 16 + g * 4 + r;
-        if (m < mlim) {
-          const float v = acc[t][c][r] + bv;
+        const float v = acc[t][c][r] + bv;
+        if constexpr (SPLIT) {
+          split_store(reinterpret_cast<uint8_t*>(out) + ((size_t)n0 * C::P + m) * (C::OC * 4), C::OC, col,
+                      v > 0.f ? v : 0.f, m < mlim);
+        } else if (m < mlim) {
           out[((size_t)n0 * C::P + m) * C::OC + col] = v > 0.f ? v : 0.f;
         }
       }
@@ -532,6 +541,308 @@ __global__ void pack_conv1_bf16x3(const float* __restrict__ w, uint16_t* __restr
   frag[idx] = hi;
   frag[plane + idx] = mid;
   frag[2 * plane + idx] = lo;
+}
+
+// =====================================================================================================
+// Split-bf16 ("fast") path: conv2 / conv3 / fc on v_mfma_f32_16x16x32_bf16 (16x the f32 MFMA rate).
+// Every activation and weight x is kept as TWO bf16 numbers, hi = bf16(x), lo = bf16(x - hi) (16 mantissa
+// bits together), and a product is evaluated as  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  with f32 accumulation:
+// the dropped terms (a_lo*b_lo and the residuals beyond 16 bits) are ~2^-16 of |a||b| per product, against
+// 2^-24 for the exact f32 path, which stays the parity mode (rela_ffnet_set_precision).  Activations travel
+// between the layers in "split records": per pixel, C channels of hi (2 B each) followed by C channels of
+// lo -- the same 4 bytes per element as f32, so HBM traffic is unchanged while the MFMA work drops 5.3x.
+// =====================================================================================================
+__device__ __forceinline__ uint32_t split_pack(float v) {  // hi in the low half, lo in the high half
+  const uint16_t hi = f32_to_bf16_rne(v);
+  const uint16_t lo = f32_to_bf16_rne(v - bf16_to_f32(hi));
+  return (uint32_t)hi | ((uint32_t)lo << 16);
+}
+// Store one value per lane of a 16-column accumulator row into a split record: lanes pair up (col, col ^ 1) so
+// that every lane issues ONE 4-byte store (even lane: the two hi halves, odd lane: the two lo halves).
+__device__ __forceinline__ void split_store(uint8_t* rec, int C, int col, float v, bool valid) {
+  const uint32_t p = split_pack(v);
+  const uint32_t q = (uint32_t)__shfl_xor((int)p, 1, 64);
+  if (!valid) return;
+  if ((col & 1) == 0)
+    *reinterpret_cast<uint32_t*>(rec + col * 2) = (p & 0xffffu) | (q << 16);
+  else
+    *reinterpret_cast<uint32_t*>(rec + C * 2 + (col - 1) * 2) = (q >> 16) | (p & 0xffff0000u);
+}
+
+// conv on split records, weight-stationary and persistent (one block per CU walks over its sample groups with
+// a double-buffered LDS tile).  k = (tap, c): one MFMA k-step = 32 channels of one input pixel, i.e. lane
+// group g reads the 16 bytes of channels 8g..8g+7 from the hi part and from the lo part of the pixel record.
+// LDS pixel / row / sample strides (in 16-byte units) are padded so that the 16 lanes ds_read_b128 services
+// together hit 16 different 16-byte bank groups: unit(p, g) = 2p + g (mod 16) over output positions p.
+template <int CIN_, int IH_, int IW_, int KH_, int KW_, int STRIDE_, int OH_, int OW_, int S_, int Q_, int RQ_, int SQ_>
+struct ConvFastCfg {
+  static constexpr int CIN = CIN_, IH = IH_, IW = IW_, KH = KH_, KW = KW_, STRIDE = STRIDE_, OH = OH_, OW = OW_, S = S_;
+  static constexpr int OC = 64, CT = 4, RG = kWaves / CT;
+  static constexpr int P = OH * OW, M = S * P, RT = (M + 15) / 16, RPW = (RT + RG - 1) / RG;
+  static constexpr int KSUB = CIN / 32;              // k-steps per tap
+  static constexpr int KS = KH * KW * KSUB;          // k-steps of 32
+  static constexpr int REC = CIN * 4;                // bytes per input pixel record
+  static constexpr int Q = Q_, RQ = RQ_, SQ = SQ_;   // pixel / row / sample stride in 16-byte units
+  static constexpr int LDS_BYTES = S * SQ * 16;      // one input buffer
+  static constexpr int OUT_BYTES = S * OH * OW * 64 * 4;  // output records of one group (staged for coalesced stores)
+  static constexpr int LDS_TOTAL = 2 * LDS_BYTES + OUT_BYTES;
+  static constexpr int IN_BYTES = IH * IW * REC;     // per sample in HBM
+  static constexpr int V16 = S * IN_BYTES / 16;      // 16-byte chunks per group
+  static constexpr int IT = (V16 + kThreads - 1) / kThreads, IT2 = (IT + 1) / 2;
+  static_assert(REC / 16 <= Q, "pixel stride too small");
+};
+constexpr int kFastMinN = 1024;  // below this the launches are latency-bound and the f32 path (split-K fc) is as fast
+// conv2: 20x20x32 -> 9x9x64, stride 2: 2*Q = 2, 2*RQ = 18 = 2 (mod 16)
+using Conv2F = ConvFastCfg<32, 20, 20, 4, 4, 2, 9, 9, 1, 9, 185, 20 * 185>;
+// conv3: 9x9x64 -> 7x7x64, stride 1: Q = 2, RQ = 14 (7 positions per row), SQ = 98 = 2 (mod 16)
+using Conv3F = ConvFastCfg<64, 9, 9, 3, 3, 1, 7, 7, 2, 18, 174, 1570>;
+
+template <class C>
+__global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict__ in, const uint4* __restrict__ Bfrag,
+                                                       const float* __restrict__ bias, uint8_t* __restrict__ out,
+                                                       int N) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int ct = wave % C::CT, rg = wave / C::CT;
+  const int li = lane & 15, g = lane >> 4;
+  const int ngroups = (N + C::S - 1) / C::S;
+
+  // weights of this wave's 16 output channels: [ks][hi, lo] fragments, resident for the whole launch
+  bf16x8 bh[C::KS], bl[C::KS];
+  {
+    const uint4* bp = Bfrag + (size_t)ct * C::KS * 2 * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+      bh[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2) * 64]);
+      bl[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2 + 1) * 64]);
+    }
+  }
+  int abase[C::RPW];
+#pragma unroll
+  for (int t = 0; t < C::RPW; ++t) {
+    const int m = (rg + t * C::RG) * 16 + li;
+    const int mm = (m < C::M) ? m : 0;
+    const int sm = mm / C::P, pos = mm - sm * C::P;
+    const int oy = pos / C::OW, ox = pos - oy * C::OW;
+    abase[t] = (sm * C::SQ + oy * C::STRIDE * C::RQ + ox * C::STRIDE * C::Q + g) * 16;
+  }
+  const int col = ct * 16 + li;
+  const float bv = bias[col];
+
+  uint4 v[C::IT2];
+  auto stage_load = [&](int grp, int phase) {
+    const int n0 = grp * C::S;
+    const int ns = min(C::S, N - n0);
+    const uint4* src = reinterpret_cast<const uint4*>(in + (size_t)n0 * C::IN_BYTES);
+#pragma unroll
+    for (int j = 0; j < C::IT2; ++j) {
+      const int i = tid + (phase * C::IT2 + j) * kThreads;
+      v[j] = (i < ns * (C::IN_BYTES / 16)) ? src[i] : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto stage_store = [&](int buf, int phase) {
+    uint8_t* dst = smem + buf * C::LDS_BYTES;
+    constexpr int UPP = C::REC / 16;  // 16-byte units per pixel record
+#pragma unroll
+    for (int j = 0; j < C::IT2; ++j) {
+      const int i = tid + (phase * C::IT2 + j) * kThreads;
+      if (i < C::V16) {
+        const int pixel = i / UPP, u = i - pixel * UPP;
+        const int sm = pixel / (C::IH * C::IW), pin = pixel - sm * (C::IH * C::IW);
+        const int y = pin / C::IW, x = pin - y * C::IW;
+        *reinterpret_cast<uint4*>(dst + (size_t)(sm * C::SQ + y * C::RQ + x * C::Q + u) * 16) = v[j];
+      }
+    }
+  };
+
+  int grp = blockIdx.x;
+  if (grp >= ngroups) return;
+  stage_load(grp, 0);
+  stage_store(0, 0);
+  stage_load(grp, 1);
+  stage_store(0, 1);
+  __syncthreads();
+  int buf = 0;
+  constexpr int NT = C::KH * C::KW;
+  constexpr int LO = C::CIN * 2;  // byte offset of the lo part inside a pixel record
+  for (; grp < ngroups; grp += gridDim.x) {
+    const bool has_next = grp + (int)gridDim.x < ngroups;
+    if (has_next) stage_load(grp + gridDim.x, 0);
+    const uint8_t* tile = smem + buf * C::LDS_BYTES;
+    f32x4 acc[C::RPW];
+#pragma unroll
+    for (int t = 0; t < C::RPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < NT; ++tap) {
+      const int kh = tap / C::KW, kw = tap - kh * C::KW;
+#pragma unroll
+      for (int sub = 0; sub < C::KSUB; ++sub) {
+        const int ks = tap * C::KSUB + sub;
+        const int koff = (kh * C::RQ + kw * C::Q) * 16 + sub * 64;
+#pragma unroll
+        for (int t = 0; t < C::RPW; ++t) {
+          const uint8_t* ap = tile + abase[t] + koff;
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
+          const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + LO));
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ks], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ks], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ks], acc[t], 0, 0, 0);
+        }
+      }
+      // the other buffer was last read one group ago (barrier since): fill it while this group computes
+      if (has_next) {
+        if (tap == NT / 3) {
+          stage_store(buf ^ 1, 0);
+          stage_load(grp + gridDim.x, 1);
+        } else if (tap == (2 * NT) / 3) {
+          stage_store(buf ^ 1, 1);
+        }
+      }
+    }
+    // epilogue: bias + ReLU + hi/lo split into an LDS copy of the group's output records, then ONE coalesced
+    // 16-byte-per-lane copy to HBM (a wave's own 16 channels are only 32 contiguous bytes per pixel)
+    const int n0 = grp * C::S;
+    const int mlim = min(C::S, N - n0) * C::P;
+    uint8_t* otile = smem + 2 * C::LDS_BYTES;
+#pragma unroll
+    for (int t = 0; t < C::RPW; ++t) {
+      const int rt = rg + t * C::RG;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = rt * 16 + g * 4 + r;
+        const float o = acc[t][r] + bv;
+        split_store(otile + (size_t)m * (C::OC * 4), C::OC, col, o > 0.f ? o : 0.f, m < C::M);
+      }
+    }
+    __syncthreads();
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(otile);
+      uint4* dst = reinterpret_cast<uint4*>(out + (size_t)n0 * C::P * (C::OC * 4));
+      const int nv = mlim * (C::OC * 4 / 16);
+      for (int i = tid; i < nv; i += kThreads) dst[i] = src[i];
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+// fc on split records: out[N][512] = relu(A x W + b), A = a3 records [N][49][hi 64 | lo 64], k = pos*64 + c.
+// Block = BM rows x 128 columns (8 waves, one 16-column tile each); A arrives per position (256 B per row,
+// double buffered in LDS, row stride 288 B: conflict-free ds_read_b128); weight fragments stream from L2 one
+// k-step ahead.
+struct FcFast {
+  static constexpr int OC = 512, BM = 128, RT = BM / 16, NPOS = 49, KS = 98;  // K = 3136 = 98 k-steps of 32
+  static constexpr int RS = 288;  // LDS row stride in bytes (18 units = 2 mod 16)
+  static constexpr int LDS_BYTES = 2 * BM * RS;
+  static constexpr int V16 = BM * 16;  // 16-byte chunks per position
+  static constexpr int IT = V16 / kThreads;  // 4
+};
+__global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__ A, const uint4* __restrict__ Bfrag,
+                                                     const float* __restrict__ bias, float* __restrict__ out, int N) {
+  using F = FcFast;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int ct = blockIdx.x * kWaves + wave;
+  const int row0 = blockIdx.y * F::BM;
+  uint4 st[F::IT];
+  auto load_pos = [&](int pos) {
+#pragma unroll
+    for (int j = 0; j < F::IT; ++j) {
+      const int i = tid + j * kThreads;
+      const int r = i >> 4, u = i & 15;
+      const int row = row0 + r;
+      st[j] = (row < N) ? *reinterpret_cast<const uint4*>(A + (size_t)row * (F::NPOS * 256) + pos * 256 + u * 16)
+                        : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_pos = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < F::IT; ++j) {
+      const int i = tid + j * kThreads;
+      const int r = i >> 4, u = i & 15;
+      *reinterpret_cast<uint4*>(smem + buf * (F::BM * F::RS) + r * F::RS + u * 16) = st[j];
+    }
+  };
+  f32x4 acc[F::RT];
+#pragma unroll
+  for (int t = 0; t < F::RT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint4* bp = Bfrag + (size_t)ct * F::KS * 2 * 64 + lane;
+  uint4 bnext[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bnext[q] = bp[(size_t)q * 64];  // k-steps 0,1 x (hi, lo)
+  load_pos(0);
+  store_pos(0);
+  __syncthreads();
+  for (int pos = 0; pos < F::NPOS; ++pos) {
+    const int buf = pos & 1;
+    if (pos + 1 < F::NPOS) load_pos(pos + 1);
+    uint4 bcur[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bcur[q] = bnext[q];
+    if (pos + 1 < F::NPOS) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bnext[q] = bp[(size_t)((pos + 1) * 4 + q) * 64];
+    }
+    const uint8_t* tile = smem + buf * (F::BM * F::RS);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const bf16x8 bh = __builtin_bit_cast(bf16x8, bcur[sub * 2]);
+      const bf16x8 bl = __builtin_bit_cast(bf16x8, bcur[sub * 2 + 1]);
+#pragma unroll
+      for (int t = 0; t < F::RT; ++t) {
+        const uint8_t* ap = tile + (t * 16 + li) * F::RS + sub * 64 + g * 16;
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
+        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 128));
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[t], 0, 0, 0);
+      }
+    }
+    if (pos + 1 < F::NPOS) store_pos(buf ^ 1);
+    __syncthreads();
+  }
+  const int col = ct * 16 + li;
+  const float bv = bias[col];
+#pragma unroll
+  for (int t = 0; t < F::RT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + t * 16 + g * 4 + r;
+      if (row < N) {
+        const float o = acc[t][r] + bv;
+        out[(size_t)row * F::OC + col] = o > 0.f ? o : 0.f;
+      }
+    }
+}
+
+// weights -> [ct][ks][hi, lo][lane] x 8 bf16 in MFMA 16x16x32 fragment order.  mode: kPackConv2 (k = tap*32 + c),
+// kPackConv3 (k = tap*64 + c), kPackFc (k = pos*64 + c  <-  torch flatten c*49 + pos)
+__global__ void pack_frags_bf16s(int mode, const float* __restrict__ w, uint16_t* __restrict__ frag, int CT, int KS) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // [ct][ks][lane][j]
+  if (idx >= (int64_t)CT * KS * 64 * 8) return;
+  const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
+  const int ks = (int)((idx >> 9) % KS), ct = (int)((idx >> 9) / KS);
+  const int k = ks * 32 + (lane >> 4) * 8 + j;
+  const int oc = ct * 16 + (lane & 15);
+  float v;
+  if (mode == 1) {  // conv2: (64,32,4,4)
+    const int c = k & 31, tap = k >> 5;
+    v = w[((oc * 32 + c) * 4 + (tap >> 2)) * 4 + (tap & 3)];
+  } else if (mode == 2) {  // conv3: (64,64,3,3)
+    const int c = k & 63, tap = k >> 6;
+    v = w[((oc * 64 + c) * 3 + tap / 3) * 3 + tap % 3];
+  } else {  // fc: (512,3136)
+    const int c = k & 63, pos = k >> 6;
+    v = w[(size_t)oc * 3136 + c * 49 + pos];
+  }
+  const uint16_t hi = f32_to_bf16_rne(v);
+  const uint16_t lo = f32_to_bf16_rne(v - bf16_to_f32(hi));
+  const size_t base = (((size_t)ct * KS + ks) * 2) * 64 * 8;
+  frag[base + (size_t)lane * 8 + j] = hi;
+  frag[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
 }
 
 // Dense layer  out[N][OC] = act(A[N][K] * W + bias)  on the same MFMA tiling.
@@ -828,6 +1139,7 @@ struct rela_ffnet {
   bool loaded = false;
   uint64_t version = 0;  // bumped by every load
   const char* const* prof_names = nullptr;  // per-kernel timing labels (actor-side by default)
+  int precision = 0;  // 0 = exact f32 MFMA (parity mode), 1 = split-bf16 MFMA for conv2 / conv3 / fc
 };
 
 
@@ -855,9 +1167,20 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
   RELA_HIP(hipMalloc(&d.bf, sizeof(float) * 512));
   RELA_HIP(hipMalloc(&d.Bh, sizeof(float) * 2 * 128 * 64));
   RELA_HIP(hipMalloc(&d.bh, sizeof(float) * 32));
+  RELA_HIP(hipMalloc(&d.B2f, sizeof(uint4) * Conv2F::CT * Conv2F::KS * 2 * 64));
+  RELA_HIP(hipMalloc(&d.B3f, sizeof(uint4) * Conv3F::CT * Conv3F::KS * 2 * 64));
+  RELA_HIP(hipMalloc(&d.Bff, sizeof(uint4) * 32 * FcFast::KS * 2 * 64));
   // opt in to > 64 KB of dynamic LDS once per process/device
-  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3),
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv1B::LDS_BYTES));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3<true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv1B::LDS_BYTES));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv2F>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv2F::LDS_TOTAL));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv3F>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv3F::LDS_TOTAL));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, FcFast::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv2::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv3>),
@@ -875,7 +1198,7 @@ extern "C" void rela_ffnet_destroy(rela_ffnet* n) {
   DeviceGuard g(n->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bf, n->d.bf, n->d.Bh, n->d.bh,
-                n->d.BfT};
+                n->d.BfT, n->d.B2f, n->d.B3f, n->d.Bff};
   for (void* p : ps) (void)hipFree(p);
   delete n;
 }
@@ -885,6 +1208,13 @@ namespace rela_amd {
 void ffnet_label_as_learner(rela_ffnet* n) { n->prof_names = kProfLearner; }
 }  // namespace rela_amd
 extern "C" uint64_t rela_ffnet_version(const rela_ffnet* n) { return n ? n->version : 0; }
+extern "C" int rela_ffnet_set_precision(rela_ffnet* n, int mode) {
+  RELA_CHECK(n && (mode == 0 || mode == 1), RELA_EINVAL, "rela_ffnet_set_precision: mode must be 0 (f32) or 1 (split-bf16)");
+  n->precision = mode;
+  n->version += 1;  // results of the two modes differ in the last bits: a cached forward must not be reused across them
+  return RELA_OK;
+}
+extern "C" int rela_ffnet_precision(const rela_ffnet* n) { return n ? n->precision : 0; }
 
 extern "C" int64_t rela_ffnet_workspace_bytes(const rela_ffnet* n, int batch) {
   (void)n;
@@ -931,6 +1261,14 @@ extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on
   pack(kPackFc, dv[6], nullptr, n->d.Bf, 32, 784);
   hipLaunchKernelGGL(pack_fc_t, dim3(ceil_div(3136 * 512, 256)), dim3(256), 0, s, dv[6], n->d.BfT);
   pack(kPackHeads, dv[10], dv[8], n->d.Bh, 2, 128);
+  auto pack_fast = [&](int mode, const float* w, uint4* frag, int CT, int KS) {
+    const int64_t total = (int64_t)CT * KS * 64 * 8;
+    hipLaunchKernelGGL(pack_frags_bf16s, dim3(ceil_div(total, 256)), dim3(256), 0, s, mode, w,
+                       reinterpret_cast<uint16_t*>(frag), CT, KS);
+  };
+  pack_fast(1, dv[2], n->d.B2f, Conv2F::CT, Conv2F::KS);
+  pack_fast(2, dv[4], n->d.B3f, Conv3F::CT, Conv3F::KS);
+  pack_fast(3, dv[6], n->d.Bff, 32, FcFast::KS);
   RELA_HIP(hipMemcpyAsync(n->d.b1, dv[1], sizeof(float) * 32, hipMemcpyDeviceToDevice, s));
   RELA_HIP(hipMemcpyAsync(n->d.b2, dv[3], sizeof(float) * 64, hipMemcpyDeviceToDevice, s));
   RELA_HIP(hipMemcpyAsync(n->d.b3, dv[5], sizeof(float) * 64, hipMemcpyDeviceToDevice, s));
@@ -962,9 +1300,33 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
   float* ha = h + kH * N;
   const FFNetDev& d = n->d;
   const char* const* names = n->prof_names ? n->prof_names : kProfActor;
+  if (n->precision == 1 && N >= kFastMinN) {
+    // split-bf16 fast path: a1 / a2 / a3 hold split records (same bytes as the f32 tensors they replace)
+    uint8_t *r1 = reinterpret_cast<uint8_t*>(a1), *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
+    {
+      ProfScope prof(names[0], s);
+      hipLaunchKernelGGL(conv1_bf16x3<true>, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
+                         d.B1, d.b1, a1, N);
+    }
+    {
+      ProfScope prof(names[1], s);
+      hipLaunchKernelGGL(conv_bf16s<Conv2F>, dim3(std::min(kNumCU, ceil_div(N, Conv2F::S))), dim3(kThreads),
+                         Conv2F::LDS_TOTAL, s, (const uint8_t*)r1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
+    }
+    {
+      ProfScope prof(names[2], s);
+      hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
+                         Conv3F::LDS_TOTAL, s, (const uint8_t*)r2, (const uint4*)d.B3f, (const float*)d.b3, r3, N);
+    }
+    {
+      ProfScope prof(names[3], s);
+      hipLaunchKernelGGL(fc_bf16s, dim3(4, ceil_div(N, FcFast::BM)), dim3(kThreads), FcFast::LDS_BYTES, s,
+                         (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, h, N);
+    }
+  } else {
   {
     ProfScope prof(names[0], s);
-    hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
+    hipLaunchKernelGGL(conv1_bf16x3<false>, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
                        d.B1, d.b1, a1, N);
   }
   {
@@ -995,6 +1357,7 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
       hipLaunchKernelGGL(gemm_mfma<GemmFc>, dim3(GemmFc::CT / GemmFc::CTB, ceil_div(N, GemmFc::BM)), dim3(kThreads), 0,
                          s, (const float*)a3, (const float*)nullptr, (const float*)d.Bf, (const float*)d.bf, h,
                          (const float*)nullptr, (float*)nullptr, N);
+  }
   }
   {
     ProfScope prof(names[4], s);
@@ -1051,7 +1414,7 @@ extern "C" int rela_lstmnet_create(rela_lstmnet** out, int num_action, int devic
   RELA_HIP(hipMalloc(&d.bh, sizeof(float) * 32));
   RELA_HIP(hipMalloc(&n->Bl, sizeof(float) * (size_t)GemmLstm::CT * GemmLstm::KS * 64));
   RELA_HIP(hipMalloc(&n->bl, sizeof(float) * 2048));
-  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3),
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3<false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv1B::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv2::LDS_BYTES));
@@ -1154,7 +1517,7 @@ extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_
   const FFNetDev& d = n->d;
   {
     ProfScope prof("conv1_bf16x3", s);
-    hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
+    hipLaunchKernelGGL(conv1_bf16x3<false>, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
                        d.b1, a1, N);
   }
   {
@@ -1203,7 +1566,7 @@ int lstmnet_trunk(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1,
   const FFNetDev& d = n->d;
   {
     ProfScope prof(names[0], s);
-    hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
+    hipLaunchKernelGGL(conv1_bf16x3<false>, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
                        d.b1, a1, N);
   }
   {

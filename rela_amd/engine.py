@@ -46,6 +46,11 @@ class FFNetHandle:
         capi.check(capi.lib.rela_ffnet_load(self.h, C.byref(p), 1, stream), "rela_ffnet_load")
         self._keep = keep  # packing kernels are stream-ordered; keep sources alive until the next load
 
+    def set_precision(self, mode):
+        """"f32" (default: exact f32 MFMA, the parity mode) or "bf16x2" (split-bf16 MFMA for conv2 / conv3 / fc,
+        Q within 1e-4 of the f32 path; include/rela_amd.h rela_ffnet_set_precision)."""
+        capi.check(capi.lib.rela_ffnet_set_precision(self.h, {"f32": 0, "bf16x2": 1}[mode]), "rela_ffnet_set_precision")
+
     def close(self):
         if getattr(self, "h", None):
             capi.lib.rela_ffnet_destroy(self.h)

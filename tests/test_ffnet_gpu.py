@@ -156,3 +156,57 @@ def test_ffnet_errors():
     # forward before load_state_dict
     assert capi.lib.rela_ffnet_forward(h, 1, None, None, None, None, 0, None) == capi.ESTATE
     capi.lib.rela_ffnet_destroy(h)
+
+
+# ---- split-bf16 fast path (rela_ffnet_set_precision(net, 1)) ----------------------------------------
+@pytest.mark.parametrize("N", [1, 130, 1024, 1025, 2003, 3333, 6400])
+def test_ffnet_fast_mode_within_stated_tolerance(N, record_property):
+    """conv2 / conv3 / fc on split-bf16 MFMA (hi + lo bf16 operands, three products, f32 accumulation): Q-values
+    within the stated tolerance 1e-4 (abs + rel) of the exact f32 path (parity mode) on the same weights and
+    frames, at ragged batch sizes and at bench.py's actor shape (N = 6400); the greedy-action agreement between
+    the two modes is recorded."""
+    from synth import synth_obs, synth_params
+
+    A = 18
+    p = synth_params(A, 77)
+    net = GpuNet(p, A)
+    s = synth_obs(N, 3000 + N)
+    rng = np.random.default_rng(N)
+    legal = (rng.uniform(size=(N, A)) < 0.8).astype(np.float32)
+    legal[:, 0] = 1.0
+    q_ref = net.forward(s, legal).cpu().numpy()
+    net.capi.check(net.capi.lib.rela_ffnet_set_precision(net.h, 1), "set_precision")
+    assert net.capi.lib.rela_ffnet_precision(net.h) == 1
+    q_fast = net.forward(s, legal).cpu().numpy()
+    net.capi.check(net.capi.lib.rela_ffnet_set_precision(net.h, 0), "set_precision")
+    q_back = net.forward(s, legal).cpu().numpy()
+    assert np.array_equal(q_ref, q_back)  # the parity mode is untouched by the switch
+    np.testing.assert_allclose(q_fast, q_ref, rtol=RTOL, atol=ATOL)
+    err = float(np.abs(q_fast - q_ref).max())
+    scale = float(np.abs(q_ref).max())
+    masked = lambda q: np.where(legal > 0, q, -np.inf).argmax(1)
+    agree = float((masked(q_fast) == masked(q_ref)).mean())
+    record_property("max_abs_err", err)
+    record_property("greedy_agreement", agree)
+    print("N=%d split-bf16 vs f32: max |dQ| = %.3g (|Q| up to %.3g), greedy agreement %.5f" % (N, err, scale, agree))
+    assert err < 3e-5 * max(1.0, scale) * 3
+    assert agree >= 0.995 or N < 200
+    net.close()
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "ffnet_*.json"))), ids=os.path.basename)
+def test_ffnet_fast_mode_vs_reference_golden(path):
+    """The fast mode against the vectors recorded from the REAL reference (same tolerance as the parity mode)."""
+    from synth import synth_obs, synth_params
+
+    g = json.load(open(path))
+    A, N = g["num_action"], g["N"]
+    on = GpuNet(synth_params(A, g["online_seed"]), A)
+    on.capi.check(on.capi.lib.rela_ffnet_set_precision(on.h, 1), "set_precision")
+    s = synth_obs(N, g["obs_seed"])
+    legal = np.ones((N, A), np.float32)
+    if g["legal_mode"] == "mask":
+        legal[:, 1::2] = 0.0
+    q = on.forward(s, legal)
+    np.testing.assert_allclose(q.cpu().numpy(), np.array(g["q"]), rtol=RTOL, atol=ATOL)
+    on.close()

@@ -20,6 +20,7 @@ from synth import synth_params
 N, A, ITERS = int(os.environ.get("N", "6400")), 18, int(os.environ.get("ITERS", "20"))
 net = FFNetHandle(A, "cuda:0")
 net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_params(A, 1).items()})
+net.set_precision(os.environ.get("PRECISION", "f32"))  # f32 | bf16x2
 s = torch.randint(0, 256, (N, 4, 84, 84), dtype=torch.uint8, device="cuda")
 legal = torch.ones((N, A), device="cuda")
 q = torch.empty((N, A), device="cuda")
