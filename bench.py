@@ -631,16 +631,20 @@ def main():
         if name in FLOP:
             # Both rooflines of the dominant kernel; `bound` = the one it sits closer to.  MFMA: algorithmic FLOPs
             # (2 * MACs) over the dense peak of the instruction the kernel issues -- f32 mode:
-            # v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s; bf16x2 mode: v_mfma_f32_16x16x32_bf16, 2,500 TFLOP/s, of which
-            # the three products per algorithmic product leave 833 (conv1 runs its exact 3-piece split in both
-            # modes).  HBM: algorithmic bytes (input + output tensors, 4 B per activation) over 8 TB/s.
+            # v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s; bf16x2 mode: v_mfma_f32_16x16x32_bf16, 2,500 TFLOP/s divided by
+            # the bf16 products issued per algorithmic product.  HBM: algorithmic bytes (input + output tensors,
+            # 4 B per activation) over 8 TB/s.
             flops = FLOP[name] * ROWS
-            split3 = args.precision == "bf16x2" or name == "conv1_bf16x3"
-            peak_mfma = PEAK_BF16_MFMA_TFLOPS / 3.0 if split3 else PEAK_F32_MFMA_TFLOPS
+            # bf16 MFMA products issued per algorithmic product: conv1 multiplies exact u8 inputs by weights split
+            # in 3 bf16 pieces (f32 mode: exact) or 2 (bf16x2 mode); the other layers 3 in bf16x2 mode
+            fast = args.precision == "bf16x2"
+            products = (2 if fast else 3) if name == "conv1_bf16x3" else (3 if fast else 0)
+            peak_mfma = PEAK_BF16_MFMA_TFLOPS / products if products else PEAK_F32_MFMA_TFLOPS
             nbytes = BYTES_PER_SAMPLE[name] * ROWS
             mfma = {"achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": peak_mfma, "unit": "TFLOP/s",
                     "algorithmic_flop_per_launch": flops,
-                    "instruction": "v_mfma_f32_16x16x32_bf16 x3 (hi/lo split)" if split3 else "v_mfma_f32_16x16x4_f32"}
+                    "instruction": ("v_mfma_f32_16x16x32_bf16 x%d (split operands)" % products) if products
+                    else "v_mfma_f32_16x16x4_f32"}
             mfma["frac"] = mfma["achieved"] / peak_mfma
             hbm = {"achieved": nbytes / (avg_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "algorithmic_bytes_per_launch": nbytes}

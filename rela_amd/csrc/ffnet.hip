@@ -46,6 +46,7 @@ struct FFNetDev {
   float *Bh = nullptr, *bh = nullptr;  // heads frags [2][128][64], bias[32]  (cols 0..A-1 = fc_a, col 31 = fc_v)
   // split-bf16 fast path: [ct][ks][hi, lo][lane] x 8 bf16 (see "Split-bf16" below)
   uint4 *B2f = nullptr, *B3f = nullptr, *Bff = nullptr;
+  uint4* B1p = nullptr;  // conv1 frags as B1, k-steps plane-major (conv1_persist)
 };
 
 namespace {
@@ -411,10 +412,6 @@ __device__ __forceinline__ uint4 u8x8_to_bf16x8(uint32_t d0, uint32_t d1) {
   return make_uint4(pk(d0, 0), pk(d0, 2), pk(d1, 0), pk(d1, 2));
 }
 
-__device__ __forceinline__ void split_store(uint8_t* rec, int C, int col, float v, bool valid);
-
-// SPLIT: the output goes out as split-bf16 pixel records (fast path below) instead of f32
-template <bool SPLIT>
 __global__ __launch_bounds__(kThreads) void conv1_bf16x3(const uint8_t* __restrict__ in,
                                                          const uint4* __restrict__ Bfrag,
                                                          const float* __restrict__ bias, float* __restrict__ out,
@@ -505,12 +502,7 @@ __global__ __launch_bounds__(kThreads) void conv1_bf16x3(const uint8_t* __restri
       for (int r = 0; r < 4; ++r) {
         const int m = rt * 16 + g * 4 + r;
         const float v = acc[t][c][r] + bv;
-        if constexpr (SPLIT) {
-          split_store(reinterpret_cast<uint8_t*>(out) + ((size_t)n0 * C::P + m) * (C::OC * 4), C::OC, col,
-                      v > 0.f ? v : 0.f, m < mlim);
-        } else if (m < mlim) {
-          out[((size_t)n0 * C::P + m) * C::OC + col] = v > 0.f ? v : 0.f;
-        }
+        if (m < mlim) out[((size_t)n0 * C::P + m) * C::OC + col] = v > 0.f ? v : 0.f;
       }
     }
   }
@@ -525,11 +517,13 @@ __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_floa
 
 // conv1 weights (32,4,8,8)/255 -> three bf16 planes in MFMA 16x16x32 fragment order.
 // w == hi + mid + lo exactly for every finite fp32 weight (each residual is exact in fp32).
-__global__ void pack_conv1_bf16x3(const float* __restrict__ w, uint16_t* __restrict__ frag) {
+// plane_major: k-step ks = kernel row ks of all four planes (lane group g = plane), the order conv1_persist reads
+// its LDS image in; otherwise k runs (c, kh, kw) linearly (conv1_bf16x3).
+__global__ void pack_conv1_bf16x3(const float* __restrict__ w, uint16_t* __restrict__ frag, int plane_major) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // [ct 2][ks 8][lane 64][j 8]
   if (idx >= 2 * 8 * 64 * 8) return;
   const int j = idx & 7, lane = (idx >> 3) & 63, ks = (idx >> 9) & 7, ct = idx >> 12;
-  const int k = ks * 32 + (lane >> 4) * 8 + j;
+  const int k = plane_major ? (lane >> 4) * 64 + ks * 8 + j : ks * 32 + (lane >> 4) * 8 + j;
   const int oc = ct * 16 + (lane & 15);
   const float v = w[oc * 256 + k] / 255.0f;
   const uint16_t hi = f32_to_bf16_rne(v);
@@ -552,21 +546,216 @@ __global__ void pack_conv1_bf16x3(const float* __restrict__ w, uint16_t* __restr
 // between the layers in "split records": per pixel, C channels of hi (2 B each) followed by C channels of
 // lo -- the same 4 bytes per element as f32, so HBM traffic is unchanged while the MFMA work drops 5.3x.
 // =====================================================================================================
-__device__ __forceinline__ uint32_t split_pack(float v) {  // hi in the low half, lo in the high half
-  const uint16_t hi = f32_to_bf16_rne(v);
-  const uint16_t lo = f32_to_bf16_rne(v - bf16_to_f32(hi));
-  return (uint32_t)hi | ((uint32_t)lo << 16);
+// Makes the compiler treat a resident weight fragment as consumed HERE: its s_waitcnt for the load lands before
+// the persistent loop instead of at the first use inside it, where on later rounds the same counter value
+// would wait for the output stores and prefetches of the round before.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pin_loaded(bf16x8& f) {
+  u32x4 t = __builtin_bit_cast(u32x4, f);
+  asm volatile("" : "+v"(t));
+  f = __builtin_bit_cast(bf16x8, t);
 }
-// Store one value per lane of a 16-column accumulator row into a split record: lanes pair up (col, col ^ 1) so
-// that every lane issues ONE 4-byte store (even lane: the two hi halves, odd lane: the two lo halves).
-__device__ __forceinline__ void split_store(uint8_t* rec, int C, int col, float v, bool valid) {
-  const uint32_t p = split_pack(v);
-  const uint32_t q = (uint32_t)__shfl_xor((int)p, 1, 64);
-  if (!valid) return;
-  if ((col & 1) == 0)
-    *reinterpret_cast<uint32_t*>(rec + col * 2) = (p & 0xffffu) | (q << 16);
-  else
-    *reinterpret_cast<uint32_t*>(rec + C * 2 + (col - 1) * 2) = (q >> 16) | (p & 0xffff0000u);
+
+// Two values of one channel (rows r, r + 1 of an accumulator tile) -> the hi and lo halves of their LDS records:
+// two packed RNE conversions (v_cvt_pk_bf16_f32) and four 2-byte LDS stores, no cross-lane exchange and no wait
+// (pairing lanes through ds_bpermute costs an LDS round trip per value, which serialised the epilogues).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_store_lds2(uint8_t* rec0, uint8_t* rec1, int C, int col, float v0, float v1) {
+  const f32x2 v = {v0, v1};
+  const bf16x2 h = __builtin_convertvector(v, bf16x2);
+  const f32x2 hf = __builtin_convertvector(h, f32x2);
+  const bf16x2 l = __builtin_convertvector(v - hf, bf16x2);
+  const u16x2 hb = __builtin_bit_cast(u16x2, h), lb = __builtin_bit_cast(u16x2, l);
+  *reinterpret_cast<uint16_t*>(rec0 + col * 2) = hb[0];
+  *reinterpret_cast<uint16_t*>(rec1 + col * 2) = hb[1];
+  *reinterpret_cast<uint16_t*>(rec0 + C * 2 + col * 2) = lb[0];
+  *reinterpret_cast<uint16_t*>(rec1 + C * 2 + col * 2) = lb[1];
+}
+
+// conv1, persistent and weight-stationary.  Differences from conv1_bf16x3 above, which it replaces for batches
+// that fill the chip:
+//   * the u8 frame is converted to bf16 ONCE, on its way into LDS (every input byte feeds 4 output pixels and
+//     both channel tiles; converting per fragment made the kernel VALU-bound: 12 conversions per 6 MFMAs);
+//   * a wave owns ONE 16-channel tile with its 3 x 8 weight fragments resident in registers, and reads its A
+//     fragments (8 consecutive bf16 = two ds_read_b64) D steps ahead of the MFMAs in a register ring;
+//   * the output tile is staged in LDS and leaves as whole 16-byte-per-lane rows;
+//   * the unit of work is HALF a frame (10 output rows = 200 pixels, 44 input rows) and a block is 4 waves, so
+//     that TWO blocks share a CU (60 KB of LDS each): a block's phases are serial (load/convert, MFMA, split +
+//     stage, copy out: measured 10 + 67 + 25 + 29 us of a 163 us launch when one 8-wave block per CU ran them
+//     in lockstep), and the second block's MFMAs fill the first one's other phases.
+// k-steps are plane-major (pack_conv1_bf16x3 plane_major = 1); per output element the k-steps ascend and the
+// weight pieces go lo, mid, hi.
+struct Conv1P {
+  static constexpr int THREADS = 256, WAVES = 4;
+  static constexpr int HP = 200, RT = 13, OC = 32, KS = 8, RG = 2, RPW = 7, D = 6;  // 12.5 row tiles per half
+  static constexpr int IN_ELEMS = 4 * 84 * 84, PLANE_ELEMS = 84 * 84;
+  static constexpr int HROWS = 44, HPLANE_ELEMS = HROWS * 84;  // input rows 40h .. 40h+43 of each plane
+  // bf16 image of a half frame; the plane stride is 128 (mod 256) bytes, so that the two planes a ds_read_b64
+  // pass serves (lanes 0-31 = lane groups 0 and 1) fall on complementary halves of the banks
+  static constexpr int PLANE_BYTES = HPLANE_ELEMS * 2 + 160;
+  static_assert(PLANE_BYTES % 256 == 128 && PLANE_BYTES % 16 == 0, "plane stride");
+  static constexpr int TILE_BYTES = 4 * PLANE_BYTES;
+  static constexpr int OUT_BYTES = HP * OC * 4;    // f32 rows or split records: 128 B per pixel either way
+  static constexpr int OROW = OC * 4 + 16;         // staged row stride: rows 4 apart (lane groups) on different banks
+  static constexpr int LDS_BYTES = TILE_BYTES + RT * 16 * OROW;  // (the 13th tile's rows 200..207 are never copied)
+  static constexpr int PV16 = HPLANE_ELEMS / 16;   // 231 16-byte chunks of u8 per plane and half
+  static constexpr int V16 = 4 * PV16;
+  static constexpr int IT = (V16 + THREADS - 1) / THREADS;
+  static constexpr int OV16 = OUT_BYTES / 16;
+  static_assert(HPLANE_ELEMS % 16 == 0 && (40 * 84) % 16 == 0 && PLANE_ELEMS % 16 == 0, "chunk alignment");
+};
+
+template <bool SPLIT, int PIECES>
+__global__ __launch_bounds__(Conv1P::THREADS, 2) void conv1_persist(const uint8_t* __restrict__ in,
+                                                                    const uint4* __restrict__ Bfrag,
+                                                                    const float* __restrict__ bias,
+                                                                    float* __restrict__ out, int N) {
+  using C = Conv1P;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* tile = smem;
+  uint8_t* ostage = smem + C::TILE_BYTES;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int ct = wave & 1, rg = wave >> 1;
+
+  // PIECES = 3: exact f32 weights (hi + mid + lo); 2: the 16 leading mantissa bits, as the other fast layers
+  bf16x8 b[PIECES][C::KS];
+#pragma unroll
+  for (int p = 0; p < PIECES; ++p)
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks)
+      b[p][ks] = __builtin_bit_cast(bf16x8, Bfrag[((p * 2 + ct) * C::KS + ks) * 64 + lane]);
+  int abase[C::RPW], abase2[C::RPW];
+#pragma unroll
+  for (int t = 0; t < C::RPW; ++t) {
+    const int rt = min(rg + t * C::RG, C::RT - 1);  // (the odd waves' 7th tile repeats the 13th, unstored)
+    const int m = min(rt * 16 + li, C::HP - 1);
+    const int oy = m / 20, ox = m - oy * 20;
+    abase[t] = g * C::PLANE_BYTES + (4 * oy * 84 + 4 * ox) * 2;
+    // The second half of a fragment is addressed through a register of its own, opaque to the compiler:
+    // with a common base it fuses the two 8-byte reads into ds_read2_b64 (8 LDS cycles, 128 B/clk) where two
+    // ds_read_b64 take 2 + 2 (256 B/clk).
+    abase2[t] = abase[t] + 8;
+    asm volatile("" : "+v"(abase2[t]));
+  }
+  const int col = ct * 16 + li;
+  const float bv = bias[col];
+
+  // unpredicated staging (clamped chunk index: the spare lanes repeat the last chunk), so that the compiler can
+  // count vmcnt instead of draining it
+  uint4 st[C::IT];
+  auto g_load = [&](int unit) {
+    const int n = unit >> 1, h = unit & 1;
+    const uint8_t* src = in + (size_t)n * C::IN_ELEMS + h * (40 * 84);
+#pragma unroll
+    for (int j = 0; j < C::IT; ++j) {
+      const int i = min(tid + j * C::THREADS, C::V16 - 1);
+      const int pl = i / C::PV16, r = i - pl * C::PV16;
+      st[j] = *reinterpret_cast<const uint4*>(src + pl * C::PLANE_ELEMS + r * 16);
+    }
+  };
+  auto cvt_store = [&]() {
+#pragma unroll
+    for (int j = 0; j < C::IT; ++j) {
+      const int i = min(tid + j * C::THREADS, C::V16 - 1);
+      const int pl = i / C::PV16, r = i - pl * C::PV16;
+      uint4* dst = reinterpret_cast<uint4*>(tile + pl * C::PLANE_BYTES + r * 32);
+      dst[0] = u8x8_to_bf16x8(st[j].x, st[j].y);
+      dst[1] = u8x8_to_bf16x8(st[j].z, st[j].w);
+    }
+  };
+
+  const int units = 2 * N;
+  int unit = blockIdx.x;
+  if (unit >= units) return;
+  g_load(unit);
+  cvt_store();
+#pragma unroll
+  for (int p = 0; p < PIECES; ++p)
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) pin_loaded(b[p][ks]);
+  __syncthreads();
+  for (; unit < units; unit += gridDim.x) {
+    const int nxt = unit + (int)gridDim.x;
+    g_load(nxt < units ? nxt : unit);  // (the last round re-reads its own half: no branch around the loads)
+    f32x4 acc[C::RPW];  // starts at the bias
+#pragma unroll
+    for (int t = 0; t < C::RPW; ++t) acc[t] = f32x4{bv, bv, bv, bv};
+    // k-step ks = kernel row ks of the four planes: lane group g owns plane g, its 8 k's are 8 CONSECUTIVE
+    // pixels of image row 4*oy + ks (8-byte aligned in the bf16 image)
+    constexpr int TOT = C::KS * C::RPW;
+    uint2 a0[C::D], a1[C::D];
+    auto a_issue = [&](int idx, int slot) {
+      const int ks = idx / C::RPW, t = idx - ks * C::RPW;
+      const int koff = ks * 84 * 2;
+      a0[slot] = *reinterpret_cast<const uint2*>(tile + abase[t] + koff);
+      a1[slot] = *reinterpret_cast<const uint2*>(tile + abase2[t] + koff);
+    };
+#pragma unroll
+    for (int i = 0; i < C::D; ++i) a_issue(i, i);
+    __builtin_amdgcn_sched_barrier(0);
+    // Row tiles go through the MFMAs in PAIRS with their three weight pieces interleaved (smallest piece first so
+    // the big one is added last): consecutive MFMAs never feed each other, which matters whenever the wave has
+    // the SIMD to itself (the other block in its staging phases).
+    auto frag = [&](int slot) {
+      return __builtin_bit_cast(bf16x8, make_uint4(a0[slot].x, a0[slot].y, a1[slot].x, a1[slot].y));
+    };
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+#pragma unroll
+      for (int t = 0; t + 1 < C::RPW; t += 2) {
+        const int idx = ks * C::RPW + t;
+        const int slot = idx % C::D, slot1 = (idx + 1) % C::D;
+        const bf16x8 x0 = frag(slot), x1 = frag(slot1);
+#pragma unroll
+        for (int p = PIECES - 1; p >= 0; --p) {
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, b[p][ks], acc[t], 0, 0, 0);
+          acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, b[p][ks], acc[t + 1], 0, 0, 0);
+        }
+        if (idx + C::D < TOT) a_issue(idx + C::D, slot);
+        if (idx + 1 + C::D < TOT) a_issue(idx + 1 + C::D, slot1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (C::RPW & 1) {
+        const int t = C::RPW - 1, idx = ks * C::RPW + t, slot = idx % C::D;
+        const bf16x8 x0 = frag(slot);
+#pragma unroll
+        for (int p = PIECES - 1; p >= 0; --p)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, b[p][ks], acc[t], 0, 0, 0);
+        if (idx + C::D < TOT) a_issue(idx + C::D, slot);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();  // everyone is done with this half frame: the next one replaces it
+    cvt_store();
+#pragma unroll
+    for (int t = 0; t < C::RPW; ++t) {
+      const int rt = min(rg + t * C::RG, C::RT - 1);  // (a repeated 13th tile is staged twice, same values)
+      const int m0 = rt * 16 + g * 4;
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        const float v0 = acc[t][r], v1 = acc[t][r + 1];
+        const float o0 = v0 > 0.f ? v0 : 0.f, o1 = v1 > 0.f ? v1 : 0.f;
+        uint8_t* rec0 = ostage + (size_t)(m0 + r) * C::OROW;
+        uint8_t* rec1 = rec0 + C::OROW;
+        if constexpr (SPLIT) {
+          split_store_lds2(rec0, rec1, C::OC, col, o0, o1);
+        } else {
+          reinterpret_cast<float*>(rec0)[col] = o0;
+          reinterpret_cast<float*>(rec1)[col] = o1;
+        }
+      }
+    }
+    __syncthreads();  // output rows complete, next half frame in place
+    {
+      uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(out) + (size_t)unit * C::OUT_BYTES);
+      for (int i = tid; i < C::OV16; i += C::THREADS)
+        dst[i] = *reinterpret_cast<const uint4*>(ostage + (i >> 3) * C::OROW + (i & 7) * 16);
+    }
+  }
 }
 
 // conv on split records, weight-stationary and persistent (one block per CU walks over its sample groups with
@@ -583,9 +772,11 @@ struct ConvFastCfg {
   static constexpr int KS = KH * KW * KSUB;          // k-steps of 32
   static constexpr int REC = CIN * 4;                // bytes per input pixel record
   static constexpr int Q = Q_, RQ = RQ_, SQ = SQ_;   // pixel / row / sample stride in 16-byte units
+  static constexpr int DEPTH = (CIN == 32) ? 4 : 3;  // A fragment pairs in flight per wave (register ring)
   static constexpr int LDS_BYTES = S * SQ * 16;      // one input buffer
   static constexpr int OUT_BYTES = S * OH * OW * 64 * 4;  // output records of one group (staged for coalesced stores)
-  static constexpr int LDS_TOTAL = 2 * LDS_BYTES + OUT_BYTES;
+  static constexpr int LDS_TOTAL = 2 * LDS_BYTES + 2 * OUT_BYTES + OC * 4;  // + one spare record
+  static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
   static constexpr int IN_BYTES = IH * IW * REC;     // per sample in HBM
   static constexpr int V16 = S * IN_BYTES / 16;      // 16-byte chunks per group
   static constexpr int IT = (V16 + kThreads - 1) / kThreads, IT2 = (IT + 1) / 2;
@@ -662,6 +853,11 @@ __global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict
   stage_store(0, 0);
   stage_load(grp, 1);
   stage_store(0, 1);
+#pragma unroll
+  for (int ks = 0; ks < C::KS; ++ks) {
+    pin_loaded(bh[ks]);
+    pin_loaded(bl[ks]);
+  }
   __syncthreads();
   int buf = 0;
   constexpr int NT = C::KH * C::KW;
@@ -670,49 +866,64 @@ __global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict
     const bool has_next = grp + (int)gridDim.x < ngroups;
     if (has_next) stage_load(grp + gridDim.x, 0);
     const uint8_t* tile = smem + buf * C::LDS_BYTES;
-    f32x4 acc[C::RPW];
+    f32x4 acc[C::RPW];  // starts at the bias
 #pragma unroll
-    for (int t = 0; t < C::RPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int tap = 0; tap < NT; ++tap) {
+    for (int t = 0; t < C::RPW; ++t) acc[t] = f32x4{bv, bv, bv, bv};
+    // A fragments run D (hi, lo) pairs ahead of the MFMAs that consume them, in a register ring over the
+    // flattened (k-step, row tile) sequence: with two waves per SIMD nothing else hides the LDS latency.
+    constexpr int TOT = C::KS * C::RPW, D = C::DEPTH;
+    uint4 ah[D], al[D];
+    auto a_issue = [&](int idx, int slot) {
+      const int ks = idx / C::RPW, t = idx - ks * C::RPW;
+      const int tap = ks / C::KSUB, sub = ks - tap * C::KSUB;
       const int kh = tap / C::KW, kw = tap - kh * C::KW;
+      const uint8_t* ap = tile + abase[t] + (kh * C::RQ + kw * C::Q) * 16 + sub * 64;
+      ah[slot] = *reinterpret_cast<const uint4*>(ap);
+      al[slot] = *reinterpret_cast<const uint4*>(ap + LO);
+    };
 #pragma unroll
-      for (int sub = 0; sub < C::KSUB; ++sub) {
-        const int ks = tap * C::KSUB + sub;
-        const int koff = (kh * C::RQ + kw * C::Q) * 16 + sub * 64;
+    for (int i = 0; i < D; ++i) a_issue(i, i);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < C::RPW; ++t) {
-          const uint8_t* ap = tile + abase[t] + koff;
-          const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
-          const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + LO));
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ks], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ks], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ks], acc[t], 0, 0, 0);
-        }
-      }
+    for (int idx = 0; idx < TOT; ++idx) {
+      const int ks = idx / C::RPW, t = idx - ks * C::RPW;
+      const int slot = idx % D;
+      const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[slot]);
+      const bf16x8 xl = __builtin_bit_cast(bf16x8, al[slot]);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh[ks], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl[ks], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh[ks], acc[t], 0, 0, 0);
+      if (idx + D < TOT) a_issue(idx + D, slot);
+      __builtin_amdgcn_sched_barrier(0);  // keep the reads where they are (the scheduler sinks them to their use)
       // the other buffer was last read one group ago (barrier since): fill it while this group computes
       if (has_next) {
-        if (tap == NT / 3) {
+        if (idx == TOT / 3) {
           stage_store(buf ^ 1, 0);
           stage_load(grp + gridDim.x, 1);
-        } else if (tap == (2 * NT) / 3) {
+        } else if (idx == (2 * TOT) / 3) {
           stage_store(buf ^ 1, 1);
         }
       }
     }
     // epilogue: bias + ReLU + hi/lo split into an LDS copy of the group's output records, then ONE coalesced
-    // 16-byte-per-lane copy to HBM (a wave's own 16 channels are only 32 contiguous bytes per pixel)
+    // 16-byte-per-lane copy to HBM (a wave's own 16 channels are only 32 contiguous bytes per pixel).  The output
+    // tile is double buffered like the input, so ONE barrier per group orders everything: it publishes this
+    // group's records and the next group's staged input, and the records of two groups ago were copied out
+    // before the barrier in between.
     const int n0 = grp * C::S;
     const int mlim = min(C::S, N - n0) * C::P;
-    uint8_t* otile = smem + 2 * C::LDS_BYTES;
+    uint8_t* otile = smem + 2 * C::LDS_BYTES + buf * C::OUT_BYTES;
+    uint8_t* spare = smem + 2 * C::LDS_BYTES + 2 * C::OUT_BYTES;  // rows past the group's last pixel land here
 #pragma unroll
     for (int t = 0; t < C::RPW; ++t) {
       const int rt = rg + t * C::RG;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < 4; r += 2) {
         const int m = rt * 16 + g * 4 + r;
-        const float o = acc[t][r] + bv;
-        split_store(otile + (size_t)m * (C::OC * 4), C::OC, col, o > 0.f ? o : 0.f, m < C::M);
+        const float v0 = acc[t][r], v1 = acc[t][r + 1];
+        uint8_t* rec0 = (m < C::M) ? otile + (size_t)m * (C::OC * 4) : spare;
+        uint8_t* rec1 = (m + 1 < C::M) ? otile + (size_t)(m + 1) * (C::OC * 4) : spare;
+        split_store_lds2(rec0, rec1, C::OC, col, v0 > 0.f ? v0 : 0.f, v1 > 0.f ? v1 : 0.f);
       }
     }
     __syncthreads();
@@ -722,48 +933,62 @@ __global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict
       const int nv = mlim * (C::OC * 4 / 16);
       for (int i = tid; i < nv; i += kThreads) dst[i] = src[i];
     }
-    __syncthreads();
     buf ^= 1;
   }
 }
 
 // fc on split records: out[N][512] = relu(A x W + b), A = a3 records [N][49][hi 64 | lo 64], k = pos*64 + c.
-// Block = BM rows x 128 columns (8 waves, one 16-column tile each); A arrives per position (256 B per row,
-// double buffered in LDS, row stride 288 B: conflict-free ds_read_b128); weight fragments stream from L2 one
-// k-step ahead.
-struct FcFast {
-  static constexpr int OC = 512, BM = 128, RT = BM / 16, NPOS = 49, KS = 98;  // K = 3136 = 98 k-steps of 32
-  static constexpr int RS = 288;  // LDS row stride in bytes (18 units = 2 mod 16)
-  static constexpr int LDS_BYTES = 2 * BM * RS;
+// Block = BM rows x 128 columns (8 waves, one 16-column tile each).  A arrives per position (256 B per row) through
+// registers into a THREE-deep LDS ring (row stride 288 B: conflict-free ds_read_b128), loaded from HBM two
+// positions before it is stored; the A fragment reads run RT (hi, lo) pairs ahead of their MFMAs in a register
+// ring that continues across positions (the next position's tile was published one barrier earlier); weight
+// fragments stream from L2 one position ahead.  BM = 112 fills 232 of the 256 CUs at N = 6400 (128: 200).
+template <int BM_>
+struct FcFastT {
+  static constexpr int OC = 512, BM = BM_, RT = BM / 16, NPOS = 49, KS = 98;  // K = 3136 = 98 k-steps of 32
+  static constexpr int RS = 288;                                              // LDS row stride in bytes (18 units = 2 mod 16)
+  static constexpr int TILE = BM * RS, NBUF = 3;
+  static constexpr int LDS_BYTES = NBUF * TILE;
   static constexpr int V16 = BM * 16;  // 16-byte chunks per position
-  static constexpr int IT = V16 / kThreads;  // 4
+  static constexpr int IT = (V16 + kThreads - 1) / kThreads;
+  static constexpr int TOT = 2 * RT, D = RT;  // fragment pairs per position, pairs in flight
 };
+using FcFast = FcFastT<112>;
+
+template <class F>
 __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__ A, const uint4* __restrict__ Bfrag,
                                                      const float* __restrict__ bias, float* __restrict__ out, int N) {
-  using F = FcFast;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int ct = blockIdx.x * kWaves + wave;
   const int row0 = blockIdx.y * F::BM;
-  uint4 st[F::IT];
-  auto load_pos = [&](int pos) {
+  uint4 st0[F::IT], st1[F::IT];
+  // No predicates on the staging loads and stores (clamped indices repeat a neighbour's chunk, row or position
+  // instead): a load inside a branch makes the compiler fall back to s_waitcnt vmcnt(0), which would wait for the
+  // prefetch that was just issued.
+  const int nrow = min(F::BM, N - row0);
+  auto load_pos = [&](int pos, auto set) {
+    constexpr int S = decltype(set)::value;
+    const int pp = min(pos, F::NPOS - 1);
 #pragma unroll
     for (int j = 0; j < F::IT; ++j) {
-      const int i = tid + j * kThreads;
-      const int r = i >> 4, u = i & 15;
-      const int row = row0 + r;
-      st[j] = (row < N) ? *reinterpret_cast<const uint4*>(A + (size_t)row * (F::NPOS * 256) + pos * 256 + u * 16)
-                        : make_uint4(0, 0, 0, 0);
+      const int i = min(tid + j * kThreads, F::V16 - 1);
+      const int r = min(i >> 4, nrow - 1), u = i & 15;
+      const uint4 v = *reinterpret_cast<const uint4*>(A + (size_t)(row0 + r) * (F::NPOS * 256) + pp * 256 + u * 16);
+      if constexpr (S == 0) st0[j] = v; else st1[j] = v;
     }
   };
-  auto store_pos = [&](int buf) {
+  auto store_pos = [&](int buf, auto set) {
+    constexpr int S = decltype(set)::value;
 #pragma unroll
     for (int j = 0; j < F::IT; ++j) {
-      const int i = tid + j * kThreads;
+      const int i = min(tid + j * kThreads, F::V16 - 1);
       const int r = i >> 4, u = i & 15;
-      *reinterpret_cast<uint4*>(smem + buf * (F::BM * F::RS) + r * F::RS + u * 16) = st[j];
+      uint4 v;
+      if constexpr (S == 0) v = st0[j]; else v = st1[j];
+      *reinterpret_cast<uint4*>(smem + buf * F::TILE + r * F::RS + u * 16) = v;
     }
   };
   f32x4 acc[F::RT];
@@ -773,36 +998,69 @@ __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__
   uint4 bnext[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) bnext[q] = bp[(size_t)q * 64];  // k-steps 0,1 x (hi, lo)
-  load_pos(0);
-  store_pos(0);
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  load_pos(0, Set0{});
+  load_pos(1, Set1{});
+  store_pos(0, Set0{});
+  load_pos(2, Set0{});
+  store_pos(1, Set1{});
+  load_pos(3, Set1{});
   __syncthreads();
-  for (int pos = 0; pos < F::NPOS; ++pos) {
-    const int buf = pos & 1;
-    if (pos + 1 < F::NPOS) load_pos(pos + 1);
+
+  // A fragment ring: pair i of a position = (sub = i / RT, row tile t = i % RT)
+  uint4 ah[F::D], al[F::D];
+  const int aoff = li * F::RS + g * 16;
+  auto a_issue = [&](const uint8_t* tile, int i, int slot) {
+    const int sub = i / F::RT, t = i - sub * F::RT;
+    const uint8_t* ap = tile + aoff + t * 16 * F::RS + sub * 64;
+    ah[slot] = *reinterpret_cast<const uint4*>(ap);
+    al[slot] = *reinterpret_cast<const uint4*>(ap + 128);
+  };
+#pragma unroll
+  for (int i = 0; i < F::D; ++i) a_issue(smem, i, i);
+
+  int buf = 0;  // pos % 3
+  auto body = [&](int pos, auto set) {
     uint4 bcur[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) bcur[q] = bnext[q];
-    if (pos + 1 < F::NPOS) {
+    {
+      const int pn = min(pos + 1, F::NPOS - 1);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bnext[q] = bp[(size_t)((pos + 1) * 4 + q) * 64];
+      for (int q = 0; q < 4; ++q) bnext[q] = bp[(size_t)(pn * 4 + q) * 64];
     }
-    const uint8_t* tile = smem + buf * (F::BM * F::RS);
+    const int nbuf = (buf == F::NBUF - 1) ? 0 : buf + 1;
+    const uint8_t* tile = smem + buf * F::TILE;
+    const uint8_t* ntile = smem + nbuf * F::TILE;  // (after the last position: stale rows, read and dropped)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
+    for (int i = 0; i < F::TOT; ++i) {
+      const int sub = i / F::RT, t = i - sub * F::RT;
+      const int slot = i % F::D;
       const bf16x8 bh = __builtin_bit_cast(bf16x8, bcur[sub * 2]);
       const bf16x8 bl = __builtin_bit_cast(bf16x8, bcur[sub * 2 + 1]);
-#pragma unroll
-      for (int t = 0; t < F::RT; ++t) {
-        const uint8_t* ap = tile + (t * 16 + li) * F::RS + sub * 64 + g * 16;
-        const bf16x8 ah = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap));
-        const bf16x8 al = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ap + 128));
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc[t], 0, 0, 0);
-      }
+      const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[slot]);
+      const bf16x8 xl = __builtin_bit_cast(bf16x8, al[slot]);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh, acc[t], 0, 0, 0);
+      if (i + F::D < F::TOT)
+        a_issue(tile, i + F::D, slot);
+      else
+        a_issue(ntile, i + F::D - F::TOT, slot);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (pos + 1 < F::NPOS) store_pos(buf ^ 1);
+    // the tile of position pos + 2 (loaded two positions ago) replaces the one read a position ago
+    const int sbuf = (nbuf == F::NBUF - 1) ? 0 : nbuf + 1;
+    store_pos(sbuf, set);  // (past the end: rewrites a tile nobody reads again)
+    load_pos(pos + 4, set);
     __syncthreads();
+    buf = nbuf;
+  };
+  for (int pos = 0; pos < F::NPOS; pos += 2) {
+    body(pos, Set0{});
+    if (pos + 1 < F::NPOS) body(pos + 1, Set1{});
   }
   const int col = ct * 16 + li;
   const float bv = bias[col];
@@ -1167,19 +1425,20 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
   RELA_HIP(hipMalloc(&d.bf, sizeof(float) * 512));
   RELA_HIP(hipMalloc(&d.Bh, sizeof(float) * 2 * 128 * 64));
   RELA_HIP(hipMalloc(&d.bh, sizeof(float) * 32));
+  RELA_HIP(hipMalloc(&d.B1p, sizeof(uint4) * Conv1B::FRAG_UINT4));
   RELA_HIP(hipMalloc(&d.B2f, sizeof(uint4) * Conv2F::CT * Conv2F::KS * 2 * 64));
   RELA_HIP(hipMalloc(&d.B3f, sizeof(uint4) * Conv3F::CT * Conv3F::KS * 2 * 64));
   RELA_HIP(hipMalloc(&d.Bff, sizeof(uint4) * 32 * FcFast::KS * 2 * 64));
   // opt in to > 64 KB of dynamic LDS once per process/device
-  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3<false>),
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv1B::LDS_BYTES));
-  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3<true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv1B::LDS_BYTES));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_persist<true, 2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv1P::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv2F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv2F::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv3F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv3F::LDS_TOTAL));
-  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s),
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s<FcFast>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, FcFast::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv2::LDS_BYTES));
@@ -1198,7 +1457,7 @@ extern "C" void rela_ffnet_destroy(rela_ffnet* n) {
   DeviceGuard g(n->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bf, n->d.bf, n->d.Bh, n->d.bh,
-                n->d.BfT, n->d.B2f, n->d.B3f, n->d.Bff};
+                n->d.BfT, n->d.B2f, n->d.B3f, n->d.Bff, n->d.B1p};
   for (void* p : ps) (void)hipFree(p);
   delete n;
 }
@@ -1255,7 +1514,9 @@ extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on
     hipLaunchKernelGGL(pack_frags, dim3(ceil_div(total, 256)), dim3(256), 0, s, mode, w, w2, A, frag, CT, KS);
   };
   hipLaunchKernelGGL(pack_conv1_bf16x3, dim3(ceil_div(2 * 8 * 64 * 8, 256)), dim3(256), 0, s, dv[0],
-                     reinterpret_cast<uint16_t*>(n->d.B1));
+                     reinterpret_cast<uint16_t*>(n->d.B1), 0);
+  hipLaunchKernelGGL(pack_conv1_bf16x3, dim3(ceil_div(2 * 8 * 64 * 8, 256)), dim3(256), 0, s, dv[0],
+                     reinterpret_cast<uint16_t*>(n->d.B1p), 1);
   pack(kPackConv2, dv[2], nullptr, n->d.B2, 4, 128);
   pack(kPackConv3, dv[4], nullptr, n->d.B3, 4, 144);
   pack(kPackFc, dv[6], nullptr, n->d.Bf, 32, 784);
@@ -1305,8 +1566,8 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
     uint8_t *r1 = reinterpret_cast<uint8_t*>(a1), *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
       ProfScope prof(names[0], s);
-      hipLaunchKernelGGL(conv1_bf16x3<true>, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
-                         d.B1, d.b1, a1, N);
+      hipLaunchKernelGGL((conv1_persist<true, 2>), dim3(std::min(2 * kNumCU, 2 * N)), dim3(Conv1P::THREADS),
+                         Conv1P::LDS_BYTES, s, s_dev, d.B1p, d.b1, a1, N);
     }
     {
       ProfScope prof(names[1], s);
@@ -1320,13 +1581,13 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
     }
     {
       ProfScope prof(names[3], s);
-      hipLaunchKernelGGL(fc_bf16s, dim3(4, ceil_div(N, FcFast::BM)), dim3(kThreads), FcFast::LDS_BYTES, s,
+      hipLaunchKernelGGL(fc_bf16s<FcFast>, dim3(4, ceil_div(N, FcFast::BM)), dim3(kThreads), FcFast::LDS_BYTES, s,
                          (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, h, N);
     }
   } else {
   {
     ProfScope prof(names[0], s);
-    hipLaunchKernelGGL(conv1_bf16x3<false>, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
+    hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
                        d.B1, d.b1, a1, N);
   }
   {
@@ -1414,7 +1675,7 @@ extern "C" int rela_lstmnet_create(rela_lstmnet** out, int num_action, int devic
   RELA_HIP(hipMalloc(&d.bh, sizeof(float) * 32));
   RELA_HIP(hipMalloc(&n->Bl, sizeof(float) * (size_t)GemmLstm::CT * GemmLstm::KS * 64));
   RELA_HIP(hipMalloc(&n->bl, sizeof(float) * 2048));
-  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3<false>),
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv1B::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv2>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv2::LDS_BYTES));
@@ -1478,7 +1739,7 @@ extern "C" int rela_lstmnet_load(rela_lstmnet* n, const rela_lstmnet_params* p, 
     hipLaunchKernelGGL(pack_frags, dim3(ceil_div(total, 256)), dim3(256), 0, s, mode, w, w2, A, frag, CT, KS);
   };
   hipLaunchKernelGGL(pack_conv1_bf16x3, dim3(ceil_div(2 * 8 * 64 * 8, 256)), dim3(256), 0, s, dv[0],
-                     reinterpret_cast<uint16_t*>(n->d.B1));
+                     reinterpret_cast<uint16_t*>(n->d.B1), 0);
   pack(kPackConv2, dv[2], nullptr, n->d.B2, 4, 128);
   pack(kPackConv3, dv[4], nullptr, n->d.B3, 4, 144);
   pack(kPackLstm, dv[6], dv[7], n->Bl, GemmLstm::CT, GemmLstm::KS);
@@ -1517,7 +1778,7 @@ extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_
   const FFNetDev& d = n->d;
   {
     ProfScope prof("conv1_bf16x3", s);
-    hipLaunchKernelGGL(conv1_bf16x3<false>, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
+    hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
                        d.b1, a1, N);
   }
   {
@@ -1566,7 +1827,7 @@ int lstmnet_trunk(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1,
   const FFNetDev& d = n->d;
   {
     ProfScope prof(names[0], s);
-    hipLaunchKernelGGL(conv1_bf16x3<false>, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
+    hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
                        d.b1, a1, N);
   }
   {

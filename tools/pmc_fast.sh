@@ -17,8 +17,8 @@ for sub in ("sq","sq2"):
         for row in csv.DictReader(open(f)):
             name=row["Kernel_Name"]
             short=None
-            for k in ("conv1_bf16x3","conv_bf16s","fc_bf16s","conv_mfma_bstat","conv_mfma","gemm_mfma"):
-                if k in name: short=k+("<Conv3>" if "Li64ELi9ELi9" in name else ""); break
+            for k in ("conv1_persist","conv1_bf16x3","conv_bf16s","fc_bf16s","conv_mfma_bstat","conv_mfma","gemm_mfma"):
+                if k in name: short=k+("<Conv3>" if "ConvFastCfg<64" in name else ""); break
             if short is None: continue
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k,v in acc.items():
