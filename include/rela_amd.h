@@ -471,6 +471,10 @@ int rela_r2d2_learner_params(rela_r2d2_learner* l, rela_lstmnet_params* online_o
 int rela_r2d2_learner_grads(rela_r2d2_learner* l, rela_lstmnet_params* grads_out);
 int rela_r2d2_learner_flat(rela_r2d2_learner* l, float** params_dev, float** grads_dev, int64_t* count);
 const float* rela_r2d2_learner_stats_dev(const rela_r2d2_learner* l); /* grad norm, clip coefficient */
+/* The T recurrent steps run as ONE persistent launch per pass with a bounded grid barrier between steps (no reference
+ * counterpart: autograd launches per step).  Synchronises `stream` and returns RELA_ESTATE if a barrier of any call
+ * since the last check gave up (never observed; the results of that call are then invalid). */
+int rela_r2d2_learner_check(rela_r2d2_learner* l, void* stream);
 
 /* ===================================================================================
  * Live per-kernel timing (HIP events on the launch stream) for bench.py's roofline line.

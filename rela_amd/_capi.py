@@ -153,6 +153,7 @@ _sig("rela_r2d2_learner_params", i32, [vp, P(LSTMNetParams), P(LSTMNetParams)])
 _sig("rela_r2d2_learner_grads", i32, [vp, P(LSTMNetParams)])
 _sig("rela_r2d2_learner_flat", i32, [vp, P(vp), P(vp), P(i64)])
 _sig("rela_r2d2_learner_stats_dev", vp, [vp])
+_sig("rela_r2d2_learner_check", i32, [vp, vp])
 _sig("rela_prof_enable", i32, [i32])
 _sig("rela_prof_set_filter", i32, [C.c_char_p])
 _sig("rela_prof_summary_json", i32, [C.c_char_p, i64])

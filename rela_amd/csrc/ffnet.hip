@@ -588,7 +588,7 @@ __device__ __forceinline__ void split_store_lds2(uint8_t* rec0, uint8_t* rec1, i
 // k-steps are plane-major (pack_conv1_bf16x3 plane_major = 1); per output element the k-steps ascend and the
 // weight pieces go lo, mid, hi.
 struct Conv1P {
-  static constexpr int THREADS = 256, WAVES = 4;
+  static constexpr int THREADS = 256;
   static constexpr int HP = 200, RT = 13, OC = 32, KS = 8, RG = 2, RPW = 7, D = 6;  // 12.5 row tiles per half
   static constexpr int IN_ELEMS = 4 * 84 * 84, PLANE_ELEMS = 84 * 84;
   static constexpr int HROWS = 44, HPLANE_ELEMS = HROWS * 84;  // input rows 40h .. 40h+43 of each plane
@@ -860,7 +860,6 @@ __global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict
   }
   __syncthreads();
   int buf = 0;
-  constexpr int NT = C::KH * C::KW;
   constexpr int LO = C::CIN * 2;  // byte offset of the lo part inside a pixel record
   for (; grp < ngroups; grp += gridDim.x) {
     const bool has_next = grp + (int)gridDim.x < ngroups;

@@ -150,6 +150,152 @@ __global__ void lstm_cell_fwd(float* __restrict__ gx, const float* __restrict__ 
   }
 }
 
+// ---- persistent recurrent forward ---------------------------------------------------------------------
+// The T recurrent steps of one net in ONE launch (2 x 123 x 3 launches of ~13 us each before: launch-bound).
+// Block j owns hidden units 4j .. 4j+3 (16 gate columns: i, f, g, o of each) for the whole batch; its slice of
+// W_hh^T stays in registers (wave w: k in [64w, 64w + 64), one f32 MFMA B-fragment register per k-step).  Per step:
+// every wave multiplies its k-slice of h_{t-1} (plain loads behind the acquire of the grid barrier) into a
+// partial [rows x 16] tile on v_mfma_f32_16x16x4_f32, the eight partials meet in LDS, one thread per batch row
+// runs the cell for the block's four units and stores c_t (plain; only this block reads it back) and h_t
+// WRITE-THROUGH (sc1 via agent-scope atomic stores: visible to the other XCDs without a release fence).  Steps are
+// separated by a grid barrier: one arrival counter per step (zeroed by a memset ahead of the launch), ONE lane
+// polls it relaxed, ONE agent-scope acquire, workgroup barrier, plain loads.  Every spin is bounded: a block
+// that gives up sets the timeout word and leaves, and the host reports it (rela_r2d2_learner_check).
+typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+constexpr int kRecBlocks = kHid / 4, kRecThreads = 512, kRecChunk = 64;
+constexpr unsigned kRecSpinLimit = 1u << 22;
+
+struct RecNet {
+  float* gx;          // [T][Bn][2048] pre-activations of the input half (+ bias); saved steps get the activated gates
+  const float* whhT;  // [512][2048]
+  float *H, *C;       // [(T + 1)][Bn][512], slot 0 = initial state
+  unsigned* bar;      // [T] arrival counters of this net's blocks
+  int save;
+};
+struct RecArgs {
+  RecNet net[2];        // blocks [0, 128) run net[0], blocks [128, 256) net[1]: two independent latency chains
+  const uint8_t* term;  // [T][Bn]
+  unsigned* tmo;        // timeout word (0 = none)
+  int T, Bn, burn;
+};
+
+__global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
+  __shared__ float red[8][kRecChunk][17];
+  __shared__ int alive;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4, j = blockIdx.x % kRecBlocks;
+  const RecNet nt = a.net[blockIdx.x / kRecBlocks];
+  const int gcol = (li >> 2) * kHid + 4 * j + (li & 3);  // column li of the block's tile = gate li/4 of unit 4j + li%4
+  float bfr[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) bfr[ks] = nt.whhT[(size_t)(wave * 64 + 16 * g + ks) * kGates + gcol];
+  const size_t blk = (size_t)a.Bn * kHid;
+  const bool one_chunk = a.Bn <= kRecChunk;
+  // x-part of the gates of (step, row = tid): independent of the other blocks, so it is fetched BEFORE the
+  // wait for h_{t-1} (batches of more than one chunk fetch per chunk instead)
+  float4 gpre[4];
+  auto gx_fetch = [&](int t, int row) {
+    const float* grow = nt.gx + ((size_t)t * a.Bn + row) * kGates + 4 * j;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gpre[q] = *reinterpret_cast<const float4*>(grow + q * kHid);
+  };
+  if (one_chunk && tid < a.Bn) gx_fetch(0, tid);
+  for (int t = 0; t < a.T; ++t) {
+    const float* Ht = nt.H + (size_t)t * blk;
+    for (int row0 = 0; row0 < a.Bn; row0 += kRecChunk) {
+      const int row = row0 + tid;
+      if (!one_chunk && tid < kRecChunk && row < a.Bn) gx_fetch(t, row);
+      f32x4 acc[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int arow = row0 + rt * 16 + li;
+        float av[16];
+        if (arow < a.Bn) {
+          const float4* hp = reinterpret_cast<const float4*>(Ht + (size_t)arow * kHid + wave * 64 + 16 * g);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = hp[q];
+            av[4 * q] = v.x, av[4 * q + 1] = v.y, av[4 * q + 2] = v.z, av[4 * q + 3] = v.w;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 16; ++q) av[q] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bfr[ks], acc[rt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][rt * 16 + 4 * g + r][li] = acc[rt][r];
+      __syncthreads();
+      if (tid < kRecChunk && row < a.Bn) {
+        float* grow = nt.gx + ((size_t)t * a.Bn + row) * kGates + 4 * j;
+        float pre[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          pre[q][0] = gpre[q].x, pre[q][1] = gpre[q].y, pre[q][2] = gpre[q].z, pre[q][3] = gpre[q].w;
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 8; ++w) pre[q][u] += red[w][tid][q * 4 + u];
+        }
+        const float4 cp4 = *reinterpret_cast<const float4*>(nt.C + (size_t)t * blk + (size_t)row * kHid + 4 * j);
+        const float cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+        float gi[4], gf[4], gg[4], go[4], c[4], h[4];
+        // the state that ENTERS the first training step is zeroed where the burn-in was a dummy (r2d2.py:149-154)
+        const bool zero = a.burn > 0 && t + 1 == a.burn && a.term[(size_t)(a.burn - 1) * a.Bn + row] != 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          gi[u] = sigm(pre[0][u]), gf[u] = sigm(pre[1][u]), gg[u] = tanhf(pre[2][u]), go[u] = sigm(pre[3][u]);
+          c[u] = gf[u] * cp[u] + gi[u] * gg[u];
+          h[u] = go[u] * tanhf(c[u]);
+          if (zero) c[u] = 0.f, h[u] = 0.f;
+        }
+        const size_t o = (size_t)(t + 1) * blk + (size_t)row * kHid + 4 * j;
+        gu64* hp = (gu64*)(nt.H + o);
+        __hip_atomic_store(hp, ((unsigned long long)__float_as_uint(h[1]) << 32) | __float_as_uint(h[0]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hp + 1, ((unsigned long long)__float_as_uint(h[3]) << 32) | __float_as_uint(h[2]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *reinterpret_cast<float4*>(nt.C + o) = make_float4(c[0], c[1], c[2], c[3]);
+        if (nt.save && t >= a.burn) {
+          *reinterpret_cast<float4*>(grow) = make_float4(gi[0], gi[1], gi[2], gi[3]);
+          *reinterpret_cast<float4*>(grow + kHid) = make_float4(gf[0], gf[1], gf[2], gf[3]);
+          *reinterpret_cast<float4*>(grow + 2 * kHid) = make_float4(gg[0], gg[1], gg[2], gg[3]);
+          *reinterpret_cast<float4*>(grow + 3 * kHid) = make_float4(go[0], go[1], go[2], go[3]);
+        }
+      }
+      __syncthreads();
+    }
+    if (t + 1 == a.T) break;
+    // grid barrier: every storing wave drains its stores, then ONE lane signals and polls
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (one_chunk && tid < a.Bn) gx_fetch(t + 1, tid);  // in flight across the wait
+    if (tid == 0) {
+      gu32* cnt = (gu32*)(nt.bar + t);
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool ok = true;
+      for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)kRecBlocks;) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kRecSpinLimit || __hip_atomic_load((gu32*)a.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store((gu32*)a.tmo, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = false;
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      alive = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!alive) return;
+  }
+}
+
 // hid *= 1 - terminal[burn_in - 1]   (r2d2.py:149-154)
 __global__ void zero_hidden_where_terminal(const uint8_t* __restrict__ term, int Bn, float* __restrict__ h,
                                            float* __restrict__ c) {
@@ -288,9 +434,12 @@ struct rela_r2d2_learner {
   float *wihT[2] = {nullptr, nullptr}, *whhT[2] = {nullptr, nullptr}, *bsum[2] = {nullptr, nullptr};  // [online, target]
   float* wihp = nullptr;                                              // online W_ih in k order (dgrad)
   float *a1 = nullptr, *a2 = nullptr, *a3 = nullptr;                  // trunk activations of T*B frames
-  float* gx = nullptr;                                                // [T*B][2048]: GX -> activated gates -> dgates
+  float* gxs[2] = {nullptr, nullptr};  // per net [T*B][2048]: GX; the online one -> activated gates -> dgates
+  float*& gx = gxs[0];
   float *Hs[2] = {nullptr, nullptr}, *Cs[2] = {nullptr, nullptr};     // [(T+1)*B][512] per net
   float* rec_part = nullptr;                                          // split-K partials of the recurrent GEMMs
+  unsigned* rec_bar = nullptr;                                        // [0] timeout word, [4 ..] per-step arrival counters
+  bool rec_persist = true;
   float *ha = nullptr, *q_on = nullptr, *q_tg = nullptr;              // heads of the training rows
   float *qmin = nullptr, *qa_on = nullptr, *qa_tg = nullptr, *dqa = nullptr, *d_ha = nullptr, *d_o = nullptr;
   float *dc_rec = nullptr;
@@ -343,24 +492,31 @@ int repack_r2d2(rela_r2d2_learner* l, bool online, bool target, hipStream_t s) {
 
 const char* const kTrunkNames[3] = {"learner_fwd_conv1", "learner_fwd_conv2", "learner_fwd_conv3"};
 
-// forward of one net over the whole batch; leaves H / C of every step in Hs[which] / Cs[which], the activated
-// gates of the training steps in l->gx (save = true) and the dueling Q of the training rows in q_out.
-int forward_net(rela_r2d2_learner* l, int which, int Bn, const uint8_t* obs, const float* legal_train,
-                const uint8_t* term, const float* h0, const float* c0, bool save, float* q_out, hipStream_t s) {
+// Forward of both nets over the whole batch, in three stages: (1) per net the conv trunk over all T*B frames and the
+// input half of the gates (target first: the online pass leaves its a1 / a2 / a3 for the backward pass); (2) the T
+// recurrent steps of BOTH nets in one persistent launch (two independent latency chains side by side); (3) the heads
+// over the training steps.  Leaves H / C of every step in Hs[w] / Cs[w], the activated gates of the online net's
+// training steps in gxs[0] and the dueling Q of the training rows in q_on / q_tg.
+int forward_pre(rela_r2d2_learner* l, int which, int Bn, const uint8_t* obs, const float* h0, const float* c0,
+                hipStream_t s) {
   const rela_lstmnet* net = which == 0 ? l->online : l->target;
-  const int T = l->T, burn = l->burn, rowsAll = T * Bn, Tt = T - burn;
+  const int rowsAll = l->T * Bn;
   int rc = lstmnet_trunk(net, rowsAll, obs, l->a1, l->a2, l->a3, s, kTrunkNames);
   if (rc != RELA_OK) return rc;
-  {
-    ProbGateX p{};
-    p.M = rowsAll, p.N = kGates, p.K = kFeat;
-    p.a3 = l->a3, p.wihT = l->wihT[which], p.bias = l->bsum[which], p.gx = l->gx;
-    launch_gemm<TileRows>(p, 1, s, "learner_lstm_gates_x");
-  }
-  float *H = l->Hs[which], *Cc = l->Cs[which];
+  ProbGateX p{};
+  p.M = rowsAll, p.N = kGates, p.K = kFeat;
+  p.a3 = l->a3, p.wihT = l->wihT[which], p.bias = l->bsum[which], p.gx = l->gxs[which];
+  launch_gemm<TileRows>(p, 1, s, "learner_lstm_gates_x");
   const size_t blk = (size_t)Bn * kHid;
-  RELA_HIP(hipMemcpyAsync(H, h0, blk * sizeof(float), hipMemcpyDeviceToDevice, s));
-  RELA_HIP(hipMemcpyAsync(Cc, c0, blk * sizeof(float), hipMemcpyDeviceToDevice, s));
+  RELA_HIP(hipMemcpyAsync(l->Hs[which], h0, blk * sizeof(float), hipMemcpyDeviceToDevice, s));
+  RELA_HIP(hipMemcpyAsync(l->Cs[which], c0, blk * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return RELA_OK;
+}
+
+int forward_rec_steps(rela_r2d2_learner* l, int which, int Bn, const uint8_t* term, bool save, hipStream_t s) {
+  const int T = l->T, burn = l->burn;
+  float *H = l->Hs[which], *Cc = l->Cs[which], *gx = l->gxs[which];
+  const size_t blk = (size_t)Bn * kHid;
   const int cell_grid = ceil_div((int64_t)Bn * kHid, 256);
   for (int t = 0; t < T; ++t) {
     if (t == burn && burn > 0) {  // state after the burn-in: zero it where the burn-in was a dummy
@@ -372,13 +528,47 @@ int forward_net(rela_r2d2_learner* l, int which, int Bn, const uint8_t* obs, con
     p.h = H + t * blk, p.whhT = l->whhT[which], p.part = l->rec_part;
     launch_gemm<TileRec>(p, kRecSplitF, s, "learner_lstm_rec_fwd");
     ProfScope prof("learner_lstm_cell", s);
-    hipLaunchKernelGGL(lstm_cell_fwd, dim3(cell_grid), dim3(256), 0, s, l->gx + (size_t)t * Bn * kGates,
+    hipLaunchKernelGGL(lstm_cell_fwd, dim3(cell_grid), dim3(256), 0, s, gx + (size_t)t * Bn * kGates,
                        (const float*)l->rec_part, kRecSplitF, Bn, (const float*)(Cc + t * blk), Cc + (t + 1) * blk,
                        H + (t + 1) * blk, (save && t >= burn) ? 1 : 0);
   }
   RELA_LAUNCH_CHECK();
+  return RELA_OK;
+}
+
+int forward_both(rela_r2d2_learner* l, int Bn, const uint8_t* obs, const float* legal_train, const uint8_t* term,
+                 const float* h0, const float* c0, hipStream_t s) {
+  const int T = l->T, burn = l->burn, Tt = T - burn;
+  int rc = forward_pre(l, 1, Bn, obs, h0, c0, s);
+  if (rc != RELA_OK) return rc;
+  rc = forward_pre(l, 0, Bn, obs, h0, c0, s);
+  if (rc != RELA_OK) return rc;
+  if (l->rec_persist) {
+    // arrival counters of this launch: words [4, 4 + 2 * Tpad) (the timeout word [0] is sticky until ..._check)
+    const int Tpad = (T + 3) / 4 * 4;
+    RELA_HIP(hipMemsetAsync(l->rec_bar + 4, 0, sizeof(unsigned) * (size_t)(2 * Tpad), s));
+    RecArgs ra{};
+    for (int w = 0; w < 2; ++w) {
+      ra.net[w].gx = l->gxs[w], ra.net[w].whhT = l->whhT[w], ra.net[w].H = l->Hs[w], ra.net[w].C = l->Cs[w];
+      ra.net[w].bar = l->rec_bar + 4 + w * Tpad, ra.net[w].save = w == 0 ? 1 : 0;
+    }
+    ra.term = term, ra.tmo = l->rec_bar, ra.T = T, ra.Bn = Bn, ra.burn = burn;
+    ProfScope prof("learner_lstm_rec_persist", s);
+    hipLaunchKernelGGL(lstm_rec_persist, dim3(2 * kRecBlocks), dim3(kRecThreads), 0, s, ra);
+    RELA_LAUNCH_CHECK();
+  } else {
+    rc = forward_rec_steps(l, 1, Bn, term, false, s);
+    if (rc != RELA_OK) return rc;
+    rc = forward_rec_steps(l, 0, Bn, term, true, s);
+    if (rc != RELA_OK) return rc;
+  }
   // heads over the training steps: o_t = H[t+1], t in [burn, T)
-  return lstmnet_heads(net, Tt * Bn, H + (size_t)(burn + 1) * blk, legal_train, l->ha, q_out, s, "learner_fwd_heads");
+  const size_t blk = (size_t)Bn * kHid;
+  rc = lstmnet_heads(l->target, Tt * Bn, l->Hs[1] + (size_t)(burn + 1) * blk, legal_train, l->ha, l->q_tg, s,
+                     "learner_fwd_heads");
+  if (rc != RELA_OK) return rc;
+  return lstmnet_heads(l->online, Tt * Bn, l->Hs[0] + (size_t)(burn + 1) * blk, legal_train, l->ha, l->q_on, s,
+                       "learner_fwd_heads");
 }
 }  // namespace
 
@@ -443,11 +633,15 @@ extern "C" int rela_r2d2_learner_create(rela_r2d2_learner** out, int num_action,
   R2_ALLOC(l->a1, rowsAll * kA1, false);
   R2_ALLOC(l->a2, rowsAll * kA2, false);
   R2_ALLOC(l->a3, rowsAll * kA3, false);
-  R2_ALLOC(l->gx, rowsAll * kGates, false);
+  R2_ALLOC(l->gxs[0], rowsAll * kGates, false);
+  R2_ALLOC(l->gxs[1], rowsAll * kGates, false);
   {
     const size_t f = (size_t)kRecSplitF * B * kGates, b = (size_t)kRecSplitB * B * kHid;
     R2_ALLOC(l->rec_part, f > b ? f : b, false);
   }
+  RELA_HIP(hipMalloc(&l->rec_bar, sizeof(unsigned) * (size_t)(8 + 2 * ((T + 3) / 4 * 4))));
+  RELA_HIP(hipMemset(l->rec_bar, 0, sizeof(unsigned) * (size_t)(8 + 2 * ((T + 3) / 4 * 4))));
+  l->rec_persist = !(getenv("RELA_R2D2_REC") && strcmp(getenv("RELA_R2D2_REC"), "steps") == 0);
   R2_ALLOC(l->ha, rowsTr * 32, false);
   R2_ALLOC(l->q_on, rowsTr * A, false);
   R2_ALLOC(l->q_tg, rowsTr * A, false);
@@ -484,6 +678,8 @@ extern "C" void rela_r2d2_learner_destroy(rela_r2d2_learner* l) {
                 l->qmin,   l->qa_on,  l->qa_tg,   l->dqa,     l->d_ha,    l->d_o,     l->dc_rec, l->d_a3,   l->d_a2,
                 l->d_a1,   l->col,    l->part,    l->cpart,   l->s32,     l->npart,   l->norm,  l->loss,    l->loss_seq};
   for (void* p : ps) (void)hipFree(p);
+  (void)hipFree(l->rec_bar);
+  (void)hipFree(l->gxs[1]);
   rela_lstmnet_destroy(l->online);
   rela_lstmnet_destroy(l->target);
   delete l;
@@ -547,6 +743,21 @@ extern "C" int rela_r2d2_learner_flat(rela_r2d2_learner* l, float** params_dev, 
 
 extern "C" const float* rela_r2d2_learner_stats_dev(const rela_r2d2_learner* l) { return l ? l->norm : nullptr; }
 
+extern "C" int rela_r2d2_learner_check(rela_r2d2_learner* l, void* stream_) {
+  RELA_CHECK(l, RELA_EINVAL, "rela_r2d2_learner_check: null learner");
+  DeviceGuard g(l->device);
+  RELA_HIP(hipStreamSynchronize((hipStream_t)stream_));
+  unsigned tmo = 0;
+  RELA_HIP(hipMemcpy(&tmo, l->rec_bar, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (tmo != 0) {
+    RELA_HIP(hipMemset(l->rec_bar, 0, sizeof(unsigned)));
+    set_last_error("rela_r2d2_learner_check: the grid barrier of a persistent recurrent kernel timed out at step %u "
+                   "(results of that call are invalid)", tmo - 1);
+    return RELA_ESTATE;
+  }
+  return RELA_OK;
+}
+
 extern "C" int rela_r2d2_learner_backward(rela_r2d2_learner* l, int batch, const void* const* rows_dev,
                                           const float* weight_dev, float* priority_dev, float* loss_dev,
                                           float* loss_seq_dev, void* stream_) {
@@ -572,9 +783,7 @@ extern "C" int rela_r2d2_learner_backward(rela_r2d2_learner* l, int batch, const
   const float* legal_tr = legal + tr0 * A;
   const int64_t* act_tr = act + tr0;
   // target net first (no gradient, :158-159), then the online net, whose activations stay for the backward pass
-  int rc = forward_net(l, 1, Bn, obs, legal_tr, term, h0, c0, false, l->q_tg, s);
-  if (rc != RELA_OK) return rc;
-  rc = forward_net(l, 0, Bn, obs, legal_tr, term, h0, c0, true, l->q_on, s);
+  int rc = forward_both(l, Bn, obs, legal_tr, term, h0, c0, s);
   if (rc != RELA_OK) return rc;
   {
     ProfScope prof("learner_seq_td", s);

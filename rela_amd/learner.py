@@ -312,6 +312,11 @@ class HipR2D2Learner:
 
         return dev_view(self._capi.lib.rela_r2d2_learner_stats_dev(self.h), (2,), torch.float32, self.device)
 
+    def check(self):
+        """Synchronises and raises if a grid barrier of the persistent recurrent kernels gave up since the last check."""
+        stream = self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self._capi.check(self._capi.lib.rela_r2d2_learner_check(self.h, stream), "rela_r2d2_learner_check")
+
     def backward(self, batch, weight):
         """batch: RNNTransition-shaped (time-major [T, B, ...] cuda tensors: obs{s, eps, legal_move}, h0{h0, c0},
         action{a}, reward, terminal, bootstrap, seq_len); weight: cuda f32[B].

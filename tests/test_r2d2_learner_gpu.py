@@ -97,6 +97,7 @@ def test_hip_r2d2_learner_matches_reference_golden():
     learner = HipR2D2Learner.from_agent(agent, g["B"], grad_clip=1e9)
     batch, weight = _golden_batch(g, "cuda:0")
     loss, prio, loss_seq = learner.backward(batch, weight)
+    learner.check()  # no grid-barrier timeout in the persistent recurrent kernels
     torch.cuda.synchronize()
     np.testing.assert_allclose(loss_seq.cpu().numpy(), np.array(g["loss"]), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(prio.cpu().numpy(), np.array(g["priority"]), rtol=1e-4, atol=1e-5)
@@ -154,6 +155,7 @@ def test_hip_r2d2_learner_matches_autograd(A, B, seq, burn, n):
     batch, weight = _random_batch(rng, A, B, seq, burn, n, "cuda:0")
     learner = HipR2D2Learner.from_agent(agent, B, grad_clip=1e9)
     loss, prio, loss_seq = learner.backward(batch, weight)
+    learner.check()  # no grid-barrier timeout in the persistent recurrent kernels
     torch.cuda.synchronize()
     ref_loss, ref_prio = agent.loss(batch, sync_priority=False)
     (ref_loss * weight).mean().backward()
