@@ -53,13 +53,16 @@ SEED = 10002
 
 # algorithmic FLOPs per sample-forward: 2 * MACs
 FLOP = {"conv1_bf16x3": 2 * 400 * 32 * 256, "conv2_mfma": 2 * 81 * 64 * 512, "conv3_mfma": 2 * 49 * 64 * 576,
-        "fc_mfma": 2 * 3136 * 512, "heads_mfma": 2 * 512 * 19}
+        "fc_mfma": 2 * 3136 * 512, "heads_mfma": 2 * 512 * 19,
+        # bf16x2 mode: conv1 and conv2 are ONE kernel (conv1's output stays in LDS)
+        "conv12_fused": 2 * 400 * 32 * 256 + 2 * 81 * 64 * 512}
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 # algorithmic HBM bytes per sample-forward of each kernel: input tensor + output tensor (activations are 4 B per
 # element in both precision modes: f32, or bf16 hi + lo), u8 frames in, f32 h out
 BYTES_PER_SAMPLE = {"conv1_bf16x3": 28224 + 400 * 32 * 4, "conv2_mfma": 400 * 32 * 4 + 81 * 64 * 4,
-                    "conv3_mfma": 81 * 64 * 4 + 49 * 64 * 4, "fc_mfma": 49 * 64 * 4 + 512 * 4, "heads_mfma": 512 * 4 + 32 * 4}
+                    "conv3_mfma": 81 * 64 * 4 + 49 * 64 * 4, "fc_mfma": 49 * 64 * 4 + 512 * 4, "heads_mfma": 512 * 4 + 32 * 4,
+                    "conv12_fused": 28224 + 81 * 64 * 4}
 PEAK_HBM_GBS = 8000.0
 
 
@@ -561,7 +564,7 @@ def main():
     # Live roofline: HIP events around the four heavy forward kernels only (the dominant kernel is one
     # of them); timing all ~100 kernels of a step costs 0.37 ms of the step itself, so the full
     # per-kernel table comes from a short untimed pass after the timed region.
-    capi.lib.rela_prof_set_filter(b"conv1_bf16x3,conv2_mfma,conv3_mfma,fc_mfma")
+    capi.lib.rela_prof_set_filter(b"conv12_fused,conv1_bf16x3,conv2_mfma,conv3_mfma,fc_mfma")
     capi.lib.rela_prof_enable(0 if os.environ.get("RELA_BENCH_NOPROF") == "1" else 1)
     add0 = replay.num_add()
     t0 = time.perf_counter()
@@ -639,11 +642,14 @@ def main():
             # in 3 bf16 pieces (f32 mode: exact) or 2 (bf16x2 mode); the other layers 3 in bf16x2 mode
             fast = args.precision == "bf16x2"
             products = (2 if fast else 3) if name == "conv1_bf16x3" else (3 if fast else 0)
+            if name == "conv12_fused":  # 2 products for conv1's FLOPs, 3 for conv2's
+                f1, f2 = FLOP["conv1_bf16x3"], FLOP["conv2_mfma"]
+                products = (2 * f1 + 3 * f2) / (f1 + f2)
             peak_mfma = PEAK_BF16_MFMA_TFLOPS / products if products else PEAK_F32_MFMA_TFLOPS
             nbytes = BYTES_PER_SAMPLE[name] * ROWS
             mfma = {"achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": peak_mfma, "unit": "TFLOP/s",
                     "algorithmic_flop_per_launch": flops,
-                    "instruction": ("v_mfma_f32_16x16x32_bf16 x%d (split operands)" % products) if products
+                    "instruction": ("v_mfma_f32_16x16x32_bf16 x%.3g (split operands)" % products) if products
                     else "v_mfma_f32_16x16x4_f32"}
             mfma["frac"] = mfma["achieved"] / peak_mfma
             hbm = {"achieved": nbytes / (avg_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -672,7 +678,7 @@ def main():
             except (OSError, ValueError, KeyError):
                 continue
         fwd_ms = sum(prof[k]["total_ms"] for k in FLOP if k in prof)
-        fwd_cnt = prof.get("conv1_bf16x3", {"count": 1})["count"]
+        fwd_cnt = prof.get("conv12_fused", prof.get("conv1_bf16x3", {"count": 1}))["count"]
         scan_ms = sum(v["total_ms"] for k, v in prof_all.items() if k.startswith("seq_") or k in (
             "replay_targets", "replay_search", "replay_pop", "replay_is_weights"))
         out = {

@@ -936,6 +936,239 @@ __global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict
   }
 }
 
+// conv1 -> conv2 fused per frame: conv1's output (400 pixels x 32 channels of split records) is written straight
+// into conv2's padded LDS input tile and never travels to HBM (-328 MB written and -328 MB read per 6,400 frames;
+// staging that read alone took 82 of conv2's 123 us, the copy-out 29 of conv1's 133).  One 8-wave block per CU:
+//   LDS = half-frame bf16 image T1 (30 KB) | conv2 input tile T2 (59 KB) | conv2 output rows O (21 KB) | conv1's
+//         weight fragments (32 KB: conv2's 128 fragment registers per lane leave no room for them)
+//   per frame: conv1 on half 0 -> T2[0..199] | barrier | convert half 1 into T1 | barrier | conv1 on half 1 ->
+//         T2[200..399] | barrier | conv2 from T2 -> O (the next frame's first half is converted into T1 meanwhile)
+//         | barrier | O -> HBM (overlaps the next frame's conv1)
+// conv1 waves: 2 channel tiles x 4 row groups (13 row tiles per half, 4 per group); conv2 waves: 4 x 2 as in
+// conv_bf16s.  Raw u8 chunks of the next half frame wait in registers (issued one stage early).
+struct Conv12 {
+  using C1 = Conv1P;
+  using C2 = Conv2F;
+  static constexpr int RPW1 = 4, RG1 = 4, D1 = 4;
+  static constexpr int T1_BYTES = C1::TILE_BYTES, T2_BYTES = C2::LDS_BYTES, O_BYTES = C2::OUT_BYTES + 256;
+  static constexpr int B1_UINT4 = 2 * 2 * C1::KS * 64;  // [piece 2][ct 2][ks 8][lane 64]
+  static constexpr int LDS_TOTAL = T1_BYTES + T2_BYTES + O_BYTES + B1_UINT4 * 16;
+  static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+  static constexpr int IT = (C1::V16 + kThreads - 1) / kThreads;  // 2
+};
+
+__global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restrict__ in,
+                                                         const uint4* __restrict__ B1frag,
+                                                         const float* __restrict__ bias1,
+                                                         const uint4* __restrict__ B2frag,
+                                                         const float* __restrict__ bias2, uint8_t* __restrict__ out,
+                                                         int N) {
+  using F = Conv12;
+  using C1 = Conv1P;
+  using C2 = Conv2F;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* t1 = smem;
+  uint8_t* t2 = smem + F::T1_BYTES;
+  uint8_t* otile = t2 + F::T2_BYTES;
+  uint8_t* spare = otile + C2::OUT_BYTES;  // 256 B: rows past the last pixel of either layer land here
+  uint4* b1s = reinterpret_cast<uint4*>(otile + F::O_BYTES);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+
+  // ---- residents ----
+  for (int i = tid; i < F::B1_UINT4; i += kThreads) b1s[i] = B1frag[i];  // pieces hi, mid of [3][2][8][64]
+  const int ct1 = wave & 1, rg1 = wave >> 1;
+  const int ct2 = wave % C2::CT, rg2 = wave / C2::CT;
+  bf16x8 bh[C2::KS], bl[C2::KS];
+  {
+    const uint4* bp = B2frag + (size_t)ct2 * C2::KS * 2 * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < C2::KS; ++ks) {
+      bh[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2) * 64]);
+      bl[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2 + 1) * 64]);
+    }
+  }
+  const int col1 = ct1 * 16 + li, col2 = ct2 * 16 + li;
+  const float bv1 = bias1[col1], bv2 = bias2[col2];
+  // conv1 A fragments: lane group g = plane, 8 consecutive pixels of image row 4*oy + ks (see conv1_persist)
+  int a1base[F::RPW1], a1base2[F::RPW1];
+#pragma unroll
+  for (int t = 0; t < F::RPW1; ++t) {
+    const int rt = min(rg1 + t * F::RG1, C1::RT - 1);
+    const int m = min(rt * 16 + li, C1::HP - 1);
+    const int oy = m / 20, ox = m - oy * 20;
+    a1base[t] = g * C1::PLANE_BYTES + (4 * oy * 84 + 4 * ox) * 2;
+    a1base2[t] = a1base[t] + 8;
+    asm volatile("" : "+v"(a1base2[t]));  // keeps the two 8-byte reads apart (ds_read2_b64 is half rate)
+  }
+  int a2base[C2::RPW];
+#pragma unroll
+  for (int t = 0; t < C2::RPW; ++t) {
+    const int m = (rg2 + t * C2::RG) * 16 + li;
+    const int mm = (m < C2::M) ? m : 0;
+    const int oy = mm / C2::OW, ox = mm - oy * C2::OW;
+    a2base[t] = (oy * C2::STRIDE * C2::RQ + ox * C2::STRIDE * C2::Q + g) * 16;
+  }
+
+  // ---- staging of u8 half frames (unpredicated, clamped chunk index) ----
+  uint4 st[F::IT];
+  auto g_load = [&](int n, int h) {
+    const uint8_t* src = in + (size_t)n * C1::IN_ELEMS + h * (40 * 84);
+#pragma unroll
+    for (int j = 0; j < F::IT; ++j) {
+      const int i = min(tid + j * kThreads, C1::V16 - 1);
+      const int pl = i / C1::PV16, r = i - pl * C1::PV16;
+      st[j] = *reinterpret_cast<const uint4*>(src + pl * C1::PLANE_ELEMS + r * 16);
+    }
+  };
+  auto cvt_store = [&]() {
+#pragma unroll
+    for (int j = 0; j < F::IT; ++j) {
+      const int i = min(tid + j * kThreads, C1::V16 - 1);
+      const int pl = i / C1::PV16, r = i - pl * C1::PV16;
+      uint4* dst = reinterpret_cast<uint4*>(t1 + pl * C1::PLANE_BYTES + r * 32);
+      dst[0] = u8x8_to_bf16x8(st[j].x, st[j].y);
+      dst[1] = u8x8_to_bf16x8(st[j].z, st[j].w);
+    }
+  };
+
+  // ---- conv1 on the half frame in T1 -> split records of pixels [200 h, 200 h + 200) in T2 ----
+  auto conv1_half = [&](int h) {
+    f32x4 acc[F::RPW1];
+#pragma unroll
+    for (int t = 0; t < F::RPW1; ++t) acc[t] = f32x4{bv1, bv1, bv1, bv1};
+    constexpr int TOT = C1::KS * F::RPW1;
+    uint2 a0[F::D1], a1[F::D1];
+    auto a_issue = [&](int idx, int slot) {
+      const int ks = idx / F::RPW1, t = idx - ks * F::RPW1;
+      a0[slot] = *reinterpret_cast<const uint2*>(t1 + a1base[t] + ks * 168);
+      a1[slot] = *reinterpret_cast<const uint2*>(t1 + a1base2[t] + ks * 168);
+    };
+    uint4 wlo[2], whi[2];  // this wave's two weight pieces of k-step ks (double buffered)
+    auto w_issue = [&](int ks, int slot) {
+      whi[slot] = b1s[((0 * 2 + ct1) * C1::KS + ks) * 64 + lane];
+      wlo[slot] = b1s[((1 * 2 + ct1) * C1::KS + ks) * 64 + lane];
+    };
+    w_issue(0, 0);
+#pragma unroll
+    for (int i = 0; i < F::D1; ++i) a_issue(i, i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < C1::KS; ++ks) {
+      if (ks + 1 < C1::KS) w_issue(ks + 1, (ks + 1) & 1);
+      const bf16x8 blo = __builtin_bit_cast(bf16x8, wlo[ks & 1]), bhi = __builtin_bit_cast(bf16x8, whi[ks & 1]);
+#pragma unroll
+      for (int t = 0; t < F::RPW1; t += 2) {
+        const int idx = ks * F::RPW1 + t;
+        const int s0 = idx % F::D1, s1 = (idx + 1) % F::D1;
+        const bf16x8 x0 = __builtin_bit_cast(bf16x8, make_uint4(a0[s0].x, a0[s0].y, a1[s0].x, a1[s0].y));
+        const bf16x8 x1 = __builtin_bit_cast(bf16x8, make_uint4(a0[s1].x, a0[s1].y, a1[s1].x, a1[s1].y));
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, blo, acc[t], 0, 0, 0);
+        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, blo, acc[t + 1], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, bhi, acc[t], 0, 0, 0);
+        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, bhi, acc[t + 1], 0, 0, 0);
+        if (idx + F::D1 < TOT) a_issue(idx + F::D1, s0);
+        if (idx + 1 + F::D1 < TOT) a_issue(idx + 1 + F::D1, s1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // ReLU + split into conv2's input tile: pixel P = 200 h + m at (y, x) = (P / 20, P % 20).  The record addresses
+    // are derived here from an opaque copy of h: hoisted out of the frame loop they would pin 32 registers.
+    int hh = h;
+    asm volatile("" : "+v"(hh));
+#pragma unroll
+    for (int t = 0; t < F::RPW1; ++t) {
+      const int rt = rg1 + t * F::RG1;
+      if (rt >= C1::RT) continue;  // (wave-uniform: a group's tiles past the 13th were only computed)
+      const int m0 = rt * 16 + g * 4;  // four consecutive pixels m0 .. m0 + 3 (m0 % 4 == 0: they share an image row)
+      const int P0 = hh * C1::HP + m0;
+      const int y = P0 / 20, x = P0 - y * 20;
+      uint8_t* rec = (m0 < C1::HP) ? t2 + (size_t)(y * C2::RQ + x * C2::Q) * 16 : spare;
+      const int step = (m0 < C1::HP) ? C2::Q * 16 : 0;
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        const float v0 = acc[t][r], v1 = acc[t][r + 1];
+        split_store_lds2(rec + r * step, rec + (r + 1) * step, 32, col1, v0 > 0.f ? v0 : 0.f, v1 > 0.f ? v1 : 0.f);
+      }
+    }
+  };
+
+  int n = blockIdx.x;
+  if (n >= N) return;
+  g_load(n, 0);
+  cvt_store();
+  g_load(n, 1);
+#pragma unroll
+  for (int ks = 0; ks < C2::KS; ++ks) {
+    pin_loaded(bh[ks]);
+    pin_loaded(bl[ks]);
+  }
+  __syncthreads();
+  constexpr int LO = C2::CIN * 2;
+  for (; n < N; n += gridDim.x) {
+    const int nn = (n + (int)gridDim.x < N) ? n + (int)gridDim.x : n;  // (the last round re-reads its own frame)
+    conv1_half(0);
+    __syncthreads();  // T1 free
+    cvt_store();      // half 1 of this frame
+    g_load(nn, 0);
+    __syncthreads();  // T1 ready
+    conv1_half(1);
+    __syncthreads();  // T2 complete, T1 free
+    // ---- conv2 from T2; the next frame's first half goes into T1 meanwhile ----
+    {
+      f32x4 acc[C2::RPW];
+#pragma unroll
+      for (int t = 0; t < C2::RPW; ++t) acc[t] = f32x4{bv2, bv2, bv2, bv2};
+      constexpr int TOT = C2::KS * C2::RPW, D = 3;
+      uint4 ah[D], al[D];
+      auto a_issue = [&](int idx, int slot) {
+        const int ks = idx / C2::RPW, t = idx - ks * C2::RPW;
+        const int kh = ks / C2::KW, kw = ks - kh * C2::KW;  // KSUB = 1: one k-step per tap
+        const uint8_t* ap = t2 + a2base[t] + (kh * C2::RQ + kw * C2::Q) * 16;
+        ah[slot] = *reinterpret_cast<const uint4*>(ap);
+        al[slot] = *reinterpret_cast<const uint4*>(ap + LO);
+      };
+#pragma unroll
+      for (int i = 0; i < D; ++i) a_issue(i, i);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int idx = 0; idx < TOT; ++idx) {
+        const int ks = idx / C2::RPW, t = idx - ks * C2::RPW;
+        const int slot = idx % D;
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[slot]);
+        const bf16x8 xl = __builtin_bit_cast(bf16x8, al[slot]);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh[ks], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl[ks], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh[ks], acc[t], 0, 0, 0);
+        if (idx + D < TOT) a_issue(idx + D, slot);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      cvt_store();  // half 0 of the next frame (its loads were issued two stages ago; the ring registers are free)
+      g_load(nn, 1);
+#pragma unroll
+      for (int t = 0; t < C2::RPW; ++t) {
+        const int rt = rg2 + t * C2::RG;
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const int m = rt * 16 + g * 4 + r;
+          const float v0 = acc[t][r], v1 = acc[t][r + 1];
+          uint8_t* rec0 = (m < C2::M) ? otile + (size_t)m * (C2::OC * 4) : spare;
+          uint8_t* rec1 = (m + 1 < C2::M) ? otile + (size_t)(m + 1) * (C2::OC * 4) : spare;
+          split_store_lds2(rec0, rec1, C2::OC, col2, v0 > 0.f ? v0 : 0.f, v1 > 0.f ? v1 : 0.f);
+        }
+      }
+    }
+    __syncthreads();  // O complete, T1 ready, T2 free
+    {
+      const uint4* src = reinterpret_cast<const uint4*>(otile);
+      uint4* dst = reinterpret_cast<uint4*>(out + (size_t)n * C2::P * (C2::OC * 4));
+      constexpr int nv = C2::P * (C2::OC * 4 / 16);
+      for (int i = tid; i < nv; i += kThreads) dst[i] = src[i];
+    }
+  }
+}
+
 // fc on split records: out[N][512] = relu(A x W + b), A = a3 records [N][49][hi 64 | lo 64], k = pos*64 + c.
 // Block = BM rows x 128 columns (8 waves, one 16-column tile each).  A arrives per position (256 B per row) through
 // registers into a THREE-deep LDS ring (row stride 288 B: conflict-free ds_read_b128), loaded from HBM two
@@ -1435,6 +1668,8 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv1P::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv2F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv2F::LDS_TOTAL));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_bf16s),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv12::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv3F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv3F::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s<FcFast>),
@@ -1563,15 +1798,21 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
   if (n->precision == 1 && N >= kFastMinN) {
     // split-bf16 fast path: a1 / a2 / a3 hold split records (same bytes as the f32 tensors they replace)
     uint8_t *r1 = reinterpret_cast<uint8_t*>(a1), *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
+    if (!getenv("RELA_NO_FUSE12")) {
+      ProfScope prof("conv12_fused", s);
+      hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
+                         (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
+    } else {
     {
       ProfScope prof(names[0], s);
       hipLaunchKernelGGL((conv1_persist<true, 2>), dim3(std::min(2 * kNumCU, 2 * N)), dim3(Conv1P::THREADS),
                          Conv1P::LDS_BYTES, s, s_dev, d.B1p, d.b1, a1, N);
-    }
-    {
+      }
+      {
       ProfScope prof(names[1], s);
       hipLaunchKernelGGL(conv_bf16s<Conv2F>, dim3(std::min(kNumCU, ceil_div(N, Conv2F::S))), dim3(kThreads),
                          Conv2F::LDS_TOTAL, s, (const uint8_t*)r1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
+      }
     }
     {
       ProfScope prof(names[2], s);
