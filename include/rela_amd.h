@@ -244,6 +244,9 @@ uint64_t rela_ffnet_version(const rela_ffnet* net);
  * (tests/test_ffnet_gpu.py reports the greedy-action agreement).  conv1 and the heads are exact in both. */
 int rela_ffnet_set_precision(rela_ffnet* net, int mode);
 int rela_ffnet_precision(const rela_ffnet* net);
+/* Test tap: synchronises the device and returns the sticky give-up word of the pipelined conv1 -> conv2 kernel
+ * (0 = no wave ever gave up waiting on a hand-off; anything else invalidates the forwards since the last read). */
+int rela_ffnet_debug_pipe_timeout(rela_ffnet* net, unsigned* out);
 /* bytes of scratch rela_ffnet_forward needs for a batch of n */
 int64_t rela_ffnet_workspace_bytes(const rela_ffnet* net, int n);
 

@@ -101,6 +101,7 @@ _sig("rela_ffnet_num_action", i32, [vp])
 _sig("rela_ffnet_version", C.c_uint64, [vp])
 _sig("rela_ffnet_set_precision", i32, [vp, i32])
 _sig("rela_ffnet_precision", i32, [vp])
+_sig("rela_ffnet_debug_pipe_timeout", i32, [vp, P(C.c_uint)])
 _sig("rela_ffnet_workspace_bytes", i64, [vp, i32])
 _sig("rela_ffnet_forward", i32, [vp, i32, vp, vp, vp, vp, i64, vp])
 _sig("rela_lstmnet_create", i32, [P(vp), i32, i32])

@@ -1169,6 +1169,311 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
   }
 }
 
+// conv1 -> conv2 as a TWO-STAGE PIPELINE inside one block (wave specialisation by layer).  The symmetric fused
+// kernel above runs its phases in lock-step on all eight waves, so the MFMA pipe idles during every epilogue,
+// conversion and copy-out (MFMA 41 % busy).  Here waves 0-3 only run conv1 (frame n + 1) and waves 4-7 only conv2
+// (frame n); a SIMD hosts one wave of each, so one layer's MFMAs fill the other's non-MFMA phases, and the two
+// layers carry about the same MFMA work (224 and 288 instructions per wave and frame).
+//   LDS = half-frame bf16 image T1 (30 KB) | conv2 input tiles T2[0], T2[1] (59 KB each) | spare record | flags.
+//   conv1 waves (2 channel tiles x 2 row groups, both weight pieces resident: 64 registers): wait until T2[b] is
+//     free -> half 0 -> T2[b][0..199] -> half 1 -> T2[b][200..399] -> full[b]++; T1 is refilled between the halves
+//     behind a barrier of the four conv1 waves.
+//   conv2 waves (one channel tile each, all six row tiles, 128 weight registers): wait full[b] -> MFMAs from T2[b]
+//     -> barrier of the four -> ReLU + split into the first 21 KB of T2[b] (its input is consumed) -> barrier ->
+//     whole rows to HBM -> free[b]++.
+// The hand-offs are monotone counters in LDS (ds_add / ds_read polls, one lane adds per wave); every spin is
+// bounded and a wave that gives up sets `*tmo` and leaves, so the launch always ends.
+// Measured (N = 6,400): 210 us against 218 us for the symmetric kernel, so it is opt-in (RELA_FUSE12=2), not the
+// default.  In-kernel stamps show why the gain is small: the hand-off locks the two stages IN phase (conv2 of frame
+// n starts when conv1 of frame n ends, which is when conv1 of frame n + 1 starts), so both layers' MFMA phases
+// coincide (the pipe is full for 8.3 k cycles per frame) and so do their other phases (7 k cycles: sub-barriers 2.3 k,
+// conversion 1.5 k, epilogue 3 k on the conv1 side); the conv1 stage alone needs 10.6 k cycles per frame.
+struct Conv12P {
+  using C1 = Conv1P;
+  using C2 = Conv2F;
+  static constexpr int RPW1 = 7, RG1 = 2, D1 = 4, D2 = 3;
+  static constexpr int T1_BYTES = C1::TILE_BYTES, T2_BYTES = C2::LDS_BYTES;
+  static constexpr int LDS_TOTAL = T1_BYTES + 2 * T2_BYTES + 256 + 64;
+  static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+  static constexpr int PTHREADS = 256;
+  static constexpr int IT = (C1::V16 + PTHREADS - 1) / PTHREADS;  // 4
+  static constexpr unsigned SPIN_LIMIT = 1u << 22;
+};
+
+__device__ __forceinline__ unsigned lds_ld(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// waits until *p >= target; false after SPIN_LIMIT polls or once another wave gave up
+__device__ __forceinline__ bool lds_wait_ge(const unsigned* p, unsigned target, const unsigned* dead, unsigned* tmo,
+                                            unsigned code) {
+  asm volatile("" ::: "memory");
+  for (unsigned spins = 0; (int)(lds_ld(p) - target) < 0; ++spins) {
+    __builtin_amdgcn_s_sleep(1);
+    if (spins > Conv12P::SPIN_LIMIT || lds_ld(dead) != 0) {
+      __hip_atomic_store(const_cast<unsigned*>(dead), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if ((threadIdx.x & 63) == 0) atomicMax(tmo, code);
+      return false;
+    }
+  }
+  asm volatile("" ::: "memory");
+  return true;
+}
+// this wave's LDS operations are complete, then ONE lane bumps the counter
+__device__ __forceinline__ void lds_signal(unsigned* p) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ __launch_bounds__(kThreads) void conv12_pipe(const uint8_t* __restrict__ in,
+                                                        const uint4* __restrict__ B1frag,
+                                                        const float* __restrict__ bias1,
+                                                        const uint4* __restrict__ B2frag,
+                                                        const float* __restrict__ bias2, uint8_t* __restrict__ out,
+                                                        int N, unsigned* tmo) {
+  using F = Conv12P;
+  using C1 = Conv1P;
+  using C2 = Conv2F;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* t1 = smem;
+  uint8_t* t2base = smem + F::T1_BYTES;
+  uint8_t* spare = t2base + 2 * F::T2_BYTES;
+  unsigned* flags = reinterpret_cast<unsigned*>(spare + 256);  // full[2], free[2], pbar, cbar, dead
+  unsigned *full = flags, *freed = flags + 2, *pbar = flags + 4, *cbar = flags + 5, *dead = flags + 6;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  if (tid < 16) flags[tid] = 0;
+  __syncthreads();
+  if ((int)blockIdx.x >= N) return;
+  const int nframes = (N - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;  // frames of this block
+
+  if (wave < 4) {
+    // ======================= conv1 waves =======================
+    const int ptid = tid;  // 0 .. 255
+    const int ct1 = wave & 1, rg1 = wave >> 1;
+    bf16x8 b1[2][C1::KS];  // [piece: hi, mid][ks]
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int ks = 0; ks < C1::KS; ++ks)
+        b1[p][ks] = __builtin_bit_cast(bf16x8, B1frag[((p * 2 + ct1) * C1::KS + ks) * 64 + lane]);
+    const int col1 = ct1 * 16 + li;
+    const float bv1 = bias1[col1];
+    int a1base[F::RPW1], a1base2[F::RPW1];
+#pragma unroll
+    for (int t = 0; t < F::RPW1; ++t) {
+      const int rt = min(rg1 + t * F::RG1, C1::RT - 1);
+      const int m = min(rt * 16 + li, C1::HP - 1);
+      const int oy = m / 20, ox = m - oy * 20;
+      a1base[t] = g * C1::PLANE_BYTES + (4 * oy * 84 + 4 * ox) * 2;
+      a1base2[t] = a1base[t] + 8;
+      asm volatile("" : "+v"(a1base2[t]));  // keeps the two 8-byte reads apart (ds_read2_b64 is half rate)
+    }
+    uint4 st[F::IT];
+    auto g_load = [&](int n, int h) {
+      const uint8_t* src = in + (size_t)n * C1::IN_ELEMS + h * (40 * 84);
+#pragma unroll
+      for (int j = 0; j < F::IT; ++j) {
+        const int i = min(ptid + j * F::PTHREADS, C1::V16 - 1);
+        const int pl = i / C1::PV16, r = i - pl * C1::PV16;
+        st[j] = *reinterpret_cast<const uint4*>(src + pl * C1::PLANE_ELEMS + r * 16);
+      }
+    };
+    auto cvt_store = [&]() {
+#pragma unroll
+      for (int j = 0; j < F::IT; ++j) {
+        const int i = min(ptid + j * F::PTHREADS, C1::V16 - 1);
+        const int pl = i / C1::PV16, r = i - pl * C1::PV16;
+        uint4* dst = reinterpret_cast<uint4*>(t1 + pl * C1::PLANE_BYTES + r * 32);
+        dst[0] = u8x8_to_bf16x8(st[j].x, st[j].y);
+        dst[1] = u8x8_to_bf16x8(st[j].z, st[j].w);
+      }
+    };
+    unsigned pgen = 0;
+    auto p_barrier = [&]() -> bool {
+      pgen += 4;
+      lds_signal(pbar);
+      return lds_wait_ge(pbar, pgen, dead, tmo, 1);
+    };
+    auto conv1_half = [&](int h, uint8_t* t2) {
+      f32x4 acc[F::RPW1];
+#pragma unroll
+      for (int t = 0; t < F::RPW1; ++t) acc[t] = f32x4{bv1, bv1, bv1, bv1};
+      constexpr int TOT = C1::KS * F::RPW1;
+      uint2 a0[F::D1], a1[F::D1];
+      auto a_issue = [&](int idx, int slot) {
+        const int ks = idx / F::RPW1, t = idx - ks * F::RPW1;
+        a0[slot] = *reinterpret_cast<const uint2*>(t1 + a1base[t] + ks * 168);
+        a1[slot] = *reinterpret_cast<const uint2*>(t1 + a1base2[t] + ks * 168);
+      };
+      auto frag = [&](int slot) {
+        return __builtin_bit_cast(bf16x8, make_uint4(a0[slot].x, a0[slot].y, a1[slot].x, a1[slot].y));
+      };
+#pragma unroll
+      for (int i = 0; i < F::D1; ++i) a_issue(i, i);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < C1::KS; ++ks) {
+#pragma unroll
+        for (int t = 0; t + 1 < F::RPW1; t += 2) {
+          const int idx = ks * F::RPW1 + t;
+          const int s0 = idx % F::D1, s1 = (idx + 1) % F::D1;
+          const bf16x8 x0 = frag(s0), x1 = frag(s1);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, b1[1][ks], acc[t], 0, 0, 0);
+          acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, b1[1][ks], acc[t + 1], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, b1[0][ks], acc[t], 0, 0, 0);
+          acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, b1[0][ks], acc[t + 1], 0, 0, 0);
+          if (idx + F::D1 < TOT) a_issue(idx + F::D1, s0);
+          if (idx + 1 + F::D1 < TOT) a_issue(idx + 1 + F::D1, s1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+          const int t = F::RPW1 - 1, idx = ks * F::RPW1 + t, s0 = idx % F::D1;
+          const bf16x8 x0 = frag(s0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, b1[1][ks], acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, b1[0][ks], acc[t], 0, 0, 0);
+          if (idx + F::D1 < TOT) a_issue(idx + F::D1, s0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      int hh = h;
+      asm volatile("" : "+v"(hh));  // (addresses derived inside the loop: hoisted they would pin registers)
+#pragma unroll
+      for (int t = 0; t < F::RPW1; ++t) {
+        const int rt = rg1 + t * F::RG1;
+        if (rt >= C1::RT) continue;  // wave-uniform
+        const int m0 = rt * 16 + g * 4;  // four consecutive pixels of one image row
+        const int P0 = hh * C1::HP + m0;
+        const int y = P0 / 20, x = P0 - y * 20;
+        uint8_t* rec = (m0 < C1::HP) ? t2 + (size_t)(y * C2::RQ + x * C2::Q) * 16 : spare;
+        const int step = (m0 < C1::HP) ? C2::Q * 16 : 0;
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const float v0 = acc[t][r], v1 = acc[t][r + 1];
+          split_store_lds2(rec + r * step, rec + (r + 1) * step, 32, col1, v0 > 0.f ? v0 : 0.f, v1 > 0.f ? v1 : 0.f);
+        }
+      }
+    };
+
+    int n = blockIdx.x;
+    g_load(n, 0);
+    cvt_store();
+    g_load(n, 1);
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int ks = 0; ks < C1::KS; ++ks) pin_loaded(b1[p][ks]);
+    if (!p_barrier()) return;
+    for (int k = 0; k < nframes; ++k, n += gridDim.x) {
+      const int b = k & 1;
+      uint8_t* t2 = t2base + b * F::T2_BYTES;
+      const int nn = (k + 1 < nframes) ? n + (int)gridDim.x : n;  // (the last round re-reads its own frame)
+      if (!lds_wait_ge(freed + b, 4u * (unsigned)(k >> 1), dead, tmo, 2)) return;
+      conv1_half(0, t2);
+      if (!p_barrier()) return;  // T1 free
+      cvt_store();               // half 1 of this frame
+      g_load(nn, 0);
+      if (!p_barrier()) return;  // T1 ready
+      conv1_half(1, t2);
+      lds_signal(full + b);      // this wave's share of T2[b] is written
+      if (!p_barrier()) return;  // T1 free
+      cvt_store();               // half 0 of the next frame
+      g_load(nn, 1);
+      if (!p_barrier()) return;  // T1 ready
+    }
+  } else {
+    // ======================= conv2 waves =======================
+    const int ctid = tid - 256;
+    const int ct2 = wave - 4;
+    bf16x8 bh[C2::KS], bl[C2::KS];
+    {
+      const uint4* bp = B2frag + (size_t)ct2 * C2::KS * 2 * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < C2::KS; ++ks) {
+        bh[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2) * 64]);
+        bl[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2 + 1) * 64]);
+      }
+    }
+    const int col2 = ct2 * 16 + li;
+    const float bv2 = bias2[col2];
+    constexpr int RT2 = C2::RT;  // 6 row tiles, all on this wave
+    int a2base[RT2];
+#pragma unroll
+    for (int t = 0; t < RT2; ++t) {
+      const int m = t * 16 + li;
+      const int mm = (m < C2::M) ? m : 0;
+      const int oy = mm / C2::OW, ox = mm - oy * C2::OW;
+      a2base[t] = (oy * C2::STRIDE * C2::RQ + ox * C2::STRIDE * C2::Q + g) * 16;
+    }
+#pragma unroll
+    for (int ks = 0; ks < C2::KS; ++ks) {
+      pin_loaded(bh[ks]);
+      pin_loaded(bl[ks]);
+    }
+    unsigned cgen = 0;
+    auto c_barrier = [&]() -> bool {
+      cgen += 4;
+      lds_signal(cbar);
+      return lds_wait_ge(cbar, cgen, dead, tmo, 3);
+    };
+    constexpr int LO = C2::CIN * 2;
+    int n = blockIdx.x;
+    for (int k = 0; k < nframes; ++k, n += gridDim.x) {
+      const int b = k & 1;
+      uint8_t* t2 = t2base + b * F::T2_BYTES;
+      if (!lds_wait_ge(full + b, 4u * (unsigned)((k >> 1) + 1), dead, tmo, 4)) return;
+      f32x4 acc[RT2];
+#pragma unroll
+      for (int t = 0; t < RT2; ++t) acc[t] = f32x4{bv2, bv2, bv2, bv2};
+      constexpr int TOT = C2::KS * RT2, D = F::D2;
+      uint4 ah[D], al[D];
+      auto a_issue = [&](int idx, int slot) {
+        const int ks = idx / RT2, t = idx - ks * RT2;
+        const int kh = ks / C2::KW, kw = ks - kh * C2::KW;  // one k-step per tap
+        const uint8_t* ap = t2 + a2base[t] + (kh * C2::RQ + kw * C2::Q) * 16;
+        ah[slot] = *reinterpret_cast<const uint4*>(ap);
+        al[slot] = *reinterpret_cast<const uint4*>(ap + LO);
+      };
+#pragma unroll
+      for (int i = 0; i < D; ++i) a_issue(i, i);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int idx = 0; idx < TOT; ++idx) {
+        const int ks = idx / RT2, t = idx - ks * RT2;
+        const int slot = idx % D;
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[slot]);
+        const bf16x8 xl = __builtin_bit_cast(bf16x8, al[slot]);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh[ks], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl[ks], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh[ks], acc[t], 0, 0, 0);
+        if (idx + D < TOT) a_issue(idx + D, slot);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!c_barrier()) return;  // every conv2 wave has read its last fragment of T2[b]
+      uint8_t* otile = t2;       // the output records take the place of the consumed input
+#pragma unroll
+      for (int t = 0; t < RT2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const int m = t * 16 + g * 4 + r;
+          const float v0 = acc[t][r], v1 = acc[t][r + 1];
+          uint8_t* rec0 = (m < C2::M) ? otile + (size_t)m * (C2::OC * 4) : spare;
+          uint8_t* rec1 = (m + 1 < C2::M) ? otile + (size_t)(m + 1) * (C2::OC * 4) : spare;
+          split_store_lds2(rec0, rec1, C2::OC, col2, v0 > 0.f ? v0 : 0.f, v1 > 0.f ? v1 : 0.f);
+        }
+      }
+      if (!c_barrier()) return;  // records complete
+      {
+        const uint4* src = reinterpret_cast<const uint4*>(otile);
+        uint4* dst = reinterpret_cast<uint4*>(out + (size_t)n * C2::P * (C2::OC * 4));
+        constexpr int nv = C2::P * (C2::OC * 4 / 16);
+        for (int i = ctid; i < nv; i += 256) dst[i] = src[i];
+      }
+      lds_signal(freed + b);  // (waits for this wave's LDS reads first)
+    }
+  }
+}
+
 // fc on split records: out[N][512] = relu(A x W + b), A = a3 records [N][49][hi 64 | lo 64], k = pos*64 + c.
 // Block = BM rows x 128 columns (8 waves, one 16-column tile each).  A arrives per position (256 B per row) through
 // registers into a THREE-deep LDS ring (row stride 288 B: conflict-free ds_read_b128), loaded from HBM two
@@ -1630,6 +1935,7 @@ struct rela_ffnet {
   uint64_t version = 0;  // bumped by every load
   const char* const* prof_names = nullptr;  // per-kernel timing labels (actor-side by default)
   int precision = 0;  // 0 = exact f32 MFMA (parity mode), 1 = split-bf16 MFMA for conv2 / conv3 / fc
+  unsigned* pipe_tmo = nullptr;  // sticky: a wave of conv12_pipe gave up waiting (never observed)
 };
 
 
@@ -1661,6 +1967,8 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
   RELA_HIP(hipMalloc(&d.B2f, sizeof(uint4) * Conv2F::CT * Conv2F::KS * 2 * 64));
   RELA_HIP(hipMalloc(&d.B3f, sizeof(uint4) * Conv3F::CT * Conv3F::KS * 2 * 64));
   RELA_HIP(hipMalloc(&d.Bff, sizeof(uint4) * 32 * FcFast::KS * 2 * 64));
+  RELA_HIP(hipMalloc(&n->pipe_tmo, 16));
+  RELA_HIP(hipMemset(n->pipe_tmo, 0, 16));
   // opt in to > 64 KB of dynamic LDS once per process/device
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv1B::LDS_BYTES));
@@ -1670,6 +1978,8 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv2F::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_bf16s),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv12::LDS_TOTAL));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_pipe),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv12P::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv3F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv3F::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s<FcFast>),
@@ -1693,7 +2003,16 @@ extern "C" void rela_ffnet_destroy(rela_ffnet* n) {
   void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bf, n->d.bf, n->d.Bh, n->d.bh,
                 n->d.BfT, n->d.B2f, n->d.B3f, n->d.Bff, n->d.B1p};
   for (void* p : ps) (void)hipFree(p);
+  (void)hipFree(n->pipe_tmo);
   delete n;
+}
+
+extern "C" int rela_ffnet_debug_pipe_timeout(rela_ffnet* n, unsigned* out) {
+  RELA_CHECK(n && out, RELA_EINVAL, "rela_ffnet_debug_pipe_timeout: null argument");
+  DeviceGuard g(n->device);
+  RELA_HIP(hipDeviceSynchronize());
+  RELA_HIP(hipMemcpy(out, n->pipe_tmo, sizeof(unsigned), hipMemcpyDeviceToHost));
+  return RELA_OK;
 }
 
 extern "C" int rela_ffnet_num_action(const rela_ffnet* n) { return n ? n->num_action : 0; }
@@ -1798,7 +2117,14 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
   if (n->precision == 1 && N >= kFastMinN) {
     // split-bf16 fast path: a1 / a2 / a3 hold split records (same bytes as the f32 tensors they replace)
     uint8_t *r1 = reinterpret_cast<uint8_t*>(a1), *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
-    if (!getenv("RELA_NO_FUSE12")) {
+    // 0: separate conv1 / conv2 kernels, 1: fused, all waves symmetric (default), 2: fused, layer-specialised waves
+    static const int fuse_mode = getenv("RELA_FUSE12") ? atoi(getenv("RELA_FUSE12")) : 1;
+    if (fuse_mode == 2) {
+      ProfScope prof("conv12_fused", s);
+      hipLaunchKernelGGL(conv12_pipe, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12P::LDS_TOTAL, s, s_dev,
+                         (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N,
+                         n->pipe_tmo);
+    } else if (fuse_mode == 1) {
       ProfScope prof("conv12_fused", s);
       hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);

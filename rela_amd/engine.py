@@ -47,9 +47,17 @@ class FFNetHandle:
         self._keep = keep  # packing kernels are stream-ordered; keep sources alive until the next load
 
     def set_precision(self, mode):
-        """"f32" (default: exact f32 MFMA, the parity mode) or "bf16x2" (split-bf16 MFMA for conv2 / conv3 / fc,
-        Q within 1e-4 of the f32 path; include/rela_amd.h rela_ffnet_set_precision)."""
+        """"f32" (default: exact f32 MFMA, the parity mode) or "bf16x2" (split-bf16 MFMA for the whole trunk,
+        Q within 1e-6 of the f32 path; include/rela_amd.h rela_ffnet_set_precision)."""
         capi.check(capi.lib.rela_ffnet_set_precision(self.h, {"f32": 0, "bf16x2": 1}[mode]), "rela_ffnet_set_precision")
+
+    def pipe_timeout(self):
+        """Synchronises; 0 unless a wave of the pipelined conv1 -> conv2 kernel ever gave up on a hand-off."""
+        import ctypes as C
+
+        out = C.c_uint(0)
+        capi.check(capi.lib.rela_ffnet_debug_pipe_timeout(self.h, C.byref(out)), "rela_ffnet_debug_pipe_timeout")
+        return out.value
 
     def close(self):
         if getattr(self, "h", None):
