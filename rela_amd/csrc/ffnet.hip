@@ -546,6 +546,22 @@ __global__ void pack_conv1_bf16x3(const float* __restrict__ w, uint16_t* __restr
 // between the layers in "split records": per pixel, C channels of hi (2 B each) followed by C channels of
 // lo -- the same 4 bytes per element as f32, so HBM traffic is unchanged while the MFMA work drops 5.3x.
 // =====================================================================================================
+// Four CONSECUTIVE channels of ONE pixel -> the hi and lo halves of its LDS record.  This is what a lane holds when the
+// MFMA is issued with the operands swapped (weights as the A operand: D[channel 4g + r][pixel li]): ReLU, two packed
+// RNE conversions per half and TWO 8-byte LDS stores for four values, where the pixel-major tile needed eight 2-byte
+// stores (the epilogues' LDS stores were a fifth of the frame time).
+__device__ __forceinline__ void split_store_lds4(uint8_t* rec, int C, int ch0, f32x4 v) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ a = {v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f}, b = {v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
+  const bf16x2_ ha = __builtin_convertvector(a, bf16x2_), hb = __builtin_convertvector(b, bf16x2_);
+  const bf16x2_ la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2_), bf16x2_);
+  const bf16x2_ lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2_), bf16x2_);
+  *reinterpret_cast<uint2*>(rec + ch0 * 2) = make_uint2(__builtin_bit_cast(uint32_t, ha), __builtin_bit_cast(uint32_t, hb));
+  *reinterpret_cast<uint2*>(rec + C * 2 + ch0 * 2) =
+      make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
+}
+
 // Makes the compiler treat a resident weight fragment as consumed HERE: its s_waitcnt for the load lands before
 // the persistent loop instead of at the first use inside it, where on later rounds the same counter value
 // would wait for the output stores and prefetches of the round before.
@@ -774,7 +790,8 @@ struct ConvFastCfg {
   static constexpr int Q = Q_, RQ = RQ_, SQ = SQ_;   // pixel / row / sample stride in 16-byte units
   static constexpr int DEPTH = (CIN == 32) ? 4 : 3;  // A fragment pairs in flight per wave (register ring)
   static constexpr int LDS_BYTES = S * SQ * 16;      // one input buffer
-  static constexpr int OUT_BYTES = S * OH * OW * 64 * 4;  // output records of one group (staged for coalesced stores)
+  static constexpr int OROW = OC * 4 + 16;  // staged record stride: the 16 pixels of a store spread over the banks
+  static constexpr int OUT_BYTES = S * OH * OW * OROW;  // output records of one group (staged for coalesced stores)
   static constexpr int LDS_TOTAL = 2 * LDS_BYTES + 2 * OUT_BYTES + OC * 4;  // + one spare record
   static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
   static constexpr int IN_BYTES = IH * IW * REC;     // per sample in HBM
@@ -818,8 +835,8 @@ __global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict
     const int oy = pos / C::OW, ox = pos - oy * C::OW;
     abase[t] = (sm * C::SQ + oy * C::STRIDE * C::RQ + ox * C::STRIDE * C::Q + g) * 16;
   }
-  const int col = ct * 16 + li;
-  const float bv = bias[col];
+  const int ch0 = ct * 16 + 4 * g;  // this lane's four output channels (operands swapped: channels are the tile rows)
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + ch0);
 
   uint4 v[C::IT2];
   auto stage_load = [&](int grp, int phase) {
@@ -867,7 +884,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict
     const uint8_t* tile = smem + buf * C::LDS_BYTES;
     f32x4 acc[C::RPW];  // starts at the bias
 #pragma unroll
-    for (int t = 0; t < C::RPW; ++t) acc[t] = f32x4{bv, bv, bv, bv};
+    for (int t = 0; t < C::RPW; ++t) acc[t] = bv;
     // A fragments run D (hi, lo) pairs ahead of the MFMAs that consume them, in a register ring over the
     // flattened (k-step, row tile) sequence: with two waves per SIMD nothing else hides the LDS latency.
     constexpr int TOT = C::KS * C::RPW, D = C::DEPTH;
@@ -889,9 +906,9 @@ __global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict
       const int slot = idx % D;
       const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[slot]);
       const bf16x8 xl = __builtin_bit_cast(bf16x8, al[slot]);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh[ks], acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl[ks], acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh[ks], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xl, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[ks], xh, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xh, acc[t], 0, 0, 0);
       if (idx + D < TOT) a_issue(idx + D, slot);
       __builtin_amdgcn_sched_barrier(0);  // keep the reads where they are (the scheduler sinks them to their use)
       // the other buffer was last read one group ago (barrier since): fill it while this group computes
@@ -915,22 +932,15 @@ __global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict
     uint8_t* spare = smem + 2 * C::LDS_BYTES + 2 * C::OUT_BYTES;  // rows past the group's last pixel land here
 #pragma unroll
     for (int t = 0; t < C::RPW; ++t) {
-      const int rt = rg + t * C::RG;
-#pragma unroll
-      for (int r = 0; r < 4; r += 2) {
-        const int m = rt * 16 + g * 4 + r;
-        const float v0 = acc[t][r], v1 = acc[t][r + 1];
-        uint8_t* rec0 = (m < C::M) ? otile + (size_t)m * (C::OC * 4) : spare;
-        uint8_t* rec1 = (m + 1 < C::M) ? otile + (size_t)(m + 1) * (C::OC * 4) : spare;
-        split_store_lds2(rec0, rec1, C::OC, col, v0 > 0.f ? v0 : 0.f, v1 > 0.f ? v1 : 0.f);
-      }
+      const int m = (rg + t * C::RG) * 16 + li;  // this lane's pixel of the tile
+      split_store_lds4((m < C::M) ? otile + (size_t)m * C::OROW : spare, C::OC, ch0, acc[t]);
     }
     __syncthreads();
     {
-      const uint4* src = reinterpret_cast<const uint4*>(otile);
       uint4* dst = reinterpret_cast<uint4*>(out + (size_t)n0 * C::P * (C::OC * 4));
       const int nv = mlim * (C::OC * 4 / 16);
-      for (int i = tid; i < nv; i += kThreads) dst[i] = src[i];
+      for (int i = tid; i < nv; i += kThreads)
+        dst[i] = *reinterpret_cast<const uint4*>(otile + (i >> 4) * C::OROW + (i & 15) * 16);
     }
     buf ^= 1;
   }
@@ -989,8 +999,9 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
       bl[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2 + 1) * 64]);
     }
   }
-  const int col1 = ct1 * 16 + li, col2 = ct2 * 16 + li;
-  const float bv1 = bias1[col1], bv2 = bias2[col2];
+  // operands swapped (weights as the A operand): a lane holds four consecutive channels of one pixel
+  const int ch1 = ct1 * 16 + 4 * g, ch2 = ct2 * 16 + 4 * g;
+  const f32x4 bv1 = *reinterpret_cast<const f32x4*>(bias1 + ch1), bv2 = *reinterpret_cast<const f32x4*>(bias2 + ch2);
   // conv1 A fragments: lane group g = plane, 8 consecutive pixels of image row 4*oy + ks (see conv1_persist)
   int a1base[F::RPW1], a1base2[F::RPW1];
 #pragma unroll
@@ -1037,7 +1048,7 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
   auto conv1_half = [&](int h) {
     f32x4 acc[F::RPW1];
 #pragma unroll
-    for (int t = 0; t < F::RPW1; ++t) acc[t] = f32x4{bv1, bv1, bv1, bv1};
+    for (int t = 0; t < F::RPW1; ++t) acc[t] = bv1;
     constexpr int TOT = C1::KS * F::RPW1;
     uint2 a0[F::D1], a1[F::D1];
     auto a_issue = [&](int idx, int slot) {
@@ -1064,10 +1075,10 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
         const int s0 = idx % F::D1, s1 = (idx + 1) % F::D1;
         const bf16x8 x0 = __builtin_bit_cast(bf16x8, make_uint4(a0[s0].x, a0[s0].y, a1[s0].x, a1[s0].y));
         const bf16x8 x1 = __builtin_bit_cast(bf16x8, make_uint4(a0[s1].x, a0[s1].y, a1[s1].x, a1[s1].y));
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, blo, acc[t], 0, 0, 0);
-        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, blo, acc[t + 1], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, bhi, acc[t], 0, 0, 0);
-        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, bhi, acc[t + 1], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo, x0, acc[t], 0, 0, 0);
+        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo, x1, acc[t + 1], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi, x0, acc[t], 0, 0, 0);
+        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi, x1, acc[t + 1], 0, 0, 0);
         if (idx + F::D1 < TOT) a_issue(idx + F::D1, s0);
         if (idx + 1 + F::D1 < TOT) a_issue(idx + 1 + F::D1, s1);
         __builtin_amdgcn_sched_barrier(0);
@@ -1081,16 +1092,10 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
     for (int t = 0; t < F::RPW1; ++t) {
       const int rt = rg1 + t * F::RG1;
       if (rt >= C1::RT) continue;  // (wave-uniform: a group's tiles past the 13th were only computed)
-      const int m0 = rt * 16 + g * 4;  // four consecutive pixels m0 .. m0 + 3 (m0 % 4 == 0: they share an image row)
-      const int P0 = hh * C1::HP + m0;
-      const int y = P0 / 20, x = P0 - y * 20;
-      uint8_t* rec = (m0 < C1::HP) ? t2 + (size_t)(y * C2::RQ + x * C2::Q) * 16 : spare;
-      const int step = (m0 < C1::HP) ? C2::Q * 16 : 0;
-#pragma unroll
-      for (int r = 0; r < 4; r += 2) {
-        const float v0 = acc[t][r], v1 = acc[t][r + 1];
-        split_store_lds2(rec + r * step, rec + (r + 1) * step, 32, col1, v0 > 0.f ? v0 : 0.f, v1 > 0.f ? v1 : 0.f);
-      }
+      const int m = rt * 16 + li;  // this lane's pixel of the tile
+      const int P = hh * C1::HP + m;
+      const int y = P / 20, x = P - y * 20;
+      split_store_lds4((m < C1::HP) ? t2 + (size_t)(y * C2::RQ + x * C2::Q) * 16 : spare, 32, ch1, acc[t]);
     }
   };
 
@@ -1119,7 +1124,7 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
     {
       f32x4 acc[C2::RPW];
 #pragma unroll
-      for (int t = 0; t < C2::RPW; ++t) acc[t] = f32x4{bv2, bv2, bv2, bv2};
+      for (int t = 0; t < C2::RPW; ++t) acc[t] = bv2;
       constexpr int TOT = C2::KS * C2::RPW, D = 3;
       uint4 ah[D], al[D];
       auto a_issue = [&](int idx, int slot) {
@@ -1138,9 +1143,9 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
         const int slot = idx % D;
         const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[slot]);
         const bf16x8 xl = __builtin_bit_cast(bf16x8, al[slot]);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh[ks], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl[ks], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh[ks], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[ks], xh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xh, acc[t], 0, 0, 0);
         if (idx + D < TOT) a_issue(idx + D, slot);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1148,23 +1153,16 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
       g_load(nn, 1);
 #pragma unroll
       for (int t = 0; t < C2::RPW; ++t) {
-        const int rt = rg2 + t * C2::RG;
-#pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-          const int m = rt * 16 + g * 4 + r;
-          const float v0 = acc[t][r], v1 = acc[t][r + 1];
-          uint8_t* rec0 = (m < C2::M) ? otile + (size_t)m * (C2::OC * 4) : spare;
-          uint8_t* rec1 = (m + 1 < C2::M) ? otile + (size_t)(m + 1) * (C2::OC * 4) : spare;
-          split_store_lds2(rec0, rec1, C2::OC, col2, v0 > 0.f ? v0 : 0.f, v1 > 0.f ? v1 : 0.f);
-        }
+        const int m = (rg2 + t * C2::RG) * 16 + li;
+        split_store_lds4((m < C2::M) ? otile + (size_t)m * C2::OROW : spare, C2::OC, ch2, acc[t]);
       }
     }
     __syncthreads();  // O complete, T1 ready, T2 free
     {
-      const uint4* src = reinterpret_cast<const uint4*>(otile);
       uint4* dst = reinterpret_cast<uint4*>(out + (size_t)n * C2::P * (C2::OC * 4));
       constexpr int nv = C2::P * (C2::OC * 4 / 16);
-      for (int i = tid; i < nv; i += kThreads) dst[i] = src[i];
+      for (int i = tid; i < nv; i += kThreads)
+        dst[i] = *reinterpret_cast<const uint4*>(otile + (i >> 4) * C2::OROW + (i & 15) * 16);
     }
   }
 }
