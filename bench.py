@@ -22,11 +22,17 @@ One STEP = what the reference does per env-step of every actor thread plus one l
       -> clip 40 -> RMSprop -> update_priority, hand-written HIP (csrc/learner.hip; RELA_BENCH_LEARNER=torch
       runs PyTorch autograd instead); actor weights re-published every 20 steps, target net every 2,500.
 
+Precision of the actor's trunk forwards: `--precision bf16x2` (default) runs them on split-bf16 MFMA (every operand
+as bf16 hi + lo, f32 accumulation, conv1 -> conv2 fused through LDS; Q within 2e-6 of the f32 path, DESIGN 4.3b);
+`--precision f32` is the exact f32-MFMA parity mode.  The learner step computes in f32 in both.
+
 Prints ONE JSON line (rank 0).  `value` = env-steps/s summed over ranks.  Extra keys carry the
 learner rate, the live roofline of the dominant kernel (HIP events around the heavy forward kernels
 inside the timed region; the full per-kernel table comes from an untimed pass), the HBM-side roofline
-of the replay insert, and the CPU baseline (the reference's own CPU-thread actor path from
-oracle/_ref when present, else the oracle's plain-C port).
+of the replay sample path and insert, two more timed regions of the same K steps -- `no_reuse` (all 4 forwards
+of the reference per tick) and `f32_mode` (actor nets in the f32 mode) -- and the CPU baseline (the
+reference's own CPU-thread actor path from oracle/_ref when present, else the oracle's plain-C port).
+`--algo r2d2` is the second line: config C4's per-GPU shape with the HIP R2D2 learner.
 """
 import argparse
 import ctypes as C
@@ -621,6 +627,29 @@ def main():
             dt4 = float(t.item())
         ms_4fwd = dt4 / args.steps * 1e3
         engine.set_reuse(True)
+    # Third timed region of the same K steps (N = 1 accounting, same bracketing): the actor nets in the exact f32
+    # parity mode, so the line carries the f32 rate next to the split-bf16 headline.
+    ms_f32 = None
+    if not ONLY and args.precision == "bf16x2":
+        online.set_precision("f32")
+        target.set_precision("f32")
+        for _ in range(min(args.warmup, 3)):
+            one_step()
+            step_idx[0] += 1
+        sync_all()
+        t5 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+            step_idx[0] += 1
+        sync_all()
+        dt5 = time.perf_counter() - t5
+        if world > 1:
+            t = torch.tensor([dt5], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt5 = float(t.item())
+        ms_f32 = dt5 / args.steps * 1e3
+        online.set_precision("bf16x2")
+        target.set_precision("bf16x2")
     st = replay.debug_state()
     assert st["dev_error"] == 0, "replay reported device error %d" % st["dev_error"]
 
@@ -710,8 +739,13 @@ def main():
                 "env_steps_per_s": ROWS * world / (ms_4fwd * 1e-3),
                 "note": "second timed region of the same K steps with the act-forward reuse off: the reference's "
                         "4 trunk forwards per env-step (SURVEY 8d: 74.8 MFLOP)"},
+            "f32_mode": None if ms_f32 is None else {
+                "steps": args.steps, "ms_per_step": ms_f32, "env_steps_per_s": ROWS * world / (ms_f32 * 1e-3),
+                "note": "third timed region of the same K steps with the actor nets in the exact f32 MFMA mode "
+                        "(--precision f32 makes it the headline)"},
             "forward_ms_per_6400": fwd_ms / max(fwd_cnt, 1),
-            "forward_tflops": sum(FLOP.values()) * ROWS / (max(fwd_ms, 1e-9) / max(fwd_cnt, 1) * 1e-3) / 1e12,
+            "forward_tflops": sum(v for k, v in FLOP.items() if k != "conv12_fused") * ROWS
+            / (max(fwd_ms, 1e-9) / max(fwd_cnt, 1) * 1e-3) / 1e12,
             "replay_sample_scan_ms": scan_ms / k_all,
             "kernels_ms_per_step": {k: v["total_ms"] / k_all for k, v in sorted(prof_all.items())},
             "kernels_ms_per_step_note": "untimed pass of %d steps with every kernel timed; the timed region times "
