@@ -312,6 +312,16 @@ class HipR2D2Learner:
 
         return dev_view(self._capi.lib.rela_r2d2_learner_stats_dev(self.h), (2,), torch.float32, self.device)
 
+    def flat_target(self):
+        """The target net's flat parameter buffer (same layout as flat()[0]) -- what a publish sends along."""
+        from .engine import dev_view
+
+        C, capi = self._C, self._capi
+        p, n = capi.LSTMNetParams(), C.c_int64()
+        capi.check(capi.lib.rela_r2d2_learner_params(self.h, None, C.byref(p)), "rela_r2d2_learner_params")
+        capi.check(capi.lib.rela_r2d2_learner_flat(self.h, None, None, C.byref(n)), "flat")
+        return dev_view(getattr(p, capi.LSTMNetParams._fields_[0][0]), (n.value,), torch.float32, self.device)
+
     def check(self):
         """Synchronises and raises if a grid barrier of the persistent recurrent kernels gave up since the last check."""
         stream = self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -383,6 +393,18 @@ def ffnet_flat_layout(num_action):
     csrc/learner.hip: rela_ffnet_params order, every segment padded to a multiple of 4 floats."""
     out, off = [], 0
     for key, shape in zip(FFNET_KEYS, HipApexLearner.SHAPES(num_action)):
+        n = 1
+        for d in shape:
+            n *= d
+        out.append((key, shape, off))
+        off += (n + 3) // 4 * 4
+    return out, off
+
+
+def lstmnet_flat_layout(num_action):
+    """As ffnet_flat_layout for the flat buffer of csrc/learner_r2d2.hip (rela_lstmnet_params order)."""
+    out, off = [], 0
+    for key, shape in zip(HipR2D2Learner.KEYS, HipR2D2Learner.SHAPES(num_action)):
         n = 1
         for d in shape:
             n *= d

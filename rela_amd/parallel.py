@@ -214,6 +214,16 @@ class FFPartition:
         self.replay.update_priority(p)
 
 
+def rnn_batch_namespace(fields):
+    """dict of gathered RNN fields (time-major) -> the RNNTransition-shaped namespace the R2D2 learners consume"""
+    from types import SimpleNamespace
+
+    return SimpleNamespace(
+        obs={"s": fields["s"], "eps": fields["eps"], "legal_move": fields["legal_move"]}, action={"a": fields["a"]},
+        reward=fields["reward"], terminal=fields["terminal"].bool(), bootstrap=fields["bootstrap"],
+        h0={"h0": fields["h0"], "c0": fields["c0"]}, seq_len=fields["seq_len"])
+
+
 def ff_batch_namespace(fields):
     """dict of gathered FF fields -> the FFTransition-shaped namespace the learners consume"""
     from types import SimpleNamespace

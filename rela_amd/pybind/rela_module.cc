@@ -472,6 +472,7 @@ class RNNPrioritizedReplay {
                       b.h0["h0"].data_ptr(), b.h0["c0"].data_ptr(), b.seqLen.data_ptr()};
     check(rela_replay_sample(h_, batchsize, rows, weight.data_ptr<float>(), torchCurrentStream(device_)),
           "RNNPrioritizedReplay.sample");
+    lastBatch_ = batchsize;
     const int want = parseDevice(device);
     if (want != device_) {
       const auto target = want < 0 ? torch::Device(torch::kCPU) : torch::Device(torch::kCUDA, (c10::DeviceIndex)want);
@@ -509,7 +510,11 @@ class RNNPrioritizedReplay {
   std::mutex m_;
   rela_replay* h_ = nullptr;
   int device_ = -1, numAction_ = 0, T_ = 0;
+  int lastBatch_ = 0;
   torch::Tensor keep_;
+
+ public:
+  std::tuple<torch::Tensor, torch::Tensor, int> lastSampleRaw_() { return lastSampleRaw(h_, device_, lastBatch_); }
 };
 
 // the actor side of a de-duplicating replay (RELA_REPLAY_DEDUP, see FFPrioritizedReplay::handle)
@@ -1220,7 +1225,8 @@ PYBIND11_MODULE(rela, m) {
       .def("size", &RNNPrioritizedReplay::size)
       .def("num_add", &RNNPrioritizedReplay::numAdd)
       .def("sample", &RNNPrioritizedReplay::sample)
-      .def("update_priority", &RNNPrioritizedReplay::updatePriority);
+      .def("update_priority", &RNNPrioritizedReplay::updatePriority)
+      .def("last_sample_raw", &RNNPrioritizedReplay::lastSampleRaw_);  // partition exchange only
 
   py::class_<Env, std::shared_ptr<Env>>(m, "Env");
 

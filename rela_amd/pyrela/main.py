@@ -190,11 +190,30 @@ class _RelaFFPartition:
         self.replay.update_priority(p.to(self.device))
 
 
+class _RelaRNNPartition:
+    """the `rela` module's RNNPrioritizedReplay (one slot = one sequence, time-major batches) as a partition"""
+
+    def __init__(self, replay, device):
+        self.replay, self.device = replay, device
+
+    def sample(self, n):
+        b, _ = self.replay.sample(n, self.device)
+        raw_w, part_sum, size = self.replay.last_sample_raw()
+        fields = {"s": b.obs["s"], "eps": b.obs["eps"], "legal_move": b.obs["legal_move"], "a": b.action["a"],
+                  "reward": b.reward, "terminal": b.terminal.to(torch.uint8), "bootstrap": b.bootstrap,
+                  "h0": b.h0["h0"], "c0": b.h0["c0"], "seq_len": b.seq_len}
+        return fields, raw_w, part_sum, size
+
+    def update_priority(self, p):
+        self.replay.update_priority(p.to(self.device))
+
+
 def _multi_worker(rank, world, args, port, results):
     import torch.distributed as dist
 
-    from rela_amd.learner import HipApexLearner, ffnet_flat_layout
-    from rela_amd.parallel import PartitionedReplay, PartitionServer, ff_batch_namespace, ff_field_specs
+    from rela_amd.learner import HipApexLearner, HipR2D2Learner, ffnet_flat_layout, lstmnet_flat_layout
+    from rela_amd.parallel import (PartitionedReplay, PartitionServer, ff_batch_namespace, ff_field_specs,
+                                   rnn_batch_namespace, rnn_field_specs)
 
     act_devices = args.act_device.split(",")
     G = len(act_devices)
@@ -209,12 +228,21 @@ def _multi_worker(rank, world, args, port, results):
     exch_device = exch or my_device
     torch.manual_seed(args.seed + 2)  # identical initial weights on every rank
     num_action = create_env.get_num_action(args.game)
-    agent = ApexAgent(lambda: AtariFFNet(num_action), args.multi_step, args.gamma).to(my_device)
-    specs = ff_field_specs(num_action)
-    layout, total = ffnet_flat_layout(num_action)
+    r2d2 = args.algo == "r2d2"
+    if r2d2:  # BASELINE C4: sequence replay partitions, LSTM nets (pyrela/main.py:98-109)
+        agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, num_action), my_device, args.multi_step, args.gamma, args.eta,
+                          args.seq_len, args.seq_burn_in, args.same_hid).to(my_device)
+        specs = rnn_field_specs(num_action, args.seq_burn_in + args.seq_len + args.multi_step)
+        layout, total = lstmnet_flat_layout(num_action)
+        to_namespace, learner_cls = rnn_batch_namespace, HipR2D2Learner
+    else:
+        agent = ApexAgent(lambda: AtariFFNet(num_action), args.multi_step, args.gamma).to(my_device)
+        specs = ff_field_specs(num_action)
+        layout, total = ffnet_flat_layout(num_action)
+        to_namespace, learner_cls = ff_batch_namespace, HipApexLearner
     assert args.batchsize % G == 0 and args.num_thread % G == 0
     if rank == 0:
-        learner = HipApexLearner.from_agent(agent, args.batchsize, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip)
+        learner = learner_cls.from_agent(agent, args.batchsize, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip)
         replay = PartitionedReplay(specs, args.batchsize, args.importance_exponent, exch_device)
         history = []
         for epoch in range(args.num_epoch):
@@ -227,7 +255,7 @@ def _multi_worker(rank, world, args, port, results):
                 if num_update % args.actor_sync_freq == 0:  # ONE broadcast per flat buffer instead of load_state_dict
                     replay.publish(learner.flat()[0].to(exch_device), learner.flat_target().to(exch_device))
                 fields, weight = replay.sample()
-                batch = ff_batch_namespace({k: v.to(my_device) for k, v in fields.items()})
+                batch = to_namespace({k: v.to(my_device) for k, v in fields.items()})
                 loss, priority = learner.step(batch, weight.to(my_device))
                 replay.update_priority(priority)
                 loss_sum += loss[0]
@@ -244,14 +272,18 @@ def _multi_worker(rank, world, args, port, results):
     else:
         g = rank - 1
         locker = rela.ModelLocker([agent, agent, agent], my_device)
-        part = rela.FFPrioritizedReplay(args.replay_buffer_size // G, args.seed + g, args.priority_exponent,
-                                        args.importance_exponent, args.prefetch)
+        part = (rela.RNNPrioritizedReplay if r2d2 else rela.FFPrioritizedReplay)(
+            args.replay_buffer_size // G, args.seed + g, args.priority_exponent, args.importance_exponent, args.prefetch)
         eps_all = utils.generate_eps(args.act_base_eps, args.act_eps_alpha, args.num_thread * args.num_game_per_thread)
         # the reference deals thread t to device t % G (main.py:155,166): this rank runs those threads
         threads = [t for t in range(args.num_thread) if t % G == g]
         K = args.num_game_per_thread
         eps = [e for t in threads for e in eps_all[t * K:(t + 1) * K]]
-        make_actor = lambda i: rela.DQNActor(locker, args.multi_step, K, args.gamma, part)
+        if r2d2:
+            make_actor = lambda i: rela.R2D2Actor(locker, args.multi_step, K, args.gamma, args.seq_len, args.seq_burn_in,
+                                                  part)
+        else:
+            make_actor = lambda i: rela.DQNActor(locker, args.multi_step, K, args.gamma, part)
         context, games, actors = create_env.create_train_env(args.seed + 7919 * g, eps, args.episode_len, len(threads), K,
                                                              make_actor)
         context.start()
@@ -269,7 +301,8 @@ def _multi_worker(rank, world, args, port, results):
             agent.load_state_dict(sd)
             locker.update_model(agent)
 
-        srv = PartitionServer(_RelaFFPartition(part, my_device), specs, args.batchsize, args.importance_exponent,
+        srv = PartitionServer((_RelaRNNPartition if r2d2 else _RelaFFPartition)(part, my_device), specs, args.batchsize,
+                              args.importance_exponent,
                               exch_device, flat_sizes=(total, total), on_weights=on_weights)
         srv.serve_forever()
         counts = torch.tensor([float(utils.total_acts(actors)), float(part.num_add())], dtype=torch.float64,
@@ -294,8 +327,8 @@ def train_multi(args):
 
     import torch.multiprocessing as mp
 
-    if args.algo != "apex":
-        raise SystemExit("train_multi: --algo apex only (the R2D2 exchange uses the same classes with rnn_field_specs)")
+    if args.algo not in ("apex", "r2d2"):
+        raise SystemExit("--algo must be apex or r2d2")
     G = len(args.act_device.split(","))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

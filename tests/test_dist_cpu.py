@@ -4,6 +4,7 @@ single learner fed the concatenated batch."""
 import os
 import socket
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -189,7 +190,9 @@ class _OraclePartition:
         rc, ids, tags, w = self.o.sample(n)
         assert rc == 0
         fields = {"tag": torch.from_numpy(tags.copy()),
-                  "payload": torch.from_numpy(np.stack([tags * 0.5, tags * 0.25, tags + 1.0], 1).astype(np.float32))}
+                  "payload": torch.from_numpy(np.stack([tags * 0.5, tags * 0.25, tags + 1.0], 1).astype(np.float32)),
+                  # a TIME-MAJOR field [T, n] as RNNTransition.makeBatch builds them (rela/types.cc:140-182)
+                  "seq": torch.from_numpy(np.stack([tags + 10.0 * t for t in range(4)], 0).astype(np.float32))}
         return fields, torch.from_numpy(self.o.last_raw_w(n)), float(np.float32(st["sum"])), st["size"]
 
     def update_priority(self, p):
@@ -203,7 +206,8 @@ def _exchange_worker(rank, world, port, out):
     from rela_amd.learner import ffnet_flat_layout
     from rela_amd.parallel import FieldSpec, PartitionedReplay, PartitionServer
 
-    specs = [FieldSpec("tag", (), torch.int64), FieldSpec("payload", (3,), torch.float32)]
+    specs = [FieldSpec("tag", (), torch.int64), FieldSpec("payload", (3,), torch.float32),
+             FieldSpec("seq", (4,), torch.float32, batch_dim=1)]
     _, total = ffnet_flat_layout(18)  # the flat buffers HipApexLearner publishes (online, target)
     if rank == 0:
         rep = PartitionedReplay(specs, _EX["batch"], _EX["beta"], "cpu")
@@ -217,7 +221,7 @@ def _exchange_worker(rank, world, port, out):
                 pass
             prio = (fields["tag"] % 7).float() * 0.3 + 0.1 + r
             rounds.append(dict(tag=fields["tag"].tolist(), payload=fields["payload"].tolist(), w=w.tolist(),
-                               prio=prio.tolist()))
+                               prio=prio.tolist(), seq=fields["seq"].tolist()))
             rep.update_priority(prio)
             if r == 1:
                 rep.publish(torch.arange(total, dtype=torch.float32), torch.arange(total, dtype=torch.float32) * 2)
@@ -272,6 +276,8 @@ def test_partitioned_replay_exchange_over_three_ranks():
         assert rec["tag"] == exp_tags.tolist(), "round %d: rows are not the partitions' own B/G samples" % r
         np.testing.assert_array_equal(np.array(rec["payload"], np.float32),
                                       np.stack([exp_tags * 0.5, exp_tags * 0.25, exp_tags + 1.0], 1).astype(np.float32))
+        np.testing.assert_array_equal(np.array(rec["seq"], np.float32),  # gathered along the batch axis of [T, B]
+                                      np.stack([exp_tags + 10.0 * t for t in range(4)], 0).astype(np.float32))
         # prioritized_replay.h:320-322 over the union: N and sum are the totals, the maximum is global
         tot_sum, tot_n = np.float64(sums[0]) + np.float64(sums[1]), float(sizes[0] + sizes[1])
         w = (np.float32(tot_n) * (np.concatenate(raw) / np.float32(tot_sum))) ** np.float32(-_EX["beta"])
@@ -286,3 +292,16 @@ def test_partitioned_replay_exchange_over_three_ranks():
         from rela_amd.learner import ffnet_flat_layout
 
         assert got == [(12345.0, 24690.0, ffnet_flat_layout(18)[1])]
+
+
+def test_lstmnet_flat_layout_matches_the_r2d2_learner_buffer():
+    """The flat buffer the R2D2 learner publishes to actor-only ranks: rela_lstmnet_params order, 4-float padding."""
+    from rela_amd.learner import HipR2D2Learner, lstmnet_flat_layout
+
+    layout, total = lstmnet_flat_layout(18)
+    assert [k for k, _, _ in layout] == list(HipR2D2Learner.KEYS)
+    sizes = [int(np.prod(s)) if len(s) else 1 for _, s, _ in layout]
+    assert sizes[6] == 2048 * 3136 and sizes[7] == 2048 * 512 and sizes[12] == 18 * 512
+    offs = [o for _, _, o in layout]
+    assert all(o % 4 == 0 for o in offs) and offs == [sum((n + 3) // 4 * 4 for n in sizes[:i]) for i in range(14)]
+    assert total == sum((n + 3) // 4 * 4 for n in sizes)

@@ -460,8 +460,10 @@ def test_benchmark_driver_tiny_grid(mods, capsys, algo):
         assert without > 0 and with_ > 0
 
 
-def test_multi_process_layout_rehearsal_on_one_gpu():
-    """The reference's multi-GPU layout (pyrela/main.py:131-166: act devices next to one learner device) as
+@pytest.mark.parametrize("algo", ["apex", "r2d2"])
+def test_multi_process_layout_rehearsal_on_one_gpu(algo):
+    """(apex = BASELINE C3's layout, r2d2 = C4's: sequence replay partitions, LSTM nets, HIP R2D2 learner.)
+    The reference's multi-GPU layout (pyrela/main.py:131-166: act devices next to one learner device) as
     one process per GPU (rela_amd/pyrela/main.py:train_multi, rela_amd/parallel.py), rehearsed with all three
     ranks on cuda:0 over gloo: two actor processes with their replay partitions and C++ actor threads, one
     learner process sampling B/G from each, gathering the rows, scattering the priorities and publishing the
@@ -474,6 +476,9 @@ def test_multi_process_layout_rehearsal_on_one_gpu():
            "--act_device", "cuda:0,cuda:0", "--num_thread", "4", "--num_game_per_thread", "4", "--batchsize", "32",
            "--epoch_len", "10", "--num_epoch", "2", "--burn_in_frames", "64", "--replay_buffer_size", "1024",
            "--episode_len", "25", "--actor_sync_freq", "5"]
+    if algo == "r2d2":
+        cmd += ["--algo", "r2d2", "--seq_len", "10", "--seq_burn_in", "4", "--batchsize", "8", "--replay_buffer_size",
+                "256", "--burn_in_frames", "16", "--epoch_len", "6"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     last = [l for l in out.stdout.splitlines() if l.startswith("{'history'")][-1]
