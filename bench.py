@@ -715,8 +715,8 @@ def main():
             "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f32 results from split-bf16 MFMA (bf16 hi+lo operands, 3 products, "
-                                                           "f32 accumulate; |dQ| < 1e-6 vs the f32 path)",
+            "dtype": "f32" if args.precision == "f32" else "f32 results from split-bf16 MFMA (bf16 hi+lo operands, 2-3 bf16 "
+                                                           "products per product, f32 accumulate; |dQ| < 2e-6 vs the f32 path)",
             "data": "synthetic",
             "config": {"workload": "Ape-X DQN, 80 threads x 80 games (6400 envs) per GPU, actor+learner on one "
                                    "MI355X, replay 2^20 per GPU device-resident, A=18, n=3, ONE learner batch of 512 per "

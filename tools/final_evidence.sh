@@ -1,22 +1,26 @@
 #!/bin/bash
-# Round-end evidence pass on the GPU box.  Outputs under gpurun_out/final/ (copied to profiles/ by hand):
+# Round-end evidence pass on the GPU box (round 2).  Outputs under gpurun_out/final/ (copied to profiles/r02_* by hand):
 #   gpu_tests.log            full `pytest -m gpu`
-#   pmc_*/, pmc_table.md     one rocprofv3 --pmc pass per counter set over tools/profile_forward.py
-#   traffic.json             HBM bytes per launch from those passes (-> profiles/r01_traffic.json)
+#   pmc_*/, pmc_table.md     one rocprofv3 --pmc pass per counter set over tools/profile_forward.py (bf16x2 mode)
+#   traffic.json             HBM bytes per launch from those passes (-> profiles/r02_traffic.json)
 #   iso_stats/               rocprofv3 --kernel-trace --stats of the same isolated script
 #   bench.json               default `python bench.py` (with cpu_baseline; reads the traffic file)
 #   prof_bench/              rocprofv3 --kernel-trace --stats of bench.py
-#   forward_small_n.log      per-kernel forward timings at N = 80 / 512 / 6400
-#   threaded_benchmark.log   rela_amd/pyrela/benchmark.py, 64 threads x 100 envs, replay 2^21
-#   threaded_benchmark_r2d2.log  the same driver with --algo r2d2, 32 threads x 100 envs
-#   r2d2_actor_tick.json     tools/time_r2d2_tick.py, 3200 envs, seq 80 / burn 40 / n 3
+#   bench_r2d2.json          `python bench.py --algo r2d2`
+#   bench_dedup_2p23.json    `python bench.py --dedup plane --replay-cap 8388608` (BASELINE C5's replay on ONE GPU)
+#   forward_modes.log        per-kernel forward timings: N = 512 / 6400, f32 and bf16x2, fused and unfused conv1 -> conv2
+#   time_sample.json         tools/time_sample.py (isolated sample path, ring 1,310,720)
+#   r2d2_learner.log         tools/time_r2d2_learner.py (isolated R2D2 learner step, persistent vs per-step launches)
+#   threaded_benchmark*.log  rela_amd/pyrela/benchmark.py through the C++ actor threads
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
-timeout -k 10 900 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1 || { tail -5 $O/gpu_tests.log; exit 1; }
-tail -1 $O/gpu_tests.log
+if [ "${SKIP_TESTS:-0}" != "1" ]; then
+  timeout -k 10 1000 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1 || { tail -5 $O/gpu_tests.log; exit 1; }
+  tail -1 $O/gpu_tests.log
+fi
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/iso_stats -- python3 $R/tools/profile_forward.py > $O/iso_stats.log 2>&1 || exit 4
 echo "iso stats done"
@@ -28,20 +32,31 @@ timeout -k 10 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES 
 echo "pmc sq done"
 cd $R
 python tools/pmc_table.py $O $O/traffic.json > $O/pmc_table.md || exit 8
-cp $O/traffic.json $R/profiles/r01_traffic.json
+cp $O/traffic.json $R/profiles/r02_traffic.json
 cat $O/pmc_table.md
 timeout -k 10 600 python bench.py > $O/bench.json 2> $O/bench.err || { tail -5 $O/bench.err; exit 2; }
-cat $O/bench.json
+cut -c1-600 $O/bench.json
 cd /tmp
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_prof.json 2> $O/bench_prof.err || exit 3
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python3 $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline > $O/bench_prof.json 2> $O/bench_prof.err || exit 3
 echo "bench prof done"
 cd $R
-for n in 80 512 6400; do TAG=N=$n N=$n timeout -k 10 120 python tools/time_forward.py 2>&1 | grep conv2; done > $O/forward_small_n.log
-cat $O/forward_small_n.log
+timeout -k 10 400 python bench.py --algo r2d2 --no-cpu-baseline > $O/bench_r2d2.json 2> $O/bench_r2d2.err || { tail -5 $O/bench_r2d2.err; exit 12; }
+cut -c1-400 $O/bench_r2d2.json
+timeout -k 10 600 python bench.py --dedup plane --replay-cap 8388608 --steps 300 --no-cpu-baseline > $O/bench_dedup_2p23.json 2> $O/bench_dedup_2p23.err || { tail -5 $O/bench_dedup_2p23.err; exit 13; }
+cut -c1-400 $O/bench_dedup_2p23.json
+{
+  for n in 512 6400; do TAG="N=$n f32" N=$n PRECISION=f32 timeout -k 10 120 python tools/time_forward.py 2>&1 | tail -1; done
+  for n in 1024 6400; do TAG="N=$n bf16x2 fused" N=$n PRECISION=bf16x2 timeout -k 10 120 python tools/time_forward.py 2>&1 | tail -1; done
+  TAG="N=6400 bf16x2 separate conv1, conv2" RELA_FUSE12=0 N=6400 PRECISION=bf16x2 timeout -k 10 120 python tools/time_forward.py 2>&1 | tail -1
+  TAG="N=6400 bf16x2 fused, layer-specialised waves" RELA_FUSE12=2 N=6400 PRECISION=bf16x2 timeout -k 10 120 python tools/time_forward.py 2>&1 | tail -1
+} > $O/forward_modes.log
+cat $O/forward_modes.log
+timeout -k 10 300 python tools/time_sample.py > $O/time_sample.json 2> $O/time_sample.err || exit 14
+tail -2 $O/time_sample.json | cut -c1-400
+{ TAG=persistent timeout -k 10 200 python tools/time_r2d2_learner.py 2>&1 | tail -1; RELA_R2D2_REC=steps TAG=per-step timeout -k 10 200 python tools/time_r2d2_learner.py 2>&1 | tail -1; } > $O/r2d2_learner.log
+cut -c1-300 $O/r2d2_learner.log
 timeout -k 10 400 python rela_amd/pyrela/benchmark.py --grid 64x100 --epoch_sec 1.5 --num_epoch 4 --replay_buffer_size 2097152 --burn_in_frames 20000 > $O/threaded_benchmark.log 2>&1 || { tail -5 $O/threaded_benchmark.log; exit 9; }
 tail -4 $O/threaded_benchmark.log
 timeout -k 10 300 python rela_amd/pyrela/benchmark.py --algo r2d2 --grid 32x100 --epoch_sec 2 --num_epoch 4 --replay_buffer_size 8192 --burn_in_frames 200 --episode_len 400 > $O/threaded_benchmark_r2d2.log 2>&1 || { tail -5 $O/threaded_benchmark_r2d2.log; exit 11; }
 tail -3 $O/threaded_benchmark_r2d2.log
-ROWS=3200 TICKS=260 timeout -k 10 300 python tools/time_r2d2_tick.py 2> $O/r2d2_actor_tick.err | tail -1 > $O/r2d2_actor_tick.json || exit 10
-cut -c1-300 $O/r2d2_actor_tick.json
 find $O -name "*.csv" -size +8M -delete

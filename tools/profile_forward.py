@@ -21,6 +21,7 @@ from synth import synth_params
 N, A, ITERS = 6400, 18, int(os.environ.get("ITERS", "10"))
 net = FFNetHandle(A, "cuda:0")
 net.load_state_dict({k: torch.from_numpy(v) for k, v in synth_params(A, 1).items()})
+net.set_precision(os.environ.get("PRECISION", "bf16x2"))  # bench.py's default; PRECISION=f32 for the parity mode
 s = torch.randint(0, 256, (N, 4, 84, 84), dtype=torch.uint8, device="cuda")
 legal = torch.ones((N, A), device="cuda")
 q = torch.empty((N, A), device="cuda")
