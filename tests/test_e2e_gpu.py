@@ -485,3 +485,23 @@ def test_multi_process_layout_rehearsal_on_one_gpu(algo):
     res = ast.literal_eval(last)
     assert len(res["history"]) == 2 and all(np.isfinite(h["loss"]) for h in res["history"])
     assert res["act"] > 0 and res["buffer_add"] > 0
+
+
+def test_rccl_collectives_single_rank():
+    """The collectives of the N > 1 paths (flat gradient all-reduce of HipApexLearner, the IS-weight normalisation,
+    the flat weight broadcast) on a one-rank RCCL communicator, on the device buffers those paths use: RCCL itself
+    runs on this GPU (more ranks need more GPUs; the multi-rank logic is covered over gloo)."""
+    import socket
+    import subprocess
+
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                                                       "rccl_single_rank_child.py"), str(port)],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["backend"] == "nccl" and rec["same_grad"] and rec["bcast_same"] and rec["isw_err"] < 1e-6, rec
