@@ -47,6 +47,7 @@ struct FFNetDev {
   // split-bf16 fast path: [ct][ks][hi, lo][lane] x 8 bf16 (see "Split-bf16" below)
   uint4 *B2f = nullptr, *B3f = nullptr, *Bff = nullptr;
   uint4* B1p = nullptr;  // conv1 frags as B1, k-steps plane-major (conv1_persist)
+  float* Bhp = nullptr;  // heads weights [ct 2][wave 4][j 32][lane 64] in the k order of heads_duel
 };
 
 namespace {
@@ -1800,6 +1801,69 @@ __global__ void dueling_kernel(const float* __restrict__ ha, const float* __rest
     for (int j = 0; j < A; ++j) q[(size_t)n * A + j] = (v + la[j]) - mean;
 }
 
+// Heads + dueling in ONE launch (AtariFFNet): [N, 512] x [512, 32] (fc_a in columns 0..A-1, fc_v in column 31) and
+// q = v + a*legal - mean_A(a*legal) (net.py:33-39).  The two separate launches (a 4-block-wide GEMM and a
+// one-thread-per-row kernel) cost 18 + 10 us at N = 6,400 and 17 + 9 us at N = 512 for 0.2 GFLOP: launch and latency,
+// not work.  Block = 16 rows, 4 waves; wave w multiplies the k-slice [128w, 128w + 128) on v_mfma_f32_16x16x4_f32 (a
+// lane reads 32 CONTIGUOUS floats of its row: k-step j of lane group g is k = 128w + 32g + j, the weights are packed
+// in that order by pack_heads_perm), the four partial tiles meet in LDS, then 16 threads per row finish the row.
+constexpr int kHeadRows = 16;
+__global__ void pack_heads_perm(const float* __restrict__ a_w, const float* __restrict__ v_w, int A,
+                                float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // [ct 2][w 4][j 32][lane 64]
+  if (idx >= 2 * 4 * 32 * 64) return;
+  const int lane = idx & 63, j = (idx >> 6) & 31, w = (idx >> 11) & 3, ct = idx >> 13;
+  const int k = 128 * w + 32 * (lane >> 4) + j, col = ct * 16 + (lane & 15);
+  out[idx] = col < A ? a_w[(size_t)col * 512 + k] : (col == 31 ? v_w[k] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void heads_duel(const float* __restrict__ h, const float* __restrict__ Bhp,
+                                                  const float* __restrict__ bias, const float* __restrict__ legal,
+                                                  float* __restrict__ ha, float* __restrict__ q, int N, int A) {
+  __shared__ float part[4][kHeadRows][33];
+  __shared__ float hs[kHeadRows][33];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int row0 = blockIdx.x * kHeadRows;
+  float av[32];
+  {
+    const int row = min(row0 + li, N - 1);
+    const float4* hp = reinterpret_cast<const float4*>(h + (size_t)row * 512 + 128 * wave + 32 * g);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float4 v = hp[c];
+      av[4 * c] = v.x, av[4 * c + 1] = v.y, av[4 * c + 2] = v.z, av[4 * c + 3] = v.w;
+    }
+  }
+  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const float* bp = Bhp + ((size_t)(ct * 4 + wave) * 32) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bp[j * 64], acc[ct], 0, 0, 0);
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][4 * g + r][ct * 16 + li] = acc[ct][r];
+  __syncthreads();
+  const int r = tid >> 4, c = tid & 15, row = row0 + r;
+#pragma unroll
+  for (int hcol = 0; hcol < 2; ++hcol) {
+    const int col = c + 16 * hcol;
+    hs[r][col] = ((part[0][r][col] + part[1][r][col]) + (part[2][r][col] + part[3][r][col])) + bias[col];
+  }
+  __syncthreads();
+  if (row >= N) return;
+  if (ha) ha[(size_t)row * 32 + c] = hs[r][c], ha[(size_t)row * 32 + c + 16] = hs[r][c + 16];
+  const float* lg = legal + (size_t)row * A;
+  float sum = 0.f;  // in column order, as the one-thread-per-row kernel summed it
+  for (int j = 0; j < A; ++j) sum += hs[r][j] * lg[j];
+  const float mean = sum / (float)A, v = hs[r][31];
+  if (c < A) q[(size_t)row * A + c] = (v + hs[r][c] * lg[c]) - mean;
+  if (c + 16 < A) q[(size_t)row * A + c + 16] = (v + hs[r][c + 16] * lg[c + 16]) - mean;
+}
+
 // ---- weight packing (load_state_dict time) ------------------------------------------------
 // ---- fc forward for small batches --------------------------------------------------------------
 // Below kFcSplitBelow rows gemm_mfma<GemmFc> launches fewer than 128 blocks, each walking all 98
@@ -1962,6 +2026,7 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
   RELA_HIP(hipMalloc(&d.Bh, sizeof(float) * 2 * 128 * 64));
   RELA_HIP(hipMalloc(&d.bh, sizeof(float) * 32));
   RELA_HIP(hipMalloc(&d.B1p, sizeof(uint4) * Conv1B::FRAG_UINT4));
+  RELA_HIP(hipMalloc(&d.Bhp, sizeof(float) * 2 * 4 * 32 * 64));
   RELA_HIP(hipMalloc(&d.B2f, sizeof(uint4) * Conv2F::CT * Conv2F::KS * 2 * 64));
   RELA_HIP(hipMalloc(&d.B3f, sizeof(uint4) * Conv3F::CT * Conv3F::KS * 2 * 64));
   RELA_HIP(hipMalloc(&d.Bff, sizeof(uint4) * 32 * FcFast::KS * 2 * 64));
@@ -1999,7 +2064,7 @@ extern "C" void rela_ffnet_destroy(rela_ffnet* n) {
   DeviceGuard g(n->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bf, n->d.bf, n->d.Bh, n->d.bh,
-                n->d.BfT, n->d.B2f, n->d.B3f, n->d.Bff, n->d.B1p};
+                n->d.BfT, n->d.B2f, n->d.B3f, n->d.Bff, n->d.B1p, n->d.Bhp};
   for (void* p : ps) (void)hipFree(p);
   (void)hipFree(n->pipe_tmo);
   delete n;
@@ -2073,6 +2138,7 @@ extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on
   pack(kPackFc, dv[6], nullptr, n->d.Bf, 32, 784);
   hipLaunchKernelGGL(pack_fc_t, dim3(ceil_div(3136 * 512, 256)), dim3(256), 0, s, dv[6], n->d.BfT);
   pack(kPackHeads, dv[10], dv[8], n->d.Bh, 2, 128);
+  hipLaunchKernelGGL(pack_heads_perm, dim3(ceil_div(2 * 4 * 32 * 64, 256)), dim3(256), 0, s, dv[10], dv[8], A, n->d.Bhp);
   auto pack_fast = [&](int mode, const float* w, uint4* frag, int CT, int KS) {
     const int64_t total = (int64_t)CT * KS * 64 * 8;
     hipLaunchKernelGGL(pack_frags_bf16s, dim3(ceil_div(total, 256)), dim3(256), 0, s, mode, w,
@@ -2186,14 +2252,8 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
   }
   {
     ProfScope prof(names[4], s);
-    hipLaunchKernelGGL(gemm_mfma<GemmHeads>, dim3(GemmHeads::CT / GemmHeads::CTB, ceil_div(N, GemmHeads::BM)),
-                       dim3(kThreads), 0, s, (const float*)h, (const float*)nullptr, (const float*)d.Bh,
-                       (const float*)d.bh, ha, (const float*)nullptr, (float*)nullptr, N);
-  }
-  {
-    ProfScope prof(names[5], s);
-    hipLaunchKernelGGL(dueling_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, s, (const float*)ha, legal_dev, q_dev,
-                       (float*)nullptr, N, n->num_action);
+    hipLaunchKernelGGL(heads_duel, dim3(ceil_div(N, kHeadRows)), dim3(256), 0, s, (const float*)h, (const float*)d.Bhp,
+                       (const float*)d.bh, legal_dev, ha, q_dev, N, n->num_action);
   }
   RELA_LAUNCH_CHECK();
   return RELA_OK;
