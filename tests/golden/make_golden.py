@@ -120,6 +120,16 @@ def replay_cases():
     save("replay_tiny_sum_clamp", s, run("replay_kat", s))
 
 
+def replay_cases_r2():
+    """alpha = 0.9 (R2D2's priority exponent, ref_run_r2d2.sh) and block sizes that mix ATen's vectorised and
+    scalar-tail pow inside one call (40 = 32 + 8; batches of 24 are all tail)."""
+    replay_kat("replay_kat_a09_b06_seed5", 32, 5, 0.9, 0.6, 8, 3)
+    replay_random("replay_wrap_evict_a09", 64, 777, 0.9, 0.6, 8, 16, 40, 2, p_uniform, 7)
+    replay_random("replay_lograng_a09", 2048, 99, 0.9, 0.6, 64, 256, 14, 4, p_loguniform, 8)
+    replay_random("replay_mixed_tail_a09", 512, 31, 0.9, 0.4, 24, 40, 30, 3, p_uniform, 9)
+    replay_random("replay_mixed_tail_a06", 512, 32, 0.6, 0.4, 40, 72, 20, 2, p_loguniform, 10)
+
+
 # ------------------------------------------------------------------ n-step cases
 def nstep_cases():
     for n, gamma, seed in [(1, 0.99, 11), (3, 0.997, 12), (5, 0.997, 13), (3, 0.5, 14)]:
@@ -457,6 +467,8 @@ if __name__ == "__main__":
         e2e_cases("CFG_SLIDING", "e2e_lockstep_apex_sliding")
     if "replay" in which:
         replay_cases()
+    if "replay_r2" in which:
+        replay_cases_r2()
     if "nstep" in which:
         nstep_cases()
     if "ffnet" in which:

@@ -91,7 +91,7 @@ def test_golden_bookkeeping_bit_exact(path):
         assert [f2h(x) for x in got["w"]] == exp["w"]
 
 
-@pytest.mark.parametrize("path", [p for p in cases("replay_") if "_a06" in p], ids=os.path.basename)
+@pytest.mark.parametrize("path", [p for p in cases("replay_") if "_a06" in p or "_a09" in p], ids=os.path.basename)
 def test_golden_device_pow(path):
     """alpha != 1 end to end with the device's restatement of ATen's pow (rela/prioritized_replay.h:188,239 ->
     SLEEF Sleef_powf_u10 for the vector lanes, double pow for the tail lanes of each K-element add): the
