@@ -1473,6 +1473,316 @@ __global__ __launch_bounds__(kThreads) void conv12_pipe(const uint8_t* __restric
   }
 }
 
+// conv1 -> conv2 with the waves specialised by KIND OF WORK: waves 0-3 ("MFMA waves", one per SIMD) only read
+// fragments and issue MFMAs -- conv1 on both half frames, then conv2 -- and hand their raw f32 accumulator tiles over
+// through LDS; waves 4-7 ("service waves", the second wave of every SIMD) do everything else: u8 -> bf16 conversion
+// into T1, bias-less ReLU + hi/lo split of the dumped tiles into T2 (conv1) or straight to HBM (conv2).  In the
+// symmetric kernel both waves of a SIMD run the same phase at the same time, so the ~2,900 VALU instructions per
+// frame of the non-MFMA phases (4 cycles of issue each, twice per SIMD) are paid on top of the MFMA time; here the
+// service wave's VALU issue overlaps the MFMA wave's asynchronous matrix work (an MFMA holds the issue port for 8
+// of its 16 cycles).
+//   LDS = T1 half-frame image (30 KB) | T2 conv2 input (59 KB) | accumulator dump, 26 tiles x 1 KB | conv1 weight
+//         fragments (32 KB) | spare record | counters.
+//   MFMA wave w: conv1 channel tile w & 1, row tiles (w >> 1) + 2t of each half; conv2 channel tile w, all six row
+//   tiles (128 weight registers).  Hand-offs are monotone LDS counters (bounded spins, `*tmo` on give-up).
+// Measured (N = 6,400): 251 us against 218 us for the symmetric kernel: opt-in (RELA_FUSE12=3).  In-kernel stamps of an
+// MFMA wave, per frame: conv1 5.1 k cycles (23 per MFMA: its weight fragments come from LDS too), conv2 5.05 k (17.5
+// per MFMA, the instruction's rate), and 7.7 k cycles WAITING -- for T2 (the service waves' split of the second half:
+// 2.4 k), for the dump to be consumed (1.8 k), for T1 refills (1.7 k), dumps and polls (1.8 k).  With ONE T1, ONE T2
+// and ONE dump region (LDS holds no second copy of any of them) the two kinds of waves depend on each other phase by
+// phase, and the chain of hand-offs costs more than the VALU work it takes off the MFMA waves.
+struct Conv12S {
+  using C1 = Conv1P;
+  using C2 = Conv2F;
+  static constexpr int RPW1 = 7, RG1 = 2, D1 = 4, D2 = 3;
+  static constexpr int T1_BYTES = C1::TILE_BYTES, T2_BYTES = C2::LDS_BYTES;
+  static constexpr int UNITS1 = C1::RT * 2, UNITS2 = C2::RT * C2::CT;  // 26, 24 accumulator tiles per phase
+  static constexpr int DUMP_BYTES = UNITS1 * 1024;
+  static constexpr int B1_UINT4 = 2 * 2 * C1::KS * 64;
+  static constexpr int LDS_TOTAL = T1_BYTES + T2_BYTES + DUMP_BYTES + B1_UINT4 * 16 + 256 + 64;
+  static_assert(LDS_TOTAL <= 160 * 1024 && UNITS2 <= UNITS1, "LDS budget");
+  static constexpr int STHREADS = 256;
+  static constexpr int IT = (C1::V16 + STHREADS - 1) / STHREADS;  // 4
+};
+
+__global__ __launch_bounds__(kThreads) void conv12_ms(const uint8_t* __restrict__ in, const uint4* __restrict__ B1frag,
+                                                      const float* __restrict__ bias1,
+                                                      const uint4* __restrict__ B2frag,
+                                                      const float* __restrict__ bias2, uint8_t* __restrict__ out,
+                                                      int N, unsigned* tmo) {
+  using F = Conv12S;
+  using C1 = Conv1P;
+  using C2 = Conv2F;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* t1 = smem;
+  uint8_t* t2 = smem + F::T1_BYTES;
+  uint4* dump = reinterpret_cast<uint4*>(t2 + F::T2_BYTES);  // [unit][lane] f32x4
+  uint4* b1s = dump + F::UNITS1 * 64;
+  uint8_t* spare = reinterpret_cast<uint8_t*>(b1s + F::B1_UINT4);
+  unsigned* flags = reinterpret_cast<unsigned*>(spare + 256);
+  unsigned *t1_ready = flags, *t1_free = flags + 1, *dfull = flags + 2, *dfree = flags + 3, *t2_ready = flags + 4,
+           *t2_free = flags + 5, *dead = flags + 6;
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  if (tid < 16) flags[tid] = 0;
+  for (int i = tid; i < F::B1_UINT4; i += kThreads) b1s[i] = B1frag[i];
+  __syncthreads();
+  if ((int)blockIdx.x >= N) return;
+  const int nframes = (N - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
+
+  if (wave < 4) {
+    // ============================ MFMA waves ============================
+    const int ct1 = wave & 1, rg1 = wave >> 1, ct2 = wave;
+    bf16x8 bh[C2::KS], bl[C2::KS];
+    {
+      const uint4* bp = B2frag + (size_t)ct2 * C2::KS * 2 * 64 + lane;
+#pragma unroll
+      for (int ks = 0; ks < C2::KS; ++ks) {
+        bh[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2) * 64]);
+        bl[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2 + 1) * 64]);
+      }
+    }
+    int a1base[F::RPW1], a1base2[F::RPW1];
+#pragma unroll
+    for (int t = 0; t < F::RPW1; ++t) {
+      const int rt = min(rg1 + t * F::RG1, C1::RT - 1);
+      const int m = min(rt * 16 + li, C1::HP - 1);
+      const int oy = m / 20, ox = m - oy * 20;
+      a1base[t] = g * C1::PLANE_BYTES + (4 * oy * 84 + 4 * ox) * 2;
+      a1base2[t] = a1base[t] + 8;
+      asm volatile("" : "+v"(a1base2[t]));  // keeps the two 8-byte reads apart (ds_read2_b64 is half rate)
+    }
+    constexpr int RT2 = C2::RT;
+    int a2base[RT2];
+#pragma unroll
+    for (int t = 0; t < RT2; ++t) {
+      const int m = t * 16 + li;
+      const int mm = (m < C2::M) ? m : 0;
+      const int oy = mm / C2::OW, ox = mm - oy * C2::OW;
+      a2base[t] = (oy * C2::STRIDE * C2::RQ + ox * C2::STRIDE * C2::Q + g) * 16;
+    }
+#pragma unroll
+    for (int ks = 0; ks < C2::KS; ++ks) {
+      pin_loaded(bh[ks]);
+      pin_loaded(bl[ks]);
+    }
+    auto conv1_half = [&](f32x4 (&acc)[F::RPW1]) {
+#pragma unroll
+      for (int t = 0; t < F::RPW1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      constexpr int TOT = C1::KS * F::RPW1;
+      uint2 a0[F::D1], a1[F::D1];
+      auto a_issue = [&](int idx, int slot) {
+        const int ks = idx / F::RPW1, t = idx - ks * F::RPW1;
+        a0[slot] = *reinterpret_cast<const uint2*>(t1 + a1base[t] + ks * 168);
+        a1[slot] = *reinterpret_cast<const uint2*>(t1 + a1base2[t] + ks * 168);
+      };
+      auto frag = [&](int slot) {
+        return __builtin_bit_cast(bf16x8, make_uint4(a0[slot].x, a0[slot].y, a1[slot].x, a1[slot].y));
+      };
+      uint4 wlo[2], whi[2];
+      auto w_issue = [&](int ks, int slot) {
+        whi[slot] = b1s[((0 * 2 + ct1) * C1::KS + ks) * 64 + lane];
+        wlo[slot] = b1s[((1 * 2 + ct1) * C1::KS + ks) * 64 + lane];
+      };
+      w_issue(0, 0);
+#pragma unroll
+      for (int i = 0; i < F::D1; ++i) a_issue(i, i);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < C1::KS; ++ks) {
+        if (ks + 1 < C1::KS) w_issue(ks + 1, (ks + 1) & 1);
+        const bf16x8 blo = __builtin_bit_cast(bf16x8, wlo[ks & 1]), bhi = __builtin_bit_cast(bf16x8, whi[ks & 1]);
+#pragma unroll
+        for (int t = 0; t + 1 < F::RPW1; t += 2) {
+          const int idx = ks * F::RPW1 + t;
+          const int s0 = idx % F::D1, s1 = (idx + 1) % F::D1;
+          const bf16x8 x0 = frag(s0), x1 = frag(s1);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo, x0, acc[t], 0, 0, 0);
+          acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo, x1, acc[t + 1], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi, x0, acc[t], 0, 0, 0);
+          acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi, x1, acc[t + 1], 0, 0, 0);
+          if (idx + F::D1 < TOT) a_issue(idx + F::D1, s0);
+          if (idx + 1 + F::D1 < TOT) a_issue(idx + 1 + F::D1, s1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+          const int t = F::RPW1 - 1, idx = ks * F::RPW1 + t, s0 = idx % F::D1;
+          const bf16x8 x0 = frag(s0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo, x0, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi, x0, acc[t], 0, 0, 0);
+          if (idx + F::D1 < TOT) a_issue(idx + F::D1, s0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    constexpr int LO = C2::CIN * 2;
+    for (int k = 0; k < nframes; ++k) {
+      const unsigned uk = (unsigned)k;
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        if (!lds_wait_ge(t1_ready, 4u * (2u * uk + 1u + h), dead, tmo, 11)) return;
+        f32x4 acc[F::RPW1];
+        conv1_half(acc);
+        lds_signal(t1_free);
+        if (!lds_wait_ge(dfree, 4u * (3u * uk + h), dead, tmo, 12)) return;
+#pragma unroll
+        for (int t = 0; t < F::RPW1; ++t) {
+          const int rt = rg1 + t * F::RG1;
+          if (rt < C1::RT) dump[(rt * 2 + ct1) * 64 + lane] = __builtin_bit_cast(uint4, acc[t]);
+        }
+        lds_signal(dfull);
+      }
+      if (!lds_wait_ge(t2_ready, 4u * (uk + 1u), dead, tmo, 13)) return;
+      {
+        f32x4 acc[RT2];
+#pragma unroll
+        for (int t = 0; t < RT2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int TOT = C2::KS * RT2, D = F::D2;
+        uint4 ah[D], al[D];
+        auto a_issue = [&](int idx, int slot) {
+          const int ks = idx / RT2, t = idx - ks * RT2;
+          const int kh = ks / C2::KW, kw = ks - kh * C2::KW;
+          const uint8_t* ap = t2 + a2base[t] + (kh * C2::RQ + kw * C2::Q) * 16;
+          ah[slot] = *reinterpret_cast<const uint4*>(ap);
+          al[slot] = *reinterpret_cast<const uint4*>(ap + LO);
+        };
+#pragma unroll
+        for (int i = 0; i < D; ++i) a_issue(i, i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int idx = 0; idx < TOT; ++idx) {
+          const int ks = idx / RT2, t = idx - ks * RT2;
+          const int slot = idx % D;
+          const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[slot]);
+          const bf16x8 xl = __builtin_bit_cast(bf16x8, al[slot]);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[ks], xh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xh, acc[t], 0, 0, 0);
+          if (idx + D < TOT) a_issue(idx + D, slot);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        lds_signal(t2_free);
+        if (!lds_wait_ge(dfree, 4u * (3u * uk + 2u), dead, tmo, 14)) return;
+#pragma unroll
+        for (int t = 0; t < RT2; ++t) dump[(t * C2::CT + ct2) * 64 + lane] = __builtin_bit_cast(uint4, acc[t]);
+        lds_signal(dfull);
+      }
+    }
+  } else {
+    // ============================ service waves ============================
+    const int stid = tid - 256, sw = wave - 4;
+    uint4 st[F::IT];
+    auto g_load = [&](int n, int h) {
+      const uint8_t* src = in + (size_t)n * C1::IN_ELEMS + h * (40 * 84);
+#pragma unroll
+      for (int j = 0; j < F::IT; ++j) {
+        const int i = min(stid + j * F::STHREADS, C1::V16 - 1);
+        const int pl = i / C1::PV16, r = i - pl * C1::PV16;
+        st[j] = *reinterpret_cast<const uint4*>(src + pl * C1::PLANE_ELEMS + r * 16);
+      }
+    };
+    uint4 cv[F::IT][2];  // the converted chunks wait in registers for T1 to be free
+    auto convert = [&]() {
+#pragma unroll
+      for (int j = 0; j < F::IT; ++j) {
+        cv[j][0] = u8x8_to_bf16x8(st[j].x, st[j].y);
+        cv[j][1] = u8x8_to_bf16x8(st[j].z, st[j].w);
+      }
+    };
+    auto store_t1 = [&]() {
+#pragma unroll
+      for (int j = 0; j < F::IT; ++j) {
+        const int i = min(stid + j * F::STHREADS, C1::V16 - 1);
+        const int pl = i / C1::PV16, r = i - pl * C1::PV16;
+        uint4* dst = reinterpret_cast<uint4*>(t1 + pl * C1::PLANE_BYTES + r * 32);
+        dst[0] = cv[j][0];
+        dst[1] = cv[j][1];
+      }
+    };
+    // biases of this lane's four channels 4g .. 4g+3 in every channel tile (kept in registers: a global load per
+    // dumped tile put its latency into every hand-off)
+    f32x4 bias1v[2], bias2v[C2::CT];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) bias1v[c] = *reinterpret_cast<const f32x4*>(bias1 + c * 16 + 4 * g);
+#pragma unroll
+    for (int c = 0; c < C2::CT; ++c) bias2v[c] = *reinterpret_cast<const f32x4*>(bias2 + c * 16 + 4 * g);
+    constexpr int UPW1 = (F::UNITS1 + 3) / 4, UPW2 = F::UNITS2 / 4;  // dumped tiles per service wave and phase: 7, 6
+    int n = blockIdx.x;
+    g_load(n, 0);
+    convert();
+    store_t1();
+    lds_signal(t1_ready);
+    g_load(n, 1);
+    for (int k = 0; k < nframes; ++k, n += gridDim.x) {
+      const unsigned uk = (unsigned)k;
+      const bool more = k + 1 < nframes;
+      const int nn = more ? n + (int)gridDim.x : n;
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        // T1 <- the other half (h = 0: half 1 of this frame; h = 1: half 0 of the next frame)
+        convert();
+        if (h == 0 || more) g_load(nn, h == 0 ? 0 : 1);  // (re-reads its own frame at the very end: harmless)
+        if (!lds_wait_ge(t1_free, 4u * (2u * uk + 1u + h), dead, tmo, 21)) return;
+        if (h == 0 || more) {
+          store_t1();
+          lds_signal(t1_ready);
+        }
+        // conv1's dumped tiles of half h -> split records in T2
+        if (!lds_wait_ge(dfull, 4u * (3u * uk + 1u + h), dead, tmo, 22)) return;
+        if (h == 0 && !lds_wait_ge(t2_free, 4u * uk, dead, tmo, 23)) return;
+        {
+          f32x4 tv[UPW1];  // all of this wave's tiles are read before the first is used
+#pragma unroll
+          for (int i = 0; i < UPW1; ++i) tv[i] = __builtin_bit_cast(f32x4, dump[min(sw + 4 * i, F::UNITS1 - 1) * 64 + lane]);
+#pragma unroll
+          for (int i = 0; i < UPW1; ++i) {
+            const int u = sw + 4 * i;
+            if (u >= F::UNITS1) break;  // wave-uniform
+            const int rt = u >> 1, ct = u & 1;  // (sw + 4 i) & 1 == sw & 1: the channel tile is fixed per wave
+            const int m = rt * 16 + li;
+            const int P = h * C1::HP + m;
+            const int y = P / 20, x = P - y * 20;
+            split_store_lds4((m < C1::HP) ? t2 + (size_t)(y * C2::RQ + x * C2::Q) * 16 : spare, 32, ct * 16 + 4 * g,
+                             tv[i] + bias1v[sw & 1]);
+          }
+        }
+        lds_signal(dfree);
+        if (h == 1) lds_signal(t2_ready);
+      }
+      // conv2's dumped tiles -> ReLU + split -> HBM (8 bytes of hi and 8 of lo per lane)
+      if (!lds_wait_ge(dfull, 4u * (3u * uk + 3u), dead, tmo, 24)) return;
+      uint8_t* orow = out + (size_t)n * C2::P * (C2::OC * 4);
+      f32x4 tv2[UPW2];
+#pragma unroll
+      for (int i = 0; i < UPW2; ++i) tv2[i] = __builtin_bit_cast(f32x4, dump[(sw + 4 * i) * 64 + lane]);
+#pragma unroll
+      for (int i = 0; i < UPW2; ++i) {
+        const int u = sw + 4 * i;
+        const int rt = u / C2::CT, ct = sw;  // u % 4 == sw
+        const int m = rt * 16 + li;
+        f32x4 bsel = bias2v[0];
+#pragma unroll
+        for (int c = 1; c < C2::CT; ++c) bsel = (sw == c) ? bias2v[c] : bsel;
+        const f32x4 v = tv2[i] + bsel;
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+        typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+        const f32x2_ a = {v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f}, b = {v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
+        const bf16x2_ ha = __builtin_convertvector(a, bf16x2_), hb = __builtin_convertvector(b, bf16x2_);
+        const bf16x2_ la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2_), bf16x2_);
+        const bf16x2_ lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2_), bf16x2_);
+        if (m < C2::M) {
+          uint8_t* rec = orow + (size_t)m * (C2::OC * 4) + (ct * 16 + 4 * g) * 2;
+          *reinterpret_cast<uint2*>(rec) = make_uint2(__builtin_bit_cast(uint32_t, ha), __builtin_bit_cast(uint32_t, hb));
+          *reinterpret_cast<uint2*>(rec + C2::OC * 2) =
+              make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
+        }
+      }
+      lds_signal(dfree);
+    }
+  }
+}
+
 // fc on split records: out[N][512] = relu(A x W + b), A = a3 records [N][49][hi 64 | lo 64], k = pos*64 + c.
 // Block = BM rows x 128 columns (8 waves, one 16-column tile each).  A arrives per position (256 B per row) through
 // registers into a THREE-deep LDS ring (row stride 288 B: conflict-free ds_read_b128), loaded from HBM two
@@ -2043,6 +2353,8 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv12::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_pipe),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv12P::LDS_TOTAL));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_ms),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv12S::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv3F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv3F::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s<FcFast>),
@@ -2181,9 +2493,15 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
   if (n->precision == 1 && N >= kFastMinN) {
     // split-bf16 fast path: a1 / a2 / a3 hold split records (same bytes as the f32 tensors they replace)
     uint8_t *r1 = reinterpret_cast<uint8_t*>(a1), *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
-    // 0: separate conv1 / conv2 kernels, 1: fused, all waves symmetric (default), 2: fused, layer-specialised waves
+    // 0: separate conv1 / conv2 kernels, 1: fused, all waves symmetric (default), 2: fused, layer-specialised waves,
+    // 3: fused, MFMA waves + service waves
     static const int fuse_mode = getenv("RELA_FUSE12") ? atoi(getenv("RELA_FUSE12")) : 1;
-    if (fuse_mode == 2) {
+    if (fuse_mode == 3) {
+      ProfScope prof("conv12_fused", s);
+      hipLaunchKernelGGL(conv12_ms, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12S::LDS_TOTAL, s, s_dev,
+                         (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N,
+                         n->pipe_tmo);
+    } else if (fuse_mode == 2) {
       ProfScope prof("conv12_fused", s);
       hipLaunchKernelGGL(conv12_pipe, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12P::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N,

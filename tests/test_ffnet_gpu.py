@@ -197,7 +197,7 @@ def test_ffnet_fast_mode_within_stated_tolerance(N, record_property):
     net.close()
 
 
-@pytest.mark.parametrize("fuse", [0, 1, 2], ids=["separate", "fused", "fused-pipelined"])
+@pytest.mark.parametrize("fuse", [0, 1, 2, 3], ids=["separate", "fused", "fused-pipelined", "fused-mfma+service-waves"])
 def test_ffnet_fast_mode_fusion_variants(fuse):
     """The three forms of conv1 -> conv2 in the fast mode (separate kernels; fused with conv1's output kept in LDS,
     the default; fused with layer-specialised waves handing tiles over through LDS counters) give the same Q within
