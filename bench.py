@@ -443,6 +443,8 @@ def main():
     target.load_state_dict(agent.target_net.state_dict())
     online.set_precision(args.precision)
     target.set_precision(args.precision)
+    if hip_learner is not None:  # the two gradient-free forwards of td_err; the pass feeding the backward stays f32
+        hip_learner.set_precision(args.precision)
 
     replay = FFReplay(args.replay_cap, SEED + rank, ALPHA, BETA, 0, NUM_ACTION, device, dedup=args.dedup,
                       guard_units=(MULTI_STEP + 8) * ROWS)
@@ -633,6 +635,8 @@ def main():
     if not ONLY and args.precision == "bf16x2":
         online.set_precision("f32")
         target.set_precision("f32")
+        if hip_learner is not None:
+            hip_learner.set_precision("f32")
         for _ in range(min(args.warmup, 3)):
             one_step()
             step_idx[0] += 1
@@ -650,6 +654,8 @@ def main():
         ms_f32 = dt5 / args.steps * 1e3
         online.set_precision("bf16x2")
         target.set_precision("bf16x2")
+        if hip_learner is not None:
+            hip_learner.set_precision("bf16x2")
     st = replay.debug_state()
     assert st["dev_error"] == 0, "replay reported device error %d" % st["dev_error"]
 
@@ -724,6 +730,7 @@ def main():
                                    "frames: no env stepping and no H2D inside the timed region",
                        "envs_per_gpu": ROWS, "replay_capacity": args.replay_cap, "learner_batch": BATCH,
                        "learner_batch_per_gpu": B_LOCAL, "replay_dedup": args.dedup, "actor_precision": args.precision,
+                       "learner_precision": "f32; the two gradient-free forwards of td_err as the actors" ,
                        "replay_frame_bytes_per_transition": {None: 56448, "stack": 28224, "plane": 7056}[args.dedup],
                        "parallelism": ("actor-shards%d+replay-partitions+grad-allreduce" % world) if world > 1
                        else "single"},

@@ -422,6 +422,10 @@ int rela_apex_learner_load(rela_apex_learner* l, const rela_ffnet_params* online
                            const rela_ffnet_params* target, int params_on_device, void* stream);
 /* ApexAgent.sync_target_with_online  apex.py:26-27 */
 int rela_apex_learner_sync_target(rela_apex_learner* l, void* stream);
+/* Precision of the two gradient-free forwards of td_err (online and target net on next_obs, apex.py:38-42): 0 = exact
+ * f32 (default), 1 = split-bf16 MFMA trunk (rela_ffnet_set_precision).  The online(obs) pass, whose activations the
+ * backward pass reads, always runs in f32. */
+int rela_apex_learner_set_precision(rela_apex_learner* l, int mode);
 /* loss + backward on one sampled batch.  rows_dev: the ten FFTransition fields in the order
  * rela_replay_sample fills them; weight_dev f32[batch] = the IS weights.  Leaves the gradient of
  * mean(smooth_l1(td_err) * weight) in the flat gradient buffer, |td_err| in priority_dev

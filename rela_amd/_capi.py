@@ -138,6 +138,7 @@ _sig("rela_apex_learner_create", i32, [P(vp), i32, i32, i32, f32, i32, f32, f32,
 _sig("rela_apex_learner_destroy", None, [vp])
 _sig("rela_apex_learner_load", i32, [vp, P(FFNetParams), P(FFNetParams), i32, vp])
 _sig("rela_apex_learner_sync_target", i32, [vp, vp])
+_sig("rela_apex_learner_set_precision", i32, [vp, i32])
 _sig("rela_apex_learner_backward", i32, [vp, i32, P(vp), vp, vp, vp, vp])
 _sig("rela_apex_learner_apply", i32, [vp, vp])
 _sig("rela_apex_learner_params", i32, [vp, P(FFNetParams), P(FFNetParams)])

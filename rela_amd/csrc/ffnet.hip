@@ -800,7 +800,8 @@ struct ConvFastCfg {
   static constexpr int IT = (V16 + kThreads - 1) / kThreads, IT2 = (IT + 1) / 2;
   static_assert(REC / 16 <= Q, "pixel stride too small");
 };
-constexpr int kFastMinN = 1024;  // below this the launches are latency-bound and the f32 path (split-K fc) is as fast
+constexpr int kFastMinN = 1024;  // below this fc_bf16s has too few blocks and the f32 split-K fc is faster
+constexpr int kFastTrunkMinN = 128;  // from here up the split-bf16 convolutions beat the f32 ones
 // conv2: 20x20x32 -> 9x9x64, stride 2: 2*Q = 2, 2*RQ = 18 = 2 (mod 16)
 using Conv2F = ConvFastCfg<32, 20, 20, 4, 4, 2, 9, 9, 1, 9, 185, 20 * 185>;
 // conv3: 9x9x64 -> 7x7x64, stride 1: Q = 2, RQ = 14 (7 positions per row), SQ = 98 = 2 (mod 16)
@@ -2174,6 +2175,21 @@ __global__ __launch_bounds__(256) void heads_duel(const float* __restrict__ h, c
   if (c + 16 < A) q[(size_t)row * A + c + 16] = (v + hs[r][c + 16] * lg[c + 16]) - mean;
 }
 
+// a3 split records -> f32 in place (per pixel: 64 x bf16 hi | 64 x bf16 lo  ->  64 x f32; hi + lo is exact in f32).
+// One wave per pixel: all of its loads complete before its stores (same wave, program order).  Used where the trunk
+// runs on split-bf16 MFMA but the batch is too small for fc_bf16s and fc goes through the f32 split-K GEMM.
+__global__ void unsplit_records64(uint8_t* __restrict__ rec, int64_t pixels) {
+  const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= pixels) return;
+  const int c = threadIdx.x & 63;
+  uint8_t* r = rec + p * 256;
+  const uint16_t hi = reinterpret_cast<const uint16_t*>(r)[c], lo = reinterpret_cast<const uint16_t*>(r)[64 + c];
+  const float v = bf16_to_f32(hi) + bf16_to_f32(lo);
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  reinterpret_cast<float*>(r)[c] = v;
+}
+
 // ---- weight packing (load_state_dict time) ------------------------------------------------
 // ---- fc forward for small batches --------------------------------------------------------------
 // Below kFcSplitBelow rows gemm_mfma<GemmFc> launches fewer than 128 blocks, each walking all 98
@@ -2476,6 +2492,11 @@ extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on
 
 extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_dev, const float* legal_dev,
                                   float* q_dev, void* ws, int64_t ws_bytes, void* stream_) {
+  return rela_amd::ffnet_forward_mode(n, N, s_dev, legal_dev, q_dev, ws, ws_bytes, stream_, -1);
+}
+
+int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_dev, const float* legal_dev, float* q_dev,
+                                 void* ws, int64_t ws_bytes, void* stream_, int mode) {
   RELA_CHECK(n && n->loaded, RELA_ESTATE, "rela_ffnet_forward: parameters were never loaded");
   RELA_CHECK(N >= 1 && s_dev && legal_dev && q_dev && ws, RELA_EINVAL, "rela_ffnet_forward: bad arguments");
   RELA_CHECK(ws_bytes >= rela_ffnet_workspace_bytes(n, N), RELA_EINVAL,
@@ -2490,24 +2511,45 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
   float* ha = h + kH * N;
   const FFNetDev& d = n->d;
   const char* const* names = n->prof_names ? n->prof_names : kProfActor;
-  if (n->precision == 1 && N >= kFastMinN) {
+  const char* name12 = n->prof_names ? "learner_fwd_conv12" : "conv12_fused";  // conv1 -> conv2 in one launch
+  static const int fast_min_n = getenv("RELA_FAST_MIN_N") ? atoi(getenv("RELA_FAST_MIN_N")) : kFastMinN;
+  const int precision = mode < 0 ? n->precision : mode;
+  // Between kFastTrunkMinN and kFastMinN rows the convolutions still win on split-bf16 MFMA (N = 512: 39 us against
+  // 90 us in f32) but fc_bf16s has too few blocks (55 us against the 24 us of the f32 split-K GEMM): the trunk runs
+  // fast, a3 is turned back into f32 in place and fc takes the f32 path.
+  const bool fast_trunk_only = precision == 1 && N < fast_min_n && N >= kFastTrunkMinN;
+  if (fast_trunk_only) {
+    uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
+    {
+      ProfScope prof(name12, s);
+      hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
+                         (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
+    }
+    {
+      ProfScope prof(names[2], s);
+      hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
+                         Conv3F::LDS_TOTAL, s, (const uint8_t*)r2, (const uint4*)d.B3f, (const float*)d.b3, r3, N);
+      hipLaunchKernelGGL(unsplit_records64, dim3(ceil_div((int64_t)N * 49, 4)), dim3(256), 0, s, r3, (int64_t)N * 49);
+    }
+  }
+  if (precision == 1 && N >= fast_min_n) {
     // split-bf16 fast path: a1 / a2 / a3 hold split records (same bytes as the f32 tensors they replace)
     uint8_t *r1 = reinterpret_cast<uint8_t*>(a1), *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     // 0: separate conv1 / conv2 kernels, 1: fused, all waves symmetric (default), 2: fused, layer-specialised waves,
     // 3: fused, MFMA waves + service waves
     static const int fuse_mode = getenv("RELA_FUSE12") ? atoi(getenv("RELA_FUSE12")) : 1;
     if (fuse_mode == 3) {
-      ProfScope prof("conv12_fused", s);
+      ProfScope prof(name12, s);
       hipLaunchKernelGGL(conv12_ms, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12S::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N,
                          n->pipe_tmo);
     } else if (fuse_mode == 2) {
-      ProfScope prof("conv12_fused", s);
+      ProfScope prof(name12, s);
       hipLaunchKernelGGL(conv12_pipe, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12P::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N,
                          n->pipe_tmo);
     } else if (fuse_mode == 1) {
-      ProfScope prof("conv12_fused", s);
+      ProfScope prof(name12, s);
       hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
     } else {
@@ -2533,6 +2575,7 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
                          (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, h, N);
     }
   } else {
+  if (!fast_trunk_only) {
   {
     ProfScope prof(names[0], s);
     hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
@@ -2545,6 +2588,7 @@ extern "C" int rela_ffnet_forward(const rela_ffnet* n, int N, const uint8_t* s_d
   {
     ProfScope prof(names[2], s);
     launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
+  }
   }
   if (N < kFcSplitBelow) {
     const int splits = fc_splits(N);

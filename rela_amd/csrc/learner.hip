@@ -191,6 +191,13 @@ extern "C" int rela_apex_learner_load(rela_apex_learner* l, const rela_ffnet_par
   return RELA_OK;
 }
 
+extern "C" int rela_apex_learner_set_precision(rela_apex_learner* l, int mode) {
+  RELA_CHECK(l && (mode == 0 || mode == 1), RELA_EINVAL, "rela_apex_learner_set_precision: mode must be 0 or 1");
+  int rc = rela_ffnet_set_precision(l->online, mode);
+  if (rc != RELA_OK) return rc;
+  return rela_ffnet_set_precision(l->target, mode);
+}
+
 extern "C" int rela_apex_learner_sync_target(rela_apex_learner* l, void* stream_) {
   RELA_CHECK(l && l->loaded, RELA_ESTATE, "rela_apex_learner_sync_target: parameters were never loaded");
   hipStream_t s = (hipStream_t)stream_;
@@ -250,7 +257,7 @@ extern "C" int rela_apex_learner_backward(rela_apex_learner* l, int batch, const
   if (rc != RELA_OK) return rc;
   rc = rela_ffnet_forward(l->target, Bn, nobs, nlegal, q_nt, l->ws_tmp, l->ws_bytes, s);
   if (rc != RELA_OK) return rc;
-  rc = rela_ffnet_forward(l->online, Bn, obs, legal, q_on, l->ws_on, l->ws_bytes, s);
+  rc = ffnet_forward_mode(l->online, Bn, obs, legal, q_on, l->ws_on, l->ws_bytes, s, 0);  // f32: the backward reads a1..h
   if (rc != RELA_OK) return rc;
   rc = rela_apex_td_from_q(Bn, A, 0, q_on, q_no, q_nt, nlegal, act, reward, boot, l->gamma_n, l->td, priority_dev, s);
   if (rc != RELA_OK) return rc;

@@ -143,6 +143,12 @@ class HipApexLearner:
         return (dev_view(pp.value, (n.value,), torch.float32, self.device),
                 dev_view(gp.value, (n.value,), torch.float32, self.device))
 
+    def set_precision(self, mode):
+        """"f32" (default) or "bf16x2": the arithmetic of the two gradient-free forwards of td_err (the pass whose
+        activations feed the backward kernels stays f32)."""
+        self._capi.check(self._capi.lib.rela_apex_learner_set_precision(self.h, {"f32": 0, "bf16x2": 1}[mode]),
+                         "rela_apex_learner_set_precision")
+
     def flat_target(self):
         """The target net's flat parameter buffer (same layout as flat()[0]) -- what a publish sends along."""
         from .engine import dev_view

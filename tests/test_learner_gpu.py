@@ -81,6 +81,37 @@ def test_loss_priority_and_gradients_match_autograd(B, A):
     learner.close()
 
 
+@pytest.mark.parametrize("B", [512, 200, 64])
+def test_learner_fast_mode_within_stated_tolerance(B):
+    """set_precision("bf16x2"): the two gradient-free forwards of td_err (online and target net on next_obs) run their
+    conv trunk on split-bf16 MFMA (fc in f32 below 1,024 rows; below 128 rows everything stays f32); the pass whose
+    activations feed the backward stays f32.  Loss, priorities and every gradient tensor stay within the fast mode's
+    stated tolerance of the all-f32 step (|dQ| < 2e-6 moves a TD error by at most that)."""
+    import torch
+
+    from rela_amd.learner import HipApexLearner
+
+    A = 18
+    agent = make_agent(A, 7)
+    batch, w = make_batch(B, A, 23)
+    learner = HipApexLearner.from_agent(agent, B)
+    loss0, prio0 = learner.backward(batch, w)
+    loss0, prio0 = loss0.clone(), prio0.clone()
+    g0 = {k: v.clone() for k, v in learner.state_dict("grads").items()}
+    learner.set_precision("bf16x2")
+    loss1, prio1 = learner.backward(batch, w)
+    g1 = learner.state_dict("grads")
+    assert float((prio1 - prio0).abs().max()) < 5e-6
+    assert abs(float(loss1) - float(loss0)) < 5e-6 * max(1.0, abs(float(loss0)))
+    for key in HipApexLearner.KEYS:
+        scale = float(g0[key].abs().max()) + 1e-12
+        assert float((g1[key] - g0[key]).abs().max()) <= 1e-4 * scale, key  # d(Huber) can flip at |err| = 1 only
+    learner.set_precision("f32")
+    loss2, prio2 = learner.backward(batch, w)
+    assert torch.equal(prio2, prio0) and torch.equal(loss2, loss0)  # the parity mode is untouched by the switch
+    learner.close()
+
+
 @pytest.mark.parametrize("opt", ["rmsprop", "adam"])
 def test_clip_and_optimizer_match_torch_on_identical_gradients(opt):
     """clip_grad_norm_ + optimiser arithmetic in isolation: autograd's gradients are copied into the
