@@ -23,7 +23,11 @@ def get_num_action(game_name):
 
 
 def create_game(seed, eps, episode_len):
-    return synth_atari.SyntheticAtariEnv(seed, eps, NUM_ACTION, episode_len)
+    # RELA_SYNTH_SLIDING=1: Atari-like frame stacks (ONE new 84x84 plane per step, the first plane of an episode
+    # repeated four times: atari/game_state.h:53-82) instead of four fresh planes per step -- a quarter of the host
+    # work per env-step, and the stacks a de-duplicating replay (RELA_REPLAY_DEDUP=plane) expects
+    sliding = os.environ.get("RELA_SYNTH_SLIDING", "0") == "1"
+    return synth_atari.SyntheticAtariEnv(seed, eps, NUM_ACTION, episode_len, sliding)
 
 
 def create_train_env(seed, eps, episode_len, num_thread, num_game_per_thread, actor_creator):
