@@ -143,7 +143,7 @@ extern "C" int rela_apex_learner_create(rela_apex_learner** out, int num_action,
   RELA_HIP(hipMalloc(&l->d_a1, sizeof(float) * B * kA1));
   RELA_HIP(hipMalloc(&l->col, sizeof(float) * trunk_col_floats(B)));
   RELA_HIP(hipMalloc(&l->part, sizeof(float) * kTrunkPartFloats));
-  RELA_HIP(hipMalloc(&l->cpart, sizeof(float) * kColsumBlocks * 512));
+  RELA_HIP(hipMalloc(&l->cpart, sizeof(float) * kColsumBlocks * (32 + 512 + 64 + 64 + 32)));  // all five jobs
   RELA_HIP(hipMalloc(&l->s32, sizeof(float) * 32));
   RELA_HIP(hipMalloc(&l->npart, sizeof(double) * kNormBlocks));
   RELA_HIP(hipMalloc(&l->norm, sizeof(float) * 2));
@@ -273,7 +273,7 @@ extern "C" int rela_apex_learner_backward(rela_apex_learner* l, int batch, const
   float* Gm[12];  // gradient tensors in rela_ffnet_params order
   for (int i = 0; i < 12; ++i) Gm[i] = l->G + l->off[i];
 
-  auto colsum = [&](const float* src, int64_t rows, int C, float* out) { colsum_launch(src, rows, C, l->cpart, out, s); };
+  ColsumJobs sums;  // the five bias gradients: queued here, one launch pair at the end of trunk_backward
 
   // heads: d_h, dWh, db
   {
@@ -288,8 +288,7 @@ extern "C" int rela_apex_learner_backward(rela_apex_learner* l, int batch, const
     p.d_ha = l->d_ha, p.h = w.h, p.g_a_w = Gm[10], p.g_v_w = Gm[8], p.A = A;
     launch_gemm<TileW32>(p, 1, s, "learner_wgrad_heads");
   }
-  colsum(l->d_ha, Bn, 32, l->s32);
-  hipLaunchKernelGGL(head_bias_grad, dim3(1), dim3(32), 0, s, (const float*)l->s32, A, Gm[11], Gm[9]);
+  sums.add(l->d_ha, Bn, 32, l->s32);
   // fc: d_a3, dWfc, db
   {
     ProbFcDgrad p{};
@@ -303,13 +302,14 @@ extern "C" int rela_apex_learner_backward(rela_apex_learner* l, int batch, const
     p.d_h = l->d_h, p.a3 = w.a3, p.g_fc_w = Gm[6];
     launch_gemm<TileWfc>(p, 1, s, "learner_wgrad_fc");
   }
-  colsum(l->d_h, Bn, 512, Gm[7]);
+  sums.add(l->d_h, Bn, 512, Gm[7]);
   {
     TrunkBwd t{};
     t.Bn = Bn, t.obs = obs, t.a1 = w.a1, t.a2 = w.a2, t.d_a3 = l->d_a3, t.d_a2 = l->d_a2, t.d_a1 = l->d_a1;
     t.col = l->col, t.part = l->part, t.cpart = l->cpart, t.w2p = l->w2p, t.w3p = l->w3p;
     t.g_c1w = Gm[0], t.g_c1b = Gm[1], t.g_c2w = Gm[2], t.g_c2b = Gm[3], t.g_c3w = Gm[4], t.g_c3b = Gm[5];
-    trunk_backward(t, s);
+    trunk_backward(t, s, &sums);
+    hipLaunchKernelGGL(head_bias_grad, dim3(1), dim3(32), 0, s, (const float*)l->s32, A, Gm[11], Gm[9]);
   }
   RELA_LAUNCH_CHECK();
   return RELA_OK;

@@ -236,6 +236,60 @@ __global__ __launch_bounds__(kColsumBlocks) void colsum_final(const float* __res
   }
   if (threadIdx.x == 0) *reinterpret_cast<float4*>(out + cg * 4) = sm[0];
 }
+// several column sums in ONE launch pair (the five bias gradients of a learner step were ten ~7 us launches):
+// blockIdx.y selects the job; every job keeps the two-stage order of colsum_partial / colsum_final, so the results
+// are bit-identical to separate launches.
+constexpr int kMaxColsumJobs = 6;
+struct ColsumJobs {
+  const float* src[kMaxColsumJobs];
+  float* out[kMaxColsumJobs];
+  float* part[kMaxColsumJobs];  // kColsumBlocks * C floats each
+  int64_t rows[kMaxColsumJobs];
+  int C[kMaxColsumJobs];
+  int n = 0;
+  void add(const float* s, int64_t r, int c, float* o) { src[n] = s, rows[n] = r, C[n] = c, out[n] = o, ++n; }
+};
+__global__ __launch_bounds__(kLT) void colsum_partial_multi(ColsumJobs jobs) {
+  __shared__ float4 sm[kLT];
+  const int j = blockIdx.y;
+  const float* src = jobs.src[j];
+  const int64_t rows = jobs.rows[j];
+  const int C = jobs.C[j];
+  const int G = C / 4, L = kLT / G;
+  const int cg = threadIdx.x % G, rl = threadIdx.x / G;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
+  float4 s = zero4();
+  for (int64_t r = r0 + rl; r < r1; r += L) {
+    const float4 v = ld4(src + r * C + cg * 4);
+    s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0) {
+    for (int l = 1; l < L; ++l) {
+      const float4 v = sm[cg + l * G];
+      s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(jobs.part[j] + (size_t)blockIdx.x * C + cg * 4) = s;
+  }
+}
+__global__ __launch_bounds__(kColsumBlocks) void colsum_final_multi(ColsumJobs jobs) {
+  __shared__ float4 sm[kColsumBlocks];
+  const int j = blockIdx.y, cg = blockIdx.x, C = jobs.C[j];
+  if (cg >= C / 4) return;  // (whole block)
+  sm[threadIdx.x] = ld4(jobs.part[j] + (size_t)threadIdx.x * C + cg * 4);
+  __syncthreads();
+  for (int o = kColsumBlocks / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const float4 v = sm[threadIdx.x + o];
+      float4& d = sm[threadIdx.x];
+      d.x += v.x, d.y += v.y, d.z += v.z, d.w += v.w;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *reinterpret_cast<float4*>(jobs.out[j] + cg * 4) = sm[0];
+}
 __global__ void head_bias_grad(const float* __restrict__ s32, int A, float* __restrict__ g_a_b,
                                float* __restrict__ g_v_b) {
   const int k = threadIdx.x;
@@ -361,14 +415,33 @@ struct TrunkBwd {
   float *g_c1w, *g_c1b, *g_c2w, *g_c2b, *g_c3w, *g_c3b;  // gradients, state_dict layout
 };
 
+// all queued jobs in one launch pair; cpart must hold kColsumBlocks * (sum of the jobs' C) floats
+inline void colsum_multi_launch(ColsumJobs& jobs, float* cpart, hipStream_t s) {
+  if (jobs.n == 0) return;
+  int maxC = 0;
+  size_t off = 0;
+  for (int j = 0; j < jobs.n; ++j) {
+    jobs.part[j] = cpart + off;
+    off += (size_t)kColsumBlocks * jobs.C[j];
+    maxC = jobs.C[j] > maxC ? jobs.C[j] : maxC;
+  }
+  ProfScope prof("learner_colsum", s);
+  hipLaunchKernelGGL(colsum_partial_multi, dim3(kColsumBlocks, jobs.n), dim3(kLT), 0, s, jobs);
+  hipLaunchKernelGGL(colsum_final_multi, dim3(maxC / 4, jobs.n), dim3(kColsumBlocks), 0, s, jobs);
+}
+
 inline void colsum_launch(const float* src, int64_t rows, int C, float* cpart, float* out, hipStream_t s) {
   ProfScope prof("learner_colsum", s);
   hipLaunchKernelGGL(colsum_partial, dim3(kColsumBlocks), dim3(kLT), 0, s, src, rows, C, cpart);
   hipLaunchKernelGGL(colsum_final, dim3(C / 4), dim3(kColsumBlocks), 0, s, (const float*)cpart, C, out);
 }
 
-inline void trunk_backward(const TrunkBwd& t, hipStream_t s) {
+// `jobs`: the caller's pending column sums; the three bias gradients of the trunk are queued behind them and the
+// whole queue goes out in one launch pair at the end (t.cpart: kColsumBlocks * (sum of all queued C) floats)
+inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending = nullptr) {
   const int Bn = t.Bn;
+  ColsumJobs own;
+  ColsumJobs& jobs = pending ? *pending : own;
   {  // conv3: dW3, db3, d_a2
     ProbW3 p{};
     p.M = 64, p.N = 576, p.K = Bn * 49;
@@ -377,7 +450,7 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s) {
     hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 576, 256)), dim3(256), 0, s, (const float*)t.part, kSplitW3, 64,
                        576, kRedConv3, t.g_c3w);
   }
-  colsum_launch(t.d_a3, (int64_t)Bn * 49, 64, t.cpart, t.g_c3b, s);
+  jobs.add(t.d_a3, (int64_t)Bn * 49, 64, t.g_c3b);
   {
     ProbConvDgrad p{};
     p.M = Bn * 49, p.N = 576, p.K = 64;
@@ -395,7 +468,7 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s) {
     hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 512, 256)), dim3(256), 0, s, (const float*)t.part, kSplitW2, 64,
                        512, kRedConv2, t.g_c2w);
   }
-  colsum_launch(t.d_a2, (int64_t)Bn * 81, 64, t.cpart, t.g_c2b, s);
+  jobs.add(t.d_a2, (int64_t)Bn * 81, 64, t.g_c2b);
   {
     ProbConvDgrad p{};
     p.M = Bn * 81, p.N = 512, p.K = 64;
@@ -413,7 +486,8 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s) {
     hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(32 * 256, 256)), dim3(256), 0, s, (const float*)t.part, kSplitW1, 32,
                        256, kRedConv1, t.g_c1w);
   }
-  colsum_launch(t.d_a1, (int64_t)Bn * 400, 32, t.cpart, t.g_c1b, s);
+  jobs.add(t.d_a1, (int64_t)Bn * 400, 32, t.g_c1b);
+  colsum_multi_launch(jobs, t.cpart, s);
 }
 
 // ---- clip_grad_norm_ + optimiser over flat parameter / gradient / state buffers -------------------
