@@ -138,6 +138,47 @@ __global__ __launch_bounds__(kThreads) void replay_append_weights(const float* _
   if (threadIdx.x == 0) st->sum = dsum;
 }
 
+// The same append in two launches for large blocks (a batched actor shard inserts thousands of rows per tick): the
+// ATen-exact pow is the expensive part and is embarrassingly parallel, only the sums are ordered.
+// (1) any number of workgroups: w = pow(prio) into the ring and into a contiguous scratch copy;
+// (2) one workgroup: per reference block the FLOAT sum in row order (one thread per block), then thread 0 folds the
+//     block sums into the f64 sum_ in order -- exactly the arithmetic of replay_append_weights.
+__global__ void replay_append_pow(const float* __restrict__ prio, int n, float alpha, float* __restrict__ w, int ring,
+                                  int start, int group, float* __restrict__ tmp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int g = group > 0 ? group : n;
+  const int gi = i / g;
+  const int glen = min(g, n - gi * g);
+  const float v = pow_aten(prio[i], alpha, i - gi * g, glen);
+  tmp[i] = v;
+  w[(int)(((int64_t)start + i) % ring)] = v;
+}
+__global__ __launch_bounds__(kThreads) void replay_append_sums(const float* __restrict__ tmp, int n, int group,
+                                                               ReplayDevState* __restrict__ st) {
+  __shared__ float gsum[kThreads];
+  const int g = group > 0 ? group : n;
+  const int ng = (n + g - 1) / g;
+  double dsum = 0.0;
+  if (threadIdx.x == 0) dsum = st->sum;
+  for (int base = 0; base < ng; base += kThreads) {
+    const int j = base + threadIdx.x;
+    if (j < ng) {
+      const int lo = j * g, hi = min(lo + g, n);
+      float f = 0.f;
+      for (int i = lo; i < hi; ++i) f += tmp[i];
+      gsum[threadIdx.x] = f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int m = min(kThreads, ng - base);
+      for (int q = 0; q < m; ++q) dsum += (double)gsum[q];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) st->sum = dsum;
+}
+
 // copies n rows of one field into ring slots start.. (mod ring); 16-byte lanes when possible
 __global__ __launch_bounds__(kThreads) void replay_scatter_rows(const uint8_t* __restrict__ src,
                                                                 uint8_t* __restrict__ dst, int64_t row_bytes,
@@ -454,6 +495,8 @@ struct rela_replay {
   float* d_w = nullptr;
   uint8_t* d_evicted = nullptr;
   ReplayDevState* d_state = nullptr;
+  float* d_tmpw = nullptr;  // contiguous copy of the weights of the block being committed (two-launch append)
+  int tmpw_cap = 0;
   int32_t* d_ids = nullptr;
   float* d_raw_w = nullptr;
   float* d_targets = nullptr;
@@ -535,6 +578,7 @@ extern "C" void rela_replay_destroy(rela_replay* r) {
   (void)hipFree(r->d_w);
   (void)hipFree(r->d_evicted);
   (void)hipFree(r->d_state);
+  (void)hipFree(r->d_tmpw);
   (void)hipFree(r->d_ids);
   (void)hipFree(r->d_raw_w);
   (void)hipFree(r->d_targets);
@@ -779,7 +823,24 @@ extern "C" int rela_replay_commit_add_grouped(rela_replay* r, int first_slot, in
   if (r->safe_tail != first_slot) return RELA_EWOULDBLOCK;  // shut down while an earlier block never committed
   RELA_HIP(hipEventRecord(r->ev_in, producer));
   RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
-  {
+  // large grouped blocks (a batched shard's tick): parallel pow + ordered sums; the single-workgroup kernel otherwise
+  // (an ungrouped block is ONE float sum over all its rows: nothing to parallelise but the pow, and small blocks
+  // gain nothing from a second launch)
+  if (group_rows > 0 && n >= 1024) {
+    if (r->tmpw_cap < n) {
+      RELA_HIP(hipStreamSynchronize(r->stream));
+      (void)hipFree(r->d_tmpw);
+      r->d_tmpw = nullptr;
+      r->tmpw_cap = 0;
+      RELA_HIP(hipMalloc(&r->d_tmpw, sizeof(float) * (size_t)n));
+      r->tmpw_cap = n;
+    }
+    ProfScope prof("replay_append_weights", r->stream);
+    hipLaunchKernelGGL(replay_append_pow, dim3((n + 255) / 256), dim3(256), 0, r->stream, priority_dev, n, r->alpha,
+                       r->d_w, r->ring, first_slot, group_rows, r->d_tmpw);
+    hipLaunchKernelGGL(replay_append_sums, dim3(1), dim3(kThreads), 0, r->stream, (const float*)r->d_tmpw, n,
+                       group_rows, r->d_state);
+  } else {
     ProfScope prof("replay_append_weights", r->stream);
     hipLaunchKernelGGL(replay_append_weights, dim3(1), dim3(kThreads), 0, r->stream, priority_dev, n, r->alpha,
                        r->d_w, r->ring, first_slot, group_rows, r->d_state);

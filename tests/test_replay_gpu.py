@@ -396,3 +396,48 @@ def test_partitions_match_reference_replays_of_capacity_over_g():
             assert dev.state()["sum"] == ora.state()["sum"]
     for dev, _ in parts:
         dev.close()
+
+
+@pytest.mark.parametrize("n,group,alpha", [(6400, 80, 0.6), (4000, 100, 0.9), (2048, 40, 1.0), (1500, 64, 0.6)])
+def test_grouped_commit_of_a_large_block_matches_per_thread_adds(n, group, alpha):
+    """A batched actor shard commits the K-row blocks of all its threads in ONE call (rela_replay_commit_add_grouped):
+    every K rows are one reference `add` -- ATen's vector / scalar-tail pow rule per block, the block's FLOAT sum
+    in row order, sum_ += (double) block sum, in block order (prioritized_replay.h:57-73,188).  Large blocks take
+    the two-launch path (parallel pow, ordered sums); the result must equal the same rows added block by block
+    through the single-workgroup path, bit for bit (weights and f64 sum_)."""
+    import ctypes as C
+
+    import torch
+
+    from gpu_util import GpuReplay, capi, cur_stream, dev, ptr
+
+    rng = np.random.default_rng(n + group)
+    prio = rng.uniform(0.01, 3.0, n).astype(np.float32)
+    tags = np.arange(n, dtype=np.int64)
+    cap = 8192
+
+    def grouped():
+        rep = GpuReplay(cap, 3, alpha, 0.4)
+        t, p = dev(tags), dev(prio)
+        first = C.c_int(0)
+        capi.check(capi.lib.rela_replay_begin_add(rep.h, n, 1, C.byref(first)), "begin_add")
+        rows = (C.c_void_p * 1)(t.data_ptr())
+        capi.check(capi.lib.rela_replay_write_rows(rep.h, first.value, 0, n, rows, cur_stream()), "write_rows")
+        capi.check(capi.lib.rela_replay_commit_add_grouped(rep.h, first.value, n, group, ptr(p), cur_stream()), "commit")
+        torch.cuda.synchronize()
+        st, w = rep.state(), rep.weights()[0][:n].copy()
+        rep.close()
+        return st, w
+
+    def per_block():
+        rep = GpuReplay(cap, 3, alpha, 0.4)
+        for lo in range(0, n, group):
+            assert rep.add_tags(tags[lo:lo + group], prio[lo:lo + group]) == 0
+        torch.cuda.synchronize()
+        st, w = rep.state(), rep.weights()[0][:n].copy()
+        rep.close()
+        return st, w
+
+    (st_g, w_g), (st_b, w_b) = grouped(), per_block()
+    assert np.array_equal(w_g.view(np.uint32), w_b.view(np.uint32))
+    assert st_g["sum"] == st_b["sum"] and st_g["size"] == st_b["size"] == n
