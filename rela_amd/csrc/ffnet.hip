@@ -520,8 +520,7 @@ __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_floa
 // w == hi + mid + lo exactly for every finite fp32 weight (each residual is exact in fp32).
 // plane_major: k-step ks = kernel row ks of all four planes (lane group g = plane), the order conv1_persist reads
 // its LDS image in; otherwise k runs (c, kh, kw) linearly (conv1_bf16x3).
-__global__ void pack_conv1_bf16x3(const float* __restrict__ w, uint16_t* __restrict__ frag, int plane_major) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // [ct 2][ks 8][lane 64][j 8]
+__device__ __forceinline__ void pack_conv1_bf16x3_at(int idx, const float* __restrict__ w, uint16_t* __restrict__ frag, int plane_major) {
   if (idx >= 2 * 8 * 64 * 8) return;
   const int j = idx & 7, lane = (idx >> 3) & 63, ks = (idx >> 9) & 7, ct = idx >> 12;
   const int k = plane_major ? (lane >> 4) * 64 + ks * 8 + j : ks * 32 + (lane >> 4) * 8 + j;
@@ -536,6 +535,9 @@ __global__ void pack_conv1_bf16x3(const float* __restrict__ w, uint16_t* __restr
   frag[idx] = hi;
   frag[plane + idx] = mid;
   frag[2 * plane + idx] = lo;
+}
+__global__ void pack_conv1_bf16x3(const float* __restrict__ w, uint16_t* __restrict__ frag, int plane_major) {
+  pack_conv1_bf16x3_at((int)blockIdx.x * blockDim.x + threadIdx.x, w, frag, plane_major);
 }
 
 // =====================================================================================================
@@ -1925,8 +1927,7 @@ __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__
 
 // weights -> [ct][ks][hi, lo][lane] x 8 bf16 in MFMA 16x16x32 fragment order.  mode: kPackConv2 (k = tap*32 + c),
 // kPackConv3 (k = tap*64 + c), kPackFc (k = pos*64 + c  <-  torch flatten c*49 + pos)
-__global__ void pack_frags_bf16s(int mode, const float* __restrict__ w, uint16_t* __restrict__ frag, int CT, int KS) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // [ct][ks][lane][j]
+__device__ __forceinline__ void pack_frags_bf16s_at(int64_t idx, int mode, const float* __restrict__ w, uint16_t* __restrict__ frag, int CT, int KS) {
   if (idx >= (int64_t)CT * KS * 64 * 8) return;
   const int j = (int)(idx & 7), lane = (int)((idx >> 3) & 63);
   const int ks = (int)((idx >> 9) % KS), ct = (int)((idx >> 9) / KS);
@@ -1948,6 +1949,9 @@ __global__ void pack_frags_bf16s(int mode, const float* __restrict__ w, uint16_t
   const size_t base = (((size_t)ct * KS + ks) * 2) * 64 * 8;
   frag[base + (size_t)lane * 8 + j] = hi;
   frag[base + 64 * 8 + (size_t)lane * 8 + j] = lo;
+}
+__global__ void pack_frags_bf16s(int mode, const float* __restrict__ w, uint16_t* __restrict__ frag, int CT, int KS) {
+  pack_frags_bf16s_at((int64_t)blockIdx.x * blockDim.x + threadIdx.x, mode, w, frag, CT, KS);
 }
 
 // Dense layer  out[N][OC] = act(A[N][K] * W + bias)  on the same MFMA tiling.
@@ -2119,13 +2123,16 @@ __global__ void dueling_kernel(const float* __restrict__ ha, const float* __rest
 // lane reads 32 CONTIGUOUS floats of its row: k-step j of lane group g is k = 128w + 32g + j, the weights are packed
 // in that order by pack_heads_perm), the four partial tiles meet in LDS, then 16 threads per row finish the row.
 constexpr int kHeadRows = 16;
-__global__ void pack_heads_perm(const float* __restrict__ a_w, const float* __restrict__ v_w, int A,
+__device__ __forceinline__ void pack_heads_perm_at(int idx, const float* __restrict__ a_w, const float* __restrict__ v_w, int A,
                                 float* __restrict__ out) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // [ct 2][w 4][j 32][lane 64]
   if (idx >= 2 * 4 * 32 * 64) return;
   const int lane = idx & 63, j = (idx >> 6) & 31, w = (idx >> 11) & 3, ct = idx >> 13;
   const int k = 128 * w + 32 * (lane >> 4) + j, col = ct * 16 + (lane & 15);
   out[idx] = col < A ? a_w[(size_t)col * 512 + k] : (col == 31 ? v_w[k] : 0.f);
+}
+__global__ void pack_heads_perm(const float* __restrict__ a_w, const float* __restrict__ v_w, int A,
+                                float* __restrict__ out) {
+  pack_heads_perm_at((int)blockIdx.x * blockDim.x + threadIdx.x, a_w, v_w, A, out);
 }
 
 __global__ __launch_bounds__(256) void heads_duel(const float* __restrict__ h, const float* __restrict__ Bhp,
@@ -2231,19 +2238,20 @@ __global__ void fc_reduce(const float* __restrict__ part, int splits, int N, con
 }
 
 // wt[k = pos*64 + c][u] = linear.0.weight[u][c*49 + pos]   (net.py:49 flattens channel-first)
-__global__ void pack_fc_t(const float* __restrict__ w, float* __restrict__ wt) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void pack_fc_t_at(int idx, const float* __restrict__ w, float* __restrict__ wt) {
   if (idx >= 3136 * 512) return;
   const int k = idx >> 9, u = idx & 511;
   const int c = k & 63, pos = k >> 6;
   wt[idx] = w[(size_t)u * 3136 + c * 49 + pos];
 }
+__global__ void pack_fc_t(const float* __restrict__ w, float* __restrict__ wt) {
+  pack_fc_t_at((int)blockIdx.x * blockDim.x + threadIdx.x, w, wt);
+}
 
 enum PackMode { kPackConv1 = 0, kPackConv2 = 1, kPackConv3 = 2, kPackFc = 3, kPackHeads = 4, kPackLstm = 5 };
 
-__global__ void pack_frags(int mode, const float* __restrict__ w, const float* __restrict__ w2, int num_action,
+__device__ __forceinline__ void pack_frags_at(int64_t idx, int mode, const float* __restrict__ w, const float* __restrict__ w2, int num_action,
                            float* __restrict__ frag, int CT, int KS) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)CT * KS * 64;
   if (idx >= total) return;
   const int lane = (int)(idx & 63);
@@ -2290,6 +2298,10 @@ __global__ void pack_frags(int mode, const float* __restrict__ w, const float* _
   }
   frag[idx] = v;
 }
+__global__ void pack_frags(int mode, const float* __restrict__ w, const float* __restrict__ w2, int num_action,
+                           float* __restrict__ frag, int CT, int KS) {
+  pack_frags_at((int64_t)blockIdx.x * blockDim.x + threadIdx.x, mode, w, w2, num_action, frag, CT, KS);
+}
 
 __global__ void pack_lstm_bias(const float* __restrict__ bih, const float* __restrict__ bhh, float* __restrict__ out) {
   const int oc = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2302,6 +2314,49 @@ __global__ void pack_lstm_bias(const float* __restrict__ bih, const float* __res
 __global__ void pack_head_bias(const float* __restrict__ ab, const float* __restrict__ vb, int A, float* __restrict__ out) {
   const int j = threadIdx.x;
   if (j < 32) out[j] = j < A ? ab[j] : (j == 31 ? vb[0] : 0.f);
+}
+
+// Every kernel-layout copy of an AtariFFNet's weights in ONE launch (a learner re-packs after every optimiser step:
+// twelve pack kernels, four device copies and the head bias were seventeen launches).  A block finds its job in a
+// table of first-block indices; the job bodies are the *_at functions of the separate kernels.
+struct PackAllArgs {
+  const float* p[12];  // rela_ffnet_params order
+  uint16_t *B1, *B1p, *B2f, *B3f, *Bff;
+  float *B2, *B3, *Bf, *BfT, *Bh, *Bhp, *b1, *b2, *b3, *bf, *bh;
+  int A;
+  int first[14];  // first block of job j; first[13] = total
+};
+__global__ void pack_ffnet_all(PackAllArgs a) {
+  const int b = blockIdx.x;
+  int j = 0;
+  while (b >= a.first[j + 1]) ++j;
+  const int64_t idx = (int64_t)(b - a.first[j]) * 256 + threadIdx.x;
+  switch (j) {
+    case 0: pack_conv1_bf16x3_at((int)idx, a.p[0], a.B1, 0); break;
+    case 1: pack_conv1_bf16x3_at((int)idx, a.p[0], a.B1p, 1); break;
+    case 2: pack_frags_at(idx, kPackConv2, a.p[2], nullptr, a.A, a.B2, 4, 128); break;
+    case 3: pack_frags_at(idx, kPackConv3, a.p[4], nullptr, a.A, a.B3, 4, 144); break;
+    case 4: pack_frags_at(idx, kPackFc, a.p[6], nullptr, a.A, a.Bf, 32, 784); break;
+    case 5: pack_fc_t_at((int)idx, a.p[6], a.BfT); break;
+    case 6: pack_frags_at(idx, kPackHeads, a.p[10], a.p[8], a.A, a.Bh, 2, 128); break;
+    case 7: pack_heads_perm_at((int)idx, a.p[10], a.p[8], a.A, a.Bhp); break;
+    case 8: pack_frags_bf16s_at(idx, 1, a.p[2], a.B2f, Conv2F::CT, Conv2F::KS); break;
+    case 9: pack_frags_bf16s_at(idx, 2, a.p[4], a.B3f, Conv3F::CT, Conv3F::KS); break;
+    case 10: pack_frags_bf16s_at(idx, 3, a.p[6], a.Bff, 32, FcFast::KS); break;
+    case 11: {  // biases: conv1 32 | conv2 64 | conv3 64 | fc 512
+      const int i = (int)idx;
+      if (i < 32) a.b1[i] = a.p[1][i];
+      else if (i < 96) a.b2[i - 32] = a.p[3][i - 32];
+      else if (i < 160) a.b3[i - 96] = a.p[5][i - 96];
+      else if (i < 672) a.bf[i - 160] = a.p[7][i - 160];
+      break;
+    }
+    default: {  // head bias
+      const int i = (int)idx;
+      if (i < 32) a.bh[i] = i < a.A ? a.p[11][i] : (i == 31 ? a.p[9][0] : 0.f);
+      break;
+    }
+  }
 }
 
 }  // namespace
@@ -2453,33 +2508,22 @@ extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on
       off += cnt[i];
     }
   }
-  auto pack = [&](int mode, const float* w, const float* w2, float* frag, int CT, int KS) {
-    const int64_t total = (int64_t)CT * KS * 64;
-    hipLaunchKernelGGL(pack_frags, dim3(ceil_div(total, 256)), dim3(256), 0, s, mode, w, w2, A, frag, CT, KS);
-  };
-  hipLaunchKernelGGL(pack_conv1_bf16x3, dim3(ceil_div(2 * 8 * 64 * 8, 256)), dim3(256), 0, s, dv[0],
-                     reinterpret_cast<uint16_t*>(n->d.B1), 0);
-  hipLaunchKernelGGL(pack_conv1_bf16x3, dim3(ceil_div(2 * 8 * 64 * 8, 256)), dim3(256), 0, s, dv[0],
-                     reinterpret_cast<uint16_t*>(n->d.B1p), 1);
-  pack(kPackConv2, dv[2], nullptr, n->d.B2, 4, 128);
-  pack(kPackConv3, dv[4], nullptr, n->d.B3, 4, 144);
-  pack(kPackFc, dv[6], nullptr, n->d.Bf, 32, 784);
-  hipLaunchKernelGGL(pack_fc_t, dim3(ceil_div(3136 * 512, 256)), dim3(256), 0, s, dv[6], n->d.BfT);
-  pack(kPackHeads, dv[10], dv[8], n->d.Bh, 2, 128);
-  hipLaunchKernelGGL(pack_heads_perm, dim3(ceil_div(2 * 4 * 32 * 64, 256)), dim3(256), 0, s, dv[10], dv[8], A, n->d.Bhp);
-  auto pack_fast = [&](int mode, const float* w, uint4* frag, int CT, int KS) {
-    const int64_t total = (int64_t)CT * KS * 64 * 8;
-    hipLaunchKernelGGL(pack_frags_bf16s, dim3(ceil_div(total, 256)), dim3(256), 0, s, mode, w,
-                       reinterpret_cast<uint16_t*>(frag), CT, KS);
-  };
-  pack_fast(1, dv[2], n->d.B2f, Conv2F::CT, Conv2F::KS);
-  pack_fast(2, dv[4], n->d.B3f, Conv3F::CT, Conv3F::KS);
-  pack_fast(3, dv[6], n->d.Bff, 32, FcFast::KS);
-  RELA_HIP(hipMemcpyAsync(n->d.b1, dv[1], sizeof(float) * 32, hipMemcpyDeviceToDevice, s));
-  RELA_HIP(hipMemcpyAsync(n->d.b2, dv[3], sizeof(float) * 64, hipMemcpyDeviceToDevice, s));
-  RELA_HIP(hipMemcpyAsync(n->d.b3, dv[5], sizeof(float) * 64, hipMemcpyDeviceToDevice, s));
-  RELA_HIP(hipMemcpyAsync(n->d.bf, dv[7], sizeof(float) * 512, hipMemcpyDeviceToDevice, s));
-  hipLaunchKernelGGL(pack_head_bias, dim3(1), dim3(64), 0, s, dv[11], dv[9], A, n->d.bh);
+  {
+    PackAllArgs a{};
+    for (int i = 0; i < 12; ++i) a.p[i] = dv[i];
+    a.B1 = reinterpret_cast<uint16_t*>(n->d.B1), a.B1p = reinterpret_cast<uint16_t*>(n->d.B1p);
+    a.B2f = reinterpret_cast<uint16_t*>(n->d.B2f), a.B3f = reinterpret_cast<uint16_t*>(n->d.B3f);
+    a.Bff = reinterpret_cast<uint16_t*>(n->d.Bff);
+    a.B2 = n->d.B2, a.B3 = n->d.B3, a.Bf = n->d.Bf, a.BfT = n->d.BfT, a.Bh = n->d.Bh, a.Bhp = n->d.Bhp;
+    a.b1 = n->d.b1, a.b2 = n->d.b2, a.b3 = n->d.b3, a.bf = n->d.bf, a.bh = n->d.bh, a.A = A;
+    const int64_t elems[13] = {2 * 8 * 64 * 8, 2 * 8 * 64 * 8, 4 * 128 * 64, 4 * 144 * 64, (int64_t)32 * 784 * 64,
+                               (int64_t)3136 * 512, 2 * 128 * 64, 2 * 4 * 32 * 64,
+                               (int64_t)Conv2F::CT * Conv2F::KS * 64 * 8, (int64_t)Conv3F::CT * Conv3F::KS * 64 * 8,
+                               (int64_t)32 * FcFast::KS * 64 * 8, 672, 32};
+    a.first[0] = 0;
+    for (int jn = 0; jn < 13; ++jn) a.first[jn + 1] = a.first[jn] + (int)ceil_div(elems[jn], 256);
+    hipLaunchKernelGGL(pack_ffnet_all, dim3(a.first[13]), dim3(256), 0, s, a);
+  }
   RELA_LAUNCH_CHECK();
   if (tmp) {
     RELA_HIP(hipStreamSynchronize(s));
