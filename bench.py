@@ -238,6 +238,11 @@ def bench_r2d2(args, world, rank, device):
     online, target = LSTMNetHandle(NUM_ACTION, device), LSTMNetHandle(NUM_ACTION, device)
     online.load_state_dict(agent.online_net.state_dict())
     target.load_state_dict(agent.target_net.state_dict())
+    # --precision bf16x2 (default): the conv trunks of the actors' nets and of the learner's target net on split-bf16
+    # MFMA; the LSTM gate GEMMs, the heads and the learner's online pass stay f32
+    online.set_precision(args.precision)
+    target.set_precision(args.precision)
+    learner.set_precision(args.precision)
     replay = RNNReplay(args.replay_cap, SEED + rank, R2_ALPHA, R2_BETA, 0, NUM_ACTION, T, device)
     eps_all = generate_eps(0.4, 7, R2_ROWS * world)
     engine = R2D2ActorEngine(R2_ROWS, R2_K, NUM_ACTION, MULTI_STEP, GAMMA, R2_SEQ, R2_BURN, R2_ETA, replay,
@@ -333,7 +338,10 @@ def bench_r2d2(args, world, rank, device):
             "metric": "env-steps/s (R2D2 Atari 84x84x4, seq 80 / burn-in 40 / n 3, actor tick + learner grad-step)",
             "value": R2_ROWS * world * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else "f32; conv trunks of the actors' nets and of the learner's target "
+                                                           "net on split-bf16 MFMA (f32 results within 2e-6)",
+            "data": "synthetic",
             "config": {"workload": "R2D2 LSTM (BASELINE config C4's shapes), 40 threads x 80 games (3200 envs) per GPU, "
                                    "actor + learner on one MI355X, sequence replay of %d x 3.47 MB device-resident, A=18, "
                                    "seq 80 / burn-in 40 / n 3, ONE learner batch of 64 sequences per step for the whole "

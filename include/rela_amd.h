@@ -293,6 +293,10 @@ int rela_lstmnet_create(rela_lstmnet** out, int num_action, int device);
 void rela_lstmnet_destroy(rela_lstmnet* net);
 int rela_lstmnet_load(rela_lstmnet* net, const rela_lstmnet_params* params, int params_on_device,
                       void* stream);
+/* 0 = exact f32 conv trunk (default), 1 = split-bf16 MFMA conv trunk for batches of 128 rows and more (as
+ * rela_ffnet_set_precision; the LSTM gate GEMM and the heads stay f32).  Bumps the weight version. */
+int rela_lstmnet_set_precision(rela_lstmnet* net, int mode);
+int rela_lstmnet_precision(const rela_lstmnet* net);
 int rela_lstmnet_num_action(const rela_lstmnet* net);
 uint64_t rela_lstmnet_version(const rela_lstmnet* net); /* as rela_ffnet_version */
 int64_t rela_lstmnet_workspace_bytes(const rela_lstmnet* net, int n);
@@ -482,6 +486,9 @@ const float* rela_r2d2_learner_stats_dev(const rela_r2d2_learner* l); /* grad no
  * counterpart: autograd launches per step).  Synchronises `stream` and returns RELA_ESTATE if a barrier of any call
  * since the last check gave up (never observed; the results of that call are then invalid). */
 int rela_r2d2_learner_check(rela_r2d2_learner* l, void* stream);
+/* 1: the TARGET net's conv trunk (no gradient) runs on split-bf16 MFMA (rela_lstmnet_set_precision); the online net's
+ * pass, whose activations the backward kernels read, stays f32.  0 (default): everything f32. */
+int rela_r2d2_learner_set_precision(rela_r2d2_learner* l, int mode);
 
 /* ===================================================================================
  * Live per-kernel timing (HIP events on the launch stream) for bench.py's roofline line.

@@ -102,6 +102,8 @@ _sig("rela_ffnet_version", C.c_uint64, [vp])
 _sig("rela_ffnet_set_precision", i32, [vp, i32])
 _sig("rela_ffnet_precision", i32, [vp])
 _sig("rela_ffnet_debug_pipe_timeout", i32, [vp, P(C.c_uint)])
+_sig("rela_lstmnet_set_precision", i32, [vp, i32])
+_sig("rela_lstmnet_precision", i32, [vp])
 _sig("rela_ffnet_workspace_bytes", i64, [vp, i32])
 _sig("rela_ffnet_forward", i32, [vp, i32, vp, vp, vp, vp, i64, vp])
 _sig("rela_lstmnet_create", i32, [P(vp), i32, i32])
@@ -156,6 +158,7 @@ _sig("rela_r2d2_learner_grads", i32, [vp, P(LSTMNetParams)])
 _sig("rela_r2d2_learner_flat", i32, [vp, P(vp), P(vp), P(i64)])
 _sig("rela_r2d2_learner_stats_dev", vp, [vp])
 _sig("rela_r2d2_learner_check", i32, [vp, vp])
+_sig("rela_r2d2_learner_set_precision", i32, [vp, i32])
 _sig("rela_prof_enable", i32, [i32])
 _sig("rela_prof_set_filter", i32, [C.c_char_p])
 _sig("rela_prof_summary_json", i32, [C.c_char_p, i64])

@@ -2676,6 +2676,7 @@ struct rela_lstmnet {
   float* bl = nullptr;   // b_ih + b_hh, permuted [2048]
   bool loaded = false;
   uint64_t version = 0;  // bumped by every load
+  int precision = 0;     // 0 = exact f32 conv trunk, 1 = split-bf16 conv trunk (the LSTM gate GEMM stays f32)
 };
 
 namespace {
@@ -2705,6 +2706,13 @@ extern "C" int rela_lstmnet_create(rela_lstmnet** out, int num_action, int devic
   RELA_HIP(hipMalloc(&d.bh, sizeof(float) * 32));
   RELA_HIP(hipMalloc(&n->Bl, sizeof(float) * (size_t)GemmLstm::CT * GemmLstm::KS * 64));
   RELA_HIP(hipMalloc(&n->bl, sizeof(float) * 2048));
+  RELA_HIP(hipMalloc(&d.B1p, sizeof(uint4) * Conv1B::FRAG_UINT4));
+  RELA_HIP(hipMalloc(&d.B2f, sizeof(uint4) * Conv2F::CT * Conv2F::KS * 2 * 64));
+  RELA_HIP(hipMalloc(&d.B3f, sizeof(uint4) * Conv3F::CT * Conv3F::KS * 2 * 64));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_bf16s),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv12::LDS_TOTAL));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv3F>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv3F::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv1B::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv2>),
@@ -2723,10 +2731,19 @@ extern "C" void rela_lstmnet_destroy(rela_lstmnet* n) {
   if (!n) return;
   DeviceGuard g(n->device);
   (void)hipDeviceSynchronize();
-  void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bh, n->d.bh, n->Bl, n->bl};
+  void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bh, n->d.bh, n->Bl, n->bl,
+                n->d.B1p, n->d.B2f, n->d.B3f};
   for (void* p : ps) (void)hipFree(p);
   delete n;
 }
+
+extern "C" int rela_lstmnet_set_precision(rela_lstmnet* n, int mode) {
+  RELA_CHECK(n && (mode == 0 || mode == 1), RELA_EINVAL, "rela_lstmnet_set_precision: mode must be 0 (f32) or 1 (bf16x2)");
+  if (n->precision != mode) n->version += 1;  // cached forwards of the other mode must not be reused
+  n->precision = mode;
+  return RELA_OK;
+}
+extern "C" int rela_lstmnet_precision(const rela_lstmnet* n) { return n ? n->precision : 0; }
 
 extern "C" int rela_lstmnet_num_action(const rela_lstmnet* n) { return n ? n->num_action : 0; }
 extern "C" uint64_t rela_lstmnet_version(const rela_lstmnet* n) { return n ? n->version : 0; }
@@ -2774,6 +2791,12 @@ extern "C" int rela_lstmnet_load(rela_lstmnet* n, const rela_lstmnet_params* p, 
   pack(kPackConv3, dv[4], nullptr, n->d.B3, 4, 144);
   pack(kPackLstm, dv[6], dv[7], n->Bl, GemmLstm::CT, GemmLstm::KS);
   pack(kPackHeads, dv[12], dv[10], n->d.Bh, 2, 128);
+  hipLaunchKernelGGL(pack_conv1_bf16x3, dim3(ceil_div(2 * 8 * 64 * 8, 256)), dim3(256), 0, s, dv[0],
+                     reinterpret_cast<uint16_t*>(n->d.B1p), 1);
+  hipLaunchKernelGGL(pack_frags_bf16s, dim3(ceil_div((int64_t)Conv2F::CT * Conv2F::KS * 64 * 8, 256)), dim3(256), 0, s, 1,
+                     dv[2], reinterpret_cast<uint16_t*>(n->d.B2f), Conv2F::CT, Conv2F::KS);
+  hipLaunchKernelGGL(pack_frags_bf16s, dim3(ceil_div((int64_t)Conv3F::CT * Conv3F::KS * 64 * 8, 256)), dim3(256), 0, s, 2,
+                     dv[4], reinterpret_cast<uint16_t*>(n->d.B3f), Conv3F::CT, Conv3F::KS);
   RELA_HIP(hipMemcpyAsync(n->d.b1, dv[1], sizeof(float) * 32, hipMemcpyDeviceToDevice, s));
   RELA_HIP(hipMemcpyAsync(n->d.b2, dv[3], sizeof(float) * 64, hipMemcpyDeviceToDevice, s));
   RELA_HIP(hipMemcpyAsync(n->d.b3, dv[5], sizeof(float) * 64, hipMemcpyDeviceToDevice, s));
@@ -2788,6 +2811,41 @@ extern "C" int rela_lstmnet_load(rela_lstmnet* n, const rela_lstmnet_params* p, 
   n->version += 1;
   return RELA_OK;
 }
+
+namespace {
+// conv trunk of an AtariLSTMNet: f32 kernels, or (fast && N >= kFastTrunkMinN) conv1 -> conv2 fused and conv3 on
+// split-bf16 MFMA with a3 turned back into f32 in place (a1 is then NOT produced, a2 holds split records)
+void lstm_trunk_launch(const FFNetDev& d, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, bool fast,
+                       hipStream_t s, const char* const* names) {
+  if (fast && N >= kFastTrunkMinN) {
+    uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
+    {
+      ProfScope prof(names[1], s);
+      hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
+                         (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
+    }
+    ProfScope prof(names[2], s);
+    hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
+                       Conv3F::LDS_TOTAL, s, (const uint8_t*)r2, (const uint4*)d.B3f, (const float*)d.b3, r3, N);
+    hipLaunchKernelGGL(unsplit_records64, dim3(ceil_div((int64_t)N * 49, 4)), dim3(256), 0, s, r3, (int64_t)N * 49);
+    return;
+  }
+  {
+    ProfScope prof(names[0], s);
+    hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
+                       d.b1, a1, N);
+  }
+  {
+    ProfScope prof(names[1], s);
+    launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
+  }
+  {
+    ProfScope prof(names[2], s);
+    launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
+  }
+}
+const char* const kLstmActorNames[3] = {"conv1_bf16x3", "conv2_mfma", "conv3_mfma"};
+}  // namespace
 
 extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_dev, const float* legal_dev,
                                  const float* h_in, const float* c_in, float* h_out, float* c_out, float* q_dev,
@@ -2806,19 +2864,7 @@ extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_
   float* a3 = a2 + kA2 * N;
   float* ha = a3 + kA3 * N;
   const FFNetDev& d = n->d;
-  {
-    ProfScope prof("conv1_bf16x3", s);
-    hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
-                       d.b1, a1, N);
-  }
-  {
-    ProfScope prof("conv2_mfma", s);
-    launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
-  }
-  {
-    ProfScope prof("conv3_mfma", s);
-    launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
-  }
+  lstm_trunk_launch(d, N, s_dev, a1, a2, a3, n->precision == 1, s, kLstmActorNames);
   {
     ProfScope prof("lstm_gates_mfma", s);
     if (prefer_bm112(N, GemmLstm::CT / GemmLstm::CTB, GemmLstm::BM))
@@ -2851,23 +2897,10 @@ extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_
 // conv trunk only: frames u8[N][4][84][84] -> a1 / a2 / a3 (channel-last, ffnet_layout.h)
 namespace rela_amd {
 int lstmnet_trunk(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, hipStream_t s,
-                  const char* const* names) {
+                  const char* const* names, bool fast) {
   RELA_CHECK(n && n->loaded, RELA_ESTATE, "lstmnet_trunk: parameters were never loaded");
   RELA_CHECK(N >= 1 && s_dev && a1 && a2 && a3, RELA_EINVAL, "lstmnet_trunk: bad arguments");
-  const FFNetDev& d = n->d;
-  {
-    ProfScope prof(names[0], s);
-    hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
-                       d.b1, a1, N);
-  }
-  {
-    ProfScope prof(names[1], s);
-    launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
-  }
-  {
-    ProfScope prof(names[2], s);
-    launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
-  }
+  lstm_trunk_launch(n->d, N, s_dev, a1, a2, a3, fast, s, names);
   RELA_LAUNCH_CHECK();
   return RELA_OK;
 }

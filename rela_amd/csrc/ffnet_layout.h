@@ -46,8 +46,10 @@ namespace rela_amd {
 // internal (not part of the C ABI): the conv trunk and the dueling heads of an AtariLSTMNet on their own,
 // for the R2D2 learner, which batches the trunk over all T*B frames of a sequence batch and runs the
 // recurrent part itself.  names: three per-kernel timing labels.
+// fast: conv1 -> conv2 fused and conv3 on split-bf16 MFMA (a3 comes out in f32 as always; a1 is NOT produced and a2 holds
+// split records, so only for passes whose activations nobody reads back)
 int lstmnet_trunk(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, hipStream_t s,
-                  const char* const* names);
+                  const char* const* names, bool fast = false);
 int lstmnet_heads(const rela_lstmnet* n, int N, const float* o, const float* legal, float* ha, float* q, hipStream_t s,
                   const char* name);
 }  // namespace rela_amd

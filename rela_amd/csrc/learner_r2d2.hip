@@ -296,6 +296,137 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
   }
 }
 
+// ---- persistent BPTT ---------------------------------------------------------------------------------
+// The seq_len + n backward steps of the online net in ONE launch (2 launches per step before: a split-K GEMM for
+// dh = dgates_{t+1} x W_hh and the cell kernel; launch gaps alone cost ~1 ms per learner step).  Block j owns hidden
+// units 16j .. 16j+15: its [2048 x 16] slice of W_hh stays in registers (wave w: gate columns [256w, 256w + 256), one
+// f32 MFMA B-fragment register per k-step), every step the eight waves multiply their slices of dgates_{t+1} (read
+// behind the acquire of the grid barrier) into partial [rows x 16] tiles that meet in LDS, a thread per (row, four
+// units) runs the cell backward and writes the gate gradients of the block's 64 gate columns WRITE-THROUGH, in
+// place of the activated gates.  Grid barrier per step as in lstm_rec_persist (bounded spins, timeout word).
+constexpr int kBpttBlocks = kHid / 16;
+
+struct BpttArgs {
+  float* ga;           // [Tt][Bn][2048] activated gates of the training steps -> gate gradients, in place
+  const float* d_o;    // [Tt][Bn][512] gradient from the heads
+  const float* whh;    // [2048][512] weight_hh_l0 (gate-major rows)
+  const float* C;      // [(T + 1)][Bn][512] cell states, slot 0 = initial
+  float* dc_rec;       // [Bn][512] running dL/dc (zeroed before the launch)
+  unsigned* bar;       // [Tt] arrival counters
+  unsigned* tmo;
+  int Tt, Bn, burn;
+};
+
+__global__ __launch_bounds__(kRecThreads) void lstm_bptt_persist(BpttArgs a) {
+  __shared__ float red[8][kRecChunk][17];
+  __shared__ int alive;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4, j = blockIdx.x;
+  // B fragments: k-step s of lane group g is gate column 256 wave + 64 g + s; column li of the tile = unit 16 j + li
+  float bfr[64];
+#pragma unroll
+  for (int ks = 0; ks < 64; ++ks) bfr[ks] = a.whh[(size_t)(256 * wave + 64 * g + ks) * kHid + 16 * j + li];
+  const size_t blk = (size_t)a.Bn * kHid;
+  for (int t = a.Tt - 1; t >= 0; --t) {
+    const bool rec = t + 1 < a.Tt;  // the newest step has no recurrent term
+    float* ga_t = a.ga + (size_t)t * a.Bn * kGates;
+    const float* dg_next = a.ga + (size_t)(t + 1) * a.Bn * kGates;
+    for (int row0 = 0; row0 < a.Bn; row0 += kRecChunk) {
+      if (rec) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const int arow = min(row0 + rt * 16 + li, a.Bn - 1);  // (rows past the batch repeat the last one, unread)
+          const float4* dp = reinterpret_cast<const float4*>(dg_next + (size_t)arow * kGates + 256 * wave + 64 * g);
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {  // every lane takes part in every MFMA: no MFMA under a lane mask
+            const float4 v = dp[c];
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, bfr[4 * c], acc[rt], 0, 0, 0);
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, bfr[4 * c + 1], acc[rt], 0, 0, 0);
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, bfr[4 * c + 2], acc[rt], 0, 0, 0);
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, bfr[4 * c + 3], acc[rt], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[wave][rt * 16 + 4 * g + r][li] = acc[rt][r];
+      }
+      __syncthreads();
+      // cell backward (lstm_cell_bwd) for (row, units 16 j + 4 q .. + 3): threads 0 .. 255
+      const int r = tid >> 2, q = tid & 3, row = row0 + r;
+      if (tid < 4 * kRecChunk && row < a.Bn) {
+        const size_t u0 = (size_t)row * kHid + 16 * j + 4 * q;
+        const int gs = a.burn + t;
+        const float4 d_o4 = *reinterpret_cast<const float4*>(a.d_o + (size_t)t * blk + u0);
+        float dh[4] = {d_o4.x, d_o4.y, d_o4.z, d_o4.w};
+        if (rec) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 8; ++w) dh[u] += red[w][r][4 * q + u];
+        }
+        float* grow = ga_t + (size_t)row * kGates + 16 * j + 4 * q;
+        const float4 gi4 = *reinterpret_cast<const float4*>(grow), gf4 = *reinterpret_cast<const float4*>(grow + kHid);
+        const float4 gg4 = *reinterpret_cast<const float4*>(grow + 2 * kHid), go4 = *reinterpret_cast<const float4*>(grow + 3 * kHid);
+        const float4 cn4 = *reinterpret_cast<const float4*>(a.C + (size_t)(gs + 1) * blk + u0);
+        const float4 cp4 = *reinterpret_cast<const float4*>(a.C + (size_t)gs * blk + u0);
+        const float4 dcr4 = *reinterpret_cast<const float4*>(a.dc_rec + u0);
+        const float gi[4] = {gi4.x, gi4.y, gi4.z, gi4.w}, gf[4] = {gf4.x, gf4.y, gf4.z, gf4.w};
+        const float gg[4] = {gg4.x, gg4.y, gg4.z, gg4.w}, go[4] = {go4.x, go4.y, go4.z, go4.w};
+        const float cn[4] = {cn4.x, cn4.y, cn4.z, cn4.w}, cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+        const float dcr[4] = {dcr4.x, dcr4.y, dcr4.z, dcr4.w};
+        float di[4], df[4], dgg[4], dgo[4], dcn[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float tc = tanhf(cn[u]);
+          const float dc = dcr[u] + dh[u] * go[u] * (1.0f - tc * tc);
+          di[u] = dc * gg[u] * gi[u] * (1.0f - gi[u]);
+          df[u] = dc * cp[u] * gf[u] * (1.0f - gf[u]);
+          dgg[u] = dc * gi[u] * (1.0f - gg[u] * gg[u]);
+          dgo[u] = dh[u] * tc * go[u] * (1.0f - go[u]);
+          dcn[u] = dc * gf[u];
+        }
+        *reinterpret_cast<float4*>(a.dc_rec + u0) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
+        auto store_wt = [&](float* dst, const float* v) {  // write-through: read by every block in the next step
+          gu64* p = (gu64*)dst;
+          __hip_atomic_store(p, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(p + 1, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        store_wt(grow, di);
+        store_wt(grow + kHid, df);
+        store_wt(grow + 2 * kHid, dgg);
+        store_wt(grow + 3 * kHid, dgo);
+      }
+      __syncthreads();
+    }
+    if (t == 0) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      gu32* cnt = (gu32*)(a.bar + t);
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool ok = true;
+      for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)kBpttBlocks;) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kRecSpinLimit || __hip_atomic_load((gu32*)a.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store((gu32*)a.tmo, (unsigned)(1000 + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = false;
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      alive = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!alive) return;
+  }
+}
+
 // hid *= 1 - terminal[burn_in - 1]   (r2d2.py:149-154)
 __global__ void zero_hidden_where_terminal(const uint8_t* __restrict__ term, int Bn, float* __restrict__ h,
                                            float* __restrict__ c) {
@@ -440,6 +571,7 @@ struct rela_r2d2_learner {
   float* rec_part = nullptr;                                          // split-K partials of the recurrent GEMMs
   unsigned* rec_bar = nullptr;                                        // [0] timeout word, [4 ..] per-step arrival counters
   bool rec_persist = true;
+  int precision = 0;  // 1: the target net's conv trunk (no gradient, activations never read back) on split-bf16 MFMA
   float *ha = nullptr, *q_on = nullptr, *q_tg = nullptr;              // heads of the training rows
   float *qmin = nullptr, *qa_on = nullptr, *qa_tg = nullptr, *dqa = nullptr, *d_ha = nullptr, *d_o = nullptr;
   float *dc_rec = nullptr;
@@ -501,7 +633,8 @@ int forward_pre(rela_r2d2_learner* l, int which, int Bn, const uint8_t* obs, con
                 hipStream_t s) {
   const rela_lstmnet* net = which == 0 ? l->online : l->target;
   const int rowsAll = l->T * Bn;
-  int rc = lstmnet_trunk(net, rowsAll, obs, l->a1, l->a2, l->a3, s, kTrunkNames);
+  // the online pass leaves a1 / a2 / a3 for the backward kernels: always f32
+  int rc = lstmnet_trunk(net, rowsAll, obs, l->a1, l->a2, l->a3, s, kTrunkNames, which == 1 && l->precision == 1);
   if (rc != RELA_OK) return rc;
   ProbGateX p{};
   p.M = rowsAll, p.N = kGates, p.K = kFeat;
@@ -743,6 +876,12 @@ extern "C" int rela_r2d2_learner_flat(rela_r2d2_learner* l, float** params_dev, 
 
 extern "C" const float* rela_r2d2_learner_stats_dev(const rela_r2d2_learner* l) { return l ? l->norm : nullptr; }
 
+extern "C" int rela_r2d2_learner_set_precision(rela_r2d2_learner* l, int mode) {
+  RELA_CHECK(l && (mode == 0 || mode == 1), RELA_EINVAL, "rela_r2d2_learner_set_precision: mode must be 0 or 1");
+  l->precision = mode;
+  return RELA_OK;
+}
+
 extern "C" int rela_r2d2_learner_check(rela_r2d2_learner* l, void* stream_) {
   RELA_CHECK(l, RELA_EINVAL, "rela_r2d2_learner_check: null learner");
   DeviceGuard g(l->device);
@@ -825,6 +964,15 @@ extern "C" int rela_r2d2_learner_backward(rela_r2d2_learner* l, int batch, const
   RELA_HIP(hipMemsetAsync(l->dc_rec, 0, blk * sizeof(float), s));
   const int cell_grid = ceil_div((int64_t)Bn * kHid, 256);
   float* ga_tr = l->gx + tr0 * kGates;
+  if (l->rec_persist) {
+    const int Tpad = (T + 3) / 4 * 4;
+    RELA_HIP(hipMemsetAsync(l->rec_bar + 4, 0, sizeof(unsigned) * (size_t)Tpad, s));
+    BpttArgs ba{};
+    ba.ga = ga_tr, ba.d_o = l->d_o, ba.whh = P.w_hh, ba.C = Cc, ba.dc_rec = l->dc_rec;
+    ba.bar = l->rec_bar + 4, ba.tmo = l->rec_bar, ba.Tt = Tt, ba.Bn = Bn, ba.burn = burn;
+    ProfScope prof("learner_lstm_bptt_persist", s);
+    hipLaunchKernelGGL(lstm_bptt_persist, dim3(kBpttBlocks), dim3(kRecThreads), 0, s, ba);
+  } else
   for (int t = Tt - 1; t >= 0; --t) {
     const int gs = burn + t;  // global step
     {

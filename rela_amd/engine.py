@@ -175,6 +175,11 @@ class LSTMNetHandle:
         capi.check(capi.lib.rela_lstmnet_load(self.h, C.byref(p), 1, stream), "rela_lstmnet_load")
         self._keep = keep
 
+    def set_precision(self, mode):
+        """"f32" (default) or "bf16x2": the conv trunk on split-bf16 MFMA for batches of 128 rows and more (the LSTM
+        gate GEMM and the heads stay f32); rela_lstmnet_set_precision."""
+        capi.check(capi.lib.rela_lstmnet_set_precision(self.h, {"f32": 0, "bf16x2": 1}[mode]), "rela_lstmnet_set_precision")
+
     def close(self):
         if getattr(self, "h", None):
             capi.lib.rela_lstmnet_destroy(self.h)

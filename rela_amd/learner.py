@@ -328,6 +328,11 @@ class HipR2D2Learner:
         capi.check(capi.lib.rela_r2d2_learner_flat(self.h, None, None, C.byref(n)), "flat")
         return dev_view(getattr(p, capi.LSTMNetParams._fields_[0][0]), (n.value,), torch.float32, self.device)
 
+    def set_precision(self, mode):
+        """"f32" (default) or "bf16x2": the target net's conv trunk on split-bf16 MFMA (no gradient flows through it)."""
+        self._capi.check(self._capi.lib.rela_r2d2_learner_set_precision(self.h, {"f32": 0, "bf16x2": 1}[mode]),
+                         "rela_r2d2_learner_set_precision")
+
     def check(self):
         """Synchronises and raises if a grid barrier of the persistent recurrent kernels gave up since the last check."""
         stream = self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

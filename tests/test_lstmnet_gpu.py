@@ -77,3 +77,30 @@ def test_lstm_step_vs_torch(N, A):
     np.testing.assert_allclose(adv, adv_r.numpy(), **tol)
     np.testing.assert_allclose(q, q_r.numpy(), **tol)
     net.close()
+
+
+@pytest.mark.parametrize("N", [127, 128, 131, 1537, 3200])
+def test_lstm_step_fast_trunk_within_stated_tolerance(N):
+    """rela_lstmnet_set_precision(1): the conv trunk on split-bf16 MFMA for batches of 128 rows and more (conv1 -> conv2
+    fused, conv3, a3 back to f32; the LSTM gate GEMM and the heads stay f32).  h, c, Q and the advantages stay within
+    the fast mode's stated tolerance of the exact f32 step (N = 127 takes the f32 kernels: identical)."""
+    from synth import synth_lstm_params, synth_obs
+
+    A = 18
+    net = GpuLstmNet(synth_lstm_params(A, 51), A)
+    rng = np.random.default_rng(N)
+    s = synth_obs(N, 900 + N)
+    legal = np.ones((N, A), np.float32)
+    h_in = rng.normal(0, 0.3, (N, 512)).astype(np.float32)
+    c_in = rng.normal(0, 0.5, (N, 512)).astype(np.float32)
+    ref = net.step(s, legal, h_in, c_in)
+    net.capi.check(net.capi.lib.rela_lstmnet_set_precision(net.h, 1), "set_precision")
+    assert net.capi.lib.rela_lstmnet_precision(net.h) == 1
+    fast = net.step(s, legal, h_in, c_in)
+    for a, b, name in zip(fast, ref, ("h", "c", "q", "adv")):
+        err = float(np.abs(a - b).max())
+        assert err < 4e-6, (name, err)
+        if N < 128:
+            assert np.array_equal(a, b), name
+    assert float((fast[2].argmax(1) == ref[2].argmax(1)).mean()) >= 0.995
+    net.close()

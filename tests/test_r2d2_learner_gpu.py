@@ -210,3 +210,33 @@ def test_hip_r2d2_learner_adam_step_and_trajectory():
     for key in on:
         assert torch.equal(tg[key], on[key])
     learner.close()
+
+
+def test_hip_r2d2_learner_fast_target_trunk_within_tolerance():
+    """set_precision("bf16x2"): the target net's conv trunk (no gradient, its activations are never read back) runs on
+    split-bf16 MFMA; loss, priorities and gradients stay within the fast mode's tolerance of the all-f32 step."""
+    import torch
+
+    from rela_amd.learner import HipR2D2Learner
+
+    A, B, seq, burn, n = 18, 16, 12, 6, 3
+    rng = np.random.default_rng(77)
+    agent = _agent(A, n, 0.997, 0.9, seq, burn, 71, 72, "cuda:0")
+    batch, weight = _random_batch(rng, A, B, seq, burn, n, "cuda:0")
+    learner = HipR2D2Learner.from_agent(agent, B, grad_clip=1e9)
+    loss0, prio0, ls0 = learner.backward(batch, weight)
+    loss0, prio0 = loss0.clone(), prio0.clone()
+    g0 = {k: v.clone() for k, v in learner.state_dict("grads").items()}
+    learner.set_precision("bf16x2")  # T * B = 336 frames >= 128: the fast trunk is taken
+    loss1, prio1, _ = learner.backward(batch, weight)
+    learner.check()
+    assert float((prio1 - prio0).abs().max()) < 2e-5
+    assert abs(float(loss1) - float(loss0)) < 2e-5 * max(1.0, abs(float(loss0)))
+    g1 = learner.state_dict("grads")
+    for key in HipR2D2Learner.KEYS:
+        scale = float(g0[key].abs().max()) + 1e-12
+        assert float((g1[key] - g0[key]).abs().max()) <= 2e-4 * scale, key
+    learner.set_precision("f32")
+    loss2, prio2, _ = learner.backward(batch, weight)
+    assert torch.equal(prio2, prio0)
+    learner.close()
