@@ -227,6 +227,13 @@ class ModelLocker {
     return out;
   }
 
+  // RELA_PRECISION=bf16x2: the actors' conv trunks on split-bf16 MFMA (Q within 2e-6 of the default exact f32 mode,
+  // DESIGN 4.3b); anything else keeps the parity mode
+  static bool fastPrecision() {
+    const char* e = std::getenv("RELA_PRECISION");
+    return e && std::string(e) == "bf16x2";
+  }
+
   void loadNet(void*& net, py::dict& sd, const std::string& prefix) {
     void* stream = torchCurrentStream(deviceIndex);
     std::vector<torch::Tensor> t;
@@ -236,7 +243,10 @@ class ModelLocker {
       const int A = (int)t[10].size(0);
       checkActions(A);
       auto* n = static_cast<rela_ffnet*>(net);
-      if (!n) check(rela_ffnet_create(&n, A, deviceIndex), "rela_ffnet_create");
+      if (!n) {
+        check(rela_ffnet_create(&n, A, deviceIndex), "rela_ffnet_create");
+        check(rela_ffnet_set_precision(n, fastPrecision() ? 1 : 0), "rela_ffnet_set_precision");
+      }
       net = n;
       auto f = [&](int i) { return t[i].data_ptr<float>(); };
       rela_ffnet_params p{f(0), f(1), f(2), f(3), f(4), f(5), f(6), f(7), f(8), f(9), f(10), f(11)};
@@ -248,7 +258,10 @@ class ModelLocker {
       const int A = (int)t[12].size(0);
       checkActions(A);
       auto* n = static_cast<rela_lstmnet*>(net);
-      if (!n) check(rela_lstmnet_create(&n, A, deviceIndex), "rela_lstmnet_create");
+      if (!n) {
+        check(rela_lstmnet_create(&n, A, deviceIndex), "rela_lstmnet_create");
+        check(rela_lstmnet_set_precision(n, fastPrecision() ? 1 : 0), "rela_lstmnet_set_precision");
+      }
       net = n;
       auto f = [&](int i) { return t[i].data_ptr<float>(); };
       rela_lstmnet_params p{f(0), f(1), f(2), f(3), f(4), f(5), f(6), f(7), f(8), f(9), f(10), f(11), f(12), f(13)};
