@@ -12,11 +12,13 @@ One STEP = what the reference does per env-step of every actor thread plus one l
   actor tick over 6,400 envs  (rela/thread_loop.h:74-105 -> rela/dqn_actor.h:153-203)
       act: 1 trunk forward + eps-greedy; post_step: n-step return, TD priority from online(s_t),
       online(s_t+n), target(s_t+n), replay insert of 6,400 transitions.
-      online(s_t+n) is the forward act() just ran on the same observation with the same weights
-      (dqn_actor.h:84,161 + apex.py:41): it is reused bit-identically instead of recomputed, so a tick
-      runs 3 trunk forwards (4 on a tick that straddles a weight publish).  `forwards_per_tick` reports
-      what ran, and `no_reuse` carries the same step measured with the reuse switched off (all 4
-      forwards of the reference).  Nothing else is cached or skipped.
+      online(s_t+n) is the forward act() just ran on the same observation with the same weights and online(s_t)
+      the one act() ran n ticks ago (dqn_actor.h:84,161 + apex.py:38,41): each is reused bit-identically when the
+      online weights were not re-loaded in between, so every observation gets ONE online and ONE target forward
+      per weight version: 2 trunk forwards on most ticks, 3-4 on the n + 1 ticks after a weight publish (every 20
+      learner steps: 2.2 on average).  `forwards_per_tick` reports what ran; `no_reuse` carries the same step
+      measured with the reuse switched off (all 4 forwards of the reference) and `reuse_next_only` with only the
+      same-tick reuse (3 forwards, the headline of rounds 1-2).  Nothing else is cached or skipped.
   learner step                (pyrela/main.py:206-251)
       replay.sample(512) [exact sequential-sum scan + gather] -> ApexAgent.loss -> backward
       -> clip 40 -> RMSprop -> update_priority, hand-written HIP (csrc/learner.hip; RELA_BENCH_LEARNER=torch
@@ -29,8 +31,8 @@ as bf16 hi + lo, f32 accumulation, conv1 -> conv2 fused through LDS; Q within 2e
 Prints ONE JSON line (rank 0).  `value` = env-steps/s summed over ranks.  Extra keys carry the
 learner rate, the live roofline of the dominant kernel (HIP events around the heavy forward kernels
 inside the timed region; the full per-kernel table comes from an untimed pass), the HBM-side roofline
-of the replay sample path and insert, two more timed regions of the same K steps -- `no_reuse` (all 4 forwards
-of the reference per tick) and `f32_mode` (actor nets in the f32 mode) -- and the CPU baseline (the
+of the replay sample path and insert, three more timed regions of the same K steps -- `no_reuse` (all 4 forwards
+of the reference per tick), `reuse_next_only` (3) and `f32_mode` (actor nets in the f32 mode) -- and the CPU baseline (the
 reference's own CPU-thread actor path from oracle/_ref when present, else the oracle's plain-C port).
 `--algo r2d2` is the second line: config C4's per-GPU shape with the HIP R2D2 learner.
 """
@@ -618,25 +620,28 @@ def main():
     # step with the act-forward reuse switched off, i.e. all 4 forwards of the reference per env-step.
     # A second timed region of exactly the same K steps, bracketed the same way (barrier + synchronize on
     # both sides, MAX over ranks), with the reuse switched off: SURVEY 8d's unit of work, 4 forwards per env-step.
-    ms_4fwd = None
+    ms_4fwd = ms_3fwd = None
     if not ONLY:
-        engine.set_reuse(False)
-        for _ in range(min(args.warmup, 3)):
-            one_step()
-            step_idx[0] += 1
-        sync_all()
-        t4 = time.perf_counter()
-        for _ in range(args.steps):
-            one_step()
-            step_idx[0] += 1
-        sync_all()
-        dt4 = time.perf_counter() - t4
-        if world > 1:
-            t = torch.tensor([dt4], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt4 = float(t.item())
-        ms_4fwd = dt4 / args.steps * 1e3
-        engine.set_reuse(True)
+        def region(mode):
+            engine.set_reuse(mode)
+            for _ in range(min(args.warmup, 3) + 4):  # (+ n + 1 ticks so every history slot is of this mode)
+                one_step()
+                step_idx[0] += 1
+            sync_all()
+            t4 = time.perf_counter()
+            for _ in range(args.steps):
+                one_step()
+                step_idx[0] += 1
+            sync_all()
+            dt4 = time.perf_counter() - t4
+            if world > 1:
+                t = torch.tensor([dt4], device=device, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt4 = float(t.item())
+            return dt4 / args.steps * 1e3
+        ms_4fwd = region(0)
+        ms_3fwd = region(2)
+        engine.set_reuse(1)
     # Third timed region of the same K steps (N = 1 accounting, same bracketing): the actor nets in the exact f32
     # parity mode, so the line carries the f32 rate next to the split-bf16 headline.
     ms_f32 = None
@@ -746,9 +751,14 @@ def main():
             "buffer_add_per_s": adds / dt,
             "learner": "hip (csrc/learner.hip)" if hip_learner is not None else "torch autograd",
             **({"diagnostic_only": ONLY} if ONLY else {}),
-            # act + compute_priority's online(obs), target(next_obs); online(next_obs) is act's own
-            # forward (same weights, same batch) and is reused bit-identically -> 3, else 4
+            # act + compute_priority's target(next_obs); online(next_obs) and online(obs) are act's own forwards
+            # of this tick and of n ticks ago (same weights, same batch), reused bit-identically -> 2, else 3-4
             "forwards_per_tick": fwd_cnt / args.steps if ONLY != "learner" else 0,
+            "reuse_next_only": None if ms_3fwd is None else {
+                "forwards_per_tick": 3, "steps": args.steps, "ms_per_step": ms_3fwd,
+                "env_steps_per_s": ROWS * world / (ms_3fwd * 1e-3),
+                "note": "timed region of the same K steps with only the same-tick reuse (online(next_obs) = act()'s "
+                        "forward): 3 trunk forwards per env-step, the headline's accounting in rounds 1-2"},
             "no_reuse": None if ms_4fwd is None else {
                 "forwards_per_tick": 4, "steps": args.steps, "ms_per_step": ms_4fwd,
                 "env_steps_per_s": ROWS * world / (ms_4fwd * 1e-3),

@@ -361,8 +361,10 @@ int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward, const uin
  * Call once, before the first act().                                                              */
 int rela_apex_actor_set_dedup(rela_apex_actor* a, int units_per_stack);
 int64_t rela_apex_actor_num_act(const rela_apex_actor* a); /* numAct()  dqn_actor.h:149-151 */
-/* post_step evaluates online(next_obs) only if act() did not already do so with the same weights
- * (bit-identical, see post_step); on = 0 always recomputes, i.e. the reference's 4 forwards per step */
+/* post_step evaluates online(obs) and online(next_obs) only if act() did not already evaluate that
+ * observation with the same weights (n ticks ago and this tick; bit-identical, see post_step).
+ * on = 1 (default): reuse both; 2: only the one of next_obs; 0: always recompute, i.e. the reference's
+ * 4 forwards per step */
 int rela_apex_actor_set_reuse(rela_apex_actor* a, int on);
 /* diagnostic: device pointers of the last Q table of act() and of the last priorities       */
 const float* rela_apex_actor_last_q_dev(const rela_apex_actor* a);

@@ -5,7 +5,8 @@
 //   act        push (obs, action) :23-29,153-171      -> 1 trunk forward + eps-greedy
 //   post_step  push (r, t) :31-40; canPop :46-48; popTransition :58-106; computePriority :193-203
 //              (online(s_t), online(s_t+n), target(s_t+n), apex.py:30-45; online(s_t+n) is act()'s own
-//              forward and is reused when the weights are unchanged); replay add :189
+//              forward of this tick and online(s_t) is act()'s forward of n ticks ago: each is reused when
+//              the online weights were not re-loaded in between); replay add :189
 // The deque of :120-123 is a ring of multi_step+1 slots in HBM; "pop_front" is a head increment.
 #include <atomic>
 #include <cmath>
@@ -33,16 +34,17 @@ struct rela_apex_actor {
   float* legal = nullptr;   // [R][A]
   float* eps_hist = nullptr;    // [n+1][R]     ... snapshotted per history slot by act(), because the
   float* legal_hist = nullptr;  // [n+1][R][A]  transition's obs side carries those of time t-n (:84-90)
-  float* q = nullptr;       // [4][R][A]
+  float* q = nullptr;       // [4][R][A]   tables recomputed in post_step (1: online(s_t), 2: online(s_t+n), 3: target)
+  float* q_hist = nullptr;  // [n+1][R][A] act()'s own Q table of every history slot
   float *out_r = nullptr, *out_b = nullptr, *prio = nullptr;
   uint8_t* out_t = nullptr;
   void* ws = nullptr;
   int64_t ws_bytes = 0;
-  // weights and history slot the Q-values in q[0] (written by act) belong to
-  const rela_ffnet* q_net = nullptr;
-  uint64_t q_version = 0;
-  int q_slot = -1;
-  bool reuse_act_forward = true;
+  // net and weight version act() evaluated every history slot with (q_hist[slot])
+  std::vector<const rela_ffnet*> qh_net;
+  std::vector<uint64_t> qh_version;
+  int q_slot = -1;     // slot of the last act()
+  int reuse_mode = 1;  // 0: recompute everything, 1: reuse both act() forwards, 2: only the one of s_t+n
   // frame-stack de-duplication (rela_apex_actor_set_dedup; replay side: rela_replay_set_schema_dedup)
   int dd_ups = 0;                    // 0 = off, 1 = one unit per stack, 4 = one unit per 84x84 plane
   int64_t dd_cap = 0;                // units in the replay's ring
@@ -119,6 +121,9 @@ extern "C" int rela_apex_actor_create(rela_apex_actor** out, int rows, int group
   RELA_HIP(hipMalloc(&a->eps_hist, H * R * sizeof(float)));
   RELA_HIP(hipMalloc(&a->legal_hist, H * R * A * sizeof(float)));
   RELA_HIP(hipMalloc(&a->q, 4 * R * A * sizeof(float)));
+  RELA_HIP(hipMalloc(&a->q_hist, H * R * A * sizeof(float)));
+  a->qh_net.assign(H, nullptr);
+  a->qh_version.assign(H, 0);
   RELA_HIP(hipMalloc(&a->out_r, R * sizeof(float)));
   RELA_HIP(hipMalloc(&a->out_b, R * sizeof(float)));
   RELA_HIP(hipMalloc(&a->prio, R * sizeof(float)));
@@ -143,7 +148,7 @@ extern "C" void rela_apex_actor_destroy(rela_apex_actor* a) {
   DeviceGuard g(a->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {a->obs, a->act, a->rew, a->term, a->eps, a->legal, a->q, a->out_r, a->out_b, a->prio, a->out_t, a->ws,
-                a->eps_hist, a->legal_hist, a->ref_hist};
+                a->eps_hist, a->legal_hist, a->ref_hist, a->q_hist};
   for (void* p : ps) (void)hipFree(p);
   delete a;
 }
@@ -155,7 +160,8 @@ extern "C" void* rela_apex_actor_obs_slot(rela_apex_actor* a) {
 }
 extern "C" int rela_apex_actor_set_reuse(rela_apex_actor* a, int on) {
   RELA_CHECK(a, RELA_EINVAL, "rela_apex_actor_set_reuse: bad arguments");
-  a->reuse_act_forward = on != 0;
+  RELA_CHECK(on >= 0 && on <= 2, RELA_EINVAL, "rela_apex_actor_set_reuse: 0 (off), 1 (on) or 2 (next_obs only)");
+  a->reuse_mode = on;
   return RELA_OK;
 }
 extern "C" int rela_apex_actor_set_dedup(rela_apex_actor* a, int units_per_stack) {
@@ -181,7 +187,9 @@ extern "C" int rela_apex_actor_set_dedup(rela_apex_actor* a, int units_per_stack
 extern "C" float* rela_apex_actor_eps_dev(rela_apex_actor* a) { return a ? a->eps : nullptr; }
 extern "C" float* rela_apex_actor_legal_dev(rela_apex_actor* a) { return a ? a->legal : nullptr; }
 extern "C" int64_t rela_apex_actor_num_act(const rela_apex_actor* a) { return a ? a->num_act.load() : 0; }
-extern "C" const float* rela_apex_actor_last_q_dev(const rela_apex_actor* a) { return a ? a->q : nullptr; }
+extern "C" const float* rela_apex_actor_last_q_dev(const rela_apex_actor* a) {
+  return a ? a->q_hist + (size_t)(a->q_slot < 0 ? 0 : a->q_slot) * a->R * a->A : nullptr;
+}
 extern "C" const float* rela_apex_actor_last_priority_dev(const rela_apex_actor* a) { return a ? a->prio : nullptr; }
 
 extern "C" int rela_apex_actor_act(rela_apex_actor* a, const rela_ffnet* online, const uint8_t* obs_host,
@@ -203,14 +211,16 @@ extern "C" int rela_apex_actor_act(rela_apex_actor* a, const rela_ffnet* online,
   float* legal_s = a->legal_hist + (size_t)slot * a->R * a->A;
   RELA_HIP(hipMemcpyAsync(eps_s, a->eps, (size_t)a->R * sizeof(float), hipMemcpyDeviceToDevice, s));
   RELA_HIP(hipMemcpyAsync(legal_s, a->legal, (size_t)a->R * a->A * sizeof(float), hipMemcpyDeviceToDevice, s));
-  int rc = rela_ffnet_forward(online, a->R, obs, legal_s, a->q, a->ws, a->ws_bytes, s);
+  float* q_s = a->q_hist + (size_t)slot * a->R * a->A;
+  a->qh_net[slot] = nullptr;
+  int rc = rela_ffnet_forward(online, a->R, obs, legal_s, q_s, a->ws, a->ws_bytes, s);
   if (rc != RELA_OK) return rc;
   int64_t* act = a->act + (size_t)slot * a->R;
-  rc = rela_apex_act_from_q(a->R, a->A, a->K, a->q, legal_s, eps_s, a->seed, a->act_calls * (uint64_t)a->R, act, s);
+  rc = rela_apex_act_from_q(a->R, a->A, a->K, q_s, legal_s, eps_s, a->seed, a->act_calls * (uint64_t)a->R, act, s);
   if (rc != RELA_OK) return rc;
   a->act_calls += 1;
-  a->q_net = online;
-  a->q_version = rela_ffnet_version(online);
+  a->qh_net[slot] = online;
+  a->qh_version[slot] = rela_ffnet_version(online);
   a->q_slot = slot;
   a->cur = slot;
   a->num_act += a->R;  // :169
@@ -291,14 +301,20 @@ extern "C" int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward
   const float* legal_n = a->legal_hist + (size_t)last * a->R * a->A;
   const float* eps_t = a->eps_hist + (size_t)first * a->R;
   const float* eps_n = a->eps_hist + (size_t)last * a->R;
-  rc = rela_ffnet_forward(online, a->R, obs_t, legal_t, a->q + QA, a->ws, a->ws_bytes, s);  // apex.py:38
-  if (rc != RELA_OK) return rc;
-  // greedy_act(next_obs) :41 -- next_obs is the observation act() just ran the online net on
-  // (dqn_actor.h:161, history.back() :84).  With the same weights (no load since) and the same
-  // legal mask and batch, that forward is bit-identical to the one act() left in q[0]: reuse it.
-  const float* q_online_n = a->q;
-  if (!(a->reuse_act_forward && a->q_net == online && a->q_version == rela_ffnet_version(online) &&
-        a->q_slot == last)) {
+  // Both online forwards of compute_priority evaluate observations act() already ran the online net on:
+  // obs is history.front(), acted on n ticks ago, and next_obs is history.back(), acted on this tick
+  // (dqn_actor.h:84,161).  With the same weights (no load since: rela_ffnet_version), the same legal mask and the
+  // same batch such a forward is bit-identical to the table act() left in q_hist[slot]: reuse it.
+  const uint64_t ver = rela_ffnet_version(online);
+  auto cached = [&](int slot) { return a->qh_net[slot] == online && a->qh_version[slot] == ver; };
+  const float* q_online_t = a->q_hist + (size_t)first * QA;
+  if (!(a->reuse_mode == 1 && cached(first))) {
+    rc = rela_ffnet_forward(online, a->R, obs_t, legal_t, a->q + QA, a->ws, a->ws_bytes, s);  // apex.py:38
+    if (rc != RELA_OK) return rc;
+    q_online_t = a->q + QA;
+  }
+  const float* q_online_n = a->q_hist + (size_t)last * QA;  // greedy_act(next_obs) :41
+  if (!(a->reuse_mode != 0 && cached(last) && a->q_slot == last)) {
     rc = rela_ffnet_forward(online, a->R, obs_n, legal_n, a->q + 2 * QA, a->ws, a->ws_bytes, s);
     if (rc != RELA_OK) return rc;
     q_online_n = a->q + 2 * QA;
@@ -306,7 +322,7 @@ extern "C" int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward
   rc = rela_ffnet_forward(target, a->R, obs_n, legal_n, a->q + 3 * QA, a->ws, a->ws_bytes, s);  // :42
   if (rc != RELA_OK) return rc;
   const int64_t* act_t = a->act + (size_t)first * a->R;
-  rc = rela_apex_td_from_q(a->R, a->A, a->K, a->q + QA, q_online_n, a->q + 3 * QA, legal_n, act_t, a->out_r,
+  rc = rela_apex_td_from_q(a->R, a->A, a->K, q_online_t, q_online_n, a->q + 3 * QA, legal_n, act_t, a->out_r,
                            a->out_b, a->gamma_n, nullptr, a->prio, s);
   if (rc != RELA_OK) return rc;
   // FFTransition rows (types.h:18-51): obs{s,eps,legal_move}, next_obs{...}, action{a}, reward, terminal, bootstrap

@@ -125,7 +125,7 @@ class ApexActorEngine:
 
     def set_reuse(self, on):
         """on=False: post_step always recomputes online(next_obs) (the reference's 4 forwards per step)."""
-        capi.check(capi.lib.rela_apex_actor_set_reuse(self.h, int(bool(on))), "rela_apex_actor_set_reuse")
+        capi.check(capi.lib.rela_apex_actor_set_reuse(self.h, int(on)), "rela_apex_actor_set_reuse")
 
     def next_obs_slot(self):
         """The HBM slot the env layer writes the next observation batch into ([R,4,84,84] u8)."""

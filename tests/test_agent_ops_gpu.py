@@ -138,10 +138,12 @@ def test_eps_greedy_statistics():
 
 
 def test_post_step_reuses_act_forward_bit_identically():
-    """post_step skips the online forward on next_obs when act() already ran it with the same
-    weights (dqn_actor.h:161 and apex.py:41 evaluate the same network on the same batch).  A twin
-    actor whose weights are re-loaded (same values, new version) before every post_step must take
-    the recompute path and end with bit-identical priorities and replay weights."""
+    """post_step skips the online forwards on obs and next_obs when act() already ran them with the same
+    weights (dqn_actor.h:84,161 and apex.py:38,41 evaluate the same network on the same batches, n ticks ago
+    and this tick).  Twin actors -- one whose weights are re-loaded (same values, new version) before every
+    post_step, one with the reuse switched off, one that reuses only the next_obs forward -- must take the
+    recompute paths and end with bit-identical priorities and replay weights.  All of them get NEW online
+    weights before tick 4, so the reusing actor has to recompute online(obs) for the n ticks that straddle it."""
     import torch
 
     from rela_amd import _capi as capi
@@ -152,9 +154,10 @@ def test_post_step_reuses_act_forward_bit_identically():
     A, R, K, n = 6, 16, 8, 3
     params = {k: torch.from_numpy(v) for k, v in synth_params(A, 5).items()}
     tparams = {k: torch.from_numpy(v) for k, v in synth_params(A, 6).items()}
+    params2 = {k: torch.from_numpy(v) for k, v in synth_params(A, 7).items()}
     eps = np.linspace(0.0, 0.4, R).astype(np.float32)
     runs = []
-    for reload_between in (False, True, "switch"):
+    for reload_between in (False, True, "switch", "next_only"):
         online, target = FFNetHandle(A, "cuda:0"), FFNetHandle(A, "cuda:0")
         online.load_state_dict(params)
         target.load_state_dict(tparams)
@@ -163,13 +166,19 @@ def test_post_step_reuses_act_forward_bit_identically():
         eng.legal.fill_(1.0)
         if reload_between == "switch":
             eng.set_reuse(False)
+        if reload_between == "next_only":
+            eng.set_reuse(2)
         prios, acts = [], []
-        for t in range(n + 4):
+        cur = params
+        for t in range(n + 8):
+            if t == 4:
+                cur = params2
+                online.load_state_dict(cur)
             eng.next_obs_slot().copy_(torch.from_numpy(synth_obs(R, 100 + t)).cuda())
             acts.append(eng.act(online).cpu().numpy().copy())
             v0 = capi.lib.rela_ffnet_version(online.h)
             if reload_between is True:
-                online.load_state_dict(params)
+                online.load_state_dict(cur)
                 assert capi.lib.rela_ffnet_version(online.h) == v0 + 1
             rew = torch.full((R,), 0.25 * t, device="cuda")
             term = torch.zeros(R, dtype=torch.uint8, device="cuda")
@@ -186,7 +195,7 @@ def test_post_step_reuses_act_forward_bit_identically():
         online.close()
         target.close()
     for other in runs[1:]:
-        assert runs[0][3] == other[3] == 4 * R
+        assert runs[0][3] == other[3] == 8 * R
         assert np.array_equal(runs[0][0], other[0])
         assert np.array_equal(runs[0][1].view(np.uint32), other[1].view(np.uint32))
         assert np.array_equal(runs[0][2].view(np.uint32), other[2].view(np.uint32))
