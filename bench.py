@@ -491,7 +491,18 @@ def main():
             engine.act(online)
             engine.post_step(reward_pool[i], term_pool[i], online, target, nonblocking=True)
 
-    def learner_sample():
+    # The HIP learner's step is software-pipelined with the replay (RELA_BENCH_PIPELINE=0: strictly one after the
+    # other): priorities are final after the forward half (rela_apex_learner_loss), so update_priority and the NEXT
+    # sample are queued before the backward half (rela_apex_learner_grad) and the replay's latency-bound sample chain
+    # runs next to the gradient kernels.  Same calls, same order on the replay's stream, same results; the batch
+    # buffers alternate between two slots because conv1's weight gradient still reads the current batch.
+    PIPE = hip_learner is not None and os.environ.get("RELA_BENCH_PIPELINE", "1") == "1"
+    sample_slot = [0]
+    pending = [None]
+    if PIPE:
+        replay.set_deferred_wait(True)
+
+    def learner_housekeeping():
         k = step_idx[0]
         if k % 2500 == 0:
             if hip_learner is not None:
@@ -506,14 +517,22 @@ def main():
                 online.load_state_dict(agent.online_net.state_dict())
                 target.load_state_dict(agent.target_net.state_dict())
             actor_stream.wait_stream(main_stream)
-        batch, weight = replay.sample(B_LOCAL)
-        if world > 1:  # one replay partition per GPU: normalise the IS weights over all of them
-            raw_p, sum_p = C.c_void_p(), C.c_void_p()
-            capi.check(capi.lib.rela_replay_last_sample_dev(replay.h, C.byref(raw_p), C.byref(sum_p)), "last_sample")
-            raw_w = dev_view(raw_p.value, (B_LOCAL,), torch.float32, torch.device(device))
-            part_sum = dev_view(sum_p.value, (1,), torch.float32, torch.device(device))
-            weight = global_is_weights(raw_w, part_sum, replay.size(), BETA)
-        return batch, weight
+
+    def learner_sample():
+        batch, weight = replay.sample(B_LOCAL, slot=sample_slot[0])
+        sample_slot[0] ^= 1 if PIPE else 0
+        return batch, weight, replay.size()
+
+    def global_weights(weight, size_at_sample):
+        if world == 1:
+            return weight
+        # one replay partition per GPU: normalise the IS weights over all of them (the raw weights and the
+        # partition's sum are the last sample's; nothing else samples in between)
+        raw_p, sum_p = C.c_void_p(), C.c_void_p()
+        capi.check(capi.lib.rela_replay_last_sample_dev(replay.h, C.byref(raw_p), C.byref(sum_p)), "last_sample")
+        raw_w = dev_view(raw_p.value, (B_LOCAL,), torch.float32, torch.device(device))
+        part_sum = dev_view(sum_p.value, (1,), torch.float32, torch.device(device))
+        return global_is_weights(raw_w, part_sum, size_at_sample, BETA)
 
     def learner_update(batch, weight):
         if hip_learner is not None:
@@ -542,11 +561,29 @@ def main():
         #                    host-side cost now overlaps the tick's GPU work instead of preceding it
         with torch.cuda.stream(main_stream):
             if ONLY != "actor":
-                batch, weight = learner_sample()
+                learner_housekeeping()
+                if pending[0] is None:
+                    pending[0] = learner_sample()
+                batch, weight, size_at_sample = pending[0]
+                pending[0] = None
             if ONLY != "learner":
                 actor_tick()
             if ONLY != "actor":
-                learner_update(batch, weight)
+                if PIPE:
+                    replay.wait()  # the batch sampled during the previous step's backward half
+                weight = global_weights(weight, size_at_sample)
+                if PIPE:
+                    loss, prio = hip_learner.loss(batch, weight)
+                    replay.update_priority(prio)
+                    pending[0] = learner_sample()
+                    hip_learner.grad()
+                    if world > 1:
+                        g = hip_learner.flat()[1]
+                        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                        g.div_(world)
+                    hip_learner.apply()
+                else:
+                    learner_update(batch, weight)
             main_stream.wait_stream(actor_stream)
 
     # fill the ring to capacity (untimed): real ticks for the history, then bulk inserts

@@ -149,6 +149,14 @@ int rela_replay_sample(rela_replay* r, int batch, void* const* out_rows_dev, flo
 int rela_replay_update_priority(rela_replay* r, int n, const float* priority, int on_device,
                                 void* stream);
 
+/* Learners that overlap the sample path with their own backward pass (rela_apex_learner_loss / _grad):
+ * with on = 1, rela_replay_sample and a device-side rela_replay_update_priority no longer make the caller's
+ * stream wait for the replay's stream; the caller inserts that wait itself with rela_replay_wait(r, stream)
+ * before it reads the sampled rows (and keeps the priority buffer untouched until then).  Results do not
+ * change: the replay's own work stays serialised on its stream in call order. */
+int rela_replay_set_deferred_wait(rela_replay* r, int on);
+int rela_replay_wait(rela_replay* r, void* stream);
+
 /* Device pointers to what the last sample() left behind, for exchanges between replay partitions
  * (SURVEY 8e): the un-normalised weights w_i of the outstanding batch (:289) and the float sum
  * the stratified targets were drawn against (:261-262).  Valid until the next sample().       */
@@ -439,6 +447,14 @@ int rela_apex_learner_set_precision(rela_apex_learner* l, int mode);
 int rela_apex_learner_backward(rela_apex_learner* l, int batch, const void* const* rows_dev,
                                const float* weight_dev, float* priority_dev, float* loss_dev,
                                void* stream);
+/* The same step in two calls: _loss runs the three forwards of td_err, the priorities and the loss (arguments as
+ * _backward); _grad the backward pass of that batch.  The backward pass does not touch the replay, so between the
+ * two a caller may feed priority_dev to rela_replay_update_priority and sample the NEXT batch (into other buffers:
+ * the `s` rows of this batch are read until _grad's work is done) -- the sample path then runs next to the
+ * gradient kernels instead of after them.  Same results as _backward, bit for bit. */
+int rela_apex_learner_loss(rela_apex_learner* l, int batch, const void* const* rows_dev,
+                           const float* weight_dev, float* priority_dev, float* loss_dev, void* stream);
+int rela_apex_learner_grad(rela_apex_learner* l, void* stream);
 /* clip_grad_norm_ + optimiser step on the flat buffers, then re-packs the kernel-layout weights.
  * Data-parallel learners all-reduce the gradient buffer between backward and apply.          */
 int rela_apex_learner_apply(rela_apex_learner* l, void* stream);

@@ -81,6 +81,8 @@ _sig("rela_replay_abort_add", i32, [vp, i32, i32])
 _sig("rela_replay_add", i32, [vp, i32, P(vp), vp, i32, vp])
 _sig("rela_replay_sample", i32, [vp, i32, P(vp), vp, vp])
 _sig("rela_replay_update_priority", i32, [vp, i32, vp, i32, vp])
+_sig("rela_replay_set_deferred_wait", i32, [vp, i32])
+_sig("rela_replay_wait", i32, [vp, vp])
 _sig("rela_replay_last_sample_dev", i32, [vp, P(vp), P(vp)])
 _sig("rela_replay_last_sample_size", i32, [vp])
 _sig("rela_replay_shutdown", i32, [vp])
@@ -142,6 +144,8 @@ _sig("rela_apex_learner_load", i32, [vp, P(FFNetParams), P(FFNetParams), i32, vp
 _sig("rela_apex_learner_sync_target", i32, [vp, vp])
 _sig("rela_apex_learner_set_precision", i32, [vp, i32])
 _sig("rela_apex_learner_backward", i32, [vp, i32, P(vp), vp, vp, vp, vp])
+_sig("rela_apex_learner_loss", i32, [vp, i32, P(vp), vp, vp, vp, vp])
+_sig("rela_apex_learner_grad", i32, [vp, vp])
 _sig("rela_apex_learner_apply", i32, [vp, vp])
 _sig("rela_apex_learner_params", i32, [vp, P(FFNetParams), P(FFNetParams)])
 _sig("rela_apex_learner_grads", i32, [vp, P(FFNetParams)])

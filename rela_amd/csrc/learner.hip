@@ -52,6 +52,9 @@ struct rela_apex_learner {
   float* norm = nullptr;  // [0] grad norm, [1] clip coefficient
   float* loss = nullptr;
   bool loaded = false;
+  // batch of the last rela_apex_learner_loss, until rela_apex_learner_grad consumes it
+  int pend_B = 0;
+  const uint8_t* pend_obs = nullptr;
 };
 
 namespace {
@@ -233,9 +236,21 @@ extern "C" const float* rela_apex_learner_stats_dev(const rela_apex_learner* l) 
 extern "C" int rela_apex_learner_backward(rela_apex_learner* l, int batch, const void* const* rows_dev,
                                           const float* weight_dev, float* priority_dev, float* loss_dev,
                                           void* stream_) {
-  RELA_CHECK(l && l->loaded, RELA_ESTATE, "rela_apex_learner_backward: parameters were never loaded");
+  int rc = rela_apex_learner_loss(l, batch, rows_dev, weight_dev, priority_dev, loss_dev, stream_);
+  if (rc != RELA_OK) return rc;
+  return rela_apex_learner_grad(l, stream_);
+}
+
+// The forward half of the step: the three forwards of td_err, the priorities and the loss (with the head gradient
+// d_ha the loss kernel leaves).  `priority_dev` is final when this returns' work is done, so a caller may hand it to
+// update_priority and ask for the next batch while rela_apex_learner_grad still runs (the replay is not touched by
+// the backward pass); the batch's `s` rows must stay untouched until then (conv1's weight gradient reads them).
+extern "C" int rela_apex_learner_loss(rela_apex_learner* l, int batch, const void* const* rows_dev,
+                                      const float* weight_dev, float* priority_dev, float* loss_dev, void* stream_) {
+  RELA_CHECK(l && l->loaded, RELA_ESTATE, "rela_apex_learner_loss: parameters were never loaded");
   RELA_CHECK(batch >= 1 && batch <= l->Bmax && rows_dev && weight_dev && priority_dev, RELA_EINVAL,
-             "rela_apex_learner_backward: bad arguments (batch %d, max %d)", batch, l->Bmax);
+             "rela_apex_learner_loss: bad arguments (batch %d, max %d)", batch, l->Bmax);
+  l->pend_B = 0;
   hipStream_t s = (hipStream_t)stream_;
   DeviceGuard g(l->device);
   const int Bn = batch, A = l->A;
@@ -248,7 +263,7 @@ extern "C" int rela_apex_learner_backward(rela_apex_learner* l, int batch, const
   const float* reward = static_cast<const float*>(rows_dev[7]);
   const float* boot = static_cast<const float*>(rows_dev[9]);
   RELA_CHECK(obs && nobs && legal && nlegal && act && reward && boot, RELA_EINVAL,
-             "rela_apex_learner_backward: a batch field is NULL");
+             "rela_apex_learner_loss: a batch field is NULL");
   float* q_on = l->q;
   float* q_no = l->q + (size_t)Bn * A;
   float* q_nt = l->q + 2 * (size_t)Bn * A;
@@ -267,6 +282,20 @@ extern "C" int rela_apex_learner_backward(rela_apex_learner* l, int batch, const
                        A, l->d_ha, l->loss);
   }
   if (loss_dev) RELA_HIP(hipMemcpyAsync(loss_dev, l->loss, sizeof(float), hipMemcpyDeviceToDevice, s));
+  RELA_LAUNCH_CHECK();
+  l->pend_B = Bn;
+  l->pend_obs = obs;
+  return RELA_OK;
+}
+
+// The backward half: gradients of the last rela_apex_learner_loss into the flat gradient buffer.
+extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
+  RELA_CHECK(l && l->loaded && l->pend_B > 0, RELA_ESTATE, "rela_apex_learner_grad: no rela_apex_learner_loss to differentiate");
+  hipStream_t s = (hipStream_t)stream_;
+  DeviceGuard g(l->device);
+  const int Bn = l->pend_B, A = l->A;
+  const uint8_t* obs = l->pend_obs;
+  l->pend_B = 0;
 
   const FFNetWs w = ffnet_ws(l->ws_on, Bn);
   const rela_ffnet_params P = params_at(l, l->P);

@@ -491,7 +491,8 @@ struct rela_replay {
   int n_sampled = 0;
   int last_full_size = 0;  // size_ as re-read by the last sample_ (:312), the N of its IS weights
   hipStream_t stream = nullptr;
-  hipEvent_t ev_in = nullptr, ev_out = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_wait = nullptr;
+  bool deferred_wait = false;  // rela_replay_set_deferred_wait: sample / update_priority do not stall the caller's stream
   float* d_w = nullptr;
   uint8_t* d_evicted = nullptr;
   ReplayDevState* d_state = nullptr;
@@ -546,6 +547,7 @@ extern "C" int rela_replay_create(rela_replay** out, int capacity, int seed, flo
   }
   RELA_HIP(hipEventCreateWithFlags(&r->ev_in, hipEventDisableTiming));
   RELA_HIP(hipEventCreateWithFlags(&r->ev_out, hipEventDisableTiming));
+  RELA_HIP(hipEventCreateWithFlags(&r->ev_wait, hipEventDisableTiming));
   RELA_HIP(hipMalloc(&r->d_w, sizeof(float) * (size_t)r->ring));
   RELA_HIP(hipMalloc(&r->d_evicted, (size_t)r->ring));
   RELA_HIP(hipMalloc(&r->d_state, sizeof(ReplayDevState)));
@@ -587,6 +589,7 @@ extern "C" void rela_replay_destroy(rela_replay* r) {
   (void)hipFree(r->d_prio);
   (void)hipEventDestroy(r->ev_in);
   (void)hipEventDestroy(r->ev_out);
+  (void)hipEventDestroy(r->ev_wait);
   (void)hipStreamDestroy(r->stream);
   delete r;
 }
@@ -991,8 +994,10 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
                        (const int32_t*)r->d_ids, batch);
   }
   RELA_LAUNCH_CHECK();
-  RELA_HIP(hipEventRecord(r->ev_out, r->stream));
-  RELA_HIP(hipStreamWaitEvent(consumer, r->ev_out, 0));
+  if (!r->deferred_wait) {
+    RELA_HIP(hipEventRecord(r->ev_out, r->stream));
+    RELA_HIP(hipStreamWaitEvent(consumer, r->ev_out, 0));
+  }
   r->n_sampled = batch;
   lk.unlock();
   if (n_pop > 0) r->cv_size.notify_all();
@@ -1024,11 +1029,27 @@ extern "C" int rela_replay_update_priority(rela_replay* r, int n, const float* p
                        r->d_w, r->d_state);
   }
   RELA_LAUNCH_CHECK();
-  if (on_device) {
+  if (on_device && !r->deferred_wait) {
     RELA_HIP(hipEventRecord(r->ev_out, r->stream));
     RELA_HIP(hipStreamWaitEvent(producer, r->ev_out, 0));
   }
   r->n_sampled = 0;  // sampledIds_.clear() :244
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_set_deferred_wait(rela_replay* r, int on) {
+  RELA_CHECK(r, RELA_EINVAL, "rela_replay_set_deferred_wait: bad arguments");
+  std::unique_lock<std::mutex> lk(r->m);
+  r->deferred_wait = on != 0;
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_wait(rela_replay* r, void* stream_) {
+  RELA_CHECK(r, RELA_EINVAL, "rela_replay_wait: bad arguments");
+  DeviceGuard g(r->device);
+  std::unique_lock<std::mutex> lk(r->m);
+  RELA_HIP(hipEventRecord(r->ev_wait, r->stream));
+  RELA_HIP(hipStreamWaitEvent((hipStream_t)stream_, r->ev_wait, 0));
   return RELA_OK;
 }
 

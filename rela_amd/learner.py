@@ -168,6 +168,18 @@ class HipApexLearner:
     def backward(self, batch, weight):
         """batch: the namespace FFReplay.sample returns (or any object with obs / next_obs / action /
         reward / terminal / bootstrap of cuda tensors); weight: cuda f32[B].  -> (loss[1], priority[B])."""
+        return self._forward_half(batch, weight, "rela_apex_learner_backward")
+
+    def loss(self, batch, weight):
+        """The forward half of `backward` (forwards, priorities, loss); `grad()` runs the backward pass of it.  In
+        between the caller may update_priority and sample the next batch into OTHER buffers (FFReplay.sample(...,
+        slot=1 - slot)): the replay's sample path then runs next to the gradient kernels."""
+        return self._forward_half(batch, weight, "rela_apex_learner_loss")
+
+    def grad(self):
+        self._capi.check(self._capi.lib.rela_apex_learner_grad(self.h, self._stream()), "rela_apex_learner_grad")
+
+    def _forward_half(self, batch, weight, entry):
         C, capi = self._C, self._capi
         B = weight.numel()
         t = {"s": batch.obs["s"], "next_s": batch.next_obs["s"], "eps": batch.obs["eps"],
@@ -178,10 +190,9 @@ class HipApexLearner:
         w = weight.detach().float().contiguous()
         rows = (C.c_void_p * 10)(*[x.data_ptr() for x in keep])
         self._keep = (keep, w)
-        capi.check(capi.lib.rela_apex_learner_backward(self.h, B, rows, C.c_void_p(w.data_ptr()),
-                                                       C.c_void_p(self._prio.data_ptr()),
-                                                       C.c_void_p(self._loss.data_ptr()), self._stream()),
-                   "rela_apex_learner_backward")
+        capi.check(getattr(capi.lib, entry)(self.h, B, rows, C.c_void_p(w.data_ptr()),
+                                            C.c_void_p(self._prio.data_ptr()),
+                                            C.c_void_p(self._loss.data_ptr()), self._stream()), entry)
         return self._loss, self._prio[:B]
 
     def apply(self):

@@ -76,21 +76,23 @@ class FFReplay:
         return rc
 
     # -- learner side -------------------------------------------------------------------
-    def _buffers(self, batch):
-        if batch not in self._out:
+    def _buffers(self, batch, slot=0):
+        if (batch, slot) not in self._out:
             dev, A = self.device, self.num_action
             mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
-            self._out[batch] = dict(
+            self._out[(batch, slot)] = dict(
                 s=mk((batch, 4, 84, 84), torch.uint8), next_s=mk((batch, 4, 84, 84), torch.uint8),
                 eps=mk((batch, 1), torch.float32), next_eps=mk((batch, 1), torch.float32),
                 legal_move=mk((batch, A), torch.float32), next_legal_move=mk((batch, A), torch.float32),
                 a=mk((batch,), torch.int64), reward=mk((batch,), torch.float32), terminal=mk((batch,), torch.bool),
                 bootstrap=mk((batch,), torch.float32), weight=mk((batch,), torch.float32))
-        return self._out[batch]
+        return self._out[(batch, slot)]
 
-    def sample(self, batchsize, device=None, gather=True):
-        """-> (FFTransition-like namespace, IS weights); tensors live on the replay's GPU."""
-        b = self._buffers(batchsize)
+    def sample(self, batchsize, device=None, gather=True, slot=0):
+        """-> (FFTransition-like namespace, IS weights); tensors live on the replay's GPU.  The batch is written into
+        the output buffers of `slot`: a caller that samples the next batch while the previous one is still being
+        read (HipApexLearner.loss / grad) alternates between two slots."""
+        b = self._buffers(batchsize, slot)
         rows = (C.c_void_p * len(self.FIELDS))(*[b[f].data_ptr() for f in self.FIELDS]) if gather else None
         capi.check(capi.lib.rela_replay_sample(self.h, batchsize, rows, C.c_void_p(b["weight"].data_ptr()),
                                                _stream_ptr(self.device)), "rela_replay_sample")
@@ -110,6 +112,13 @@ class FFReplay:
         else:
             rc = capi.lib.rela_replay_update_priority(self.h, p.numel(), C.c_void_p(p.data_ptr()), 0, None)
         capi.check(rc, "rela_replay_update_priority")
+
+    def set_deferred_wait(self, on):
+        """on: sample / update_priority no longer stall the caller's stream; call wait() before reading a batch."""
+        capi.check(capi.lib.rela_replay_set_deferred_wait(self.h, int(bool(on))), "rela_replay_set_deferred_wait")
+
+    def wait(self):
+        capi.check(capi.lib.rela_replay_wait(self.h, _stream_ptr(self.device)), "rela_replay_wait")
 
     def debug_state(self):
         st = capi.ReplayState()
@@ -145,6 +154,8 @@ class RNNReplay:
     size = FFReplay.size
     num_add = FFReplay.num_add
     update_priority = FFReplay.update_priority
+    set_deferred_wait = FFReplay.set_deferred_wait
+    wait = FFReplay.wait
     debug_state = FFReplay.debug_state
 
     def _buffers(self, batch):

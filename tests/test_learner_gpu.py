@@ -112,6 +112,64 @@ def test_learner_fast_mode_within_stated_tolerance(B):
     learner.close()
 
 
+def test_pipelined_step_is_bit_identical_to_the_sequential_one():
+    """rela_apex_learner_loss / _grad with the replay in deferred-wait mode: update_priority and the NEXT sample are
+    queued between the two halves (the sample path then runs next to the gradient kernels; batches alternate between
+    two buffer slots).  Sampled ids, IS weights, priorities, losses and the parameters after six steps must equal the
+    strictly sequential sample -> backward -> apply -> update_priority loop bit for bit."""
+    import ctypes as C
+
+    import torch
+
+    from rela_amd import _capi as capi
+    from rela_amd.learner import HipApexLearner
+    from rela_amd.replay import FFReplay
+
+    A, B, cap, rows = 6, 64, 512, 640
+    data, _ = make_batch(rows, A, 5)
+    prio = torch.rand(rows, device="cuda") * 3 + 0.05
+    out = []
+    for pipelined in (False, True):
+        agent = make_agent(A, 9)
+        learner = HipApexLearner.from_agent(agent, B)
+        rep = FFReplay(cap, 17, 0.6, 0.4, 0, A, "cuda:0")
+        ptrs = [data.obs["s"], data.next_obs["s"], data.obs["eps"], data.next_obs["eps"], data.obs["legal_move"],
+                data.next_obs["legal_move"], data.action["a"], data.reward, data.terminal.to(torch.uint8),
+                data.bootstrap]
+        for lo in range(0, rows, 128):  # more rows than capacity: the first sample evicts
+            rep.add_rows(128, [t[lo:lo + 128].contiguous().data_ptr() for t in ptrs], prio[lo:lo + 128].contiguous())
+        trace = []
+        if not pipelined:
+            for k in range(6):
+                batch, w = rep.sample(B)
+                loss, p = learner.step(batch, w)
+                rep.update_priority(p)
+                trace.append((batch.action["a"].clone(), batch.reward.clone(), w.clone(), p.clone(), loss.clone()))
+        else:
+            rep.set_deferred_wait(True)
+            nxt = rep.sample(B, slot=0)
+            for k in range(6):
+                batch, w = nxt
+                rep.wait()
+                loss, p = learner.loss(batch, w)
+                rep.update_priority(p)
+                trace.append((batch.action["a"].clone(), batch.reward.clone(), w.clone(), p.clone(), loss.clone()))
+                if k < 5:
+                    nxt = rep.sample(B, slot=(k + 1) & 1)
+                learner.grad()
+                learner.apply()
+            rep.wait()
+        torch.cuda.synchronize()
+        assert rep.debug_state()["dev_error"] == 0
+        out.append((trace, learner.flat()[0].clone()))
+        learner.close()
+        rep.close()
+    for a, b in zip(out[0][0], out[1][0]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert torch.equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize("opt", ["rmsprop", "adam"])
 def test_clip_and_optimizer_match_torch_on_identical_gradients(opt):
     """clip_grad_norm_ + optimiser arithmetic in isolation: autograd's gradients are copied into the
