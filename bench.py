@@ -376,8 +376,8 @@ def bench_r2d2(args, world, rank, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # default window: 600 steps of ~3.5 ms = ~2 s of timed work (r01's 20-step window was 72 ms)
-    ap.add_argument("--steps", type=int, default=600)
+    # default window: 1,500 steps of ~1.6 ms = ~2.5 s of timed work per region (r01's 20-step window was 72 ms)
+    ap.add_argument("--steps", type=int, default=1500)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--replay-cap", type=int, default=None)
