@@ -17,6 +17,7 @@
 //             dW_hh = DG^T x H_prev, dW_ih = DG^T x a3, d_a3 = DG x W_ih (ReLU mask) and the shared conv-trunk
 //             backward of learner_common.h.  Every contraction is an instance of gemm_lds (f32 MFMA).
 //   update    clip_grad_norm_ + Adam (pyrela/main.py:124-126,233-238) on flat buffers in state_dict order.
+#include "gemm_bf16s.h"
 #include "learner_common.h"
 
 using namespace rela_amd;
@@ -571,7 +572,14 @@ struct rela_r2d2_learner {
   float* rec_part = nullptr;                                          // split-K partials of the recurrent GEMMs
   unsigned* rec_bar = nullptr;                                        // [0] timeout word, [4 ..] per-step arrival counters
   bool rec_persist = true;
-  int precision = 0;  // 1: the target net's conv trunk (no gradient, activations never read back) on split-bf16 MFMA
+  // 1: the target net's conv trunk (no gradient, activations never read back) and the three large GEMMs of the LSTM's
+  //    input side (gate GEMM of both nets, its data and weight gradients) on split-bf16 MFMA (gemm_bf16s.h)
+  int precision = 0;
+  // rec64 operands of those GEMMs (hi | lo bf16 records, 4 bytes per element)
+  uint8_t* wrec[2] = {nullptr, nullptr};  // W_ih [2048][49 chunks], k = pos * 64 + c       (gate GEMM, per net)
+  uint8_t* wTrec = nullptr;               // W_ih^T [3136][32 chunks], online                 (data gradient)
+  uint8_t *arec = nullptr, *trec = nullptr;  // activations / gate gradients by rows; transposed operands of dW_ih
+  uint64_t wver[2] = {1, 1}, rec_ver[2] = {0, 0};  // weight version (repack) / version the records were made from
   float *ha = nullptr, *q_on = nullptr, *q_tg = nullptr;              // heads of the training rows
   float *qmin = nullptr, *qa_on = nullptr, *qa_tg = nullptr, *dqa = nullptr, *d_ha = nullptr, *d_o = nullptr;
   float *dc_rec = nullptr;
@@ -610,6 +618,7 @@ int repack_r2d2(rela_r2d2_learner* l, bool online, bool target, hipStream_t s) {
     hipLaunchKernelGGL(pack_lstm_learner, dim3(ceil_div(total, 256)), dim3(256), 0, s, p.w_ih, p.w_hh, p.b_ih, p.b_hh,
                        l->wihT[0], l->wihp, l->whhT[0], l->bsum[0]);
     RELA_LAUNCH_CHECK();
+    l->wver[0] += 1;
   }
   if (target) {
     const rela_lstmnet_params p = lparams_at(l, l->PT);
@@ -618,7 +627,29 @@ int repack_r2d2(rela_r2d2_learner* l, bool online, bool target, hipStream_t s) {
     hipLaunchKernelGGL(pack_lstm_learner, dim3(ceil_div(total, 256)), dim3(256), 0, s, p.w_ih, p.w_hh, p.b_ih, p.b_hh,
                        l->wihT[1], (float*)nullptr, l->whhT[1], l->bsum[1]);
     RELA_LAUNCH_CHECK();
+    l->wver[1] += 1;
   }
+  return RELA_OK;
+}
+
+// rec64 copies of W_ih for the split-bf16 GEMMs, made from the packed f32 copies when those changed
+int refresh_weight_records(rela_r2d2_learner* l, int which, hipStream_t s) {
+  if (l->rec_ver[which] == l->wver[which]) return RELA_OK;
+  using namespace gemm16;
+  ProfScope prof("learner_lstm_split_w", s);
+  if (which == 0) {
+    // wihp [2048][3136] (k = pos * 64 + c) row-wise; wihT [3136][2048] row-wise = W_ih^T
+    hipLaunchKernelGGL(split_rows_rec64, dim3(ceil_div((int64_t)kGates * kFeat / 8, 256)), dim3(256), 0, s,
+                       (const float*)l->wihp, (int64_t)kGates, kFeat, l->wrec[0]);
+    hipLaunchKernelGGL(split_rows_rec64, dim3(ceil_div((int64_t)kGates * kFeat / 8, 256)), dim3(256), 0, s,
+                       (const float*)l->wihT[0], (int64_t)kFeat, kGates, l->wTrec);
+  } else {
+    // the target net keeps only wihT [3136][2048]: its columns are W_ih's rows
+    hipLaunchKernelGGL(split_cols_rec64, dim3(kGates / 64, kFeat / 64), dim3(256), 0, s, (const float*)l->wihT[1],
+                       (int64_t)kFeat, kGates, 0, l->wrec[1]);
+  }
+  RELA_LAUNCH_CHECK();
+  l->rec_ver[which] = l->wver[which];
   return RELA_OK;
 }
 
@@ -636,10 +667,24 @@ int forward_pre(rela_r2d2_learner* l, int which, int Bn, const uint8_t* obs, con
   // the online pass leaves a1 / a2 / a3 for the backward kernels: always f32
   int rc = lstmnet_trunk(net, rowsAll, obs, l->a1, l->a2, l->a3, s, kTrunkNames, which == 1 && l->precision == 1);
   if (rc != RELA_OK) return rc;
-  ProbGateX p{};
-  p.M = rowsAll, p.N = kGates, p.K = kFeat;
-  p.a3 = l->a3, p.wihT = l->wihT[which], p.bias = l->bsum[which], p.gx = l->gxs[which];
-  launch_gemm<TileRows>(p, 1, s, "learner_lstm_gates_x");
+  if (l->precision == 1) {
+    using namespace gemm16;
+    rc = refresh_weight_records(l, which, s);
+    if (rc != RELA_OK) return rc;
+    {
+      ProfScope prof("learner_lstm_split_rows", s);
+      hipLaunchKernelGGL(split_rows_rec64, dim3(ceil_div((int64_t)rowsAll * kFeat / 8, 256)), dim3(256), 0, s,
+                         (const float*)l->a3, (int64_t)rowsAll, kFeat, l->arec);
+    }
+    rc = launch_rec64_nt(l->arec, l->wrec[which], rowsAll, kGates, kFeat / 64,
+                         EpiBias{l->gxs[which], l->bsum[which], kGates}, s, "learner_lstm_gates_x");
+    if (rc != RELA_OK) return rc;
+  } else {
+    ProbGateX p{};
+    p.M = rowsAll, p.N = kGates, p.K = kFeat;
+    p.a3 = l->a3, p.wihT = l->wihT[which], p.bias = l->bsum[which], p.gx = l->gxs[which];
+    launch_gemm<TileRows>(p, 1, s, "learner_lstm_gates_x");
+  }
   const size_t blk = (size_t)Bn * kHid;
   RELA_HIP(hipMemcpyAsync(l->Hs[which], h0, blk * sizeof(float), hipMemcpyDeviceToDevice, s));
   RELA_HIP(hipMemcpyAsync(l->Cs[which], c0, blk * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -763,6 +808,20 @@ extern "C" int rela_r2d2_learner_create(rela_r2d2_learner** out, int num_action,
     R2_ALLOC(l->Cs[w], (T + 1) * B * kHid, true);
   }
   R2_ALLOC(l->wihp, (size_t)kGates * kFeat, false);
+  {
+    const size_t chunks = (rowsAll + 63) / 64;
+    float* tmp = nullptr;
+    for (int w = 0; w < 2; ++w) {
+      R2_ALLOC(tmp, (size_t)kGates * kFeat, false);
+      l->wrec[w] = reinterpret_cast<uint8_t*>(tmp);
+    }
+    R2_ALLOC(tmp, (size_t)kGates * kFeat, false);
+    l->wTrec = reinterpret_cast<uint8_t*>(tmp);
+    R2_ALLOC(tmp, rowsAll * kFeat, false);
+    l->arec = reinterpret_cast<uint8_t*>(tmp);
+    R2_ALLOC(tmp, (size_t)(kGates + kFeat) * chunks * 64, false);  // [2048][chunks] followed by [3136][chunks]
+    l->trec = reinterpret_cast<uint8_t*>(tmp);
+  }
   R2_ALLOC(l->a1, rowsAll * kA1, false);
   R2_ALLOC(l->a2, rowsAll * kA2, false);
   R2_ALLOC(l->a3, rowsAll * kA3, false);
@@ -813,6 +872,11 @@ extern "C" void rela_r2d2_learner_destroy(rela_r2d2_learner* l) {
   for (void* p : ps) (void)hipFree(p);
   (void)hipFree(l->rec_bar);
   (void)hipFree(l->gxs[1]);
+  (void)hipFree(l->wrec[0]);
+  (void)hipFree(l->wrec[1]);
+  (void)hipFree(l->wTrec);
+  (void)hipFree(l->arec);
+  (void)hipFree(l->trec);
   rela_lstmnet_destroy(l->online);
   rela_lstmnet_destroy(l->target);
   delete l;
@@ -998,7 +1062,21 @@ extern "C" int rela_r2d2_learner_backward(rela_r2d2_learner* l, int batch, const
     p.dg = DG, p.hprev = hprev, p.out = Gm[7];
     launch_gemm<TileWg>(p, 1, s, "learner_wgrad_lstm_hh");
   }
-  {
+  if (l->precision == 1) {
+    // dW_ih[g][c*49+pos] = sum_r dg[r][g] * a3[r][pos*64+c]: both operands transposed into rec64 rows of 64 r each
+    // (a3's columns land in weight_ih_l0's own column order, so the result is stored row-major as it is)
+    using namespace gemm16;
+    const int chunks = ceil_div(rowsTr, 64);
+    uint8_t* dgT = l->trec;
+    uint8_t* a3T = l->trec + (size_t)kGates * chunks * REC;
+    {
+      ProfScope prof("learner_lstm_split_cols", s);
+      hipLaunchKernelGGL(split_cols_rec64, dim3(kGates / 64, chunks), dim3(256), 0, s, DG, (int64_t)rowsTr, kGates, 0, dgT);
+      hipLaunchKernelGGL(split_cols_rec64, dim3(kFeat / 64, chunks), dim3(256), 0, s, a3_tr, (int64_t)rowsTr, kFeat, 1, a3T);
+    }
+    int rc = launch_rec64_nt(dgT, a3T, kGates, kFeat, chunks, EpiPlain{Gm[6], kFeat}, s, "learner_wgrad_lstm_ih");
+    if (rc != RELA_OK) return rc;
+  } else {
     ProbWih p{};
     p.M = kGates, p.N = kFeat, p.K = rowsTr;
     p.dg = DG, p.a3 = a3_tr, p.out = Gm[6];
@@ -1006,7 +1084,17 @@ extern "C" int rela_r2d2_learner_backward(rela_r2d2_learner* l, int batch, const
   }
   colsum_launch(DG, rowsTr, kGates, l->cpart, Gm[8], s);  // bias_ih_l0 and bias_hh_l0 see the same gradient
   RELA_HIP(hipMemcpyAsync(Gm[9], Gm[8], sizeof(float) * kGates, hipMemcpyDeviceToDevice, s));
-  {
+  if (l->precision == 1) {
+    using namespace gemm16;
+    {
+      ProfScope prof("learner_lstm_split_rows", s);
+      hipLaunchKernelGGL(split_rows_rec64, dim3(ceil_div((int64_t)rowsTr * kGates / 8, 256)), dim3(256), 0, s, DG,
+                         (int64_t)rowsTr, kGates, l->arec);
+    }
+    int rc = launch_rec64_nt(l->arec, l->wTrec, rowsTr, kFeat, kGates / 64, EpiReluMask{l->d_a3, a3_tr, kFeat}, s,
+                             "learner_dgrad_lstm_ih");
+    if (rc != RELA_OK) return rc;
+  } else {
     ProbIhDgrad p{};
     p.M = rowsTr, p.N = kFeat, p.K = kGates;
     p.dg = DG, p.wihp = l->wihp, p.a3 = a3_tr, p.d_a3 = l->d_a3;

@@ -213,8 +213,11 @@ def test_hip_r2d2_learner_adam_step_and_trajectory():
 
 
 def test_hip_r2d2_learner_fast_target_trunk_within_tolerance():
-    """set_precision("bf16x2"): the target net's conv trunk (no gradient, its activations are never read back) runs on
-    split-bf16 MFMA; loss, priorities and gradients stay within the fast mode's tolerance of the all-f32 step."""
+    """set_precision("bf16x2"): the target net's conv trunk (no gradient, its activations are never read back) and the
+    three large GEMMs of the LSTM's input side -- the gate GEMM of both nets, its data gradient and its weight gradient
+    (csrc/gemm_bf16s.h: hi + lo bf16 operands, three MFMAs per product, f32 accumulation) -- run on split-bf16 MFMA;
+    loss, priorities and gradients stay within the fast mode's tolerance of the all-f32 step.  T * B = 336 rows and
+    240 training rows: every GEMM has a ragged last row block and the weight gradient a zero-padded last k-chunk."""
     import torch
 
     from rela_amd.learner import HipR2D2Learner

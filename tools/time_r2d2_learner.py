@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel HIP-event timings of the isolated R2D2 learner step at C4's shape (B = 64, seq 80 / burn 40 / n 3).
 
-  ITERS=10 python tools/time_r2d2_learner.py      -> one line: kernel -> ms per step
+  ITERS=10 [PRECISION=bf16x2] python tools/time_r2d2_learner.py      -> one line: kernel -> ms per step
 """
 import ctypes as C
 import json
@@ -24,6 +24,7 @@ rng = np.random.default_rng(5)
 agent = _agent(A, N, 0.997, 0.9, SEQ, BURN, 71, 72, "cuda:0")
 batch, weight = _random_batch(rng, A, B, SEQ, BURN, N, "cuda:0")
 learner = HipR2D2Learner.from_agent(agent, B)
+learner.set_precision(os.environ.get("PRECISION", "f32"))
 for _ in range(2):
     learner.step(batch, weight)
 learner.check()
