@@ -14,6 +14,10 @@ cp $F/time_sample.json profiles/r02_time_sample_isolated.json
 cp $F/r2d2_learner.log profiles/r02_r2d2_learner_isolated.log
 cp $F/threaded_benchmark.log profiles/r02_threaded_benchmark_final.log
 cp $F/threaded_benchmark_r2d2.log profiles/r02_threaded_benchmark_r2d2_final.log
+[ -f $F/bench_rehearsal_2ranks.json ] && cp $F/bench_rehearsal_2ranks.json profiles/r02_bench_rehearsal_2ranks_one_gpu.json || true
+[ -f $F/bench_only_learner.json ] && cp $F/bench_only_learner.json profiles/r02_bench_only_learner.json || true
+[ -f $F/bench_only_actor.json ] && cp $F/bench_only_actor.json profiles/r02_bench_only_actor.json || true
+[ -f $F/lds_conflicts.txt ] && cp $F/lds_conflicts.txt profiles/r02_lds_conflict_model_conv12.txt || true
 cp "$(newest "$F/prof_bench/*/*_kernel_stats.csv")" profiles/r02_bench_kernel_stats.csv
 cp "$(newest "$F/iso_stats/*/*_kernel_stats.csv")" profiles/r02_isolated_kernel_stats.csv
 python3 tools/per_shape_stats.py $F/prof_bench profiles/r02_bench_kernel_per_shape.csv
@@ -24,8 +28,9 @@ python3 - <<'PY'
 import json
 d = json.load(open("profiles/r02_bench_latest.json"))
 r = d["roofline"]
-print("bench: %.3f M env-steps/s, %.0f grad-steps/s, %.3f ms/step; no_reuse %.3f M; f32_mode %.3f M" % (
-    d["value"] / 1e6, d["grad_steps_per_s"], d["ms_per_step"], d["no_reuse"]["env_steps_per_s"] / 1e6,
+print("bench: %.3f M env-steps/s, %.0f grad-steps/s, %.3f ms/step, %.2f forwards/tick; reuse_next_only %.3f M; no_reuse %.3f M; f32_mode %.3f M" % (
+    d["value"] / 1e6, d["grad_steps_per_s"], d["ms_per_step"], d["forwards_per_tick"],
+    d["reuse_next_only"]["env_steps_per_s"] / 1e6, d["no_reuse"]["env_steps_per_s"] / 1e6,
     d["f32_mode"]["env_steps_per_s"] / 1e6))
 print("roofline: %s %s frac %.3f (mfma %.3f, hbm %.3f), %.1f us live, traffic %s" % (
     r["kernel"], r["bound"], r["frac"], r["mfma"]["frac"], r["hbm"]["frac"], r["avg_launch_ms"] * 1e3, r["traffic"]))

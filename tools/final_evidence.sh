@@ -10,7 +10,10 @@
 #   bench_dedup_2p23.json    `python bench.py --dedup plane --replay-cap 8388608` (BASELINE C5's replay on ONE GPU)
 #   forward_modes.log        per-kernel forward timings: N = 512 / 6400, f32 and bf16x2, fused and unfused conv1 -> conv2
 #   time_sample.json         tools/time_sample.py (isolated sample path, ring 1,310,720)
-#   r2d2_learner.log         tools/time_r2d2_learner.py (isolated R2D2 learner step, persistent vs per-step launches)
+#   r2d2_learner.log         tools/time_r2d2_learner.py (isolated R2D2 learner step: bf16x2 / f32, persistent vs per-step launches)
+#   bench_rehearsal_2ranks.json   `bench.py --gpus 2` with both ranks on the one card over gloo (N > 1 code path)
+#   bench_only_{learner,actor}.json   one side of the step alone (diagnosis: RELA_BENCH_ONLY)
+#   lds_conflicts.txt        tools/lds_conflicts.py (bank-conflict model of conv12_bf16s; compare SQ_LDS_BANK_CONFLICT)
 #   threaded_benchmark*.log  rela_amd/pyrela/benchmark.py through the C++ actor threads
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -53,10 +56,15 @@ cut -c1-400 $O/bench_dedup_2p23.json
 cat $O/forward_modes.log
 timeout -k 10 300 python tools/time_sample.py > $O/time_sample.json 2> $O/time_sample.err || exit 14
 tail -2 $O/time_sample.json | cut -c1-400
-{ TAG=persistent timeout -k 10 200 python tools/time_r2d2_learner.py 2>&1 | tail -1; RELA_R2D2_REC=steps TAG=per-step timeout -k 10 200 python tools/time_r2d2_learner.py 2>&1 | tail -1; } > $O/r2d2_learner.log
+{ TAG="bf16x2 (bench default), persistent" PRECISION=bf16x2 timeout -k 10 200 python tools/time_r2d2_learner.py 2>&1 | tail -1; TAG="f32, persistent" timeout -k 10 200 python tools/time_r2d2_learner.py 2>&1 | tail -1; RELA_R2D2_REC=steps TAG="f32, per-step launches" timeout -k 10 200 python tools/time_r2d2_learner.py 2>&1 | tail -1; } > $O/r2d2_learner.log
 cut -c1-300 $O/r2d2_learner.log
 timeout -k 10 400 python rela_amd/pyrela/benchmark.py --grid 64x100 --epoch_sec 1.5 --num_epoch 4 --replay_buffer_size 2097152 --burn_in_frames 20000 > $O/threaded_benchmark.log 2>&1 || { tail -5 $O/threaded_benchmark.log; exit 9; }
 tail -4 $O/threaded_benchmark.log
 timeout -k 10 300 python rela_amd/pyrela/benchmark.py --algo r2d2 --grid 32x100 --epoch_sec 2 --num_epoch 4 --replay_buffer_size 8192 --burn_in_frames 200 --episode_len 400 > $O/threaded_benchmark_r2d2.log 2>&1 || { tail -5 $O/threaded_benchmark_r2d2.log; exit 11; }
 tail -3 $O/threaded_benchmark_r2d2.log
+RELA_BENCH_REHEARSAL=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 200 --warmup 5 --replay-cap 262144 --no-cpu-baseline > $O/bench_rehearsal_2ranks.json 2> $O/bench_rehearsal_2ranks.err || { tail -5 $O/bench_rehearsal_2ranks.err; exit 15; }
+cut -c1-300 $O/bench_rehearsal_2ranks.json
+RELA_BENCH_ONLY=learner timeout -k 10 200 python bench.py --no-cpu-baseline --steps 300 > $O/bench_only_learner.json 2> /dev/null
+RELA_BENCH_ONLY=actor timeout -k 10 200 python bench.py --no-cpu-baseline --steps 300 > $O/bench_only_actor.json 2> /dev/null
+python tools/lds_conflicts.py > $O/lds_conflicts.txt
 find $O -name "*.csv" -size +8M -delete
