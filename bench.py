@@ -270,6 +270,11 @@ def bench_r2d2(args, world, rank, device):
             engine.post_step(reward, term, online, target, nonblocking=True)
         tick_idx[0] += 1
 
+    R2_PIPE = os.environ.get("RELA_BENCH_PIPELINE", "1") == "1"
+    r2_pending, r2_slot = [None], [0]
+    if R2_PIPE:
+        replay.set_deferred_wait(True)
+
     def one_step():
         with torch.cuda.stream(main_stream):
             k = step_idx[0]
@@ -279,10 +284,29 @@ def bench_r2d2(args, world, rank, device):
                 main_stream.wait_stream(actor_stream)
                 learner.publish(online, target)
                 actor_stream.wait_stream(main_stream)
-            batch, weight = replay.sample(B_LOCAL)
+            if r2_pending[0] is None:
+                r2_pending[0] = replay.sample(B_LOCAL, slot=r2_slot[0])
+                r2_slot[0] ^= 1 if R2_PIPE else 0
+            batch, weight = r2_pending[0]
+            r2_pending[0] = None
             actor_tick()
-            loss, prio = learner.step(batch, weight, world_size=world)
-            replay.update_priority(prio)
+            if R2_PIPE:
+                # as the Ape-X step below: update_priority and the next sample (0.44 ms: the time-major gather of
+                # 64 x 3.47 MB) are queued between the forward and the backward half and run next to BPTT
+                replay.wait()
+                loss, prio, _ = learner.loss(batch, weight)
+                replay.update_priority(prio)
+                r2_pending[0] = replay.sample(B_LOCAL, slot=r2_slot[0])
+                r2_slot[0] ^= 1
+                learner.grad()
+                if world > 1:
+                    g = learner.flat()[1]
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                    g.div_(world)
+                learner.apply()
+            else:
+                loss, prio = learner.step(batch, weight, world_size=world)
+                replay.update_priority(prio)
             main_stream.wait_stream(actor_stream)
         step_idx[0] += 1
 

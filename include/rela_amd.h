@@ -494,6 +494,13 @@ int rela_r2d2_learner_sync_target(rela_r2d2_learner* l, void* stream); /* r2d2.p
 int rela_r2d2_learner_backward(rela_r2d2_learner* l, int batch, const void* const* rows_dev,
                                const float* weight_dev, float* priority_dev, float* loss_dev,
                                float* loss_seq_dev, void* stream);
+/* The same step in two calls, as rela_apex_learner_loss / rela_apex_learner_grad: priority_dev is final after
+ * _loss, so rela_replay_update_priority and the next rela_replay_sample (into other buffers) may be queued before
+ * _grad; same results as _backward, bit for bit. */
+int rela_r2d2_learner_loss(rela_r2d2_learner* l, int batch, const void* const* rows_dev,
+                           const float* weight_dev, float* priority_dev, float* loss_dev,
+                           float* loss_seq_dev, void* stream);
+int rela_r2d2_learner_grad(rela_r2d2_learner* l, void* stream);
 int rela_r2d2_learner_apply(rela_r2d2_learner* l, void* stream); /* clip + optimiser + repack */
 int rela_r2d2_learner_params(rela_r2d2_learner* l, rela_lstmnet_params* online_out,
                              rela_lstmnet_params* target_out);

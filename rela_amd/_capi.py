@@ -156,6 +156,8 @@ _sig("rela_r2d2_learner_destroy", None, [vp])
 _sig("rela_r2d2_learner_load", i32, [vp, P(LSTMNetParams), P(LSTMNetParams), i32, vp])
 _sig("rela_r2d2_learner_sync_target", i32, [vp, vp])
 _sig("rela_r2d2_learner_backward", i32, [vp, i32, P(vp), vp, vp, vp, vp, vp])
+_sig("rela_r2d2_learner_loss", i32, [vp, i32, P(vp), vp, vp, vp, vp, vp])
+_sig("rela_r2d2_learner_grad", i32, [vp, vp])
 _sig("rela_r2d2_learner_apply", i32, [vp, vp])
 _sig("rela_r2d2_learner_params", i32, [vp, P(LSTMNetParams), P(LSTMNetParams)])
 _sig("rela_r2d2_learner_grads", i32, [vp, P(LSTMNetParams)])

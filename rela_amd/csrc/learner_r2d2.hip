@@ -588,6 +588,9 @@ struct rela_r2d2_learner {
   double* npart = nullptr;
   float *norm = nullptr, *loss = nullptr, *loss_seq = nullptr;
   bool loaded = false;
+  // batch of the last rela_r2d2_learner_loss, until rela_r2d2_learner_grad consumes it
+  int pend_B = 0;
+  const uint8_t* pend_obs = nullptr;
 };
 
 namespace {
@@ -964,11 +967,24 @@ extern "C" int rela_r2d2_learner_check(rela_r2d2_learner* l, void* stream_) {
 extern "C" int rela_r2d2_learner_backward(rela_r2d2_learner* l, int batch, const void* const* rows_dev,
                                           const float* weight_dev, float* priority_dev, float* loss_dev,
                                           float* loss_seq_dev, void* stream_) {
-  RELA_CHECK(l && l->loaded, RELA_ESTATE, "rela_r2d2_learner_backward: parameters were never loaded");
+  int rc = rela_r2d2_learner_loss(l, batch, rows_dev, weight_dev, priority_dev, loss_dev, loss_seq_dev, stream_);
+  if (rc != RELA_OK) return rc;
+  return rela_r2d2_learner_grad(l, stream_);
+}
+
+// The forward half of the step (both unrolls, sequence TD errors, aggregated priorities, loss, head gradient) and,
+// below, the backward half (BPTT, weight and data gradients): as rela_apex_learner_loss / _grad -- the priorities are
+// final after the first half, so update_priority and the next sample may be queued between the two; the batch's
+// frames must stay untouched until the second half's work is done.
+extern "C" int rela_r2d2_learner_loss(rela_r2d2_learner* l, int batch, const void* const* rows_dev,
+                                      const float* weight_dev, float* priority_dev, float* loss_dev,
+                                      float* loss_seq_dev, void* stream_) {
+  RELA_CHECK(l && l->loaded, RELA_ESTATE, "rela_r2d2_learner_loss: parameters were never loaded");
   RELA_CHECK(batch >= 1 && batch <= l->Bmax && rows_dev && weight_dev && priority_dev, RELA_EINVAL,
-             "rela_r2d2_learner_backward: bad arguments (batch %d, max %d)", batch, l->Bmax);
+             "rela_r2d2_learner_loss: bad arguments (batch %d, max %d)", batch, l->Bmax);
   hipStream_t s = (hipStream_t)stream_;
   DeviceGuard g(l->device);
+  l->pend_B = 0;
   const int Bn = batch, A = l->A, T = l->T, burn = l->burn, Tt = T - burn, rowsTr = Tt * Bn;
   // RNNTransition batch, time-major (types.cc:140-182), in the order of the 10-field sequence schema
   const uint8_t* obs = static_cast<const uint8_t*>(rows_dev[0]);     // [T][B][4][84][84]
@@ -981,7 +997,7 @@ extern "C" int rela_r2d2_learner_backward(rela_r2d2_learner* l, int batch, const
   const float* c0 = static_cast<const float*>(rows_dev[8]);
   const float* seq_len = static_cast<const float*>(rows_dev[9]);     // [B]
   RELA_CHECK(obs && legal && act && reward && term && boot && h0 && c0 && seq_len, RELA_EINVAL,
-             "rela_r2d2_learner_backward: a batch field is NULL");
+             "rela_r2d2_learner_loss: a batch field is NULL");
   const size_t tr0 = (size_t)burn * Bn;  // first training row
   const float* legal_tr = legal + tr0 * A;
   const int64_t* act_tr = act + tr0;
@@ -1002,6 +1018,20 @@ extern "C" int rela_r2d2_learner_backward(rela_r2d2_learner* l, int batch, const
   if (loss_dev) RELA_HIP(hipMemcpyAsync(loss_dev, l->loss, sizeof(float), hipMemcpyDeviceToDevice, s));
   if (loss_seq_dev)
     RELA_HIP(hipMemcpyAsync(loss_seq_dev, l->loss_seq, sizeof(float) * Bn, hipMemcpyDeviceToDevice, s));
+  RELA_LAUNCH_CHECK();
+  l->pend_B = Bn;
+  l->pend_obs = obs;
+  return RELA_OK;
+}
+
+extern "C" int rela_r2d2_learner_grad(rela_r2d2_learner* l, void* stream_) {
+  RELA_CHECK(l && l->loaded && l->pend_B > 0, RELA_ESTATE, "rela_r2d2_learner_grad: no rela_r2d2_learner_loss to differentiate");
+  hipStream_t s = (hipStream_t)stream_;
+  DeviceGuard g(l->device);
+  const int Bn = l->pend_B, A = l->A, T = l->T, burn = l->burn, Tt = T - burn, rowsTr = Tt * Bn;
+  const uint8_t* obs = l->pend_obs;
+  const size_t tr0 = (size_t)burn * Bn;  // first training row
+  l->pend_B = 0;
 
   const rela_lstmnet_params P = lparams_at(l, l->P);
   float* Gm[14];  // gradient tensors in rela_lstmnet_params order

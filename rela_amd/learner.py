@@ -353,6 +353,18 @@ class HipR2D2Learner:
         """batch: RNNTransition-shaped (time-major [T, B, ...] cuda tensors: obs{s, eps, legal_move}, h0{h0, c0},
         action{a}, reward, terminal, bootstrap, seq_len); weight: cuda f32[B].
         -> (mean(loss * weight)[1], aggregated priority[B], per-sequence loss[B])."""
+        return self._forward_half(batch, weight, "rela_r2d2_learner_backward")
+
+    def loss(self, batch, weight):
+        """The forward half of `backward` (unrolls, TD errors, priorities, loss); `grad()` runs the backward pass of
+        it.  In between the caller may update_priority and sample the next batch into OTHER buffers
+        (RNNReplay.sample(..., slot=1 - slot))."""
+        return self._forward_half(batch, weight, "rela_r2d2_learner_loss")
+
+    def grad(self):
+        self._capi.check(self._capi.lib.rela_r2d2_learner_grad(self.h, self._stream()), "rela_r2d2_learner_grad")
+
+    def _forward_half(self, batch, weight, entry):
         C, capi = self._C, self._capi
         B = weight.numel()
         dev = self.device
@@ -366,11 +378,9 @@ class HipR2D2Learner:
         w = weight.detach().to(dev).float().contiguous()
         rows = (C.c_void_p * 10)(*[x.data_ptr() for x in keep])
         self._keep = (keep, w)
-        capi.check(capi.lib.rela_r2d2_learner_backward(self.h, B, rows, C.c_void_p(w.data_ptr()),
-                                                       C.c_void_p(self._prio.data_ptr()),
-                                                       C.c_void_p(self._loss.data_ptr()),
-                                                       C.c_void_p(self._loss_seq.data_ptr()), self._stream()),
-                   "rela_r2d2_learner_backward")
+        capi.check(getattr(capi.lib, entry)(self.h, B, rows, C.c_void_p(w.data_ptr()),
+                                            C.c_void_p(self._prio.data_ptr()), C.c_void_p(self._loss.data_ptr()),
+                                            C.c_void_p(self._loss_seq.data_ptr()), self._stream()), entry)
         return self._loss, self._prio[:B], self._loss_seq[:B]
 
     def apply(self):

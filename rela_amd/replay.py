@@ -158,21 +158,21 @@ class RNNReplay:
     wait = FFReplay.wait
     debug_state = FFReplay.debug_state
 
-    def _buffers(self, batch):
-        if batch not in self._out:
+    def _buffers(self, batch, slot=0):
+        if (batch, slot) not in self._out:
             dev, A, T = self.device, self.num_action, self.T
             mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
-            self._out[batch] = dict(
+            self._out[(batch, slot)] = dict(
                 s=mk((T, batch, 4, 84, 84), torch.uint8), eps=mk((T, batch, 1), torch.float32),
                 legal_move=mk((T, batch, A), torch.float32), a=mk((T, batch), torch.int64),
                 reward=mk((T, batch), torch.float32), terminal=mk((T, batch), torch.bool),
                 bootstrap=mk((T, batch), torch.float32), h0=mk((1, batch, 512), torch.float32),
                 c0=mk((1, batch, 512), torch.float32), seq_len=mk((batch,), torch.float32),
                 weight=mk((batch,), torch.float32))
-        return self._out[batch]
+        return self._out[(batch, slot)]
 
-    def sample(self, batchsize, device=None, gather=True):
-        b = self._buffers(batchsize)
+    def sample(self, batchsize, device=None, gather=True, slot=0):
+        b = self._buffers(batchsize, slot)
         rows = (C.c_void_p * len(self.FIELDS))(*[b[f].data_ptr() for f in self.FIELDS]) if gather else None
         capi.check(capi.lib.rela_replay_sample(self.h, batchsize, rows, C.c_void_p(b["weight"].data_ptr()),
                                                _stream_ptr(self.device)), "rela_replay_sample")

@@ -212,6 +212,33 @@ def test_hip_r2d2_learner_adam_step_and_trajectory():
     learner.close()
 
 
+def test_hip_r2d2_learner_loss_then_grad_equals_backward():
+    """rela_r2d2_learner_loss + rela_r2d2_learner_grad (the step in two halves, so that update_priority and the next
+    sample can be queued in between) leave the same loss, priorities and gradients as rela_r2d2_learner_backward,
+    bit for bit; grad() without a loss() before it is refused."""
+    import torch
+
+    from rela_amd.learner import HipR2D2Learner
+
+    A, B, seq, burn, n = 6, 5, 8, 4, 3
+    rng = np.random.default_rng(31)
+    agent = _agent(A, n, 0.997, 0.9, seq, burn, 41, 42, "cuda:0")
+    batch, weight = _random_batch(rng, A, B, seq, burn, n, "cuda:0")
+    learner = HipR2D2Learner.from_agent(agent, B, grad_clip=1e9)
+    loss0, prio0, ls0 = learner.backward(batch, weight)
+    loss0, prio0, ls0 = loss0.clone(), prio0.clone(), ls0.clone()
+    g0 = learner.flat()[1].clone()
+    learner.flat()[1].zero_()
+    loss1, prio1, ls1 = learner.loss(batch, weight)
+    assert torch.equal(loss1, loss0) and torch.equal(prio1, prio0) and torch.equal(ls1, ls0)
+    learner.grad()
+    learner.check()
+    assert torch.equal(learner.flat()[1], g0)
+    with pytest.raises(RuntimeError):
+        learner.grad()
+    learner.close()
+
+
 def test_hip_r2d2_learner_fast_target_trunk_within_tolerance():
     """set_precision("bf16x2"): the target net's conv trunk (no gradient, its activations are never read back) and the
     three large GEMMs of the LSTM's input side -- the gate GEMM of both nets, its data gradient and its weight gradient
