@@ -337,6 +337,7 @@ extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
     t.Bn = Bn, t.obs = obs, t.a1 = w.a1, t.a2 = w.a2, t.d_a3 = l->d_a3, t.d_a2 = l->d_a2, t.d_a1 = l->d_a1;
     t.col = l->col, t.part = l->part, t.cpart = l->cpart, t.w2p = l->w2p, t.w3p = l->w3p;
     t.g_c1w = Gm[0], t.g_c1b = Gm[1], t.g_c2w = Gm[2], t.g_c2b = Gm[3], t.g_c3w = Gm[4], t.g_c3b = Gm[5];
+    t.fast = rela_ffnet_precision(l->online) == 1;
     trunk_backward(t, s, &sums);
     hipLaunchKernelGGL(head_bias_grad, dim3(1), dim3(32), 0, s, (const float*)l->s32, A, Gm[11], Gm[9]);
   }

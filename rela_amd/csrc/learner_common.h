@@ -11,6 +11,7 @@
 #include "ffnet_layout.h"
 #include "gemm_lds.h"
 #include "prof.h"
+#include "wgrad_conv1_bf16.h"
 
 namespace rela_amd {
 namespace {
@@ -398,7 +399,10 @@ __global__ void adam_update(float* __restrict__ p, const float* __restrict__ g, 
 
 // ---- backward pass of the conv trunk (net.{0,2,4}), shared by both learners ---------------------
 constexpr int kSplitW3 = 28, kSplitW2 = 27, kSplitW1 = 64;
-constexpr size_t kTrunkPartFloats = (size_t)kSplitW3 * 64 * 576;  // the largest split-K partial buffer
+// the largest partial buffer: conv3's split-K tiles, or one [32][256] tile per block of the bf16 conv1 gradient
+constexpr size_t kTrunkPartFloats = (size_t)kSplitW3 * 64 * 576 > (size_t)w1fast::kMaxBlocks * 32 * 256
+                                        ? (size_t)kSplitW3 * 64 * 576
+                                        : (size_t)w1fast::kMaxBlocks * 32 * 256;
 static_assert(kSplitW3 * 64 * 576 >= kSplitW2 * 64 * 512 && kSplitW3 * 64 * 576 >= kSplitW1 * 32 * 256, "part size");
 inline size_t trunk_col_floats(size_t frames) { return frames * (size_t)(81 * 512 > 49 * 576 ? 81 * 512 : 49 * 576); }
 
@@ -413,6 +417,7 @@ struct TrunkBwd {
   float* cpart;        // scratch, kColsumBlocks * 512
   const float *w2p, *w3p;  // conv2 / conv3 weights in dgrad k order (permute_weights)
   float *g_c1w, *g_c1b, *g_c2w, *g_c2b, *g_c3w, *g_c3b;  // gradients, state_dict layout
+  bool fast = false;   // the learner's bf16x2 mode: conv1's weight gradient on bf16 MFMA
 };
 
 // all queued jobs in one launch pair; cpart must hold kColsumBlocks * (sum of the jobs' C) floats
@@ -478,7 +483,15 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     hipLaunchKernelGGL(col2im2, dim3(ceil_div((int64_t)Bn * 400 * 8, 256)), dim3(256), 0, s, (const float*)t.col, t.a1,
                        t.d_a1, Bn);
   }
-  {  // conv1: dW1, db1 (no gradient flows into the frames)
+  if (t.fast) {  // conv1 on bf16 MFMA (wgrad_conv1_bf16.h): exact u8 frames x (hi + lo) gradients
+    int blocks = 0;
+    {
+      ProfScope prof("learner_wgrad_conv1", s);
+      (void)w1fast::launch(t.obs, t.d_a1, Bn, t.part, s, &blocks);
+    }
+    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(32 * 256, 256)), dim3(256), 0, s, (const float*)t.part, blocks, 32,
+                       256, kRedConv1, t.g_c1w);
+  } else {  // conv1: dW1, db1 (no gradient flows into the frames)
     ProbW1 p{};
     p.M = 32, p.N = 256, p.K = Bn * 400;
     p.d_out = t.d_a1, p.obs = t.obs, p.part = t.part;

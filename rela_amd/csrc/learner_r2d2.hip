@@ -1136,6 +1136,7 @@ extern "C" int rela_r2d2_learner_grad(rela_r2d2_learner* l, void* stream_) {
     t.d_a2 = l->d_a2, t.d_a1 = l->d_a1, t.col = l->col, t.part = l->part, t.cpart = l->cpart;
     t.w2p = l->w2p, t.w3p = l->w3p;
     t.g_c1w = Gm[0], t.g_c1b = Gm[1], t.g_c2w = Gm[2], t.g_c2b = Gm[3], t.g_c3w = Gm[4], t.g_c3b = Gm[5];
+    t.fast = l->precision == 1;
     trunk_backward(t, s);
   }
   RELA_LAUNCH_CHECK();
