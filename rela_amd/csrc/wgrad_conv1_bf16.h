@@ -65,8 +65,10 @@ __global__ __launch_bounds__(kT) void wgrad_conv1_bf16(const uint8_t* __restrict
 
   // ---- staging registers: the half frame after the one being multiplied ----
   // image: 924 chunks of 16 u8 per half (4 planes x 44 rows x 84), two per thread (clamped: the last threads repeat
-  // chunk 923, writing the same values twice); d: 1,600 float4 (200 pixels x 8 channel quads), four per thread
-  // (threads past 1,600 repeat quad 1,599)
+  // chunk 923, writing the same values twice); d: 1,600 float4 (8 channel quads x 200 pixels), four per thread
+  // (threads past 1,600 repeat number 1,599).  Quad-major numbering: the 64 lanes of a wave hold 64 consecutive
+  // pixels of ONE channel quad, so their 2-byte LDS stores fall on 32 different banks (pixel-major numbering put a
+  // wave's eight quads, whose rows are 2,176 B apart, on the same four banks: 8-way conflicts on every store).
   uint4 im0, im1;
   float4 d0, d1, d2, d3;
   const int ci0 = min(tid, 923), ci1 = min(tid + kT, 923);
@@ -77,10 +79,10 @@ __global__ __launch_bounds__(kT) void wgrad_conv1_bf16(const uint8_t* __restrict
     im0 = *reinterpret_cast<const uint4*>(fo__ + (ci0 / 231) * 7056 + (ci0 % 231) * 16);                      \
     im1 = *reinterpret_cast<const uint4*>(fo__ + (ci1 / 231) * 7056 + (ci1 % 231) * 16);                      \
     const float* fd__ = d_a1 + ((size_t)(F) * 400 + (H) * 200) * 32;                                          \
-    d0 = *reinterpret_cast<const float4*>(fd__ + (size_t)di0 * 4);                                            \
-    d1 = *reinterpret_cast<const float4*>(fd__ + (size_t)di1 * 4);                                            \
-    d2 = *reinterpret_cast<const float4*>(fd__ + (size_t)di2 * 4);                                            \
-    d3 = *reinterpret_cast<const float4*>(fd__ + (size_t)di3 * 4);                                            \
+    d0 = *reinterpret_cast<const float4*>(fd__ + (di0 % 200) * 32 + (di0 / 200) * 4);                         \
+    d1 = *reinterpret_cast<const float4*>(fd__ + (di1 % 200) * 32 + (di1 / 200) * 4);                         \
+    d2 = *reinterpret_cast<const float4*>(fd__ + (di2 % 200) * 32 + (di2 / 200) * 4);                         \
+    d3 = *reinterpret_cast<const float4*>(fd__ + (di3 % 200) * 32 + (di3 / 200) * 4);                         \
   } while (0)
 
   auto put_img = [&](int ci, uint4 v) {
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(kT) void wgrad_conv1_bf16(const uint8_t* __restrict
     }
   };
   auto put_d = [&](int di, float4 v) {
-    const int px = di >> 3, oc0 = (di & 7) * 4;
+    const int px = di % 200, oc0 = (di / 200) * 4;
     const int oy = px / 20, ox = px - oy * 20;
     const int k0 = oy * 24 + ox;
     const float x[4] = {v.x, v.y, v.z, v.w};
