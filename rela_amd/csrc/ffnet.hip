@@ -2379,6 +2379,7 @@ struct rela_ffnet {
   const char* const* prof_names = nullptr;  // per-kernel timing labels (actor-side by default)
   int precision = 0;  // 0 = exact f32 MFMA (parity mode), 1 = split-bf16 MFMA for conv2 / conv3 / fc
   unsigned* pipe_tmo = nullptr;  // sticky: a wave of conv12_pipe gave up waiting (never observed)
+  int max_rows = 0;  // > 0: the owner never runs more rows (a learner's batch): layouts only larger batches read are not packed
 };
 
 
@@ -2464,6 +2465,7 @@ extern "C" int rela_ffnet_debug_pipe_timeout(rela_ffnet* n, unsigned* out) {
 extern "C" int rela_ffnet_num_action(const rela_ffnet* n) { return n ? n->num_action : 0; }
 namespace rela_amd {
 void ffnet_label_as_learner(rela_ffnet* n) { n->prof_names = kProfLearner; }
+void ffnet_set_max_rows(rela_ffnet* n, int rows) { n->max_rows = rows; }
 }  // namespace rela_amd
 extern "C" uint64_t rela_ffnet_version(const rela_ffnet* n) { return n ? n->version : 0; }
 extern "C" int rela_ffnet_set_precision(rela_ffnet* n, int mode) {
@@ -2520,8 +2522,14 @@ extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on
                                (int64_t)3136 * 512, 2 * 128 * 64, 2 * 4 * 32 * 64,
                                (int64_t)Conv2F::CT * Conv2F::KS * 64 * 8, (int64_t)Conv3F::CT * Conv3F::KS * 64 * 8,
                                (int64_t)32 * FcFast::KS * 64 * 8, 672, 32};
+    // a net whose owner never runs large batches (a learner re-packs after every step) skips the two fc layouts
+    // only large batches read: Bf (f32 fragments, N >= kFcSplitBelow) and Bff (bf16 fragments, N >= kFastMinN)
+    int64_t el[13];
+    for (int jn = 0; jn < 13; ++jn) el[jn] = elems[jn];
+    if (n->max_rows > 0 && n->max_rows < kFcSplitBelow) el[4] = 0;
+    if (n->max_rows > 0 && n->max_rows < kFastMinN) el[10] = 0;
     a.first[0] = 0;
-    for (int jn = 0; jn < 13; ++jn) a.first[jn + 1] = a.first[jn] + (int)ceil_div(elems[jn], 256);
+    for (int jn = 0; jn < 13; ++jn) a.first[jn + 1] = a.first[jn] + (int)ceil_div(el[jn], 256);
     hipLaunchKernelGGL(pack_ffnet_all, dim3(a.first[13]), dim3(256), 0, s, a);
   }
   RELA_LAUNCH_CHECK();
@@ -2556,7 +2564,11 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
   const FFNetDev& d = n->d;
   const char* const* names = n->prof_names ? n->prof_names : kProfActor;
   const char* name12 = n->prof_names ? "learner_fwd_conv12" : "conv12_fused";  // conv1 -> conv2 in one launch
-  static const int fast_min_n = getenv("RELA_FAST_MIN_N") ? atoi(getenv("RELA_FAST_MIN_N")) : kFastMinN;
+  RELA_CHECK(n->max_rows <= 0 || N <= n->max_rows, RELA_EINVAL,
+             "rela_ffnet_forward: batch %d on a net whose owner declared at most %d rows", N, n->max_rows);
+  static const int fast_min_env = getenv("RELA_FAST_MIN_N") ? atoi(getenv("RELA_FAST_MIN_N")) : kFastMinN;
+  // (a net packed for small batches only has no bf16 fc fragments: it keeps the f32 fc whatever the threshold says)
+  const int fast_min_n = (n->max_rows > 0 && n->max_rows < kFastMinN) ? n->max_rows + 1 : fast_min_env;
   const int precision = mode < 0 ? n->precision : mode;
   // Between kFastTrunkMinN and kFastMinN rows the convolutions still win on split-bf16 MFMA (N = 512: 39 us against
   // 90 us in f32) but fc_bf16s has too few blocks (55 us against the 24 us of the f32 split-K GEMM): the trunk runs

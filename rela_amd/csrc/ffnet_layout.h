@@ -35,6 +35,8 @@ struct rela_ffnet;
 namespace rela_amd {
 // per-kernel timing labels "learner_fwd_*" instead of the actor-side names (prof.h)
 void ffnet_label_as_learner(rela_ffnet* n);
+// the owner never runs more than `rows` rows through this net: rela_ffnet_load skips the layouts only larger batches read
+void ffnet_set_max_rows(rela_ffnet* n, int rows);
 // rela_ffnet_forward with the precision chosen by the caller: mode -1 = the net's own (rela_ffnet_set_precision),
 // 0 = exact f32 whatever the net says -- the learner's pass that keeps a1 / a2 / a3 / h for the backward kernels
 int ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_dev, const float* legal_dev, float* q_dev, void* ws,

@@ -131,6 +131,8 @@ extern "C" int rela_apex_learner_create(rela_apex_learner** out, int num_action,
   if (rc != RELA_OK) return rc;
   ffnet_label_as_learner(l->online);
   ffnet_label_as_learner(l->target);
+  ffnet_set_max_rows(l->online, max_batch);
+  ffnet_set_max_rows(l->target, max_batch);
   RELA_HIP(hipMalloc(&l->w2p, sizeof(float) * 64 * 512));
   RELA_HIP(hipMalloc(&l->w3p, sizeof(float) * 64 * 576));
   RELA_HIP(hipMalloc(&l->wfcp, sizeof(float) * 512 * 3136));
