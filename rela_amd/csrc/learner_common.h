@@ -12,6 +12,7 @@
 #include "gemm_lds.h"
 #include "prof.h"
 #include "wgrad_conv1_bf16.h"
+#include "wgrad_conv2_bf16.h"
 
 namespace rela_amd {
 namespace {
@@ -399,10 +400,11 @@ __global__ void adam_update(float* __restrict__ p, const float* __restrict__ g, 
 
 // ---- backward pass of the conv trunk (net.{0,2,4}), shared by both learners ---------------------
 constexpr int kSplitW3 = 28, kSplitW2 = 27, kSplitW1 = 64;
-// the largest partial buffer: conv3's split-K tiles, or one [32][256] tile per block of the bf16 conv1 gradient
-constexpr size_t kTrunkPartFloats = (size_t)kSplitW3 * 64 * 576 > (size_t)w1fast::kMaxBlocks * 32 * 256
-                                        ? (size_t)kSplitW3 * 64 * 576
-                                        : (size_t)w1fast::kMaxBlocks * 32 * 256;
+// the largest partial buffer: conv3's split-K tiles, or one tile per block of the bf16 conv1 ([32][256]) / conv2
+// ([64][512]) gradients
+constexpr size_t kTrunkPartFloats = (size_t)w2fast::kMaxBlocks * 64 * 512;
+static_assert(kTrunkPartFloats >= (size_t)kSplitW3 * 64 * 576 && kTrunkPartFloats >= (size_t)w1fast::kMaxBlocks * 32 * 256,
+              "part size");
 static_assert(kSplitW3 * 64 * 576 >= kSplitW2 * 64 * 512 && kSplitW3 * 64 * 576 >= kSplitW1 * 32 * 256, "part size");
 inline size_t trunk_col_floats(size_t frames) { return frames * (size_t)(81 * 512 > 49 * 576 ? 81 * 512 : 49 * 576); }
 
@@ -465,7 +467,15 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     hipLaunchKernelGGL(col2im3, dim3(ceil_div((int64_t)Bn * 81 * 16, 256)), dim3(256), 0, s, (const float*)t.col, t.a2,
                        t.d_a2, Bn);
   }
-  {  // conv2: dW2, db2, d_a1
+  if (t.fast) {  // conv2's weight gradient on bf16 MFMA (wgrad_conv2_bf16.h)
+    int blocks = 0;
+    {
+      ProfScope prof("learner_wgrad_conv2", s);
+      (void)w2fast::launch(t.a1, t.d_a2, Bn, t.part, s, &blocks);
+    }
+    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 512, 256)), dim3(256), 0, s, (const float*)t.part, blocks, 64,
+                       512, kRedConv2, t.g_c2w);
+  } else {  // conv2: dW2, db2, d_a1
     ProbW2 p{};
     p.M = 64, p.N = 512, p.K = Bn * 81;
     p.d_out = t.d_a2, p.in = t.a1, p.part = t.part;
