@@ -13,6 +13,7 @@
 #include "prof.h"
 #include "wgrad_conv1_bf16.h"
 #include "wgrad_conv2_bf16.h"
+#include "wgrad_conv3_bf16.h"
 
 namespace rela_amd {
 namespace {
@@ -402,12 +403,14 @@ __global__ void adam_update(float* __restrict__ p, const float* __restrict__ g, 
 constexpr int kSplitW3 = 28, kSplitW2 = 27, kSplitW1 = 64;
 // the largest partial buffer: conv3's split-K tiles, or one tile per block of the bf16 conv1 ([32][256]) / conv2
 // ([64][512]) gradients
-constexpr size_t kTrunkPartFloats = (size_t)w2fast::kMaxBlocks * 64 * 512;
-static_assert(kTrunkPartFloats >= (size_t)kSplitW3 * 64 * 576 && kTrunkPartFloats >= (size_t)w1fast::kMaxBlocks * 32 * 256,
+constexpr size_t kTrunkPartFloats = (size_t)w3fast::kMaxBlocks * 64 * 576;
+static_assert(kTrunkPartFloats >= (size_t)kSplitW3 * 64 * 576 && kTrunkPartFloats >= (size_t)w1fast::kMaxBlocks * 32 * 256 &&
+                  kTrunkPartFloats >= (size_t)w2fast::kMaxBlocks * 64 * 512,
               "part size");
 static_assert(kSplitW3 * 64 * 576 >= kSplitW2 * 64 * 512 && kSplitW3 * 64 * 576 >= kSplitW1 * 32 * 256, "part size");
 inline size_t trunk_col_floats(size_t frames) { return frames * (size_t)(81 * 512 > 49 * 576 ? 81 * 512 : 49 * 576); }
 
+constexpr int kFastWgradMinFrames = 2048;
 struct TrunkBwd {
   int Bn;              // frames
   const uint8_t* obs;  // [Bn][4][84][84] u8
@@ -449,7 +452,18 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
   const int Bn = t.Bn;
   ColsumJobs own;
   ColsumJobs& jobs = pending ? *pending : own;
-  {  // conv3: dW3, db3, d_a2
+  // conv2 / conv3 on bf16 MFMA only for many frames (R2D2: T * B): at 512 frames their per-block fixed costs (LDS
+  // zero fill, 256 partial tiles of 128 / 144 KB for reduce_splits) cancel the gain (Ape-X: step 0.83 -> 0.91 ms)
+  const bool fast23 = t.fast && Bn >= kFastWgradMinFrames;
+  if (fast23) {  // conv3's weight gradient on bf16 MFMA (wgrad_conv3_bf16.h)
+    int blocks = 0;
+    {
+      ProfScope prof("learner_wgrad_conv3", s);
+      (void)w3fast::launch(t.a2, t.d_a3, Bn, t.part, s, &blocks);
+    }
+    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 576, 256)), dim3(256), 0, s, (const float*)t.part, blocks, 64,
+                       576, kRedConv3, t.g_c3w);
+  } else {  // conv3: dW3, db3, d_a2
     ProbW3 p{};
     p.M = 64, p.N = 576, p.K = Bn * 49;
     p.d_out = t.d_a3, p.in = t.a2, p.part = t.part;
@@ -467,7 +481,7 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     hipLaunchKernelGGL(col2im3, dim3(ceil_div((int64_t)Bn * 81 * 16, 256)), dim3(256), 0, s, (const float*)t.col, t.a2,
                        t.d_a2, Bn);
   }
-  if (t.fast) {  // conv2's weight gradient on bf16 MFMA (wgrad_conv2_bf16.h)
+  if (fast23) {  // conv2's weight gradient on bf16 MFMA (wgrad_conv2_bf16.h)
     int blocks = 0;
     {
       ProfScope prof("learner_wgrad_conv2", s);

@@ -239,17 +239,20 @@ def test_hip_r2d2_learner_loss_then_grad_equals_backward():
     learner.close()
 
 
-def test_hip_r2d2_learner_fast_target_trunk_within_tolerance():
+@pytest.mark.parametrize("B,seq,burn", [(16, 12, 6), (32, 80, 40)])
+def test_hip_r2d2_learner_fast_target_trunk_within_tolerance(B, seq, burn):
     """set_precision("bf16x2"): the target net's conv trunk (no gradient, its activations are never read back) and the
     three large GEMMs of the LSTM's input side -- the gate GEMM of both nets, its data gradient and its weight gradient
     (csrc/gemm_bf16s.h: hi + lo bf16 operands, three MFMAs per product, f32 accumulation) -- run on split-bf16 MFMA;
     loss, priorities and gradients stay within the fast mode's tolerance of the all-f32 step.  T * B = 336 rows and
-    240 training rows: every GEMM has a ragged last row block and the weight gradient a zero-padded last k-chunk."""
+    240 training rows: every GEMM has a ragged last row block and the weight gradient a zero-padded last k-chunk.
+    conv1's weight gradient runs on bf16 MFMA at both shapes (csrc/wgrad_conv1_bf16.h), conv2's and conv3's
+    (wgrad_conv2_bf16.h, wgrad_conv3_bf16.h) from 2,048 training frames up: the second shape, 83 x 32 = 2,656."""
     import torch
 
     from rela_amd.learner import HipR2D2Learner
 
-    A, B, seq, burn, n = 18, 16, 12, 6, 3
+    A, n = 18, 3
     rng = np.random.default_rng(77)
     agent = _agent(A, n, 0.997, 0.9, seq, burn, 71, 72, "cuda:0")
     batch, weight = _random_batch(rng, A, B, seq, burn, n, "cuda:0")
