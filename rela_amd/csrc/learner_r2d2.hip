@@ -1086,7 +1086,7 @@ extern "C" int rela_r2d2_learner_grad(rela_r2d2_learner* l, void* stream_) {
   const float* DG = ga_tr;                          // [rowsTr][2048]
   const float* hprev = H + (size_t)burn * blk;      // h_{t-1} of training step t = H[burn + t]
   const float* a3_tr = l->a3 + tr0 * kA3;
-  {
+  if (l->precision != 1) {
     ProbWhh p{};
     p.M = kGates, p.N = kHid, p.K = rowsTr;
     p.dg = DG, p.hprev = hprev, p.out = Gm[7];
@@ -1105,6 +1105,14 @@ extern "C" int rela_r2d2_learner_grad(rela_r2d2_learner* l, void* stream_) {
       hipLaunchKernelGGL(split_cols_rec64, dim3(kFeat / 64, chunks), dim3(256), 0, s, a3_tr, (int64_t)rowsTr, kFeat, 1, a3T);
     }
     int rc = launch_rec64_nt(dgT, a3T, kGates, kFeat, chunks, EpiPlain{Gm[6], kFeat}, s, "learner_wgrad_lstm_ih");
+    if (rc != RELA_OK) return rc;
+    // dW_hh[g][k] = sum_r dg[r][g] * hprev[r][k]: the same transposed gate gradients against hprev^T (which takes
+    // the place of a3^T, consumed by the launch above)
+    {
+      ProfScope prof("learner_lstm_split_cols", s);
+      hipLaunchKernelGGL(split_cols_rec64, dim3(kHid / 64, chunks), dim3(256), 0, s, hprev, (int64_t)rowsTr, kHid, 0, a3T);
+    }
+    rc = launch_rec64_nt(dgT, a3T, kGates, kHid, chunks, EpiPlain{Gm[7], kHid}, s, "learner_wgrad_lstm_hh");
     if (rc != RELA_OK) return rc;
   } else {
     ProbWih p{};
