@@ -407,8 +407,10 @@ int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward_host,
                               const rela_lstmnet* target, int nonblocking, int* n_sequences,
                               void* stream);
 int64_t rela_r2d2_actor_num_act(const rela_r2d2_actor* a);
-/* as rela_apex_actor_set_reuse: online_net.act(next_obs, next_hid) of compute_priority (r2d2.py:91) is the
- * step act() just ran; it is recomputed only if the weights changed in between (or on = 0)       */
+/* as rela_apex_actor_set_reuse: online_net.act(next_obs, next_hid) of compute_priority (r2d2.py:91) is the step
+ * act() ran on this tick, and online_net(obs, hid) (:89) the step act() ran n ticks ago on the same frames, recurrent
+ * state (historyHidden_.front()) and legal mask: with unchanged weights both are reused bit-identically.
+ * on = 1 (default): both; 2: only the one of next_obs; 0: recompute */
 int rela_r2d2_actor_set_reuse(rela_r2d2_actor* a, int on);
 /* diagnostics: current recurrent state (which = 0: h, 1: c) f32[rows,512]; last step priorities */
 const float* rela_r2d2_actor_hidden_dev(const rela_r2d2_actor* a, int which);

@@ -197,11 +197,14 @@ struct rela_r2d2_actor {
   float *eps = nullptr, *legal = nullptr;          // current values (uploaded / written by the caller)
   float *eps_hist = nullptr, *legal_hist = nullptr;  // [n+1][R], [n+1][R][A]: snapshots per history slot
   float* q = nullptr;  // [4][R][A]: adv(act), q_online, adv_next, q_target
+  float* q_hist = nullptr;  // [n+1][R][A]: act()'s own Q table of every history slot
   // weights and history slot the advantages in q[0] (written by act) belong to
   const rela_lstmnet* q_net = nullptr;
   uint64_t q_version = 0;
   int q_slot = -1;
-  bool reuse_act_step = true;
+  int reuse_mode = 1;  // 0: recompute everything, 1: reuse both act() steps, 2: only the one of next_obs
+  std::vector<const rela_lstmnet*> qh_net;  // net / weight version act() evaluated every history slot with
+  std::vector<uint64_t> qh_version;
   float *out_r = nullptr, *out_b = nullptr, *prio_step = nullptr;
   uint8_t* out_t = nullptr;
   Windows w{};
@@ -273,6 +276,9 @@ extern "C" int rela_r2d2_actor_create(rela_r2d2_actor** out, int rows, int group
   RELA_ALLOC(a->eps_hist, H * R * sizeof(float));
   RELA_ALLOC(a->legal_hist, H * R * A * sizeof(float));
   RELA_ALLOC(a->q, 4 * R * A * sizeof(float));
+  RELA_ALLOC(a->q_hist, (size_t)(multi_step + 1) * R * A * sizeof(float));
+  a->qh_net.assign((size_t)multi_step + 1, nullptr);
+  a->qh_version.assign((size_t)multi_step + 1, 0);
   RELA_ALLOC(a->out_r, R * sizeof(float));
   RELA_ALLOC(a->out_b, R * sizeof(float));
   RELA_ALLOC(a->prio_step, R * sizeof(float));
@@ -329,7 +335,7 @@ extern "C" void rela_r2d2_actor_destroy(rela_r2d2_actor* a) {
                 a->tmp_c, a->eps,    a->legal,  a->eps_hist, a->legal_hist, a->q,         a->out_r,  a->out_b,  a->prio_step, a->out_t, a->w.s,
                 a->w.eps, a->w.legal, a->w.a,   a->w.reward,  a->w.term, a->w.boot, a->w.prio, a->w.h0,   a->w.c0,
                 a->w.nh0, a->w.nc0,  a->prow,   a->lens,      a->agg,    a->d_slot, a->d_flags, a->d_ranges, a->d_emits, a->d_gather,
-                a->d_envs, a->ws};
+                a->d_envs, a->ws, a->q_hist};
   for (void* p : ps) (void)hipFree(p);
   a->stage.destroy();
   delete a->book;
@@ -343,7 +349,8 @@ extern "C" void* rela_r2d2_actor_obs_slot(rela_r2d2_actor* a) {
 }
 extern "C" int rela_r2d2_actor_set_reuse(rela_r2d2_actor* a, int on) {
   RELA_CHECK(a, RELA_EINVAL, "rela_r2d2_actor_set_reuse: bad arguments");
-  a->reuse_act_step = on != 0;
+  RELA_CHECK(on >= 0 && on <= 2, RELA_EINVAL, "rela_r2d2_actor_set_reuse: 0 (off), 1 (on) or 2 (next_obs only)");
+  a->reuse_mode = on;
   return RELA_OK;
 }
 extern "C" int64_t rela_r2d2_actor_num_act(const rela_r2d2_actor* a) { return a ? a->num_act.load() : 0; }
@@ -374,9 +381,13 @@ extern "C" int rela_r2d2_actor_act(rela_r2d2_actor* a, const rela_lstmnet* onlin
   float* legal_s = a->legal_hist + (size_t)slot * R * a->A;
   RELA_HIP(hipMemcpyAsync(eps_s, a->eps, R * sizeof(float), hipMemcpyDeviceToDevice, s));
   RELA_HIP(hipMemcpyAsync(legal_s, a->legal, R * a->A * sizeof(float), hipMemcpyDeviceToDevice, s));
-  int rc = rela_lstmnet_step(online, a->R, obs, legal_s, a->hid_h, a->hid_c, a->tmp_h, a->tmp_c, nullptr, a->q, a->ws,
-                             a->ws_bytes, s);
+  // (the dueling Q of this step goes to the slot's table: compute_priority's online_net(obs, hid) n ticks from now)
+  a->qh_net[slot] = nullptr;
+  int rc = rela_lstmnet_step(online, a->R, obs, legal_s, a->hid_h, a->hid_c, a->tmp_h, a->tmp_c,
+                             a->q_hist + (size_t)slot * R * a->A, a->q, a->ws, a->ws_bytes, s);
   if (rc != RELA_OK) return rc;
+  a->qh_net[slot] = online;
+  a->qh_version[slot] = rela_lstmnet_version(online);
   std::swap(a->hid_h, a->tmp_h);  // hidden_ <- new state :241
   std::swap(a->hid_c, a->tmp_c);
   int64_t* act = a->act + (size_t)slot * R;
@@ -451,13 +462,19 @@ extern "C" int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward
   const float* legal_n = a->legal_hist + (size_t)last * R * a->A;
   const float* eps_t = a->eps_hist + (size_t)first * R;
   // compute_priority  r2d2.py:76-100
-  rc = rela_lstmnet_step(online, a->R, obs_t, legal_t, h_t, c_t, a->tmp_h, a->tmp_c, a->q + QA, nullptr, a->ws,
-                         a->ws_bytes, s);  // online_net(obs, hid) :89
-  if (rc != RELA_OK) return rc;
+  // online_net(obs, hid) :89 is the step act() ran n ticks ago on the same frames with the same recurrent state
+  // (historyHidden_.front()) and legal mask: with unchanged weights its Q table in q_hist[first] is reused
+  const float* q_online_t = a->q_hist + (size_t)first * QA;
+  if (!(a->reuse_mode == 1 && a->qh_net[first] == online && a->qh_version[first] == rela_lstmnet_version(online))) {
+    rc = rela_lstmnet_step(online, a->R, obs_t, legal_t, h_t, c_t, a->tmp_h, a->tmp_c, a->q + QA, nullptr, a->ws,
+                           a->ws_bytes, s);
+    if (rc != RELA_OK) return rc;
+    q_online_t = a->q + QA;
+  }
   // online_net.act(next_obs, next_hid) :91 is the very step act() ran on this tick (same frames, same
   // recurrent state, same legal mask): with unchanged weights its advantages in q[0] are reused
   const float* adv_next = a->q;
-  if (!(a->reuse_act_step && a->q_net == online && a->q_version == rela_lstmnet_version(online) && a->q_slot == last)) {
+  if (!(a->reuse_mode != 0 && a->q_net == online && a->q_version == rela_lstmnet_version(online) && a->q_slot == last)) {
     rc = rela_lstmnet_step(online, a->R, obs_n, legal_n, h_n, c_n, a->tmp_h, a->tmp_c, nullptr, a->q + 2 * QA, a->ws,
                            a->ws_bytes, s);
     if (rc != RELA_OK) return rc;
@@ -467,7 +484,7 @@ extern "C" int rela_r2d2_actor_post_step(rela_r2d2_actor* a, const float* reward
                          a->ws_bytes, s);  // target_net(next_obs, next_hid, next_action) :93
   if (rc != RELA_OK) return rc;
   const int64_t* act_t = a->act + (size_t)first * R;
-  rc = rela_apex_td_from_q(a->R, a->A, a->K, a->q + QA, adv_next, a->q + 3 * QA, legal_n, act_t, a->out_r, a->out_b,
+  rc = rela_apex_td_from_q(a->R, a->A, a->K, q_online_t, adv_next, a->q + 3 * QA, legal_n, act_t, a->out_r, a->out_b,
                            a->gamma_n, nullptr, a->prio_step, s);
   if (rc != RELA_OK) return rc;
 

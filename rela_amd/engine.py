@@ -225,7 +225,7 @@ class R2D2ActorEngine:
         return capi.lib.rela_r2d2_actor_num_act(self.h)
 
     def set_reuse(self, on):
-        capi.check(capi.lib.rela_r2d2_actor_set_reuse(self.h, int(bool(on))), "rela_r2d2_actor_set_reuse")
+        capi.check(capi.lib.rela_r2d2_actor_set_reuse(self.h, int(on)), "rela_r2d2_actor_set_reuse")
 
     def next_obs_slot(self):
         return dev_view(capi.lib.rela_r2d2_actor_obs_slot(self.h), (self.R, 4, 84, 84), torch.uint8, self.device)
