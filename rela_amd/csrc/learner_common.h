@@ -11,6 +11,7 @@
 #include "ffnet_layout.h"
 #include "gemm_lds.h"
 #include "prof.h"
+#include "dgrad_conv_bf16.h"
 #include "wgrad_conv1_bf16.h"
 #include "wgrad_conv2_bf16.h"
 #include "wgrad_conv3_bf16.h"
@@ -404,6 +405,7 @@ constexpr int kSplitW3 = 28, kSplitW2 = 27, kSplitW1 = 64;
 // the largest partial buffer: conv3's split-K tiles, or one tile per block of the bf16 conv1 ([32][256]) / conv2
 // ([64][512]) gradients
 constexpr size_t kTrunkPartFloats = (size_t)w3fast::kMaxBlocks * 64 * 576;
+static_assert(kTrunkPartFloats * 4 >= dgfast::kFrag3Bytes && kTrunkPartFloats * 4 >= dgfast::kFrag2Bytes, "frag scratch");
 static_assert(kTrunkPartFloats >= (size_t)kSplitW3 * 64 * 576 && kTrunkPartFloats >= (size_t)w1fast::kMaxBlocks * 32 * 256 &&
                   kTrunkPartFloats >= (size_t)w2fast::kMaxBlocks * 64 * 512,
               "part size");
@@ -472,7 +474,10 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
                        576, kRedConv3, t.g_c3w);
   }
   jobs.add(t.d_a3, (int64_t)Bn * 49, 64, t.g_c3b);
-  {
+  if (t.fast) {  // transposed convolution on bf16 MFMA, ReLU mask fused, no column buffer (dgrad_conv_bf16.h)
+    ProfScope prof("learner_dgrad_conv3", s);
+    (void)dgfast::launch_conv3(t.d_a3, t.w3p, t.a2, t.d_a2, Bn, t.part, s);
+  } else {
     ProbConvDgrad p{};
     p.M = Bn * 49, p.N = 576, p.K = 64;
     p.d_out = t.d_a3, p.wp = t.w3p, p.col = t.col;
@@ -498,7 +503,10 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
                        512, kRedConv2, t.g_c2w);
   }
   jobs.add(t.d_a2, (int64_t)Bn * 81, 64, t.g_c2b);
-  {
+  if (t.fast) {
+    ProfScope prof("learner_dgrad_conv2", s);
+    (void)dgfast::launch_conv2(t.d_a2, t.w2p, t.a1, t.d_a1, Bn, t.part, s);
+  } else {
     ProbConvDgrad p{};
     p.M = Bn * 81, p.N = 512, p.K = 64;
     p.d_out = t.d_a2, p.wp = t.w2p, p.col = t.col;
