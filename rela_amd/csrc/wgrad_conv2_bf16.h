@@ -66,13 +66,16 @@ __global__ __launch_bounds__(kT) void wgrad_conv2_bf16(const float* __restrict__
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // ---- staging registers: the next frame (quad-major numbering: a wave's lanes hold consecutive pixels of one
-  // channel quad, see wgrad_conv1_bf16.h) ----
+  // ---- staging registers: the next frame.  a1's float4 are numbered (channel quad, parity class, cell of the 10 x 10
+  // sub-image): a wave's lanes then store consecutive cells of ONE sub-image (conflict-free 2-byte stores; with
+  // consecutive PIXELS neighbouring lanes alternate between two sub-images 11,776 B = 0 banks apart: 3.7 x the store
+  // time, tools/lds_conflicts.py).  d_a2's are numbered (channel quad, pixel) as in wgrad_conv1_bf16.h. ----
   float4 x0, x1, x2, x3, x4, x5, x6;  // a1: 3,200 float4 = 8 quads x 400 pixels, seven per thread (clamped)
   float4 e0, e1, e2, e3;              // d_a2: 2 x 648 float4 = per oc half 8 quads x 81 pixels, two per thread and half
 #define W2_AI(J) min(tid + (J) * kT, kA1Quads - 1)
 #define W2_DI(J) min(tid + (J) * kT, kDQuads - 1)
-#define W2_ALOAD(J) (*reinterpret_cast<const float4*>(fa__ + (W2_AI(J) % 400) * 32 + (W2_AI(J) / 400) * 4))
+#define W2_APX(I) ((2 * (((I) % 100) / 10) + (((I) % 400) / 200)) * 20 + 2 * (((I) % 100) % 10) + ((((I) % 400) / 100) & 1))
+#define W2_ALOAD(J) (*reinterpret_cast<const float4*>(fa__ + W2_APX(W2_AI(J)) * 32 + (W2_AI(J) / 400) * 4))
 #define W2_DLOAD(J, H) (*reinterpret_cast<const float4*>(fd__ + (W2_DI(J) % 81) * 64 + (H) * 32 + (W2_DI(J) / 81) * 4))
 #define W2_LOAD(F)                                            \
   do {                                                        \
@@ -84,10 +87,8 @@ __global__ __launch_bounds__(kT) void wgrad_conv2_bf16(const float* __restrict__
   } while (0)
 
   auto put_a = [&](int ai, float4 v) {
-    const int px = ai % 400, c0 = (ai / 400) * 4;
-    const int y = px / 20, x = px - y * 20;
-    const int sr = (y & 1) * 2 + (x & 1);
-    uint8_t* cell = img + (sr * 32 + c0) * SUB + ((y >> 1) * 16 + (x >> 1)) * 2;
+    const int c0 = (ai / 400) * 4, rest = ai % 400, sr = rest / 100, cl = rest % 100;  // (= W2_APX's decomposition)
+    uint8_t* cell = img + (sr * 32 + c0) * SUB + ((cl / 10) * 16 + cl % 10) * 2;
     const float f[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -175,6 +176,7 @@ __global__ __launch_bounds__(kT) void wgrad_conv2_bf16(const float* __restrict__
   }
 #undef W2_LOAD
 #undef W2_ALOAD
+#undef W2_APX
 #undef W2_DLOAD
   // every wave owns its columns: straight to this block's partial tile, n = (kh * 4 + kw) * 32 + c
   float* out = part + (size_t)blockIdx.x * (64 * 512);
