@@ -23,6 +23,7 @@
 
 namespace rela_amd {
 namespace gemm16 {
+namespace {  // (included by both learners' translation units)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -245,5 +246,6 @@ inline int launch_rec64_nt(const uint8_t* A, const uint8_t* B, int M, int N, int
   return RELA_OK;
 }
 
+}  // namespace
 }  // namespace gemm16
 }  // namespace rela_amd
