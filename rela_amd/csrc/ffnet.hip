@@ -2827,8 +2827,10 @@ extern "C" int rela_lstmnet_load(rela_lstmnet* n, const rela_lstmnet_params* p, 
 namespace {
 // conv trunk of an AtariLSTMNet: f32 kernels, or (fast && N >= kFastTrunkMinN) conv1 -> conv2 fused and conv3 on
 // split-bf16 MFMA with a3 turned back into f32 in place (a1 is then NOT produced, a2 holds split records)
-void lstm_trunk_launch(const FFNetDev& d, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, bool fast,
-                       hipStream_t s, const char* const* names) {
+// records (with fast): a3 stays in split records (the rec64 operand of the learner's split-bf16 gate GEMM); returns
+// whether it did
+bool lstm_trunk_launch(const FFNetDev& d, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, bool fast,
+                       hipStream_t s, const char* const* names, bool records = false) {
   if (fast && N >= kFastTrunkMinN) {
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
@@ -2839,8 +2841,9 @@ void lstm_trunk_launch(const FFNetDev& d, int N, const uint8_t* s_dev, float* a1
     ProfScope prof(names[2], s);
     hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
                        Conv3F::LDS_TOTAL, s, (const uint8_t*)r2, (const uint4*)d.B3f, (const float*)d.b3, r3, N);
+    if (records) return true;
     hipLaunchKernelGGL(unsplit_records64, dim3(ceil_div((int64_t)N * 49, 4)), dim3(256), 0, s, r3, (int64_t)N * 49);
-    return;
+    return false;
   }
   {
     ProfScope prof(names[0], s);
@@ -2855,6 +2858,7 @@ void lstm_trunk_launch(const FFNetDev& d, int N, const uint8_t* s_dev, float* a1
     ProfScope prof(names[2], s);
     launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
   }
+  return false;
 }
 const char* const kLstmActorNames[3] = {"conv1_bf16x3", "conv2_mfma", "conv3_mfma"};
 }  // namespace
@@ -2909,10 +2913,11 @@ extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_
 // conv trunk only: frames u8[N][4][84][84] -> a1 / a2 / a3 (channel-last, ffnet_layout.h)
 namespace rela_amd {
 int lstmnet_trunk(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, hipStream_t s,
-                  const char* const* names, bool fast) {
+                  const char* const* names, bool fast, bool* a3_records) {
   RELA_CHECK(n && n->loaded, RELA_ESTATE, "lstmnet_trunk: parameters were never loaded");
   RELA_CHECK(N >= 1 && s_dev && a1 && a2 && a3, RELA_EINVAL, "lstmnet_trunk: bad arguments");
-  lstm_trunk_launch(n->d, N, s_dev, a1, a2, a3, fast, s, names);
+  const bool rec = lstm_trunk_launch(n->d, N, s_dev, a1, a2, a3, fast, s, names, a3_records != nullptr);
+  if (a3_records) *a3_records = rec;
   RELA_LAUNCH_CHECK();
   return RELA_OK;
 }

@@ -50,8 +50,9 @@ namespace rela_amd {
 // recurrent part itself.  names: three per-kernel timing labels.
 // fast: conv1 -> conv2 fused and conv3 on split-bf16 MFMA (a3 comes out in f32 as always; a1 is NOT produced and a2 holds
 // split records, so only for passes whose activations nobody reads back)
+// a3_records != NULL (with fast): a3 may stay in split records [rows][49][64 hi | 64 lo] (*a3_records says whether)
 int lstmnet_trunk(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, hipStream_t s,
-                  const char* const* names, bool fast = false);
+                  const char* const* names, bool fast = false, bool* a3_records = nullptr);
 int lstmnet_heads(const rela_lstmnet* n, int N, const float* o, const float* legal, float* ha, float* q, hipStream_t s,
                   const char* name);
 }  // namespace rela_amd

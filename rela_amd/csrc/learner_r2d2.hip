@@ -668,18 +668,23 @@ int forward_pre(rela_r2d2_learner* l, int which, int Bn, const uint8_t* obs, con
   const rela_lstmnet* net = which == 0 ? l->online : l->target;
   const int rowsAll = l->T * Bn;
   // the online pass leaves a1 / a2 / a3 for the backward kernels: always f32
-  int rc = lstmnet_trunk(net, rowsAll, obs, l->a1, l->a2, l->a3, s, kTrunkNames, which == 1 && l->precision == 1);
+  const bool fast_target = which == 1 && l->precision == 1;
+  bool a3_records = false;  // the target net's fast trunk hands a3 over as the split records the gate GEMM reads
+  int rc = lstmnet_trunk(net, rowsAll, obs, l->a1, l->a2, l->a3, s, kTrunkNames, fast_target,
+                         fast_target ? &a3_records : nullptr);
   if (rc != RELA_OK) return rc;
   if (l->precision == 1) {
     using namespace gemm16;
     rc = refresh_weight_records(l, which, s);
     if (rc != RELA_OK) return rc;
-    {
+    const uint8_t* arec = reinterpret_cast<const uint8_t*>(l->a3);
+    if (!a3_records) {
       ProfScope prof("learner_lstm_split_rows", s);
       hipLaunchKernelGGL(split_rows_rec64, dim3(ceil_div((int64_t)rowsAll * kFeat / 8, 256)), dim3(256), 0, s,
                          (const float*)l->a3, (int64_t)rowsAll, kFeat, l->arec);
+      arec = l->arec;
     }
-    rc = launch_rec64_nt(l->arec, l->wrec[which], rowsAll, kGates, kFeat / 64,
+    rc = launch_rec64_nt(arec, l->wrec[which], rowsAll, kGates, kFeat / 64,
                          EpiBias{l->gxs[which], l->bsum[which], kGates}, s, "learner_lstm_gates_x");
     if (rc != RELA_OK) return rc;
   } else {
