@@ -28,6 +28,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "gemm_bf16s.h"
 #include "ffnet_layout.h"
 #include "gemm_lds.h"
 #include "prof.h"
@@ -1961,9 +1962,12 @@ enum GemmEpilogue { kEpiBias = 0, kEpiBiasRelu = 1, kEpiLstmCell = 2 };
 
 // K1_ = leading part of K that comes from the first A matrix ([N][K1]); the rest comes from a
 // second matrix ([N][K-K1]) -- the LSTM gate GEMM reads [conv features | previous h].
-template <int K_, int OC_, int BM_, int EPI_, int K1_ = K_>
+// KSS / KSO: k-steps per column tile of the fragment array and the first one this GEMM uses (a GEMM over a k-range of a
+// larger packed operand); INIT: the accumulators start from a [N][OC] tensor passed in A2's place
+template <int K_, int OC_, int BM_, int EPI_, int K1_ = K_, int KSS_ = K_ / 4, int KSO_ = 0, bool INIT_ = false>
 struct GemmCfg {
-  static constexpr int K = K_, OC = OC_, BM = BM_, EPI = EPI_, K1 = K1_;
+  static constexpr int K = K_, OC = OC_, BM = BM_, EPI = EPI_, K1 = K1_, KSS = KSS_, KSO = KSO_;
+  static constexpr bool INIT = INIT_;
   static constexpr bool RELU = EPI_ == kEpiBiasRelu;
   static constexpr int CT = OC / 16;
   static constexpr int CTB = CT < kWaves ? CT : kWaves;  // column tiles per block
@@ -1987,6 +1991,10 @@ using GemmHeads = GemmCfg<512, 32, 128, kEpiBias>;
 // four gates of a hidden unit sit in four adjacent lanes of one accumulator tile.
 using GemmLstm = GemmCfg<3648, 2048, 128, kEpiLstmCell, 3136>;
 using GemmLstm112 = GemmCfg<3648, 2048, 112, kEpiLstmCell, 3136>;
+// bf16x2 mode of the actors' LSTM step: the x part of the gates comes from the split-bf16 GEMM (gemm_bf16s.h) and
+// this GEMM adds h x W_hh (k-steps 784 .. 911 of the same fragment array) and runs the cell
+using GemmLstmH = GemmCfg<512, 2048, 128, kEpiLstmCell, 512, 912, 784, true>;
+using GemmLstmH112 = GemmCfg<512, 2048, 112, kEpiLstmCell, 512, 912, 784, true>;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -2032,9 +2040,18 @@ __global__ __launch_bounds__(kThreads) void gemm_mfma(const float* __restrict__ 
 
   f32x4 acc[G::RPW];
 #pragma unroll
-  for (int t = 0; t < G::RPW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < G::RPW; ++t) {
+    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (G::INIT) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + (rg * G::RPW + t) * 16 + kk * 4 + r;
+        if (row < N) acc[t][r] = A2[(size_t)row * G::OC + blockIdx.x * G::CTB * 16 + ctw * 16 + li];
+      }
+    }
+  }
 
-  const float* bptr = Bfrag + (size_t)ct * G::KS * 64 + lane;
+  const float* bptr = Bfrag + ((size_t)ct * G::KSS + G::KSO) * 64 + lane;
 
   load_chunk(0);
   store_chunk(0);
@@ -2303,6 +2320,23 @@ __global__ void pack_frags(int mode, const float* __restrict__ w, const float* _
   pack_frags_at((int64_t)blockIdx.x * blockDim.x + threadIdx.x, mode, w, w2, num_action, frag, CT, KS);
 }
 
+// weight_ih_l0 [gate*512 + unit][c*49 + pos] -> rec64 rows in the gate GEMM's permuted column order:
+// rec[col = 4*unit + gate][chunk = pos][64 hi | 64 lo] over c (the B operand of gemm16::gemm_rec64_nt for the x part)
+__global__ void pack_wih_rec64_perm(const float* __restrict__ wih, uint8_t* __restrict__ rec) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 8 channels
+  if (i >= (int64_t)2048 * 392) return;
+  const int col = (int)(i / 392), o = (int)(i - (int64_t)col * 392);
+  const int pos = o >> 3, c0 = (o & 7) * 8;
+  const float* w = wih + (size_t)((col & 3) * 512 + (col >> 2)) * 3136 + pos;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = w[(c0 + j) * 49];
+  uint4 hi, lo;
+  gemm16::split8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]), hi, lo);
+  uint8_t* r = rec + ((size_t)col * 49 + pos) * 256 + (o & 7) * 16;
+  *reinterpret_cast<uint4*>(r) = hi;
+  *reinterpret_cast<uint4*>(r + 128) = lo;
+}
 __global__ void pack_lstm_bias(const float* __restrict__ bih, const float* __restrict__ bhh, float* __restrict__ out) {
   const int oc = blockIdx.x * blockDim.x + threadIdx.x;
   if (oc < 2048) {
@@ -2686,13 +2720,16 @@ struct rela_lstmnet {
   FFNetDev d;            // B1..b3 (trunk) and Bh/bh (heads); Bf/bf unused
   float* Bl = nullptr;   // lstm frags [128][912][64]
   float* bl = nullptr;   // b_ih + b_hh, permuted [2048]
+  uint8_t* Wrec = nullptr;  // weight_ih_l0 as rec64 rows in the permuted column order [2048][49][64 hi | 64 lo]
   bool loaded = false;
   uint64_t version = 0;  // bumped by every load
-  int precision = 0;     // 0 = exact f32 conv trunk, 1 = split-bf16 conv trunk (the LSTM gate GEMM stays f32)
+  // 0 = exact f32; 1 = split-bf16 conv trunk and, from kFastMinN rows up, the x part of the gate GEMM on split-bf16
+  // MFMA too (the recurrent part and the cell stay f32)
+  int precision = 0;
 };
 
 namespace {
-constexpr int64_t kLstmWsFloats = kA1 + kA2 + kA3 + kHA;
+constexpr int64_t kLstmWsFloats = kA1 + kA2 + kA3 + kHA + 2048;  // + the x part of the gates (bf16x2 mode)
 }
 
 extern "C" int rela_lstmnet_create(rela_lstmnet** out, int num_action, int device) {
@@ -2717,6 +2754,7 @@ extern "C" int rela_lstmnet_create(rela_lstmnet** out, int num_action, int devic
   RELA_HIP(hipMalloc(&d.Bh, sizeof(float) * 2 * 128 * 64));
   RELA_HIP(hipMalloc(&d.bh, sizeof(float) * 32));
   RELA_HIP(hipMalloc(&n->Bl, sizeof(float) * (size_t)GemmLstm::CT * GemmLstm::KS * 64));
+  RELA_HIP(hipMalloc(&n->Wrec, (size_t)2048 * 49 * 256));
   RELA_HIP(hipMalloc(&n->bl, sizeof(float) * 2048));
   RELA_HIP(hipMalloc(&d.B1p, sizeof(uint4) * Conv1B::FRAG_UINT4));
   RELA_HIP(hipMalloc(&d.B2f, sizeof(uint4) * Conv2F::CT * Conv2F::KS * 2 * 64));
@@ -2744,7 +2782,7 @@ extern "C" void rela_lstmnet_destroy(rela_lstmnet* n) {
   DeviceGuard g(n->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bh, n->d.bh, n->Bl, n->bl,
-                n->d.B1p, n->d.B2f, n->d.B3f};
+                n->d.B1p, n->d.B2f, n->d.B3f, n->Wrec};
   for (void* p : ps) (void)hipFree(p);
   delete n;
 }
@@ -2802,6 +2840,7 @@ extern "C" int rela_lstmnet_load(rela_lstmnet* n, const rela_lstmnet_params* p, 
   pack(kPackConv2, dv[2], nullptr, n->d.B2, 4, 128);
   pack(kPackConv3, dv[4], nullptr, n->d.B3, 4, 144);
   pack(kPackLstm, dv[6], dv[7], n->Bl, GemmLstm::CT, GemmLstm::KS);
+  hipLaunchKernelGGL(pack_wih_rec64_perm, dim3(ceil_div((int64_t)2048 * 3136 / 8, 256)), dim3(256), 0, s, dv[6], n->Wrec);
   pack(kPackHeads, dv[12], dv[10], n->d.Bh, 2, 128);
   hipLaunchKernelGGL(pack_conv1_bf16x3, dim3(ceil_div(2 * 8 * 64 * 8, 256)), dim3(256), 0, s, dv[0],
                      reinterpret_cast<uint16_t*>(n->d.B1p), 1);
@@ -2879,9 +2918,26 @@ extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_
   float* a2 = a1 + kA1 * N;
   float* a3 = a2 + kA2 * N;
   float* ha = a3 + kA3 * N;
+  float* gx = ha + kHA * N;
   const FFNetDev& d = n->d;
-  lstm_trunk_launch(d, N, s_dev, a1, a2, a3, n->precision == 1, s, kLstmActorNames);
-  {
+  // bf16x2 mode from kFastMinN rows up: a3 stays in split records, the x part of the gates is one split-bf16 GEMM
+  // (gemm_bf16s.h: 41 GFLOP at 3,200 rows) and the f32 MFMA kernel only adds h x W_hh (K = 512) and runs the cell
+  const bool fast_gates = n->precision == 1 && N >= kFastMinN;
+  const bool recs = lstm_trunk_launch(d, N, s_dev, a1, a2, a3, n->precision == 1, s, kLstmActorNames, fast_gates);
+  if (fast_gates && recs) {
+    int rc = gemm16::launch_rec64_nt(reinterpret_cast<const uint8_t*>(a3), n->Wrec, N, 2048, 49, gemm16::EpiPlain{gx, 2048}, s,
+                                     "lstm_gates_x_bf16");
+    if (rc != RELA_OK) return rc;
+    ProfScope prof("lstm_gates_mfma", s);
+    if (prefer_bm112(N, GemmLstmH::CT / GemmLstmH::CTB, GemmLstmH::BM))
+      hipLaunchKernelGGL(gemm_mfma<GemmLstmH112>, dim3(GemmLstmH112::CT / GemmLstmH112::CTB, ceil_div(N, GemmLstmH112::BM)),
+                         dim3(kThreads), 0, s, h_in, (const float*)gx, (const float*)n->Bl, (const float*)n->bl, h_out,
+                         c_in, c_out, N);
+    else
+      hipLaunchKernelGGL(gemm_mfma<GemmLstmH>, dim3(GemmLstmH::CT / GemmLstmH::CTB, ceil_div(N, GemmLstmH::BM)),
+                         dim3(kThreads), 0, s, h_in, (const float*)gx, (const float*)n->Bl, (const float*)n->bl, h_out,
+                         c_in, c_out, N);
+  } else {
     ProfScope prof("lstm_gates_mfma", s);
     if (prefer_bm112(N, GemmLstm::CT / GemmLstm::CTB, GemmLstm::BM))
       hipLaunchKernelGGL(gemm_mfma<GemmLstm112>, dim3(GemmLstm112::CT / GemmLstm112::CTB, ceil_div(N, GemmLstm112::BM)),

@@ -82,8 +82,10 @@ def test_lstm_step_vs_torch(N, A):
 @pytest.mark.parametrize("N", [127, 128, 131, 1537, 3200])
 def test_lstm_step_fast_trunk_within_stated_tolerance(N):
     """rela_lstmnet_set_precision(1): the conv trunk on split-bf16 MFMA for batches of 128 rows and more (conv1 -> conv2
-    fused, conv3, a3 back to f32; the LSTM gate GEMM and the heads stay f32).  h, c, Q and the advantages stay within
-    the fast mode's stated tolerance of the exact f32 step (N = 127 takes the f32 kernels: identical)."""
+    fused, conv3); below 1,024 rows a3 goes back to f32 for the f32 gate GEMM, from 1,024 rows up (1537: ragged last
+    row block, 3200: the bench's shape) the x part of the gates is one split-bf16 GEMM on a3's records and the f32 MFMA
+    kernel adds h x W_hh and runs the cell; the heads stay f32.  h, c, Q and the advantages stay within the fast mode's
+    stated tolerance of the exact f32 step (N = 127 takes the f32 kernels: identical)."""
     from synth import synth_lstm_params, synth_obs
 
     A = 18
