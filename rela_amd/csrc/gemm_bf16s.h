@@ -12,7 +12,9 @@
 //
 // Kernel: 256 x 128 block tile, 8 waves of 64 x 64 (16 accumulator tiles), k-stages of 32 double-buffered in LDS
 // (row = 64 B hi | 64 B lo | 32 B pad: 10 sixteen-byte units, conflict-free for the ds_read_b128 lane groups,
-// tools/lds_conflicts.py), next stage's global loads in registers during the MFMAs, ONE barrier per stage.
+// tools/lds_conflicts.py), the global loads of the next TWO stages in two register sets during the MFMAs, ONE barrier
+// per stage.  PMC at R2D2's shapes (tools/pmc_r2d2_learner.sh): MFMA pipe 36 % busy, LDS 21 %, no bank conflicts --
+// what is left are the read burst after and the store burst before every barrier, on all eight waves at once.
 // Blocks are mapped XCD-aware: block b runs on XCD b % 8, and within an XCD consecutive blocks walk the column
 // blocks of one row block, so the co-resident blocks of an L2 share their A rows and all of B's current k-range.
 #pragma once
@@ -147,7 +149,9 @@ __global__ __launch_bounds__(kT) void gemm_rec64_nt(const uint8_t* __restrict__ 
   // re-reads its last row instead of branching; those accumulators are never stored).  Six named registers, no
   // arrays and no branches around the loads: either pushes the staging data into scratch memory with a wait behind
   // every load.
-  uint4 ra0, ra1, ra2, ra3, rb0, rb1;
+  // two register sets, P and Q: a stage's loads are issued TWO stages before its LDS store (one stage of MFMAs,
+  // 0.64 us, did not cover an L2 miss: MFMA pipe 36 % busy with one set)
+  uint4 pa_0, pa_1, pa_2, pa_3, pb_0, pb_1, qa_0, qa_1, qa_2, qa_3, qb_0, qb_1;
   const int su = tid & 7, srow = tid >> 3;  // this thread's unit and first tile row (rows srow + 64 j)
   const int gofs = (su >> 2) * 128 + (su & 3) * 16;
   const size_t rstride = (size_t)KC * REC;
@@ -158,26 +162,26 @@ __global__ __launch_bounds__(kT) void gemm_rec64_nt(const uint8_t* __restrict__ 
   const uint8_t* pb0 = B + (size_t)min(n0 + srow, N - 1) * rstride + gofs;
   const uint8_t* pb1 = B + (size_t)min(n0 + srow + 64, N - 1) * rstride + gofs;
   const int sofs = srow * ROW + su * 16;
-#define RELA_G_LOAD(ST)                                                          \
+#define RELA_G_LOAD(S, ST)                                                       \
   do {                                                                           \
     const int st__ = min((ST), 2 * KC - 1);                                      \
     const int o__ = (st__ >> 1) * REC + (st__ & 1) * 64;                         \
-    ra0 = *reinterpret_cast<const uint4*>(pa0 + o__);                            \
-    ra1 = *reinterpret_cast<const uint4*>(pa1 + o__);                            \
-    ra2 = *reinterpret_cast<const uint4*>(pa2 + o__);                            \
-    ra3 = *reinterpret_cast<const uint4*>(pa3 + o__);                            \
-    rb0 = *reinterpret_cast<const uint4*>(pb0 + o__);                            \
-    rb1 = *reinterpret_cast<const uint4*>(pb1 + o__);                            \
+    S##a_0 = *reinterpret_cast<const uint4*>(pa0 + o__);                         \
+    S##a_1 = *reinterpret_cast<const uint4*>(pa1 + o__);                         \
+    S##a_2 = *reinterpret_cast<const uint4*>(pa2 + o__);                         \
+    S##a_3 = *reinterpret_cast<const uint4*>(pa3 + o__);                         \
+    S##b_0 = *reinterpret_cast<const uint4*>(pb0 + o__);                         \
+    S##b_1 = *reinterpret_cast<const uint4*>(pb1 + o__);                         \
   } while (0)
-#define RELA_S_STORE(BUF)                                                        \
+#define RELA_S_STORE(S, BUF)                                                     \
   do {                                                                           \
     uint8_t* ta__ = smem + (BUF) * STAGE + sofs;                                 \
-    *reinterpret_cast<uint4*>(ta__) = ra0;                                       \
-    *reinterpret_cast<uint4*>(ta__ + 64 * ROW) = ra1;                            \
-    *reinterpret_cast<uint4*>(ta__ + 128 * ROW) = ra2;                           \
-    *reinterpret_cast<uint4*>(ta__ + 192 * ROW) = ra3;                           \
-    *reinterpret_cast<uint4*>(ta__ + A_BYTES) = rb0;                             \
-    *reinterpret_cast<uint4*>(ta__ + A_BYTES + 64 * ROW) = rb1;                  \
+    *reinterpret_cast<uint4*>(ta__) = S##a_0;                                    \
+    *reinterpret_cast<uint4*>(ta__ + 64 * ROW) = S##a_1;                         \
+    *reinterpret_cast<uint4*>(ta__ + 128 * ROW) = S##a_2;                        \
+    *reinterpret_cast<uint4*>(ta__ + 192 * ROW) = S##a_3;                        \
+    *reinterpret_cast<uint4*>(ta__ + A_BYTES) = S##b_0;                          \
+    *reinterpret_cast<uint4*>(ta__ + A_BYTES + 64 * ROW) = S##b_1;               \
   } while (0)
 
   f32x4 acc[4][4];
@@ -186,14 +190,15 @@ __global__ __launch_bounds__(kT) void gemm_rec64_nt(const uint8_t* __restrict__ 
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int NS = 2 * KC;
-  RELA_G_LOAD(0);
-  RELA_S_STORE(0);
-  RELA_G_LOAD(1);
+  const int NS = 2 * KC;  // (even)
+  RELA_G_LOAD(p, 0);
+  RELA_S_STORE(p, 0);
+  RELA_G_LOAD(p, 1);
+  RELA_G_LOAD(q, 2);
   __syncthreads();
   const int aoff = (wm * 64 + li) * ROW + g * 16, boff = A_BYTES + (wn * 64 + li) * ROW + g * 16;
-  for (int st = 0; st < NS; ++st) {
-    const uint8_t* base = smem + (st & 1) * STAGE;
+  auto mma_stage = [&](int buf) {
+    const uint8_t* base = smem + buf * STAGE;
     uint4 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -213,8 +218,16 @@ __global__ __launch_bounds__(kT) void gemm_rec64_nt(const uint8_t* __restrict__ 
         acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[t][u], 0, 0, 0);
         acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[t][u], 0, 0, 0);
       }
-    RELA_S_STORE((st + 1) & 1);  // (that buffer was last read in stage st - 1: every wave is past its barrier)
-    RELA_G_LOAD(st + 2);
+  };
+  // stage st is in LDS buffer st & 1 when iteration st starts; set P holds stage st + 1 and set Q stage st + 2 at even st
+  for (int st = 0; st < NS; st += 2) {
+    mma_stage(0);
+    RELA_S_STORE(p, 1);  // (buffer 1 was last read in stage st - 1: every wave is past that barrier)
+    RELA_G_LOAD(p, st + 3);
+    __syncthreads();
+    mma_stage(1);
+    RELA_S_STORE(q, 0);
+    RELA_G_LOAD(q, st + 4);
     __syncthreads();
   }
 #undef RELA_G_LOAD
