@@ -20,6 +20,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "prof.h"
 
@@ -244,6 +246,101 @@ __global__ __launch_bounds__(kT) void gemm_rec64_nt(const uint8_t* __restrict__ 
   }
 }
 
+// The same GEMM with a 128 x 128 block tile: 80 KB of LDS and at most 128 registers, so that TWO blocks share a CU and
+// one block's MFMAs fill the other's barrier, read and store bursts (8 waves of 64 x 32, one staging register set).
+constexpr int SBM = 128, S_STAGE = (SBM + BN) * ROW, S_LDS = 2 * S_STAGE;  // 81,920 B
+template <class Epi>
+__global__ __launch_bounds__(kT, 2) void gemm_rec64_nt_s(const uint8_t* __restrict__ A, const uint8_t* __restrict__ B,
+                                                         int M, int N, int KC, Epi epi) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int NRB = (M + SBM - 1) / SBM, NCB = (N + BN - 1) / BN;
+  const int xcd = blockIdx.x & 7, sidx = blockIdx.x >> 3;
+  const int cb = sidx % NCB, rb = (sidx / NCB) * 8 + xcd;
+  if (rb >= NRB) return;
+  const int m0 = rb * SBM, n0 = cb * BN;
+  const int wm = wave >> 2, wn = wave & 3;  // 2 x 4 waves of 64 x 32
+  uint4 ra0, ra1, rb0, rb1;
+  const int su = tid & 7, srow = tid >> 3;
+  const int gofs = (su >> 2) * 128 + (su & 3) * 16;
+  const size_t rstride = (size_t)KC * REC;
+  const uint8_t* pa0 = A + (size_t)min(m0 + srow, M - 1) * rstride + gofs;
+  const uint8_t* pa1 = A + (size_t)min(m0 + srow + 64, M - 1) * rstride + gofs;
+  const uint8_t* pb0 = B + (size_t)min(n0 + srow, N - 1) * rstride + gofs;
+  const uint8_t* pb1 = B + (size_t)min(n0 + srow + 64, N - 1) * rstride + gofs;
+  const int sofs = srow * ROW + su * 16;
+  constexpr int SA = SBM * ROW;
+#define RELA_SG_LOAD(ST)                                      \
+  do {                                                        \
+    const int st__ = min((ST), 2 * KC - 1);                   \
+    const int o__ = (st__ >> 1) * REC + (st__ & 1) * 64;      \
+    ra0 = *reinterpret_cast<const uint4*>(pa0 + o__);         \
+    ra1 = *reinterpret_cast<const uint4*>(pa1 + o__);         \
+    rb0 = *reinterpret_cast<const uint4*>(pb0 + o__);         \
+    rb1 = *reinterpret_cast<const uint4*>(pb1 + o__);         \
+  } while (0)
+#define RELA_SS_STORE(BUF)                                    \
+  do {                                                        \
+    uint8_t* ta__ = smem + (BUF) * S_STAGE + sofs;            \
+    *reinterpret_cast<uint4*>(ta__) = ra0;                    \
+    *reinterpret_cast<uint4*>(ta__ + 64 * ROW) = ra1;         \
+    *reinterpret_cast<uint4*>(ta__ + SA) = rb0;               \
+    *reinterpret_cast<uint4*>(ta__ + SA + 64 * ROW) = rb1;    \
+  } while (0)
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int NS = 2 * KC;
+  RELA_SG_LOAD(0);
+  RELA_SS_STORE(0);
+  RELA_SG_LOAD(1);
+  __syncthreads();
+  const int aoff = (wm * 64 + li) * ROW + g * 16, boff = SA + (wn * 32 + li) * ROW + g * 16;
+  for (int st = 0; st < NS; ++st) {
+    const uint8_t* base = smem + (st & 1) * S_STAGE;
+    uint4 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ah[t] = *reinterpret_cast<const uint4*>(base + aoff + t * 16 * ROW);
+      al[t] = *reinterpret_cast<const uint4*>(base + aoff + t * 16 * ROW + 64);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bh[u] = *reinterpret_cast<const uint4*>(base + boff + u * 16 * ROW);
+      bl[u] = *reinterpret_cast<const uint4*>(base + boff + u * 16 * ROW + 64);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[t]), xl = __builtin_bit_cast(bf16x8, al[t]);
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, bh[u]), wl = __builtin_bit_cast(bf16x8, bl[u]);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[t][u], 0, 0, 0);
+      }
+    RELA_SS_STORE((st + 1) & 1);
+    RELA_SG_LOAD(st + 2);
+    __syncthreads();
+  }
+#undef RELA_SG_LOAD
+#undef RELA_SS_STORE
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int m = m0 + wm * 64 + t * 16 + li;
+    if (m >= M) continue;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int n = n0 + wn * 32 + u * 16 + 4 * g;
+      if (n < N) epi(m, n, acc[t][u]);
+    }
+  }
+}
+
 template <class Epi>
 inline int launch_rec64_nt(const uint8_t* A, const uint8_t* B, int M, int N, int KC, Epi epi, hipStream_t s,
                            const char* name) {
@@ -252,6 +349,23 @@ inline int launch_rec64_nt(const uint8_t* A, const uint8_t* B, int M, int N, int
     RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rec64_nt<Epi>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
     attr_set = true;
+  }
+  // the small tile when the large one would leave most CUs without a block (dW_hh: 32 blocks -> 64 on twice the CUs,
+  // 0.18 -> 0.11 ms); on the large GEMMs it loses to the large tile's operand reuse (gates_x 0.55 -> 0.59 ms) although
+  // two blocks per CU fill each other's barriers: they are bound by operand traffic.  RELA_GEMM_SMALL_TILE=0|1 forces.
+  static const int force = getenv("RELA_GEMM_SMALL_TILE") ? atoi(getenv("RELA_GEMM_SMALL_TILE")) : -1;
+  const bool small_tile = force >= 0 ? force != 0 : ceil_div(M, BM) * ceil_div(N, BN) < 128;
+  if (small_tile) {
+    static bool attr_s = false;
+    if (!attr_s) {
+      RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rec64_nt_s<Epi>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS));
+      attr_s = true;
+    }
+    const int NRB = ceil_div(M, SBM), NCB = ceil_div(N, BN);
+    ProfScope prof(name, s);
+    hipLaunchKernelGGL(gemm_rec64_nt_s<Epi>, dim3(8 * NCB * ceil_div(NRB, 8)), dim3(kT), S_LDS, s, A, B, M, N, KC, epi);
+    return RELA_OK;
   }
   const int NRB = ceil_div(M, BM), NCB = ceil_div(N, BN);
   ProfScope prof(name, s);
