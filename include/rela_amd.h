@@ -301,8 +301,9 @@ int rela_lstmnet_create(rela_lstmnet** out, int num_action, int device);
 void rela_lstmnet_destroy(rela_lstmnet* net);
 int rela_lstmnet_load(rela_lstmnet* net, const rela_lstmnet_params* params, int params_on_device,
                       void* stream);
-/* 0 = exact f32 conv trunk (default), 1 = split-bf16 MFMA conv trunk for batches of 128 rows and more (as
- * rela_ffnet_set_precision; the LSTM gate GEMM and the heads stay f32).  Bumps the weight version. */
+/* 0 = exact f32 (default), 1 = split-bf16 MFMA conv trunk for batches of 128 rows and more (as
+ * rela_ffnet_set_precision) and, from 1,024 rows up, the input side of the LSTM gate GEMM as well (h x W_hh, the
+ * cell and the heads stay f32); h, c, Q within 4e-6 of mode 0.  Bumps the weight version. */
 int rela_lstmnet_set_precision(rela_lstmnet* net, int mode);
 int rela_lstmnet_precision(const rela_lstmnet* net);
 int rela_lstmnet_num_action(const rela_lstmnet* net);
@@ -438,9 +439,11 @@ int rela_apex_learner_load(rela_apex_learner* l, const rela_ffnet_params* online
                            const rela_ffnet_params* target, int params_on_device, void* stream);
 /* ApexAgent.sync_target_with_online  apex.py:26-27 */
 int rela_apex_learner_sync_target(rela_apex_learner* l, void* stream);
-/* Precision of the two gradient-free forwards of td_err (online and target net on next_obs, apex.py:38-42): 0 = exact
- * f32 (default), 1 = split-bf16 MFMA trunk (rela_ffnet_set_precision).  The online(obs) pass, whose activations the
- * backward pass reads, always runs in f32. */
+/* 0 = exact f32 (default).  1 = the two gradient-free forwards of td_err (online and target net on next_obs,
+ * apex.py:38-42) on the split-bf16 MFMA trunk (rela_ffnet_set_precision), conv1's weight gradient and the conv2 /
+ * conv3 data gradients on bf16 MFMA (hi + lo operands, f32 accumulation).  The online(obs) pass, whose activations
+ * and ReLU masks the backward pass reads, always runs in f32: priorities and loss within 5e-6, every gradient within
+ * 1e-4 of its largest entry of mode 0. */
 int rela_apex_learner_set_precision(rela_apex_learner* l, int mode);
 /* loss + backward on one sampled batch.  rows_dev: the ten FFTransition fields in the order
  * rela_replay_sample fills them; weight_dev f32[batch] = the IS weights.  Leaves the gradient of
@@ -513,8 +516,11 @@ const float* rela_r2d2_learner_stats_dev(const rela_r2d2_learner* l); /* grad no
  * counterpart: autograd launches per step).  Synchronises `stream` and returns RELA_ESTATE if a barrier of any call
  * since the last check gave up (never observed; the results of that call are then invalid). */
 int rela_r2d2_learner_check(rela_r2d2_learner* l, void* stream);
-/* 1: the TARGET net's conv trunk (no gradient) runs on split-bf16 MFMA (rela_lstmnet_set_precision); the online net's
- * pass, whose activations the backward kernels read, stays f32.  0 (default): everything f32. */
+/* 1: the TARGET net's conv trunk (no gradient) runs on split-bf16 MFMA (rela_lstmnet_set_precision) and so do the GEMMs
+ * of the LSTM's input side (gate GEMM of both nets, its data and weight gradients, dW_hh), the conv weight gradients
+ * and the conv data gradients (hi + lo bf16 operands, f32 accumulation); the online net's conv trunk, whose
+ * activations and ReLU masks the backward kernels read, stays f32.  Loss, priorities within 2e-5, gradients within
+ * 2e-4 of their largest entry of mode 0.  0 (default): everything f32. */
 int rela_r2d2_learner_set_precision(rela_r2d2_learner* l, int mode);
 
 /* ===================================================================================

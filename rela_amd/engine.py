@@ -176,8 +176,9 @@ class LSTMNetHandle:
         self._keep = keep
 
     def set_precision(self, mode):
-        """"f32" (default) or "bf16x2": the conv trunk on split-bf16 MFMA for batches of 128 rows and more (the LSTM
-        gate GEMM and the heads stay f32); rela_lstmnet_set_precision."""
+        """"f32" (default) or "bf16x2": the conv trunk on split-bf16 MFMA for batches of 128 rows and more and, from
+        1,024 rows up, the input side of the LSTM gate GEMM (h x W_hh, the cell and the heads stay f32);
+        rela_lstmnet_set_precision."""
         capi.check(capi.lib.rela_lstmnet_set_precision(self.h, {"f32": 0, "bf16x2": 1}[mode]), "rela_lstmnet_set_precision")
 
     def close(self):
