@@ -185,6 +185,7 @@ __global__ void reduce_splits(const float* __restrict__ part, int splits, int M,
   if (idx >= M * N) return;
   const int m = idx / N, n = idx - m * N;
   float s = 0.f;
+#pragma unroll 8  // (the adds stay in z order; eight loads in flight instead of one)
   for (int z = 0; z < splits; ++z) s += part[((size_t)z * M + m) * N + n];
   if (mode == kRedConv1) {
     out[(size_t)m * N + n] = s / 255.0f;
