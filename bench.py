@@ -322,7 +322,7 @@ def bench_r2d2(args, world, rank, device):
     for _ in range(args.warmup):
         one_step()
     sync_all()
-    capi.lib.rela_prof_set_filter(b"lstm_gates_mfma,conv1_bf16x3,conv2_mfma,conv3_mfma")
+    capi.lib.rela_prof_set_filter(b"lstm_gates_mfma,lstm_gates_x_bf16,conv1_bf16x3,conv2_mfma,conv3_mfma")
     capi.lib.rela_prof_enable(1)
     add0 = replay.num_add()
     t0 = time.perf_counter()
@@ -352,9 +352,14 @@ def bench_r2d2(args, world, rank, device):
     st = replay.debug_state()
     assert st["dev_error"] == 0
     if rank == 0:
-        rec = prof.get("lstm_gates_mfma", {"total_ms": 0.0, "count": 1})
+        # the actors' gate GEMM: one f32 MFMA kernel over [x | h] (f32 mode), or (bf16x2 mode, >= 1,024 rows) the x part as a
+        # split-bf16 GEMM (three bf16 MFMAs per product) followed by the f32 kernel over h only: the roofline is the x part's
+        split_gates = "lstm_gates_x_bf16" in prof
+        roof_name = "lstm_gates_x_bf16" if split_gates else "lstm_gates_mfma"
+        rec = prof.get(roof_name, {"total_ms": 0.0, "count": 1})
         avg_ms = rec["total_ms"] / max(rec["count"], 1)
-        flops = FLOP_LSTM_GATES * R2_ROWS
+        flops = (2 * 3136 * 2048 if split_gates else FLOP_LSTM_GATES) * R2_ROWS
+        roof_peak = PEAK_BF16_MFMA_TFLOPS / 3 if split_gates else PEAK_F32_MFMA_TFLOPS
         ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else None
         sample_ms = sum(v["total_ms"] for k, v in prof_all.items() if k.startswith("seq_") or k.startswith("replay_gather")
                         or k in ("replay_targets", "replay_search", "replay_pop", "replay_is_weights")) / k_all
@@ -365,8 +370,10 @@ def bench_r2d2(args, world, rank, device):
             "value": R2_ROWS * world * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f32; conv trunks of the actors' nets and of the learner's target "
-                                                           "net on split-bf16 MFMA (f32 results within 2e-6)",
+            "dtype": "f32" if args.precision == "f32" else "f32 results from split-bf16 MFMA (bf16 hi+lo operands, f32 accumulate): "
+                                                           "the actors' conv trunks and gate GEMM (h, c, Q within 4e-6), the "
+                                                           "learner's target trunk, LSTM GEMMs and conv gradients (gradients "
+                                                           "within 2e-4); recurrences, cells, heads and the online trunk in f32",
             "data": "synthetic",
             "config": {"workload": "R2D2 LSTM (BASELINE config C4's shapes), 40 threads x 80 games (3200 envs) per GPU, "
                                    "actor + learner on one MI355X, sequence replay of %d x 3.47 MB device-resident, A=18, "
@@ -382,9 +389,11 @@ def bench_r2d2(args, world, rank, device):
             # R2D2 grad-step (B = 64) ~ 0.80 TFLOP algorithmic
             "learner_tflops": 0.80 * (B_LOCAL / 64.0) / (learner_ms * 1e-3) if learner_ms > 0 else None,
             "kernels_ms_per_step": {k: v["total_ms"] / k_all for k, v in sorted(prof_all.items())},
-            "roofline": {"kernel": "lstm_gates_mfma", "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": None if ach is None else ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "avg_launch_ms": avg_ms, "launches": rec["count"], "algorithmic_flop_per_launch": flops},
+            "roofline": {"kernel": roof_name, "bound": "mfma", "achieved": ach, "peak": roof_peak,
+                         "unit": "TFLOP/s", "frac": None if ach is None else ach / roof_peak, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches": rec["count"], "algorithmic_flop_per_launch": flops,
+                         "instruction": "v_mfma_f32_16x16x32_bf16 x3 (split operands)" if split_gates
+                         else "v_mfma_f32_16x16x4_f32"},
             "roofline_hbm": None if sample_ms <= 0 else {
                 "kernel": "rela_replay_sample (scan + time-major gather of 64 x 3.47 MB)", "bound": "hbm", "unit": "GB/s",
                 "peak": PEAK_HBM_GBS, "achieved": sample_bytes / (sample_ms * 1e-3) / 1e9,
