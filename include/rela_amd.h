@@ -375,7 +375,8 @@ int64_t rela_apex_actor_num_act(const rela_apex_actor* a); /* numAct()  dqn_acto
  * on = 1 (default): reuse both; 2: only the one of next_obs; 0: always recompute, i.e. the reference's
  * 4 forwards per step */
 int rela_apex_actor_set_reuse(rela_apex_actor* a, int on);
-/* diagnostic: device pointers of the last Q table of act() and of the last priorities       */
+/* diagnostic: device pointers of the last Q table of act() (it lives in the history slot that act() wrote: look the
+ * pointer up after every act()) and of the last priorities */
 const float* rela_apex_actor_last_q_dev(const rela_apex_actor* a);
 const float* rela_apex_actor_last_priority_dev(const rela_apex_actor* a);
 

@@ -102,7 +102,7 @@ class ApexActorEngine:
         self.obs_hist = dev_view(base, (multi_step + 1, rows, 4, 84, 84), torch.uint8, dev)
         self.eps = dev_view(capi.lib.rela_apex_actor_eps_dev(h), (rows, 1), torch.float32, dev)
         self.legal = dev_view(capi.lib.rela_apex_actor_legal_dev(h), (rows, num_action), torch.float32, dev)
-        self.q = dev_view(capi.lib.rela_apex_actor_last_q_dev(h), (4, rows, num_action), torch.float32, dev)
+        self._rows, self._A = rows, num_action
         self.prio = dev_view(capi.lib.rela_apex_actor_last_priority_dev(h), (rows,), torch.float32, dev)
         self.eps.copy_(torch.as_tensor(eps, dtype=torch.float32).reshape(rows, 1))
         self._slot = 0
@@ -123,8 +123,15 @@ class ApexActorEngine:
     def num_act(self):
         return capi.lib.rela_apex_actor_num_act(self.h)
 
+    @property
+    def q(self):
+        """[1, rows, A] view of the Q table of the last act() (rela_apex_actor_last_q_dev: the table lives in the
+        history slot act() wrote, so the pointer is looked up per call)."""
+        return dev_view(capi.lib.rela_apex_actor_last_q_dev(self.h), (1, self._rows, self._A), torch.float32, self.device)
+
     def set_reuse(self, on):
-        """on=False: post_step always recomputes online(next_obs) (the reference's 4 forwards per step)."""
+        """on=0 / False: post_step always recomputes (the reference's 4 forwards per step); 1 / True: reuses act()'s
+        forwards of this tick and of n ticks ago; 2: only the one of this tick."""
         capi.check(capi.lib.rela_apex_actor_set_reuse(self.h, int(on)), "rela_apex_actor_set_reuse")
 
     def next_obs_slot(self):
