@@ -44,6 +44,28 @@ struct ProbHeadDgrad : ProbBase {
   }
 };
 
+// the same over many rows (R2D2: 5,312 training rows), split over blockIdx.z into partial tiles part[z][32][512]
+// that head_wgrad_reduce sums in z order (one 32 x 512 output: without the split the GEMM is 8 blocks)
+struct ProbHeadWgradPart : ProbBase {
+  const float *d_ha, *h;
+  float* part;
+  __device__ float4 loadA(int b, int m) const { return b < K ? ld4(d_ha + (size_t)b * 32 + m) : zero4(); }
+  __device__ float4 loadB(int b, int n) const { return b < K ? ld4(h + (size_t)b * 512 + n) : zero4(); }
+  __device__ void store(int z, int m, int n, float v) const { part[((size_t)z * 32 + m) * 512 + n] = v; }
+};
+__global__ void head_wgrad_reduce(const float* __restrict__ part, int splits, int A, float* __restrict__ g_a_w,
+                                  float* __restrict__ g_v_w) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 32 * 512) return;
+  const int m = idx >> 9, n = idx & 511;
+  if (m >= A && m != 31) return;
+  float s = 0.f;
+#pragma unroll 8
+  for (int z = 0; z < splits; ++z) s += part[(size_t)z * (32 * 512) + idx];
+  if (m < A) g_a_w[(size_t)m * 512 + n] = s;
+  else g_v_w[n] = s;
+}
+
 // dWh[k][u] = sum_b d_ha[b][k] * h[b][u]
 struct ProbHeadWgrad : ProbBase {
   const float *d_ha, *h;

@@ -1051,7 +1051,16 @@ extern "C" int rela_r2d2_learner_grad(rela_r2d2_learner* l, void* stream_) {
     p.d_ha = l->d_ha, p.a_w = P.a_w, p.v_w = P.v_w, p.d_o = l->d_o, p.A = A;
     launch_gemm<TileRows>(p, 1, s, "learner_dgrad_heads");
   }
-  {
+  if (rowsTr >= 1024) {  // split-K over 32 slices: 256 blocks instead of 8 (0.13 ms on 8 CUs at 5,312 rows)
+    constexpr int kSplitHeads = 32;
+    static_assert((size_t)kSplitHeads * 32 * 512 <= kTrunkPartFloats, "part size");
+    ProbHeadWgradPart p{};
+    p.M = 32, p.N = kHid, p.K = rowsTr;
+    p.d_ha = l->d_ha, p.h = o_tr, p.part = l->part;
+    launch_gemm<TileW32r>(p, kSplitHeads, s, "learner_wgrad_heads");
+    hipLaunchKernelGGL(head_wgrad_reduce, dim3(ceil_div(32 * 512, 256)), dim3(256), 0, s, (const float*)l->part,
+                       kSplitHeads, A, Gm[12], Gm[10]);
+  } else {
     ProbHeadWgrad p{};
     p.M = 32, p.N = kHid, p.K = rowsTr;
     p.d_ha = l->d_ha, p.h = o_tr, p.g_a_w = Gm[12], p.g_v_w = Gm[10], p.A = A;
