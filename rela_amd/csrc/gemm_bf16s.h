@@ -344,24 +344,20 @@ __global__ __launch_bounds__(kT, 2) void gemm_rec64_nt_s(const uint8_t* __restri
 template <class Epi>
 inline int launch_rec64_nt(const uint8_t* A, const uint8_t* B, int M, int N, int KC, Epi epi, hipStream_t s,
                            const char* name) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rec64_nt<Epi>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    attr_set = true;
-  }
+  // (initialised once, thread-safely: launches may come from several host threads)
+  static const hipError_t attr_set =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rec64_nt<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+  RELA_HIP(attr_set);
   // the small tile when the large one would leave most CUs without a block (dW_hh: 32 blocks -> 64 on twice the CUs,
   // 0.18 -> 0.11 ms); on the large GEMMs it loses to the large tile's operand reuse (gates_x 0.55 -> 0.59 ms) although
   // two blocks per CU fill each other's barriers: they are bound by operand traffic.  RELA_GEMM_SMALL_TILE=0|1 forces.
   static const int force = getenv("RELA_GEMM_SMALL_TILE") ? atoi(getenv("RELA_GEMM_SMALL_TILE")) : -1;
   const bool small_tile = force >= 0 ? force != 0 : ceil_div(M, BM) * ceil_div(N, BN) < 128;
   if (small_tile) {
-    static bool attr_s = false;
-    if (!attr_s) {
-      RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rec64_nt_s<Epi>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS));
-      attr_s = true;
-    }
+    // (initialised once, thread-safely: launches may come from several host threads)
+    static const hipError_t attr_s =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_rec64_nt_s<Epi>), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS);
+    RELA_HIP(attr_s);
     const int NRB = ceil_div(M, SBM), NCB = ceil_div(N, BN);
     ProfScope prof(name, s);
     hipLaunchKernelGGL(gemm_rec64_nt_s<Epi>, dim3(8 * NCB * ceil_div(NRB, 8)), dim3(kT), S_LDS, s, A, B, M, N, KC, epi);

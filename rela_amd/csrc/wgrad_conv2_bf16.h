@@ -195,12 +195,10 @@ __global__ __launch_bounds__(kT) void wgrad_conv2_bf16(const float* __restrict__
 }
 
 inline int launch(const float* a1, const float* d_a2, int frames, float* part, hipStream_t s, int* blocks_out) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_conv2_bf16),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL));
-    attr_set = true;
-  }
+  // (initialised once, thread-safely: launches may come from several host threads)
+  static const hipError_t attr_set =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_conv2_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+  RELA_HIP(attr_set);
   const int blocks = frames < kMaxBlocks ? frames : kMaxBlocks;
   hipLaunchKernelGGL(wgrad_conv2_bf16, dim3(blocks), dim3(kT), LDS_TOTAL, s, a1, d_a2, frames, part);
   *blocks_out = blocks;
