@@ -262,7 +262,23 @@ def test_learner_errors():
     assert capi.lib.rela_apex_learner_create(C.byref(h), 40, 32, 3, 0.99, 0, 1e-4, 1e-4, 40.0, 0) == capi.EINVAL
     assert capi.lib.rela_apex_learner_create(C.byref(h), 6, 32, 3, 0.99, 0, 1e-4, 1e-4, 40.0, 0) == capi.OK
     assert capi.lib.rela_apex_learner_apply(h, None) == capi.ESTATE  # never loaded
+    assert capi.lib.rela_apex_learner_grad(h, None) == capi.ESTATE  # never loaded, and no loss() to differentiate
     capi.lib.rela_apex_learner_destroy(h)
+    # grad() needs a loss() before it, once per loss(); a batch larger than the learner's is refused by its nets
+    from rela_amd.learner import HipApexLearner
+
+    learner = HipApexLearner.from_agent(make_agent(6, 3), 32)
+    with pytest.raises(RuntimeError):
+        learner.grad()
+    batch, w = make_batch(32, 6, 4)
+    learner.loss(batch, w)
+    learner.grad()
+    with pytest.raises(RuntimeError):
+        learner.grad()
+    big, wb = make_batch(48, 6, 4)
+    with pytest.raises(RuntimeError):
+        learner.loss(big, wb)
+    learner.close()
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "learner_*.json"))), ids=os.path.basename)
