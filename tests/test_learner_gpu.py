@@ -84,9 +84,11 @@ def test_loss_priority_and_gradients_match_autograd(B, A):
 @pytest.mark.parametrize("B", [512, 200, 64])
 def test_learner_fast_mode_within_stated_tolerance(B):
     """set_precision("bf16x2"): the two gradient-free forwards of td_err (online and target net on next_obs) run their
-    conv trunk on split-bf16 MFMA (fc in f32 below 1,024 rows; below 128 rows everything stays f32); the pass whose
-    activations feed the backward stays f32.  Loss, priorities and every gradient tensor stay within the fast mode's
-    stated tolerance of the all-f32 step (|dQ| < 2e-6 moves a TD error by at most that)."""
+    conv trunk on split-bf16 MFMA (fc in f32 below 1,024 rows; below 128 rows everything stays f32), conv1's weight
+    gradient (csrc/wgrad_conv1_bf16.h: 2 frames per block at B = 512, one at 200 and 64) and the conv2 / conv3 data
+    gradients (csrc/dgrad_conv_bf16.h) run on bf16 MFMA; the online(obs) pass, whose activations and ReLU masks feed
+    the backward, stays f32.  Loss, priorities and every gradient tensor stay within the fast mode's stated tolerance
+    of the all-f32 step (|dQ| < 2e-6 moves a TD error by at most that)."""
     import torch
 
     from rela_amd.learner import HipApexLearner
