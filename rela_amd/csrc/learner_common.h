@@ -389,10 +389,19 @@ __global__ __launch_bounds__(256) void sumsq_partial(const float* __restrict__ g
   if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 // out[0] = total 2-norm, out[1] = min(1, max_norm / (norm + 1e-6))   (torch clip_grad_norm_)
-__global__ void clip_coef(const double* __restrict__ part, int nblk, float max_norm, float* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s = 0.0;
-  for (int i = 0; i < nblk; ++i) s += part[i];
+__global__ __launch_bounds__(256) void clip_coef(const double* __restrict__ part, int nblk, float max_norm,
+                                                 float* __restrict__ out) {
+  // one block of 256 threads: fixed-order tree over the (at most 256) partial sums (a single thread walking them took
+  // 20 us of every learner step)
+  __shared__ double red[256];
+  red[threadIdx.x] = (int)threadIdx.x < nblk ? part[threadIdx.x] : 0.0;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double s = red[0];
   const float norm = (float)sqrt(s);
   out[0] = norm;
   const float c = max_norm / (norm + 1e-6f);
@@ -568,7 +577,7 @@ inline void optimizer_apply(OptimState& o, float* P, const float* G, float* S1, 
                             float* norm, hipStream_t s) {
   ProfScope prof("learner_optimizer", s);
   hipLaunchKernelGGL(sumsq_partial, dim3(kNormBlocks), dim3(256), 0, s, G, n, npart);
-  hipLaunchKernelGGL(clip_coef, dim3(1), dim3(1), 0, s, (const double*)npart, kNormBlocks, o.clip, norm);
+  hipLaunchKernelGGL(clip_coef, dim3(1), dim3(256), 0, s, (const double*)npart, kNormBlocks, o.clip, norm);
   if (o.optimizer == 0) {
     hipLaunchKernelGGL(rmsprop_update, dim3(ceil_div(n, 256)), dim3(256), 0, s, P, G, S1, n, o.lr, 0.99f, o.eps,
                        (const float*)norm);
