@@ -535,6 +535,12 @@ int rela_prof_enable(int on);
 int rela_prof_set_filter(const char* names);
 /* synchronises the device; writes {"kernel":{"count":n,"total_ms":t},...} and clears */
 int rela_prof_summary_json(char* out, int64_t cap);
+/* Launch census for the parity tests: counts launches by the kernel that REALLY ran (the timing labels above are
+ * per layer and shared by the f32 and the split-bf16 kernels), so a test of a fast mode can assert that the fast
+ * kernels were launched and not silently replaced by the f32 ones.  rela_prof_counts_json writes
+ * {"kernel": launches, ...} since the enable / the last call and clears.                         */
+int rela_prof_count_enable(int on);
+int rela_prof_counts_json(char* out, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -168,6 +168,8 @@ _sig("rela_r2d2_learner_set_precision", i32, [vp, i32])
 _sig("rela_prof_enable", i32, [i32])
 _sig("rela_prof_set_filter", i32, [C.c_char_p])
 _sig("rela_prof_summary_json", i32, [C.c_char_p, i64])
+_sig("rela_prof_count_enable", i32, [i32])
+_sig("rela_prof_counts_json", i32, [C.c_char_p, i64])
 
 
 class RelaError(RuntimeError):
@@ -180,3 +182,22 @@ class RelaError(RuntimeError):
 def check(code, where):
     if code != OK:
         raise RelaError(code, where)
+
+
+class launch_census:
+    """`with launch_census() as c: ...; c.counts` -- the kernels that REALLY ran inside the block, by name
+    (rela_prof_count_enable / rela_prof_counts_json): the parity tests of a fast mode assert on it."""
+
+    def __enter__(self):
+        check(lib.rela_prof_count_enable(1), "rela_prof_count_enable")
+        self.counts = {}
+        return self
+
+    def __exit__(self, *exc):
+        import json
+
+        buf = C.create_string_buffer(1 << 16)
+        check(lib.rela_prof_counts_json(buf, len(buf)), "rela_prof_counts_json")
+        lib.rela_prof_count_enable(0)
+        self.counts = json.loads(buf.value.decode())
+        return False

@@ -20,6 +20,7 @@
 // MFMAs), one barrier per frame, A fragments three steps ahead in a register ring, the ReLU mask rows of a frame's
 // outputs loaded before its MFMAs.  conv2 moves 654 MB of compulsory traffic in 0.138 ms at R2D2's shape (4.7 TB/s).
 #pragma once
+#include "prof.h"
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -352,6 +353,7 @@ inline int launch_conv2(const float* d_a2, const float* w2p, const float* a1, fl
       hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_conv2_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, D2::LDS);
   RELA_HIP(attr_set);
   hipLaunchKernelGGL(pack_dgrad2_frags, dim3(ceil_div(4 * 2 * 8 * 64, 256)), dim3(256), 0, s, w2p, (uint4*)scratch);
+  note_launch("dgrad_conv2_bf16");
   hipLaunchKernelGGL(dgrad_conv2_bf16, dim3(frames < 256 ? frames : 256), dim3(kT), D2::LDS, s, d_a2,
                      (const uint4*)scratch, a1, d_a1, frames);
   return RELA_OK;
@@ -363,6 +365,7 @@ inline int launch_conv3(const float* d_a3, const float* w3p, const float* a2, fl
       hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_conv3_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, D3::LDS);
   RELA_HIP(attr_set);
   hipLaunchKernelGGL(pack_dgrad3_frags, dim3(ceil_div(4 * 18 * 64, 256)), dim3(256), 0, s, w3p, (uint4*)scratch);
+  note_launch("dgrad_conv3_bf16");
   hipLaunchKernelGGL(dgrad_conv3_bf16, dim3(frames < 256 ? frames : 256), dim3(kT), D3::LDS, s, d_a3,
                      (const uint4*)scratch, a2, d_a2, frames);
   return RELA_OK;

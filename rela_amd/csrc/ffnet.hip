@@ -377,6 +377,7 @@ __global__ __launch_bounds__(kThreads) void conv_mfma_bstat(const float* __restr
 template <class C>
 void launch_conv(const float* in, const float* Bfrag, const float* bias, float* out, int N, hipStream_t s) {
   const int ngroups = ceil_div(N, C::S);
+  note_launch(C::K == 512 ? "conv_mfma<Conv2> (f32)" : "conv_mfma<Conv3> (f32)");
   if (C::BSTAT && ngroups >= 2 * kNumCU)
     hipLaunchKernelGGL(conv_mfma_bstat<C>, dim3(kNumCU), dim3(kThreads), 2 * C::LDS_BYTES, s, in, Bfrag, bias, out, N);
   else
@@ -2612,14 +2613,14 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
       ProfScope prof(name12, s);
-      hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
+      note_launch("conv12_bf16s"); hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
     }
     {
       ProfScope prof(names[2], s);
-      hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
+      note_launch("conv_bf16s<Conv3F>"); hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
                          Conv3F::LDS_TOTAL, s, (const uint8_t*)r2, (const uint4*)d.B3f, (const float*)d.b3, r3, N);
-      hipLaunchKernelGGL(unsplit_records64, dim3(ceil_div((int64_t)N * 49, 4)), dim3(256), 0, s, r3, (int64_t)N * 49);
+      note_launch("unsplit_records64"); hipLaunchKernelGGL(unsplit_records64, dim3(ceil_div((int64_t)N * 49, 4)), dim3(256), 0, s, r3, (int64_t)N * 49);
     }
   }
   if (precision == 1 && N >= fast_min_n) {
@@ -2630,45 +2631,45 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     static const int fuse_mode = getenv("RELA_FUSE12") ? atoi(getenv("RELA_FUSE12")) : 1;
     if (fuse_mode == 3) {
       ProfScope prof(name12, s);
-      hipLaunchKernelGGL(conv12_ms, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12S::LDS_TOTAL, s, s_dev,
+      note_launch("conv12_ms"); hipLaunchKernelGGL(conv12_ms, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12S::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N,
                          n->pipe_tmo);
     } else if (fuse_mode == 2) {
       ProfScope prof(name12, s);
-      hipLaunchKernelGGL(conv12_pipe, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12P::LDS_TOTAL, s, s_dev,
+      note_launch("conv12_pipe"); hipLaunchKernelGGL(conv12_pipe, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12P::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N,
                          n->pipe_tmo);
     } else if (fuse_mode == 1) {
       ProfScope prof(name12, s);
-      hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
+      note_launch("conv12_bf16s"); hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
     } else {
     {
       ProfScope prof(names[0], s);
-      hipLaunchKernelGGL((conv1_persist<true, 2>), dim3(std::min(2 * kNumCU, 2 * N)), dim3(Conv1P::THREADS),
+      note_launch("conv1_persist"); hipLaunchKernelGGL((conv1_persist<true, 2>), dim3(std::min(2 * kNumCU, 2 * N)), dim3(Conv1P::THREADS),
                          Conv1P::LDS_BYTES, s, s_dev, d.B1p, d.b1, a1, N);
       }
       {
       ProfScope prof(names[1], s);
-      hipLaunchKernelGGL(conv_bf16s<Conv2F>, dim3(std::min(kNumCU, ceil_div(N, Conv2F::S))), dim3(kThreads),
+      note_launch("conv_bf16s<Conv2F>"); hipLaunchKernelGGL(conv_bf16s<Conv2F>, dim3(std::min(kNumCU, ceil_div(N, Conv2F::S))), dim3(kThreads),
                          Conv2F::LDS_TOTAL, s, (const uint8_t*)r1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
       }
     }
     {
       ProfScope prof(names[2], s);
-      hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
+      note_launch("conv_bf16s<Conv3F>"); hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
                          Conv3F::LDS_TOTAL, s, (const uint8_t*)r2, (const uint4*)d.B3f, (const float*)d.b3, r3, N);
     }
     {
       ProfScope prof(names[3], s);
-      hipLaunchKernelGGL(fc_bf16s<FcFast>, dim3(4, ceil_div(N, FcFast::BM)), dim3(kThreads), FcFast::LDS_BYTES, s,
+      note_launch("fc_bf16s"); hipLaunchKernelGGL(fc_bf16s<FcFast>, dim3(4, ceil_div(N, FcFast::BM)), dim3(kThreads), FcFast::LDS_BYTES, s,
                          (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, h, N);
     }
   } else {
   if (!fast_trunk_only) {
   {
     ProfScope prof(names[0], s);
-    hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
+    note_launch("conv1_bf16x3"); hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
                        d.B1, d.b1, a1, N);
   }
   {
@@ -2688,10 +2689,11 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     p.M = N, p.N = 512, p.K = 3136;
     p.a3 = a3, p.wt = d.BfT, p.part = part;
     gemm::launch_gemm<TileFcSmall>(p, splits, s, names[3]);
-    hipLaunchKernelGGL(fc_reduce, dim3(ceil_div(N * 128, 256)), dim3(256), 0, s, (const float*)part, splits, N,
+    note_launch("fc_reduce"); hipLaunchKernelGGL(fc_reduce, dim3(ceil_div(N * 128, 256)), dim3(256), 0, s, (const float*)part, splits, N,
                        (const float*)d.bf, h);
   } else {
     ProfScope prof(names[3], s);
+    note_launch("gemm_mfma<GemmFc> (f32)");
     if (prefer_bm112(N, GemmFc::CT / GemmFc::CTB, GemmFc::BM))
       hipLaunchKernelGGL(gemm_mfma<GemmFc112>, dim3(GemmFc112::CT / GemmFc112::CTB, ceil_div(N, GemmFc112::BM)),
                          dim3(kThreads), 0, s, (const float*)a3, (const float*)nullptr, (const float*)d.Bf,
@@ -2704,7 +2706,7 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
   }
   {
     ProfScope prof(names[4], s);
-    hipLaunchKernelGGL(heads_duel, dim3(ceil_div(N, kHeadRows)), dim3(256), 0, s, (const float*)h, (const float*)d.Bhp,
+    note_launch("heads_duel"); hipLaunchKernelGGL(heads_duel, dim3(ceil_div(N, kHeadRows)), dim3(256), 0, s, (const float*)h, (const float*)d.Bhp,
                        (const float*)d.bh, legal_dev, ha, q_dev, N, n->num_action);
   }
   RELA_LAUNCH_CHECK();
@@ -2874,19 +2876,19 @@ bool lstm_trunk_launch(const FFNetDev& d, int N, const uint8_t* s_dev, float* a1
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
       ProfScope prof(names[1], s);
-      hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
+      note_launch("conv12_bf16s"); hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
     }
     ProfScope prof(names[2], s);
-    hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
+    note_launch("conv_bf16s<Conv3F>"); hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
                        Conv3F::LDS_TOTAL, s, (const uint8_t*)r2, (const uint4*)d.B3f, (const float*)d.b3, r3, N);
     if (records) return true;
-    hipLaunchKernelGGL(unsplit_records64, dim3(ceil_div((int64_t)N * 49, 4)), dim3(256), 0, s, r3, (int64_t)N * 49);
+    note_launch("unsplit_records64"); hipLaunchKernelGGL(unsplit_records64, dim3(ceil_div((int64_t)N * 49, 4)), dim3(256), 0, s, r3, (int64_t)N * 49);
     return false;
   }
   {
     ProfScope prof(names[0], s);
-    hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
+    note_launch("conv1_bf16x3"); hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
                        d.b1, a1, N);
   }
   {
@@ -2929,6 +2931,7 @@ extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_
                                      "lstm_gates_x_bf16");
     if (rc != RELA_OK) return rc;
     ProfScope prof("lstm_gates_mfma", s);
+    note_launch("gemm_mfma<GemmLstmH> (f32)");
     if (prefer_bm112(N, GemmLstmH::CT / GemmLstmH::CTB, GemmLstmH::BM))
       hipLaunchKernelGGL(gemm_mfma<GemmLstmH112>, dim3(GemmLstmH112::CT / GemmLstmH112::CTB, ceil_div(N, GemmLstmH112::BM)),
                          dim3(kThreads), 0, s, h_in, (const float*)gx, (const float*)n->Bl, (const float*)n->bl, h_out,
@@ -2939,6 +2942,7 @@ extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_
                          c_in, c_out, N);
   } else {
     ProfScope prof("lstm_gates_mfma", s);
+    note_launch("gemm_mfma<GemmLstm> (f32)");
     if (prefer_bm112(N, GemmLstm::CT / GemmLstm::CTB, GemmLstm::BM))
       hipLaunchKernelGGL(gemm_mfma<GemmLstm112>, dim3(GemmLstm112::CT / GemmLstm112::CTB, ceil_div(N, GemmLstm112::BM)),
                          dim3(kThreads), 0, s, (const float*)a3, h_in, (const float*)n->Bl, (const float*)n->bl, h_out,

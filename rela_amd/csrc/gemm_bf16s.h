@@ -360,11 +360,13 @@ inline int launch_rec64_nt(const uint8_t* A, const uint8_t* B, int M, int N, int
     RELA_HIP(attr_s);
     const int NRB = ceil_div(M, SBM), NCB = ceil_div(N, BN);
     ProfScope prof(name, s);
+    note_launch("gemm_rec64_nt");
     hipLaunchKernelGGL(gemm_rec64_nt_s<Epi>, dim3(8 * NCB * ceil_div(NRB, 8)), dim3(kT), S_LDS, s, A, B, M, N, KC, epi);
     return RELA_OK;
   }
   const int NRB = ceil_div(M, BM), NCB = ceil_div(N, BN);
   ProfScope prof(name, s);
+  note_launch("gemm_rec64_nt");
   hipLaunchKernelGGL(gemm_rec64_nt<Epi>, dim3(8 * NCB * ceil_div(NRB, 8)), dim3(kT), LDS_TOTAL, s, A, B, M, N, KC, epi);
   return RELA_OK;
 }

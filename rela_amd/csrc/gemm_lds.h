@@ -156,6 +156,7 @@ void launch_gemm(P p, int splits, hipStream_t s, const char* name) {
   const int nch = ceil_div(p.K, BK);
   p.kslice = ceil_div(nch, splits);
   ProfScope prof(name, s);
+  note_launch("gemm_lds (f32)");
   hipLaunchKernelGGL((gemm_lds<T, P>), dim3(ceil_div(p.N, T::BN), ceil_div(p.M, T::BM), splits), dim3(kLT), 0, s, p);
 }
 

@@ -23,6 +23,9 @@ std::vector<hipEvent_t> g_pool;
 std::vector<std::string> g_filter;  // non-empty: only these kernel names are timed
 std::atomic<int> g_filtered{0};
 
+std::atomic<int> g_count_on{0};
+std::map<std::string, long> g_counts;
+
 hipEvent_t get_event() {
   if (!g_pool.empty()) {
     hipEvent_t e = g_pool.back();
@@ -55,9 +58,41 @@ ProfScope::~ProfScope() {
   if (slot < (int)g_recs.size()) (void)hipEventRecord(g_recs[slot].b, stream);
 }
 
+void note_launch(const char* kernel) {
+  if (!g_count_on.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_m);
+  g_counts[kernel] += 1;
+}
+
 }  // namespace rela_amd
 
 using namespace rela_amd;
+
+extern "C" int rela_prof_count_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_m);
+  if (on && !g_count_on.load()) g_counts.clear();
+  g_count_on.store(on ? 1 : 0);
+  return RELA_OK;
+}
+
+// {"kernel": launches, ...} since rela_prof_count_enable(1) or the last call; clears the counters.
+extern "C" int rela_prof_counts_json(char* out, int64_t cap) {
+  RELA_CHECK(out && cap > 2, RELA_EINVAL, "rela_prof_counts_json: bad arguments");
+  std::lock_guard<std::mutex> lk(g_m);
+  std::string s = "{";
+  bool first = true;
+  for (auto& kv : g_counts) {
+    char buf[256];
+    snprintf(buf, sizeof(buf), "%s\"%s\":%ld", first ? "" : ",", kv.first.c_str(), kv.second);
+    s += buf;
+    first = false;
+  }
+  s += "}";
+  g_counts.clear();
+  RELA_CHECK((int64_t)s.size() + 1 <= cap, RELA_EINVAL, "rela_prof_counts_json: buffer too small");
+  memcpy(out, s.c_str(), s.size() + 1);
+  return RELA_OK;
+}
 
 extern "C" int rela_prof_enable(int on) {
   g_on.store(on ? 1 : 0);

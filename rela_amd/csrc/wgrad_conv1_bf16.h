@@ -19,6 +19,7 @@
 //   of d) waits in registers during the MFMAs.
 // Output: part[block][oc][j] partial sums in state_dict order for reduce_splits (which applies the 1/255).
 #pragma once
+#include "prof.h"
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -195,6 +196,7 @@ inline int launch(const uint8_t* obs, const float* d_a1, int frames, float* part
       hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_conv1_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
   RELA_HIP(attr_set);
   const int blocks = frames < kMaxBlocks ? frames : kMaxBlocks;
+  note_launch("wgrad_conv1_bf16");
   hipLaunchKernelGGL(wgrad_conv1_bf16, dim3(blocks), dim3(kT), LDS_TOTAL, s, obs, d_a1, frames, part);
   *blocks_out = blocks;
   return RELA_OK;

@@ -16,6 +16,7 @@
 // One persistent block per CU, frames strided over the blocks, the next frame's raw data in registers during the
 // MFMAs.  Output: part[block][oc][(kh * 4 + kw) * 32 + c] for reduce_splits (kRedConv2).
 #pragma once
+#include "prof.h"
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -200,6 +201,7 @@ inline int launch(const float* a1, const float* d_a2, int frames, float* part, h
       hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_conv2_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
   RELA_HIP(attr_set);
   const int blocks = frames < kMaxBlocks ? frames : kMaxBlocks;
+  note_launch("wgrad_conv2_bf16");
   hipLaunchKernelGGL(wgrad_conv2_bf16, dim3(blocks), dim3(kT), LDS_TOTAL, s, a1, d_a2, frames, part);
   *blocks_out = blocks;
   return RELA_OK;

@@ -13,6 +13,7 @@
 //        288 B apart) 111 KB.
 // Output: part[block][oc][(kh * 3 + kw) * 64 + c] for reduce_splits (kRedConv3).
 #pragma once
+#include "prof.h"
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -172,6 +173,7 @@ inline int launch(const float* a2, const float* d_a3, int frames, float* part, h
       hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_conv3_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
   RELA_HIP(attr_set);
   const int blocks = frames < kMaxBlocks ? frames : kMaxBlocks;
+  note_launch("wgrad_conv3_bf16");
   hipLaunchKernelGGL(wgrad_conv3_bf16, dim3(blocks), dim3(kT), LDS_TOTAL, s, a2, d_a3, frames, part);
   *blocks_out = blocks;
   return RELA_OK;

@@ -20,7 +20,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from synth import synth_obs, synth_params  # noqa: E402  (tests/synth.py)
+from synth import f32_to_hex, synth_obs, synth_params, synth_r2d2_batch  # noqa: E402  (tests/synth.py)
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REFBIN = os.path.join(ROOT, "oracle", "_ref")
 
@@ -253,6 +253,155 @@ def learner_cases():
              params_after=after)
 
 
+
+def ffnet_big_cases():
+    """Batches large enough to reach the split-bf16 kernels (ffnet.hip: trunk from 128 rows, fc from 1,024), recorded
+    from the REAL reference's net.py / apex.py on the CPU; Q tables stored bit-exactly as hex strings of their
+    float32 bytes.  `*_q50`: every weight tensor times 4.6 (|Q| of 30-60, a trained agent's scale)."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference/pyrela")
+    import torch
+    from apex import ApexAgent  # noqa: the reference's own modules
+    from net import AtariFFNet
+
+    torch.set_num_threads(8)
+    for name, A, N, gain in [("ffnet_A18_N1024", 18, 1024, 1.0), ("ffnet_A18_N256_q50", 18, 256, 4.6)]:
+        agent = ApexAgent(lambda: AtariFFNet(A), 3, 0.997)
+        on, tg = synth_params(A, 1001, gain), synth_params(A, 2002, gain)
+        agent.online_net.load_state_dict({k: torch.from_numpy(v) for k, v in on.items()})
+        agent.target_net.load_state_dict({k: torch.from_numpy(v) for k, v in tg.items()})
+        s, ns = synth_obs(N, 131), synth_obs(N, 132)
+        rng = np.random.default_rng(133)
+        legal = (rng.uniform(size=(N, A)) < 0.8).astype(np.float32)
+        legal[:, 0] = 1.0
+        action = (rng.uniform(size=(N, A)) * legal).argmax(1)
+        reward = rng.integers(-1, 2, N).astype(np.float32)
+        bootstrap = (rng.uniform(size=N) < 0.8).astype(np.float32)
+        obs = {"s": torch.from_numpy(s), "legal_move": torch.from_numpy(legal), "eps": torch.zeros(N, 1)}
+        nobs = {"s": torch.from_numpy(ns), "legal_move": torch.from_numpy(legal), "eps": torch.zeros(N, 1)}
+        with torch.no_grad():
+            q = agent.online_net(obs)
+            qn = agent.online_net(nobs)
+            qt = agent.target_net(nobs)
+            greedy = agent.greedy_act(obs)
+            prio = agent.compute_priority(
+                obs, {"a": torch.from_numpy(action)}, torch.from_numpy(reward), torch.zeros(N, dtype=torch.bool),
+                torch.from_numpy(bootstrap), nobs)
+            err = agent.td_err(obs, {"a": torch.from_numpy(action)}, torch.from_numpy(reward),
+                               torch.from_numpy(bootstrap), nobs)
+        save(name, [], [], num_action=A, N=N, gain=gain, legal_mode="random(133) < 0.8, column 0 legal", online_seed=1001,
+             target_seed=2002, obs_seed=131, next_obs_seed=132, misc_seed=133, multi_step=3, gamma=0.997,
+             q_absmax=float(q.abs().max()), q_hex=f32_to_hex(q.numpy()), q_next_online_hex=f32_to_hex(qn.numpy()),
+             q_next_target_hex=f32_to_hex(qt.numpy()), greedy=greedy.tolist(), priority_hex=f32_to_hex(prio.numpy()),
+             td_err_hex=f32_to_hex(err.numpy()))
+
+
+def learner_big_cases():
+    """learner_cases at B = 128 (the learner's split-bf16 kernels start at 128 rows), inputs re-derived from seeds
+    by the test (legal / action / reward / bootstrap / weight: rng 143 in this order)."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference/pyrela")
+    import types
+
+    import torch
+    from apex import ApexAgent  # noqa: the reference's own modules
+    from net import AtariFFNet
+
+    torch.set_num_threads(8)
+    for name, A, B, clip in [("learner_apex_A18_B128", 18, 128, 0.5)]:
+        multi_step, gamma, lr, eps = 3, 0.997, 1e-3, 1.5e-4
+        agent = ApexAgent(lambda: AtariFFNet(A), multi_step, gamma)
+        on, tg = synth_params(A, 3003), synth_params(A, 4004)
+        agent.online_net.load_state_dict({k: torch.from_numpy(v) for k, v in on.items()})
+        agent.target_net.load_state_dict({k: torch.from_numpy(v) for k, v in tg.items()})
+        s, ns = synth_obs(B, 141), synth_obs(B, 142)
+        rng = np.random.default_rng(143)
+        legal = (rng.uniform(size=(B, A)) < 0.8).astype(np.float32)
+        nlegal = (rng.uniform(size=(B, A)) < 0.8).astype(np.float32)
+        legal[:, 0] = 1.0
+        nlegal[:, 1] = 1.0
+        action = np.array([rng.choice(np.flatnonzero(legal[i])) for i in range(B)], np.int64)
+        reward = rng.normal(0.0, 1.5, B).astype(np.float32)
+        bootstrap = (rng.uniform(size=B) < 0.8).astype(np.float32)
+        weight = rng.uniform(0.1, 1.0, B).astype(np.float32)
+        batch = types.SimpleNamespace(
+            obs={"s": torch.from_numpy(s), "legal_move": torch.from_numpy(legal), "eps": torch.zeros(B, 1)},
+            next_obs={"s": torch.from_numpy(ns), "legal_move": torch.from_numpy(nlegal), "eps": torch.zeros(B, 1)},
+            action={"a": torch.from_numpy(action)}, reward=torch.from_numpy(reward),
+            terminal=torch.zeros(B, dtype=torch.bool), bootstrap=torch.from_numpy(bootstrap))
+        params = list(agent.online_net.parameters())
+        optim = torch.optim.RMSprop(params, lr=lr, eps=eps)
+        loss, priority = agent.loss(batch)
+        loss = (loss * torch.from_numpy(weight)).mean()
+        loss.backward()
+        named = dict(agent.online_net.named_parameters())
+        pick = {k: np.random.default_rng(7).integers(0, v.numel(), 48) for k, v in named.items()}
+
+        def digest(get):
+            out = {}
+            for k, v in named.items():
+                t = get(v).detach().double().reshape(-1)
+                out[k] = {"l2": float(t.norm()), "sum": float(t.sum()), "absmax": float(t.abs().max()),
+                          "idx": pick[k].tolist(), "val": t[torch.from_numpy(pick[k])].tolist()}
+            return out
+
+        grads = digest(lambda v: v.grad)
+        g_norm = torch.nn.utils.clip_grad_norm_(params, clip)
+        optim.step()
+        after = digest(lambda v: v)
+        save(name, [], [], num_action=A, B=B, multi_step=multi_step, gamma=gamma, lr=lr, eps=eps, grad_clip=clip,
+             online_seed=3003, target_seed=4004, obs_seed=141, next_obs_seed=142,
+             legal=legal.tolist(), next_legal=nlegal.tolist(), action=action.tolist(), reward=reward.tolist(),
+             bootstrap=bootstrap.tolist(), weight=weight.tolist(), loss=float(loss),
+             priority=priority.numpy().astype(np.float64).tolist(), grad_norm=float(g_norm), grads=grads,
+             params_after=after)
+
+
+def r2d2loss_big_cases():
+    """R2D2Agent.loss + backward of the REAL reference at BASELINE config C4's sequence shape (seq 80 / burn-in 40 /
+    n 3: T = 123) with B = 16 and A = 18: 1,968 frames, enough rows for every split-bf16 kernel of the HIP learner
+    (trunk >= 128 frames, rec64 GEMMs, conv gradient kernels >= 128).  Inputs come from tests/synth.py
+    (synth_r2d2_batch, seed 61); only the reference's outputs are stored."""
+    import types
+
+    sys.dont_write_bytecode = True
+    sys.modules.setdefault("tensorboardX", types.ModuleType("tensorboardX"))
+    sys.modules["tensorboardX"].SummaryWriter = object
+    sys.path.insert(0, "/root/reference/pyrela")
+    import torch
+    from net import AtariLSTMNet
+    from r2d2 import R2D2Agent
+    from synth import synth_lstm_params
+
+    torch.set_num_threads(8)
+    A, B, seq, burn, n, gamma, eta = 18, 16, 80, 40, 3, 0.997, 0.9
+    agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, A), "cpu", n, gamma, eta, seq, burn, 0)
+    sd = {}
+    for prefix, seed in (("online_net.", 7007), ("target_net.", 8008)):
+        for k, v in synth_lstm_params(A, seed).items():
+            sd[prefix + k] = torch.from_numpy(v)
+    agent.load_state_dict(sd)
+    d = synth_r2d2_batch(61, A, B, seq, burn, n)
+    T = burn + seq + n
+    tt = torch.from_numpy
+    batch = types.SimpleNamespace(
+        obs={"s": tt(d["s"]), "legal_move": tt(d["legal"]), "eps": torch.zeros(T, B, 1)},
+        h0={"h0": tt(d["h0"]), "c0": tt(d["c0"])}, action={"a": tt(d["action"])}, reward=tt(d["reward"]),
+        terminal=tt(d["terminal"]).bool(), bootstrap=tt(d["bootstrap"]), seq_len=tt(d["seq_len"]))
+    loss, priority = agent.loss(batch)
+    (loss * tt(d["weight"])).mean().backward()
+    named = dict(agent.online_net.named_parameters())
+    grads = {}
+    for k, v in named.items():
+        t = v.grad.detach().double().reshape(-1)
+        idx = np.random.default_rng(7).integers(0, t.numel(), 32)
+        grads[k] = {"l2": float(t.norm()), "absmax": float(t.abs().max()), "idx": idx.tolist(),
+                    "val": t[torch.from_numpy(idx)].tolist()}
+    save("r2d2_loss_A18_B16_T123", [], [], num_action=A, B=B, seq_len=seq, burn_in=burn, multi_step=n, gamma=gamma,
+         eta=eta, online_seed=7007, target_seed=8008, batch_seed=61, seq_lens=d["seq_len"].tolist(),
+         loss=loss.detach().double().tolist(), priority=priority.double().tolist(), grads=grads)
+
+
 def r2d2buf_cases():
     """R2D2TransitionBuffer traces: episodes shorter than the window, full windows with carry-over,
     terminals inside the carried region, overlapping carry (burn+n > seq), burn_in = 0."""
@@ -479,3 +628,9 @@ if __name__ == "__main__":
         r2d2loss_cases()
     if "powf" in which:
         powf_cases()
+    if "ffnet_big" in which:      # r3: batches that reach the split-bf16 kernels
+        ffnet_big_cases()
+    if "learner_big" in which:
+        learner_big_cases()
+    if "r2d2loss_big" in which:   # ~2 minutes on 8 cores
+        r2d2loss_big_cases()

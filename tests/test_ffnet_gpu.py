@@ -33,11 +33,16 @@ class GpuNet:
             setattr(p, field, a.ctypes.data_as(C.c_void_p))
         capi.check(capi.lib.rela_ffnet_load(h, C.byref(p), 0, None), "rela_ffnet_load")
 
-    def forward(self, s, legal):
+    def set_precision(self, mode):
+        self.capi.check(self.capi.lib.rela_ffnet_set_precision(self.h, {"f32": 0, "bf16x2": 1}[mode]), "set_precision")
+
+    def forward(self, s, legal, precision=None):
         import torch
 
         from gpu_util import cur_stream, dev, ptr
 
+        if precision is not None:
+            self.set_precision(precision)
         n = s.shape[0]
         d_s, d_l = dev(s), dev(legal)
         q = torch.empty((n, self.A), device="cuda")
@@ -54,64 +59,95 @@ class GpuNet:
             self.h = None
 
 
+# Which kernels a forward of N rows must launch in each precision mode (csrc/ffnet.hip: ffnet_forward_mode).  The
+# tests of the split-bf16 mode assert this through the launch census (rela_prof_count_enable), so a silent fall-back
+# to the f32 kernels -- what a batch below 128 rows gets, by design -- cannot pass for a test of the fast kernels.
+FAST_TRUNK_MIN_N, FAST_FC_MIN_N = 128, 1024
+
+
+def expected_kernels(N, precision):
+    if precision == "bf16x2" and N >= FAST_TRUNK_MIN_N:
+        trunk = {"conv12_bf16s", "conv_bf16s<Conv3F>"}
+        return trunk | ({"fc_bf16s"} if N >= FAST_FC_MIN_N else {"unsplit_records64"})
+    return {"conv1_bf16x3", "conv_mfma<Conv2> (f32)", "conv_mfma<Conv3> (f32)"}
+
+
+def forward_checked(net, s, legal, precision):
+    """forward in `precision`; asserts the kernels of that mode -- and none of the other mode's -- ran."""
+    with net.capi.launch_census() as c:
+        q = net.forward(s, legal, precision)
+    want = expected_kernels(s.shape[0], precision)
+    other = (expected_kernels(s.shape[0], "f32") | expected_kernels(s.shape[0], "bf16x2")) - want
+    assert want <= set(c.counts), "N=%d %s: launched %s, expected %s" % (s.shape[0], precision, sorted(c.counts), sorted(want))
+    assert not (other & set(c.counts)), "N=%d %s: kernels of the other mode ran: %s" % (s.shape[0], precision, sorted(c.counts))
+    return q
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x2"])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "ffnet_*.json"))), ids=os.path.basename)
-def test_ffnet_golden(path):
-    """Q(s), greedy action and TD priority vs the reference's own net.py/apex.py outputs."""
+def test_ffnet_golden(path, precision, record_property):
+    """Q(s), greedy action and TD priority vs the REAL reference's own net.py / apex.py outputs, in BOTH precision
+    modes.  ffnet_A18_N1024 reaches every split-bf16 kernel (conv12_bf16s, conv_bf16s<Conv3F>, fc_bf16s),
+    ffnet_A18_N256_q50 the fast trunk at a trained agent's |Q| of ~55 (every weight tensor x 4.6); the two small
+    goldens (N = 5 and 3) run the f32 kernels in either mode -- all asserted through the launch census.
+    Tolerance: 1e-4 of max|Q| + 1e-4 relative (the reference's library convolutions sum in another order)."""
     import torch
 
+    from golden_util import decisive_rows, ffnet_case, table
     from gpu_util import cur_stream, dev, ptr
     from synth import synth_obs, synth_params
 
     g = json.load(open(path))
-    A, N = g["num_action"], g["N"]
-    on, tg = GpuNet(synth_params(A, g["online_seed"]), A), GpuNet(synth_params(A, g["target_seed"]), A)
+    c = ffnet_case(g)
+    A, N, legal = c["A"], c["N"], c["legal"]
+    on = GpuNet(synth_params(A, g["online_seed"], c["gain"]), A)
+    tg = GpuNet(synth_params(A, g["target_seed"], c["gain"]), A)
     s, ns = synth_obs(N, g["obs_seed"]), synth_obs(N, g["next_obs_seed"])
-    legal = np.ones((N, A), np.float32)
-    if g["legal_mode"] == "mask":
-        legal[:, 1::2] = 0.0
-    q = on.forward(s, legal)
-    np.testing.assert_allclose(q.cpu().numpy(), np.array(g["q"]), rtol=RTOL, atol=ATOL)
-    qn = on.forward(ns, legal)
-    qt = tg.forward(ns, legal)
-    np.testing.assert_allclose(qn.cpu().numpy(), np.array(g["q_next_online"]), rtol=RTOL, atol=ATOL)
-    np.testing.assert_allclose(qt.cpu().numpy(), np.array(g["q_next_target"]), rtol=RTOL, atol=ATOL)
+    q_ref, qn_ref = table(g, "q", (N, A)), table(g, "q_next_online", (N, A))
+    scale = max(1.0, float(np.abs(q_ref).max()))
+    atol = ATOL * scale
+    q = forward_checked(on, s, legal, precision)
+    np.testing.assert_allclose(q.cpu().numpy(), q_ref, rtol=RTOL, atol=atol)
+    qn = forward_checked(on, ns, legal, precision)
+    qt = forward_checked(tg, ns, legal, precision)
+    np.testing.assert_allclose(qn.cpu().numpy(), qn_ref, rtol=RTOL, atol=atol)
+    np.testing.assert_allclose(qt.cpu().numpy(), table(g, "q_next_target", (N, A)), rtol=RTOL, atol=atol)
+    record_property("max_abs_err_vs_reference", float(np.abs(q.cpu().numpy() - q_ref).max()))
     capi = on.capi
     d_legal, d_eps = dev(legal), dev(np.zeros(N, np.float32))
     act = torch.empty(N, dtype=torch.int64, device="cuda")
     capi.check(capi.lib.rela_apex_act_from_q(N, A, 0, ptr(q), ptr(d_legal), ptr(d_eps), 0, 0, ptr(act), cur_stream()), "act")
-    assert act.cpu().numpy().tolist() == g["greedy"] == g["act_eps0"]
-    d_a, d_r, d_b = dev(np.array(g["action"], np.int64)), dev(np.array(g["reward"], np.float32)), dev(
-        np.array(g["bootstrap"], np.float32))
+    # an arg-max is determined only where the reference's own top two legal Q-values are further apart than the
+    # comparison's tolerance (every row of the small goldens; all but a handful of the large ones)
+    tol2 = 2 * (atol + RTOL * scale)
+    ok_g, ok_b = decisive_rows(q_ref, legal, tol2), decisive_rows(qn_ref, legal, tol2)
+    if not c["big"]:  # the small goldens: every row, exactly (as recorded)
+        ok_g[:] = ok_b[:] = True
+    assert ok_g.mean() > 0.95 and ok_b.mean() > 0.95
+    got, want = act.cpu().numpy(), np.array(g["greedy"])
+    assert np.array_equal(got[ok_g], want[ok_g]), np.flatnonzero((got != want) & ok_g)
+    record_property("greedy_agreement_vs_reference", float((got == want).mean()))
+    d_a, d_r, d_b = dev(c["action"]), dev(c["reward"]), dev(c["bootstrap"])
     td, pr = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
     gamma_n = np.float32(np.float64(g["gamma"]) ** g["multi_step"])
     capi.check(capi.lib.rela_apex_td_from_q(N, A, 0, ptr(q), ptr(qn), ptr(qt), ptr(d_legal), ptr(d_a), ptr(d_r), ptr(d_b),
                                             C.c_float(gamma_n), ptr(td), ptr(pr), cur_stream()), "td")
-    np.testing.assert_allclose(td.cpu().numpy(), np.array(g["td_err"]), rtol=RTOL, atol=ATOL)
-    np.testing.assert_allclose(pr.cpu().numpy(), np.array(g["priority"]), rtol=RTOL, atol=ATOL)
+    pr_ref = table(g, "priority", (N,))
+    np.testing.assert_allclose(td.cpu().numpy()[ok_b], table(g, "td_err", (N,))[ok_b], rtol=RTOL, atol=4 * atol)
+    np.testing.assert_allclose(pr.cpu().numpy()[ok_b], pr_ref[ok_b], rtol=RTOL, atol=4 * atol)
+    record_property("max_abs_priority_err_vs_reference", float(np.abs(pr.cpu().numpy() - pr_ref)[ok_b].max()))
     on.close()
     tg.close()
 
 
-@pytest.mark.parametrize("N", [1, 2, 3, 7, 80, 130, 257, 514, 1537, 2003, 6400])
-def test_ffnet_vs_torch_fp32(N):
-    """Ragged batch sizes (partial sample tiles in every kernel) vs a plain PyTorch fp32 forward of
-    the same architecture on the same device.  N >= 512 / 1536 switches conv2 / conv3 to the
-    weight-stationary persistent kernels (uneven groups per block, partial last group); N = 6400 is the
-    shape of bench.py's actor tick (80 threads x 80 envs)."""
+def _torch_fp32_forward(p, s, legal):
     import torch
     import torch.nn.functional as F
 
-    from synth import synth_obs, synth_params
-
-    A = 18
-    p = synth_params(A, 77)
-    net = GpuNet(p, A)
-    s = synth_obs(N, 1000 + N)
-    rng = np.random.default_rng(N)
-    legal = (rng.uniform(size=(N, A)) < 0.8).astype(np.float32)
-    q = net.forward(s, legal).cpu().numpy()
+    N = s.shape[0]
     t = {k: torch.from_numpy(v).cuda() for k, v in p.items()}
     torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
     with torch.no_grad():
         x = torch.from_numpy(s).cuda().float() / 255.0
         x = F.relu(F.conv2d(x, t["net.0.weight"], t["net.0.bias"], stride=4))
@@ -120,31 +156,114 @@ def test_ffnet_vs_torch_fp32(N):
         h = F.relu(F.linear(x.reshape(N, 3136), t["linear.0.weight"], t["linear.0.bias"]))
         v = F.linear(h, t["fc_v.weight"], t["fc_v.bias"])
         a = F.linear(h, t["fc_a.weight"], t["fc_a.bias"]) * torch.from_numpy(legal).cuda()
-        ref = (v + a - a.mean(1, keepdim=True)).cpu().numpy()
-    np.testing.assert_allclose(q, ref, rtol=RTOL, atol=ATOL)
+        return (v + a - a.mean(1, keepdim=True)).cpu().numpy()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x2"])
+@pytest.mark.parametrize("N", [1, 2, 3, 7, 80, 128, 130, 257, 514, 1024, 1537, 2003, 6400])
+def test_ffnet_vs_torch_fp32(N, precision):
+    """Ragged batch sizes (partial sample tiles in every kernel) vs a plain PyTorch fp32 forward of the same
+    architecture on the same device, in BOTH precision modes, with the launched kernels asserted: the split-bf16
+    kernels (conv12_bf16s, conv_bf16s<Conv3F> from 128 rows, fc_bf16s from 1,024) are compared with torch-fp32
+    directly, not through the library's own f32 mode.  N >= 512 / 1536 switches the f32 conv2 / conv3 to the
+    weight-stationary persistent kernels; N = 6400 is the shape of bench.py's actor tick (80 threads x 80 envs)."""
+    from synth import synth_obs, synth_params
+
+    A = 18
+    p = synth_params(A, 77)
+    net = GpuNet(p, A)
+    s = synth_obs(N, 1000 + N)
+    rng = np.random.default_rng(N)
+    legal = (rng.uniform(size=(N, A)) < 0.8).astype(np.float32)
+    q = forward_checked(net, s, legal, precision).cpu().numpy()
+    np.testing.assert_allclose(q, _torch_fp32_forward(p, s, legal), rtol=RTOL, atol=ATOL)
     net.close()
 
 
-def test_ffnet_vs_oracle_c():
-    """Same comparison against the plain-C oracle (oracle/dqn_oracle.c), N small."""
+@pytest.mark.parametrize("precision", ["f32", "bf16x2"])
+@pytest.mark.parametrize("N", [6, 128, 1024, 2003, 6400])
+def test_ffnet_vs_oracle_c(N, precision):
+    """The same comparison against the plain-C oracle (oracle/dqn_oracle.c, itself pinned to the reference's
+    goldens by tests/test_oracle_golden.py), in both precision modes, up to bench.py's 6,400 rows."""
     from oracle_lib import load
     from synth import synth_obs, synth_params
     from test_oracle_golden import _ffnet_struct
 
-    A, N = 18, 6
+    A = 18
     p = synth_params(A, 5)
     net = GpuNet(p, A)
     s = synth_obs(N, 6)
     legal = np.ones((N, A), np.float32)
-    q = net.forward(s, legal).cpu().numpy()
+    legal[1::3, 2::5] = 0.0
+    q = forward_checked(net, s, legal, precision).cpu().numpy()
     lib = load()
-    lib.oracle_set_threads(4)
+    lib.oracle_set_threads(min(16, os.cpu_count() or 4))
     on = _ffnet_struct(lib, p, A)
     ref = np.zeros((N, A), np.float32)
     lib.oracle_ffnet_forward(C.byref(on), N, s.ctypes.data_as(C.POINTER(C.c_uint8)),
                              legal.ctypes.data_as(C.POINTER(C.c_float)), ref.ctypes.data_as(C.POINTER(C.c_float)))
     np.testing.assert_allclose(q, ref, rtol=RTOL, atol=ATOL)
     net.close()
+
+
+def test_ffnet_trained_scale_weights(record_property):
+    """|Q| of a trained agent (30-60: every weight tensor x 4.6) instead of the |Q| <= 0.5 of a fresh initialisation:
+    the split-bf16 mode against the f32 mode, torch-fp32 and the REAL reference's recorded Q at N = 2003 / 256.
+    Errors of the fast mode are relative to the magnitudes summed (2^-16 per product), so the stated tolerance
+    scales with max|Q|: |dQ| < 2e-6 * max|Q| against the f32 mode.  |dQ|, the TD-priority difference and the
+    greedy-action agreement are recorded; a greedy action may differ only where the top two legal Q-values are
+    closer than twice that tolerance."""
+    import torch
+
+    from gpu_util import cur_stream, dev, ptr
+    from synth import synth_obs, synth_params
+
+    A, N = 18, 2003
+    p_on, p_tg = synth_params(A, 1001, 4.6), synth_params(A, 2002, 4.6)
+    on, tg = GpuNet(p_on, A), GpuNet(p_tg, A)
+    s, ns = synth_obs(N, 4001), synth_obs(N, 4002)
+    rng = np.random.default_rng(9)
+    legal = (rng.uniform(size=(N, A)) < 0.8).astype(np.float32)
+    legal[:, 0] = 1.0
+    q = {m: forward_checked(on, s, legal, m) for m in ("f32", "bf16x2")}
+    qn = {m: forward_checked(on, ns, legal, m) for m in ("f32", "bf16x2")}
+    qt = {m: forward_checked(tg, ns, legal, m) for m in ("f32", "bf16x2")}
+    ref = _torch_fp32_forward(p_on, s, legal)
+    scale = float(np.abs(ref).max())
+    assert 25.0 < scale < 120.0, scale
+    qf, qb = q["f32"].cpu().numpy(), q["bf16x2"].cpu().numpy()
+    np.testing.assert_allclose(qf, ref, rtol=RTOL, atol=ATOL * scale)
+    np.testing.assert_allclose(qb, ref, rtol=RTOL, atol=ATOL * scale)
+    err = float(np.abs(qb - qf).max())
+    assert err < 2e-6 * scale, (err, scale)
+    masked = lambda t: np.where(legal > 0, t, -np.inf)
+    top2 = np.sort(masked(qf), axis=1)[:, -2:]
+    differ = masked(qb).argmax(1) != masked(qf).argmax(1)
+    assert np.all(~differ | ((top2[:, 1] - top2[:, 0]) < 4e-6 * scale))
+    # TD priorities of both modes from their own three Q tables (apex.py:30-45)
+    action = (rng.uniform(size=(N, A)) * legal).argmax(1).astype(np.int64)
+    reward = rng.integers(-1, 2, N).astype(np.float32)
+    boot = (rng.uniform(size=N) < 0.8).astype(np.float32)
+    d_legal, d_a, d_r, d_b = dev(legal), dev(action), dev(reward), dev(boot)
+    pr = {}
+    for m in ("f32", "bf16x2"):
+        td, pm = torch.empty(N, device="cuda"), torch.empty(N, device="cuda")
+        on.capi.check(on.capi.lib.rela_apex_td_from_q(N, A, 0, ptr(q[m]), ptr(qn[m]), ptr(qt[m]), ptr(d_legal), ptr(d_a),
+                                                      ptr(d_r), ptr(d_b), C.c_float(np.float32(0.997 ** 3)), ptr(td),
+                                                      ptr(pm), cur_stream()), "td")
+        pr[m] = pm.cpu().numpy()
+    n2 = np.sort(masked(qn["f32"].cpu().numpy()), axis=1)[:, -2:]
+    same_boot = (n2[:, 1] - n2[:, 0]) >= 4e-6 * scale  # rows whose bootstrap arg-max cannot flip between the modes
+    dprio = float(np.abs(pr["bf16x2"] - pr["f32"])[same_boot].max())
+    assert dprio < 6e-6 * scale, dprio  # three Q-values of <= 2e-6 * scale error each
+    record_property("q_absmax", scale)
+    record_property("max_abs_dq_fast_vs_f32", err)
+    record_property("max_abs_dpriority_fast_vs_f32", dprio)
+    record_property("greedy_agreement", float((~differ).mean()))
+    print("|Q| up to %.1f: max |dQ| = %.3g (%.2g relative), max |dpriority| = %.3g, greedy agreement %.5f"
+          % (scale, err, err / scale, dprio, float((~differ).mean())))
+    on.close()
+    tg.close()
 
 
 def test_ffnet_errors():
@@ -177,7 +296,7 @@ def test_ffnet_fast_mode_within_stated_tolerance(N, record_property):
     q_ref = net.forward(s, legal).cpu().numpy()
     net.capi.check(net.capi.lib.rela_ffnet_set_precision(net.h, 1), "set_precision")
     assert net.capi.lib.rela_ffnet_precision(net.h) == 1
-    q_fast = net.forward(s, legal).cpu().numpy()
+    q_fast = forward_checked(net, s, legal, "bf16x2").cpu().numpy()
     tmo = C.c_uint(7)
     net.capi.check(net.capi.lib.rela_ffnet_debug_pipe_timeout(net.h, C.byref(tmo)), "pipe_timeout")
     assert tmo.value == 0, "a wave of the pipelined conv1 -> conv2 kernel gave up on a hand-off (code %d)" % tmo.value
@@ -193,7 +312,11 @@ def test_ffnet_fast_mode_within_stated_tolerance(N, record_property):
     record_property("greedy_agreement", agree)
     print("N=%d split-bf16 vs f32: max |dQ| = %.3g (|Q| up to %.3g), greedy agreement %.5f" % (N, err, scale, agree))
     assert err < 2e-6  # the stated tolerance of the fast mode; measured 6e-7 at |Q| <= 0.41
-    assert agree >= 0.995 or N < 200
+    # the greedy action of the two modes may differ only where the f32 mode's top two legal Q-values are closer than
+    # twice the tolerance (measured: 100 % agreement at every size)
+    top2 = np.sort(np.where(legal > 0, q_ref, -np.inf), axis=1)[:, -2:]
+    differ = masked(q_fast) != masked(q_ref)
+    assert np.all(~differ | ((top2[:, 1] - top2[:, 0]) < 4e-6)), np.flatnonzero(differ)
     net.close()
 
 
@@ -211,21 +334,3 @@ def test_ffnet_fast_mode_fusion_variants(fuse):
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert rec["timeout"] == 0 and rec["max_err"] < 2e-6 and rec["agree"] >= 0.995, rec
-
-
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "ffnet_*.json"))), ids=os.path.basename)
-def test_ffnet_fast_mode_vs_reference_golden(path):
-    """The fast mode against the vectors recorded from the REAL reference (same tolerance as the parity mode)."""
-    from synth import synth_obs, synth_params
-
-    g = json.load(open(path))
-    A, N = g["num_action"], g["N"]
-    on = GpuNet(synth_params(A, g["online_seed"]), A)
-    on.capi.check(on.capi.lib.rela_ffnet_set_precision(on.h, 1), "set_precision")
-    s = synth_obs(N, g["obs_seed"])
-    legal = np.ones((N, A), np.float32)
-    if g["legal_mode"] == "mask":
-        legal[:, 1::2] = 0.0
-    q = on.forward(s, legal)
-    np.testing.assert_allclose(q.cpu().numpy(), np.array(g["q"]), rtol=RTOL, atol=ATOL)
-    on.close()

@@ -81,6 +81,18 @@ def test_loss_priority_and_gradients_match_autograd(B, A):
     learner.close()
 
 
+def _assert_fast_learner_kernels(counts, B):
+    """The kernels a bf16x2 learner step of B rows must launch (csrc/learner.hip, learner_common.h): from 128 rows the
+    two gradient-free forwards' conv trunks, at every size conv1's weight gradient and the conv2 / conv3 data
+    gradients on bf16 MFMA -- so a silent fall-back to the f32 kernels cannot pass for a test of the fast ones."""
+    want = {"wgrad_conv1_bf16", "dgrad_conv2_bf16", "dgrad_conv3_bf16"}
+    if B >= 128:
+        want |= {"conv12_bf16s", "conv_bf16s<Conv3F>"}
+    assert want <= set(counts), "B=%d: launched %s, expected %s" % (B, sorted(counts), sorted(want))
+    if B >= 128:
+        assert counts["conv12_bf16s"] == 2 and counts["conv1_bf16x3"] == 1  # td_err's two forwards; online(obs) in f32
+
+
 @pytest.mark.parametrize("B", [512, 200, 64])
 def test_learner_fast_mode_within_stated_tolerance(B):
     """set_precision("bf16x2"): the two gradient-free forwards of td_err (online and target net on next_obs) run their
@@ -101,8 +113,12 @@ def test_learner_fast_mode_within_stated_tolerance(B):
     loss0, prio0 = loss0.clone(), prio0.clone()
     g0 = {k: v.clone() for k, v in learner.state_dict("grads").items()}
     learner.set_precision("bf16x2")
-    loss1, prio1 = learner.backward(batch, w)
+    from rela_amd import _capi as capi
+
+    with capi.launch_census() as census:
+        loss1, prio1 = learner.backward(batch, w)
     g1 = learner.state_dict("grads")
+    _assert_fast_learner_kernels(census.counts, B)
     assert float((prio1 - prio0).abs().max()) < 5e-6
     assert abs(float(loss1) - float(loss0)) < 5e-6 * max(1.0, abs(float(loss0)))
     for key in HipApexLearner.KEYS:
@@ -283,12 +299,15 @@ def test_learner_errors():
     learner.close()
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x2"])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "learner_*.json"))), ids=os.path.basename)
-def test_learner_step_matches_the_reference_golden(path):
+def test_learner_step_matches_the_reference_golden(path, precision):
     """One learner step against vectors recorded from the REAL reference on CPU
     (tests/golden/make_golden.py learner_cases: pyrela/apex.py loss -> backward -> clip_grad_norm_ ->
     RMSprop.step of pyrela/main.py:226-239): loss, priorities, gradient norm, and for every parameter
-    tensor its gradient / updated value (l2 norm, sum, 48 sampled entries)."""
+    tensor its gradient / updated value (l2 norm, sum, 48 sampled entries) -- in BOTH precision modes, with the
+    launched kernels asserted (learner_apex_A18_B128 reaches the split-bf16 forward trunk; the bf16 gradient
+    kernels run at every batch size)."""
     import torch
     from types import SimpleNamespace
 
@@ -310,7 +329,15 @@ def test_learner_step_matches_the_reference_golden(path):
                   "eps": torch.zeros(B, 1, device=dev), "legal_move": f32(g["next_legal"])},
         action={"a": torch.tensor(g["action"], dtype=torch.int64, device=dev)}, reward=f32(g["reward"]),
         terminal=torch.zeros(B, dtype=torch.bool, device=dev), bootstrap=f32(g["bootstrap"]))
-    loss, prio = learner.backward(batch, f32(g["weight"]))
+    from rela_amd import _capi as capi
+
+    learner.set_precision(precision)
+    with capi.launch_census() as census:
+        loss, prio = learner.backward(batch, f32(g["weight"]))
+    if precision == "bf16x2":
+        _assert_fast_learner_kernels(census.counts, B)
+    else:
+        assert not ({"wgrad_conv1_bf16", "dgrad_conv2_bf16", "conv12_bf16s"} & set(census.counts)), census.counts
     np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(prio.cpu().numpy(), np.array(g["priority"]), rtol=1e-4, atol=1e-4)
 

@@ -100,7 +100,8 @@ def test_aggregate_priority_matches_reference():
         np.testing.assert_allclose(out, ref, rtol=2e-7, atol=0)  # torch sums pairwise; the oracle left to right
 
 
-def test_r2d2_learner_loss_matches_reference_golden():
+@pytest.mark.parametrize("name", ["r2d2_loss_A6_B3", "r2d2_loss_A18_B16_T123"])
+def test_r2d2_learner_loss_matches_reference_golden(name):
     """rela_amd/pyrela/r2d2.py (R2D2Agent.td_err / loss / aggregate_priority, the learner side of SURVEY
     rows N2/G2) against vectors recorded from the REAL reference's R2D2Agent on CPU
     (tests/golden/make_golden.py r2d2loss: loss per sequence, aggregated priority, and the gradients of
@@ -116,25 +117,36 @@ def test_r2d2_learner_loss_matches_reference_golden():
     from rela_amd.pyrela.r2d2 import R2D2Agent
     from synth import synth_lstm_params, synth_obs
 
-    g = json.load(open(os.path.join(GOLD, "r2d2_loss_A6_B3.json")))
+    g = json.load(open(os.path.join(GOLD, name + ".json")))
     A, B, seq, burn, n = g["num_action"], g["B"], g["seq_len"], g["burn_in"], g["multi_step"]
     T = burn + seq + n
-    torch.set_num_threads(4)
+    torch.set_num_threads(min(8, os.cpu_count() or 4))
     agent = R2D2Agent(lambda dev: AtariLSTMNet(dev, A), "cpu", n, g["gamma"], g["eta"], seq, burn, 0)
     sd = {}
     for prefix, seed in (("online_net.", g["online_seed"]), ("target_net.", g["target_seed"])):
         for k, v in synth_lstm_params(A, seed).items():
             sd[prefix + k] = torch.from_numpy(v)
     agent.load_state_dict(sd)
-    m = g["batch"]
     f32 = lambda x: torch.tensor(x, dtype=torch.float32)
-    hid = lambda key: torch.tensor([h2f(v) for v in m[key]], dtype=torch.float32).reshape(1, B, 512)
-    batch = SimpleNamespace(
-        obs={"s": torch.from_numpy(synth_obs(T * B, m["obs_seed"]).reshape(T, B, 4, 84, 84)),
-             "legal_move": f32(m["legal"]), "eps": torch.zeros(T, B, 1)},
-        h0={"h0": hid("h0"), "c0": hid("c0")}, action={"a": torch.tensor(m["action"], dtype=torch.int64)},
-        reward=f32(m["reward"]), terminal=f32(m["terminal"]).bool(), bootstrap=f32(m["bootstrap"]),
-        seq_len=f32(m["seq_len"]))
+    if "batch" in g:
+        m = g["batch"]
+        hid = lambda key: torch.tensor([h2f(v) for v in m[key]], dtype=torch.float32).reshape(1, B, 512)
+        batch = SimpleNamespace(
+            obs={"s": torch.from_numpy(synth_obs(T * B, m["obs_seed"]).reshape(T, B, 4, 84, 84)),
+                 "legal_move": f32(m["legal"]), "eps": torch.zeros(T, B, 1)},
+            h0={"h0": hid("h0"), "c0": hid("c0")}, action={"a": torch.tensor(m["action"], dtype=torch.int64)},
+            reward=f32(m["reward"]), terminal=f32(m["terminal"]).bool(), bootstrap=f32(m["bootstrap"]),
+            seq_len=f32(m["seq_len"]))
+    else:  # C4's sequence shape: the inputs are re-derived from tests/synth.py
+        from synth import synth_r2d2_batch
+
+        d = synth_r2d2_batch(g["batch_seed"], A, B, seq, burn, n)
+        tt = torch.from_numpy
+        m = {"weight": d["weight"].tolist()}
+        batch = SimpleNamespace(
+            obs={"s": tt(d["s"]), "legal_move": tt(d["legal"]), "eps": torch.zeros(T, B, 1)},
+            h0={"h0": tt(d["h0"]), "c0": tt(d["c0"])}, action={"a": tt(d["action"])}, reward=tt(d["reward"]),
+            terminal=tt(d["terminal"]).bool(), bootstrap=tt(d["bootstrap"]), seq_len=tt(d["seq_len"]))
     loss, prio = agent.loss(batch)
     np.testing.assert_allclose(loss.detach().numpy(), np.array(g["loss"]), rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(prio.numpy(), np.array(g["priority"]), rtol=1e-4, atol=1e-5)

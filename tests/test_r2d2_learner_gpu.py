@@ -84,6 +84,63 @@ def test_pytorch_r2d2_loss_on_gpu_matches_reference_golden():
     _check_grads_vs_golden({k: v.grad for k, v in agent.online_net.named_parameters()}, g)
 
 
+def _synth_batch(g, device):
+    """the batch of a golden whose inputs are re-derived from tests/synth.py (synth_r2d2_batch)"""
+    import torch
+
+    from synth import synth_r2d2_batch
+
+    B, seq, burn, n = g["B"], g["seq_len"], g["burn_in"], g["multi_step"]
+    d = synth_r2d2_batch(g["batch_seed"], g["num_action"], B, seq, burn, n)
+    assert d["seq_len"].tolist() == g["seq_lens"]
+    T = burn + seq + n
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    batch = SimpleNamespace(
+        obs={"s": tt(d["s"]), "legal_move": tt(d["legal"]), "eps": torch.zeros(T, B, 1, device=device)},
+        h0={"h0": tt(d["h0"]), "c0": tt(d["c0"])}, action={"a": tt(d["action"])}, reward=tt(d["reward"]),
+        terminal=tt(d["terminal"]).bool(), bootstrap=tt(d["bootstrap"]), seq_len=tt(d["seq_len"]))
+    return batch, tt(d["weight"]), d["weight"]
+
+
+# kernels a bf16x2 R2D2 learner step must launch once T * B >= 128 frames (csrc/learner_r2d2.hip)
+R2D2_FAST_KERNELS = {"conv12_bf16s", "conv_bf16s<Conv3F>", "gemm_rec64_nt", "wgrad_conv1_bf16", "dgrad_conv2_bf16",
+                     "dgrad_conv3_bf16"}
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x2"])
+def test_hip_r2d2_learner_matches_reference_golden_c4_shape(precision):
+    """BASELINE config C4's sequence shape (seq 80 / burn-in 40 / n 3: T = 123) with B = 16, A = 18 -- 1,968 frames,
+    1,328 training rows: loss per sequence, aggregated priority and every gradient tensor of the hand-written step
+    against vectors recorded from the REAL reference's R2D2Agent.loss + backward on CPU
+    (tests/golden/r2d2_loss_A18_B16_T123.json), in BOTH precision modes.  In bf16x2 mode the launch census must show
+    the split-bf16 kernels (target trunk, rec64 GEMMs of the LSTM's input side, bf16 conv gradient kernels): this is
+    the direct pin of those kernels to the reference."""
+    import torch
+
+    from rela_amd import _capi as capi
+    from rela_amd.learner import HipR2D2Learner
+
+    g = json.load(open(os.path.join(GOLD, "r2d2_loss_A18_B16_T123.json")))
+    agent = _agent(g["num_action"], g["multi_step"], g["gamma"], g["eta"], g["seq_len"], g["burn_in"], g["online_seed"],
+                   g["target_seed"], "cuda:0")
+    learner = HipR2D2Learner.from_agent(agent, g["B"], grad_clip=1e9)
+    learner.set_precision(precision)
+    batch, weight, w_np = _synth_batch(g, "cuda:0")
+    with capi.launch_census() as census:
+        loss, prio, loss_seq = learner.backward(batch, weight)
+    learner.check()
+    torch.cuda.synchronize()
+    if precision == "bf16x2":
+        assert R2D2_FAST_KERNELS <= set(census.counts), sorted(census.counts)
+    else:
+        assert not (R2D2_FAST_KERNELS & set(census.counts)), sorted(census.counts)
+    np.testing.assert_allclose(loss_seq.cpu().numpy(), np.array(g["loss"]), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(prio.cpu().numpy(), np.array(g["priority"]), rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(float(loss.cpu()[0]), float((np.array(g["loss"]) * w_np).mean()), rtol=2e-4)
+    _check_grads_vs_golden(learner.state_dict("grads"), g)
+    learner.close()
+
+
 def test_hip_r2d2_learner_matches_reference_golden():
     """Loss per sequence, aggregated priority and every gradient tensor of the hand-written step against the
     REAL reference (padded short sequence, dummy burn-in with zeroed state, illegal actions)."""
@@ -261,8 +318,14 @@ def test_hip_r2d2_learner_fast_target_trunk_within_tolerance(B, seq, burn):
     loss0, prio0 = loss0.clone(), prio0.clone()
     g0 = {k: v.clone() for k, v in learner.state_dict("grads").items()}
     learner.set_precision("bf16x2")  # T * B = 336 frames >= 128: the fast trunk is taken
-    loss1, prio1, _ = learner.backward(batch, weight)
+    from rela_amd import _capi as capi
+
+    with capi.launch_census() as census:
+        loss1, prio1, _ = learner.backward(batch, weight)
     learner.check()
+    assert R2D2_FAST_KERNELS <= set(census.counts), sorted(census.counts)
+    if B * (seq + 3) >= 2048:
+        assert {"wgrad_conv2_bf16", "wgrad_conv3_bf16"} <= set(census.counts), sorted(census.counts)
     assert float((prio1 - prio0).abs().max()) < 2e-5
     assert abs(float(loss1) - float(loss0)) < 2e-5 * max(1.0, abs(float(loss0)))
     g1 = learner.state_dict("grads")
