@@ -72,6 +72,14 @@ BYTES_PER_SAMPLE = {"conv1_bf16x3": 28224 + 400 * 32 * 4, "conv2_mfma": 400 * 32
                     "conv3_mfma": 81 * 64 * 4 + 49 * 64 * 4, "fc_mfma": 49 * 64 * 4 + 512 * 4, "heads_mfma": 512 * 4 + 32 * 4,
                     "conv12_fused": 28224 + 81 * 64 * 4}
 PEAK_HBM_GBS = 8000.0
+# what the HIP Ape-X learner step computes in, per --precision (csrc/learner.hip)
+LEARNER_PRECISION_NOTE = {
+    "f32": "f32 throughout (exact f32 MFMA forwards, f32 MFMA GEMM backward, f32 clip + RMSprop)",
+    "bf16x2": "mixed: td_err's two gradient-free forwards (online(s'), target(s')) with conv trunk on split-bf16 MFMA; "
+              "conv1 weight gradient and conv2 / conv3 data gradients on bf16 MFMA (hi + lo operands, f32 accumulate); "
+              "online(s) forward whose activations / ReLU masks feed the backward, fc and head GEMMs, conv2 / conv3 weight "
+              "gradients, loss, clip, RMSprop in f32",
+}
 
 
 def generate_eps(base_eps, alpha, num_actor):
@@ -79,6 +87,68 @@ def generate_eps(base_eps, alpha, num_actor):
     if num_actor == 1:
         return [base_eps]
     return [base_eps ** (1 + i / (num_actor - 1) * alpha) for i in range(num_actor)]
+
+
+# rela_prof label -> substring of the HIP kernel name in the rocprofv3 CSVs
+PMC_KERNEL_OF = {"conv12_fused": "conv12_bf16s", "conv3_mfma": "conv_bf16s<", "fc_mfma": "fc_bf16s",
+                 "conv1_bf16x3": "conv1_bf16x3", "conv2_mfma": "ConvCfg<32", "replay_scatter_rows": "replay_scatter_rows"}
+
+
+def traffic_from_profiles(label):
+    """HBM-side bytes per launch of the kernel behind a rela_prof label, from the PMC passes TRACKED under profiles/
+    (PMC counters cannot be read from inside this process): first a summary profiles/r0N_traffic.json, else straight
+    from profiles/r0N_pmc/pmc_{fetch,write}_counter_collection.csv -- separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE runs of the isolated forward at the same N = 6400 (tools/final_evidence.sh).  Corrections as
+    MI355X_MICROARCH.md prescribes: both counters are in KB; FETCH_SIZE reports half the bytes of wide coalesced
+    reads on gfx950 and is doubled.  Newest round first.  -> (bytes, source) or (None, None)."""
+    import csv
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            rec = json.load(open(path))["kernels"].get(label)
+        except (OSError, ValueError, KeyError):
+            continue
+        if rec is not None:
+            return rec["read_bytes"] + rec["write_bytes"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, not this run)" % os.path.basename(path)
+    needle = PMC_KERNEL_OF.get(label)
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc")), reverse=True):
+        tot = {}
+        for kind, counter, scale in (("fetch", "FETCH_SIZE", 2 * 1024.0), ("write", "WRITE_SIZE", 1024.0)):
+            try:
+                rows = [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(d, "pmc_%s_counter_collection.csv" % kind)))
+                        if needle and needle in r["Kernel_Name"] and r["Counter_Name"] == counter]
+            except (OSError, ValueError, KeyError):
+                rows = []
+            if rows:
+                tot[kind] = scale * sum(rows) / len(rows)
+        if len(tot) == 2:
+            return tot["fetch"] + tot["write"], ("profiles/%s/pmc_{fetch,write}_counter_collection.csv (rocprofv3 --pmc, separate "
+                                                 "passes, FETCH_SIZE x2 per the gfx950 correction; not this run)" % os.path.basename(d))
+    return None, None
+
+
+def threaded_leg(seconds=4.0, epochs=2, threads=64, games=100):
+    """The metric as the reference defines it (pyrela/benchmark.py:73-109): sum of DQNActor.num_act() deltas per
+    second through rela.Context + BasicThreadLoop + DQNActor + FFPrioritizedReplay of the drop-in `rela` module --
+    C++ actor threads stepping HOST envs, per-step host -> HBM observation upload -- without and with a concurrent
+    unthrottled B = 512 sample / update_priority loop, in a child process on this box's host cores (bounded: the
+    reference protocol is 6 x 30 s windows per mode, this leg runs `epochs` x `seconds`)."""
+    cmd = [sys.executable, os.path.join(ROOT, "rela_amd", "pyrela", "benchmark.py"), "--grid", "%dx%d" % (threads, games),
+           "--epoch_sec", str(seconds), "--num_epoch", str(epochs), "--replay_buffer_size", str(1 << 20)]
+    t0 = time.time()
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        line = [l for l in out.stdout.splitlines() if l.startswith("act rate: without sample:")][-1]
+        without, with_ = (float(x.split(":")[-1]) for x in line[len("act rate: "):].split(","))
+    except Exception as e:  # noqa: BLE001  (reported, never fatal for the headline)
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    return {"metric": "env-steps/s = d(sum of DQNActor.num_act())/dt through rela.Context / BasicThreadLoop / DQNActor "
+                      "(pyrela/benchmark.py:73-109), host envs + H2D upload included",
+            "without_sampler": without, "with_sampler": with_, "unit": "env-steps/s", "threads": threads,
+            "games_per_thread": games, "host_cores": len(os.sched_getaffinity(0)), "window_s": seconds, "windows": epochs,
+            "sampler": "unthrottled B=512 sample + update_priority loop on the Python thread", "wall_s": time.time() - t0,
+            "note": "bounded sample of the reference's 6 x 30 s protocol; mean of the last half of the windows"}
 
 
 def cpu_baseline_reference():
@@ -351,6 +421,7 @@ def bench_r2d2(args, world, rank, device):
     prof_all = json.loads(buf.value.decode())
     st = replay.debug_state()
     assert st["dev_error"] == 0
+    learner.check()  # raises if a grid barrier of the persistent recurrent kernels ever gave up (updates were skipped)
     if rank == 0:
         # the actors' gate GEMM: one f32 MFMA kernel over [x | h] (f32 mode), or (bf16x2 mode, >= 1,024 rows) the x part as a
         # split-bf16 GEMM (three bf16 MFMAs per product) followed by the f32 kernel over h only: the roofline is the x part's
@@ -409,10 +480,13 @@ def bench_r2d2(args, world, rank, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # default window: 1,500 steps of ~1.6 ms = ~2.5 s of timed work per region (r01's 20-step window was 72 ms)
-    ap.add_argument("--steps", type=int, default=1500)
+    # default: 5 repeats x 300 steps of ~1.5 ms = ~2.3 s of timed work per region
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="how many times every K-step timed region is repeated (the line reports the median repeat)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-threaded", action="store_true", help="skip the threaded leg (rela.Context + C++ actor threads)")
     ap.add_argument("--replay-cap", type=int, default=None)
     ap.add_argument("--dedup", default=None, choices=[None, "stack", "plane"],
                     help="frame-stack de-duplication in the replay (SURVEY 8f-3): stack = 28,224 B per env-step, plane = "
@@ -645,9 +719,33 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-        step_idx[0] += 1
+    def run_steps(k):
+        for _ in range(k):
+            one_step()
+            step_idx[0] += 1
+
+    def bracketed(k):
+        """EXACTLY k steps between barrier + synchronize on both sides; MAX over ranks; -> seconds"""
+        sync_all()
+        t0 = time.perf_counter()
+        run_steps(k)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def region(settle):
+        """a timed region: `settle` untimed steps, then the K-step bracket repeated args.repeats times (with
+        --steps 20 one bracket is 30 ms: too short to be a measurement on its own) -> ms per step of every repeat"""
+        run_steps(settle)
+        return [bracketed(args.steps) / args.steps * 1e3 for _ in range(args.repeats)]
+
+    median = lambda xs: float(np.median(xs))
+
+    run_steps(args.warmup)
     sync_all()
     # Live roofline: HIP events around the four heavy forward kernels only (the dominant kernel is one
     # of them); timing all ~100 kernels of a step costs 0.37 ms of the step itself, so the full
@@ -655,21 +753,15 @@ def main():
     capi.lib.rela_prof_set_filter(b"conv12_fused,conv1_bf16x3,conv2_mfma,conv3_mfma,fc_mfma")
     capi.lib.rela_prof_enable(0 if os.environ.get("RELA_BENCH_NOPROF") == "1" else 1)
     add0 = replay.num_add()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-        step_idx[0] += 1
-    sync_all()
-    dt = time.perf_counter() - t0
+    ms_head = region(0)
     capi.lib.rela_prof_enable(0)
     adds = replay.num_add() - add0
+    dt_total = sum(ms_head) * 1e-3 * args.steps
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
         a = torch.tensor([adds], device=device, dtype=torch.float64)
         dist.all_reduce(a, op=dist.ReduceOp.SUM)
         adds = float(a.item())
+    n_head_steps = args.steps * args.repeats
 
     buf = C.create_string_buffer(1 << 16)
     capi.check(capi.lib.rela_prof_summary_json(buf, len(buf)), "rela_prof_summary_json")
@@ -677,73 +769,47 @@ def main():
     # untimed: the same step with every kernel timed, for the kernels_ms_per_step table
     capi.lib.rela_prof_set_filter(None)
     capi.lib.rela_prof_enable(1)
-    k_all = max(5, args.steps // 3)
-    for _ in range(k_all):
-        one_step()
-        step_idx[0] += 1
+    k_all = max(5, min(100, n_head_steps // 3))
+    run_steps(k_all)
     sync_all()
     capi.lib.rela_prof_enable(0)
     capi.check(capi.lib.rela_prof_summary_json(buf, len(buf)), "rela_prof_summary_json")
     prof_all = json.loads(buf.value.decode())
 
-    # Reference-style accounting next to the headline (N = 1 only, untimed by the driver): the same
-    # step with the act-forward reuse switched off, i.e. all 4 forwards of the reference per env-step.
-    # A second timed region of exactly the same K steps, bracketed the same way (barrier + synchronize on
-    # both sides, MAX over ranks), with the reuse switched off: SURVEY 8d's unit of work, 4 forwards per env-step.
-    ms_4fwd = ms_3fwd = None
+    # More timed regions of the same K steps x repeats, bracketed the same way, so that the line carries the
+    # reference-style accountings next to the headline:
+    #   reuse_next_only  only the same-tick reuse: 3 trunk forwards per env-step (rounds 1-2's headline accounting)
+    #   no_reuse         reuse off: the reference's 4 trunk forwards per env-step (SURVEY 8d's unit: 74.8 MFLOP)
+    #   f32_mode         actor nets and learner in the exact f32 mode, reuse on
+    #   strict           BOTH: the reference's arithmetic (f32) and the reference's work (4 forwards)
+    def set_all_precision(mode):
+        online.set_precision(mode)
+        target.set_precision(mode)
+        if hip_learner is not None:
+            hip_learner.set_precision(mode)
+
+    settle = min(args.warmup, 3) + MULTI_STEP + 1  # (+ n + 1 ticks so every history slot is of the region's mode)
+    ms_4fwd = ms_3fwd = ms_f32 = ms_strict = None
     if not ONLY:
-        def region(mode):
-            engine.set_reuse(mode)
-            for _ in range(min(args.warmup, 3) + 4):  # (+ n + 1 ticks so every history slot is of this mode)
-                one_step()
-                step_idx[0] += 1
-            sync_all()
-            t4 = time.perf_counter()
-            for _ in range(args.steps):
-                one_step()
-                step_idx[0] += 1
-            sync_all()
-            dt4 = time.perf_counter() - t4
-            if world > 1:
-                t = torch.tensor([dt4], device=device, dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt4 = float(t.item())
-            return dt4 / args.steps * 1e3
-        ms_4fwd = region(0)
-        ms_3fwd = region(2)
+        engine.set_reuse(0)
+        ms_4fwd = region(settle)
+        engine.set_reuse(2)
+        ms_3fwd = region(settle)
         engine.set_reuse(1)
-    # Third timed region of the same K steps (N = 1 accounting, same bracketing): the actor nets in the exact f32
-    # parity mode, so the line carries the f32 rate next to the split-bf16 headline.
-    ms_f32 = None
-    if not ONLY and args.precision == "bf16x2":
-        online.set_precision("f32")
-        target.set_precision("f32")
-        if hip_learner is not None:
-            hip_learner.set_precision("f32")
-        for _ in range(min(args.warmup, 3)):
-            one_step()
-            step_idx[0] += 1
-        sync_all()
-        t5 = time.perf_counter()
-        for _ in range(args.steps):
-            one_step()
-            step_idx[0] += 1
-        sync_all()
-        dt5 = time.perf_counter() - t5
-        if world > 1:
-            t = torch.tensor([dt5], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt5 = float(t.item())
-        ms_f32 = dt5 / args.steps * 1e3
-        online.set_precision("bf16x2")
-        target.set_precision("bf16x2")
-        if hip_learner is not None:
-            hip_learner.set_precision("bf16x2")
+        if args.precision == "bf16x2":
+            set_all_precision("f32")
+            ms_f32 = region(settle)
+            engine.set_reuse(0)
+            ms_strict = region(settle)
+            engine.set_reuse(1)
+            set_all_precision("bf16x2")
+        else:
+            ms_strict = ms_4fwd
     st = replay.debug_state()
     assert st["dev_error"] == 0, "replay reported device error %d" % st["dev_error"]
 
     if rank == 0:
-        env_steps = ROWS * world * args.steps
+        ms_med = median(ms_head)
         # dominant kernel = largest total time among the timed hot-path kernels
         if not prof:  # RELA_BENCH_NOPROF=1 diagnosis run: no per-kernel events were recorded
             prof = {"(profiling off)": {"total_ms": 0.0, "count": 1}}
@@ -782,27 +848,23 @@ def main():
                     "traffic": None, "avg_launch_ms": avg_ms, "launches": rec["count"]}
         if roof["achieved"] is not None:
             roof["frac"] = roof["achieved"] / roof["peak"]
-        # HBM bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the
-        # figure comes from the committed PMC passes of the isolated forward at the same N (separate
-        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, tools/final_evidence.sh + tools/pmc_table.py); newest round first
-        for tname in ("r02_traffic.json", "r01_traffic.json"):
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
-                rec_t = tj["kernels"].get(name)
-                if rec_t is not None:
-                    roof["traffic"] = rec_t["read_bytes"] + rec_t["write_bytes"]
-                    roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, not this run)" % tname
-                    break
-            except (OSError, ValueError, KeyError):
-                continue
+        roof["traffic"], roof["traffic_source"] = traffic_from_profiles(name)
         fwd_ms = sum(prof[k]["total_ms"] for k in FLOP if k in prof)
         fwd_cnt = prof.get("conv12_fused", prof.get("conv1_bf16x3", {"count": 1}))["count"]
+
+        def sub_region(ms, forwards, note):
+            return None if ms is None else {"forwards_per_tick": forwards, "steps": args.steps, "repeats": len(ms),
+                                            "ms_per_step": median(ms), "ms_per_step_repeats": ms,
+                                            "env_steps_per_s": ROWS * world / (median(ms) * 1e-3), "note": note}
         scan_ms = sum(v["total_ms"] for k, v in prof_all.items() if k.startswith("seq_") or k in (
             "replay_targets", "replay_search", "replay_pop", "replay_is_weights"))
         out = {
             "metric": "env-steps/s (Ape-X Atari 84x84x4, actor tick + learner grad-step)",
-            "value": env_steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "value": ROWS * world / (ms_med * 1e-3), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_med, "repeats": args.repeats, "ms_per_step_repeats": ms_head,
+            "ms_per_step_note": "the K-step region (barrier + synchronize on both sides, MAX over ranks) is timed "
+                                "`repeats` times back to back; ms_per_step and value are the MEDIAN repeat",
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "f32" else "f32 results from split-bf16 MFMA (bf16 hi+lo operands, 2-3 bf16 "
                                                            "products per product, f32 accumulate; |dQ| < 2e-6 vs the f32 path)",
@@ -813,31 +875,26 @@ def main():
                                    "frames: no env stepping and no H2D inside the timed region",
                        "envs_per_gpu": ROWS, "replay_capacity": args.replay_cap, "learner_batch": BATCH,
                        "learner_batch_per_gpu": B_LOCAL, "replay_dedup": args.dedup, "actor_precision": args.precision,
-                       "learner_precision": "f32; the two gradient-free forwards of td_err as the actors" ,
+                       "learner_precision": LEARNER_PRECISION_NOTE[args.precision] if hip_learner is not None
+                       else "f32 (PyTorch autograd)",
                        "replay_frame_bytes_per_transition": {None: 56448, "stack": 28224, "plane": 7056}[args.dedup],
                        "parallelism": ("actor-shards%d+replay-partitions+grad-allreduce" % world) if world > 1
                        else "single"},
-            "grad_steps_per_s": args.steps / dt, "train_samples_per_s": args.steps * BATCH / dt,
-            "buffer_add_per_s": adds / dt,
+            "grad_steps_per_s": 1e3 / ms_med, "train_samples_per_s": BATCH * 1e3 / ms_med,
+            "buffer_add_per_s": adds / dt_total,
             "learner": "hip (csrc/learner.hip)" if hip_learner is not None else "torch autograd",
             **({"diagnostic_only": ONLY} if ONLY else {}),
             # act + compute_priority's target(next_obs); online(next_obs) and online(obs) are act's own forwards
             # of this tick and of n ticks ago (same weights, same batch), reused bit-identically -> 2, else 3-4
-            "forwards_per_tick": fwd_cnt / args.steps if ONLY != "learner" else 0,
-            "reuse_next_only": None if ms_3fwd is None else {
-                "forwards_per_tick": 3, "steps": args.steps, "ms_per_step": ms_3fwd,
-                "env_steps_per_s": ROWS * world / (ms_3fwd * 1e-3),
-                "note": "timed region of the same K steps with only the same-tick reuse (online(next_obs) = act()'s "
-                        "forward): 3 trunk forwards per env-step, the headline's accounting in rounds 1-2"},
-            "no_reuse": None if ms_4fwd is None else {
-                "forwards_per_tick": 4, "steps": args.steps, "ms_per_step": ms_4fwd,
-                "env_steps_per_s": ROWS * world / (ms_4fwd * 1e-3),
-                "note": "second timed region of the same K steps with the act-forward reuse off: the reference's "
-                        "4 trunk forwards per env-step (SURVEY 8d: 74.8 MFLOP)"},
-            "f32_mode": None if ms_f32 is None else {
-                "steps": args.steps, "ms_per_step": ms_f32, "env_steps_per_s": ROWS * world / (ms_f32 * 1e-3),
-                "note": "third timed region of the same K steps with the actor nets in the exact f32 MFMA mode "
-                        "(--precision f32 makes it the headline)"},
+            "forwards_per_tick": fwd_cnt / n_head_steps if ONLY != "learner" else 0,
+            "reuse_next_only": sub_region(ms_3fwd, 3, "only the same-tick reuse (online(next_obs) = act()'s forward): 3 trunk "
+                                          "forwards per env-step, the headline's accounting in rounds 1-2"),
+            "no_reuse": sub_region(ms_4fwd, 4, "act-forward reuse off: the reference's 4 trunk forwards per env-step "
+                                   "(SURVEY 8d: 74.8 MFLOP), split-bf16 arithmetic"),
+            "f32_mode": sub_region(ms_f32, fwd_cnt / n_head_steps, "actor nets and learner in the exact f32 MFMA mode "
+                                   "(the reference's arithmetic), forwards memoised as in the headline"),
+            "strict": sub_region(ms_strict, 4, "the reference's arithmetic AND the reference's work: exact f32 MFMA mode for "
+                                 "actors and learner, all 4 trunk forwards per env-step (--precision f32 + reuse off)"),
             "forward_ms_per_6400": fwd_ms / max(fwd_cnt, 1),
             "forward_tflops": sum(v for k, v in FLOP.items() if k != "conv12_fused") * ROWS
             / (max(fwd_ms, 1e-9) / max(fwd_cnt, 1) * 1e-3) / 1e12,
@@ -863,6 +920,11 @@ def main():
                 "algorithmic_bytes_per_step": ROWS * 2 * 28224 * 2, "ms_per_step": ms})(
                     prof_all.get("replay_scatter_rows", {"total_ms": 0.0})["total_ms"] / k_all),
         }
+        if world == 1 and not ONLY and not args.no_threaded:
+            # the drop-in's own metric; the big device buffers of this process go first (the child owns a replay too)
+            replay.close()
+            torch.cuda.empty_cache()
+            out["threaded"] = threaded_leg()
         if world == 1 and not args.no_cpu_baseline:
             port = cpu_baseline()
             ref = cpu_baseline_reference()

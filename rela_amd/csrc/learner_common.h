@@ -389,8 +389,10 @@ __global__ __launch_bounds__(256) void sumsq_partial(const float* __restrict__ g
   if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 // out[0] = total 2-norm, out[1] = min(1, max_norm / (norm + 1e-6))   (torch clip_grad_norm_)
+// `abort_word` (may be NULL): a device word that is non-zero when the gradients of this step must not be applied (the
+// R2D2 learner's grid-barrier timeout word): the coefficient becomes -1 and the update kernels leave everything alone.
 __global__ __launch_bounds__(256) void clip_coef(const double* __restrict__ part, int nblk, float max_norm,
-                                                 float* __restrict__ out) {
+                                                 float* __restrict__ out, const unsigned* __restrict__ abort_word) {
   // one block of 256 threads: fixed-order tree over the (at most 256) partial sums (a single thread walking them took
   // 20 us of every learner step)
   __shared__ double red[256];
@@ -406,12 +408,13 @@ __global__ __launch_bounds__(256) void clip_coef(const double* __restrict__ part
   out[0] = norm;
   const float c = max_norm / (norm + 1e-6f);
   out[1] = c < 1.0f ? c : 1.0f;
+  if (abort_word && *abort_word != 0) out[1] = -1.0f;
 }
 // torch.optim.RMSprop (momentum 0, not centred): sq = alpha*sq + (1-alpha)*g*g; p -= lr * g / (sqrt(sq) + eps)
 __global__ void rmsprop_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, int64_t n,
                                float lr, float alpha, float eps, const float* __restrict__ coef) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || coef[1] < 0.f) return;
   const float gi = g[i] * coef[1];
   const float s = alpha * sq[i] + (1.0f - alpha) * gi * gi;
   sq[i] = s;
@@ -422,7 +425,7 @@ __global__ void adam_update(float* __restrict__ p, const float* __restrict__ g, 
                             float* __restrict__ m2, int64_t n, float lr, float b1, float b2, float eps, float bc1,
                             float bc2_sqrt, const float* __restrict__ coef) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || coef[1] < 0.f) return;
   const float gi = g[i] * coef[1];
   const float a = b1 * m1[i] + (1.0f - b1) * gi;
   const float b = b2 * m2[i] + (1.0f - b2) * gi * gi;
@@ -574,10 +577,10 @@ struct OptimState {
   int64_t adam_t = 0;
 };
 inline void optimizer_apply(OptimState& o, float* P, const float* G, float* S1, float* S2, int64_t n, double* npart,
-                            float* norm, hipStream_t s) {
+                            float* norm, hipStream_t s, const unsigned* abort_word = nullptr) {
   ProfScope prof("learner_optimizer", s);
   hipLaunchKernelGGL(sumsq_partial, dim3(kNormBlocks), dim3(256), 0, s, G, n, npart);
-  hipLaunchKernelGGL(clip_coef, dim3(1), dim3(256), 0, s, (const double*)npart, kNormBlocks, o.clip, norm);
+  hipLaunchKernelGGL(clip_coef, dim3(1), dim3(256), 0, s, (const double*)npart, kNormBlocks, o.clip, norm, abort_word);
   if (o.optimizer == 0) {
     hipLaunchKernelGGL(rmsprop_update, dim3(ceil_div(n, 256)), dim3(256), 0, s, P, G, S1, n, o.lr, 0.99f, o.eps,
                        (const float*)norm);

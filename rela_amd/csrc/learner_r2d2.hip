@@ -860,6 +860,22 @@ extern "C" int rela_r2d2_learner_create(rela_r2d2_learner** out, int num_action,
   RELA_HIP(hipMalloc(&l->rec_bar, sizeof(unsigned) * (size_t)(8 + 2 * ((T + 3) / 4 * 4))));
   RELA_HIP(hipMemset(l->rec_bar, 0, sizeof(unsigned) * (size_t)(8 + 2 * ((T + 3) / 4 * 4))));
   l->rec_persist = !(getenv("RELA_R2D2_REC") && strcmp(getenv("RELA_R2D2_REC"), "steps") == 0);
+  if (l->rec_persist) {
+    // The persistent kernels spin on a grid barrier: every block must be resident at once.  A plain launch checks
+    // nothing, so check here -- blocks per CU the occupancy query admits x the CUs this process sees (a CU-masked or
+    // partitioned device reports fewer) against the grids, with the query's known over-report of one block per CU
+    // taken off -- and fall back to the per-step launches (split-K GEMM + cell kernel) when they would not fit.
+    int cus = 0, occ_f = 0, occ_b = 0;
+    RELA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, lstm_rec_persist, kRecThreads, 0));
+    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, lstm_bptt_persist, kRecThreads, 0));
+    const int64_t room_f = (int64_t)cus * (occ_f > 1 ? occ_f - 1 : occ_f), room_b = (int64_t)cus * (occ_b > 1 ? occ_b - 1 : occ_b);
+    if (room_f < 2 * kRecBlocks || room_b < kBpttBlocks) {
+      fprintf(stderr, "rela_r2d2_learner_create: %d CUs x (%d, %d) resident blocks cannot hold the persistent recurrent "
+                      "grids (%d, %d): using the per-step launches\n", cus, occ_f, occ_b, 2 * kRecBlocks, kBpttBlocks);
+      l->rec_persist = false;
+    }
+  }
   R2_ALLOC(l->ha, rowsTr * 32, false);
   R2_ALLOC(l->q_on, rowsTr * A, false);
   R2_ALLOC(l->q_tg, rowsTr * A, false);
@@ -980,8 +996,12 @@ extern "C" int rela_r2d2_learner_check(rela_r2d2_learner* l, void* stream_) {
   RELA_HIP(hipMemcpy(&tmo, l->rec_bar, sizeof(unsigned), hipMemcpyDeviceToHost));
   if (tmo != 0) {
     RELA_HIP(hipMemset(l->rec_bar, 0, sizeof(unsigned)));
-    set_last_error("rela_r2d2_learner_check: the grid barrier of a persistent recurrent kernel timed out at step %u "
-                   "(results of that call are invalid)", tmo - 1);
+    // every apply() since the timeout was skipped on the device (clip_coef saw the word); from here on this learner
+    // runs the recurrences as per-step launches, which need no co-residency
+    l->rec_persist = false;
+    set_last_error("rela_r2d2_learner_check: the grid barrier of a persistent recurrent kernel timed out at step %u: the "
+                   "results of that call are invalid, no optimiser update was applied since, and this learner now uses "
+                   "the per-step launches", tmo - 1);
     return RELA_ESTATE;
   }
   return RELA_OK;
@@ -1187,7 +1207,9 @@ extern "C" int rela_r2d2_learner_apply(rela_r2d2_learner* l, void* stream_) {
   RELA_CHECK(l && l->loaded, RELA_ESTATE, "rela_r2d2_learner_apply: parameters were never loaded");
   hipStream_t s = (hipStream_t)stream_;
   DeviceGuard g(l->device);
-  optimizer_apply(l->opt, l->P, l->G, l->S1, l->S2, l->off[14], l->npart, l->norm, s);
+  // (a grid-barrier timeout of this step's persistent kernels leaves stale gradients: the update is skipped on the
+  // device, rela_r2d2_learner_check reports it and switches to the per-step launches)
+  optimizer_apply(l->opt, l->P, l->G, l->S1, l->S2, l->off[14], l->npart, l->norm, s, l->rec_bar);
   RELA_LAUNCH_CHECK();
   return repack_r2d2(l, true, false, s);
 }

@@ -144,6 +144,7 @@ def train(args, on_epoch=None):
             replay_buffer.update_priority(priority)
             loss_sum += loss.detach()
         torch.cuda.synchronize()
+        _check_learner(learner)
         dt = time.time() - t0
         print("epoch: %d, time: %.1fs, loss: %.5f" % (epoch, dt, float(loss_sum) / args.epoch_len))
         rates = tach.lap(actors, replay_buffer, args.epoch_len * args.batchsize)
@@ -260,6 +261,7 @@ def _multi_worker(rank, world, args, port, results):
                 replay.update_priority(priority)
                 loss_sum += loss[0]
             torch.cuda.synchronize()
+            _check_learner(learner)
             dt = time.time() - t0
             history.append(dict(epoch=epoch, seconds=dt, train=args.epoch_len * args.batchsize / dt,
                                 loss=float(loss_sum) / args.epoch_len))
@@ -320,6 +322,18 @@ def _multi_worker(rank, world, args, port, results):
     dist.destroy_process_group()
 
 
+
+def _check_learner(learner):
+    """Once per epoch: a HIP learner whose persistent kernels gave up on a grid barrier (rela_r2d2_learner_check)
+    has skipped its optimiser updates since and now runs the per-step launches; say so loudly and carry on."""
+    if learner is None or not hasattr(learner, "check"):
+        return
+    try:
+        learner.check()
+    except RuntimeError as e:
+        print("WARNING: %s" % e, flush=True)
+
+
 def train_multi(args):
     """--act_device cuda:1,cuda:2,...: one actor process per act device, each with its replay partition, plus
     the learner process on --train_device (rela_amd/parallel.py).  Processes are spawned BEFORE any GPU call."""
@@ -339,11 +353,36 @@ def train_multi(args):
     procs = [ctx.Process(target=_multi_worker, args=(r, G + 1, args, port, results)) for r in range(G + 1)]
     for p in procs:
         p.start()
-    res = results.get(timeout=3600)
-    for p in procs:
-        p.join(timeout=120)
-        if p.exitcode != 0:
-            raise SystemExit("rank process exited with %s" % p.exitcode)
+    # No global deadline (a default run lasts many hours): poll for the learner's result and watch every rank.  The
+    # first rank that dies takes the job down -- its peers would otherwise hang in their collectives.
+    import queue
+
+    def stop_all():
+        for q in procs:
+            if q.is_alive():
+                q.terminate()
+        for q in procs:
+            q.join(timeout=10)
+
+    res = None
+    while res is None:
+        try:
+            res = results.get(timeout=5)
+        except queue.Empty:
+            dead = [(r, q.exitcode) for r, q in enumerate(procs) if q.exitcode not in (None, 0)]
+            if dead:
+                stop_all()
+                raise SystemExit("rank %d exited with code %s before the run finished; the other ranks were stopped" % dead[0])
+            if all(q.exitcode == 0 for q in procs):
+                raise SystemExit("every rank exited without a result")
+    for r, q in enumerate(procs):
+        q.join(timeout=120)
+        if q.exitcode is None:  # still running two minutes after the result: stop it, the run itself succeeded
+            q.terminate()
+            q.join(timeout=10)
+        elif q.exitcode != 0:
+            stop_all()
+            raise SystemExit("rank %d exited with code %s" % (r, q.exitcode))
     return res
 
 

