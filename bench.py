@@ -128,14 +128,16 @@ def traffic_from_profiles(label):
     return None, None
 
 
-def threaded_leg(seconds=4.0, epochs=2, threads=64, games=100):
+def threaded_leg(seconds=2.0, epochs=2, threads=64, games=100):
     """The metric as the reference defines it (pyrela/benchmark.py:73-109): sum of DQNActor.num_act() deltas per
     second through rela.Context + BasicThreadLoop + DQNActor + FFPrioritizedReplay of the drop-in `rela` module --
     C++ actor threads stepping HOST envs, per-step host -> HBM observation upload -- without and with a concurrent
     unthrottled B = 512 sample / update_priority loop, in a child process on this box's host cores (bounded: the
-    reference protocol is 6 x 30 s windows per mode, this leg runs `epochs` x `seconds`)."""
+    reference protocol is 6 x 30 s windows per mode, this leg runs `epochs` x `seconds`; the replay holds 2^21
+    transitions as in pyrela/benchmark.py:161, so the windows without a sampler end before its ring is full and the
+    actors never park on back-pressure)."""
     cmd = [sys.executable, os.path.join(ROOT, "rela_amd", "pyrela", "benchmark.py"), "--grid", "%dx%d" % (threads, games),
-           "--epoch_sec", str(seconds), "--num_epoch", str(epochs), "--replay_buffer_size", str(1 << 20)]
+           "--epoch_sec", str(seconds), "--num_epoch", str(epochs), "--replay_buffer_size", str(1 << 21)]
     t0 = time.time()
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
@@ -146,7 +148,8 @@ def threaded_leg(seconds=4.0, epochs=2, threads=64, games=100):
     return {"metric": "env-steps/s = d(sum of DQNActor.num_act())/dt through rela.Context / BasicThreadLoop / DQNActor "
                       "(pyrela/benchmark.py:73-109), host envs + H2D upload included",
             "without_sampler": without, "with_sampler": with_, "unit": "env-steps/s", "threads": threads,
-            "games_per_thread": games, "host_cores": len(os.sched_getaffinity(0)), "window_s": seconds, "windows": epochs,
+            "games_per_thread": games, "host_cores_visible": len(os.sched_getaffinity(0)), "window_s": seconds,
+            "windows": epochs,
             "sampler": "unthrottled B=512 sample + update_priority loop on the Python thread", "wall_s": time.time() - t0,
             "note": "bounded sample of the reference's 6 x 30 s protocol; mean of the last half of the windows"}
 

@@ -1806,15 +1806,21 @@ struct FcFastT {
 };
 using FcFast = FcFastT<112>;
 
-template <class F>
+// SPLIT (batches of a few hundred rows, where 4 x ceil(N / BM) blocks would leave most CUs idle): blockIdx.z owns the
+// positions [z * per, z * per + per) of the contraction and writes its raw partial sums to out[z][N][512]; fc_reduce adds
+// them up in z order with the bias and the ReLU.  Without SPLIT the range is the compile-time [0, 49).
+template <class F, bool SPLIT = false>
 __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__ A, const uint4* __restrict__ Bfrag,
-                                                     const float* __restrict__ bias, float* __restrict__ out, int N) {
+                                                     const float* __restrict__ bias, float* __restrict__ out, int N,
+                                                     int per) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int ct = blockIdx.x * kWaves + wave;
   const int row0 = blockIdx.y * F::BM;
+  const int p0 = SPLIT ? (int)blockIdx.z * per : 0;
+  const int p1 = SPLIT ? min(F::NPOS, p0 + per) : F::NPOS;
   uint4 st0[F::IT], st1[F::IT];
   // No predicates on the staging loads and stores (clamped indices repeat a neighbour's chunk, row or position
   // instead): a load inside a branch makes the compiler fall back to s_waitcnt vmcnt(0), which would wait for the
@@ -1822,7 +1828,7 @@ __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__
   const int nrow = min(F::BM, N - row0);
   auto load_pos = [&](int pos, auto set) {
     constexpr int S = decltype(set)::value;
-    const int pp = min(pos, F::NPOS - 1);
+    const int pp = min(pos, p1 - 1);
 #pragma unroll
     for (int j = 0; j < F::IT; ++j) {
       const int i = min(tid + j * kThreads, F::V16 - 1);
@@ -1848,15 +1854,15 @@ __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__
   const uint4* bp = Bfrag + (size_t)ct * F::KS * 2 * 64 + lane;
   uint4 bnext[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) bnext[q] = bp[(size_t)q * 64];  // k-steps 0,1 x (hi, lo)
+  for (int q = 0; q < 4; ++q) bnext[q] = bp[(size_t)(p0 * 4 + q) * 64];  // k-steps 0,1 of the first position x (hi, lo)
   using Set0 = std::integral_constant<int, 0>;
   using Set1 = std::integral_constant<int, 1>;
-  load_pos(0, Set0{});
-  load_pos(1, Set1{});
+  load_pos(p0, Set0{});
+  load_pos(p0 + 1, Set1{});
   store_pos(0, Set0{});
-  load_pos(2, Set0{});
+  load_pos(p0 + 2, Set0{});
   store_pos(1, Set1{});
-  load_pos(3, Set1{});
+  load_pos(p0 + 3, Set1{});
   __syncthreads();
 
   // A fragment ring: pair i of a position = (sub = i / RT, row tile t = i % RT)
@@ -1877,7 +1883,7 @@ __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__
 #pragma unroll
     for (int q = 0; q < 4; ++q) bcur[q] = bnext[q];
     {
-      const int pn = min(pos + 1, F::NPOS - 1);
+      const int pn = min(pos + 1, p1 - 1);
 #pragma unroll
       for (int q = 0; q < 4; ++q) bnext[q] = bp[(size_t)(pn * 4 + q) * 64];
     }
@@ -1909,11 +1915,22 @@ __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__
     __syncthreads();
     buf = nbuf;
   };
-  for (int pos = 0; pos < F::NPOS; pos += 2) {
+  for (int pos = p0; pos < p1; pos += 2) {
     body(pos, Set0{});
-    if (pos + 1 < F::NPOS) body(pos + 1, Set1{});
+    if (pos + 1 < p1) body(pos + 1, Set1{});
   }
   const int col = ct * 16 + li;
+  if constexpr (SPLIT) {
+    float* part = out + (size_t)blockIdx.z * N * F::OC;
+#pragma unroll
+    for (int t = 0; t < F::RT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = row0 + t * 16 + g * 4 + r;
+        if (row < N) part[(size_t)row * F::OC + col] = acc[t][r];
+      }
+    return;
+  }
   const float bv = bias[col];
 #pragma unroll
   for (int t = 0; t < F::RT; ++t)
@@ -2222,7 +2239,7 @@ __global__ void unsplit_records64(uint8_t* __restrict__ rec, int64_t pixels) {
 // gemm_lds (gemm_lds.h) over ~256 blocks; fc_reduce sums the partial tiles in a fixed order and
 // applies bias + ReLU.  The partial tiles live in the caller's workspace behind `ha`.
 constexpr int kFcSplitBelow = 2048;
-constexpr int64_t kFcPartFloats = (int64_t)4096 * 512;  // splits * N <= 32 * 128
+constexpr int64_t kFcPartFloats = (int64_t)8192 * 512;  // splits * N <= 8192 rows of partial sums (f32 split-K: <= 4096)
 inline int fc_splits(int N) {
   const int rb = ceil_div(N, 128);
   const int sp = 32 / rb;
@@ -2464,6 +2481,8 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv12S::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv3F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv3F::LDS_TOTAL));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s<FcFast, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, FcFast::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s<FcFast>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, FcFast::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma<Conv2>),
@@ -2562,7 +2581,7 @@ extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on
     int64_t el[13];
     for (int jn = 0; jn < 13; ++jn) el[jn] = elems[jn];
     if (n->max_rows > 0 && n->max_rows < kFcSplitBelow) el[4] = 0;
-    if (n->max_rows > 0 && n->max_rows < kFastMinN) el[10] = 0;
+    if (n->max_rows > 0 && n->max_rows < kFastTrunkMinN) el[10] = 0;  // (the split-K fc_bf16s serves 128 rows and up)
     a.first[0] = 0;
     for (int jn = 0; jn < 13; ++jn) a.first[jn + 1] = a.first[jn] + (int)ceil_div(el[jn], 256);
     hipLaunchKernelGGL(pack_ffnet_all, dim3(a.first[13]), dim3(256), 0, s, a);
@@ -2609,6 +2628,9 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
   // 90 us in f32) but fc_bf16s has too few blocks (55 us against the 24 us of the f32 split-K GEMM): the trunk runs
   // fast, a3 is turned back into f32 in place and fc takes the f32 path.
   const bool fast_trunk_only = precision == 1 && N < fast_min_n && N >= kFastTrunkMinN;
+  // ... and (r3) fc too, as a split-K launch of fc_bf16s, when this net packs the bf16 fc fragments
+  static const int fc_split_env = getenv("RELA_FC_SPLIT_BF16") ? atoi(getenv("RELA_FC_SPLIT_BF16")) : 1;
+  const bool fc_split_bf16 = fast_trunk_only && fc_split_env && !(n->max_rows > 0 && n->max_rows < kFastTrunkMinN);
   if (fast_trunk_only) {
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
@@ -2620,7 +2642,28 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
       ProfScope prof(names[2], s);
       note_launch("conv_bf16s<Conv3F>"); hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
                          Conv3F::LDS_TOTAL, s, (const uint8_t*)r2, (const uint4*)d.B3f, (const float*)d.b3, r3, N);
-      note_launch("unsplit_records64"); hipLaunchKernelGGL(unsplit_records64, dim3(ceil_div((int64_t)N * 49, 4)), dim3(256), 0, s, r3, (int64_t)N * 49);
+      if (!fc_split_bf16) {
+        note_launch("unsplit_records64"); hipLaunchKernelGGL(unsplit_records64, dim3(ceil_div((int64_t)N * 49, 4)), dim3(256), 0, s, r3, (int64_t)N * 49);
+      }
+    }
+    if (fc_split_bf16) {
+      // fc on split-bf16 MFMA straight from a3's records, the contraction split over blockIdx.z so that ~256 blocks
+      // run (r3; the f32 split-K GEMM after an unsplit pass took 21 + 6 + 6 us at 512 rows); a3 STAYS in records
+      const int rb = ceil_div(N, FcFast::BM);
+      int slices = std::max(1, std::min(FcFast::NPOS, kNumCU / (4 * rb)));
+      slices = std::min(slices, (int)(8192 / N));
+      const int per = ceil_div(FcFast::NPOS, slices);
+      slices = ceil_div(FcFast::NPOS, per);
+      float* part = ha + kHA * N;
+      part += (64 - ((part - static_cast<float*>(ws)) & 63)) & 63;
+      {
+        ProfScope prof(names[3], s);
+        note_launch("fc_bf16s (split-K)");
+        hipLaunchKernelGGL((fc_bf16s<FcFast, true>), dim3(4, rb, slices), dim3(kThreads), FcFast::LDS_BYTES, s,
+                           (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, part, N, per);
+      }
+      note_launch("fc_reduce"); hipLaunchKernelGGL(fc_reduce, dim3(ceil_div(N * 128, 256)), dim3(256), 0, s, (const float*)part, slices, N,
+                         (const float*)d.bf, h);
     }
   }
   if (precision == 1 && N >= fast_min_n) {
@@ -2663,7 +2706,7 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     {
       ProfScope prof(names[3], s);
       note_launch("fc_bf16s"); hipLaunchKernelGGL(fc_bf16s<FcFast>, dim3(4, ceil_div(N, FcFast::BM)), dim3(kThreads), FcFast::LDS_BYTES, s,
-                         (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, h, N);
+                         (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, h, N, 0);
     }
   } else {
   if (!fast_trunk_only) {
@@ -2681,7 +2724,9 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
   }
   }
-  if (N < kFcSplitBelow) {
+  if (fc_split_bf16) {
+    // (h is already there)
+  } else if (N < kFcSplitBelow) {
     const int splits = fc_splits(N);
     float* part = ha + kHA * N;
     part += (64 - ((part - static_cast<float*>(ws)) & 63)) & 63;  // 256-byte aligned (float4 loads)

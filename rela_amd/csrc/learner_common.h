@@ -287,7 +287,17 @@ __global__ __launch_bounds__(kLT) void colsum_partial_multi(ColsumJobs jobs) {
   const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = blockIdx.x * per, r1 = min(rows, r0 + per);
   float4 s = zero4();
-  for (int64_t r = r0 + rl; r < r1; r += L) {
+  // eight row loads in flight per thread (one at a time left the 26 MB of d_a1 latency-bound: 47 us per step); the
+  // adds keep their order, so the sums are bit-identical to the one-load loop
+  int64_t r = r0 + rl;
+  for (; r + 7 * (int64_t)L < r1; r += 8 * (int64_t)L) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ld4(src + (r + u * (int64_t)L) * C + cg * 4);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s.x += v[u].x, s.y += v[u].y, s.z += v[u].z, s.w += v[u].w;
+  }
+  for (; r < r1; r += L) {
     const float4 v = ld4(src + r * C + cg * 4);
     s.x += v.x, s.y += v.y, s.z += v.z, s.w += v.w;
   }
@@ -376,10 +386,27 @@ __global__ void permute_weights(int mode, const float* __restrict__ src, float* 
 // ---- clip_grad_norm_ + optimiser over the flat buffers ----------------------------------------
 constexpr int kNormBlocks = 256;
 __global__ __launch_bounds__(256) void sumsq_partial(const float* __restrict__ g, int64_t n, double* __restrict__ part) {
+  // n is a multiple of 4 (every segment of the flat buffer is padded to 4 floats) and g is 16-byte aligned: float4
+  // loads, four in flight per thread; fixed association (deterministic), f64 accumulation as before
   __shared__ double red[256];
   double s = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
-    s += (double)g[i] * (double)g[i];
+  const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * 256;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = g4[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      s += (double)v[u].x * (double)v[u].x + (double)v[u].y * (double)v[u].y + (double)v[u].z * (double)v[u].z +
+           (double)v[u].w * (double)v[u].w;
+  }
+  for (; i < n4; i += stride) {
+    const float4 v = g4[i];
+    s += (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) s += (double)g[(n4 << 2) + threadIdx.x] * (double)g[(n4 << 2) + threadIdx.x];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -411,27 +438,42 @@ __global__ __launch_bounds__(256) void clip_coef(const double* __restrict__ part
   if (abort_word && *abort_word != 0) out[1] = -1.0f;
 }
 // torch.optim.RMSprop (momentum 0, not centred): sq = alpha*sq + (1-alpha)*g*g; p -= lr * g / (sqrt(sq) + eps)
-__global__ void rmsprop_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, int64_t n,
+// (four elements per thread: 16-byte accesses; n4 = ceil(n / 4), the flat buffers are padded to 4 floats)
+__global__ void rmsprop_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq, int64_t n4,
                                float lr, float alpha, float eps, const float* __restrict__ coef) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || coef[1] < 0.f) return;
-  const float gi = g[i] * coef[1];
-  const float s = alpha * sq[i] + (1.0f - alpha) * gi * gi;
-  sq[i] = s;
-  p[i] -= lr * (gi / (sqrtf(s) + eps));
+  const float cf = coef[1];
+  if (i >= n4 || cf < 0.f) return;
+  const float4 gv = reinterpret_cast<const float4*>(g)[i];
+  float4 sv = reinterpret_cast<float4*>(sq)[i], pv = reinterpret_cast<float4*>(p)[i];
+  auto upd = [&](float gi, float& s, float& pi) {
+    gi = gi * cf;
+    s = alpha * s + (1.0f - alpha) * gi * gi;
+    pi -= lr * (gi / (sqrtf(s) + eps));
+  };
+  upd(gv.x, sv.x, pv.x), upd(gv.y, sv.y, pv.y), upd(gv.z, sv.z, pv.z), upd(gv.w, sv.w, pv.w);
+  reinterpret_cast<float4*>(sq)[i] = sv;
+  reinterpret_cast<float4*>(p)[i] = pv;
 }
 // torch.optim.Adam (no amsgrad, no weight decay); bias corrections computed on the host per step
 __global__ void adam_update(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1,
-                            float* __restrict__ m2, int64_t n, float lr, float b1, float b2, float eps, float bc1,
+                            float* __restrict__ m2, int64_t n4, float lr, float b1, float b2, float eps, float bc1,
                             float bc2_sqrt, const float* __restrict__ coef) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || coef[1] < 0.f) return;
-  const float gi = g[i] * coef[1];
-  const float a = b1 * m1[i] + (1.0f - b1) * gi;
-  const float b = b2 * m2[i] + (1.0f - b2) * gi * gi;
-  m1[i] = a;
-  m2[i] = b;
-  p[i] -= (lr / bc1) * (a / (sqrtf(b) / bc2_sqrt + eps));
+  const float cf = coef[1];
+  if (i >= n4 || cf < 0.f) return;
+  const float4 gv = reinterpret_cast<const float4*>(g)[i];
+  float4 av = reinterpret_cast<float4*>(m1)[i], bv = reinterpret_cast<float4*>(m2)[i], pv = reinterpret_cast<float4*>(p)[i];
+  auto upd = [&](float gi, float& a, float& b, float& pi) {
+    gi = gi * cf;
+    a = b1 * a + (1.0f - b1) * gi;
+    b = b2 * b + (1.0f - b2) * gi * gi;
+    pi -= (lr / bc1) * (a / (sqrtf(b) / bc2_sqrt + eps));
+  };
+  upd(gv.x, av.x, bv.x, pv.x), upd(gv.y, av.y, bv.y, pv.y), upd(gv.z, av.z, bv.z, pv.z), upd(gv.w, av.w, bv.w, pv.w);
+  reinterpret_cast<float4*>(m1)[i] = av;
+  reinterpret_cast<float4*>(m2)[i] = bv;
+  reinterpret_cast<float4*>(p)[i] = pv;
 }
 
 
@@ -582,15 +624,15 @@ inline void optimizer_apply(OptimState& o, float* P, const float* G, float* S1, 
   hipLaunchKernelGGL(sumsq_partial, dim3(kNormBlocks), dim3(256), 0, s, G, n, npart);
   hipLaunchKernelGGL(clip_coef, dim3(1), dim3(256), 0, s, (const double*)npart, kNormBlocks, o.clip, norm, abort_word);
   if (o.optimizer == 0) {
-    hipLaunchKernelGGL(rmsprop_update, dim3(ceil_div(n, 256)), dim3(256), 0, s, P, G, S1, n, o.lr, 0.99f, o.eps,
+    hipLaunchKernelGGL(rmsprop_update, dim3(ceil_div(n / 4, 256)), dim3(256), 0, s, P, G, S1, n / 4, o.lr, 0.99f, o.eps,
                        (const float*)norm);
   } else {
     o.adam_t += 1;
     const float b1 = 0.9f, b2 = 0.999f;
     const float bc1 = 1.0f - (float)pow((double)b1, (double)o.adam_t);
     const float bc2s = (float)sqrt(1.0 - pow((double)b2, (double)o.adam_t));
-    hipLaunchKernelGGL(adam_update, dim3(ceil_div(n, 256)), dim3(256), 0, s, P, G, S1, S2, n, o.lr, b1, b2, o.eps, bc1,
-                       bc2s, (const float*)norm);
+    hipLaunchKernelGGL(adam_update, dim3(ceil_div(n / 4, 256)), dim3(256), 0, s, P, G, S1, S2, n / 4, o.lr, b1, b2, o.eps,
+                       bc1, bc2s, (const float*)norm);
   }
 }
 

@@ -68,7 +68,7 @@ FAST_TRUNK_MIN_N, FAST_FC_MIN_N = 128, 1024
 def expected_kernels(N, precision):
     if precision == "bf16x2" and N >= FAST_TRUNK_MIN_N:
         trunk = {"conv12_bf16s", "conv_bf16s<Conv3F>"}
-        return trunk | ({"fc_bf16s"} if N >= FAST_FC_MIN_N else {"unsplit_records64"})
+        return trunk | ({"fc_bf16s"} if N >= FAST_FC_MIN_N else {"fc_bf16s (split-K)"})
     return {"conv1_bf16x3", "conv_mfma<Conv2> (f32)", "conv_mfma<Conv3> (f32)"}
 
 
@@ -164,7 +164,7 @@ def _torch_fp32_forward(p, s, legal):
 def test_ffnet_vs_torch_fp32(N, precision):
     """Ragged batch sizes (partial sample tiles in every kernel) vs a plain PyTorch fp32 forward of the same
     architecture on the same device, in BOTH precision modes, with the launched kernels asserted: the split-bf16
-    kernels (conv12_bf16s, conv_bf16s<Conv3F> from 128 rows, fc_bf16s from 1,024) are compared with torch-fp32
+    kernels (conv12_bf16s, conv_bf16s<Conv3F>, fc_bf16s as split-K from 128 rows, fc_bf16s from 1,024) are compared with torch-fp32
     directly, not through the library's own f32 mode.  N >= 512 / 1536 switches the f32 conv2 / conv3 to the
     weight-stationary persistent kernels; N = 6400 is the shape of bench.py's actor tick (80 threads x 80 envs)."""
     from synth import synth_obs, synth_params
