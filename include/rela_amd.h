@@ -472,6 +472,10 @@ int rela_apex_learner_grads(rela_apex_learner* l, rela_ffnet_params* grads_out);
 int rela_apex_learner_flat(rela_apex_learner* l, float** params_dev, float** grads_dev, int64_t* count);
 /* f32[2] on the device: total gradient norm before clipping, clip coefficient of the last apply */
 const float* rela_apex_learner_stats_dev(const rela_apex_learner* l);
+/* Debug / tests: the activations of online(obs) the last rela_apex_learner_loss left for the backward pass, f32,
+ * channel-last: a1 [B][400][32], a2 [B][81][64], a3 [B][49][64], h [B][512] (their > 0 pattern is the ReLU mask the
+ * gradients were computed with).  Valid until the next rela_apex_learner_loss.                  */
+int rela_apex_learner_debug_activations(rela_apex_learner* l, float** a1, float** a2, float** a3, float** h, int* batch);
 
 /* ===================================================================================
  * R2D2 learner step  --  pyrela/main.py:206-251 with R2D2Agent.loss (pyrela/r2d2.py:189-206):

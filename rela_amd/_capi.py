@@ -151,6 +151,7 @@ _sig("rela_apex_learner_params", i32, [vp, P(FFNetParams), P(FFNetParams)])
 _sig("rela_apex_learner_grads", i32, [vp, P(FFNetParams)])
 _sig("rela_apex_learner_flat", i32, [vp, P(vp), P(vp), P(i64)])
 _sig("rela_apex_learner_stats_dev", vp, [vp])
+_sig("rela_apex_learner_debug_activations", i32, [vp, P(vp), P(vp), P(vp), P(vp), P(i32)])
 _sig("rela_r2d2_learner_create", i32, [P(vp), i32, i32, i32, f32, i32, i32, f64, i32, f32, f32, f32, i32])
 _sig("rela_r2d2_learner_destroy", None, [vp])
 _sig("rela_r2d2_learner_load", i32, [vp, P(LSTMNetParams), P(LSTMNetParams), i32, vp])

@@ -812,9 +812,9 @@ using Conv2F = ConvFastCfg<32, 20, 20, 4, 4, 2, 9, 9, 1, 9, 185, 20 * 185>;
 using Conv3F = ConvFastCfg<64, 9, 9, 3, 3, 1, 7, 7, 2, 18, 174, 1570>;
 
 template <class C>
-__global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict__ in, const uint4* __restrict__ Bfrag,
-                                                       const float* __restrict__ bias, uint8_t* __restrict__ out,
-                                                       int N) {
+__device__ __forceinline__ void conv_bf16s_body(const uint8_t* __restrict__ in, const uint4* __restrict__ Bfrag,
+                                                const float* __restrict__ bias, uint8_t* __restrict__ out, int N, int bid,
+                                                int nblk) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict
     }
   };
 
-  int grp = blockIdx.x;
+  int grp = bid;
   if (grp >= ngroups) return;
   stage_load(grp, 0);
   stage_store(0, 0);
@@ -884,9 +884,9 @@ __global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict
   __syncthreads();
   int buf = 0;
   constexpr int LO = C::CIN * 2;  // byte offset of the lo part inside a pixel record
-  for (; grp < ngroups; grp += gridDim.x) {
-    const bool has_next = grp + (int)gridDim.x < ngroups;
-    if (has_next) stage_load(grp + gridDim.x, 0);
+  for (; grp < ngroups; grp += nblk) {
+    const bool has_next = grp + nblk < ngroups;
+    if (has_next) stage_load(grp + nblk, 0);
     const uint8_t* tile = smem + buf * C::LDS_BYTES;
     f32x4 acc[C::RPW];  // starts at the bias
 #pragma unroll
@@ -921,7 +921,7 @@ __global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict
       if (has_next) {
         if (idx == TOT / 3) {
           stage_store(buf ^ 1, 0);
-          stage_load(grp + gridDim.x, 1);
+          stage_load(grp + nblk, 1);
         } else if (idx == (2 * TOT) / 3) {
           stage_store(buf ^ 1, 1);
         }
@@ -952,6 +952,13 @@ __global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict
   }
 }
 
+template <class C>
+__global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict__ in, const uint4* __restrict__ Bfrag,
+                                                       const float* __restrict__ bias, uint8_t* __restrict__ out,
+                                                       int N) {
+  conv_bf16s_body<C>(in, Bfrag, bias, out, N, blockIdx.x, gridDim.x);
+}
+
 // conv1 -> conv2 fused per frame: conv1's output (400 pixels x 32 channels of split records) is written straight
 // into conv2's padded LDS input tile and never travels to HBM (-328 MB written and -328 MB read per 6,400 frames;
 // staging that read alone took 82 of conv2's 123 us, the copy-out 29 of conv1's 133).  One 8-wave block per CU:
@@ -973,12 +980,16 @@ struct Conv12 {
   static constexpr int IT = (C1::V16 + kThreads - 1) / kThreads;  // 2
 };
 
-__global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restrict__ in,
-                                                         const uint4* __restrict__ B1frag,
-                                                         const float* __restrict__ bias1,
-                                                         const uint4* __restrict__ B2frag,
-                                                         const float* __restrict__ bias2, uint8_t* __restrict__ out,
-                                                         int N) {
+// The body of the kernel, shared by conv12_bf16s (one net, blocks = the whole grid) and conv12_bf16s_jobs (the
+// learner's forwards: several nets / batches in ONE launch, each job on its own range of blocks).  JOBS adds: rows
+// from two source buffers (rows >= n_in0 come from in1), and a copy of conv1's records (a1, which otherwise never
+// leaves LDS) to a1_out for the rows < n_a1 -- the pass whose activations the backward kernels read.
+template <bool JOBS>
+__device__ __forceinline__ void conv12_body(const uint8_t* __restrict__ in, const uint8_t* __restrict__ in1, int n_in0,
+                                            const uint4* __restrict__ B1frag, const float* __restrict__ bias1,
+                                            const uint4* __restrict__ B2frag, const float* __restrict__ bias2,
+                                            uint8_t* __restrict__ out, uint8_t* __restrict__ a1_out, int n_a1, int N,
+                                            int bid, int nblk) {
   using F = Conv12;
   using C1 = Conv1P;
   using C2 = Conv2F;
@@ -1031,7 +1042,8 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
   // ---- staging of u8 half frames (unpredicated, clamped chunk index) ----
   uint4 st[F::IT];
   auto g_load = [&](int n, int h) {
-    const uint8_t* src = in + (size_t)n * C1::IN_ELEMS + h * (40 * 84);
+    const uint8_t* src = (!JOBS || n < n_in0 ? in + (size_t)n * C1::IN_ELEMS : in1 + (size_t)(n - n_in0) * C1::IN_ELEMS) +
+                         h * (40 * 84);
 #pragma unroll
     for (int j = 0; j < F::IT; ++j) {
       const int i = min(tid + j * kThreads, C1::V16 - 1);
@@ -1105,7 +1117,7 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
     }
   };
 
-  int n = blockIdx.x;
+  int n = bid;
   if (n >= N) return;
   g_load(n, 0);
   cvt_store();
@@ -1117,8 +1129,8 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
   }
   __syncthreads();
   constexpr int LO = C2::CIN * 2;
-  for (; n < N; n += gridDim.x) {
-    const int nn = (n + (int)gridDim.x < N) ? n + (int)gridDim.x : n;  // (the last round re-reads its own frame)
+  for (; n < N; n += nblk) {
+    const int nn = (n + nblk < N) ? n + nblk : n;  // (the last round re-reads its own frame)
     conv1_half(0);
     __syncthreads();  // T1 free
     cvt_store();      // half 1 of this frame
@@ -1126,6 +1138,16 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
     __syncthreads();  // T1 ready
     conv1_half(1);
     __syncthreads();  // T2 complete, T1 free
+    if constexpr (JOBS) {
+      if (a1_out && n < n_a1) {  // (block-uniform) conv1's records of this frame: [400 pixels][32 hi | 32 lo]
+        uint4* dst = reinterpret_cast<uint4*>(a1_out + (size_t)n * (400 * 128));
+        for (int i = tid; i < 400 * 8; i += kThreads) {
+          const int px = i >> 3, u = i & 7;
+          const int y = px / 20, x = px - y * 20;
+          dst[i] = *reinterpret_cast<const uint4*>(t2 + (size_t)(y * C2::RQ + x * C2::Q + u) * 16);
+        }
+      }
+    }
     // ---- conv2 from T2; the next frame's first half goes into T1 meanwhile ----
     {
       f32x4 acc[C2::RPW];
@@ -1171,6 +1193,46 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
         dst[i] = *reinterpret_cast<const uint4*>(otile + (i >> 4) * C2::OROW + (i & 15) * 16);
     }
   }
+}
+
+__global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restrict__ in,
+                                                         const uint4* __restrict__ B1frag,
+                                                         const float* __restrict__ bias1,
+                                                         const uint4* __restrict__ B2frag,
+                                                         const float* __restrict__ bias2, uint8_t* __restrict__ out,
+                                                         int N) {
+  conv12_body<false>(in, nullptr, N, B1frag, bias1, B2frag, bias2, out, nullptr, 0, N, blockIdx.x, gridDim.x);
+}
+
+// Several trunk passes in one launch (the learner's three forwards: online over [s ; s'], target over s'): job j owns
+// the blocks [block0, block0 + nblocks) and walks its own frames with its own weights.
+struct TrunkJob {
+  const uint8_t *in0, *in1;  // rows [0, n_in0) of in0, then rows of in1
+  int n_in0;
+  const uint4 *B1, *B2, *B3;  // conv1 / conv2 / conv3 fragments of the job's net
+  const float *b1, *b2, *b3;
+  uint8_t *a1_out;  // conv1's records for rows < n_a1, or NULL
+  int n_a1;
+  uint8_t *a2, *a3;  // conv2's / conv3's split records [N][81][256 B] / [N][49][256 B]
+  int N, block0, nblocks;
+};
+constexpr int kMaxTrunkJobs = 3;
+struct TrunkJobs {
+  TrunkJob j[kMaxTrunkJobs];
+  int n;
+};
+__global__ __launch_bounds__(kThreads) void conv12_bf16s_jobs(TrunkJobs jobs) {
+  int k = 0;
+  while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].block0) ++k;
+  const TrunkJob& t = jobs.j[k];
+  conv12_body<true>(t.in0, t.in1, t.n_in0, t.B1, t.b1, t.B2, t.b2, t.a2, t.a1_out, t.n_a1, t.N, (int)blockIdx.x - t.block0,
+                    t.nblocks);
+}
+__global__ __launch_bounds__(kThreads) void conv3_bf16s_jobs(TrunkJobs jobs) {
+  int k = 0;
+  while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].block0) ++k;
+  const TrunkJob& t = jobs.j[k];
+  conv_bf16s_body<Conv3F>(t.a2, t.B3, t.b3, t.a3, t.N, (int)blockIdx.x - t.block0, t.nblocks);
 }
 
 // conv1 -> conv2 as a TWO-STAGE PIPELINE inside one block (wave specialisation by layer).  The symmetric fused
@@ -2376,7 +2438,8 @@ struct PackAllArgs {
   uint16_t *B1, *B1p, *B2f, *B3f, *Bff;
   float *B2, *B3, *Bf, *BfT, *Bh, *Bhp, *b1, *b2, *b3, *bf, *bh;
   int A;
-  int first[14];  // first block of job j; first[13] = total
+  float *w2p, *w3p, *wfcp;  // the learner's dgrad operand copies (ffnet_layout.h), or NULL
+  int first[17];  // first block of job j; first[16] = total
 };
 __global__ void pack_ffnet_all(PackAllArgs a) {
   const int b = blockIdx.x;
@@ -2403,11 +2466,14 @@ __global__ void pack_ffnet_all(PackAllArgs a) {
       else if (i < 672) a.bf[i - 160] = a.p[7][i - 160];
       break;
     }
-    default: {  // head bias
+    case 12: {  // head bias
       const int i = (int)idx;
       if (i < 32) a.bh[i] = i < a.A ? a.p[11][i] : (i == 31 ? a.p[9][0] : 0.f);
       break;
     }
+    case 13: if (idx < 64 * 512) permute_weight_at(kPermConv2, (int)idx, a.p[2], a.w2p); break;
+    case 14: if (idx < 64 * 576) permute_weight_at(kPermConv3, (int)idx, a.p[4], a.w3p); break;
+    default: if (idx < 512 * 3136) permute_weight_at(kPermFc, (int)idx, a.p[6], a.wfcp); break;
   }
 }
 
@@ -2518,6 +2584,7 @@ extern "C" int rela_ffnet_debug_pipe_timeout(rela_ffnet* n, unsigned* out) {
 
 extern "C" int rela_ffnet_num_action(const rela_ffnet* n) { return n ? n->num_action : 0; }
 namespace rela_amd {
+int ffnet_load_impl(rela_ffnet* n, const rela_ffnet_params* p, int on_device, void* stream_, const FFNetExtraPacks& extra);
 void ffnet_label_as_learner(rela_ffnet* n) { n->prof_names = kProfLearner; }
 void ffnet_set_max_rows(rela_ffnet* n, int rows) { n->max_rows = rows; }
 }  // namespace rela_amd
@@ -2537,6 +2604,14 @@ extern "C" int64_t rela_ffnet_workspace_bytes(const rela_ffnet* n, int batch) {
 }
 
 extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on_device, void* stream_) {
+  return rela_amd::ffnet_load_impl(n, p, on_device, stream_, rela_amd::FFNetExtraPacks{});
+}
+int rela_amd::ffnet_load_extra(rela_ffnet* n, const rela_ffnet_params* p, void* stream_, const FFNetExtraPacks& extra) {
+  return ffnet_load_impl(n, p, 1, stream_, extra);
+}
+
+int rela_amd::ffnet_load_impl(rela_ffnet* n, const rela_ffnet_params* p, int on_device, void* stream_,
+                              const FFNetExtraPacks& extra) {
   RELA_CHECK(n && p, RELA_EINVAL, "rela_ffnet_load: bad arguments");
   hipStream_t s = (hipStream_t)stream_;
   DeviceGuard g(n->device);
@@ -2572,19 +2647,21 @@ extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on
     a.Bff = reinterpret_cast<uint16_t*>(n->d.Bff);
     a.B2 = n->d.B2, a.B3 = n->d.B3, a.Bf = n->d.Bf, a.BfT = n->d.BfT, a.Bh = n->d.Bh, a.Bhp = n->d.Bhp;
     a.b1 = n->d.b1, a.b2 = n->d.b2, a.b3 = n->d.b3, a.bf = n->d.bf, a.bh = n->d.bh, a.A = A;
-    const int64_t elems[13] = {2 * 8 * 64 * 8, 2 * 8 * 64 * 8, 4 * 128 * 64, 4 * 144 * 64, (int64_t)32 * 784 * 64,
+    a.w2p = extra.w2p, a.w3p = extra.w3p, a.wfcp = extra.wfcp;
+    const int64_t elems[16] = {2 * 8 * 64 * 8, 2 * 8 * 64 * 8, 4 * 128 * 64, 4 * 144 * 64, (int64_t)32 * 784 * 64,
                                (int64_t)3136 * 512, 2 * 128 * 64, 2 * 4 * 32 * 64,
                                (int64_t)Conv2F::CT * Conv2F::KS * 64 * 8, (int64_t)Conv3F::CT * Conv3F::KS * 64 * 8,
-                               (int64_t)32 * FcFast::KS * 64 * 8, 672, 32};
+                               (int64_t)32 * FcFast::KS * 64 * 8, 672, 32,
+                               extra.w2p ? 64 * 512 : 0, extra.w3p ? 64 * 576 : 0, extra.wfcp ? (int64_t)512 * 3136 : 0};
     // a net whose owner never runs large batches (a learner re-packs after every step) skips the two fc layouts
     // only large batches read: Bf (f32 fragments, N >= kFcSplitBelow) and Bff (bf16 fragments, N >= kFastMinN)
-    int64_t el[13];
-    for (int jn = 0; jn < 13; ++jn) el[jn] = elems[jn];
+    int64_t el[16];
+    for (int jn = 0; jn < 16; ++jn) el[jn] = elems[jn];
     if (n->max_rows > 0 && n->max_rows < kFcSplitBelow) el[4] = 0;
     if (n->max_rows > 0 && n->max_rows < kFastTrunkMinN) el[10] = 0;  // (the split-K fc_bf16s serves 128 rows and up)
     a.first[0] = 0;
-    for (int jn = 0; jn < 13; ++jn) a.first[jn + 1] = a.first[jn] + (int)ceil_div(el[jn], 256);
-    hipLaunchKernelGGL(pack_ffnet_all, dim3(a.first[13]), dim3(256), 0, s, a);
+    for (int jn = 0; jn < 16; ++jn) a.first[jn + 1] = a.first[jn] + (int)ceil_div(el[jn], 256);
+    hipLaunchKernelGGL(pack_ffnet_all, dim3(a.first[16]), dim3(256), 0, s, a);
   }
   RELA_LAUNCH_CHECK();
   if (tmp) {
@@ -2757,6 +2834,138 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
   RELA_LAUNCH_CHECK();
   return RELA_OK;
 }
+
+// ---- the Ape-X learner's three forwards in split-bf16, one launch per layer (csrc/learner.hip) ----------------
+namespace rela_amd {
+namespace {
+// split records -> f32, in place, for the rows the backward kernels read: a1 [rows][400] records of 32 channels
+// (64 B hi | 64 B lo), a2 [rows][81] and a3 [rows][49] records of 64 channels (128 B hi | 128 B lo).  A record is read
+// whole by the lanes that then overwrite it (one wave per 64-channel record, half a wave per 32-channel one).
+__global__ void unsplit_trunk_rows(uint8_t* __restrict__ a1, uint8_t* __restrict__ a2, uint8_t* __restrict__ a3, int rows,
+                                   int blocks1, int blocks2) {
+  int b = blockIdx.x;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (b < blocks1) {  // 8 records of 32 channels per 256-thread block
+    const int64_t p = (int64_t)b * 8 + w * 2 + (lane >> 5);
+    const int c = lane & 31;
+    const bool ok = p < (int64_t)rows * 400;
+    uint8_t* r = a1 + (ok ? p : 0) * 128;
+    const uint16_t hi = reinterpret_cast<const uint16_t*>(r)[c], lo = reinterpret_cast<const uint16_t*>(r)[32 + c];
+    const float v = bf16_to_f32(hi) + bf16_to_f32(lo);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ok) reinterpret_cast<float*>(r)[c] = v;
+    return;
+  }
+  b -= blocks1;
+  uint8_t* base = a2;
+  int64_t pixels = (int64_t)rows * 81;
+  if (b >= blocks2) b -= blocks2, base = a3, pixels = (int64_t)rows * 49;
+  const int64_t p = (int64_t)b * 4 + w;
+  if (p >= pixels) return;
+  uint8_t* r = base + p * 256;
+  const uint16_t hi = reinterpret_cast<const uint16_t*>(r)[lane], lo = reinterpret_cast<const uint16_t*>(r)[64 + lane];
+  const float v = bf16_to_f32(hi) + bf16_to_f32(lo);
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  reinterpret_cast<float*>(r)[lane] = v;
+}
+}  // namespace
+
+bool ffnet_learner_forward_ok(const rela_ffnet* on, const rela_ffnet* tg, int B) {
+  static const int off = getenv("RELA_LEARNER_MERGED_FWD") ? !atoi(getenv("RELA_LEARNER_MERGED_FWD")) : 0;
+  const auto packs_bf16_fc = [](const rela_ffnet* n) { return !(n->max_rows > 0 && n->max_rows < kFastTrunkMinN); };
+  return !off && on && tg && on->loaded && tg->loaded && B >= kFastTrunkMinN && 2 * B < kFcSplitBelow && packs_bf16_fc(on) &&
+         packs_bf16_fc(tg);
+}
+
+// online over [s ; s'] (2 B rows: rows < B are s) and target over s' (B rows): conv1 -> conv2 of both nets in ONE
+// launch (block ranges in proportion to the rows), conv3 likewise, fc as split-K launches of fc_bf16s straight from
+// a3's records, the dueling heads per Q table.  ws_on has the ffnet_ws layout for 2 B rows, ws_tg for B rows; a1 (rows
+// < B only), a2 and a3 hold split RECORDS: ffnet_learner_unsplit turns the rows < B into f32 for the backward pass.
+int ffnet_learner_forward(const rela_ffnet* on, const rela_ffnet* tg, int B, const uint8_t* s_obs, const uint8_t* s_next,
+                          const float* legal, const float* nlegal, float* q_on, float* q_no, float* q_nt, void* ws_on,
+                          void* ws_tg, int64_t ws_bytes, hipStream_t s) {
+  RELA_CHECK(ffnet_learner_forward_ok(on, tg, B), RELA_ESTATE, "ffnet_learner_forward: nets not loaded / batch %d unsupported", B);
+  RELA_CHECK(ws_bytes >= rela_ffnet_workspace_bytes(on, 2 * B), RELA_EINVAL, "ffnet_learner_forward: workspace too small");
+  RELA_CHECK(((uintptr_t)s_obs & 15) == 0 && ((uintptr_t)s_next & 15) == 0, RELA_EINVAL, "ffnet_learner_forward: frames must be 16-byte aligned");
+  const FFNetWs w = ffnet_ws(ws_on, 2 * B), wt = ffnet_ws(ws_tg, B);
+  TrunkJobs jobs{};
+  jobs.n = 2;
+  const int total = std::min(kNumCU, 3 * B);
+  const int nb0 = std::max(1, std::min(total - 1, (int)((int64_t)total * 2 / 3)));
+  TrunkJob& j0 = jobs.j[0];
+  j0.in0 = s_obs, j0.in1 = s_next, j0.n_in0 = B;
+  j0.B1 = (const uint4*)on->d.B1p, j0.B2 = (const uint4*)on->d.B2f, j0.B3 = (const uint4*)on->d.B3f;
+  j0.b1 = on->d.b1, j0.b2 = on->d.b2, j0.b3 = on->d.b3;
+  j0.a1_out = reinterpret_cast<uint8_t*>(w.a1), j0.n_a1 = B;
+  j0.a2 = reinterpret_cast<uint8_t*>(w.a2), j0.a3 = reinterpret_cast<uint8_t*>(w.a3);
+  j0.N = 2 * B, j0.block0 = 0, j0.nblocks = nb0;
+  TrunkJob& j1 = jobs.j[1];
+  j1.in0 = s_next, j1.in1 = s_next, j1.n_in0 = B;
+  j1.B1 = (const uint4*)tg->d.B1p, j1.B2 = (const uint4*)tg->d.B2f, j1.B3 = (const uint4*)tg->d.B3f;
+  j1.b1 = tg->d.b1, j1.b2 = tg->d.b2, j1.b3 = tg->d.b3;
+  j1.a1_out = nullptr, j1.n_a1 = 0;
+  j1.a2 = reinterpret_cast<uint8_t*>(wt.a2), j1.a3 = reinterpret_cast<uint8_t*>(wt.a3);
+  j1.N = B, j1.block0 = nb0, j1.nblocks = total - nb0;
+  {
+    ProfScope prof("learner_fwd_conv12", s);
+    note_launch("conv12_bf16s_jobs");
+    hipLaunchKernelGGL(conv12_bf16s_jobs, dim3(total), dim3(kThreads), Conv12::LDS_TOTAL, s, jobs);
+  }
+  {
+    // conv3 walks groups of Conv3F::S frames: the same block ranges serve (a job never has more blocks than groups
+    // would keep busy only below 2 * 256 frames per job, where the surplus blocks leave at once)
+    ProfScope prof("learner_fwd_conv3", s);
+    note_launch("conv3_bf16s_jobs");
+    hipLaunchKernelGGL(conv3_bf16s_jobs, dim3(total), dim3(kThreads), Conv3F::LDS_TOTAL, s, jobs);
+  }
+  auto fc = [&](const rela_ffnet* n, const FFNetWs& ww, int N, void* wsp) {
+    const int rb = ceil_div(N, FcFast::BM);
+    int slices = std::max(1, std::min(FcFast::NPOS, kNumCU / (4 * rb)));
+    slices = std::min(slices, 8192 / N);
+    const int per = ceil_div(FcFast::NPOS, slices);
+    slices = ceil_div(FcFast::NPOS, per);
+    float* part = ww.ha + kHA * N;
+    part += (64 - ((part - static_cast<float*>(wsp)) & 63)) & 63;
+    {
+      ProfScope prof("learner_fwd_fc", s);
+      note_launch("fc_bf16s (split-K)");
+      hipLaunchKernelGGL((fc_bf16s<FcFast, true>), dim3(4, rb, slices), dim3(kThreads), FcFast::LDS_BYTES, s,
+                         (const uint8_t*)ww.a3, (const uint4*)n->d.Bff, (const float*)n->d.bf, part, N, per);
+    }
+    note_launch("fc_reduce");
+    hipLaunchKernelGGL(fc_reduce, dim3(ceil_div(N * 128, 256)), dim3(256), 0, s, (const float*)part, slices, N,
+                       (const float*)n->d.bf, ww.h);
+  };
+  fc(on, w, 2 * B, ws_on);
+  fc(tg, wt, B, ws_tg);
+  {
+    ProfScope prof("learner_fwd_heads", s);
+    const int A = on->num_action;
+    note_launch("heads_duel");
+    hipLaunchKernelGGL(heads_duel, dim3(ceil_div(B, kHeadRows)), dim3(256), 0, s, (const float*)w.h, (const float*)on->d.Bhp,
+                       (const float*)on->d.bh, legal, w.ha, q_on, B, A);
+    hipLaunchKernelGGL(heads_duel, dim3(ceil_div(B, kHeadRows)), dim3(256), 0, s, (const float*)(w.h + (size_t)B * kH),
+                       (const float*)on->d.Bhp, (const float*)on->d.bh, nlegal, w.ha + (size_t)B * kHA, q_no, B, A);
+    hipLaunchKernelGGL(heads_duel, dim3(ceil_div(B, kHeadRows)), dim3(256), 0, s, (const float*)wt.h, (const float*)tg->d.Bhp,
+                       (const float*)tg->d.bh, nlegal, wt.ha, q_nt, B, A);
+  }
+  RELA_LAUNCH_CHECK();
+  return RELA_OK;
+}
+
+int ffnet_learner_unsplit(int B, void* ws_on, hipStream_t s) {
+  const FFNetWs w = ffnet_ws(ws_on, 2 * B);
+  const int b1 = (int)ceil_div((int64_t)B * 400, 8), b2 = (int)ceil_div((int64_t)B * 81, 4), b3 = (int)ceil_div((int64_t)B * 49, 4);
+  ProfScope prof("learner_unsplit", s);
+  note_launch("unsplit_trunk_rows");
+  hipLaunchKernelGGL(unsplit_trunk_rows, dim3(b1 + b2 + b3), dim3(256), 0, s, reinterpret_cast<uint8_t*>(w.a1),
+                     reinterpret_cast<uint8_t*>(w.a2), reinterpret_cast<uint8_t*>(w.a3), B, b1, b2);
+  RELA_LAUNCH_CHECK();
+  return RELA_OK;
+}
+}  // namespace rela_amd
 
 // =====================================================================================
 // AtariLSTMNet (pyrela/net.py:58-163): trunk -> LSTM gates + cell (one fused GEMM) -> heads

@@ -31,8 +31,33 @@ inline FFNetWs ffnet_ws(void* ws, int N) {
 
 }  // namespace rela_amd
 
-struct rela_ffnet;
 namespace rela_amd {
+// weight copies in the k order the learner's dgrad GEMMs read (one element per call):
+//   conv2: dst[oc][(kh*4+kw)*32+c], conv3: dst[oc][(kh*3+kw)*64+c], fc: dst[u][pos*64+c] <- src[u][c*49+pos]
+enum { kPermConv2 = 0, kPermConv3 = 1, kPermFc = 2 };
+__device__ __forceinline__ void permute_weight_at(int mode, int idx, const float* __restrict__ src, float* __restrict__ dst) {
+  if (mode == kPermConv2) {
+    const int oc = idx >> 9, n = idx & 511, c = n & 31, r = n >> 5;
+    dst[idx] = src[((oc * 32 + c) * 4 + (r >> 2)) * 4 + (r & 3)];
+  } else if (mode == kPermConv3) {
+    const int oc = idx / 576, n = idx - oc * 576, c = n & 63, r = n >> 6;
+    dst[idx] = src[((oc * 64 + c) * 3 + r / 3) * 3 + r % 3];
+  } else {
+    const int u = idx / 3136, n = idx - u * 3136, c = n & 63, pos = n >> 6;
+    dst[idx] = src[(size_t)u * 3136 + c * 49 + pos];
+  }
+}
+// the three copies above, made by the SAME launch that re-packs the net's own layouts (a learner re-packs after
+// every optimiser step: three more launches otherwise); any pointer may be NULL
+struct FFNetExtraPacks {
+  float *w2p = nullptr, *w3p = nullptr, *wfcp = nullptr;
+};
+}  // namespace rela_amd
+
+#include "../../include/rela_amd.h"
+namespace rela_amd {
+// rela_ffnet_load from device pointers + the learner's dgrad operand copies in the same launch
+int ffnet_load_extra(rela_ffnet* n, const rela_ffnet_params* p, void* stream, const FFNetExtraPacks& extra);
 // per-kernel timing labels "learner_fwd_*" instead of the actor-side names (prof.h)
 void ffnet_label_as_learner(rela_ffnet* n);
 // the owner never runs more than `rows` rows through this net: rela_ffnet_load skips the layouts only larger batches read
@@ -41,6 +66,14 @@ void ffnet_set_max_rows(rela_ffnet* n, int rows);
 // 0 = exact f32 whatever the net says -- the learner's pass that keeps a1 / a2 / a3 / h for the backward kernels
 int ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_dev, const float* legal_dev, float* q_dev, void* ws,
                        int64_t ws_bytes, void* stream, int mode);
+// The Ape-X learner's three forwards of td_err (apex.py:30-45) in split-bf16 with one launch per layer: online over
+// [s ; s'] (2 B rows) and target over s' (B rows).  ws_on: ffnet_ws layout for 2 B rows, ws_tg for B rows; a1 (rows < B),
+// a2, a3 come out as split records; ffnet_learner_unsplit turns the rows < B into f32 in place for the backward pass.
+bool ffnet_learner_forward_ok(const rela_ffnet* on, const rela_ffnet* tg, int B);
+int ffnet_learner_forward(const rela_ffnet* on, const rela_ffnet* tg, int B, const uint8_t* s_obs, const uint8_t* s_next,
+                          const float* legal, const float* nlegal, float* q_on, float* q_no, float* q_nt, void* ws_on,
+                          void* ws_tg, int64_t ws_bytes, hipStream_t s);
+int ffnet_learner_unsplit(int B, void* ws_on, hipStream_t s);
 }  // namespace rela_amd
 
 struct rela_lstmnet;

@@ -53,7 +53,8 @@ struct rela_apex_learner {
   float* loss = nullptr;
   bool loaded = false;
   // batch of the last rela_apex_learner_loss, until rela_apex_learner_grad consumes it
-  int pend_B = 0;
+  int pend_B = 0, last_B = 0;
+  int pend_rows = 0;  // rows of the ffnet_ws layout the last forward used for ws_on (B, or 2 B for the merged forward)
   const uint8_t* pend_obs = nullptr;
 };
 
@@ -68,15 +69,10 @@ rela_ffnet_params params_at(const rela_apex_learner* l, float* base) {
 int repack(rela_apex_learner* l, bool online, bool target, hipStream_t s) {
   if (online) {
     const rela_ffnet_params p = params_at(l, l->P);
-    int rc = rela_ffnet_load(l->online, &p, 1, s);
+    FFNetExtraPacks extra;  // the dgrad operand copies ride along in the re-pack launch
+    extra.w2p = l->w2p, extra.w3p = l->w3p, extra.wfcp = l->wfcp;
+    int rc = ffnet_load_extra(l->online, &p, s, extra);
     if (rc != RELA_OK) return rc;
-    hipLaunchKernelGGL(permute_weights, dim3(ceil_div(64 * 512, 256)), dim3(256), 0, s, kPermConv2, p.conv2_w, l->w2p,
-                       64 * 512);
-    hipLaunchKernelGGL(permute_weights, dim3(ceil_div(64 * 576, 256)), dim3(256), 0, s, kPermConv3, p.conv3_w, l->w3p,
-                       64 * 576);
-    hipLaunchKernelGGL(permute_weights, dim3(ceil_div(512 * 3136, 256)), dim3(256), 0, s, kPermFc, p.fc_w, l->wfcp,
-                       512 * 3136);
-    RELA_LAUNCH_CHECK();
   }
   if (target) {
     const rela_ffnet_params p = params_at(l, l->PT);
@@ -136,7 +132,8 @@ extern "C" int rela_apex_learner_create(rela_apex_learner** out, int num_action,
   RELA_HIP(hipMalloc(&l->w2p, sizeof(float) * 64 * 512));
   RELA_HIP(hipMalloc(&l->w3p, sizeof(float) * 64 * 576));
   RELA_HIP(hipMalloc(&l->wfcp, sizeof(float) * 512 * 3136));
-  l->ws_bytes = rela_ffnet_workspace_bytes(nullptr, max_batch);
+  // (the merged split-bf16 forward runs the online net over 2 x batch rows: [s ; s'])
+  l->ws_bytes = std::max(rela_ffnet_workspace_bytes(nullptr, max_batch), rela_ffnet_workspace_bytes(nullptr, 2 * max_batch));
   RELA_HIP(hipMalloc(&l->ws_on, (size_t)l->ws_bytes));
   RELA_HIP(hipMalloc(&l->ws_tmp, (size_t)l->ws_bytes));
   RELA_HIP(hipMalloc(&l->q, sizeof(float) * 3 * B * A));
@@ -235,6 +232,18 @@ extern "C" int rela_apex_learner_flat(rela_apex_learner* l, float** params_dev, 
 
 extern "C" const float* rela_apex_learner_stats_dev(const rela_apex_learner* l) { return l ? l->norm : nullptr; }
 
+extern "C" int rela_apex_learner_debug_activations(rela_apex_learner* l, float** a1, float** a2, float** a3, float** h,
+                                                   int* batch) {
+  RELA_CHECK(l && l->last_B > 0, RELA_ESTATE, "rela_apex_learner_debug_activations: no rela_apex_learner_loss yet");
+  const FFNetWs w = ffnet_ws(l->ws_on, l->pend_rows);
+  if (a1) *a1 = w.a1;
+  if (a2) *a2 = w.a2;
+  if (a3) *a3 = w.a3;
+  if (h) *h = w.h;
+  if (batch) *batch = l->last_B;
+  return RELA_OK;
+}
+
 extern "C" int rela_apex_learner_backward(rela_apex_learner* l, int batch, const void* const* rows_dev,
                                           const float* weight_dev, float* priority_dev, float* loss_dev,
                                           void* stream_) {
@@ -270,12 +279,25 @@ extern "C" int rela_apex_learner_loss(rela_apex_learner* l, int batch, const voi
   float* q_no = l->q + (size_t)Bn * A;
   float* q_nt = l->q + 2 * (size_t)Bn * A;
   // td_err (apex.py:30-45): greedy_act(next_obs) and target_net(next_obs) carry no gradient
-  int rc = rela_ffnet_forward(l->online, Bn, nobs, nlegal, q_no, l->ws_tmp, l->ws_bytes, s);
-  if (rc != RELA_OK) return rc;
-  rc = rela_ffnet_forward(l->target, Bn, nobs, nlegal, q_nt, l->ws_tmp, l->ws_bytes, s);
-  if (rc != RELA_OK) return rc;
-  rc = ffnet_forward_mode(l->online, Bn, obs, legal, q_on, l->ws_on, l->ws_bytes, s, 0);  // f32: the backward reads a1..h
-  if (rc != RELA_OK) return rc;
+  int rc;
+  l->pend_rows = Bn;
+  if (rela_ffnet_precision(l->online) == 1 && ffnet_learner_forward_ok(l->online, l->target, Bn)) {
+    // bf16x2: all three forwards on split-bf16 MFMA, one launch per layer (online over [s ; s'], target over s'); the
+    // backward then reads the activations -- and the ReLU masks -- of THIS forward (turned back into f32 below)
+    rc = ffnet_learner_forward(l->online, l->target, Bn, obs, nobs, legal, nlegal, q_on, q_no, q_nt, l->ws_on, l->ws_tmp,
+                               l->ws_bytes, s);
+    if (rc != RELA_OK) return rc;
+    rc = ffnet_learner_unsplit(Bn, l->ws_on, s);
+    if (rc != RELA_OK) return rc;
+    l->pend_rows = 2 * Bn;  // the workspace layout the backward must address
+  } else {
+    rc = rela_ffnet_forward(l->online, Bn, nobs, nlegal, q_no, l->ws_tmp, l->ws_bytes, s);
+    if (rc != RELA_OK) return rc;
+    rc = rela_ffnet_forward(l->target, Bn, nobs, nlegal, q_nt, l->ws_tmp, l->ws_bytes, s);
+    if (rc != RELA_OK) return rc;
+    rc = ffnet_forward_mode(l->online, Bn, obs, legal, q_on, l->ws_on, l->ws_bytes, s, 0);  // f32: the backward reads a1..h
+    if (rc != RELA_OK) return rc;
+  }
   rc = rela_apex_td_from_q(Bn, A, 0, q_on, q_no, q_nt, nlegal, act, reward, boot, l->gamma_n, l->td, priority_dev, s);
   if (rc != RELA_OK) return rc;
   {
@@ -285,7 +307,7 @@ extern "C" int rela_apex_learner_loss(rela_apex_learner* l, int batch, const voi
   }
   if (loss_dev) RELA_HIP(hipMemcpyAsync(loss_dev, l->loss, sizeof(float), hipMemcpyDeviceToDevice, s));
   RELA_LAUNCH_CHECK();
-  l->pend_B = Bn;
+  l->pend_B = l->last_B = Bn;
   l->pend_obs = obs;
   return RELA_OK;
 }
@@ -299,7 +321,7 @@ extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
   const uint8_t* obs = l->pend_obs;
   l->pend_B = 0;
 
-  const FFNetWs w = ffnet_ws(l->ws_on, Bn);
+  const FFNetWs w = ffnet_ws(l->ws_on, l->pend_rows);
   const rela_ffnet_params P = params_at(l, l->P);
   float* Gm[12];  // gradient tensors in rela_ffnet_params order
   for (int i = 0; i < 12; ++i) Gm[i] = l->G + l->off[i];

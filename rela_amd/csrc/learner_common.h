@@ -366,21 +366,10 @@ __global__ __launch_bounds__(kLT) void learner_loss_grad(const float* __restrict
   if (threadIdx.x == 0) loss_out[0] = red[0] * inv_b;
 }
 
-// ---- weight copies in the k order the dgrad GEMMs read ----------------------------------------
-enum { kPermConv2 = 0, kPermConv3 = 1, kPermFc = 2 };
+// ---- weight copies in the k order the dgrad GEMMs read (ffnet_layout.h: permute_weight_at) ------
 __global__ void permute_weights(int mode, const float* __restrict__ src, float* __restrict__ dst, int total) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  if (mode == kPermConv2) {  // dst[oc][(kh*4+kw)*32+c]
-    const int oc = idx >> 9, n = idx & 511, c = n & 31, r = n >> 5;
-    dst[idx] = src[((oc * 32 + c) * 4 + (r >> 2)) * 4 + (r & 3)];
-  } else if (mode == kPermConv3) {  // dst[oc][(kh*3+kw)*64+c]
-    const int oc = idx / 576, n = idx - oc * 576, c = n & 63, r = n >> 6;
-    dst[idx] = src[((oc * 64 + c) * 3 + r / 3) * 3 + r % 3];
-  } else {  // dst[u][pos*64+c] <- src[u][c*49+pos]
-    const int u = idx / 3136, n = idx - u * 3136, c = n & 63, pos = n >> 6;
-    dst[idx] = src[(size_t)u * 3136 + c * 49 + pos];
-  }
+  if (idx < total) permute_weight_at(mode, idx, src, dst);
 }
 
 // ---- clip_grad_norm_ + optimiser over the flat buffers ----------------------------------------

@@ -165,6 +165,18 @@ class HipApexLearner:
 
         return dev_view(self._capi.lib.rela_apex_learner_stats_dev(self.h), (2,), torch.float32, self.device)
 
+    def debug_activations(self):
+        """f32 views of online(obs)'s activations the last loss() left for the backward pass (channel-last):
+        a1 [B,400,32], a2 [B,81,64], a3 [B,49,64], h [B,512]; their > 0 pattern is the ReLU mask of the gradients."""
+        from .engine import dev_view
+
+        C, capi = self._C, self._capi
+        p = [C.c_void_p() for _ in range(4)]
+        b = C.c_int()
+        capi.check(capi.lib.rela_apex_learner_debug_activations(self.h, *[C.byref(x) for x in p], C.byref(b)), "debug_activations")
+        shapes = [(b.value, 400, 32), (b.value, 81, 64), (b.value, 49, 64), (b.value, 512)]
+        return [dev_view(x.value, sh, torch.float32, self.device) for x, sh in zip(p, shapes)]
+
     def backward(self, batch, weight):
         """batch: the namespace FFReplay.sample returns (or any object with obs / next_obs / action /
         reward / terminal / bootstrap of cuda tensors); weight: cuda f32[B].  -> (loss[1], priority[B])."""

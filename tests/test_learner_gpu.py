@@ -81,26 +81,42 @@ def test_loss_priority_and_gradients_match_autograd(B, A):
     learner.close()
 
 
+MERGED_MIN_B, MERGED_MAX_B = 128, 1023  # batches the merged split-bf16 forward serves (csrc/ffnet.hip)
+
+
 def _assert_fast_learner_kernels(counts, B):
-    """The kernels a bf16x2 learner step of B rows must launch (csrc/learner.hip, learner_common.h): from 128 rows the
-    two gradient-free forwards' conv trunks, at every size conv1's weight gradient and the conv2 / conv3 data
+    """The kernels a bf16x2 learner step of B rows must launch (csrc/learner.hip, ffnet.hip, learner_common.h): from
+    128 rows the three forwards of td_err as ONE split-bf16 launch per layer (conv12_bf16s_jobs, conv3_bf16s_jobs,
+    fc_bf16s split-K) and no f32 trunk kernel at all; at every size conv1's weight gradient and the conv2 / conv3 data
     gradients on bf16 MFMA -- so a silent fall-back to the f32 kernels cannot pass for a test of the fast ones."""
     want = {"wgrad_conv1_bf16", "dgrad_conv2_bf16", "dgrad_conv3_bf16"}
-    if B >= 128:
-        want |= {"conv12_bf16s", "conv_bf16s<Conv3F>"}
+    if MERGED_MIN_B <= B <= MERGED_MAX_B:
+        want |= {"conv12_bf16s_jobs", "conv3_bf16s_jobs", "fc_bf16s (split-K)", "unsplit_trunk_rows"}
     assert want <= set(counts), "B=%d: launched %s, expected %s" % (B, sorted(counts), sorted(want))
-    if B >= 128:
-        assert counts["conv12_bf16s"] == 2 and counts["conv1_bf16x3"] == 1  # td_err's two forwards; online(obs) in f32
+    if MERGED_MIN_B <= B <= MERGED_MAX_B:
+        assert not ({"conv1_bf16x3", "conv_mfma<Conv2> (f32)", "conv_mfma<Conv3> (f32)"} & set(counts)), sorted(counts)
+        assert counts["conv12_bf16s_jobs"] == 1 and counts["fc_bf16s (split-K)"] == 2
+
+
+def _relu_pattern_disagreement(a, b):
+    """fraction of units whose ReLU state differs between two sets of activations [a1, a2, a3, h]"""
+    diff = sum(int(((x > 0) != (y > 0)).sum()) for x, y in zip(a, b))
+    return diff / float(sum(x.numel() for x in a))
 
 
 @pytest.mark.parametrize("B", [512, 200, 64])
 def test_learner_fast_mode_within_stated_tolerance(B):
-    """set_precision("bf16x2"): the two gradient-free forwards of td_err (online and target net on next_obs) run their
-    conv trunk on split-bf16 MFMA (fc in f32 below 1,024 rows; below 128 rows everything stays f32), conv1's weight
-    gradient (csrc/wgrad_conv1_bf16.h: 2 frames per block at B = 512, one at 200 and 64) and the conv2 / conv3 data
-    gradients (csrc/dgrad_conv_bf16.h) run on bf16 MFMA; the online(obs) pass, whose activations and ReLU masks feed
-    the backward, stays f32.  Loss, priorities and every gradient tensor stay within the fast mode's stated tolerance
-    of the all-f32 step (|dQ| < 2e-6 moves a TD error by at most that)."""
+    """set_precision("bf16x2") against the all-f32 step on the same batch.  From 128 rows ALL THREE forwards of td_err
+    run on split-bf16 MFMA (r3: online over [s ; s'] and target over s', one launch per layer), so the backward pass
+    reads the activations and ReLU pattern of a forward whose pre-activations differ from the f32 ones by ~2^-16
+    relative: loss and priorities stay within 5e-6, and the ReLU patterns agree on all but a few units in 10^5
+    (asserted: < 1e-4) -- units whose pre-activation is within that error of zero, where the gradient of the network is
+    discontinuous anyway.  Each flipped unit moves its layer's weight gradient by one term of a random-sign sum, so the
+    gradient TENSORS agree to ~5e-3 of their norm (asserted: relative L2 error < 2e-2, cosine > 0.9998), while the
+    gradients are exact for the forward they belong to
+    (test_fast_mode_gradients_match_autograd_on_the_forwards_own_relu_pattern: 2e-3 of the largest entry, the f32
+    mode's own bound).  Below 128 rows only the gradient kernels are bf16 (conv1's weight gradient, conv2 / conv3 data
+    gradients) and the gradients stay within 1e-4 of the f32 step's."""
     import torch
 
     from rela_amd.learner import HipApexLearner
@@ -112,6 +128,7 @@ def test_learner_fast_mode_within_stated_tolerance(B):
     loss0, prio0 = learner.backward(batch, w)
     loss0, prio0 = loss0.clone(), prio0.clone()
     g0 = {k: v.clone() for k, v in learner.state_dict("grads").items()}
+    act0 = [t.clone() for t in learner.debug_activations()]
     learner.set_precision("bf16x2")
     from rela_amd import _capi as capi
 
@@ -121,12 +138,80 @@ def test_learner_fast_mode_within_stated_tolerance(B):
     _assert_fast_learner_kernels(census.counts, B)
     assert float((prio1 - prio0).abs().max()) < 5e-6
     assert abs(float(loss1) - float(loss0)) < 5e-6 * max(1.0, abs(float(loss0)))
+    merged = MERGED_MIN_B <= B <= MERGED_MAX_B
+    flips = _relu_pattern_disagreement(act0, learner.debug_activations())
+    print("B=%d: ReLU pattern disagreement bf16x2 vs f32 forward: %.3g" % (B, flips))
+    assert flips < 1e-4 if merged else flips == 0.0
     for key in HipApexLearner.KEYS:
-        scale = float(g0[key].abs().max()) + 1e-12
-        assert float((g1[key] - g0[key]).abs().max()) <= 1e-4 * scale, key  # d(Huber) can flip at |err| = 1 only
+        if merged:
+            d, n0 = float((g1[key] - g0[key]).norm()), float(g0[key].norm()) + 1e-20
+            cos = float((g1[key] * g0[key]).sum()) / (float(g1[key].norm()) * n0 + 1e-30)
+            assert d <= 2e-2 * n0 and cos > 0.9998, (key, d / n0, cos)
+        else:
+            scale = float(g0[key].abs().max()) + 1e-12
+            assert float((g1[key] - g0[key]).abs().max()) <= 1e-4 * scale, key  # d(Huber) can flip at |err| = 1 only
     learner.set_precision("f32")
     loss2, prio2 = learner.backward(batch, w)
     assert torch.equal(prio2, prio0) and torch.equal(loss2, loss0)  # the parity mode is untouched by the switch
+    learner.close()
+
+
+@pytest.mark.parametrize("B", [512, 200])
+def test_fast_mode_gradients_match_autograd_on_the_forwards_own_relu_pattern(B):
+    """The bf16x2 step's gradients against PyTorch autograd of the SAME network with the ReLUs replaced by the 0/1
+    pattern the HIP forward actually produced (rela_apex_learner_debug_activations): where a pre-activation sits
+    within rounding of zero the two forwards may disagree about a unit, and the gradient of the network is
+    discontinuous there -- with the pattern fixed the comparison is as tight as the f32 mode's own bound against
+    autograd (2e-3 of each tensor's largest entry; RTOL / ATOL above)."""
+    import torch
+    import torch.nn.functional as F
+
+    from rela_amd.learner import HipApexLearner
+
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    A = 18
+    agent = make_agent(A, 13)
+    batch, w = make_batch(B, A, 31)
+    learner = HipApexLearner.from_agent(agent, B)
+    learner.set_precision("bf16x2")
+    loss, prio = learner.backward(batch, w)
+    a1, a2, a3, h = learner.debug_activations()
+    m1 = (a1 > 0).float().reshape(B, 20, 20, 32).permute(0, 3, 1, 2)
+    m2 = (a2 > 0).float().reshape(B, 9, 9, 64).permute(0, 3, 1, 2)
+    m3 = (a3 > 0).float().reshape(B, 7, 7, 64).permute(0, 3, 1, 2)
+    mh = (h > 0).float()
+    net = agent.online_net
+    p = dict(net.named_parameters())
+
+    def q_masked(s, legal):
+        x = s.float() / 255.0
+        x = F.conv2d(x, p["net.0.weight"], p["net.0.bias"], stride=4) * m1
+        x = F.conv2d(x, p["net.2.weight"], p["net.2.bias"], stride=2) * m2
+        x = F.conv2d(x, p["net.4.weight"], p["net.4.bias"], stride=1) * m3
+        hh = F.linear(x.reshape(B, 3136), p["linear.0.weight"], p["linear.0.bias"]) * mh
+        v, a = F.linear(hh, p["fc_v.weight"], p["fc_v.bias"]), F.linear(hh, p["fc_a.weight"], p["fc_a.bias"]) * legal
+        return v + a - a.mean(1, keepdim=True)
+
+    with torch.no_grad():  # td target exactly as apex.py:30-45 (the no-grad forwards through the real ReLUs)
+        nobs = batch.next_obs
+        qn = agent.online_net(nobs)
+        na = ((1 + qn - qn.min()) * nobs["legal_move"]).argmax(1)
+        qt = agent.target_net(nobs).gather(1, na.unsqueeze(1)).squeeze(1)
+        target = batch.reward + batch.bootstrap * (agent.gamma ** agent.multi_step) * qt
+    qa = q_masked(batch.obs["s"], batch.obs["legal_move"]).gather(1, batch.action["a"].unsqueeze(1)).squeeze(1)
+    err = target - qa
+    ref_loss = (F.smooth_l1_loss(err, torch.zeros_like(err), reduction="none") * w).mean()
+    ref_loss.backward()
+    np.testing.assert_allclose(loss.item(), ref_loss.item(), rtol=1e-4, atol=1e-5)
+    grads = learner.state_dict("grads")
+    worst = 0.0
+    for key in HipApexLearner.KEYS:
+        gr, rr = grads[key].cpu().numpy(), p[key].grad.cpu().numpy()
+        scale = float(np.abs(rr).max()) + 1e-12
+        worst = max(worst, float(np.abs(gr - rr).max()) / scale)
+        np.testing.assert_allclose(gr, rr, rtol=RTOL, atol=ATOL + 1e-3 * scale, err_msg=key)
+    print("B=%d: worst |dgrad| / max|grad| against autograd on the forward's own ReLU pattern: %.3g" % (B, worst))
     learner.close()
 
 
@@ -350,7 +435,10 @@ def test_learner_step_matches_the_reference_golden(path, precision):
             np.testing.assert_allclose(t[torch.tensor(rec["idx"])].numpy(), np.array(rec["val"]), rtol=2e-3,
                                        atol=tol_scale * scale, err_msg="%s %s" % (what, key))
 
-    check(learner.state_dict("grads"), g["grads"], 2e-3, "grad")
+    # (bf16x2 from 128 rows: the backward differentiates the split-bf16 forward, whose ReLU pattern differs from the
+    # reference's f32 forward in a few units per 10^5 -- see test_learner_fast_mode_within_stated_tolerance)
+    merged = precision == "bf16x2" and MERGED_MIN_B <= B <= MERGED_MAX_B
+    check(learner.state_dict("grads"), g["grads"], 1e-2 if merged else 2e-3, "grad")
     learner.apply()
     st = learner.stats().cpu().numpy()
     np.testing.assert_allclose(st[0], g["grad_norm"], rtol=1e-3)
