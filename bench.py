@@ -883,6 +883,11 @@ def main():
                        "replay_frame_bytes_per_transition": {None: 56448, "stack": 28224, "plane": 7056}[args.dedup],
                        "parallelism": ("actor-shards%d+replay-partitions+grad-allreduce" % world) if world > 1
                        else "single"},
+            # the communicator the collectives of this run went through (None: single process, no collective)
+            "comm": None if world == 1 else {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size()
+                                             if dist.get_backend() == "nccl" else 0, "ranks": dist.get_world_size(),
+                                             "collectives_per_step": "all-reduce SUM of the flat 6.8 MB gradient buffer; "
+                                                                     "IS weights: SUM of the partition size + MAX of the weight maximum"},
             "grad_steps_per_s": 1e3 / ms_med, "train_samples_per_s": BATCH * 1e3 / ms_med,
             "buffer_add_per_s": adds / dt_total,
             "learner": "hip (csrc/learner.hip)" if hip_learner is not None else "torch autograd",

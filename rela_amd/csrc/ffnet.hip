@@ -2232,14 +2232,14 @@ __global__ void pack_heads_perm(const float* __restrict__ a_w, const float* __re
   pack_heads_perm_at((int)blockIdx.x * blockDim.x + threadIdx.x, a_w, v_w, A, out);
 }
 
-__global__ __launch_bounds__(256) void heads_duel(const float* __restrict__ h, const float* __restrict__ Bhp,
-                                                  const float* __restrict__ bias, const float* __restrict__ legal,
-                                                  float* __restrict__ ha, float* __restrict__ q, int N, int A) {
+__device__ __forceinline__ void heads_duel_body(const float* __restrict__ h, const float* __restrict__ Bhp,
+                                                const float* __restrict__ bias, const float* __restrict__ legal,
+                                                float* __restrict__ ha, float* __restrict__ q, int N, int A, int bid) {
   __shared__ float part[4][kHeadRows][33];
   __shared__ float hs[kHeadRows][33];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
-  const int row0 = blockIdx.x * kHeadRows;
+  const int row0 = bid * kHeadRows;
   float av[32];
   {
     const int row = min(row0 + li, N - 1);
@@ -2277,6 +2277,22 @@ __global__ __launch_bounds__(256) void heads_duel(const float* __restrict__ h, c
   const float mean = sum / (float)A, v = hs[r][31];
   if (c < A) q[(size_t)row * A + c] = (v + hs[r][c] * lg[c]) - mean;
   if (c + 16 < A) q[(size_t)row * A + c + 16] = (v + hs[r][c + 16] * lg[c + 16]) - mean;
+}
+__global__ __launch_bounds__(256) void heads_duel(const float* __restrict__ h, const float* __restrict__ Bhp,
+                                                  const float* __restrict__ bias, const float* __restrict__ legal,
+                                                  float* __restrict__ ha, float* __restrict__ q, int N, int A) {
+  heads_duel_body(h, Bhp, bias, legal, ha, q, N, A, blockIdx.x);
+}
+// up to three head passes in one launch (the learner's three Q tables): segment j owns blocks [first[j], first[j + 1])
+struct HeadJobs {
+  const float *h[3], *Bhp[3], *bias[3], *legal[3];
+  float *ha[3], *q[3];
+  int N[3], first[4];
+};
+__global__ __launch_bounds__(256) void heads_duel_jobs(HeadJobs jb, int A) {
+  int j = 0;
+  while (j < 2 && (int)blockIdx.x >= jb.first[j + 1]) ++j;
+  heads_duel_body(jb.h[j], jb.Bhp[j], jb.bias[j], jb.legal[j], jb.ha[j], jb.q[j], jb.N[j], A, (int)blockIdx.x - jb.first[j]);
 }
 
 // a3 split records -> f32 in place (per pixel: 64 x bf16 hi | 64 x bf16 lo  ->  64 x f32; hi + lo is exact in f32).
@@ -2843,32 +2859,33 @@ namespace {
 // whole by the lanes that then overwrite it (one wave per 64-channel record, half a wave per 32-channel one).
 __global__ void unsplit_trunk_rows(uint8_t* __restrict__ a1, uint8_t* __restrict__ a2, uint8_t* __restrict__ a3, int rows,
                                    int blocks1, int blocks2) {
+  // a thread owns four channels of a record: 8 B of hi + 8 B of lo in, 16 B of f32 out; the 8 (a1) or 16 (a2, a3) lanes
+  // of a record sit in one wave, which reads all its records before it overwrites any
   int b = blockIdx.x;
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (b < blocks1) {  // 8 records of 32 channels per 256-thread block
-    const int64_t p = (int64_t)b * 8 + w * 2 + (lane >> 5);
-    const int c = lane & 31;
-    const bool ok = p < (int64_t)rows * 400;
-    uint8_t* r = a1 + (ok ? p : 0) * 128;
-    const uint16_t hi = reinterpret_cast<const uint16_t*>(r)[c], lo = reinterpret_cast<const uint16_t*>(r)[32 + c];
-    const float v = bf16_to_f32(hi) + bf16_to_f32(lo);
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (ok) reinterpret_cast<float*>(r)[c] = v;
-    return;
+  const int t = threadIdx.x;
+  int64_t rec;
+  int q, C;
+  uint8_t* base;
+  bool ok;
+  if (b < blocks1) {
+    rec = (int64_t)b * 32 + (t >> 3), q = t & 7, C = 32, base = a1, ok = rec < (int64_t)rows * 400;
+  } else {
+    b -= blocks1;
+    base = a2;
+    int64_t pixels = (int64_t)rows * 81;
+    if (b >= blocks2) b -= blocks2, base = a3, pixels = (int64_t)rows * 49;
+    rec = (int64_t)b * 16 + (t >> 4), q = t & 15, C = 64, ok = rec < pixels;
   }
-  b -= blocks1;
-  uint8_t* base = a2;
-  int64_t pixels = (int64_t)rows * 81;
-  if (b >= blocks2) b -= blocks2, base = a3, pixels = (int64_t)rows * 49;
-  const int64_t p = (int64_t)b * 4 + w;
-  if (p >= pixels) return;
-  uint8_t* r = base + p * 256;
-  const uint16_t hi = reinterpret_cast<const uint16_t*>(r)[lane], lo = reinterpret_cast<const uint16_t*>(r)[64 + lane];
-  const float v = bf16_to_f32(hi) + bf16_to_f32(lo);
+  uint8_t* r = base + (ok ? rec : 0) * (C * 4);
+  const uint2 hi = *reinterpret_cast<const uint2*>(r + q * 8), lo = *reinterpret_cast<const uint2*>(r + C * 2 + q * 8);
+  float4 v;
+  v.x = __uint_as_float(hi.x << 16) + __uint_as_float(lo.x << 16);
+  v.y = __uint_as_float(hi.x & 0xffff0000u) + __uint_as_float(lo.x & 0xffff0000u);
+  v.z = __uint_as_float(hi.y << 16) + __uint_as_float(lo.y << 16);
+  v.w = __uint_as_float(hi.y & 0xffff0000u) + __uint_as_float(lo.y & 0xffff0000u);
   __builtin_amdgcn_wave_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  reinterpret_cast<float*>(r)[lane] = v;
+  if (ok) *reinterpret_cast<float4*>(r + q * 16) = v;
 }
 }  // namespace
 
@@ -2942,14 +2959,20 @@ int ffnet_learner_forward(const rela_ffnet* on, const rela_ffnet* tg, int B, con
   fc(tg, wt, B, ws_tg);
   {
     ProfScope prof("learner_fwd_heads", s);
-    const int A = on->num_action;
-    note_launch("heads_duel");
-    hipLaunchKernelGGL(heads_duel, dim3(ceil_div(B, kHeadRows)), dim3(256), 0, s, (const float*)w.h, (const float*)on->d.Bhp,
-                       (const float*)on->d.bh, legal, w.ha, q_on, B, A);
-    hipLaunchKernelGGL(heads_duel, dim3(ceil_div(B, kHeadRows)), dim3(256), 0, s, (const float*)(w.h + (size_t)B * kH),
-                       (const float*)on->d.Bhp, (const float*)on->d.bh, nlegal, w.ha + (size_t)B * kHA, q_no, B, A);
-    hipLaunchKernelGGL(heads_duel, dim3(ceil_div(B, kHeadRows)), dim3(256), 0, s, (const float*)wt.h, (const float*)tg->d.Bhp,
-                       (const float*)tg->d.bh, nlegal, wt.ha, q_nt, B, A);
+    const int A = on->num_action, nb = ceil_div(B, kHeadRows);
+    HeadJobs jb{};
+    const float* hs[3] = {w.h, w.h + (size_t)B * kH, wt.h};
+    float* has[3] = {w.ha, w.ha + (size_t)B * kHA, wt.ha};
+    const rela_ffnet* nets[3] = {on, on, tg};
+    const float* legals[3] = {legal, nlegal, nlegal};
+    float* qs[3] = {q_on, q_no, q_nt};
+    for (int k = 0; k < 3; ++k) {
+      jb.h[k] = hs[k], jb.Bhp[k] = nets[k]->d.Bhp, jb.bias[k] = nets[k]->d.bh, jb.legal[k] = legals[k];
+      jb.ha[k] = has[k], jb.q[k] = qs[k], jb.N[k] = B, jb.first[k] = k * nb;
+    }
+    jb.first[3] = 3 * nb;
+    note_launch("heads_duel_jobs");
+    hipLaunchKernelGGL(heads_duel_jobs, dim3(3 * nb), dim3(256), 0, s, jb, A);
   }
   RELA_LAUNCH_CHECK();
   return RELA_OK;
@@ -2957,7 +2980,7 @@ int ffnet_learner_forward(const rela_ffnet* on, const rela_ffnet* tg, int B, con
 
 int ffnet_learner_unsplit(int B, void* ws_on, hipStream_t s) {
   const FFNetWs w = ffnet_ws(ws_on, 2 * B);
-  const int b1 = (int)ceil_div((int64_t)B * 400, 8), b2 = (int)ceil_div((int64_t)B * 81, 4), b3 = (int)ceil_div((int64_t)B * 49, 4);
+  const int b1 = (int)ceil_div((int64_t)B * 400, 32), b2 = (int)ceil_div((int64_t)B * 81, 16), b3 = (int)ceil_div((int64_t)B * 49, 16);
   ProfScope prof("learner_unsplit", s);
   note_launch("unsplit_trunk_rows");
   hipLaunchKernelGGL(unsplit_trunk_rows, dim3(b1 + b2 + b3), dim3(256), 0, s, reinterpret_cast<uint8_t*>(w.a1),

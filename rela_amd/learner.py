@@ -28,19 +28,21 @@ def allreduce_grads(params, world_size, group=None):
 def global_is_weights(raw_w, partition_sum, partition_size, beta, group=None):
     """Importance weights of one replay PARTITION normalised over ALL partitions.
 
-    The reference computes  w = (size * raw / sum) ** -beta;  w /= w.max()  over its single buffer
-    (rela/prioritized_replay.h:320-322).  With one partition per actor GPU, `size` and `sum` become the
-    totals over the partitions (one SUM all-reduce of two scalars) and the maximum is taken over every
-    rank's batch (one MAX all-reduce of a scalar) -- the "priority all-reduce" of the north star.
-    raw_w: f32[B] un-normalised weights of this rank's sample; partition_sum / partition_size: this
-    partition's weight sum (tensor or float) and item count.  Two tiny collectives per learner step.
+    The reference computes  w = (size * P(i)) ** -beta;  w /= w.max()  with P(i) = raw_i / sum, the probability of
+    drawing item i from its single buffer (rela/prioritized_replay.h:320-322).  With one partition per actor GPU every
+    partition contributes exactly B / G of the B draws, so item i of partition g is drawn with probability
+    P(i) = raw_i / (G * sum_g) -- NOT raw_i / sum_total unless all partition sums are equal -- and the correction is
+        w_i = (N_total * raw_i / (G * sum_g)) ** -beta,   normalised by the maximum over every rank's batch.
+    One SUM all-reduce of the partition size and one MAX all-reduce of a scalar per learner step: the "priority
+    all-reduce" of the north star.  raw_w: f32[B] un-normalised weights of this rank's sample; partition_sum /
+    partition_size: this partition's weight sum (tensor or float) and item count.
     """
     dev = raw_w.device
-    stats = torch.stack([torch.as_tensor(partition_sum, dtype=torch.float64, device=dev).reshape(()),
-                         torch.as_tensor(float(partition_size), dtype=torch.float64, device=dev).reshape(())])
-    dist.all_reduce(stats, op=dist.ReduceOp.SUM, group=group)
-    total_sum, total_size = stats[0].float(), stats[1].float()
-    w = (total_size * (raw_w / total_sum)).pow(-beta)
+    G = dist.get_world_size(group)
+    total = torch.as_tensor(float(partition_size), dtype=torch.float64, device=dev).reshape(1)
+    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    part_sum = torch.as_tensor(partition_sum, dtype=torch.float32, device=dev).reshape(())
+    w = (total[0].float() * (raw_w / (float(G) * part_sum))).pow(-beta)
     top = w.max()
     dist.all_reduce(top, op=dist.ReduceOp.MAX, group=group)
     return w / top

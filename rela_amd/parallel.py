@@ -17,7 +17,10 @@ logical replay:
     PartitionedReplay.publish(flat)     -->   one broadcast of the flat parameter buffer(s); the actor rank
                                               loads them into its nets (ModelLocker.update_model)
 
-A rank-0 command word keeps the collectives of all ranks in the same order (RCCL requires it).  The
+A rank-0 command word keeps the collectives of all ranks in the same order (RCCL requires it); in `scheduled`
+mode only the weight publish (every actor_sync_freq steps) and the final stop carry one, the sample / update pairs in
+between follow the announced cycle without any host synchronisation.  A sample is ONE gather of a packed per-rank
+record into a pre-allocated buffer; `sample(async_op=True)` lets it overlap the learner's backward pass.  The
 exchange is backend-agnostic: a partition is any object with
 
     sample(n) -> (fields: dict[str, Tensor] with leading dimension n (or [T, n, ...] when time_major),
@@ -66,10 +69,17 @@ def rnn_field_specs(num_action, steps):
             FieldSpec("c0", (1, 512), torch.float32, 1), FieldSpec("seq_len", (), torch.float32)]
 
 
-class _Exchange:
-    """State shared by both sides: ranks, groups, specs."""
+def _pad16(n):
+    return (n + 15) // 16 * 16
 
-    def __init__(self, specs, batch, beta, device, learner_rank=0, group=None):
+
+class _Exchange:
+    """State shared by both sides: ranks, groups, specs and the PACKED per-rank sample record -- every field of the
+    b_local rows a partition contributes, then its b_local IS weights, each at a 16-byte aligned offset of ONE
+    contiguous uint8 buffer, so that a sample is ONE gather into a pre-allocated buffer (r3; it was one gather per
+    field, each allocating `world` receive buffers)."""
+
+    def __init__(self, specs, batch, beta, device, learner_rank=0, group=None, scheduled=False):
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.learner_rank = learner_rank
@@ -79,103 +89,175 @@ class _Exchange:
         assert self.G >= 1 and batch % self.G == 0, "the learner batch (%d) must split over %d partitions" % (batch, self.G)
         self.batch, self.b_local, self.beta = batch, batch // self.G, beta
         self.specs, self.device = specs, torch.device(device)
+        self.scheduled = scheduled
         # every rank creates the actor-only subgroup (new_group is collective over the default group)
         self.actor_group = dist.new_group(ranks=self.actor_ranks)
         self._cmd = torch.zeros(2, dtype=torch.int64, device=self.device)
+        self._layout = []  # (spec, byte offset, bytes, local shape)
+        off = 0
+        for sp in specs:
+            shape = list(sp.shape)
+            shape.insert(sp.batch_dim, self.b_local)
+            nb = int(torch.empty(shape, dtype=sp.dtype, device="meta").numel()) * torch.empty((), dtype=sp.dtype).element_size()
+            self._layout.append((sp, off, nb, tuple(shape)))
+            off += _pad16(nb)
+        self._w_off = off
+        self.rank_bytes = _pad16(off + 4 * self.b_local)
 
     def _bcast_cmd(self, code=0, arg=0):
+        """the one host-synchronising exchange: in scheduled mode only publish / stop use it"""
         if self.rank == self.learner_rank:
             self._cmd[0], self._cmd[1] = code, arg
         dist.broadcast(self._cmd, src=self.learner_rank, group=self.group)
         return int(self._cmd[0]), int(self._cmd[1])
 
 
+class _PendingSample:
+    def __init__(self, owner, slot, work):
+        self.owner, self.slot, self.work = owner, slot, work
+
+    def wait(self):
+        """-> (fields, IS weights) once the packed gather has landed"""
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        return self.owner._unpack(self.slot)
+
+
 class PartitionedReplay(_Exchange):
     """Learner side: one logical replay over the actor ranks' partitions, with the reference's surface
-    (sample / update_priority, one outstanding batch, rela/prioritized_replay.h:202-245)."""
+    (sample / update_priority, one outstanding batch, rela/prioritized_replay.h:202-245).
 
-    def __init__(self, specs, batch, beta, device, learner_rank=0, group=None):
-        super().__init__(specs, batch, beta, device, learner_rank, group)
+    scheduled = False: every call is announced by a rank-0 command word (a host synchronisation on every rank).
+    scheduled = True (the steady state of a training run): only `publish(..., steps=n)` and `stop()` carry a command
+    word; the n sample / update_priority pairs that follow a publish need none -- the actor ranks know the cycle."""
+
+    def __init__(self, specs, batch, beta, device, learner_rank=0, group=None, scheduled=False):
+        super().__init__(specs, batch, beta, device, learner_rank, group, scheduled)
         self._outstanding = False
+        self._left = 0  # scheduled mode: sample / update pairs left in the announced cycle
+        # two receive slots (a prefetched sample lands while the previous batch is still being read), allocated once
+        self._recv = [torch.empty(self.world * self.rank_bytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self._out = [{sp.name: sp.empty(self.batch, self.device) for sp in specs} for _ in range(2)]
+        self._w = [torch.empty(self.batch, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self._slot = 0
+        self._prio = torch.zeros(self.world * self.b_local, dtype=torch.float32, device=self.device)
+        self._prio_recv = torch.empty(self.b_local, dtype=torch.float32, device=self.device)
+        ar = self.actor_ranks
+        self._contig = ar == list(range(ar[0], ar[0] + self.G))
 
-    def _gather(self, local):
-        """rows of every rank's `local` (this rank contributes a dummy) -> list ordered by actor rank"""
-        bufs = [torch.empty_like(local) for _ in range(self.world)]
-        dist.gather(local, bufs, dst=self.learner_rank, group=self.group)
-        return [bufs[r] for r in self.actor_ranks]
+    def _unpack(self, slot):
+        rows = self._recv[slot].view(self.world, self.rank_bytes)
+        rows = rows[self.actor_ranks[0]:self.actor_ranks[0] + self.G] if self._contig else rows[self.actor_ranks]
+        out = self._out[slot]
+        for sp, off, nb, shape in self._layout:
+            src = rows[:, off:off + nb].view(sp.dtype).reshape((self.G,) + shape)  # [G, *local shape]
+            dst = out[sp.name]
+            dshape = list(dst.shape)
+            dshape[sp.batch_dim:sp.batch_dim + 1] = [self.G, self.b_local]
+            perm = list(range(1, sp.batch_dim + 1)) + [0] + list(range(sp.batch_dim + 1, len(shape) + 1))
+            dst.view(dshape).copy_(src.permute(perm))  # ONE strided copy per field
+        self._w[slot].view(self.G, self.b_local).copy_(rows[:, self._w_off:self._w_off + 4 * self.b_local].view(torch.float32))
+        return out, self._w[slot]
 
-    def sample(self):
-        """-> (fields: dict of [B, ...] (or [T, B, ...]) tensors on the learner device, IS weights [B])"""
+    def sample(self, async_op=False):
+        """-> (fields: dict of [B, ...] (or [T, B, ...]) tensors on the learner device, IS weights [B]); with
+        async_op a handle whose wait() returns them (the gather then overlaps whatever the caller does meanwhile,
+        e.g. the backward half of the previous step).  The returned tensors are valid until the sample after next."""
         assert not self._outstanding, "Error: previous samples' priority has not been updated."  # :203-206
-        self._bcast_cmd(CMD_SAMPLE)
-        out = {}
-        for sp in self.specs:
-            parts = self._gather(sp.empty(self.b_local, self.device))
-            out[sp.name] = torch.cat(parts, dim=sp.batch_dim)
-        weight = torch.cat(self._gather(torch.empty(self.b_local, dtype=torch.float32, device=self.device)))
+        if self.scheduled:
+            assert self._left > 0, "scheduled mode: publish(..., steps=n) announces the next n sample / update pairs"
+        else:
+            self._bcast_cmd(CMD_SAMPLE)
+        slot = self._slot
+        self._slot ^= 1
+        recv = self._recv[slot]
+        views = [recv[r * self.rank_bytes:(r + 1) * self.rank_bytes] for r in range(self.world)]
+        work = dist.gather(views[self.rank], views, dst=self.learner_rank, group=self.group, async_op=async_op)
         self._outstanding = True
-        return out, weight
+        pending = _PendingSample(self, slot, work if async_op else None)
+        return pending if async_op else pending.wait()
 
     def update_priority(self, priority):
         assert self._outstanding and priority.numel() == self.batch
-        self._bcast_cmd(CMD_UPDATE)
-        p = priority.detach().to(self.device, torch.float32).reshape(self.batch)
-        chunks = list(p.split(self.b_local))
-        scatter = []
-        it = iter(chunks)
-        for r in range(self.world):
-            scatter.append(torch.zeros(self.b_local, device=self.device) if r == self.learner_rank else next(it).contiguous())
-        recv = torch.empty(self.b_local, dtype=torch.float32, device=self.device)
-        dist.scatter(recv, scatter, src=self.learner_rank, group=self.group)
+        if self.scheduled:
+            self._left -= 1
+        else:
+            self._bcast_cmd(CMD_UPDATE)
+        p = priority.detach().to(self.device, torch.float32).reshape(self.G, self.b_local)
+        full = self._prio.view(self.world, self.b_local)
+        if self._contig:
+            full[self.actor_ranks[0]:self.actor_ranks[0] + self.G].copy_(p)
+        else:
+            full[self.actor_ranks] = p
+        dist.scatter(self._prio_recv, list(full.unbind(0)), src=self.learner_rank, group=self.group)
         self._outstanding = False
 
-    def publish(self, *flats):
-        """ModelLocker.update_model across processes: one broadcast per flat parameter buffer
-        (online, target; 6.8 MB each for AtariFFNet, 30 MB for AtariLSTMNet)."""
-        self._bcast_cmd(CMD_PUBLISH, len(flats))
+    def publish(self, *flats, steps=0):
+        """ModelLocker.update_model across processes: one broadcast per flat parameter buffer (online, target; 6.8 MB
+        each for AtariFFNet, 30 MB for AtariLSTMNet).  scheduled mode: `steps` = the sample / update_priority pairs that
+        follow before the next publish or stop."""
+        assert not self.scheduled or self._left == 0, "scheduled mode: %d announced steps are still to run" % self._left
+        self._bcast_cmd(CMD_PUBLISH, len(flats) + 1000 * int(steps))
+        self._left = int(steps)
         for f in flats:
             dist.broadcast(f, src=self.learner_rank, group=self.group)
 
     def stop(self):
+        assert not self.scheduled or self._left == 0, "scheduled mode: stop() in the middle of an announced cycle"
         self._bcast_cmd(CMD_STOP)
 
 
 class PartitionServer(_Exchange):
     """Actor-rank side: serves the learner's commands against this rank's replay partition."""
 
-    def __init__(self, partition, specs, batch, beta, device, flat_sizes=(), on_weights=None, learner_rank=0, group=None):
-        super().__init__(specs, batch, beta, device, learner_rank, group)
+    def __init__(self, partition, specs, batch, beta, device, flat_sizes=(), on_weights=None, learner_rank=0, group=None,
+                 scheduled=False):
+        super().__init__(specs, batch, beta, device, learner_rank, group, scheduled)
         self.partition = partition
         self.on_weights = on_weights
         self._flats = [torch.empty(n, dtype=torch.float32, device=self.device) for n in flat_sizes]
+        self._send = torch.zeros(self.rank_bytes, dtype=torch.uint8, device=self.device)
+        self._prio_recv = torch.empty(self.b_local, dtype=torch.float32, device=self.device)
         self.served = 0
 
-    def _gather(self, local):
-        dist.gather(local.contiguous(), None, dst=self.learner_rank, group=self.group)
+    def _sample_step(self):
+        fields, raw_w, part_sum, part_size = self.partition.sample(self.b_local)
+        # the "priority all-reduce": total size and the global maximum over the actor ranks
+        weight = global_is_weights(raw_w.to(self.device), part_sum, part_size, self.beta, group=self.actor_group)
+        for sp, off, nb, shape in self._layout:
+            t = fields[sp.name]
+            t = t.to(self.device, sp.dtype) if (t.dtype != sp.dtype or t.device != self.device) else t
+            self._send[off:off + nb].view(sp.dtype).view(shape).copy_(t.reshape(shape))
+        self._send[self._w_off:self._w_off + 4 * self.b_local].view(torch.float32).copy_(weight.float())
+        dist.gather(self._send, None, dst=self.learner_rank, group=self.group)
+        self.served += 1
+
+    def _update_step(self):
+        dist.scatter(self._prio_recv, None, src=self.learner_rank, group=self.group)
+        self.partition.update_priority(self._prio_recv)
+
+    def _publish_step(self, arg):
+        assert arg % 1000 == len(self._flats), "publish of %d buffers, %d expected" % (arg % 1000, len(self._flats))
+        for f in self._flats:
+            dist.broadcast(f, src=self.learner_rank, group=self.group)
+        if self.on_weights is not None:
+            self.on_weights(*self._flats)
+        return arg // 1000
 
     def serve_one(self):
-        """-> False after CMD_STOP"""
+        """-> False after CMD_STOP.  scheduled mode: one command = a publish and the whole cycle it announces."""
         code, arg = self._bcast_cmd()
         if code == CMD_SAMPLE:
-            fields, raw_w, part_sum, part_size = self.partition.sample(self.b_local)
-            # the "priority all-reduce": totals of (sum, size) and the global maximum over the actor ranks
-            weight = global_is_weights(raw_w.to(self.device), part_sum, part_size, self.beta, group=self.actor_group)
-            for sp in self.specs:
-                t = fields[sp.name]
-                t = t.to(self.device, sp.dtype) if (t.dtype != sp.dtype or t.device != self.device) else t
-                self._gather(t.reshape(sp.empty(self.b_local, "meta").shape))
-            self._gather(weight.float())
-            self.served += 1
+            self._sample_step()
         elif code == CMD_UPDATE:
-            recv = torch.empty(self.b_local, dtype=torch.float32, device=self.device)
-            dist.scatter(recv, None, src=self.learner_rank, group=self.group)
-            self.partition.update_priority(recv)
+            self._update_step()
         elif code == CMD_PUBLISH:
-            assert arg == len(self._flats), "publish of %d buffers, %d expected" % (arg, len(self._flats))
-            for f in self._flats:
-                dist.broadcast(f, src=self.learner_rank, group=self.group)
-            if self.on_weights is not None:
-                self.on_weights(*self._flats)
+            steps = self._publish_step(arg)
+            if self.scheduled:
+                for _ in range(steps):  # no command words inside the cycle: no host synchronisation per step
+                    self._sample_step()
+                    self._update_step()
         elif code == CMD_STOP:
             return False
         return True

@@ -244,7 +244,10 @@ def _multi_worker(rank, world, args, port, results):
     assert args.batchsize % G == 0 and args.num_thread % G == 0
     if rank == 0:
         learner = learner_cls.from_agent(agent, args.batchsize, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip)
-        replay = PartitionedReplay(specs, args.batchsize, args.importance_exponent, exch_device)
+        # scheduled exchange: command words (a host synchronisation on every rank) only with the weight publish every
+        # actor_sync_freq steps; the sample / update_priority pairs in between follow the announced cycle
+        replay = PartitionedReplay(specs, args.batchsize, args.importance_exponent, exch_device, scheduled=True)
+        total_updates = args.num_epoch * args.epoch_len
         history = []
         for epoch in range(args.num_epoch):
             t0 = time.time()
@@ -254,7 +257,8 @@ def _multi_worker(rank, world, args, port, results):
                 if num_update % args.num_update_between_sync == 0:
                     learner.sync_target_with_online()
                 if num_update % args.actor_sync_freq == 0:  # ONE broadcast per flat buffer instead of load_state_dict
-                    replay.publish(learner.flat()[0].to(exch_device), learner.flat_target().to(exch_device))
+                    replay.publish(learner.flat()[0].to(exch_device), learner.flat_target().to(exch_device),
+                                   steps=min(args.actor_sync_freq, total_updates - num_update))
                 fields, weight = replay.sample()
                 batch = to_namespace({k: v.to(my_device) for k, v in fields.items()})
                 loss, priority = learner.step(batch, weight.to(my_device))
@@ -305,7 +309,7 @@ def _multi_worker(rank, world, args, port, results):
 
         srv = PartitionServer((_RelaRNNPartition if r2d2 else _RelaFFPartition)(part, my_device), specs, args.batchsize,
                               args.importance_exponent,
-                              exch_device, flat_sizes=(total, total), on_weights=on_weights)
+                              exch_device, flat_sizes=(total, total), on_weights=on_weights, scheduled=True)
         srv.serve_forever()
         counts = torch.tensor([float(utils.total_acts(actors)), float(part.num_add())], dtype=torch.float64,
                               device=exch_device)

@@ -2,6 +2,8 @@
 all-reduce per step (rela_amd/learner.py) -- replicas must stay bit-identical and equal to a
 single learner fed the concatenated batch."""
 import os
+
+import pytest
 import socket
 
 import numpy as np
@@ -91,7 +93,11 @@ def _is_worker(rank, world, port, out):
 
 
 def test_two_partition_is_weight_normalisation():
-    """IS weights over two replay partitions == the single-buffer formula on the union."""
+    """IS weights over two replay partitions with deliberately UNEQUAL sums (123.5 vs 77.25) and sizes: every
+    partition contributes B / G draws, so item i of partition g is drawn with probability raw_i / (G * sum_g) and the
+    correction is (N_total * that) ** -beta over the global maximum -- the single-buffer formula of
+    prioritized_replay.h:320-322 applied to the probabilities the partitioned sampler really draws with.  With equal
+    partition sums it coincides with the reference's formula on the union (second half of the test)."""
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
@@ -104,12 +110,19 @@ def test_two_partition_is_weight_normalisation():
         assert p.exitcode == 0
     g = torch.Generator().manual_seed(5)
     raw = torch.rand(2, 16, generator=g) + 0.05
-    total_sum, total_size = torch.tensor(123.5 + 77.25), torch.tensor(1640.0)
-    ref = (total_size * (raw.reshape(-1) / total_sum)).pow(-0.4)  # prioritized_replay.h:320-322 on the union
+    sums, total_size = torch.tensor([123.5, 77.25]), torch.tensor(1640.0)
+    prob = raw / (2.0 * sums[:, None])                # P(draw item i) under B / G draws per partition
+    ref = (total_size * prob).pow(-0.4).reshape(-1)
     ref = ref / ref.max()
     got = torch.tensor(res).reshape(-1)
     torch.testing.assert_close(got, ref, rtol=1e-6, atol=0)
     assert got.max() == 1.0
+    # the expectation of w_i**(-1/beta) * P(i) ... sanity of the probabilities themselves: they sum to one over both
+    # partitions when summed over ALL items (here: per partition sum_g / (G * sum_g) = 1 / G)
+    # equal sums: identical to the reference's single-buffer formula on the union
+    eq = (total_size * (raw / (2.0 * 100.0))).pow(-0.4)
+    single = (total_size * (raw / 200.0)).pow(-0.4)
+    torch.testing.assert_close(eq, single, rtol=0, atol=0)
 
 
 def _publish_worker(rank, world, port, out):
@@ -199,7 +212,7 @@ class _OraclePartition:
         assert self.o.update(p.numpy()) == 0
 
 
-def _exchange_worker(rank, world, port, out):
+def _exchange_worker(rank, world, port, out, scheduled=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -210,10 +223,16 @@ def _exchange_worker(rank, world, port, out):
              FieldSpec("seq", (4,), torch.float32, batch_dim=1)]
     _, total = ffnet_flat_layout(18)  # the flat buffers HipApexLearner publishes (online, target)
     if rank == 0:
-        rep = PartitionedReplay(specs, _EX["batch"], _EX["beta"], "cpu")
+        rep = PartitionedReplay(specs, _EX["batch"], _EX["beta"], "cpu", scheduled=scheduled)
         rounds = []
+        if scheduled:  # first cycle: two sample / update pairs, announced with the first publish
+            rep.publish(torch.zeros(total), torch.zeros(total), steps=2)
         for r in range(_EX["rounds"]):
-            fields, w = rep.sample()
+            if scheduled and r % 2 == 1:  # a prefetching learner: the gather runs while it does something else
+                pending = rep.sample(async_op=True)
+                fields, w = pending.wait()
+            else:
+                fields, w = rep.sample()
             try:
                 rep.sample()
                 raise SystemExit("second sample without update was accepted")
@@ -222,24 +241,29 @@ def _exchange_worker(rank, world, port, out):
             prio = (fields["tag"] % 7).float() * 0.3 + 0.1 + r
             rounds.append(dict(tag=fields["tag"].tolist(), payload=fields["payload"].tolist(), w=w.tolist(),
                                prio=prio.tolist(), seq=fields["seq"].tolist()))
+            fields = {k: v.clone() for k, v in fields.items()}  # (the buffers are reused two samples later)
             rep.update_priority(prio)
             if r == 1:
-                rep.publish(torch.arange(total, dtype=torch.float32), torch.arange(total, dtype=torch.float32) * 2)
+                rep.publish(torch.arange(total, dtype=torch.float32), torch.arange(total, dtype=torch.float32) * 2,
+                            steps=_EX["rounds"] - 2)
         rep.stop()
         out.put(("learner", rounds))
     else:
         got = []
         srv = PartitionServer(_OraclePartition(rank), specs, _EX["batch"], _EX["beta"], "cpu", flat_sizes=(total, total),
-                              on_weights=lambda on, tg: got.append((float(on[12345]), float(tg[12345]), on.numel())))
+                              on_weights=lambda on, tg: got.append((float(on[12345]), float(tg[12345]), on.numel())),
+                              scheduled=scheduled)
         srv.serve_forever()
         out.put(("actor", rank, srv.partition.o.state()["sum"], srv.served, got))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_partitioned_replay_exchange_over_three_ranks():
-    """Learner rank + two actor ranks (gloo): B/G sampling per partition, row gather, IS weights normalised
-    over both partitions, priority scatter and the flat weight publish.  Each partition must behave exactly
+@pytest.mark.parametrize("scheduled", [False, True], ids=["command-words", "scheduled"])
+def test_partitioned_replay_exchange_over_three_ranks(scheduled):
+    """Learner rank + two actor ranks (gloo): B/G sampling per partition, ONE packed row gather per sample, IS weights
+    normalised over both partitions, priority scatter and the flat weight publish -- with a command word per call and
+    in scheduled mode (command words only at publish / stop, an asynchronous sample in between).  Each partition must behave exactly
     like a reference PrioritizedReplay(capacity/G, seed_g) fed the same stream and asked for B/G (SURVEY 8e's
     parity definition): the test replays both partitions locally on the oracle and compares everything."""
     import numpy as np
@@ -249,7 +273,7 @@ def test_partitioned_replay_exchange_over_three_ranks():
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_exchange_worker, args=(r, 3, port, out)) for r in range(3)]
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 3, port, out, scheduled)) for r in range(3)]
     for p in procs:
         p.start()
     msgs = [out.get(timeout=180) for _ in range(3)]
@@ -278,9 +302,11 @@ def test_partitioned_replay_exchange_over_three_ranks():
                                       np.stack([exp_tags * 0.5, exp_tags * 0.25, exp_tags + 1.0], 1).astype(np.float32))
         np.testing.assert_array_equal(np.array(rec["seq"], np.float32),  # gathered along the batch axis of [T, B]
                                       np.stack([exp_tags + 10.0 * t for t in range(4)], 0).astype(np.float32))
-        # prioritized_replay.h:320-322 over the union: N and sum are the totals, the maximum is global
-        tot_sum, tot_n = np.float64(sums[0]) + np.float64(sums[1]), float(sizes[0] + sizes[1])
-        w = (np.float32(tot_n) * (np.concatenate(raw) / np.float32(tot_sum))) ** np.float32(-_EX["beta"])
+        # prioritized_replay.h:320-322 with the probabilities the partitioned sampler draws with: N is the total size,
+        # item i of partition g has P(i) = raw_i / (G * sum_g) (B / G draws per partition), the maximum is global
+        tot_n = float(sizes[0] + sizes[1])
+        prob = np.concatenate([raw[i] / (np.float32(2.0) * sums[i]) for i in range(2)])
+        w = (np.float32(tot_n) * prob) ** np.float32(-_EX["beta"])
         np.testing.assert_allclose(np.array(rec["w"], np.float32), w / w.max(), rtol=2e-6)
         assert max(rec["w"]) == 1.0
         prio = np.array(rec["prio"], np.float32)
@@ -291,7 +317,8 @@ def test_partitioned_replay_exchange_over_three_ranks():
         assert served == _EX["rounds"] and final_sum == mirrors[g].state()["sum"]
         from rela_amd.learner import ffnet_flat_layout
 
-        assert got == [(12345.0, 24690.0, ffnet_flat_layout(18)[1])]
+        expect = [(12345.0, 24690.0, ffnet_flat_layout(18)[1])]
+        assert got == ([(0.0, 0.0, ffnet_flat_layout(18)[1])] + expect if scheduled else expect)
 
 
 def test_lstmnet_flat_layout_matches_the_r2d2_learner_buffer():
