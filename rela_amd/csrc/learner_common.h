@@ -472,6 +472,7 @@ constexpr int kSplitW3 = 28, kSplitW2 = 27, kSplitW1 = 64;
 // ([64][512]) gradients
 constexpr size_t kTrunkPartFloats = (size_t)w3fast::kMaxBlocks * 64 * 576;
 static_assert(kTrunkPartFloats * 4 >= dgfast::kFrag3Bytes && kTrunkPartFloats * 4 >= dgfast::kFrag2Bytes, "frag scratch");
+static_assert(kTrunkPartFloats >= (size_t)kSplitW3 * 8 * 64 * 576, "part size (split multiplier up to 8)");
 static_assert(kTrunkPartFloats >= (size_t)kSplitW3 * 64 * 576 && kTrunkPartFloats >= (size_t)w1fast::kMaxBlocks * 32 * 256 &&
                   kTrunkPartFloats >= (size_t)w2fast::kMaxBlocks * 64 * 512,
               "part size");
@@ -535,8 +536,12 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     ProbW3 p{};
     p.M = 64, p.N = 576, p.K = Bn * 49;
     p.d_out = t.d_a3, p.in = t.a2, p.part = t.part;
-    launch_gemm<TileW64>(p, kSplitW3, s, "learner_wgrad_conv3");
-    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 576, 256)), dim3(256), 0, s, (const float*)t.part, kSplitW3, 64,
+    // (a few hundred frames: 3 x the splits = 3-4 blocks per CU instead of one; a block alone on its CU waits out
+    // every chunk's load latency with two waves per SIMD)
+    static const int mul = getenv("RELA_WGRAD_SPLIT_MUL") ? atoi(getenv("RELA_WGRAD_SPLIT_MUL")) : 3;
+    const int split3 = Bn <= 1024 ? kSplitW3 * mul : kSplitW3;
+    launch_gemm<TileW64>(p, split3, s, "learner_wgrad_conv3");
+    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 576, 256)), dim3(256), 0, s, (const float*)t.part, split3, 64,
                        576, kRedConv3, t.g_c3w);
   }
   jobs.add(t.d_a3, (int64_t)Bn * 49, 64, t.g_c3b);
@@ -564,8 +569,10 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     ProbW2 p{};
     p.M = 64, p.N = 512, p.K = Bn * 81;
     p.d_out = t.d_a2, p.in = t.a1, p.part = t.part;
-    launch_gemm<TileW64>(p, kSplitW2, s, "learner_wgrad_conv2");
-    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 512, 256)), dim3(256), 0, s, (const float*)t.part, kSplitW2, 64,
+    static const int mul = getenv("RELA_WGRAD_SPLIT_MUL") ? atoi(getenv("RELA_WGRAD_SPLIT_MUL")) : 3;
+    const int split2 = Bn <= 1024 ? kSplitW2 * mul : kSplitW2;
+    launch_gemm<TileW64>(p, split2, s, "learner_wgrad_conv2");
+    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 512, 256)), dim3(256), 0, s, (const float*)t.part, split2, 64,
                        512, kRedConv2, t.g_c2w);
   }
   jobs.add(t.d_a2, (int64_t)Bn * 81, 64, t.g_c2b);

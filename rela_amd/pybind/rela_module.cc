@@ -21,6 +21,7 @@
 #include <cstring>
 #include <exception>
 #include <mutex>
+#include <optional>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -362,7 +363,22 @@ class FFPrioritizedReplay {
     if (h_) rela_replay_shutdown(h_);
   }
 
+  // prefetch > 0 (rela/prioritized_replay.h:223-230: sampler futures that run next to the learner): here a DEVICE-side
+  // prefetch -- update_priority k queues sample k + 1 right behind itself on the replay's stream, so its latency-bound
+  // kernels run while the Python learner loop gets from update_priority back to sample; sample() then hands that
+  // batch over.  One outstanding batch at a time as in the library's protocol, and the same sequence of library calls
+  // as without prefetch: ids, weights and rows are bit-identical to prefetch = 0 (tests/test_e2e_gpu.py).
   std::tuple<FFTransition, torch::Tensor> sample(int batchsize, const std::string& device) {
+    if (prefetched_ && prefetchedBatch_ == batchsize && prefetchedDevice_ == device) {
+      auto r = std::move(*prefetched_);
+      prefetched_.reset();
+      return r;
+    }
+    if (prefetched_) throw std::runtime_error("FFPrioritizedReplay.sample: batch size / device changed under prefetch");
+    return sampleNow(batchsize, device);
+  }
+
+  std::tuple<FFTransition, torch::Tensor> sampleNow(int batchsize, const std::string& device) {
     if (!h_) throw std::runtime_error("FFPrioritizedReplay.sample: the replay is empty");
     const auto dev = torch::Device(torch::kCUDA, (c10::DeviceIndex)device_);
     auto u8 = torch::TensorOptions().dtype(torch::kUInt8).device(dev);
@@ -387,6 +403,7 @@ class FFPrioritizedReplay {
     check(rela_replay_sample(h_, batchsize, rows, weight.data_ptr<float>(), torchCurrentStream(device_)),
           "FFPrioritizedReplay.sample");
     lastBatch_ = batchsize;
+    lastDevice_ = device;
     const int want = parseDevice(device);
     if (want != device_) {  // learner on another GPU (or the cpu): move the batch, types.cc:34-43
       const auto target = want < 0 ? torch::Device(torch::kCPU) : torch::Device(torch::kCUDA, (c10::DeviceIndex)want);
@@ -416,6 +433,11 @@ class FFPrioritizedReplay {
       check(rela_replay_update_priority(h_, (int)p.numel(), p.data_ptr<float>(), 0, nullptr),
             "FFPrioritizedReplay.update_priority");
     }
+    if (prefetch_ > 0 && lastBatch_ > 0 && rela_replay_size(h_) >= lastBatch_) {
+      prefetched_.emplace(sampleNow(lastBatch_, lastDevice_));
+      prefetchedBatch_ = lastBatch_;
+      prefetchedDevice_ = lastDevice_;
+    }
   }
 
  private:
@@ -426,7 +448,11 @@ class FFPrioritizedReplay {
   rela_replay* h_ = nullptr;
   int device_ = -1, numAction_ = 0;
   int lastBatch_ = 0;
+  std::string lastDevice_;
   torch::Tensor keep_;
+  std::optional<std::tuple<FFTransition, torch::Tensor>> prefetched_;
+  int prefetchedBatch_ = 0;
+  std::string prefetchedDevice_;
 };
 
 // =====================================================================================
@@ -463,7 +489,18 @@ class RNNPrioritizedReplay {
     if (h_) rela_replay_shutdown(h_);
   }
 
+  // (prefetch: as FFPrioritizedReplay::sample)
   std::tuple<RNNTransition, torch::Tensor> sample(int batchsize, const std::string& device) {
+    if (prefetched_ && prefetchedBatch_ == batchsize && prefetchedDevice_ == device) {
+      auto r = std::move(*prefetched_);
+      prefetched_.reset();
+      return r;
+    }
+    if (prefetched_) throw std::runtime_error("RNNPrioritizedReplay.sample: batch size / device changed under prefetch");
+    return sampleNow(batchsize, device);
+  }
+
+  std::tuple<RNNTransition, torch::Tensor> sampleNow(int batchsize, const std::string& device) {
     if (!h_) throw std::runtime_error("RNNPrioritizedReplay.sample: the replay is empty");
     const auto dev = torch::Device(torch::kCUDA, (c10::DeviceIndex)device_);
     auto opt = [&](torch::ScalarType t) { return torch::TensorOptions().dtype(t).device(dev); };
@@ -486,6 +523,7 @@ class RNNPrioritizedReplay {
     check(rela_replay_sample(h_, batchsize, rows, weight.data_ptr<float>(), torchCurrentStream(device_)),
           "RNNPrioritizedReplay.sample");
     lastBatch_ = batchsize;
+    lastDevice_ = device;
     const int want = parseDevice(device);
     if (want != device_) {
       const auto target = want < 0 ? torch::Device(torch::kCPU) : torch::Device(torch::kCUDA, (c10::DeviceIndex)want);
@@ -514,6 +552,11 @@ class RNNPrioritizedReplay {
       check(rela_replay_update_priority(h_, (int)p.numel(), p.data_ptr<float>(), 0, nullptr),
             "RNNPrioritizedReplay.update_priority");
     }
+    if (prefetch_ > 0 && lastBatch_ > 0 && rela_replay_size(h_) >= lastBatch_) {
+      prefetched_.emplace(sampleNow(lastBatch_, lastDevice_));
+      prefetchedBatch_ = lastBatch_;
+      prefetchedDevice_ = lastDevice_;
+    }
   }
 
  private:
@@ -524,7 +567,11 @@ class RNNPrioritizedReplay {
   rela_replay* h_ = nullptr;
   int device_ = -1, numAction_ = 0, T_ = 0;
   int lastBatch_ = 0;
+  std::string lastDevice_;
   torch::Tensor keep_;
+  std::optional<std::tuple<RNNTransition, torch::Tensor>> prefetched_;
+  int prefetchedBatch_ = 0;
+  std::string prefetchedDevice_;
 
  public:
   std::tuple<torch::Tensor, torch::Tensor, int> lastSampleRaw_() { return lastSampleRaw(h_, device_, lastBatch_); }

@@ -28,10 +28,10 @@ def _wait(cond, what, timeout=120.0):
 CFG_SLIDING = dict(CFG, sliding=True, env_seed=950, rounds=8)
 
 
-def run_lockstep(rela, synth_atari, agent, act_device, sample_device, cfg=CFG):
+def run_lockstep(rela, synth_atari, agent, act_device, sample_device, cfg=CFG, prefetch=0):
     """agent: an ApexAgent-shaped module whose state_dict carries online_net.* / target_net.*."""
     ring = int(1.25 * cfg["capacity"])
-    replay = rela.FFPrioritizedReplay(cfg["capacity"], cfg["seed"], cfg["alpha"], cfg["beta"], 0)
+    replay = rela.FFPrioritizedReplay(cfg["capacity"], cfg["seed"], cfg["alpha"], cfg["beta"], prefetch)
     locker = rela.ModelLocker([agent], act_device)
     actor = rela.DQNActor(locker, cfg["multi_step"], cfg["K"], cfg["gamma"], replay)
     vec = rela.VectorEnv()

@@ -66,6 +66,22 @@ def test_lockstep_matches_reference(mods, dedup_env, dedup):
     _check_apex_rounds(run_lockstep(rela, synth, agent, "cuda:0", "cuda:0"), gold)
 
 
+def test_lockstep_with_prefetch_matches_reference(mods, dedup_env):
+    """FFPrioritizedReplay(..., prefetch = 2): update_priority queues the next sample behind itself on the replay's
+    stream and sample() hands that batch over (rela/prioritized_replay.h:223-230 runs sampler futures next to the
+    learner).  The library sees the same calls in the same order as with prefetch = 0, so every round must still equal
+    what the REAL reference (prefetch 0) returned."""
+    from e2e_lockstep import CFG, load_agent_params, run_lockstep
+    from rela_amd.pyrela.apex import ApexAgent
+    from rela_amd.pyrela.net import AtariFFNet
+
+    rela, synth = mods
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_lockstep_apex.json")))
+    dedup_env(None)
+    agent = load_agent_params(ApexAgent(lambda: AtariFFNet(CFG["num_action"]), CFG["multi_step"], CFG["gamma"]))
+    _check_apex_rounds(run_lockstep(rela, synth, agent, "cuda:0", "cuda:0", prefetch=2), gold)
+
+
 @pytest.mark.parametrize("dedup", [None, "stack", "plane"])
 def test_lockstep_sliding_env_matches_reference(mods, dedup_env, dedup):
     """An Atari-like env (one new 84x84 plane per step, sliding stack, first frame of an episode repeated four
