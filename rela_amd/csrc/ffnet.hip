@@ -988,8 +988,8 @@ template <bool JOBS>
 __device__ __forceinline__ void conv12_body(const uint8_t* __restrict__ in, const uint8_t* __restrict__ in1, int n_in0,
                                             const uint4* __restrict__ B1frag, const float* __restrict__ bias1,
                                             const uint4* __restrict__ B2frag, const float* __restrict__ bias2,
-                                            uint8_t* __restrict__ out, uint8_t* __restrict__ a1_out, int n_a1, int N,
-                                            int bid, int nblk) {
+                                            uint8_t* __restrict__ out, uint8_t* __restrict__ a1_out, int a1_lo, int n_a1,
+                                            int N, int bid, int nblk) {
   using F = Conv12;
   using C1 = Conv1P;
   using C2 = Conv2F;
@@ -1139,7 +1139,7 @@ __device__ __forceinline__ void conv12_body(const uint8_t* __restrict__ in, cons
     conv1_half(1);
     __syncthreads();  // T2 complete, T1 free
     if constexpr (JOBS) {
-      if (a1_out && n < n_a1) {  // (block-uniform) conv1's records of this frame: [400 pixels][32 hi | 32 lo]
+      if (a1_out && (unsigned)(n - a1_lo) < (unsigned)n_a1) {  // (block-uniform) conv1's records: [400 pixels][32 hi | 32 lo]
         uint4* dst = reinterpret_cast<uint4*>(a1_out + (size_t)n * (400 * 128));
         for (int i = tid; i < 400 * 8; i += kThreads) {
           const int px = i >> 3, u = i & 7;
@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
                                                          const uint4* __restrict__ B2frag,
                                                          const float* __restrict__ bias2, uint8_t* __restrict__ out,
                                                          int N) {
-  conv12_body<false>(in, nullptr, N, B1frag, bias1, B2frag, bias2, out, nullptr, 0, N, blockIdx.x, gridDim.x);
+  conv12_body<false>(in, nullptr, N, B1frag, bias1, B2frag, bias2, out, nullptr, 0, 0, N, blockIdx.x, gridDim.x);
 }
 
 // Several trunk passes in one launch (the learner's three forwards: online over [s ; s'], target over s'): job j owns
@@ -1211,8 +1211,8 @@ struct TrunkJob {
   int n_in0;
   const uint4 *B1, *B2, *B3;  // conv1 / conv2 / conv3 fragments of the job's net
   const float *b1, *b2, *b3;
-  uint8_t *a1_out;  // conv1's records for rows < n_a1, or NULL
-  int n_a1;
+  uint8_t *a1_out;  // conv1's records [N][400][128 B], written for the rows [a1_lo, a1_lo + n_a1); or NULL
+  int a1_lo, n_a1;
   uint8_t *a2, *a3;  // conv2's / conv3's split records [N][81][256 B] / [N][49][256 B]
   int N, block0, nblocks;
 };
@@ -1225,8 +1225,8 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s_jobs(TrunkJobs jobs) {
   int k = 0;
   while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].block0) ++k;
   const TrunkJob& t = jobs.j[k];
-  conv12_body<true>(t.in0, t.in1, t.n_in0, t.B1, t.b1, t.B2, t.b2, t.a2, t.a1_out, t.n_a1, t.N, (int)blockIdx.x - t.block0,
-                    t.nblocks);
+  conv12_body<true>(t.in0, t.in1, t.n_in0, t.B1, t.b1, t.B2, t.b2, t.a2, t.a1_out, t.a1_lo, t.n_a1, t.N,
+                    (int)blockIdx.x - t.block0, t.nblocks);
 }
 __global__ __launch_bounds__(kThreads) void conv3_bf16s_jobs(TrunkJobs jobs) {
   int k = 0;
@@ -1914,9 +1914,13 @@ __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__
 #pragma unroll
   for (int t = 0; t < F::RT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   const uint4* bp = Bfrag + (size_t)ct * F::KS * 2 * 64 + lane;
-  uint4 bnext[4];
+  // weight fragments stream from L2 TWO positions ahead (r3; one ahead left the L2 -> CU stream, which bounds this
+  // kernel, at 45 GB/s per CU): set s holds the fragments of the positions of parity s
+  uint4 bq0[4], bq1[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) bnext[q] = bp[(size_t)(p0 * 4 + q) * 64];  // k-steps 0,1 of the first position x (hi, lo)
+  for (int q = 0; q < 4; ++q) bq0[q] = bp[(size_t)(p0 * 4 + q) * 64];  // k-steps 0,1 of the first position x (hi, lo)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bq1[q] = bp[(size_t)(min(p0 + 1, p1 - 1) * 4 + q) * 64];
   using Set0 = std::integral_constant<int, 0>;
   using Set1 = std::integral_constant<int, 1>;
   load_pos(p0, Set0{});
@@ -1941,13 +1945,19 @@ __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__
 
   int buf = 0;  // pos % 3
   auto body = [&](int pos, auto set) {
+    constexpr int SB = decltype(set)::value;
     uint4 bcur[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) bcur[q] = bnext[q];
+    for (int q = 0; q < 4; ++q) {
+      if constexpr (SB == 0) bcur[q] = bq0[q]; else bcur[q] = bq1[q];
+    }
     {
-      const int pn = min(pos + 1, p1 - 1);
+      const int pn = min(pos + 2, p1 - 1);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bnext[q] = bp[(size_t)(pn * 4 + q) * 64];
+      for (int q = 0; q < 4; ++q) {
+        const uint4 v = bp[(size_t)(pn * 4 + q) * 64];
+        if constexpr (SB == 0) bq0[q] = v; else bq1[q] = v;
+      }
     }
     const int nbuf = (buf == F::NBUF - 1) ? 0 : buf + 1;
     const uint8_t* tile = smem + buf * F::TILE;
@@ -2915,14 +2925,14 @@ int ffnet_learner_forward(const rela_ffnet* on, const rela_ffnet* tg, int B, con
   j0.in0 = s_obs, j0.in1 = s_next, j0.n_in0 = B;
   j0.B1 = (const uint4*)on->d.B1p, j0.B2 = (const uint4*)on->d.B2f, j0.B3 = (const uint4*)on->d.B3f;
   j0.b1 = on->d.b1, j0.b2 = on->d.b2, j0.b3 = on->d.b3;
-  j0.a1_out = reinterpret_cast<uint8_t*>(w.a1), j0.n_a1 = B;
+  j0.a1_out = reinterpret_cast<uint8_t*>(w.a1), j0.a1_lo = 0, j0.n_a1 = B;
   j0.a2 = reinterpret_cast<uint8_t*>(w.a2), j0.a3 = reinterpret_cast<uint8_t*>(w.a3);
   j0.N = 2 * B, j0.block0 = 0, j0.nblocks = nb0;
   TrunkJob& j1 = jobs.j[1];
   j1.in0 = s_next, j1.in1 = s_next, j1.n_in0 = B;
   j1.B1 = (const uint4*)tg->d.B1p, j1.B2 = (const uint4*)tg->d.B2f, j1.B3 = (const uint4*)tg->d.B3f;
   j1.b1 = tg->d.b1, j1.b2 = tg->d.b2, j1.b3 = tg->d.b3;
-  j1.a1_out = nullptr, j1.n_a1 = 0;
+  j1.a1_out = nullptr, j1.a1_lo = 0, j1.n_a1 = 0;
   j1.a2 = reinterpret_cast<uint8_t*>(wt.a2), j1.a3 = reinterpret_cast<uint8_t*>(wt.a3);
   j1.N = B, j1.block0 = nb0, j1.nblocks = total - nb0;
   {
@@ -2978,15 +2988,20 @@ int ffnet_learner_forward(const rela_ffnet* on, const rela_ffnet* tg, int B, con
   return RELA_OK;
 }
 
-int ffnet_learner_unsplit(int B, void* ws_on, hipStream_t s) {
-  const FFNetWs w = ffnet_ws(ws_on, 2 * B);
-  const int b1 = (int)ceil_div((int64_t)B * 400, 32), b2 = (int)ceil_div((int64_t)B * 81, 16), b3 = (int)ceil_div((int64_t)B * 49, 16);
+int trunk_unsplit_rows(float* a1, float* a2, float* a3, int rows, hipStream_t s) {
+  const int b1 = (int)ceil_div((int64_t)rows * 400, 32), b2 = (int)ceil_div((int64_t)rows * 81, 16),
+            b3 = (int)ceil_div((int64_t)rows * 49, 16);
   ProfScope prof("learner_unsplit", s);
   note_launch("unsplit_trunk_rows");
-  hipLaunchKernelGGL(unsplit_trunk_rows, dim3(b1 + b2 + b3), dim3(256), 0, s, reinterpret_cast<uint8_t*>(w.a1),
-                     reinterpret_cast<uint8_t*>(w.a2), reinterpret_cast<uint8_t*>(w.a3), B, b1, b2);
+  hipLaunchKernelGGL(unsplit_trunk_rows, dim3(b1 + b2 + b3), dim3(256), 0, s, reinterpret_cast<uint8_t*>(a1),
+                     reinterpret_cast<uint8_t*>(a2), reinterpret_cast<uint8_t*>(a3), rows, b1, b2);
   RELA_LAUNCH_CHECK();
   return RELA_OK;
+}
+
+int ffnet_learner_unsplit(int B, void* ws_on, hipStream_t s) {
+  const FFNetWs w = ffnet_ws(ws_on, 2 * B);
+  return trunk_unsplit_rows(w.a1, w.a2, w.a3, B, s);
 }
 }  // namespace rela_amd
 
@@ -3255,6 +3270,38 @@ int lstmnet_trunk(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1,
   RELA_CHECK(N >= 1 && s_dev && a1 && a2 && a3, RELA_EINVAL, "lstmnet_trunk: bad arguments");
   const bool rec = lstm_trunk_launch(n->d, N, s_dev, a1, a2, a3, fast, s, names, a3_records != nullptr);
   if (a3_records) *a3_records = rec;
+  RELA_LAUNCH_CHECK();
+  return RELA_OK;
+}
+
+// The ONLINE net's conv trunk of the R2D2 learner on split-bf16 MFMA (r3): conv1 -> conv2 fused, with conv1's records
+// copied out for the rows [a1_lo, N) -- the training frames, whose a1 the backward kernels read -- and conv3; a1 (those
+// rows), a2 and a3 come out as split RECORDS in the f32 tensors' places.  The caller feeds a3's records to the gate GEMM
+// and then turns the training rows back into f32 with trunk_unsplit_rows.
+int lstmnet_trunk_records(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, int a1_lo,
+                          hipStream_t s, const char* const* names) {
+  RELA_CHECK(n && n->loaded, RELA_ESTATE, "lstmnet_trunk_records: parameters were never loaded");
+  RELA_CHECK(N >= 1 && s_dev && a1 && a2 && a3 && a1_lo >= 0 && a1_lo <= N, RELA_EINVAL, "lstmnet_trunk_records: bad arguments");
+  const FFNetDev& d = n->d;
+  TrunkJobs jobs{};
+  jobs.n = 1;
+  TrunkJob& j0 = jobs.j[0];
+  j0.in0 = s_dev, j0.in1 = s_dev, j0.n_in0 = N;
+  j0.B1 = (const uint4*)d.B1p, j0.B2 = (const uint4*)d.B2f, j0.B3 = (const uint4*)d.B3f;
+  j0.b1 = d.b1, j0.b2 = d.b2, j0.b3 = d.b3;
+  j0.a1_out = reinterpret_cast<uint8_t*>(a1), j0.a1_lo = a1_lo, j0.n_a1 = N - a1_lo;
+  j0.a2 = reinterpret_cast<uint8_t*>(a2), j0.a3 = reinterpret_cast<uint8_t*>(a3);
+  j0.N = N, j0.block0 = 0, j0.nblocks = std::min(kNumCU, N);
+  {
+    ProfScope prof(names[1], s);
+    note_launch("conv12_bf16s_jobs");
+    hipLaunchKernelGGL(conv12_bf16s_jobs, dim3(j0.nblocks), dim3(kThreads), Conv12::LDS_TOTAL, s, jobs);
+  }
+  {
+    ProfScope prof(names[2], s);
+    note_launch("conv3_bf16s_jobs");
+    hipLaunchKernelGGL(conv3_bf16s_jobs, dim3(j0.nblocks), dim3(kThreads), Conv3F::LDS_TOTAL, s, jobs);
+  }
   RELA_LAUNCH_CHECK();
   return RELA_OK;
 }

@@ -88,4 +88,9 @@ int lstmnet_trunk(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1,
                   const char* const* names, bool fast = false, bool* a3_records = nullptr);
 int lstmnet_heads(const rela_lstmnet* n, int N, const float* o, const float* legal, float* ha, float* q, hipStream_t s,
                   const char* name);
+// the online net's trunk on split-bf16 MFMA with conv1's records kept for the rows [a1_lo, N): a1 / a2 / a3 come out as
+// split records; trunk_unsplit_rows turns `rows` rows of each (from the given pointers) back into f32 in place
+int lstmnet_trunk_records(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, int a1_lo,
+                          hipStream_t s, const char* const* names);
+int trunk_unsplit_rows(float* a1, float* a2, float* a3, int rows, hipStream_t s);
 }  // namespace rela_amd

@@ -685,11 +685,22 @@ int forward_pre(rela_r2d2_learner* l, int which, int Bn, const uint8_t* obs, con
                 hipStream_t s) {
   const rela_lstmnet* net = which == 0 ? l->online : l->target;
   const int rowsAll = l->T * Bn;
-  // the online pass leaves a1 / a2 / a3 for the backward kernels: always f32
+  // bf16x2 (r3): BOTH trunks on split-bf16 MFMA.  The online pass leaves a1 / a2 / a3 of the training frames for the
+  // backward kernels: its conv1 records are copied out (they never leave LDS otherwise), a3's records feed the gate GEMM
+  // directly, then the training rows are turned back into f32 in place (below) -- the backward differentiates the
+  // forward that really ran, ReLU pattern included.  RELA_R2D2_ONLINE_F32=1 keeps the online trunk in f32 (r2).
+  static const bool online_f32 = getenv("RELA_R2D2_ONLINE_F32") && atoi(getenv("RELA_R2D2_ONLINE_F32")) != 0;
   const bool fast_target = which == 1 && l->precision == 1;
-  bool a3_records = false;  // the target net's fast trunk hands a3 over as the split records the gate GEMM reads
-  int rc = lstmnet_trunk(net, rowsAll, obs, l->a1, l->a2, l->a3, s, kTrunkNames, fast_target,
-                         fast_target ? &a3_records : nullptr);
+  const bool fast_online = which == 0 && l->precision == 1 && !online_f32 && rowsAll >= 128;
+  bool a3_records = false;  // a fast trunk hands a3 over as the split records the gate GEMM reads
+  int rc;
+  if (fast_online) {
+    rc = lstmnet_trunk_records(net, rowsAll, obs, l->a1, l->a2, l->a3, l->burn * Bn, s, kTrunkNames);
+    a3_records = true;
+  } else {
+    rc = lstmnet_trunk(net, rowsAll, obs, l->a1, l->a2, l->a3, s, kTrunkNames, fast_target,
+                       fast_target ? &a3_records : nullptr);
+  }
   if (rc != RELA_OK) return rc;
   if (l->precision == 1) {
     using namespace gemm16;
@@ -705,6 +716,11 @@ int forward_pre(rela_r2d2_learner* l, int which, int Bn, const uint8_t* obs, con
     rc = launch_rec64_nt(arec, l->wrec[which], rowsAll, kGates, kFeat / 64,
                          EpiBias{l->gxs[which], l->bsum[which], kGates}, s, "learner_lstm_gates_x");
     if (rc != RELA_OK) return rc;
+    if (fast_online) {  // the training frames' activations back into f32 for the backward pass
+      const size_t tr0 = (size_t)l->burn * Bn;
+      rc = trunk_unsplit_rows(l->a1 + tr0 * kA1, l->a2 + tr0 * kA2, l->a3 + tr0 * kA3, rowsAll - (int)tr0, s);
+      if (rc != RELA_OK) return rc;
+    }
   } else {
     ProbGateX p{};
     p.M = rowsAll, p.N = kGates, p.K = kFeat;

@@ -57,16 +57,16 @@ def _golden_batch(g, device):
     return batch, f32(m["weight"])
 
 
-def _check_grads_vs_golden(named_grads, g):
+def _check_grads_vs_golden(named_grads, g, tol=2e-3):
     import torch
 
     assert set(named_grads) == set(g["grads"])
     for key, rec in g["grads"].items():
         t = named_grads[key].detach().double().reshape(-1).cpu()
         scale = rec["absmax"] + 1e-12
-        np.testing.assert_allclose(float(t.norm()), rec["l2"], rtol=2e-3, atol=1e-4 * scale, err_msg=key)
-        np.testing.assert_allclose(t[torch.tensor(rec["idx"])].numpy(), np.array(rec["val"]), rtol=2e-3,
-                                   atol=2e-3 * scale, err_msg=key)
+        np.testing.assert_allclose(float(t.norm()), rec["l2"], rtol=tol, atol=1e-4 * scale, err_msg=key)
+        np.testing.assert_allclose(t[torch.tensor(rec["idx"])].numpy(), np.array(rec["val"]), rtol=tol,
+                                   atol=tol * scale, err_msg=key)
 
 
 def test_pytorch_r2d2_loss_on_gpu_matches_reference_golden():
@@ -104,7 +104,9 @@ def _synth_batch(g, device):
 
 # kernels a bf16x2 R2D2 learner step must launch once T * B >= 128 frames (csrc/learner_r2d2.hip)
 R2D2_FAST_KERNELS = {"conv12_bf16s", "conv_bf16s<Conv3F>", "gemm_rec64_nt", "wgrad_conv1_bf16", "dgrad_conv2_bf16",
-                     "dgrad_conv3_bf16"}
+                     "dgrad_conv3_bf16",
+                     # r3: the ONLINE trunk too (conv1's records kept for the backward, then turned back into f32)
+                     "conv12_bf16s_jobs", "conv3_bf16s_jobs", "unsplit_trunk_rows"}
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x2"])
@@ -137,7 +139,10 @@ def test_hip_r2d2_learner_matches_reference_golden_c4_shape(precision):
     np.testing.assert_allclose(loss_seq.cpu().numpy(), np.array(g["loss"]), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(prio.cpu().numpy(), np.array(g["priority"]), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(float(loss.cpu()[0]), float((np.array(g["loss"]) * w_np).mean()), rtol=2e-4)
-    _check_grads_vs_golden(learner.state_dict("grads"), g)
+    # bf16x2: the backward differentiates the split-bf16 forward, whose ReLU pattern differs from the reference's f32
+    # forward in a few units per 10^5 (tests/test_learner_gpu.py::test_learner_fast_mode_within_stated_tolerance and
+    # ..._on_the_forwards_own_relu_pattern pin that mechanism on the shared trunk kernels)
+    _check_grads_vs_golden(learner.state_dict("grads"), g, 1e-2 if precision == "bf16x2" else 2e-3)
     learner.close()
 
 
@@ -330,8 +335,11 @@ def test_hip_r2d2_learner_fast_target_trunk_within_tolerance(B, seq, burn):
     assert abs(float(loss1) - float(loss0)) < 2e-5 * max(1.0, abs(float(loss0)))
     g1 = learner.state_dict("grads")
     for key in HipR2D2Learner.KEYS:
-        scale = float(g0[key].abs().max()) + 1e-12
-        assert float((g1[key] - g0[key]).abs().max()) <= 2e-4 * scale, key
+        # r3: the online trunk runs on split-bf16 MFMA too, so a few ReLUs in 10^5 sit on the other side of zero and
+        # every gradient tensor moves by a few 1e-3 of its norm (see tests/test_learner_gpu.py for the mechanism)
+        d, n0 = float((g1[key] - g0[key]).norm()), float(g0[key].norm()) + 1e-20
+        cos = float((g1[key] * g0[key]).sum()) / (float(g1[key].norm()) * n0 + 1e-30)
+        assert d <= 2e-2 * n0 and cos > 0.9998, (key, d / n0, cos)
     learner.set_precision("f32")
     loss2, prio2, _ = learner.backward(batch, weight)
     assert torch.equal(prio2, prio0)
