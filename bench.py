@@ -72,6 +72,9 @@ BYTES_PER_SAMPLE = {"conv1_bf16x3": 28224 + 400 * 32 * 4, "conv2_mfma": 400 * 32
                     "conv3_mfma": 81 * 64 * 4 + 49 * 64 * 4, "fc_mfma": 49 * 64 * 4 + 512 * 4, "heads_mfma": 512 * 4 + 32 * 4,
                     "conv12_fused": 28224 + 81 * 64 * 4}
 PEAK_HBM_GBS = 8000.0
+DTYPE_NOTE = ("f32 results from split-bf16 MFMA (bf16 hi + lo operands = 16 significant bits, 2-3 bf16 products per product, "
+              "f32 accumulate): |dQ| < 2e-5 * max|Q| against the exact f32 mode (measured 6e-7 at max|Q| = 0.4, 8.7e-4 at "
+              "max|Q| = 56; tests/test_ffnet_gpu.py)")
 # what the HIP Ape-X learner step computes in, per --precision (csrc/learner.hip)
 LEARNER_PRECISION_NOTE = {
     "f32": "f32 throughout (exact f32 MFMA forwards, f32 MFMA GEMM backward, f32 clip + RMSprop)",
@@ -480,6 +483,190 @@ def bench_r2d2(args, world, rank, device):
         dist.destroy_process_group()
 
 
+# ---- the reference's own multi-GPU layout (pyrela/main.py:131-136,155,166; BASELINE C3 / C4) ---------------------
+def bench_reference_layout(args, world, rank, device, rehearsal):
+    """`--layout reference`: ONE learner (rank 0, its own GPU) + world - 1 actor-only ranks, every actor rank with
+    6,400 envs and a replay PARTITION (capacity / G) fed by its own actors -- rela_amd/parallel.py's exchange:
+    per learner step ONE packed gather of B / G rows per partition (issued asynchronously right after the previous
+    update_priority, so it lands under the backward half), one priority scatter, IS weights normalised over the
+    partitions (SUM of sizes, MAX of the maximum), the flat weight buffers broadcast every 20 steps.  Command words (a
+    host synchronisation on every rank) only with those publishes.  Actors tick freely, as the reference's actor
+    threads do: env-steps/s = the ticks all actor ranks completed inside the timed window x 6,400 / its duration;
+    the window is K learner steps on rank 0 between two publishes, at which every actor rank records its tick count."""
+    import threading
+
+    import torch.distributed as dist
+
+    from rela_amd import _capi as capi
+    from rela_amd.engine import ApexActorEngine, FFNetHandle
+    from rela_amd.learner import HipApexLearner, ffnet_flat_layout, load_net_from_flat
+    from rela_amd.parallel import FFPartition, PartitionedReplay, PartitionServer, ff_batch_namespace, ff_field_specs
+    from rela_amd.pyrela.apex import ApexAgent
+    from rela_amd.pyrela.net import AtariFFNet
+    from rela_amd.replay import FFReplay
+
+    G = world - 1
+    assert G >= 1 and BATCH % G == 0, "--layout reference needs >= 2 ranks and a batch that splits over the actor ranks"
+    ctrl = dist.new_group(backend="gloo")  # counters / barriers of the main threads only (the exchange has its own order)
+    # RCCL moves device buffers; the one-GPU gloo rehearsal exchanges through host memory
+    exch = "cpu" if dist.get_backend() == "gloo" else device
+    specs = ff_field_specs(NUM_ACTION)
+    _, total = ffnet_flat_layout(NUM_ACTION)
+    K, R = args.steps, args.repeats
+    cycle = 20  # actor_sync_freq, pyrela/main.py:213-215
+    torch.manual_seed(SEED + 2)
+    agent = ApexAgent(lambda: AtariFFNet(NUM_ACTION), MULTI_STEP, GAMMA).to(device)
+    for p_ in agent.parameters():
+        dist.broadcast(p_.data, 0)
+    marks = []  # actor ranks: (publish index, monotonic time, ticks so far)
+    if rank == 0:
+        learner = HipApexLearner.from_agent(agent, BATCH, lr=6.25e-5, eps=1.5e-4, grad_clip=40.0)
+        learner.set_precision(args.precision)
+        rep = PartitionedReplay(specs, BATCH, BETA, exch, scheduled=True)
+        flat_on, flat_tg = learner.flat()[0], learner.flat_target()
+        on_exch = (lambda t: t) if exch == device else (lambda t: t.to(exch))
+        times = []
+
+        def run(n_steps, pending):
+            """n_steps learner steps; publishes at its start and every `cycle` steps; -> pending sample"""
+            done = 0
+            while done < n_steps:
+                seg = min(cycle, n_steps - done)
+                rep.publish(on_exch(flat_on), on_exch(flat_tg), steps=seg)
+                times.append(time.perf_counter())
+                if pending is None:
+                    pending = rep.sample(async_op=True)
+                for i in range(seg):
+                    fields, weight = pending.wait()
+                    if exch != device:
+                        fields, weight = {k: v.to(device) for k, v in fields.items()}, weight.to(device)
+                    loss, prio = learner.loss(ff_batch_namespace(fields), weight)
+                    rep.update_priority(prio)
+                    # the next gather runs under this step's backward half (not across a publish: that needs a command word)
+                    pending = rep.sample(async_op=True) if i + 1 < seg else None
+                    learner.grad()
+                    learner.apply()
+                done += seg
+            return pending
+
+        warm = max(cycle, (args.warmup + cycle - 1) // cycle * cycle)
+        pending = run(warm, None)
+        windows = []
+        for _ in range(R):
+            torch.cuda.synchronize()
+            i0, t0 = len(times), time.perf_counter()
+            pending = run(K, pending)
+            torch.cuda.synchronize()
+            windows.append((i0, len(times), t0, time.perf_counter()))
+        rep.publish(on_exch(flat_on), on_exch(flat_tg), steps=0)  # the closing mark of the last window
+        times.append(time.perf_counter())
+        rep.stop()
+    else:
+        g = rank - 1
+        online, target = FFNetHandle(NUM_ACTION, device), FFNetHandle(NUM_ACTION, device)
+        online.load_state_dict(agent.online_net.state_dict())
+        target.load_state_dict(agent.target_net.state_dict())
+        online.set_precision(args.precision)
+        target.set_precision(args.precision)
+        part = FFReplay(args.replay_cap // G, SEED + rank, ALPHA, BETA, 0, NUM_ACTION, device)
+        eps_all = generate_eps(0.4, 7, ROWS * G)
+        engine = ApexActorEngine(ROWS, K_GAMES, NUM_ACTION, MULTI_STEP, GAMMA, part, eps_all[g * ROWS:(g + 1) * ROWS], device,
+                                 seed=SEED + rank)
+        gen = torch.Generator(device=device)
+        gen.manual_seed(SEED + 7 + rank)
+        for h in range(MULTI_STEP + 1):
+            engine.obs_hist[h].copy_(torch.randint(0, 256, engine.obs_hist[h].shape, dtype=torch.uint8, device=device,
+                                                   generator=gen))
+        reward = torch.randint(-1, 2, (ROWS,), device=device, generator=gen).float()
+        term = (torch.rand((ROWS,), device=device, generator=gen) < 0.005).to(torch.uint8)
+        lock = threading.Lock()
+        ticks, stopped = [0], [False]
+        actor_stream = torch.cuda.Stream(device=device)
+
+        def tick():
+            with lock, torch.cuda.stream(actor_stream):
+                engine.act(online)
+                engine.post_step(reward, term, online, target, nonblocking=True)
+            ticks[0] += 1
+
+        while part.size() < BATCH:  # the partition must be able to serve before the learner asks
+            tick()
+        torch.cuda.synchronize()
+
+        def on_weights(on_flat, tg_flat):
+            marks.append((len(marks), time.perf_counter(), ticks[0]))
+            with lock, torch.cuda.stream(server_stream):
+                server_stream.wait_stream(actor_stream)
+                load_net_from_flat(online, on_flat.to(device, copy=True), NUM_ACTION)
+                load_net_from_flat(target, tg_flat.to(device, copy=True), NUM_ACTION)
+                actor_stream.wait_stream(server_stream)
+
+        server_stream = torch.cuda.Stream(device=device)
+
+        failure = []
+
+        def serve():
+            try:
+                torch.cuda.set_device(device)
+                with torch.cuda.stream(server_stream):
+                    srv = PartitionServer(FFPartition(part), specs, BATCH, BETA, exch, flat_sizes=(total, total),
+                                          on_weights=on_weights, scheduled=True)
+                    srv.serve_forever()
+            except BaseException as e:  # noqa: BLE001  (re-raised on the main thread)
+                failure.append(e)
+            finally:
+                stopped[0] = True
+
+    # both constructors create the actor subgroup collectively: rank 0 did it in PartitionedReplay(...), the actor ranks
+    # do it in PartitionServer(...) on their server threads
+    if rank != 0:
+        th = threading.Thread(target=serve, daemon=True)
+        th.start()
+        while not stopped[0]:
+            tick()
+            if ticks[0] % 8 == 0:
+                actor_stream.synchronize()  # (bounds the launch queue; the reference's actor threads block on act() too)
+        th.join()
+        torch.cuda.synchronize()
+        if failure:
+            raise failure[0]
+    # gather the actor ranks' marks on rank 0
+    mine = torch.zeros(4096, 2, dtype=torch.float64)
+    for i, t, c in marks:
+        mine[i, 0], mine[i, 1] = t, c
+    allm = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, allm, dst=0, group=ctrl)
+    if rank == 0:
+        ms, envs = [], []
+        for i0, i1, t0, t1 in windows:
+            # publish i0 opened the window, publish i1 (the first of the next run / the closing mark) ended it
+            n = sum(float(allm[r][i1, 1] - allm[r][i0, 1]) for r in range(1, world)) * ROWS
+            ms.append((t1 - t0) / K * 1e3)
+            envs.append(n / (t1 - t0))
+        med = int(np.argsort(ms)[len(ms) // 2])
+        out = {
+            "metric": "env-steps/s (Ape-X Atari 84x84x4, 1 learner GPU + %d actor GPUs, the reference's own layout)" % G,
+            "value": envs[med], "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": ms[med], "repeats": R, "ms_per_step_repeats": ms, "env_steps_per_s_repeats": envs,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "f32" else DTYPE_NOTE, "data": "synthetic",
+            "config": {"workload": "Ape-X DQN in the reference's multi-GPU layout (pyrela/main.py:131-166, BASELINE C3): ONE "
+                                   "learner GPU (batch 512) + %d actor-only GPUs x 80 threads x 80 games (6400 envs each), one "
+                                   "replay partition of 2^20 / %d per actor GPU, B / G rows sampled per partition; "
+                                   "device-resident static frames" % (G, G),
+                       "layout": "reference", "actor_gpus": G, "envs_per_actor_gpu": ROWS, "learner_batch": BATCH,
+                       "replay_capacity_total": args.replay_cap, "parallelism": "1 learner + %d actor shards / replay partitions" % G},
+            "grad_steps_per_s": 1e3 / ms[med], "learner": "hip (csrc/learner.hip)",
+            "comm": {"backend": dist.get_backend(), "rccl_ranks": world if dist.get_backend() == "nccl" else 0, "ranks": world,
+                     "collectives_per_step": "1 packed gather (B/G rows per partition), 1 priority scatter, all-reduce SUM "
+                                             "(partition size) + MAX (IS-weight maximum) among the actor ranks; 2 broadcasts "
+                                             "of 6.8 MB + 1 command word every %d steps" % cycle},
+        }
+        print(json.dumps(out))
+    dist.barrier(group=ctrl)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -499,6 +686,10 @@ def main():
                     help="arithmetic of the actors' conv2 / conv3 / fc: bf16x2 = split-bf16 MFMA (hi + lo bf16 operands, "
                          "three products, f32 accumulation; Q within 1e-6 of the f32 path in tests/test_ffnet_gpu.py, stated "
                          "tolerance 1e-4), f32 = exact f32 MFMA (the parity mode, round 1's headline)")
+    ap.add_argument("--layout", default="replicated", choices=["replicated", "reference"],
+                    help="N > 1: replicated (default) = actors + replay partition + learner replica on every rank, gradient "
+                         "all-reduce; reference = the reference's own layout, ONE learner rank + N - 1 actor-only ranks "
+                         "with replay partitions (pyrela/main.py:131-166, BASELINE C3 / C4)")
     ap.add_argument("--algo", default="apex", help="apex (BASELINE.json's metric, the default) | r2d2 (config C4's "
                                                    "sequence shape: seq 80 / burn-in 40 / n 3, 3200 envs, B = 64)")
     args = ap.parse_args()
@@ -539,6 +730,8 @@ def main():
         dist.barrier()
     if args.algo == "r2d2":
         return bench_r2d2(args, world, rank, device)
+    if args.layout == "reference" and world > 1:
+        return bench_reference_layout(args, world, rank, device, rehearsal)
     from rela_amd import _capi as capi
     from rela_amd.engine import ApexActorEngine, FFNetHandle
     from rela_amd.engine import dev_view
@@ -869,8 +1062,7 @@ def main():
                                 "`repeats` times back to back; ms_per_step and value are the MEDIAN repeat",
             "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f32 results from split-bf16 MFMA (bf16 hi+lo operands, 2-3 bf16 "
-                                                           "products per product, f32 accumulate; |dQ| < 2e-6 vs the f32 path)",
+            "dtype": "f32" if args.precision == "f32" else DTYPE_NOTE,
             "data": "synthetic",
             "config": {"workload": "Ape-X DQN, 80 threads x 80 games (6400 envs) per GPU, actor+learner on one "
                                    "MI355X, replay 2^20 per GPU device-resident, A=18, n=3, ONE learner batch of 512 per "

@@ -1871,7 +1871,7 @@ using FcFast = FcFastT<112>;
 // SPLIT (batches of a few hundred rows, where 4 x ceil(N / BM) blocks would leave most CUs idle): blockIdx.z owns the
 // positions [z * per, z * per + per) of the contraction and writes its raw partial sums to out[z][N][512]; fc_reduce adds
 // them up in z order with the bias and the ReLU.  Without SPLIT the range is the compile-time [0, 49).
-template <class F, bool SPLIT = false>
+template <class F, bool SPLIT = false, int BD = 2>
 __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__ A, const uint4* __restrict__ Bfrag,
                                                      const float* __restrict__ bias, float* __restrict__ out, int N,
                                                      int per) {
@@ -1952,11 +1952,13 @@ __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__
       if constexpr (SB == 0) bcur[q] = bq0[q]; else bcur[q] = bq1[q];
     }
     {
-      const int pn = min(pos + 2, p1 - 1);
+      // BD = 2: this set is refilled for position pos + 2; BD = 1 (the r2 schedule, kept for A/B runs:
+      // RELA_FC_BDEPTH=1): the OTHER set gets position pos + 1
+      const int pn = min(pos + BD, p1 - 1);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const uint4 v = bp[(size_t)(pn * 4 + q) * 64];
-        if constexpr (SB == 0) bq0[q] = v; else bq1[q] = v;
+        if constexpr ((SB == 0) == (BD == 2)) bq0[q] = v; else bq1[q] = v;
       }
     }
     const int nbuf = (buf == F::NBUF - 1) ? 0 : buf + 1;
@@ -2573,6 +2575,8 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv12S::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv3F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv3F::LDS_TOTAL));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s<FcFast, false, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, FcFast::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s<FcFast, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, FcFast::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s<FcFast>),
@@ -2808,8 +2812,14 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     }
     {
       ProfScope prof(names[3], s);
-      note_launch("fc_bf16s"); hipLaunchKernelGGL(fc_bf16s<FcFast>, dim3(4, ceil_div(N, FcFast::BM)), dim3(kThreads), FcFast::LDS_BYTES, s,
-                         (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, h, N, 0);
+      static const int bdepth = getenv("RELA_FC_BDEPTH") ? atoi(getenv("RELA_FC_BDEPTH")) : 2;
+      note_launch("fc_bf16s");
+      if (bdepth == 1)
+        hipLaunchKernelGGL((fc_bf16s<FcFast, false, 1>), dim3(4, ceil_div(N, FcFast::BM)), dim3(kThreads), FcFast::LDS_BYTES, s,
+                           (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, h, N, 0);
+      else
+        hipLaunchKernelGGL(fc_bf16s<FcFast>, dim3(4, ceil_div(N, FcFast::BM)), dim3(kThreads), FcFast::LDS_BYTES, s,
+                           (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, h, N, 0);
     }
   } else {
   if (!fast_trunk_only) {

@@ -27,6 +27,11 @@ def create_game(seed, eps, episode_len):
     # repeated four times: atari/game_state.h:53-82) instead of four fresh planes per step -- a quarter of the host
     # work per env-step, and the stacks a de-duplicating replay (RELA_REPLAY_DEDUP=plane) expects
     sliding = os.environ.get("RELA_SYNTH_SLIDING", "0") == "1"
+    if os.environ.get("RELA_REPLAY_DEDUP") == "plane" and not sliding:
+        # plane mode stores ONE new plane per env-step and rebuilds a stack from the previous step's planes: with an
+        # env that emits four fresh planes per step it would hand the learner stacks that never existed
+        raise ValueError("RELA_REPLAY_DEDUP=plane needs an env whose frame stack slides by one plane per step: set "
+                         "RELA_SYNTH_SLIDING=1 (or use RELA_REPLAY_DEDUP=stack, which is valid for any env)")
     return synth_atari.SyntheticAtariEnv(seed, eps, NUM_ACTION, episode_len, sliding)
 
 
