@@ -366,6 +366,65 @@ __global__ __launch_bounds__(kLT) void learner_loss_grad(const float* __restrict
   if (threadIdx.x == 0) loss_out[0] = red[0] * inv_b;
 }
 
+// td_err (apex.py:30-45: batch-global q.min() of greedy_act(next_obs), double-DQN target, un-fused arithmetic as
+// agent_ops.hip's td_kernel) + the loss kernel above in ONE single-workgroup launch (two latency-bound launches
+// before: 15 + 19 us).  Same arithmetic in the same order, so priorities, loss and d_ha are bit-identical.
+__global__ __launch_bounds__(1024) void learner_td_loss_grad(int Bn, int A, const float* __restrict__ q,
+                                                             const float* __restrict__ qno, const float* __restrict__ qnt,
+                                                             const float* __restrict__ nlegal,
+                                                             const int64_t* __restrict__ act,
+                                                             const float* __restrict__ reward,
+                                                             const float* __restrict__ bootstrap, float gamma_n,
+                                                             const float* __restrict__ w, const float* __restrict__ legal,
+                                                             float* __restrict__ td, float* __restrict__ prio,
+                                                             float* __restrict__ d_ha, float* __restrict__ loss_out) {
+  __shared__ float red[1024];
+  float m = INFINITY;
+  for (int i = threadIdx.x; i < Bn * A; i += 1024) m = fminf(m, qno[i]);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 512; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] = fminf(red[threadIdx.x], red[threadIdx.x + off]);
+    __syncthreads();
+  }
+  const float qmin = red[0];
+  __syncthreads();
+  float lsum = 0.f;
+  const float inv_b = 1.0f / (float)Bn, inv_a = 1.0f / (float)A;
+  for (int i = threadIdx.x; i < Bn; i += 1024) {
+    int na = 0;
+    float bv = -INFINITY;
+    for (int j = 0; j < A; ++j) {  // greedy_act(next_obs): first maximal index of (1 + q - qmin) * legal (apex.py:51)
+      const float lq = __fmul_rn(__fsub_rn(__fadd_rn(1.0f, qno[(size_t)i * A + j]), qmin), nlegal[(size_t)i * A + j]);
+      if (lq > bv) bv = lq, na = j;
+    }
+    const int a = (int)act[i];
+    const float qa = q[(size_t)i * A + a];
+    const float bq = qnt[(size_t)i * A + na];
+    const float tgt = __fadd_rn(reward[i], __fmul_rn(__fmul_rn(bootstrap[i], gamma_n), bq));
+    const float e = __fsub_rn(tgt, qa), ae = fabsf(e);
+    td[i] = e;
+    prio[i] = ae;
+    lsum += (ae < 1.0f ? 0.5f * e * e : ae - 0.5f) * w[i];
+    const float g = -(w[i] * fminf(fmaxf(e, -1.0f), 1.0f)) * inv_b;
+    float* row = d_ha + (size_t)i * 32;
+    for (int k = 0; k < 32; ++k) {
+      float v = 0.f;
+      if (k < A) v = legal[(size_t)i * A + k] * (g * ((k == a ? 1.0f : 0.0f) - inv_a));
+      if (k == 31) v = g;
+      row[k] = v;
+    }
+  }
+  // the same tree as learner_loss_grad's kLT = 512 lanes when Bn <= 512: lanes >= 512 hold zeros and fold in first
+  red[threadIdx.x] = lsum;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss_out[0] = red[0] * inv_b;
+}
+
 // ---- weight copies in the k order the dgrad GEMMs read (ffnet_layout.h: permute_weight_at) ------
 __global__ void permute_weights(int mode, const float* __restrict__ src, float* __restrict__ dst, int total) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;

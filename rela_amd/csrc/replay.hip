@@ -700,6 +700,14 @@ extern "C" int rela_replay_set_block_min_unit(rela_replay* r, int first_slot, in
   RELA_CHECK(r && r->dd_ups > 0 && n > 0 && first_slot >= 0 && first_slot < r->ring && n <= r->ring, RELA_EINVAL,
              "rela_replay_set_block_min_unit: bad arguments");
   std::lock_guard<std::mutex> lk(r->m);
+  // units_reserve protects the units the live slots declare (dd_slot_min); units a producer has stored AHEAD of the
+  // transitions that will refer to them rest on the guard window (guard_units) bounding the skew between producers.
+  // A producer that was stalled past that window would commit references to units that have been overwritten since:
+  // refuse the block loudly instead (the actor's thread then stops its Context with this error).
+  RELA_CHECK(min_seq >= r->dd_next_seq - r->dd_cap, RELA_ESTATE,
+             "rela_replay_set_block_min_unit: block refers to unit %lld but units below %lld were already overwritten "
+             "(a producer fell more than the guard window of %lld units behind: raise guard_units)",
+             (long long)min_seq, (long long)(r->dd_next_seq - r->dd_cap), (long long)(r->dd_cap - r->ring));
   for (int i = 0; i < n; ++i) r->dd_slot_min[(size_t)((first_slot + i) % r->ring)] = min_seq;
   return RELA_OK;
 }
