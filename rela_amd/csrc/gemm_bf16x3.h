@@ -1,0 +1,228 @@
+// gemm_bf16x3.h -- the learner's small f32 GEMMs on the bf16 matrix cores, with the SAME loader functors as gemm_lds.h.
+//
+//   C[M][N] = sum_k A(m,k) * B(k,n),  A and B delivered as f32 by the Problem's loadA / loadB (im2col, transposition and
+//   u8 -> f32 conversion stay index arithmetic in the loader), optional split-K over blockIdx.z -> Problem::store(z, ..).
+//
+// gemm_lds.h multiplies on v_mfma_f32_16x16x4_f32 (157 TFLOP/s peak); at the learner's sizes (batch 512: K = 512 for
+// the fc layer, 25 k - 41 k for the conv weight gradients, 64 - 512 output rows) its blocks also wait out every K-chunk's
+// load latency.  Here every operand is split on the way INTO LDS into bf16 hi = bf16(x) and lo = bf16(x - hi) (16
+// significant bits together) and a product is  a_lo*b_hi + a_hi*b_lo + a_hi*b_hi  on v_mfma_f32_16x16x32_bf16 with f32
+// accumulation: ~2^-16 relative per product, 16 x the MFMA rate per instruction and 8 x the k per instruction.
+//
+// LDS images are K-MAJOR for an operand that arrives m- (or n-) contiguous -- the transposed operand of a weight
+// gradient, and every B -- : rows = k, columns = m, exactly what the loader's float4 fills with one 8-byte store per
+// half, and the MFMA fragment (8 consecutive k of one row m per lane) comes out of TWO ds_read_b64_tr_b16, the
+// hardware's transposing read (cdna_hip_programming.md T10): per 16-lane group a block of 4 k-rows x 16 columns is
+// delivered column-major.  The 32 k of a step are stored in the order  row(8g + j) = 4g + j (j < 4), 16 + 4g + (j - 4)
+// so that the two lane groups of a 32-lane half read 8 CONSECUTIVE image rows; with a row stride of 8 (mod 16) x odd
+// banks (BM * 2 + 32 bytes, BM a multiple of 32) those 8 rows x 8 banks cover the 64 banks once: conflict-free.
+// An A that arrives k-contiguous (the data-gradient GEMMs) gets an [m][k] image and plain ds_read_b128 fragments.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "gemm_lds.h"
+#include "prof.h"
+
+namespace rela_amd {
+namespace gemm3 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_ptr;
+
+constexpr int kT = 512;  // 8 wavefronts
+constexpr int BK = 32;   // one MFMA k-step per staged chunk
+
+// image row of logical k (0..31) of a chunk
+__device__ __forceinline__ int krow(int k) {
+  const int g = k >> 3, j = k & 7;
+  return j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4);
+}
+
+// four floats -> 4 bf16 hi (8 bytes) and 4 bf16 lo
+__device__ __forceinline__ void split4(float4 v, uint2& hi, uint2& lo) {
+  const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+  const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
+  const bf16x2 la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2), bf16x2);
+  const bf16x2 lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2), bf16x2);
+  hi = make_uint2(__builtin_bit_cast(uint32_t, ha), __builtin_bit_cast(uint32_t, hb));
+  lo = make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
+}
+
+// AMC as in gemm_lds.h: true = loadA(k, m) returns A[m..m+3][k] (m-contiguous, k-major image, transposed reads);
+// false = loadA(m, k) returns A[m][k..k+3] (k-contiguous, [m][k] image, row reads).  B: loadB(k, n) -> B[k][n..n+3].
+template <int BM_, int BN_, int WM_, int WN_, bool AMC_>
+struct TileCfg {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr bool AMC = AMC_;
+  static_assert(WM * WN == 8, "8 wavefronts per block");
+  static_assert(BM % 32 == 0 && BN % 32 == 0, "k-major row strides need multiples of 32 columns");
+  static constexpr int TM = BM / 16 / WM, TN = BN / 16 / WN;  // 16x16 tiles per wave
+  static_assert(TM >= 1 && TN >= 1, "tile too small for the wave grid");
+  static constexpr int LDA = AMC ? BM * 2 + 32 : BK * 2 + 16;  // bytes per image row ([k][m] or [m][k])
+  static constexpr int A_HALF = AMC ? BK * LDA : BM * LDA;     // bytes of one of hi / lo
+  static constexpr int LDB = BN * 2 + 32;
+  static constexpr int B_HALF = BK * LDB;
+  static constexpr int BUF = 2 * A_HALF + 2 * B_HALF;          // one stage
+  static constexpr int LDS_BYTES = 2 * BUF;
+  static constexpr int A_V4 = BM * BK / 4, B_V4 = BN * BK / 4;
+  static constexpr int A_IT = (A_V4 + kT - 1) / kT, B_IT = (B_V4 + kT - 1) / kT;
+};
+
+template <class T, class P>
+__global__ __launch_bounds__(kT) void gemm_bf16x3(const P p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int wm = wave / T::WN, wn = wave % T::WN;
+  const int m0 = blockIdx.y * T::BM, n0 = blockIdx.x * T::BN;
+  const int nch = (p.K + BK - 1) / BK;
+  const int c0 = blockIdx.z * p.kslice;
+  const int c1 = min(nch, c0 + p.kslice);
+
+  float4 ra[T::A_IT], rb[T::B_IT];
+  auto gload = [&](int ch) {
+    const int k0 = ch * BK;
+#pragma unroll
+    for (int j = 0; j < T::A_IT; ++j) {
+      const int idx = min(tid + j * kT, T::A_V4 - 1);  // (clamped, not predicated: a surplus thread repeats a neighbour)
+      if constexpr (T::AMC) {
+        const int kr = idx / (T::BM / 4), q = idx % (T::BM / 4);
+        ra[j] = p.loadA(k0 + kr, m0 + 4 * q);
+      } else {
+        const int r = idx >> 3, q = idx & 7;
+        ra[j] = p.loadA(m0 + r, k0 + 4 * q);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < T::B_IT; ++j) {
+      const int idx = min(tid + j * kT, T::B_V4 - 1);
+      const int kr = idx / (T::BN / 4), q = idx % (T::BN / 4);
+      rb[j] = p.loadB(k0 + kr, n0 + 4 * q);
+    }
+  };
+  auto sstore = [&](int buf) {
+    uint8_t* base = smem + buf * T::BUF;
+#pragma unroll
+    for (int j = 0; j < T::A_IT; ++j) {
+      const int idx = min(tid + j * kT, T::A_V4 - 1);
+      uint2 hi, lo;
+      split4(ra[j], hi, lo);
+      int off;
+      if constexpr (T::AMC) {
+        const int kr = idx / (T::BM / 4), q = idx % (T::BM / 4);
+        off = krow(kr) * T::LDA + q * 8;
+      } else {
+        const int r = idx >> 3, q = idx & 7;
+        off = r * T::LDA + q * 8;
+      }
+      *reinterpret_cast<uint2*>(base + off) = hi;
+      *reinterpret_cast<uint2*>(base + T::A_HALF + off) = lo;
+    }
+    uint8_t* bb = base + 2 * T::A_HALF;
+#pragma unroll
+    for (int j = 0; j < T::B_IT; ++j) {
+      const int idx = min(tid + j * kT, T::B_V4 - 1);
+      const int kr = idx / (T::BN / 4), q = idx % (T::BN / 4);
+      uint2 hi, lo;
+      split4(rb[j], hi, lo);
+      const int off = krow(kr) * T::LDB + q * 8;
+      *reinterpret_cast<uint2*>(bb + off) = hi;
+      *reinterpret_cast<uint2*>(bb + T::B_HALF + off) = lo;
+    }
+  };
+
+  // transposed fragment of a k-major image: rows 4g + q and 16 + 4g + q, columns col0 + 4p .. + 3 (lane = 16g + 4q + p)
+  const int tr_off = (4 * g + (li >> 2));  // image row of the first read; + 16 rows for the second
+  auto frag_tr = [&](const uint8_t* img, int ld, int col0) -> bf16x8 {
+    const uint8_t* a0 = img + tr_off * ld + (col0 + 4 * (li & 3)) * 2;
+    const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));
+    const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0 + 16 * ld));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 z = {x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+    return __builtin_bit_cast(bf16x8, z);
+  };
+  // row fragment of an [m][k] image: 8 consecutive k (16 bytes) of row `row`
+  auto frag_row = [&](const uint8_t* img, int row) -> bf16x8 {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + row * T::LDA + g * 16));
+  };
+
+  f32x4 acc[T::TM][T::TN];
+#pragma unroll
+  for (int t = 0; t < T::TM; ++t)
+#pragma unroll
+    for (int u = 0; u < T::TN; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (c0 < c1) {
+    gload(c0);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int ch = c0; ch < c1; ++ch) {
+    const int buf = (ch - c0) & 1;
+    if (ch + 1 < c1) gload(ch + 1);
+    const uint8_t* base = smem + buf * T::BUF;
+    const uint8_t* bb = base + 2 * T::A_HALF;
+    bf16x8 bh[T::TN], bl[T::TN];
+#pragma unroll
+    for (int u = 0; u < T::TN; ++u) {
+      const int col0 = (wn * T::TN + u) * 16;
+      bh[u] = frag_tr(bb, T::LDB, col0);
+      bl[u] = frag_tr(bb + T::B_HALF, T::LDB, col0);
+    }
+#pragma unroll
+    for (int t = 0; t < T::TM; ++t) {
+      const int row0 = (wm * T::TM + t) * 16;
+      bf16x8 ah, al;
+      if constexpr (T::AMC) {
+        ah = frag_tr(base, T::LDA, row0);
+        al = frag_tr(base + T::A_HALF, T::LDA, row0);
+      } else {
+        ah = frag_row(base, row0 + li);
+        al = frag_row(base + T::A_HALF, row0 + li);
+      }
+#pragma unroll
+      for (int u = 0; u < T::TN; ++u) {
+        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[u], acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[u], acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[u], acc[t][u], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < c1) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t = 0; t < T::TM; ++t)
+#pragma unroll
+    for (int u = 0; u < T::TN; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + (wm * T::TM + t) * 16 + g * 4 + r;
+        const int n = n0 + (wn * T::TN + u) * 16 + li;
+        if (m < p.M && n < p.N) p.store(blockIdx.z, m, n, acc[t][u][r]);
+      }
+}
+
+// same contract as gemm::launch_gemm (the Problem's kslice is counted in chunks of BK = 32 here as well)
+template <class T, class P>
+int launch_gemm(P p, int splits, hipStream_t s, const char* name) {
+  static const hipError_t attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3<T, P>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+  RELA_HIP(attr_set);
+  const int nch = ceil_div(p.K, BK);
+  p.kslice = ceil_div(nch, splits);
+  ProfScope prof(name, s);
+  note_launch("gemm_bf16x3");
+  hipLaunchKernelGGL((gemm_bf16x3<T, P>), dim3(ceil_div(p.N, T::BN), ceil_div(p.M, T::BM), splits), dim3(kT), T::LDS_BYTES, s,
+                     p);
+  return RELA_OK;
+}
+
+}  // namespace gemm3
+}  // namespace rela_amd

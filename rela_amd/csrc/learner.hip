@@ -333,19 +333,22 @@ extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
   for (int i = 0; i < 12; ++i) Gm[i] = l->G + l->off[i];
 
   ColsumJobs sums;  // the five bias gradients: queued here, one launch pair at the end of trunk_backward
+  const bool g3 = rela_ffnet_precision(l->online) == 1 && gemm_bf16x3_on();  // bf16x2: the GEMMs on bf16 MFMA too
 
   // heads: d_h, dWh, db
   {
     ProbHeadDgrad p{};
     p.M = Bn, p.N = 512, p.K = 32;
     p.d_ha = l->d_ha, p.a_w = P.a_w, p.v_w = P.v_w, p.h = w.h, p.d_h = l->d_h, p.A = A;
-    launch_gemm<TileDgrad>(p, 1, s, "learner_dgrad_heads");
+    if (g3) (void)gemm3::launch_gemm<Tile3Dgrad>(p, 1, s, "learner_dgrad_heads");
+    else launch_gemm<TileDgrad>(p, 1, s, "learner_dgrad_heads");
   }
   {
     ProbHeadWgrad p{};
     p.M = 32, p.N = 512, p.K = Bn;
     p.d_ha = l->d_ha, p.h = w.h, p.g_a_w = Gm[10], p.g_v_w = Gm[8], p.A = A;
-    launch_gemm<TileW32>(p, 1, s, "learner_wgrad_heads");
+    if (g3) (void)gemm3::launch_gemm<Tile3W32>(p, 1, s, "learner_wgrad_heads");
+    else launch_gemm<TileW32>(p, 1, s, "learner_wgrad_heads");
   }
   sums.add(l->d_ha, Bn, 32, l->s32);
   // fc: d_a3, dWfc, db
@@ -353,13 +356,15 @@ extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
     ProbFcDgrad p{};
     p.M = Bn, p.N = 3136, p.K = 512;
     p.d_h = l->d_h, p.wfcp = l->wfcp, p.a3 = w.a3, p.d_a3 = l->d_a3;
-    launch_gemm<TileDgrad>(p, 1, s, "learner_dgrad_fc");
+    if (g3) (void)gemm3::launch_gemm<Tile3Dgrad>(p, 1, s, "learner_dgrad_fc");
+    else launch_gemm<TileDgrad>(p, 1, s, "learner_dgrad_fc");
   }
   {
     ProbFcWgrad p{};
     p.M = 512, p.N = 3136, p.K = Bn;
     p.d_h = l->d_h, p.a3 = w.a3, p.g_fc_w = Gm[6];
-    launch_gemm<TileWfc>(p, 1, s, "learner_wgrad_fc");
+    if (g3) (void)gemm3::launch_gemm<Tile3Wfc>(p, 1, s, "learner_wgrad_fc");
+    else launch_gemm<TileWfc>(p, 1, s, "learner_wgrad_fc");
   }
   sums.add(l->d_h, Bn, 512, Gm[7]);
   {

@@ -10,6 +10,7 @@
 #include "common.h"
 #include "ffnet_layout.h"
 #include "gemm_lds.h"
+#include "gemm_bf16x3.h"
 #include "prof.h"
 #include "dgrad_conv_bf16.h"
 #include "wgrad_conv1_bf16.h"
@@ -25,6 +26,16 @@ using TileDgrad = TileCfg<128, 64, 4, 2, false>;  // M = batch rows, A k-contigu
 using TileWfc = TileCfg<128, 64, 4, 2, true>;     // fc weight gradient (M = 512 units)
 using TileW64 = TileCfg<64, 64, 2, 4, true>;      // conv2 / conv3 weight gradients (M = 64 channels)
 using TileW32 = TileCfg<32, 64, 2, 4, true>;      // conv1 / head weight gradients (M = 32)
+// the same shapes on the bf16 matrix cores (gemm_bf16x3.h: operands split into bf16 hi + lo on the way into LDS, three
+// MFMAs per product): the learners' bf16x2 mode.  RELA_LEARNER_GEMM=f32 keeps the f32 MFMA GEMMs.
+using Tile3Dgrad = gemm3::TileCfg<128, 64, 4, 2, false>;
+using Tile3Wfc = gemm3::TileCfg<128, 64, 4, 2, true>;
+using Tile3W64 = gemm3::TileCfg<64, 64, 2, 4, true>;
+using Tile3W32 = gemm3::TileCfg<32, 64, 2, 4, true>;
+inline bool gemm_bf16x3_on() {
+  static const bool off = getenv("RELA_LEARNER_GEMM") && strcmp(getenv("RELA_LEARNER_GEMM"), "f32") == 0;
+  return !off;
+}
 
 
 // d_h[b][u] = relu'(h) * sum_k d_ha[b][k] * Wh[k][u]      Wh rows: 0..A-1 = fc_a.weight, 31 = fc_v.weight
@@ -599,7 +610,8 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     // every chunk's load latency with two waves per SIMD)
     static const int mul = getenv("RELA_WGRAD_SPLIT_MUL") ? atoi(getenv("RELA_WGRAD_SPLIT_MUL")) : 3;
     const int split3 = Bn <= 1024 ? kSplitW3 * mul : kSplitW3;
-    launch_gemm<TileW64>(p, split3, s, "learner_wgrad_conv3");
+    if (t.fast && gemm_bf16x3_on()) (void)gemm3::launch_gemm<Tile3W64>(p, split3, s, "learner_wgrad_conv3");
+    else launch_gemm<TileW64>(p, split3, s, "learner_wgrad_conv3");
     hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 576, 256)), dim3(256), 0, s, (const float*)t.part, split3, 64,
                        576, kRedConv3, t.g_c3w);
   }
@@ -630,7 +642,8 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     p.d_out = t.d_a2, p.in = t.a1, p.part = t.part;
     static const int mul = getenv("RELA_WGRAD_SPLIT_MUL") ? atoi(getenv("RELA_WGRAD_SPLIT_MUL")) : 3;
     const int split2 = Bn <= 1024 ? kSplitW2 * mul : kSplitW2;
-    launch_gemm<TileW64>(p, split2, s, "learner_wgrad_conv2");
+    if (t.fast && gemm_bf16x3_on()) (void)gemm3::launch_gemm<Tile3W64>(p, split2, s, "learner_wgrad_conv2");
+    else launch_gemm<TileW64>(p, split2, s, "learner_wgrad_conv2");
     hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 512, 256)), dim3(256), 0, s, (const float*)t.part, split2, 64,
                        512, kRedConv2, t.g_c2w);
   }
