@@ -20,6 +20,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "gemm_lds.h"
 #include "prof.h"
@@ -85,34 +87,41 @@ __global__ __launch_bounds__(kT) void gemm_bf16x3(const P p) {
   const int c0 = blockIdx.z * p.kslice;
   const int c1 = min(nch, c0 + p.kslice);
 
-  float4 ra[T::A_IT], rb[T::B_IT];
-  auto gload = [&](int ch) {
+  // Staging registers: D chunks in flight.  A chunk is 24 (or fewer) MFMAs per wave -- far less than one load's
+  // latency -- and these GEMMs have only a handful of chunks per block (fc at batch 512: 16), so with ONE chunk
+  // ahead (gemm_lds.h) every chunk waited out its loads: 29 us for the fc weight gradient, 16 x ~1.5 us.  Chunk c of
+  // the block lives in register set (c - c0) % D; the chunk loop is unrolled by D so that the sets are named statically.
+  constexpr int D = 4;
+  float4 ra[D][T::A_IT], rb[D][T::B_IT];
+  auto gload = [&](int ch, auto set) {
+    constexpr int S = decltype(set)::value;
     const int k0 = ch * BK;
 #pragma unroll
     for (int j = 0; j < T::A_IT; ++j) {
       const int idx = min(tid + j * kT, T::A_V4 - 1);  // (clamped, not predicated: a surplus thread repeats a neighbour)
       if constexpr (T::AMC) {
         const int kr = idx / (T::BM / 4), q = idx % (T::BM / 4);
-        ra[j] = p.loadA(k0 + kr, m0 + 4 * q);
+        ra[S][j] = p.loadA(k0 + kr, m0 + 4 * q);
       } else {
         const int r = idx >> 3, q = idx & 7;
-        ra[j] = p.loadA(m0 + r, k0 + 4 * q);
+        ra[S][j] = p.loadA(m0 + r, k0 + 4 * q);
       }
     }
 #pragma unroll
     for (int j = 0; j < T::B_IT; ++j) {
       const int idx = min(tid + j * kT, T::B_V4 - 1);
       const int kr = idx / (T::BN / 4), q = idx % (T::BN / 4);
-      rb[j] = p.loadB(k0 + kr, n0 + 4 * q);
+      rb[S][j] = p.loadB(k0 + kr, n0 + 4 * q);
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, auto set) {
+    constexpr int S = decltype(set)::value;
     uint8_t* base = smem + buf * T::BUF;
 #pragma unroll
     for (int j = 0; j < T::A_IT; ++j) {
       const int idx = min(tid + j * kT, T::A_V4 - 1);
       uint2 hi, lo;
-      split4(ra[j], hi, lo);
+      split4(ra[S][j], hi, lo);
       int off;
       if constexpr (T::AMC) {
         const int kr = idx / (T::BM / 4), q = idx % (T::BM / 4);
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(kT) void gemm_bf16x3(const P p) {
       const int idx = min(tid + j * kT, T::B_V4 - 1);
       const int kr = idx / (T::BN / 4), q = idx % (T::BN / 4);
       uint2 hi, lo;
-      split4(rb[j], hi, lo);
+      split4(rb[S][j], hi, lo);
       const int off = krow(kr) * T::LDB + q * 8;
       *reinterpret_cast<uint2*>(bb + off) = hi;
       *reinterpret_cast<uint2*>(bb + T::B_HALF + off) = lo;
@@ -158,14 +167,21 @@ __global__ __launch_bounds__(kT) void gemm_bf16x3(const P p) {
 #pragma unroll
     for (int u = 0; u < T::TN; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (c0 < c1) {
-    gload(c0);
-    sstore(0);
-  }
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  using S3 = std::integral_constant<int, 3>;
+  if (c0 < c1) gload(c0, S0{});
+  if (c0 + 1 < c1) gload(c0 + 1, S1{});
+  if (c0 + 2 < c1) gload(c0 + 2, S2{});
+  if (c0 + 3 < c1) gload(c0 + 3, S3{});
+  if (c0 < c1) sstore(0, S0{});
   __syncthreads();
-  for (int ch = c0; ch < c1; ++ch) {
-    const int buf = (ch - c0) & 1;
-    if (ch + 1 < c1) gload(ch + 1);
+  // one chunk: LDS[buf] holds chunk `cur` (stored a step ago from set `cs`, which is free now): refill that set with
+  // chunk cur + D, multiply chunk cur, store chunk cur + 1 (set `ns`, loaded D - 1 steps ago) into the other buffer
+  auto step = [&](int cur, auto cs, auto ns) {
+    const int buf = (cur - c0) & 1;
+    if (cur + D < c1) gload(cur + D, cs);
     const uint8_t* base = smem + buf * T::BUF;
     const uint8_t* bb = base + 2 * T::A_HALF;
     bf16x8 bh[T::TN], bl[T::TN];
@@ -193,8 +209,14 @@ __global__ __launch_bounds__(kT) void gemm_bf16x3(const P p) {
         acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[u], acc[t][u], 0, 0, 0);
       }
     }
-    if (ch + 1 < c1) sstore(buf ^ 1);
+    if (cur + 1 < c1) sstore(buf ^ 1, ns);
     __syncthreads();
+  };
+  for (int base = c0; base < c1; base += D) {  // (the conditions below are block-uniform)
+    step(base, S0{}, S1{});
+    if (base + 1 < c1) step(base + 1, S1{}, S2{});
+    if (base + 2 < c1) step(base + 2, S2{}, S3{});
+    if (base + 3 < c1) step(base + 3, S3{}, S0{});
   }
 
 #pragma unroll
