@@ -17,7 +17,7 @@ cp $F/bench_only_actor.json profiles/r03_bench_only_actor.json
 cp $F/bench_layout_reference_rehearsal.json profiles/r03_bench_layout_reference_rehearsal_2ranks_one_gpu.json
 cp $F/bench_rehearsal_2ranks.json profiles/r03_bench_rehearsal_2ranks_one_gpu.json
 cp "$(newest "$F/prof_bench/*/*_kernel_stats.csv")" profiles/r03_bench_kernel_stats.csv
-python3 tools/per_shape_stats.py $F/prof_bench profiles/r03_bench_kernel_per_shape.csv
+[ -f $F/bench_kernel_per_shape.csv ] && cp $F/bench_kernel_per_shape.csv profiles/r03_bench_kernel_per_shape.csv || true
 mkdir -p profiles/r03_pmc
 for d in pmc_fetch pmc_write pmc_sq; do cp "$(newest "$F/$d/*/*_counter_collection.csv")" profiles/r03_pmc/${d}_counter_collection.csv; done
 python3 - <<'PY'

@@ -46,5 +46,6 @@ RELA_BENCH_REHEARSAL=1 timeout -k 10 300 python -m torch.distributed.run --nnode
 cut -c1-300 $O/bench_layout_reference_rehearsal.json
 RELA_BENCH_REHEARSAL=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --steps 100 --warmup 5 --repeats 3 --replay-cap 262144 --no-cpu-baseline > $O/bench_rehearsal_2ranks.json 2> $O/bench_rehearsal_2ranks.err || { tail -5 $O/bench_rehearsal_2ranks.err; exit 16; }
 cut -c1-300 $O/bench_rehearsal_2ranks.json
+python3 tools/per_shape_stats.py $O/prof_bench $O/bench_kernel_per_shape.csv || exit 17  # (before the large traces go)
 find $O -name "*.csv" -size +8M -delete
 echo "evidence pass complete"
