@@ -104,3 +104,70 @@ def test_dedup_plane_survives_dropped_blocks():
         for s, ns in zip(rec["s"], rec["ns"]):
             t0, r0 = int(s[3, 0, 0]), int(s[3, 0, 1])  # newest plane of obs: (tick, row)
             assert np.array_equal(s, stacks[t0, r0]) and np.array_equal(ns, stacks[t0 + n, r0])
+
+
+def test_dedup_plane_ring_of_2p23_slots_on_one_gpu():
+    """BASELINE C5's replay size on ONE GPU: capacity 2^23 (ring 10,485,760 slots) with de-duplicated planes -- 74 GB of
+    unit storage instead of the 592 GB two full stacks per slot would take.  6,400 envs feed it through the actor shard
+    until the slot ring AND the unit ring have wrapped.  Every plane's bytes are a function of (tick, row) and its first
+    four bytes carry (tick, row) themselves, so every sampled transition is checked IN FULL on the device: obs must be
+    the env's four planes up to its tick (the first plane repeated at the start of the run, game_state.h:66-70),
+    next_obs the same env's stack n ticks later."""
+    import torch
+
+    from rela_amd.engine import ApexActorEngine, FFNetHandle
+    from rela_amd.replay import FFReplay
+    from synth import synth_params
+
+    free, _ = torch.cuda.mem_get_info()
+    if free < 120e9:
+        pytest.skip("needs ~90 GB of free HBM")
+    dev = "cuda:0"
+    R, K, n, A, cap, B = 6400, 80, 3, 6, 1 << 23, 512
+    on, tg = FFNetHandle(A, dev), FFNetHandle(A, dev)
+    on.load_state_dict({k: torch.from_numpy(v) for k, v in synth_params(A, 11).items()})
+    tg.load_state_dict({k: torch.from_numpy(v) for k, v in synth_params(A, 12).items()})
+    on.set_precision("bf16x2")
+    tg.set_precision("bf16x2")
+    replay = FFReplay(cap, 7, 0.6, 0.4, 0, A, dev, dedup="plane", guard_units=(n + 8) * R)
+    eng = ApexActorEngine(R, K, A, n, 0.997, replay, [0.0] * R, dev)
+    pix = torch.arange(84 * 84, device=dev, dtype=torch.int32)[None, :]
+
+    def plane(tick, row):  # tick, row: int32 [m, 1] -> [m, 7056] u8
+        p = ((tick * 131 + row * 31 + pix * 7) & 255).to(torch.uint8)
+        p[:, 0], p[:, 1] = (tick[:, 0] & 255).to(torch.uint8), (tick[:, 0] >> 8).to(torch.uint8)
+        p[:, 2], p[:, 3] = (row[:, 0] & 255).to(torch.uint8), (row[:, 0] >> 8).to(torch.uint8)
+        return p
+
+    def stack_at(tick, row):  # the env's stack at `tick`: planes tick-3 .. tick, clamped to the first plane
+        return torch.stack([plane(torch.clamp(tick - 3 + k, min=0), row) for k in range(4)], 1).reshape(-1, 4, 84, 84)
+
+    all_rows = torch.arange(R, device=dev, dtype=torch.int32)[:, None]
+    ring = int(1.25 * cap)
+    ticks = ring // R + 420  # the slot ring is full after 1,638 ticks; 420 more wrap it and the unit ring behind it
+    zeros_r, zeros_t = torch.zeros(R, device=dev), torch.zeros(R, dtype=torch.uint8, device=dev)
+    cur = stack_at(torch.zeros(R, 1, dtype=torch.int32, device=dev), all_rows)
+    checked = 0
+    for t in range(ticks):
+        if t > 0:
+            tt = torch.full((R, 1), t, dtype=torch.int32, device=dev)
+            cur = torch.cat([cur[:, 1:], plane(tt, all_rows).reshape(R, 1, 84, 84)], 1)
+        eng.next_obs_slot().copy_(cur)
+        eng.act(on)
+        eng.post_step(zeros_r, zeros_t, on, tg, nonblocking=False)
+        if replay.size() > ring - R or t == ticks - 1:  # sample (which evicts down to capacity) and verify the batch
+            b, w = replay.sample(B)
+            s, ns = b.obs["s"].reshape(B, 4, -1), b.next_obs["s"].reshape(B, 4, -1)
+            t0 = (s[:, 3, 0].int() | (s[:, 3, 1].int() << 8))[:, None]  # the newest plane names its tick and row
+            r0 = (s[:, 3, 2].int() | (s[:, 3, 3].int() << 8))[:, None]
+            assert int(t0.max()) <= t - n and int(t0.min()) >= 0 and int(r0.max()) < R
+            assert torch.equal(b.obs["s"], stack_at(t0, r0)), "obs is not the env's stack at its tick"
+            assert torch.equal(b.next_obs["s"], stack_at(t0 + n, r0)), "next_obs is not the same env's stack n ticks later"
+            assert replay.debug_state()["dev_error"] == 0
+            checked += B
+            replay.update_priority(torch.linspace(0.3, 1.7, B, device=dev))
+    st = replay.debug_state()
+    assert st["num_add"] > ring + 2 * R and checked >= 2 * B  # the rings wrapped and samples were checked
+    assert st["size"] >= cap - R
+    eng.close()
+    replay.close()
