@@ -333,11 +333,17 @@ struct BpttArgs {
   int Tt, Bn, burn;
 };
 
+// r3: the batch rows are split over kBpttRowSplit copies of every unit block (grid = 32 x 4 = 128): a block re-reads
+// the step's gate gradients of ITS row tiles only -- 128 KB instead of 512 KB per step from L2 (at ~70 GB/s per CU the
+// 512 KB alone were 7 us of a 21-us step) -- and issues a quarter of the f32 MFMAs; W_hh's slice is simply resident
+// in four blocks instead of one.  Block b: units 16 (b % 32) .. + 15, row tiles (b / 32), (b / 32) + 4, ...
+constexpr int kBpttRowSplit = 4;
 __global__ __launch_bounds__(kRecThreads) void lstm_bptt_persist(BpttArgs a) {
-  __shared__ float red[8][kRecChunk][17];
+  __shared__ float red[8][16][17];
   __shared__ int alive;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, g = lane >> 4, j = blockIdx.x;
+  const int li = lane & 15, g = lane >> 4, j = blockIdx.x % kBpttBlocks, rs = blockIdx.x / kBpttBlocks;
+  const int nsplit = gridDim.x / kBpttBlocks;
   // B fragments: k-step s of lane group g is gate column 256 wave + 64 g + s; column li of the tile = unit 16 j + li
   float bfr[64];
 #pragma unroll
@@ -347,32 +353,28 @@ __global__ __launch_bounds__(kRecThreads) void lstm_bptt_persist(BpttArgs a) {
     const bool rec = t + 1 < a.Tt;  // the newest step has no recurrent term
     float* ga_t = a.ga + (size_t)t * a.Bn * kGates;
     const float* dg_next = a.ga + (size_t)(t + 1) * a.Bn * kGates;
-    for (int row0 = 0; row0 < a.Bn; row0 += kRecChunk) {
+    for (int row0 = rs * 16; row0 < a.Bn; row0 += 16 * nsplit) {
       if (rec) {
-        f32x4 acc[4];
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int arow = min(row0 + li, a.Bn - 1);  // (rows past the batch repeat the last one, unread)
+        const float4* dp = reinterpret_cast<const float4*>(dg_next + (size_t)arow * kGates + 256 * wave + 64 * g);
+        float4 v[16];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-          acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-          const int arow = min(row0 + rt * 16 + li, a.Bn - 1);  // (rows past the batch repeat the last one, unread)
-          const float4* dp = reinterpret_cast<const float4*>(dg_next + (size_t)arow * kGates + 256 * wave + 64 * g);
+        for (int c = 0; c < 16; ++c) v[c] = dp[c];  // all of the tile's loads in flight before the first MFMA
 #pragma unroll
-          for (int c = 0; c < 16; ++c) {  // every lane takes part in every MFMA: no MFMA under a lane mask
-            const float4 v = dp[c];
-            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, bfr[4 * c], acc[rt], 0, 0, 0);
-            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, bfr[4 * c + 1], acc[rt], 0, 0, 0);
-            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, bfr[4 * c + 2], acc[rt], 0, 0, 0);
-            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, bfr[4 * c + 3], acc[rt], 0, 0, 0);
-          }
+        for (int c = 0; c < 16; ++c) {  // every lane takes part in every MFMA: no MFMA under a lane mask
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c].x, bfr[4 * c], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c].y, bfr[4 * c + 1], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c].z, bfr[4 * c + 2], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c].w, bfr[4 * c + 3], acc, 0, 0, 0);
         }
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) red[wave][rt * 16 + 4 * g + r][li] = acc[rt][r];
+        for (int r = 0; r < 4; ++r) red[wave][4 * g + r][li] = acc[r];
       }
       __syncthreads();
-      // cell backward (lstm_cell_bwd) for (row, units 16 j + 4 q .. + 3): threads 0 .. 255
+      // cell backward (lstm_cell_bwd) for (row, units 16 j + 4 q .. + 3): threads 0 .. 63
       const int r = tid >> 2, q = tid & 3, row = row0 + r;
-      if (tid < 4 * kRecChunk && row < a.Bn) {
+      if (tid < 4 * 16 && row < a.Bn) {
         const size_t u0 = (size_t)row * kHid + 16 * j + 4 * q;
         const int gs = a.burn + t;
         const float4 d_o4 = *reinterpret_cast<const float4*>(a.d_o + (size_t)t * blk + u0);
@@ -426,7 +428,7 @@ __global__ __launch_bounds__(kRecThreads) void lstm_bptt_persist(BpttArgs a) {
       gu32* cnt = (gu32*)(a.bar + t);
       __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       bool ok = true;
-      for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)kBpttBlocks;) {
+      for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x;) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > kRecSpinLimit || __hip_atomic_load((gu32*)a.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
           __hip_atomic_store((gu32*)a.tmo, (unsigned)(1000 + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -886,9 +888,9 @@ extern "C" int rela_r2d2_learner_create(rela_r2d2_learner** out, int num_action,
     RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, lstm_rec_persist, kRecThreads, 0));
     RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, lstm_bptt_persist, kRecThreads, 0));
     const int64_t room_f = (int64_t)cus * (occ_f > 1 ? occ_f - 1 : occ_f), room_b = (int64_t)cus * (occ_b > 1 ? occ_b - 1 : occ_b);
-    if (room_f < 2 * kRecBlocks || room_b < kBpttBlocks) {
+    if (room_f < 2 * kRecBlocks || room_b < kBpttBlocks * kBpttRowSplit) {
       fprintf(stderr, "rela_r2d2_learner_create: %d CUs x (%d, %d) resident blocks cannot hold the persistent recurrent "
-                      "grids (%d, %d): using the per-step launches\n", cus, occ_f, occ_b, 2 * kRecBlocks, kBpttBlocks);
+                      "grids (%d, %d): using the per-step launches\n", cus, occ_f, occ_b, 2 * kRecBlocks, kBpttBlocks * kBpttRowSplit);
       l->rec_persist = false;
     }
   }
@@ -1133,7 +1135,9 @@ extern "C" int rela_r2d2_learner_grad(rela_r2d2_learner* l, void* stream_) {
     ba.ga = ga_tr, ba.d_o = l->d_o, ba.whh = P.w_hh, ba.C = Cc, ba.dc_rec = l->dc_rec;
     ba.bar = l->rec_bar + 4, ba.tmo = l->rec_bar, ba.Tt = Tt, ba.Bn = Bn, ba.burn = burn;
     ProfScope prof("learner_lstm_bptt_persist", s);
-    hipLaunchKernelGGL(lstm_bptt_persist, dim3(kBpttBlocks), dim3(kRecThreads), 0, s, ba);
+    // (a batch of fewer row tiles than the split leaves the surplus copies idle at the barrier: they still arrive)
+    static const int rsplit = getenv("RELA_BPTT_ROW_SPLIT") ? std::max(1, std::min(8, atoi(getenv("RELA_BPTT_ROW_SPLIT")))) : kBpttRowSplit;
+    hipLaunchKernelGGL(lstm_bptt_persist, dim3(kBpttBlocks * rsplit), dim3(kRecThreads), 0, s, ba);
   } else
   for (int t = Tt - 1; t >= 0; --t) {
     const int gs = burn + t;  // global step
