@@ -179,7 +179,7 @@ __global__ void lstm_cell_fwd(float* __restrict__ gx, const float* __restrict__ 
 // that gives up sets the timeout word and leaves, and the host reports it (rela_r2d2_learner_check).
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
-constexpr int kRecBlocks = kHid / 4, kRecThreads = 512;
+constexpr int kRecBlocks = kHid / 4, kRecThreads = 512, kRecChunk = 64;
 constexpr unsigned kRecSpinLimit = 1u << 22;
 
 struct RecNet {
@@ -196,93 +196,97 @@ struct RecArgs {
   int T, Bn, burn;
 };
 
-// r3: like the BPTT kernel below, the batch rows are split over kRecRowSplit copies of every unit block (grid = 2 nets x
-// 128 x 2 = 512 blocks, two per CU: <= 128 registers): a block loads h_{t-1} of ITS row tiles only and runs a row tile
-// (16 rows) at a time.  Block b of a net: units 4 (b % 128) .. + 3, row tiles (b / 128), (b / 128) + split, ...
-constexpr int kRecRowSplit = 2;
-__global__ __launch_bounds__(kRecThreads, 4) void lstm_rec_persist(RecArgs a, int nsplit) {
-  __shared__ float red[8][16][17];
+// (r3: a row split as in the BPTT kernel below was built and measured for this kernel too -- a row tile at a time with the
+// cell on one thread per (row, unit), two copies of every unit block = 512 blocks at two per CU -- and is SLOWER: 1.75 ->
+// 2.27 ms with one copy, 3.09 ms with two.  The forward step is a latency chain (load h, MFMAs, LDS reduce, the cell's
+// sigmoid / tanh chain, write-through stores), and handling the four row tiles of a batch of 64 in ONE pass, as this
+// kernel does, pays that chain once per step instead of once per tile.)
+__global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
+  __shared__ float red[8][kRecChunk][17];
   __shared__ int alive;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, g = lane >> 4;
-  const int per_net = kRecBlocks * nsplit, bn = (int)blockIdx.x % per_net;
-  const int j = bn % kRecBlocks, rs = bn / kRecBlocks;
-  const RecNet nt = a.net[blockIdx.x / per_net];
+  const int li = lane & 15, g = lane >> 4, j = blockIdx.x % kRecBlocks;
+  const RecNet nt = a.net[blockIdx.x / kRecBlocks];
   const int gcol = (li >> 2) * kHid + 4 * j + (li & 3);  // column li of the block's tile = gate li/4 of unit 4j + li%4
   float bfr[16];
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) bfr[ks] = nt.whhT[(size_t)(wave * 64 + 16 * g + ks) * kGates + gcol];
   const size_t blk = (size_t)a.Bn * kHid;
+  const bool one_chunk = a.Bn <= kRecChunk;
+  // x-part of the gates of (step, row = tid): independent of the other blocks, so it is fetched BEFORE the
+  // wait for h_{t-1} (batches of more than one chunk fetch per chunk instead)
+  float4 gpre[4];
+  auto gx_fetch = [&](int t, int row) {
+    const float* grow = nt.gx + ((size_t)t * a.Bn + row) * kGates + 4 * j;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gpre[q] = *reinterpret_cast<const float4*>(grow + q * kHid);
+  };
+  if (one_chunk && tid < a.Bn) gx_fetch(0, tid);
   for (int t = 0; t < a.T; ++t) {
     const float* Ht = nt.H + (size_t)t * blk;
-    for (int row0 = rs * 16; row0 < a.Bn; row0 += 16 * nsplit) {
-      // the cell runs on wave 0, one thread per (row, unit): tid = 4 * row-of-tile + unit (few registers per thread: the
-      // block must fit twice on a CU); the four units of a row meet in the unit-0 lane for the 16-byte stores
-      const int cr = tid >> 2, cu = tid & 3, crow = row0 + cr;
-      const bool cell = tid < 64 && crow < a.Bn;
-      float gp[4] = {0.f, 0.f, 0.f, 0.f};
-      if (cell) {  // x-part of the gates of (step, row, unit): in flight under the MFMAs
-        const float* grow = nt.gx + ((size_t)t * a.Bn + crow) * kGates + 4 * j + cu;
+    for (int row0 = 0; row0 < a.Bn; row0 += kRecChunk) {
+      const int row = row0 + tid;
+      if (!one_chunk && tid < kRecChunk && row < a.Bn) gx_fetch(t, row);
+      f32x4 acc[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) gp[q] = grow[q * kHid];
-      }
-      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-      {
-        const int arow = min(row0 + li, a.Bn - 1);  // (rows past the batch repeat the last one, unread)
-        const float4* hp = reinterpret_cast<const float4*>(Ht + (size_t)arow * kHid + wave * 64 + 16 * g);
-        float4 v[4];
+      for (int rt = 0; rt < 4; ++rt) {
+        acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int arow = row0 + rt * 16 + li;
+        float av[16];
+        if (arow < a.Bn) {
+          const float4* hp = reinterpret_cast<const float4*>(Ht + (size_t)arow * kHid + wave * 64 + 16 * g);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = hp[q];
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = hp[q];
+            av[4 * q] = v.x, av[4 * q + 1] = v.y, av[4 * q + 2] = v.z, av[4 * q + 3] = v.w;
+          }
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q].x, bfr[4 * q], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q].y, bfr[4 * q + 1], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q].z, bfr[4 * q + 2], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[q].w, bfr[4 * q + 3], acc, 0, 0, 0);
+          for (int q = 0; q < 16; ++q) av[q] = 0.f;
         }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bfr[ks], acc[rt], 0, 0, 0);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave][4 * g + r][li] = acc[r];
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][rt * 16 + 4 * g + r][li] = acc[rt][r];
       __syncthreads();
-      if (tid < 64) {  // (the whole of wave 0: the shuffles below need every lane)
-        float pre[4];
+      if (tid < kRecChunk && row < a.Bn) {
+        float* grow = nt.gx + ((size_t)t * a.Bn + row) * kGates + 4 * j;
+        float pre[4][4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          pre[q] = gp[q];
+          pre[q][0] = gpre[q].x, pre[q][1] = gpre[q].y, pre[q][2] = gpre[q].z, pre[q][3] = gpre[q].w;
 #pragma unroll
-          for (int w = 0; w < 8; ++w) pre[q] += red[w][cr][q * 4 + cu];
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 8; ++w) pre[q][u] += red[w][tid][q * 4 + u];
         }
-        const size_t st = (size_t)min(crow, a.Bn - 1) * kHid + 4 * j + cu;
-        const float cp = nt.C[(size_t)t * blk + st];
+        const float4 cp4 = *reinterpret_cast<const float4*>(nt.C + (size_t)t * blk + (size_t)row * kHid + 4 * j);
+        const float cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+        float gi[4], gf[4], gg[4], go[4], c[4], h[4];
         // the state that ENTERS the first training step is zeroed where the burn-in was a dummy (r2d2.py:149-154)
-        const bool zero = a.burn > 0 && t + 1 == a.burn && a.term[(size_t)(a.burn - 1) * a.Bn + min(crow, a.Bn - 1)] != 0;
-        const float gi = sigm(pre[0]), gf = sigm(pre[1]), gg = tanhf(pre[2]), go = sigm(pre[3]);
-        float c = gf * cp + gi * gg;
-        float h = go * tanhf(c);
-        if (zero) c = 0.f, h = 0.f;
-        // units 1..3 of the row -> the unit-0 lane
-        float hv[4], cv[4], giv[4], gfv[4], ggv[4], gov[4];
+        const bool zero = a.burn > 0 && t + 1 == a.burn && a.term[(size_t)(a.burn - 1) * a.Bn + row] != 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          hv[u] = __shfl_down(h, u, 64), cv[u] = __shfl_down(c, u, 64);
-          giv[u] = __shfl_down(gi, u, 64), gfv[u] = __shfl_down(gf, u, 64);
-          ggv[u] = __shfl_down(gg, u, 64), gov[u] = __shfl_down(go, u, 64);
+          gi[u] = sigm(pre[0][u]), gf[u] = sigm(pre[1][u]), gg[u] = tanhf(pre[2][u]), go[u] = sigm(pre[3][u]);
+          c[u] = gf[u] * cp[u] + gi[u] * gg[u];
+          h[u] = go[u] * tanhf(c[u]);
+          if (zero) c[u] = 0.f, h[u] = 0.f;
         }
-        if (cell && cu == 0) {
-          const size_t o = (size_t)(t + 1) * blk + (size_t)crow * kHid + 4 * j;
-          gu64* hp = (gu64*)(nt.H + o);
-          __hip_atomic_store(hp, ((unsigned long long)__float_as_uint(hv[1]) << 32) | __float_as_uint(hv[0]),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(hp + 1, ((unsigned long long)__float_as_uint(hv[3]) << 32) | __float_as_uint(hv[2]),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          *reinterpret_cast<float4*>(nt.C + o) = make_float4(cv[0], cv[1], cv[2], cv[3]);
-          if (nt.save && t >= a.burn) {
-            float* grow = nt.gx + ((size_t)t * a.Bn + crow) * kGates + 4 * j;
-            *reinterpret_cast<float4*>(grow) = make_float4(giv[0], giv[1], giv[2], giv[3]);
-            *reinterpret_cast<float4*>(grow + kHid) = make_float4(gfv[0], gfv[1], gfv[2], gfv[3]);
-            *reinterpret_cast<float4*>(grow + 2 * kHid) = make_float4(ggv[0], ggv[1], ggv[2], ggv[3]);
-            *reinterpret_cast<float4*>(grow + 3 * kHid) = make_float4(gov[0], gov[1], gov[2], gov[3]);
-          }
+        const size_t o = (size_t)(t + 1) * blk + (size_t)row * kHid + 4 * j;
+        gu64* hp = (gu64*)(nt.H + o);
+        __hip_atomic_store(hp, ((unsigned long long)__float_as_uint(h[1]) << 32) | __float_as_uint(h[0]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hp + 1, ((unsigned long long)__float_as_uint(h[3]) << 32) | __float_as_uint(h[2]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *reinterpret_cast<float4*>(nt.C + o) = make_float4(c[0], c[1], c[2], c[3]);
+        if (nt.save && t >= a.burn) {
+          *reinterpret_cast<float4*>(grow) = make_float4(gi[0], gi[1], gi[2], gi[3]);
+          *reinterpret_cast<float4*>(grow + kHid) = make_float4(gf[0], gf[1], gf[2], gf[3]);
+          *reinterpret_cast<float4*>(grow + 2 * kHid) = make_float4(gg[0], gg[1], gg[2], gg[3]);
+          *reinterpret_cast<float4*>(grow + 3 * kHid) = make_float4(go[0], go[1], go[2], go[3]);
         }
       }
       __syncthreads();
@@ -291,11 +295,12 @@ __global__ __launch_bounds__(kRecThreads, 4) void lstm_rec_persist(RecArgs a, in
     // grid barrier: every storing wave drains its stores, then ONE lane signals and polls
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (one_chunk && tid < a.Bn) gx_fetch(t + 1, tid);  // in flight across the wait
     if (tid == 0) {
       gu32* cnt = (gu32*)(nt.bar + t);
       __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       bool ok = true;
-      for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)per_net;) {
+      for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)kRecBlocks;) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > kRecSpinLimit || __hip_atomic_load((gu32*)a.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
           __hip_atomic_store((gu32*)a.tmo, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -776,8 +781,7 @@ int forward_both(rela_r2d2_learner* l, int Bn, const uint8_t* obs, const float* 
     }
     ra.term = term, ra.tmo = l->rec_bar, ra.T = T, ra.Bn = Bn, ra.burn = burn;
     ProfScope prof("learner_lstm_rec_persist", s);
-    static const int rsplit = getenv("RELA_REC_ROW_SPLIT") ? std::max(1, std::min(2, atoi(getenv("RELA_REC_ROW_SPLIT")))) : kRecRowSplit;
-    hipLaunchKernelGGL(lstm_rec_persist, dim3(2 * kRecBlocks * rsplit), dim3(kRecThreads), 0, s, ra, rsplit);
+    hipLaunchKernelGGL(lstm_rec_persist, dim3(2 * kRecBlocks), dim3(kRecThreads), 0, s, ra);
     RELA_LAUNCH_CHECK();
   } else {
     rc = forward_rec_steps(l, 1, Bn, term, false, s);
@@ -891,9 +895,9 @@ extern "C" int rela_r2d2_learner_create(rela_r2d2_learner** out, int num_action,
     // (the query's known over-report concerns kernels near an SGPR allocation step at several blocks per CU: take one
     // block per CU off from four up; these kernels use < 80 SGPRs and need two blocks per CU at most)
     const int64_t room_f = (int64_t)cus * (occ_f >= 4 ? occ_f - 1 : occ_f), room_b = (int64_t)cus * (occ_b >= 4 ? occ_b - 1 : occ_b);
-    if (room_f < 2 * kRecBlocks * kRecRowSplit || room_b < kBpttBlocks * kBpttRowSplit) {
+    if (room_f < 2 * kRecBlocks || room_b < kBpttBlocks * kBpttRowSplit) {
       fprintf(stderr, "rela_r2d2_learner_create: %d CUs x (%d, %d) resident blocks cannot hold the persistent recurrent "
-                      "grids (%d, %d): using the per-step launches\n", cus, occ_f, occ_b, 2 * kRecBlocks * kRecRowSplit, kBpttBlocks * kBpttRowSplit);
+                      "grids (%d, %d): using the per-step launches\n", cus, occ_f, occ_b, 2 * kRecBlocks, kBpttBlocks * kBpttRowSplit);
       l->rec_persist = false;
     }
   }
