@@ -166,6 +166,25 @@ __global__ void lstm_cell_fwd(float* __restrict__ gx, const float* __restrict__ 
   }
 }
 
+// Reads of bytes another CU wrote inside this launch.  With the acquire fence (`buffer_inv sc1` + the wait for it:
+// ~1.7 us per grid barrier) plain loads are fine; WITHOUT it every such load must bypass this CU's L1: a buffer load with
+// the sc1 bit.  MI355X_MICROARCH.md measured that form for exactly this hand-off -- sc1 stores of 8 bytes, every storing
+// wave drained, ONE lane of each workgroup adding to an agent-scope counter behind a workgroup barrier, the consumer's
+// lane polling it with sc1 loads and the other waves loading behind a workgroup barrier, one workgroup per CU.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sc1_rsrc(const void* base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+template <bool SC1>
+__device__ __forceinline__ float4 ld4_shared(__amdgpu_buffer_rsrc_t rs, const float* base, size_t index) {
+  if constexpr (SC1) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(index * 4), 0, 16);  // aux 16 = sc1
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+  } else {
+    return *reinterpret_cast<const float4*>(base + index);
+  }
+}
+
 // ---- persistent recurrent forward ---------------------------------------------------------------------
 // The T recurrent steps of one net in ONE launch (2 x 123 x 3 launches of ~13 us each before: launch-bound).
 // Block j owns hidden units 4j .. 4j+3 (16 gate columns: i, f, g, o of each) for the whole batch; its slice of
@@ -181,6 +200,11 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 constexpr int kRecBlocks = kHid / 4, kRecThreads = 512, kRecChunk = 64;
 constexpr unsigned kRecSpinLimit = 1u << 22;
+// RELA_R2D2_ACQUIRE=fence: plain loads behind an agent-scope acquire fence per grid barrier (r2); default (r3): sc1 loads
+inline bool sc1_handoff() {
+  static const bool fence = getenv("RELA_R2D2_ACQUIRE") && strcmp(getenv("RELA_R2D2_ACQUIRE"), "fence") == 0;
+  return !fence;
+}
 
 struct RecNet {
   float* gx;          // [T][Bn][2048] pre-activations of the input half (+ bias); saved steps get the activated gates
@@ -201,6 +225,7 @@ struct RecArgs {
 // 2.27 ms with one copy, 3.09 ms with two.  The forward step is a latency chain (load h, MFMAs, LDS reduce, the cell's
 // sigmoid / tanh chain, write-through stores), and handling the four row tiles of a batch of 64 in ONE pass, as this
 // kernel does, pays that chain once per step instead of once per tile.)
+template <bool SC1>
 __global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
   __shared__ float red[8][kRecChunk][17];
   __shared__ int alive;
@@ -212,6 +237,7 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
 #pragma unroll
   for (int ks = 0; ks < 16; ++ks) bfr[ks] = nt.whhT[(size_t)(wave * 64 + 16 * g + ks) * kGates + gcol];
   const size_t blk = (size_t)a.Bn * kHid;
+  const __amdgpu_buffer_rsrc_t rsH = sc1_rsrc(nt.H, (size_t)(a.T + 1) * blk * 4), rsC = sc1_rsrc(nt.C, (size_t)(a.T + 1) * blk * 4);
   const bool one_chunk = a.Bn <= kRecChunk;
   // x-part of the gates of (step, row = tid): independent of the other blocks, so it is fetched BEFORE the
   // wait for h_{t-1} (batches of more than one chunk fetch per chunk instead)
@@ -223,7 +249,6 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
   };
   if (one_chunk && tid < a.Bn) gx_fetch(0, tid);
   for (int t = 0; t < a.T; ++t) {
-    const float* Ht = nt.H + (size_t)t * blk;
     for (int row0 = 0; row0 < a.Bn; row0 += kRecChunk) {
       const int row = row0 + tid;
       if (!one_chunk && tid < kRecChunk && row < a.Bn) gx_fetch(t, row);
@@ -234,10 +259,10 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
         const int arow = row0 + rt * 16 + li;
         float av[16];
         if (arow < a.Bn) {
-          const float4* hp = reinterpret_cast<const float4*>(Ht + (size_t)arow * kHid + wave * 64 + 16 * g);
+          const size_t hoff = (size_t)t * blk + (size_t)arow * kHid + wave * 64 + 16 * g;
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float4 v = hp[q];
+            const float4 v = ld4_shared<SC1>(rsH, nt.H, hoff + 4 * q);
             av[4 * q] = v.x, av[4 * q + 1] = v.y, av[4 * q + 2] = v.z, av[4 * q + 3] = v.w;
           }
         } else {
@@ -263,7 +288,7 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
 #pragma unroll
             for (int w = 0; w < 8; ++w) pre[q][u] += red[w][tid][q * 4 + u];
         }
-        const float4 cp4 = *reinterpret_cast<const float4*>(nt.C + (size_t)t * blk + (size_t)row * kHid + 4 * j);
+        const float4 cp4 = ld4_shared<SC1>(rsC, nt.C, (size_t)t * blk + (size_t)row * kHid + 4 * j);
         const float cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
         float gi[4], gf[4], gg[4], go[4], c[4], h[4];
         // the state that ENTERS the first training step is zeroed where the burn-in was a dummy (r2d2.py:149-154)
@@ -308,8 +333,10 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (!SC1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       alive = ok ? 1 : 0;
     }
     __syncthreads();
@@ -343,6 +370,7 @@ struct BpttArgs {
 // 512 KB alone were 7 us of a 21-us step) -- and issues a quarter of the f32 MFMAs; W_hh's slice is simply resident
 // in four blocks instead of one.  Block b: units 16 (b % 32) .. + 15, row tiles (b / 32), (b / 32) + 4, ...
 constexpr int kBpttRowSplit = 4;
+template <bool SC1>
 __global__ __launch_bounds__(kRecThreads) void lstm_bptt_persist(BpttArgs a) {
   __shared__ float red[8][16][17];
   __shared__ int alive;
@@ -354,18 +382,18 @@ __global__ __launch_bounds__(kRecThreads) void lstm_bptt_persist(BpttArgs a) {
 #pragma unroll
   for (int ks = 0; ks < 64; ++ks) bfr[ks] = a.whh[(size_t)(256 * wave + 64 * g + ks) * kHid + 16 * j + li];
   const size_t blk = (size_t)a.Bn * kHid;
+  const __amdgpu_buffer_rsrc_t rsG = sc1_rsrc(a.ga, (size_t)a.Tt * a.Bn * kGates * 4), rsD = sc1_rsrc(a.dc_rec, blk * 4);
   for (int t = a.Tt - 1; t >= 0; --t) {
     const bool rec = t + 1 < a.Tt;  // the newest step has no recurrent term
     float* ga_t = a.ga + (size_t)t * a.Bn * kGates;
-    const float* dg_next = a.ga + (size_t)(t + 1) * a.Bn * kGates;
     for (int row0 = rs * 16; row0 < a.Bn; row0 += 16 * nsplit) {
       if (rec) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         const int arow = min(row0 + li, a.Bn - 1);  // (rows past the batch repeat the last one, unread)
-        const float4* dp = reinterpret_cast<const float4*>(dg_next + (size_t)arow * kGates + 256 * wave + 64 * g);
+        const size_t doff = (size_t)(t + 1) * a.Bn * kGates + (size_t)arow * kGates + 256 * wave + 64 * g;
         float4 v[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = dp[c];  // all of the tile's loads in flight before the first MFMA
+        for (int c = 0; c < 16; ++c) v[c] = ld4_shared<SC1>(rsG, a.ga, doff + 4 * c);  // all in flight before the first MFMA
 #pragma unroll
         for (int c = 0; c < 16; ++c) {  // every lane takes part in every MFMA: no MFMA under a lane mask
           acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c].x, bfr[4 * c], acc, 0, 0, 0);
@@ -395,7 +423,7 @@ __global__ __launch_bounds__(kRecThreads) void lstm_bptt_persist(BpttArgs a) {
         const float4 gg4 = *reinterpret_cast<const float4*>(grow + 2 * kHid), go4 = *reinterpret_cast<const float4*>(grow + 3 * kHid);
         const float4 cn4 = *reinterpret_cast<const float4*>(a.C + (size_t)(gs + 1) * blk + u0);
         const float4 cp4 = *reinterpret_cast<const float4*>(a.C + (size_t)gs * blk + u0);
-        const float4 dcr4 = *reinterpret_cast<const float4*>(a.dc_rec + u0);
+        const float4 dcr4 = ld4_shared<SC1>(rsD, a.dc_rec, u0);
         const float gi[4] = {gi4.x, gi4.y, gi4.z, gi4.w}, gf[4] = {gf4.x, gf4.y, gf4.z, gf4.w};
         const float gg[4] = {gg4.x, gg4.y, gg4.z, gg4.w}, go[4] = {go4.x, go4.y, go4.z, go4.w};
         const float cn[4] = {cn4.x, cn4.y, cn4.z, cn4.w}, cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
@@ -441,8 +469,10 @@ __global__ __launch_bounds__(kRecThreads) void lstm_bptt_persist(BpttArgs a) {
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (!SC1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       alive = ok ? 1 : 0;
     }
     __syncthreads();
@@ -781,7 +811,8 @@ int forward_both(rela_r2d2_learner* l, int Bn, const uint8_t* obs, const float* 
     }
     ra.term = term, ra.tmo = l->rec_bar, ra.T = T, ra.Bn = Bn, ra.burn = burn;
     ProfScope prof("learner_lstm_rec_persist", s);
-    hipLaunchKernelGGL(lstm_rec_persist, dim3(2 * kRecBlocks), dim3(kRecThreads), 0, s, ra);
+    if (sc1_handoff()) hipLaunchKernelGGL(lstm_rec_persist<true>, dim3(2 * kRecBlocks), dim3(kRecThreads), 0, s, ra);
+    else hipLaunchKernelGGL(lstm_rec_persist<false>, dim3(2 * kRecBlocks), dim3(kRecThreads), 0, s, ra);
     RELA_LAUNCH_CHECK();
   } else {
     rc = forward_rec_steps(l, 1, Bn, term, false, s);
@@ -890,8 +921,8 @@ extern "C" int rela_r2d2_learner_create(rela_r2d2_learner** out, int num_action,
     // taken off -- and fall back to the per-step launches (split-K GEMM + cell kernel) when they would not fit.
     int cus = 0, occ_f = 0, occ_b = 0;
     RELA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, lstm_rec_persist, kRecThreads, 0));
-    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, lstm_bptt_persist, kRecThreads, 0));
+    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, lstm_rec_persist<true>, kRecThreads, 0));
+    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, lstm_bptt_persist<true>, kRecThreads, 0));
     // (the query's known over-report concerns kernels near an SGPR allocation step at several blocks per CU: take one
     // block per CU off from four up; these kernels use < 80 SGPRs and need two blocks per CU at most)
     const int64_t room_f = (int64_t)cus * (occ_f >= 4 ? occ_f - 1 : occ_f), room_b = (int64_t)cus * (occ_b >= 4 ? occ_b - 1 : occ_b);
@@ -1144,7 +1175,8 @@ extern "C" int rela_r2d2_learner_grad(rela_r2d2_learner* l, void* stream_) {
     ProfScope prof("learner_lstm_bptt_persist", s);
     // (a batch of fewer row tiles than the split leaves the surplus copies idle at the barrier: they still arrive)
     static const int rsplit = getenv("RELA_BPTT_ROW_SPLIT") ? std::max(1, std::min(8, atoi(getenv("RELA_BPTT_ROW_SPLIT")))) : kBpttRowSplit;
-    hipLaunchKernelGGL(lstm_bptt_persist, dim3(kBpttBlocks * rsplit), dim3(kRecThreads), 0, s, ba);
+    if (sc1_handoff()) hipLaunchKernelGGL(lstm_bptt_persist<true>, dim3(kBpttBlocks * rsplit), dim3(kRecThreads), 0, s, ba);
+    else hipLaunchKernelGGL(lstm_bptt_persist<false>, dim3(kBpttBlocks * rsplit), dim3(kRecThreads), 0, s, ba);
   } else
   for (int t = Tt - 1; t >= 0; --t) {
     const int gs = burn + t;  // global step
