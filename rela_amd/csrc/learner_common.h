@@ -405,6 +405,7 @@ __global__ __launch_bounds__(1024) void learner_td_loss_grad(int Bn, int A, cons
   for (int i = threadIdx.x; i < Bn; i += 1024) {
     int na = 0;
     float bv = -INFINITY;
+#pragma unroll 6  // (the loads of several actions in flight: one at a time this loop was most of the kernel's 19 us)
     for (int j = 0; j < A; ++j) {  // greedy_act(next_obs): first maximal index of (1 + q - qmin) * legal (apex.py:51)
       const float lq = __fmul_rn(__fsub_rn(__fadd_rn(1.0f, qno[(size_t)i * A + j]), qmin), nlegal[(size_t)i * A + j]);
       if (lq > bv) bv = lq, na = j;
@@ -418,13 +419,16 @@ __global__ __launch_bounds__(1024) void learner_td_loss_grad(int Bn, int A, cons
     prio[i] = ae;
     lsum += (ae < 1.0f ? 0.5f * e * e : ae - 0.5f) * w[i];
     const float g = -(w[i] * fminf(fmaxf(e, -1.0f), 1.0f)) * inv_b;
-    float* row = d_ha + (size_t)i * 32;
+    float4* row = reinterpret_cast<float4*>(d_ha + (size_t)i * 32);
+    float v[32];
+#pragma unroll
     for (int k = 0; k < 32; ++k) {
-      float v = 0.f;
-      if (k < A) v = legal[(size_t)i * A + k] * (g * ((k == a ? 1.0f : 0.0f) - inv_a));
-      if (k == 31) v = g;
-      row[k] = v;
+      v[k] = 0.f;
+      if (k < A) v[k] = legal[(size_t)i * A + k] * (g * ((k == a ? 1.0f : 0.0f) - inv_a));
+      if (k == 31) v[k] = g;
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) row[k] = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
   }
   // the same tree as learner_loss_grad's kLT = 512 lanes when Bn <= 512: lanes >= 512 hold zeros and fold in first
   red[threadIdx.x] = lsum;

@@ -166,7 +166,7 @@ __global__ void lstm_cell_fwd(float* __restrict__ gx, const float* __restrict__ 
   }
 }
 
-// Reads of bytes another CU wrote inside this launch.  With the acquire fence (`buffer_inv sc1` + the wait for it:
+// Reads of bytes another CU wrote inside this launch (see sc1_handoff below).  With the acquire fence (`buffer_inv sc1` + the wait for it:
 // ~1.7 us per grid barrier) plain loads are fine; WITHOUT it every such load must bypass this CU's L1: a buffer load with
 // the sc1 bit.  MI355X_MICROARCH.md measured that form for exactly this hand-off -- sc1 stores of 8 bytes, every storing
 // wave drained, ONE lane of each workgroup adding to an agent-scope counter behind a workgroup barrier, the consumer's
@@ -200,12 +200,15 @@ typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 constexpr int kRecBlocks = kHid / 4, kRecThreads = 512, kRecChunk = 64;
 constexpr unsigned kRecSpinLimit = 1u << 22;
-// RELA_R2D2_ACQUIRE=fence: plain loads behind an agent-scope acquire fence per grid barrier (r2); default (r3): sc1 loads
+// How a block reads what other CUs wrote in the previous step: plain loads behind an agent-scope acquire fence per grid
+// barrier (default), or -- RELA_R2D2_ACQUIRE=sc1 -- sc1 buffer loads and no fence.  The second form was built and measured
+// in r3 (one workgroup per CU, the envelope MI355X_MICROARCH.md gives for it; bit-reproducible under uneven load, same
+// results): the forward launch 1.73 -> 1.70 ms, but BPTT 0.88 -> 1.02 ms (its 128 KB of gate gradients per block and step
+// then bypass L1): 6.07 -> 6.14 ms per learner step.  Not the default.
 inline bool sc1_handoff() {
-  static const bool fence = getenv("RELA_R2D2_ACQUIRE") && strcmp(getenv("RELA_R2D2_ACQUIRE"), "fence") == 0;
-  return !fence;
+  static const bool sc1 = getenv("RELA_R2D2_ACQUIRE") && strcmp(getenv("RELA_R2D2_ACQUIRE"), "sc1") == 0;
+  return sc1;
 }
-
 struct RecNet {
   float* gx;          // [T][Bn][2048] pre-activations of the input half (+ bias); saved steps get the activated gates
   const float* whhT;  // [512][2048]

@@ -344,3 +344,41 @@ def test_hip_r2d2_learner_fast_target_trunk_within_tolerance(B, seq, burn):
     loss2, prio2, _ = learner.backward(batch, weight)
     assert torch.equal(prio2, prio0)
     learner.close()
+
+
+def test_hip_r2d2_learner_is_bit_reproducible_under_uneven_load():
+    """The persistent recurrent kernels hand h_t / the gate gradients from CU to CU inside one launch (write-through
+    stores, one counter per step, sc1 loads in place of an acquire fence: csrc/learner_r2d2.hip).  A stale read would be
+    a race: it would come and go with timing.  The same batch at C4's shape is therefore differentiated twelve times --
+    alone, and next to another stream that keeps the chip unevenly busy with GEMMs and copies -- and loss, priorities
+    and every gradient must be bit-identical each time (and match autograd, test_hip_r2d2_learner_matches_autograd)."""
+    import torch
+
+    from rela_amd.learner import HipR2D2Learner
+
+    A, B, seq, burn, n = 18, 64, 80, 40, 3
+    rng = np.random.default_rng(123)
+    agent = _agent(A, n, 0.997, 0.9, seq, burn, 71, 72, "cuda:0")
+    batch, weight = _random_batch(rng, A, B, seq, burn, n, "cuda:0")
+    learner = HipR2D2Learner.from_agent(agent, B, grad_clip=1e9)
+    learner.set_precision("bf16x2")
+    side = torch.cuda.Stream()
+    x = torch.randn(3072, 3072, device="cuda")
+    big = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    ref = None
+    for rep in range(12):
+        if rep % 2 == 1:  # uneven load: a burst of other work on another stream, started just before the step
+            with torch.cuda.stream(side):
+                for _ in range(1 + rep % 5):
+                    x = (x @ x).clamp_(-1, 1)
+                    big.fill_(rep)
+        loss, prio, loss_seq = learner.backward(batch, weight)
+        learner.check()
+        torch.cuda.synchronize()
+        cur = (loss.clone(), prio.clone(), loss_seq.clone(), learner.flat()[1].clone())
+        if ref is None:
+            ref = cur
+        else:
+            for a, b, name in zip(cur, ref, ("loss", "priority", "loss_seq", "gradients")):
+                assert torch.equal(a, b), "run %d differs from run 0 in %s" % (rep, name)
+    learner.close()
