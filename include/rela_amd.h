@@ -254,6 +254,13 @@ int rela_ffnet_set_precision(rela_ffnet* net, int mode);
 int rela_ffnet_precision(const rela_ffnet* net);
 /* Test tap: synchronises the device and returns the sticky give-up word of the pipelined conv1 -> conv2 kernel
  * (0 = no wave ever gave up waiting on a hand-off; anything else invalidates the forwards since the last read). */
+/* Diagnostic build of the fused conv1 -> conv2 kernel: shader-clock stamps at its 12 phase boundaries for the first 8
+ * frames of block 0 (waves 0 and 7) -> out_host [2][8][12] u64 (tools/conv12_phases.py). */
+int rela_ffnet_debug_conv12_stamps(const rela_ffnet* net, int n, const uint8_t* s_dev, unsigned long long* out_host,
+                                   void* stream);
+/* The same for fc_bf16s (positions 8..15 of block 0; 5 points per position). */
+int rela_ffnet_debug_fc_stamps(const rela_ffnet* net, int n, const uint8_t* a3_records, unsigned long long* out_host,
+                               void* stream);
 int rela_ffnet_debug_pipe_timeout(rela_ffnet* net, unsigned* out);
 /* bytes of scratch rela_ffnet_forward needs for a batch of n */
 int64_t rela_ffnet_workspace_bytes(const rela_ffnet* net, int n);

@@ -345,29 +345,36 @@ __global__ __launch_bounds__(kT) void dgrad_conv3_bf16(const float* __restrict__
 
 constexpr size_t kFrag2Bytes = (size_t)4 * 2 * 8 * 2 * 64 * 16, kFrag3Bytes = (size_t)4 * 18 * 2 * 64 * 16;
 
-// d_a1 = [a1 > 0] * conv2^T(d_a2); `scratch` (>= kFrag2Bytes) receives the weight fragments
+// The weight fragments alone (a caller that keeps them across steps packs them when the weights change and passes
+// them as `frags` below)
+inline void pack_frags(const float* w2p, const float* w3p, void* frag2, void* frag3, hipStream_t s) {
+  hipLaunchKernelGGL(pack_dgrad2_frags, dim3(ceil_div(4 * 2 * 8 * 64, 256)), dim3(256), 0, s, w2p, (uint4*)frag2);
+  hipLaunchKernelGGL(pack_dgrad3_frags, dim3(ceil_div(4 * 18 * 64, 256)), dim3(256), 0, s, w3p, (uint4*)frag3);
+}
+
+// d_a1 = [a1 > 0] * conv2^T(d_a2); `scratch` (>= kFrag2Bytes) receives the weight fragments unless `frags` has them
 inline int launch_conv2(const float* d_a2, const float* w2p, const float* a1, float* d_a1, int frames, void* scratch,
-                        hipStream_t s) {
+                        hipStream_t s, const void* frags = nullptr) {
   // (initialised once, thread-safely: launches may come from several host threads)
   static const hipError_t attr_set =
       hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_conv2_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, D2::LDS);
   RELA_HIP(attr_set);
-  hipLaunchKernelGGL(pack_dgrad2_frags, dim3(ceil_div(4 * 2 * 8 * 64, 256)), dim3(256), 0, s, w2p, (uint4*)scratch);
+  if (!frags) hipLaunchKernelGGL(pack_dgrad2_frags, dim3(ceil_div(4 * 2 * 8 * 64, 256)), dim3(256), 0, s, w2p, (uint4*)scratch);
   note_launch("dgrad_conv2_bf16");
   hipLaunchKernelGGL(dgrad_conv2_bf16, dim3(frames < 256 ? frames : 256), dim3(kT), D2::LDS, s, d_a2,
-                     (const uint4*)scratch, a1, d_a1, frames);
+                     (const uint4*)(frags ? frags : scratch), a1, d_a1, frames);
   return RELA_OK;
 }
 inline int launch_conv3(const float* d_a3, const float* w3p, const float* a2, float* d_a2, int frames, void* scratch,
-                        hipStream_t s) {
+                        hipStream_t s, const void* frags = nullptr) {
   // (initialised once, thread-safely: launches may come from several host threads)
   static const hipError_t attr_set =
       hipFuncSetAttribute(reinterpret_cast<const void*>(&dgrad_conv3_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, D3::LDS);
   RELA_HIP(attr_set);
-  hipLaunchKernelGGL(pack_dgrad3_frags, dim3(ceil_div(4 * 18 * 64, 256)), dim3(256), 0, s, w3p, (uint4*)scratch);
+  if (!frags) hipLaunchKernelGGL(pack_dgrad3_frags, dim3(ceil_div(4 * 18 * 64, 256)), dim3(256), 0, s, w3p, (uint4*)scratch);
   note_launch("dgrad_conv3_bf16");
   hipLaunchKernelGGL(dgrad_conv3_bf16, dim3(frames < 256 ? frames : 256), dim3(kT), D3::LDS, s, d_a3,
-                     (const uint4*)scratch, a2, d_a2, frames);
+                     (const uint4*)(frags ? frags : scratch), a2, d_a2, frames);
   return RELA_OK;
 }
 

@@ -980,17 +980,27 @@ struct Conv12 {
   static constexpr int IT = (C1::V16 + kThreads - 1) / kThreads;  // 2
 };
 
+constexpr int kStampFrames = 8, kStampPoints = 12;
 // The body of the kernel, shared by conv12_bf16s (one net, blocks = the whole grid) and conv12_bf16s_jobs (the
 // learner's forwards: several nets / batches in ONE launch, each job on its own range of blocks).  JOBS adds: rows
 // from two source buffers (rows >= n_in0 come from in1), and a copy of conv1's records (a1, which otherwise never
 // leaves LDS) to a1_out for the rows < n_a1 -- the pass whose activations the backward kernels read.
-template <bool JOBS>
+template <bool JOBS, bool STAMPS = false>
 __device__ __forceinline__ void conv12_body(const uint8_t* __restrict__ in, const uint8_t* __restrict__ in1, int n_in0,
                                             const uint4* __restrict__ B1frag, const float* __restrict__ bias1,
                                             const uint4* __restrict__ B2frag, const float* __restrict__ bias2,
                                             uint8_t* __restrict__ out, uint8_t* __restrict__ a1_out, int a1_lo, int n_a1,
-                                            int N, int bid, int nblk) {
+                                            int N, int bid, int nblk, unsigned long long* stamps = nullptr) {
   using F = Conv12;
+  // STAMPS (diagnostic build of the kernel only, rela_ffnet_debug_conv12_stamps): lane 0 of waves 0 and 7 of block 0
+  // writes the shader clock at every phase boundary of its first frames to `stamps` [2 waves][kStampFrames][kStampPoints]
+  int stamp_frame = 0;
+  auto stamp = [&](int point) {
+    if constexpr (STAMPS) {
+      if (bid == 0 && (threadIdx.x == 0 || threadIdx.x == 448) && stamp_frame < kStampFrames)
+        stamps[((threadIdx.x == 0 ? 0 : 1) * kStampFrames + stamp_frame) * kStampPoints + point] = __builtin_amdgcn_s_memtime();
+    }
+  };
   using C1 = Conv1P;
   using C2 = Conv2F;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1131,13 +1141,20 @@ __device__ __forceinline__ void conv12_body(const uint8_t* __restrict__ in, cons
   constexpr int LO = C2::CIN * 2;
   for (; n < N; n += nblk) {
     const int nn = (n + nblk < N) ? n + nblk : n;  // (the last round re-reads its own frame)
+    stamp(0);
     conv1_half(0);
+    stamp(1);
     __syncthreads();  // T1 free
+    stamp(2);
     cvt_store();      // half 1 of this frame
     g_load(nn, 0);
+    stamp(3);
     __syncthreads();  // T1 ready
+    stamp(4);
     conv1_half(1);
+    stamp(5);
     __syncthreads();  // T2 complete, T1 free
+    stamp(6);
     if constexpr (JOBS) {
       if (a1_out && (unsigned)(n - a1_lo) < (unsigned)n_a1) {  // (block-uniform) conv1's records: [400 pixels][32 hi | 32 lo]
         uint4* dst = reinterpret_cast<uint4*>(a1_out + (size_t)n * (400 * 128));
@@ -1177,21 +1194,27 @@ __device__ __forceinline__ void conv12_body(const uint8_t* __restrict__ in, cons
         if (idx + D < TOT) a_issue(idx + D, slot);
         __builtin_amdgcn_sched_barrier(0);
       }
+      stamp(7);
       cvt_store();  // half 0 of the next frame (its loads were issued two stages ago; the ring registers are free)
       g_load(nn, 1);
+      stamp(8);
 #pragma unroll
       for (int t = 0; t < C2::RPW; ++t) {
         const int m = (rg2 + t * C2::RG) * 16 + li;
         split_store_lds4((m < C2::M) ? otile + (size_t)m * C2::OROW : spare, C2::OC, ch2, acc[t]);
       }
     }
+    stamp(9);
     __syncthreads();  // O complete, T1 ready, T2 free
+    stamp(10);
     {
       uint4* dst = reinterpret_cast<uint4*>(out + (size_t)n * C2::P * (C2::OC * 4));
       constexpr int nv = C2::P * (C2::OC * 4 / 16);
       for (int i = tid; i < nv; i += kThreads)
         dst[i] = *reinterpret_cast<const uint4*>(otile + (i >> 4) * C2::OROW + (i & 15) * 16);
     }
+    stamp(11);
+    stamp_frame += 1;
   }
 }
 
@@ -1227,6 +1250,12 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s_jobs(TrunkJobs jobs) {
   const TrunkJob& t = jobs.j[k];
   conv12_body<true>(t.in0, t.in1, t.n_in0, t.B1, t.b1, t.B2, t.b2, t.a2, t.a1_out, t.a1_lo, t.n_a1, t.N,
                     (int)blockIdx.x - t.block0, t.nblocks);
+}
+__global__ __launch_bounds__(kThreads) void conv12_bf16s_stamps(const uint8_t* __restrict__ in, const uint4* __restrict__ B1frag,
+                                                                const float* __restrict__ bias1, const uint4* __restrict__ B2frag,
+                                                                const float* __restrict__ bias2, uint8_t* __restrict__ out, int N,
+                                                                unsigned long long* stamps) {
+  conv12_body<false, true>(in, nullptr, N, B1frag, bias1, B2frag, bias2, out, nullptr, 0, 0, N, blockIdx.x, gridDim.x, stamps);
 }
 __global__ __launch_bounds__(kThreads) void conv3_bf16s_jobs(TrunkJobs jobs) {
   int k = 0;
@@ -1871,64 +1900,107 @@ using FcFast = FcFastT<112>;
 // SPLIT (batches of a few hundred rows, where 4 x ceil(N / BM) blocks would leave most CUs idle): blockIdx.z owns the
 // positions [z * per, z * per + per) of the contraction and writes its raw partial sums to out[z][N][512]; fc_reduce adds
 // them up in z order with the bias and the ReLU.  Without SPLIT the range is the compile-time [0, 49).
-template <class F, bool SPLIT = false, int BD = 2>
+// grid of fc_bf16s for `units` (row block, slice) pairs: XCD-aware 1-D form, or (RELA_FC_XCD_MAP=0) the plain (4, rb, slices)
+inline dim3 fc_grid_xcd(int rb, int slices) {
+  static const bool xmap = !(getenv("RELA_FC_XCD_MAP") && atoi(getenv("RELA_FC_XCD_MAP")) == 0);
+  if (!xmap) return dim3(4, rb, slices);
+  return dim3(32 * ceil_div(rb * slices, 8));
+}
+// Loads stay ordinary (compiler-tracked) loads.  Tried in r3 and dropped: issuing them through inline asm with
+// hand-placed `s_waitcnt vmcnt(N)` (hipcc drains the loads in flight across the loop's back-edge every other position,
+// vmcnt(4), i.e. a prefetch distance of one position where the source asks for two).  With the copy-behind-the-wait
+// blocks that makes sound (a tied "+v" wait is not: the compiler satisfies the tie with a copy BEFORE the wait, and it
+// reuses the registers of a prefetch past the end while that load can still land) the kernel was 4 % SLOWER
+// (71.3 vs 68.2 us at N = 6400): the exposed wait is not what bounds a position.
+template <class F, bool SPLIT = false, bool STAMPS = false>
 __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__ A, const uint4* __restrict__ Bfrag,
                                                      const float* __restrict__ bias, float* __restrict__ out, int N,
-                                                     int per) {
+                                                     int per, unsigned long long* stamps = nullptr) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, g = lane >> 4;
-  const int ct = blockIdx.x * kWaves + wave;
-  const int row0 = blockIdx.y * F::BM;
-  const int p0 = SPLIT ? (int)blockIdx.z * per : 0;
-  const int p1 = SPLIT ? min(F::NPOS, p0 + per) : F::NPOS;
-  uint4 st0[F::IT], st1[F::IT];
-  // No predicates on the staging loads and stores (clamped indices repeat a neighbour's chunk, row or position
-  // instead): a load inside a branch makes the compiler fall back to s_waitcnt vmcnt(0), which would wait for the
-  // prefetch that was just issued.
-  const int nrow = min(F::BM, N - row0);
-  auto load_pos = [&](int pos, auto set) {
-    constexpr int S = decltype(set)::value;
-    const int pp = min(pos, p1 - 1);
-#pragma unroll
-    for (int j = 0; j < F::IT; ++j) {
-      const int i = min(tid + j * kThreads, F::V16 - 1);
-      const int r = min(i >> 4, nrow - 1), u = i & 15;
-      const uint4 v = *reinterpret_cast<const uint4*>(A + (size_t)(row0 + r) * (F::NPOS * 256) + pp * 256 + u * 16);
-      if constexpr (S == 0) st0[j] = v; else st1[j] = v;
+  // STAMPS (rela_ffnet_debug_fc_stamps only): shader clock at the phase boundaries of positions 8..15, block 0,
+  // waves 0 and 7 -> stamps [2][kStampFrames][kStampPoints]
+  int stamp_pos = 0;
+  auto stamp = [&](int point) {
+    if constexpr (STAMPS) {
+      if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 448) && stamp_pos >= 8 && stamp_pos < 8 + kStampFrames)
+        stamps[((threadIdx.x == 0 ? 0 : 1) * kStampFrames + stamp_pos - 8) * kStampPoints + point] = __builtin_amdgcn_s_memtime();
     }
   };
-  auto store_pos = [&](int buf, auto set) {
-    constexpr int S = decltype(set)::value;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  // Block -> (column group, row block, slice).  A 1-D grid (fc_grid_xcd) is XCD-aware: workgroups go to the 8 XCDs
+  // round-robin by linear id, so the four column groups that read the SAME rows of A are given ids with the same
+  // id % 8 and consecutive id / 8 -- they run on one XCD at the same time and A comes from HBM once instead of four
+  // times (the (4, rb) grid put them on four XCDs: 334 MB of HBM reads for 80 MB of records at N = 6400; 126 MB now,
+  // the weights included, which no longer fit one XCD's L2).  Ids past the last unit leave at once (block-uniform,
+  // before any barrier).
+  int cg, rb_, sl;
+  if (gridDim.x == 4) {
+    cg = blockIdx.x, rb_ = blockIdx.y, sl = blockIdx.z;
+  } else {
+    const int rb = (N + F::BM - 1) / F::BM;
+    const int units = rb * (SPLIT ? (F::NPOS + per - 1) / per : 1);
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int unit = (j >> 2) * 8 + xcd;
+    if (unit >= units) return;
+    cg = j & 3, rb_ = unit % rb, sl = unit / rb;
+  }
+  const int ct = cg * kWaves + wave;
+  const int row0 = rb_ * F::BM;
+  const int p0 = SPLIT ? sl * per : 0;
+  const int p1 = SPLIT ? min(F::NPOS, p0 + per) : F::NPOS;
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+  // Staging registers: set s holds the tile chunks / weight fragments of the positions of parity s (relative to p0).
+  // No predicates on the staging loads and stores (clamped indices repeat a neighbour's chunk, row or position).
+  u32x4 st0[F::IT], st1[F::IT], bq0[4], bq1[4];
+  const int nrow = min(F::BM, N - row0);
+  const uint8_t* arow[F::IT];  // this thread's chunk j of position 0
+  int soff[F::IT];
 #pragma unroll
-    for (int j = 0; j < F::IT; ++j) {
-      const int i = min(tid + j * kThreads, F::V16 - 1);
-      const int r = i >> 4, u = i & 15;
-      uint4 v;
-      if constexpr (S == 0) v = st0[j]; else v = st1[j];
-      *reinterpret_cast<uint4*>(smem + buf * F::TILE + r * F::RS + u * 16) = v;
+  for (int j = 0; j < F::IT; ++j) {
+    const int i = min(tid + j * kThreads, F::V16 - 1);
+    arow[j] = A + (size_t)(row0 + min(i >> 4, nrow - 1)) * (F::NPOS * 256) + (i & 15) * 16;
+    soff[j] = (i >> 4) * F::RS + (i & 15) * 16;
+  }
+  auto load_chunk = [&](int pos, auto set, int j) {
+    const uint8_t* src = arow[j] + min(pos, p1 - 1) * 256;
+    if constexpr (decltype(set)::value == 0) st0[j] = *reinterpret_cast<const u32x4*>(src); else st1[j] = *reinterpret_cast<const u32x4*>(src);
+  };
+  auto store_chunk = [&](int buf, auto set, int j) {
+    u32x4* dst = reinterpret_cast<u32x4*>(smem + buf * F::TILE + soff[j]);
+    if constexpr (decltype(set)::value == 0) *dst = st0[j]; else *dst = st1[j];
+  };
+  const uint4* bp = Bfrag + (size_t)ct * F::KS * 2 * 64 + lane;
+  auto load_w = [&](int pos, auto set) {  // k-steps 0, 1 of the position x (hi, lo)
+    const u32x4* src = reinterpret_cast<const u32x4*>(bp + (size_t)(min(pos, p1 - 1) * 4) * 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if constexpr (decltype(set)::value == 0) bq0[q] = src[q * 64]; else bq1[q] = src[q * 64];
     }
   };
   f32x4 acc[F::RT];
 #pragma unroll
   for (int t = 0; t < F::RT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const uint4* bp = Bfrag + (size_t)ct * F::KS * 2 * 64 + lane;
-  // weight fragments stream from L2 TWO positions ahead (r3; one ahead left the L2 -> CU stream, which bounds this
-  // kernel, at 45 GB/s per CU): set s holds the fragments of the positions of parity s
-  uint4 bq0[4], bq1[4];
+
+  // Prologue: tiles p0 and p0 + 1 into the ring; then the loads a steady-state position finds in flight, in its
+  // order: W(p) | A(p + 2) | W(p + 1) | A(p + 3)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) bq0[q] = bp[(size_t)(p0 * 4 + q) * 64];  // k-steps 0,1 of the first position x (hi, lo)
+  for (int j = 0; j < F::IT; ++j) load_chunk(p0, Set0{}, j);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) bq1[q] = bp[(size_t)(min(p0 + 1, p1 - 1) * 4 + q) * 64];
-  using Set0 = std::integral_constant<int, 0>;
-  using Set1 = std::integral_constant<int, 1>;
-  load_pos(p0, Set0{});
-  load_pos(p0 + 1, Set1{});
-  store_pos(0, Set0{});
-  load_pos(p0 + 2, Set0{});
-  store_pos(1, Set1{});
-  load_pos(p0 + 3, Set1{});
+  for (int j = 0; j < F::IT; ++j) load_chunk(p0 + 1, Set1{}, j);
+#pragma unroll
+  for (int j = 0; j < F::IT; ++j) {
+    store_chunk(0, Set0{}, j);
+    store_chunk(1, Set1{}, j);
+  }
+  load_w(p0, Set0{});
+#pragma unroll
+  for (int j = 0; j < F::IT; ++j) load_chunk(p0 + 2, Set0{}, j);
+  load_w(p0 + 1, Set1{});
+#pragma unroll
+  for (int j = 0; j < F::IT; ++j) load_chunk(p0 + 3, Set1{}, j);
   __syncthreads();
 
   // A fragment ring: pair i of a position = (sub = i / RT, row tile t = i % RT)
@@ -1943,28 +2015,27 @@ __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__
 #pragma unroll
   for (int i = 0; i < F::D; ++i) a_issue(smem, i, i);
 
-  int buf = 0;  // pos % 3
+  // One position.  In flight when it starts (issue order): W(pos) | A(pos + 2) x IT | W(pos + 1) | A(pos + 3) x IT.
+  // The chunks of the tile of position + 2 go to LDS and the loads of position + 4 are issued INSIDE the MFMA loop,
+  // one 16-byte chunk per fragment pair: as a block after the loop, on all eight waves at once, they left the matrix
+  // pipe idle for ~640 of a position's ~2980 cycles (tools/fc_phases.py).  The tile stored during position p lives in
+  // the buffer that was last read during p - 1, which every wave left at the previous barrier.
+  static_assert(2 * F::IT + 1 <= F::TOT, "a store and a load slot per chunk");
+  int buf = 0;  // (pos - p0) % 3
   auto body = [&](int pos, auto set) {
     constexpr int SB = decltype(set)::value;
-    uint4 bcur[4];
+    u32x4 bcur[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if constexpr (SB == 0) bcur[q] = bq0[q]; else bcur[q] = bq1[q];
     }
-    {
-      // BD = 2: this set is refilled for position pos + 2; BD = 1 (the r2 schedule, kept for A/B runs:
-      // RELA_FC_BDEPTH=1): the OTHER set gets position pos + 1
-      const int pn = min(pos + BD, p1 - 1);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint4 v = bp[(size_t)(pn * 4 + q) * 64];
-        if constexpr ((SB == 0) == (BD == 2)) bq0[q] = v; else bq1[q] = v;
-      }
-    }
+    load_w(pos + 2, set);
     const int nbuf = (buf == F::NBUF - 1) ? 0 : buf + 1;
+    const int sbuf = (nbuf == F::NBUF - 1) ? 0 : nbuf + 1;
     const uint8_t* tile = smem + buf * F::TILE;
     const uint8_t* ntile = smem + nbuf * F::TILE;  // (after the last position: stale rows, read and dropped)
     __builtin_amdgcn_sched_barrier(0);
+    stamp(0);
 #pragma unroll
     for (int i = 0; i < F::TOT; ++i) {
       const int sub = i / F::RT, t = i - sub * F::RT;
@@ -1980,13 +2051,16 @@ __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__
         a_issue(tile, i + F::D, slot);
       else
         a_issue(ntile, i + F::D - F::TOT, slot);
+      // chunk j of the tile of position pos + 2 (past the end: rewrites a tile nobody reads again) goes to LDS after
+      // pair 2 j + 1 and its registers take chunk j of position pos + 4 after pair 2 j + 2
+      if ((i & 1) == 1 && i / 2 < F::IT) store_chunk(sbuf, set, i / 2);
+      if ((i & 1) == 0 && i >= 2 && i / 2 - 1 < F::IT) load_chunk(pos + 4, set, i / 2 - 1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the tile of position pos + 2 (loaded two positions ago) replaces the one read a position ago
-    const int sbuf = (nbuf == F::NBUF - 1) ? 0 : nbuf + 1;
-    store_pos(sbuf, set);  // (past the end: rewrites a tile nobody reads again)
-    load_pos(pos + 4, set);
+    stamp(1);
     __syncthreads();
+    stamp(4);
+    stamp_pos += 1;
     buf = nbuf;
   };
   for (int pos = p0; pos < p1; pos += 2) {
@@ -1995,7 +2069,7 @@ __global__ __launch_bounds__(kThreads) void fc_bf16s(const uint8_t* __restrict__
   }
   const int col = ct * 16 + li;
   if constexpr (SPLIT) {
-    float* part = out + (size_t)blockIdx.z * N * F::OC;
+    float* part = out + (size_t)sl * N * F::OC;
 #pragma unroll
     for (int t = 0; t < F::RT; ++t)
 #pragma unroll
@@ -2575,8 +2649,6 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv12S::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv3F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv3F::LDS_TOTAL));
-  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s<FcFast, false, 1>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, FcFast::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s<FcFast, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, FcFast::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s<FcFast>),
@@ -2609,6 +2681,61 @@ extern "C" int rela_ffnet_debug_pipe_timeout(rela_ffnet* n, unsigned* out) {
   DeviceGuard g(n->device);
   RELA_HIP(hipDeviceSynchronize());
   RELA_HIP(hipMemcpy(out, n->pipe_tmo, sizeof(unsigned), hipMemcpyDeviceToHost));
+  return RELA_OK;
+}
+
+// Diagnostic: the fused conv1 -> conv2 kernel with shader-clock stamps at its phase boundaries (block 0, waves 0 and 7,
+// first 8 frames): out_host receives [2][8][12] u64.  Points: 0 frame start | 1 conv1 half 0 done | 2 barrier | 3 convert
+// half 1 + loads issued | 4 barrier | 5 conv1 half 1 done | 6 barrier | 7 conv2 MFMAs done | 8 convert next half 0 + loads |
+// 9 conv2 epilogue stored | 10 barrier | 11 copy-out issued.
+extern "C" int rela_ffnet_debug_conv12_stamps(const rela_ffnet* n, int N, const uint8_t* s_dev, unsigned long long* out_host,
+                                              void* stream_) {
+  RELA_CHECK(n && n->loaded && N >= 1 && s_dev && out_host, RELA_EINVAL, "rela_ffnet_debug_conv12_stamps: bad arguments");
+  DeviceGuard g(n->device);
+  hipStream_t s = (hipStream_t)stream_;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_bf16s_stamps),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Conv12::LDS_TOTAL);
+  RELA_HIP(attr);
+  uint8_t* a2 = nullptr;
+  unsigned long long* st = nullptr;
+  const size_t nst = (size_t)2 * kStampFrames * kStampPoints;
+  RELA_HIP(hipMalloc(&a2, (size_t)N * 81 * 256));
+  RELA_HIP(hipMalloc(&st, nst * 8));
+  RELA_HIP(hipMemsetAsync(st, 0, nst * 8, s));
+  const FFNetDev& d = n->d;
+  hipLaunchKernelGGL(conv12_bf16s_stamps, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
+                     (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, a2, N, st);
+  RELA_HIP(hipStreamSynchronize(s));
+  RELA_HIP(hipMemcpy(out_host, st, nst * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(a2);
+  (void)hipFree(st);
+  return RELA_OK;
+}
+
+// Diagnostic: fc_bf16s with shader-clock stamps (block 0, waves 0 and 7, positions 8..15): out_host [2][8][12] u64, points
+// 0 position start (weight fragments in registers) | 1 MFMA loop done | 2 next tile stored | 3 loads issued | 4 barrier.
+// a3_records: [N][49][hi 64 | lo 64] split records (any bytes do for timing).
+extern "C" int rela_ffnet_debug_fc_stamps(const rela_ffnet* n, int N, const uint8_t* a3_records, unsigned long long* out_host,
+                                          void* stream_) {
+  RELA_CHECK(n && n->loaded && N >= FcFast::BM && a3_records && out_host, RELA_EINVAL, "rela_ffnet_debug_fc_stamps: bad arguments");
+  DeviceGuard g(n->device);
+  hipStream_t s = (hipStream_t)stream_;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s<FcFast, false, true>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, FcFast::LDS_BYTES);
+  RELA_HIP(attr);
+  float* h = nullptr;
+  unsigned long long* st = nullptr;
+  const size_t nst = (size_t)2 * kStampFrames * kStampPoints;
+  RELA_HIP(hipMalloc(&h, (size_t)N * 512 * 4));
+  RELA_HIP(hipMalloc(&st, nst * 8));
+  RELA_HIP(hipMemsetAsync(st, 0, nst * 8, s));
+  const FFNetDev& d = n->d;
+  hipLaunchKernelGGL((fc_bf16s<FcFast, false, true>), fc_grid_xcd(ceil_div(N, FcFast::BM), 1), dim3(kThreads),
+                     FcFast::LDS_BYTES, s, a3_records, (const uint4*)d.Bff, (const float*)d.bf, h, N, 0, st);
+  RELA_HIP(hipStreamSynchronize(s));
+  RELA_HIP(hipMemcpy(out_host, st, nst * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(h);
+  (void)hipFree(st);
   return RELA_OK;
 }
 
@@ -2766,7 +2893,7 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
       {
         ProfScope prof(names[3], s);
         note_launch("fc_bf16s (split-K)");
-        hipLaunchKernelGGL((fc_bf16s<FcFast, true>), dim3(4, rb, slices), dim3(kThreads), FcFast::LDS_BYTES, s,
+        hipLaunchKernelGGL((fc_bf16s<FcFast, true>), fc_grid_xcd(rb, slices), dim3(kThreads), FcFast::LDS_BYTES, s,
                            (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, part, N, per);
       }
       note_launch("fc_reduce"); hipLaunchKernelGGL(fc_reduce, dim3(ceil_div(N * 128, 256)), dim3(256), 0, s, (const float*)part, slices, N,
@@ -2812,13 +2939,8 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     }
     {
       ProfScope prof(names[3], s);
-      static const int bdepth = getenv("RELA_FC_BDEPTH") ? atoi(getenv("RELA_FC_BDEPTH")) : 2;
       note_launch("fc_bf16s");
-      if (bdepth == 1)
-        hipLaunchKernelGGL((fc_bf16s<FcFast, false, 1>), dim3(4, ceil_div(N, FcFast::BM)), dim3(kThreads), FcFast::LDS_BYTES, s,
-                           (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, h, N, 0);
-      else
-        hipLaunchKernelGGL(fc_bf16s<FcFast>, dim3(4, ceil_div(N, FcFast::BM)), dim3(kThreads), FcFast::LDS_BYTES, s,
+      hipLaunchKernelGGL(fc_bf16s<FcFast>, fc_grid_xcd(ceil_div(N, FcFast::BM), 1), dim3(kThreads), FcFast::LDS_BYTES, s,
                            (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, h, N, 0);
     }
   } else {
@@ -2968,7 +3090,7 @@ int ffnet_learner_forward(const rela_ffnet* on, const rela_ffnet* tg, int B, con
     {
       ProfScope prof("learner_fwd_fc", s);
       note_launch("fc_bf16s (split-K)");
-      hipLaunchKernelGGL((fc_bf16s<FcFast, true>), dim3(4, rb, slices), dim3(kThreads), FcFast::LDS_BYTES, s,
+      hipLaunchKernelGGL((fc_bf16s<FcFast, true>), fc_grid_xcd(rb, slices), dim3(kThreads), FcFast::LDS_BYTES, s,
                          (const uint8_t*)ww.a3, (const uint4*)n->d.Bff, (const float*)n->d.bf, part, N, per);
     }
     note_launch("fc_reduce");

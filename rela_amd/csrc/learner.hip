@@ -56,6 +56,13 @@ struct rela_apex_learner {
   int pend_B = 0, last_B = 0;
   int pend_rows = 0;  // rows of the ffnet_ws layout the last forward used for ws_on (B, or 2 B for the merged forward)
   const uint8_t* pend_obs = nullptr;
+  // The side lane of the backward pass (TrunkBwd in learner_common.h): the weight gradients of heads, fc, conv3 and
+  // conv2, the column sums and the records -> f32 conversion of the forward's activations run on `side` next to the
+  // data-gradient chain on the caller's stream; RELA_LEARNER_LANES=1 keeps everything on the caller's stream.
+  hipStream_t side = nullptr;
+  hipEvent_t ev[8] = {nullptr};  // 0 forward done | 1 unsplit done | 2 d_ha | 3 d_h | 4 d_a3 | 5 d_a2 | 6 side lane done
+  float *part_side = nullptr, *cpart_side = nullptr;
+  void *frag2 = nullptr, *frag3 = nullptr;  // conv2 / conv3 data-gradient weight fragments, re-packed with the weights
 };
 
 namespace {
@@ -73,6 +80,7 @@ int repack(rela_apex_learner* l, bool online, bool target, hipStream_t s) {
     extra.w2p = l->w2p, extra.w3p = l->w3p, extra.wfcp = l->wfcp;
     int rc = ffnet_load_extra(l->online, &p, s, extra);
     if (rc != RELA_OK) return rc;
+    if (l->frag2) dgfast::pack_frags(l->w2p, l->w3p, l->frag2, l->frag3, s);
   }
   if (target) {
     const rela_ffnet_params p = params_at(l, l->PT);
@@ -150,6 +158,15 @@ extern "C" int rela_apex_learner_create(rela_apex_learner** out, int num_action,
   RELA_HIP(hipMalloc(&l->npart, sizeof(double) * kNormBlocks));
   RELA_HIP(hipMalloc(&l->norm, sizeof(float) * 2));
   RELA_HIP(hipMalloc(&l->loss, sizeof(float)));
+  static const bool lanes = !(getenv("RELA_LEARNER_LANES") && atoi(getenv("RELA_LEARNER_LANES")) == 1);
+  if (lanes) {
+    RELA_HIP(hipStreamCreateWithFlags(&l->side, hipStreamNonBlocking));
+    for (hipEvent_t& e : l->ev) RELA_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    RELA_HIP(hipMalloc(&l->part_side, sizeof(float) * kTrunkPartFloats));
+    RELA_HIP(hipMalloc(&l->cpart_side, sizeof(float) * kColsumBlocks * (32 + 512 + 64 + 64 + 32)));
+    RELA_HIP(hipMalloc(&l->frag2, dgfast::kFrag2Bytes));
+    RELA_HIP(hipMalloc(&l->frag3, dgfast::kFrag3Bytes));
+  }
   *out = l;
   return RELA_OK;
 }
@@ -160,8 +177,11 @@ extern "C" void rela_apex_learner_destroy(rela_apex_learner* l) {
   (void)hipDeviceSynchronize();
   void* ps[] = {l->P,  l->PT,   l->G,    l->S1,   l->S2,   l->w2p, l->w3p,  l->wfcp,  l->ws_on, l->ws_tmp, l->q,
                 l->td, l->d_ha, l->d_h,  l->d_a3, l->d_a2, l->d_a1, l->col, l->part,  l->cpart, l->s32,    l->npart,
-                l->norm, l->loss};
+                l->norm, l->loss, l->part_side, l->cpart_side, l->frag2, l->frag3};
   for (void* p : ps) (void)hipFree(p);
+  for (hipEvent_t e : l->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (l->side) (void)hipStreamDestroy(l->side);
   rela_ffnet_destroy(l->online);
   rela_ffnet_destroy(l->target);
   delete l;
@@ -280,6 +300,7 @@ extern "C" int rela_apex_learner_loss(rela_apex_learner* l, int batch, const voi
   float* q_nt = l->q + 2 * (size_t)Bn * A;
   // td_err (apex.py:30-45): greedy_act(next_obs) and target_net(next_obs) carry no gradient
   int rc;
+  bool unsplit_side = false;
   l->pend_rows = Bn;
   if (rela_ffnet_precision(l->online) == 1 && ffnet_learner_forward_ok(l->online, l->target, Bn)) {
     // bf16x2: all three forwards on split-bf16 MFMA, one launch per layer (online over [s ; s'], target over s'); the
@@ -287,8 +308,10 @@ extern "C" int rela_apex_learner_loss(rela_apex_learner* l, int batch, const voi
     rc = ffnet_learner_forward(l->online, l->target, Bn, obs, nobs, legal, nlegal, q_on, q_no, q_nt, l->ws_on, l->ws_tmp,
                                l->ws_bytes, s);
     if (rc != RELA_OK) return rc;
-    rc = ffnet_learner_unsplit(Bn, l->ws_on, s);
+    if (l->side) lane_dep(l->ev[0], s, l->side);  // (the loss kernel below reads Q only: the conversion runs next to it)
+    rc = ffnet_learner_unsplit(Bn, l->ws_on, l->side ? l->side : s);
     if (rc != RELA_OK) return rc;
+    unsplit_side = l->side != nullptr;
     l->pend_rows = 2 * Bn;  // the workspace layout the backward must address
   } else {
     rc = rela_ffnet_forward(l->online, Bn, nobs, nlegal, q_no, l->ws_tmp, l->ws_bytes, s);
@@ -312,6 +335,7 @@ extern "C" int rela_apex_learner_loss(rela_apex_learner* l, int batch, const voi
                        A, l->d_ha, l->loss);
   }
   if (loss_dev) RELA_HIP(hipMemcpyAsync(loss_dev, l->loss, sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (unsplit_side) lane_dep(l->ev[1], l->side, s);  // the caller's stream owns the workspace again from here
   RELA_LAUNCH_CHECK();
   l->pend_B = l->last_B = Bn;
   l->pend_obs = obs;
@@ -334,6 +358,9 @@ extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
 
   ColsumJobs sums;  // the five bias gradients: queued here, one launch pair at the end of trunk_backward
   const bool g3 = rela_ffnet_precision(l->online) == 1 && gemm_bf16x3_on();  // bf16x2: the GEMMs on bf16 MFMA too
+  const bool lanes = l->side != nullptr;
+  hipStream_t sw = lanes ? l->side : s;  // the weight-gradient lane
+  if (lanes) lane_dep(l->ev[2], s, sw);  // d_ha and the forward's activations are ready
 
   // heads: d_h, dWh, db
   {
@@ -347,10 +374,11 @@ extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
     ProbHeadWgrad p{};
     p.M = 32, p.N = 512, p.K = Bn;
     p.d_ha = l->d_ha, p.h = w.h, p.g_a_w = Gm[10], p.g_v_w = Gm[8], p.A = A;
-    if (g3) (void)gemm3::launch_gemm<Tile3W32>(p, 1, s, "learner_wgrad_heads");
-    else launch_gemm<TileW32>(p, 1, s, "learner_wgrad_heads");
+    if (g3) (void)gemm3::launch_gemm<Tile3W32>(p, 1, sw, "learner_wgrad_heads");
+    else launch_gemm<TileW32>(p, 1, sw, "learner_wgrad_heads");
   }
   sums.add(l->d_ha, Bn, 32, l->s32);
+  if (lanes) lane_dep(l->ev[3], s, sw);  // d_h is ready
   // fc: d_a3, dWfc, db
   {
     ProbFcDgrad p{};
@@ -363,8 +391,8 @@ extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
     ProbFcWgrad p{};
     p.M = 512, p.N = 3136, p.K = Bn;
     p.d_h = l->d_h, p.a3 = w.a3, p.g_fc_w = Gm[6];
-    if (g3) (void)gemm3::launch_gemm<Tile3Wfc>(p, 1, s, "learner_wgrad_fc");
-    else launch_gemm<TileWfc>(p, 1, s, "learner_wgrad_fc");
+    if (g3) (void)gemm3::launch_gemm<Tile3Wfc>(p, 1, sw, "learner_wgrad_fc");
+    else launch_gemm<TileWfc>(p, 1, sw, "learner_wgrad_fc");
   }
   sums.add(l->d_h, Bn, 512, Gm[7]);
   {
@@ -373,8 +401,14 @@ extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
     t.col = l->col, t.part = l->part, t.cpart = l->cpart, t.w2p = l->w2p, t.w3p = l->w3p;
     t.g_c1w = Gm[0], t.g_c1b = Gm[1], t.g_c2w = Gm[2], t.g_c2b = Gm[3], t.g_c3w = Gm[4], t.g_c3b = Gm[5];
     t.fast = rela_ffnet_precision(l->online) == 1;
+    if (lanes) {
+      t.side = sw, t.ev_da3 = l->ev[4], t.ev_da2 = l->ev[5], t.ev_side = l->ev[6];
+      t.part_side = l->part_side, t.cpart_side = l->cpart_side;
+      if (t.fast) t.frag2 = l->frag2, t.frag3 = l->frag3;
+      t.s32 = l->s32, t.A = A, t.g_a_b = Gm[11], t.g_v_b = Gm[9];
+    }
     trunk_backward(t, s, &sums);
-    hipLaunchKernelGGL(head_bias_grad, dim3(1), dim3(32), 0, s, (const float*)l->s32, A, Gm[11], Gm[9]);
+    if (!lanes) hipLaunchKernelGGL(head_bias_grad, dim3(1), dim3(32), 0, s, (const float*)l->s32, A, Gm[11], Gm[9]);
   }
   RELA_LAUNCH_CHECK();
   return RELA_OK;

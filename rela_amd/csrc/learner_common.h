@@ -566,7 +566,23 @@ struct TrunkBwd {
   const float *w2p, *w3p;  // conv2 / conv3 weights in dgrad k order (permute_weights)
   float *g_c1w, *g_c1b, *g_c2w, *g_c2b, *g_c3w, *g_c3b;  // gradients, state_dict layout
   bool fast = false;   // the learner's bf16x2 mode: conv1's weight gradient on bf16 MFMA
+  // Two-lane form (the Ape-X learner): conv3's and conv2's weight gradients, and the column sums of every tensor that
+  // exists by then (the caller's pending jobs, d_a3, d_a2), run on `side` next to the data-gradient chain on the
+  // caller's stream; the caller's stream waits for the side lane before trunk_backward returns.  Every kernel computes
+  // what it computes on one lane (same grids, same summation orders): the results are bit-identical.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_da3 = nullptr, ev_da2 = nullptr, ev_side = nullptr;
+  float *part_side = nullptr, *cpart_side = nullptr;  // the side lane's own `part` / `cpart`
+  const void *frag2 = nullptr, *frag3 = nullptr;  // dgrad weight fragments packed ahead (else per call, into `part`)
+  const float* s32 = nullptr;                     // (side lane) head_bias_grad after the column sums
+  float *g_a_b = nullptr, *g_v_b = nullptr;
+  int A = 0;
 };
+// `to` continues only after everything queued on `from` so far
+inline void lane_dep(hipEvent_t ev, hipStream_t from, hipStream_t to) {
+  (void)hipEventRecord(ev, from);
+  (void)hipStreamWaitEvent(to, ev, 0);
+}
 
 // all queued jobs in one launch pair; cpart must hold kColsumBlocks * (sum of the jobs' C) floats
 inline void colsum_multi_launch(ColsumJobs& jobs, float* cpart, hipStream_t s) {
@@ -595,34 +611,38 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
   const int Bn = t.Bn;
   ColsumJobs own;
   ColsumJobs& jobs = pending ? *pending : own;
+  const bool lanes = t.side != nullptr;
+  hipStream_t sw = lanes ? t.side : s;  // the lane of conv3's / conv2's weight gradients
+  float* partw = lanes ? t.part_side : t.part;
+  if (lanes) lane_dep(t.ev_da3, s, sw);  // d_a3 (and everything the pending jobs read) is ready
   // conv2 / conv3 on bf16 MFMA only for many frames (R2D2: T * B): at 512 frames their per-block fixed costs (LDS
   // zero fill, 256 partial tiles of 128 / 144 KB for reduce_splits) cancel the gain (Ape-X: step 0.83 -> 0.91 ms)
   const bool fast23 = t.fast && Bn >= kFastWgradMinFrames;
   if (fast23) {  // conv3's weight gradient on bf16 MFMA (wgrad_conv3_bf16.h)
     int blocks = 0;
     {
-      ProfScope prof("learner_wgrad_conv3", s);
-      (void)w3fast::launch(t.a2, t.d_a3, Bn, t.part, s, &blocks);
+      ProfScope prof("learner_wgrad_conv3", sw);
+      (void)w3fast::launch(t.a2, t.d_a3, Bn, partw, sw, &blocks);
     }
-    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 576, 256)), dim3(256), 0, s, (const float*)t.part, blocks, 64,
+    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 576, 256)), dim3(256), 0, sw, (const float*)partw, blocks, 64,
                        576, kRedConv3, t.g_c3w);
   } else {  // conv3: dW3, db3, d_a2
     ProbW3 p{};
     p.M = 64, p.N = 576, p.K = Bn * 49;
-    p.d_out = t.d_a3, p.in = t.a2, p.part = t.part;
+    p.d_out = t.d_a3, p.in = t.a2, p.part = partw;
     // (a few hundred frames: 3 x the splits = 3-4 blocks per CU instead of one; a block alone on its CU waits out
     // every chunk's load latency with two waves per SIMD)
     static const int mul = getenv("RELA_WGRAD_SPLIT_MUL") ? atoi(getenv("RELA_WGRAD_SPLIT_MUL")) : 3;
     const int split3 = Bn <= 1024 ? kSplitW3 * mul : kSplitW3;
-    if (t.fast && gemm_bf16x3_on()) (void)gemm3::launch_gemm<Tile3W64>(p, split3, s, "learner_wgrad_conv3");
-    else launch_gemm<TileW64>(p, split3, s, "learner_wgrad_conv3");
-    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 576, 256)), dim3(256), 0, s, (const float*)t.part, split3, 64,
+    if (t.fast && gemm_bf16x3_on()) (void)gemm3::launch_gemm<Tile3W64>(p, split3, sw, "learner_wgrad_conv3");
+    else launch_gemm<TileW64>(p, split3, sw, "learner_wgrad_conv3");
+    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 576, 256)), dim3(256), 0, sw, (const float*)partw, split3, 64,
                        576, kRedConv3, t.g_c3w);
   }
   jobs.add(t.d_a3, (int64_t)Bn * 49, 64, t.g_c3b);
   if (t.fast) {  // transposed convolution on bf16 MFMA, ReLU mask fused, no column buffer (dgrad_conv_bf16.h)
     ProfScope prof("learner_dgrad_conv3", s);
-    (void)dgfast::launch_conv3(t.d_a3, t.w3p, t.a2, t.d_a2, Bn, t.part, s);
+    (void)dgfast::launch_conv3(t.d_a3, t.w3p, t.a2, t.d_a2, Bn, t.part, s, t.frag3);
   } else {
     ProbConvDgrad p{};
     p.M = Bn * 49, p.N = 576, p.K = 64;
@@ -632,29 +652,35 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     hipLaunchKernelGGL(col2im3, dim3(ceil_div((int64_t)Bn * 81 * 16, 256)), dim3(256), 0, s, (const float*)t.col, t.a2,
                        t.d_a2, Bn);
   }
+  if (lanes) lane_dep(t.ev_da2, s, sw);  // d_a2 is ready
   if (fast23) {  // conv2's weight gradient on bf16 MFMA (wgrad_conv2_bf16.h)
     int blocks = 0;
     {
-      ProfScope prof("learner_wgrad_conv2", s);
-      (void)w2fast::launch(t.a1, t.d_a2, Bn, t.part, s, &blocks);
+      ProfScope prof("learner_wgrad_conv2", sw);
+      (void)w2fast::launch(t.a1, t.d_a2, Bn, partw, sw, &blocks);
     }
-    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 512, 256)), dim3(256), 0, s, (const float*)t.part, blocks, 64,
+    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 512, 256)), dim3(256), 0, sw, (const float*)partw, blocks, 64,
                        512, kRedConv2, t.g_c2w);
   } else {  // conv2: dW2, db2, d_a1
     ProbW2 p{};
     p.M = 64, p.N = 512, p.K = Bn * 81;
-    p.d_out = t.d_a2, p.in = t.a1, p.part = t.part;
+    p.d_out = t.d_a2, p.in = t.a1, p.part = partw;
     static const int mul = getenv("RELA_WGRAD_SPLIT_MUL") ? atoi(getenv("RELA_WGRAD_SPLIT_MUL")) : 3;
     const int split2 = Bn <= 1024 ? kSplitW2 * mul : kSplitW2;
-    if (t.fast && gemm_bf16x3_on()) (void)gemm3::launch_gemm<Tile3W64>(p, split2, s, "learner_wgrad_conv2");
-    else launch_gemm<TileW64>(p, split2, s, "learner_wgrad_conv2");
-    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 512, 256)), dim3(256), 0, s, (const float*)t.part, split2, 64,
+    if (t.fast && gemm_bf16x3_on()) (void)gemm3::launch_gemm<Tile3W64>(p, split2, sw, "learner_wgrad_conv2");
+    else launch_gemm<TileW64>(p, split2, sw, "learner_wgrad_conv2");
+    hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 512, 256)), dim3(256), 0, sw, (const float*)partw, split2, 64,
                        512, kRedConv2, t.g_c2w);
   }
   jobs.add(t.d_a2, (int64_t)Bn * 81, 64, t.g_c2b);
+  if (lanes) {  // the side lane ends here: the column sums of everything but d_a1, then the head biases
+    colsum_multi_launch(jobs, t.cpart_side, sw);
+    if (t.s32) hipLaunchKernelGGL(head_bias_grad, dim3(1), dim3(32), 0, sw, t.s32, t.A, t.g_a_b, t.g_v_b);
+    jobs.n = 0;
+  }
   if (t.fast) {
     ProfScope prof("learner_dgrad_conv2", s);
-    (void)dgfast::launch_conv2(t.d_a2, t.w2p, t.a1, t.d_a1, Bn, t.part, s);
+    (void)dgfast::launch_conv2(t.d_a2, t.w2p, t.a1, t.d_a1, Bn, t.part, s, t.frag2);
   } else {
     ProbConvDgrad p{};
     p.M = Bn * 81, p.N = 512, p.K = 64;
@@ -682,6 +708,7 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
   }
   jobs.add(t.d_a1, (int64_t)Bn * 400, 32, t.g_c1b);
   colsum_multi_launch(jobs, t.cpart, s);
+  if (lanes) lane_dep(t.ev_side, sw, s);
 }
 
 // ---- clip_grad_norm_ + optimiser over flat parameter / gradient / state buffers -------------------

@@ -36,7 +36,6 @@ RELA_BENCH_ONLY=actor timeout -k 10 200 python bench.py --no-cpu-baseline --no-t
 {
   for n in 512 6400; do TAG="N=$n f32" N=$n PRECISION=f32 timeout -k 10 120 python tools/time_forward.py 2>&1 | tail -1; done
   for n in 512 1024 6400; do TAG="N=$n bf16x2" N=$n PRECISION=bf16x2 timeout -k 10 120 python tools/time_forward.py 2>&1 | tail -1; done
-  TAG="N=6400 bf16x2 fc weight fragments one position ahead (r2)" RELA_FC_BDEPTH=1 N=6400 PRECISION=bf16x2 timeout -k 10 120 python tools/time_forward.py 2>&1 | tail -1
 } > $O/forward_modes.log
 cat $O/forward_modes.log
 timeout -k 10 300 python tools/time_sample.py > $O/time_sample.json 2> $O/time_sample.err || exit 14
