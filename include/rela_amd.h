@@ -258,6 +258,12 @@ int rela_ffnet_precision(const rela_ffnet* net);
  * frames of block 0 (waves 0 and 7) -> out_host [2][8][12] u64 (tools/conv12_phases.py). */
 int rela_ffnet_debug_conv12_stamps(const rela_ffnet* net, int n, const uint8_t* s_dev, unsigned long long* out_host,
                                    void* stream);
+/* Test hook: conv1 -> conv2 of the split-bf16 mode for n frames through the job form of the kernel.  a1_records
+ * [n][400][hi 32 | lo 32] bf16 and a2_records [n][81][hi 64 | lo 64] bf16 are device buffers; scale_host / bias_host
+ * (32 floats each, or NULL) receive conv1's packed per-channel scales and biases when conv1 runs on the int8 matrix cores
+ * (csrc/ffnet.hip: conv12_i8), zeros otherwise. */
+int rela_ffnet_debug_conv12_records(const rela_ffnet* net, int n, const uint8_t* s_dev, uint8_t* a1_records,
+                                    uint8_t* a2_records, float* scale_host, float* bias_host, void* stream);
 /* The same for fc_bf16s (positions 8..15 of block 0; 5 points per position). */
 int rela_ffnet_debug_fc_stamps(const rela_ffnet* net, int n, const uint8_t* a3_records, unsigned long long* out_host,
                                void* stream);

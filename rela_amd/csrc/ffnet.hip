@@ -49,6 +49,10 @@ struct FFNetDev {
   uint4 *B2f = nullptr, *B3f = nullptr, *Bff = nullptr;
   uint4* B1p = nullptr;  // conv1 frags as B1, k-steps plane-major (conv1_persist)
   float* Bhp = nullptr;  // heads weights [ct 2][wave 4][j 32][lane 64] in the k order of heads_duel
+  // conv1 for the int8 matrix cores (conv12_i8): digits [hi, mid, lo][ct 2][tap 4][lane 64] x 16 int8, the channels'
+  // scales s_c and the biases b_c + 128 s_c sum_k q_k
+  uint4* W1d = nullptr;
+  float *s1q = nullptr, *b1q = nullptr;
 };
 
 namespace {
@@ -1227,6 +1231,305 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
   conv12_body<false>(in, nullptr, N, B1frag, bias1, B2frag, bias2, out, nullptr, 0, 0, N, blockIdx.x, gridDim.x);
 }
 
+// ---- conv1 on the INT8 matrix cores, whole frame at a time (r3) ----------------------------------------------------
+// The frames are u8, so conv1 needs no floating-point operand at all: the weights of an output channel c become
+// 24-bit fixed point, w = s_c * q with |q| <= 127 * 65536 + 127 * 256 + 127 and q = 65536 d_hi + 256 d_mid + d_lo in
+// balanced base-256 digits (int8 each), the pixels x - 128 (int8), and
+//     conv1(x)[c] = s_c * (65536 S_hi + 256 S_mid + S_lo) + (b_c + 128 s_c sum_k q_k),   S_d = sum_k (x_k - 128) d_k
+// with the three S exact in i32 (|S| <= 256 * 128 * 128 = 2^22).  v_mfma_i32_16x16x64_i8 runs at twice the bf16 rate:
+// three digit products cost 0.75 of the two bf16 products (hi, mid) they replace -- and carry 24 bits of every weight
+// relative to its channel's largest instead of 16, so conv1 of the split-bf16 mode is now within an f32 rounding or
+// two of the exact mode and independent of summation order.  The float part is fixed (tests mirror it bit for bit):
+//     u = f32(S_hi) * 65536 + f32(S_mid) * 256;  u = u + f32(S_lo);  y = u * s_c + b'_c      (no fused multiply-add)
+//
+// Layout.  K = 4 taps x 64: the 8 x 8 stride-4 kernel is a 2 x 2 stride-1 kernel over the 4 x 4 space-to-depth image
+// (21 x 21 cells of [plane 4][yy 4][xx 4] bytes).  LDS holds the WHOLE frame as [plane][cell 441][16 B] (28 KB; the
+// bf16 image of HALF a frame took 30): the B operand of tap (dy, dx) for output pixel (oy, ox) is one aligned
+// ds_read_b128 at plane g, cell (oy + dy) * 21 + ox + dx -- 16 consecutive pixels of a tile read 16 consecutive cells,
+// and the plane stride is 0 (mod 256), so the lanes a b128 pass serves ({li 0-3, 12-15 of g} + {li 4-11 of g + 1})
+// cover the 64 banks once.  A thread stages a cell with four dword loads (rows 4 Y .. 4 Y + 3 of the plane; a wave
+// reads 21-cell runs of 84 contiguous bytes), flips the sign bits and stores it with one ds_write_b128.
+//
+// Schedule (two barriers per frame where the half-frame kernel had five):
+//   phase A  conv1: T1 -> T2 (conv2's padded input tile of split records); the previous frame's conv2 output tile O
+//            leaves for HBM in the shadow of these MFMAs
+//   phase B  conv2: T2 -> O; the next frame's cells are loaded at its start and stored into T1 in its second half
+struct Conv12I {
+  using C2 = Conv2F;
+  static constexpr int GW = 21, NPIX = GW * GW, PLANE_ELEMS = 84 * 84, IN_ELEMS = 4 * PLANE_ELEMS;
+  static constexpr int PLANE1 = 7168;  // 441 cells x 16 B, padded to a multiple of 256 B
+  static_assert(PLANE1 >= NPIX * 16 && PLANE1 % 256 == 0, "plane stride");
+  static constexpr int T1_BYTES = 4 * PLANE1, T2_BYTES = C2::LDS_BYTES, O_BYTES = C2::OUT_BYTES + 256;
+  static constexpr int W1_UINT4 = 3 * 2 * 4 * 64;  // [digit hi, mid, lo][ct 2][tap 4][lane 64] x 16 int8
+  static constexpr int LDS_TOTAL = T1_BYTES + T2_BYTES + O_BYTES + W1_UINT4 * 16;
+  static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+  static constexpr int CELLS = 4 * NPIX;
+  static constexpr int IT = (CELLS + kThreads - 1) / kThreads;  // 4 cells per thread
+  static constexpr int RT = 25, RG = 4, RPW = 7;  // 400 pixels = 25 tiles of 16; wave (ct, rg) owns tiles rg + 4 t
+  static constexpr int G0 = 3, G1 = 2, G2 = 2;    // three passes over the taps (tiles 0..2, 3..4, 5..6): 12 accumulator registers per tile
+  static constexpr int OV16 = C2::P * (C2::OC * 4 / 16);  // 16-byte chunks of an output tile
+  static constexpr int OIT = (OV16 + kThreads - 1) / kThreads;
+};
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <bool JOBS, bool STAMPS = false>
+__device__ __forceinline__ void conv12i_body(const uint8_t* __restrict__ in, const uint8_t* __restrict__ in1, int n_in0,
+                                             const uint4* __restrict__ W1d, const float* __restrict__ scale1,
+                                             const float* __restrict__ bias1q, const uint4* __restrict__ B2frag,
+                                             const float* __restrict__ bias2, uint8_t* __restrict__ out,
+                                             uint8_t* __restrict__ a1_out, int a1_lo, int n_a1, int N, int bid, int nblk,
+                                             unsigned long long* stamps = nullptr) {
+  using F = Conv12I;
+  using C2 = Conv2F;
+  int stamp_frame = 0;
+  auto stamp = [&](int point) {
+    if constexpr (STAMPS) {
+      if (bid == 0 && (threadIdx.x == 0 || threadIdx.x == 448) && stamp_frame < kStampFrames)
+        stamps[((threadIdx.x == 0 ? 0 : 1) * kStampFrames + stamp_frame) * kStampPoints + point] = __builtin_amdgcn_s_memtime();
+    }
+  };
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* t1 = smem;
+  uint8_t* t2 = smem + F::T1_BYTES;
+  uint8_t* otile = t2 + F::T2_BYTES;
+  uint8_t* spare = otile + C2::OUT_BYTES;  // 256 B: rows past the last pixel of either layer land here
+  uint4* w1s = reinterpret_cast<uint4*>(otile + F::O_BYTES);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+
+  // ---- residents ----
+  for (int i = tid; i < F::W1_UINT4; i += kThreads) w1s[i] = W1d[i];
+  const int ct1 = wave & 1, rg1 = wave >> 1;
+  const int ct2 = wave % C2::CT, rg2 = wave / C2::CT;
+  bf16x8 bh[C2::KS], bl[C2::KS];
+  {
+    const uint4* bp = B2frag + (size_t)ct2 * C2::KS * 2 * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < C2::KS; ++ks) {
+      bh[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2) * 64]);
+      bl[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2 + 1) * 64]);
+    }
+  }
+  // operands swapped (weights as the A operand): a lane holds four consecutive channels of one pixel
+  const int ch1 = ct1 * 16 + 4 * g, ch2 = ct2 * 16 + 4 * g;
+  const f32x4 bv2 = *reinterpret_cast<const f32x4*>(bias2 + ch2);
+  // conv1 B fragments: lane (li, g) reads plane g's cell of its pixel (+ the tap's cell offset)
+  int a1base[F::RPW];
+#pragma unroll
+  for (int t = 0; t < F::RPW; ++t) {
+    const int m = min((min(rg1 + t * F::RG, F::RT - 1)) * 16 + li, 399);
+    const int oy = m / 20, ox = m - oy * 20;
+    a1base[t] = g * F::PLANE1 + (oy * F::GW + ox) * 16;
+  }
+  int a2base[C2::RPW];
+#pragma unroll
+  for (int t = 0; t < C2::RPW; ++t) {
+    const int m = (rg2 + t * C2::RG) * 16 + li;
+    const int mm = (m < C2::M) ? m : 0;
+    const int oy = mm / C2::OW, ox = mm - oy * C2::OW;
+    a2base[t] = (oy * C2::STRIDE * C2::RQ + ox * C2::STRIDE * C2::Q + g) * 16;
+  }
+
+  // ---- staging of a frame's cells (unpredicated, clamped cell index) ----
+  // (the cell addresses are derived per use from an opaque copy of tid: hoisted out of the frame loop they pin 8 registers)
+  auto cell_of = [&](int j, int& goff, int& loff) {
+    int tq = tid;
+    asm volatile("" : "+v"(tq));
+    const int c = min(tq + j * kThreads, F::CELLS - 1);
+    const int pl = c / F::NPIX, P = c - pl * F::NPIX;
+    const int Y = P / F::GW, X = P - Y * F::GW;
+    goff = pl * F::PLANE_ELEMS + 4 * Y * 84 + 4 * X;
+    loff = pl * F::PLANE1 + P * 16;
+  };
+  uint32_t st[F::IT][4];
+  auto g_load = [&](int n) {
+    const uint8_t* src = (!JOBS || n < n_in0) ? in + (size_t)n * F::IN_ELEMS : in1 + (size_t)(n - n_in0) * F::IN_ELEMS;
+#pragma unroll
+    for (int j = 0; j < F::IT; ++j) {
+      int goff, loff;
+      cell_of(j, goff, loff);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[j][r] = *reinterpret_cast<const uint32_t*>(src + goff + r * 84);
+    }
+  };
+  auto s_store = [&](int j) {  // x -> x - 128 as int8: flip the sign bits
+    int goff, loff;
+    cell_of(j, goff, loff);
+    *reinterpret_cast<uint4*>(t1 + loff) = make_uint4(st[j][0] ^ 0x80808080u, st[j][1] ^ 0x80808080u,
+                                                      st[j][2] ^ 0x80808080u, st[j][3] ^ 0x80808080u);
+  };
+
+  // ---- conv1 over the tiles [T0, T0 + NT) of this wave: T1 -> split records in T2 ----
+  // `hook(i)` runs after the MFMAs of pair i (the caller's copy-out slices)
+  auto conv1_pass = [&](auto t0_tag, auto nt_tag, auto&& hook) {
+    constexpr int T0 = decltype(t0_tag)::value, NT = decltype(nt_tag)::value;
+    i32x4 s_hi[NT], s_mid[NT], s_lo[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s_hi[t] = s_mid[t] = s_lo[t] = i32x4{0, 0, 0, 0};
+    constexpr int TOT = 4 * NT, D = 4;
+    uint4 x[D];
+    auto a_issue = [&](int idx, int slot) {
+      const int ks = idx / NT, t = T0 + idx - ks * NT;
+      x[slot] = *reinterpret_cast<const uint4*>(t1 + a1base[t] + ((ks >> 1) * F::GW + (ks & 1)) * 16);
+    };
+    // this wave's digit fragments of the current tap: ONE register set (a second one spills: conv2's resident weights
+    // hold 128 of the 256 registers); the next tap's are issued behind the last MFMAs that read these
+    uint4 wd[3];
+    auto w_issue = [&](int ks) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) wd[d] = w1s[((d * 2 + ct1) * 4 + ks) * 64 + lane];
+    };
+    w_issue(0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) a_issue(i, i);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int idx = ks * NT + t, slot = idx % D;
+        const i32x4 xv = __builtin_bit_cast(i32x4, x[slot]);
+        s_hi[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, wd[0]), xv, s_hi[t], 0, 0, 0);
+        s_mid[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, wd[1]), xv, s_mid[t], 0, 0, 0);
+        s_lo[t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, wd[2]), xv, s_lo[t], 0, 0, 0);
+        if (idx + D < TOT) a_issue(idx + D, slot);
+        if (t == NT - 1 && ks + 1 < 4) w_issue(ks + 1);
+        hook(idx);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // (scale and bias come from L1 per pass: kept across the frame loop they would cost eight registers)
+    int chq = ch1;
+    asm volatile("" : "+v"(chq));
+    const f32x4 sc1 = *reinterpret_cast<const f32x4*>(scale1 + chq), bv1 = *reinterpret_cast<const f32x4*>(bias1q + chq);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int rt = rg1 + (T0 + t) * F::RG;
+      if (rt >= F::RT) continue;  // (wave-uniform: only the group rg = 0 has a seventh tile)
+      const int m = rt * 16 + li;
+      const int y = m / 20, xx = m - y * 20;
+      f32x4 u = __builtin_convertvector(s_hi[t], f32x4) * 65536.0f + __builtin_convertvector(s_mid[t], f32x4) * 256.0f;
+      u = u + __builtin_convertvector(s_lo[t], f32x4);
+      const f32x4 v = u * sc1 + bv1;
+      split_store_lds4((m < 400) ? t2 + (size_t)(y * C2::RQ + xx * C2::Q) * 16 : spare, 32, ch1, v);
+    }
+  };
+
+  int n = bid;
+  if (n >= N) return;
+  g_load(n);
+#pragma unroll
+  for (int j = 0; j < F::IT; ++j) s_store(j);
+#pragma unroll
+  for (int ks = 0; ks < C2::KS; ++ks) {
+    pin_loaded(bh[ks]);
+    pin_loaded(bl[ks]);
+  }
+  __syncthreads();
+  constexpr int LO = C2::CIN * 2;
+  int prev = -1;  // the frame whose conv2 output waits in O
+  // the output tile of frame `prev` -> HBM: chunk j is read from O after pair RD(j) of conv1's first pass and stored
+  // after pair RD(j) + 2 (first frame: the reads return stale bytes and the stores are skipped)
+  static_assert(F::OIT == 3, "three named chunk registers below (an array indexed inside the hook stays in scratch)");
+  uint4 oc0, oc1, oc2;
+  auto o_read = [&](int j) {
+    const int i = min(tid + j * kThreads, F::OV16 - 1);
+    return *reinterpret_cast<const uint4*>(otile + (i >> 4) * C2::OROW + (i & 15) * 16);
+  };
+  auto o_write = [&](int j, const uint4& v) {
+    const int i = min(tid + j * kThreads, F::OV16 - 1);
+    if (prev >= 0) reinterpret_cast<uint4*>(out + (size_t)prev * C2::P * (C2::OC * 4))[i] = v;
+  };
+  auto copy_hook = [&](int idx) {
+    if (idx == 1) oc0 = o_read(0);
+    if (idx == 3) o_write(0, oc0);
+    if (idx == 5) oc1 = o_read(1);
+    if (idx == 7) o_write(1, oc1);
+    if (idx == 9) oc2 = o_read(2);
+    if (idx == 11) o_write(2, oc2);
+  };
+  static_assert(3 + 4 * (F::OIT - 1) < 4 * F::G0 && F::G0 + F::G1 + F::G2 == F::RPW, "copy-out slots inside the first pass");
+  for (; n < N; n += nblk) {
+    const int nn = (n + nblk < N) ? n + nblk : n;  // (the last round re-stages its own frame)
+    stamp(0);
+    conv1_pass(std::integral_constant<int, 0>{}, std::integral_constant<int, F::G0>{}, copy_hook);
+    conv1_pass(std::integral_constant<int, F::G0>{}, std::integral_constant<int, F::G1>{}, [](int) {});
+    conv1_pass(std::integral_constant<int, F::G0 + F::G1>{}, std::integral_constant<int, F::G2>{}, [](int) {});
+    stamp(1);
+    __syncthreads();  // T2 complete, T1 and O free
+    stamp(2);
+    g_load(nn);
+    if constexpr (JOBS) {
+      if (a1_out && (unsigned)(n - a1_lo) < (unsigned)n_a1) {  // (block-uniform) conv1's records: [400 pixels][32 hi | 32 lo]
+        uint4* dst = reinterpret_cast<uint4*>(a1_out + (size_t)n * (400 * 128));
+        for (int i = tid; i < 400 * 8; i += kThreads) {
+          const int px = i >> 3, u = i & 7;
+          const int y = px / 20, x = px - y * 20;
+          dst[i] = *reinterpret_cast<const uint4*>(t2 + (size_t)(y * C2::RQ + x * C2::Q + u) * 16);
+        }
+      }
+    }
+    // ---- conv2 from T2; the next frame's cells go into T1 in the second half ----
+    {
+      f32x4 acc[C2::RPW];
+#pragma unroll
+      for (int t = 0; t < C2::RPW; ++t) acc[t] = bv2;
+      constexpr int TOT = C2::KS * C2::RPW, D = 3;
+      uint4 ah[D], al[D];
+      auto a_issue = [&](int idx, int slot) {
+        const int ks = idx / C2::RPW, t = idx - ks * C2::RPW;
+        const int kh = ks / C2::KW, kw = ks - kh * C2::KW;  // KSUB = 1: one k-step per tap
+        const uint8_t* ap = t2 + a2base[t] + (kh * C2::RQ + kw * C2::Q) * 16;
+        ah[slot] = *reinterpret_cast<const uint4*>(ap);
+        al[slot] = *reinterpret_cast<const uint4*>(ap + LO);
+      };
+#pragma unroll
+      for (int i = 0; i < D; ++i) a_issue(i, i);
+      __builtin_amdgcn_sched_barrier(0);
+      static_assert(TOT / 2 + 6 * (F::IT - 1) < TOT, "staging slots inside the loop");
+#pragma unroll
+      for (int idx = 0; idx < TOT; ++idx) {
+        const int ks = idx / C2::RPW, t = idx - ks * C2::RPW;
+        const int slot = idx % D;
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[slot]);
+        const bf16x8 xl = __builtin_bit_cast(bf16x8, al[slot]);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[ks], xh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xh, acc[t], 0, 0, 0);
+        if (idx + D < TOT) a_issue(idx + D, slot);
+#pragma unroll
+        for (int j = 0; j < F::IT; ++j)
+          if (idx == TOT / 2 + 6 * j) s_store(j);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      stamp(3);
+#pragma unroll
+      for (int t = 0; t < C2::RPW; ++t) {
+        const int m = (rg2 + t * C2::RG) * 16 + li;
+        split_store_lds4((m < C2::M) ? otile + (size_t)m * C2::OROW : spare, C2::OC, ch2, acc[t]);
+      }
+    }
+    stamp(4);
+    __syncthreads();  // O complete, T1 ready, T2 free
+    stamp(5);
+    stamp_frame += 1;
+    prev = n;
+  }
+  {  // the last frame's output tile
+    uint4* dst = reinterpret_cast<uint4*>(out + (size_t)prev * C2::P * (C2::OC * 4));
+    for (int i = tid; i < F::OV16; i += kThreads)
+      dst[i] = *reinterpret_cast<const uint4*>(otile + (i >> 4) * C2::OROW + (i & 15) * 16);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void conv12_i8(const uint8_t* __restrict__ in, const uint4* __restrict__ W1d,
+                                                      const float* __restrict__ scale1, const float* __restrict__ bias1q,
+                                                      const uint4* __restrict__ B2frag, const float* __restrict__ bias2,
+                                                      uint8_t* __restrict__ out, int N) {
+  conv12i_body<false>(in, nullptr, N, W1d, scale1, bias1q, B2frag, bias2, out, nullptr, 0, 0, N, blockIdx.x, gridDim.x);
+}
+
 // Several trunk passes in one launch (the learner's three forwards: online over [s ; s'], target over s'): job j owns
 // the blocks [block0, block0 + nblocks) and walks its own frames with its own weights.
 struct TrunkJob {
@@ -1234,6 +1537,8 @@ struct TrunkJob {
   int n_in0;
   const uint4 *B1, *B2, *B3;  // conv1 / conv2 / conv3 fragments of the job's net
   const float *b1, *b2, *b3;
+  const uint4* W1d;  // conv1 for the int8 matrix cores (conv12_i8_jobs), or NULL
+  const float *s1q, *b1q;
   uint8_t *a1_out;  // conv1's records [N][400][128 B], written for the rows [a1_lo, a1_lo + n_a1); or NULL
   int a1_lo, n_a1;
   uint8_t *a2, *a3;  // conv2's / conv3's split records [N][81][256 B] / [N][49][256 B]
@@ -1250,6 +1555,19 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s_jobs(TrunkJobs jobs) {
   const TrunkJob& t = jobs.j[k];
   conv12_body<true>(t.in0, t.in1, t.n_in0, t.B1, t.b1, t.B2, t.b2, t.a2, t.a1_out, t.a1_lo, t.n_a1, t.N,
                     (int)blockIdx.x - t.block0, t.nblocks);
+}
+__global__ __launch_bounds__(kThreads) void conv12_i8_stamps(const uint8_t* __restrict__ in, const uint4* __restrict__ W1d,
+                                                             const float* __restrict__ scale1, const float* __restrict__ bias1q,
+                                                             const uint4* __restrict__ B2frag, const float* __restrict__ bias2,
+                                                             uint8_t* __restrict__ out, int N, unsigned long long* stamps) {
+  conv12i_body<false, true>(in, nullptr, N, W1d, scale1, bias1q, B2frag, bias2, out, nullptr, 0, 0, N, blockIdx.x, gridDim.x, stamps);
+}
+__global__ __launch_bounds__(kThreads) void conv12_i8_jobs(TrunkJobs jobs) {
+  int k = 0;
+  while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].block0) ++k;
+  const TrunkJob& t = jobs.j[k];
+  conv12i_body<true>(t.in0, t.in1, t.n_in0, t.W1d, t.s1q, t.b1q, t.B2, t.b2, t.a2, t.a1_out, t.a1_lo, t.n_a1, t.N,
+                     (int)blockIdx.x - t.block0, t.nblocks);
 }
 __global__ __launch_bounds__(kThreads) void conv12_bf16s_stamps(const uint8_t* __restrict__ in, const uint4* __restrict__ B1frag,
                                                                 const float* __restrict__ bias1, const uint4* __restrict__ B2frag,
@@ -1900,6 +2218,11 @@ using FcFast = FcFastT<112>;
 // SPLIT (batches of a few hundred rows, where 4 x ceil(N / BM) blocks would leave most CUs idle): blockIdx.z owns the
 // positions [z * per, z * per + per) of the contraction and writes its raw partial sums to out[z][N][512]; fc_reduce adds
 // them up in z order with the bias and the ReLU.  Without SPLIT the range is the compile-time [0, 49).
+// conv1 of the split-bf16 mode on the int8 matrix cores (conv12_i8); RELA_CONV12=bf16 keeps the half-frame bf16 kernel
+inline bool conv12_i8_on() {
+  static const bool on = !(getenv("RELA_CONV12") && strcmp(getenv("RELA_CONV12"), "bf16") == 0);
+  return on;
+}
 // grid of fc_bf16s for `units` (row block, slice) pairs: XCD-aware 1-D form, or (RELA_FC_XCD_MAP=0) the plain (4, rb, slices)
 inline dim3 fc_grid_xcd(int rb, int slices) {
   static const bool xmap = !(getenv("RELA_FC_XCD_MAP") && atoi(getenv("RELA_FC_XCD_MAP")) == 0);
@@ -2532,6 +2855,60 @@ __global__ void pack_head_bias(const float* __restrict__ ab, const float* __rest
   if (j < 32) out[j] = j < A ? ab[j] : (j == 31 ? vb[0] : 0.f);
 }
 
+// conv1 for conv12_i8: one block of 256 threads per output channel c (thread = weight k = p*64 + ky*8 + kx of
+// state_dict's [32][4][8][8]).  s_c = max|w| / QMAX rounded UP to f32 (so that |w / s_c| <= QMAX), q = rint(w / s_c) in
+// double, balanced base-256 digits; b' = b + 128 s_c sum q in double, rounded once.  Digit d of (c, k) is byte
+// j = (ky % 4) * 4 + kx % 4 of lane (g = p) * 16 + c % 16 of fragment [d][c / 16][tap (ky / 4) * 2 + kx / 4].
+constexpr int kConv1QMax = 127 * 65536 + 127 * 256 + 127;
+__device__ __forceinline__ void pack_conv1_i8_block(int c, const float* __restrict__ w, const float* __restrict__ b,
+                                                    uint8_t* __restrict__ W1d, float* __restrict__ s1q, float* __restrict__ b1q) {
+  __shared__ float amax[256];
+  __shared__ long long qsum[256];
+  const int k = threadIdx.x;
+  const float wv = w[c * 256 + k] / 255.0f;  // the s / 255 of net.py:46, folded as in the other conv1 packs
+  amax[k] = fabsf(wv);
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (k < o) amax[k] = fmaxf(amax[k], amax[k + o]);
+    __syncthreads();
+  }
+  const float mx = amax[0];
+  float sc = 1.0f;
+  if (mx > 0.f) {
+    sc = (float)((double)mx / (double)kConv1QMax);
+    if (sc <= 0.f || (double)mx / (double)sc > (double)kConv1QMax) sc = nextafterf(sc, INFINITY);
+  }
+  long long q = llrint((double)wv / (double)sc);
+  q = q > kConv1QMax ? kConv1QMax : (q < -kConv1QMax ? -kConv1QMax : q);
+  qsum[k] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (k < o) qsum[k] += qsum[k + o];
+    __syncthreads();
+  }
+  if (k == 0) {
+    s1q[c] = sc;
+    b1q[c] = (float)((double)b[c] + 128.0 * (double)sc * (double)qsum[0]);
+  }
+  // balanced digits: lo, mid in [-128, 127], hi = the rest (|hi| <= 127 by the bound on q)
+  const int qi = (int)q;
+  const int lo = ((qi + 128) & 255) - 128;
+  const int q1 = (qi - lo) >> 8;
+  const int mid = ((q1 + 128) & 255) - 128;
+  const int hi = (q1 - mid) >> 8;
+  const int pl = k >> 6, ky = (k >> 3) & 7, kx = k & 7;
+  const int tap = (ky >> 2) * 2 + (kx >> 2), j = (ky & 3) * 4 + (kx & 3);
+  const int lane = pl * 16 + (c & 15), ct = c >> 4;
+  const int dig[3] = {hi, mid, lo};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) W1d[((size_t)((d * 2 + ct) * 4 + tap) * 64 + lane) * 16 + j] = (uint8_t)(int8_t)dig[d];
+}
+
+__global__ __launch_bounds__(256) void pack_conv1_i8(const float* __restrict__ w, const float* __restrict__ b, uint8_t* __restrict__ W1d,
+                                                     float* __restrict__ s1q, float* __restrict__ b1q) {
+  pack_conv1_i8_block((int)blockIdx.x, w, b, W1d, s1q, b1q);
+}
+
 // Every kernel-layout copy of an AtariFFNet's weights in ONE launch (a learner re-packs after every optimiser step:
 // twelve pack kernels, four device copies and the head bias were seventeen launches).  A block finds its job in a
 // table of first-block indices; the job bodies are the *_at functions of the separate kernels.
@@ -2541,7 +2918,9 @@ struct PackAllArgs {
   float *B2, *B3, *Bf, *BfT, *Bh, *Bhp, *b1, *b2, *b3, *bf, *bh;
   int A;
   float *w2p, *w3p, *wfcp;  // the learner's dgrad operand copies (ffnet_layout.h), or NULL
-  int first[17];  // first block of job j; first[16] = total
+  uint8_t* W1d;             // conv1 for the int8 matrix cores (pack_conv1_i8_block)
+  float *s1q, *b1q;
+  int first[18];  // first block of job j; first[17] = total
 };
 __global__ void pack_ffnet_all(PackAllArgs a) {
   const int b = blockIdx.x;
@@ -2575,7 +2954,8 @@ __global__ void pack_ffnet_all(PackAllArgs a) {
     }
     case 13: if (idx < 64 * 512) permute_weight_at(kPermConv2, (int)idx, a.p[2], a.w2p); break;
     case 14: if (idx < 64 * 576) permute_weight_at(kPermConv3, (int)idx, a.p[4], a.w3p); break;
-    default: if (idx < 512 * 3136) permute_weight_at(kPermFc, (int)idx, a.p[6], a.wfcp); break;
+    case 15: if (idx < 512 * 3136) permute_weight_at(kPermFc, (int)idx, a.p[6], a.wfcp); break;
+    default: pack_conv1_i8_block(b - a.first[16], a.p[0], a.p[1], a.W1d, a.s1q, a.b1q); break;  // (block-uniform: it synchronises)
   }
 }
 
@@ -2628,6 +3008,13 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
   RELA_HIP(hipMalloc(&d.Bh, sizeof(float) * 2 * 128 * 64));
   RELA_HIP(hipMalloc(&d.bh, sizeof(float) * 32));
   RELA_HIP(hipMalloc(&d.B1p, sizeof(uint4) * Conv1B::FRAG_UINT4));
+  RELA_HIP(hipMalloc(&d.W1d, sizeof(uint4) * Conv12I::W1_UINT4));
+  RELA_HIP(hipMalloc(&d.s1q, sizeof(float) * 32));
+  RELA_HIP(hipMalloc(&d.b1q, sizeof(float) * 32));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_i8), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               Conv12I::LDS_TOTAL));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_i8_jobs), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               Conv12I::LDS_TOTAL));
   RELA_HIP(hipMalloc(&d.Bhp, sizeof(float) * 2 * 4 * 32 * 64));
   RELA_HIP(hipMalloc(&d.B2f, sizeof(uint4) * Conv2F::CT * Conv2F::KS * 2 * 64));
   RELA_HIP(hipMalloc(&d.B3f, sizeof(uint4) * Conv3F::CT * Conv3F::KS * 2 * 64));
@@ -2670,7 +3057,7 @@ extern "C" void rela_ffnet_destroy(rela_ffnet* n) {
   DeviceGuard g(n->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bf, n->d.bf, n->d.Bh, n->d.bh,
-                n->d.BfT, n->d.B2f, n->d.B3f, n->d.Bff, n->d.B1p, n->d.Bhp};
+                n->d.BfT, n->d.B2f, n->d.B3f, n->d.Bff, n->d.B1p, n->d.Bhp, n->d.W1d, n->d.s1q, n->d.b1q};
   for (void* p : ps) (void)hipFree(p);
   (void)hipFree(n->pipe_tmo);
   delete n;
@@ -2703,6 +3090,13 @@ extern "C" int rela_ffnet_debug_conv12_stamps(const rela_ffnet* n, int N, const 
   RELA_HIP(hipMalloc(&st, nst * 8));
   RELA_HIP(hipMemsetAsync(st, 0, nst * 8, s));
   const FFNetDev& d = n->d;
+  if (d.W1d && conv12_i8_on()) {  // points: 0 frame start | 1 conv1 done | 2 barrier | 3 conv2 MFMAs done | 4 epilogue | 5 barrier
+    static const hipError_t attr8 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_i8_stamps),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, Conv12I::LDS_TOTAL);
+    RELA_HIP(attr8);
+    hipLaunchKernelGGL(conv12_i8_stamps, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
+                       (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, a2, N, st);
+  } else
   hipLaunchKernelGGL(conv12_bf16s_stamps, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
                      (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, a2, N, st);
   RELA_HIP(hipStreamSynchronize(s));
@@ -2736,6 +3130,50 @@ extern "C" int rela_ffnet_debug_fc_stamps(const rela_ffnet* n, int N, const uint
   RELA_HIP(hipMemcpy(out_host, st, nst * 8, hipMemcpyDeviceToHost));
   (void)hipFree(h);
   (void)hipFree(st);
+  return RELA_OK;
+}
+
+// Diagnostic / test hook: conv1 -> conv2 of the split-bf16 mode for n frames through the job form of the kernel, which
+// also copies conv1's records out: a1_records [n][400][hi 32 | lo 32] bf16 (128 B per pixel), a2_records [n][81][hi 64 |
+// lo 64] (256 B per pixel), both device pointers; plus the packed conv1 scales and biases (host, 32 floats each) when
+// conv1 runs on the int8 matrix cores (zeros otherwise).
+extern "C" int rela_ffnet_debug_conv12_records(const rela_ffnet* n, int N, const uint8_t* s_dev, uint8_t* a1_records,
+                                               uint8_t* a2_records, float* scale_host, float* bias_host, void* stream_) {
+  RELA_CHECK(n && n->loaded && N >= 1 && s_dev && a1_records && a2_records, RELA_EINVAL, "rela_ffnet_debug_conv12_records: bad arguments");
+  DeviceGuard g(n->device);
+  hipStream_t s = (hipStream_t)stream_;
+  const FFNetDev& d = n->d;
+  TrunkJobs jobs{};
+  jobs.n = 1;
+  TrunkJob& j0 = jobs.j[0];
+  j0.in0 = s_dev, j0.in1 = s_dev, j0.n_in0 = N;
+  j0.B1 = (const uint4*)d.B1p, j0.B2 = (const uint4*)d.B2f, j0.B3 = (const uint4*)d.B3f;
+  j0.b1 = d.b1, j0.b2 = d.b2, j0.b3 = d.b3;
+  j0.W1d = d.W1d, j0.s1q = d.s1q, j0.b1q = d.b1q;
+  j0.a1_out = a1_records, j0.a1_lo = 0, j0.n_a1 = N;
+  j0.a2 = a2_records, j0.a3 = nullptr;
+  j0.N = N, j0.block0 = 0, j0.nblocks = std::min(kNumCU, N);
+  const bool i8 = d.W1d && conv12_i8_on();
+  if (i8) {
+    note_launch("conv12_i8_jobs");
+    hipLaunchKernelGGL(conv12_i8_jobs, dim3(j0.nblocks), dim3(kThreads), Conv12I::LDS_TOTAL, s, jobs);
+  } else {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_bf16s_jobs),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, Conv12::LDS_TOTAL);
+    RELA_HIP(attr);
+    note_launch("conv12_bf16s_jobs");
+    hipLaunchKernelGGL(conv12_bf16s_jobs, dim3(j0.nblocks), dim3(kThreads), Conv12::LDS_TOTAL, s, jobs);
+  }
+  RELA_HIP(hipStreamSynchronize(s));
+  if (scale_host) {
+    if (i8) RELA_HIP(hipMemcpy(scale_host, d.s1q, 32 * sizeof(float), hipMemcpyDeviceToHost));
+    else memset(scale_host, 0, 32 * sizeof(float));
+  }
+  if (bias_host) {
+    if (i8) RELA_HIP(hipMemcpy(bias_host, d.b1q, 32 * sizeof(float), hipMemcpyDeviceToHost));
+    else memset(bias_host, 0, 32 * sizeof(float));
+  }
+  RELA_LAUNCH_CHECK();
   return RELA_OK;
 }
 
@@ -2805,20 +3243,22 @@ int rela_amd::ffnet_load_impl(rela_ffnet* n, const rela_ffnet_params* p, int on_
     a.B2 = n->d.B2, a.B3 = n->d.B3, a.Bf = n->d.Bf, a.BfT = n->d.BfT, a.Bh = n->d.Bh, a.Bhp = n->d.Bhp;
     a.b1 = n->d.b1, a.b2 = n->d.b2, a.b3 = n->d.b3, a.bf = n->d.bf, a.bh = n->d.bh, a.A = A;
     a.w2p = extra.w2p, a.w3p = extra.w3p, a.wfcp = extra.wfcp;
-    const int64_t elems[16] = {2 * 8 * 64 * 8, 2 * 8 * 64 * 8, 4 * 128 * 64, 4 * 144 * 64, (int64_t)32 * 784 * 64,
+    a.W1d = reinterpret_cast<uint8_t*>(n->d.W1d), a.s1q = n->d.s1q, a.b1q = n->d.b1q;
+    const int64_t elems[17] = {2 * 8 * 64 * 8, 2 * 8 * 64 * 8, 4 * 128 * 64, 4 * 144 * 64, (int64_t)32 * 784 * 64,
                                (int64_t)3136 * 512, 2 * 128 * 64, 2 * 4 * 32 * 64,
                                (int64_t)Conv2F::CT * Conv2F::KS * 64 * 8, (int64_t)Conv3F::CT * Conv3F::KS * 64 * 8,
                                (int64_t)32 * FcFast::KS * 64 * 8, 672, 32,
-                               extra.w2p ? 64 * 512 : 0, extra.w3p ? 64 * 576 : 0, extra.wfcp ? (int64_t)512 * 3136 : 0};
+                               extra.w2p ? 64 * 512 : 0, extra.w3p ? 64 * 576 : 0, extra.wfcp ? (int64_t)512 * 3136 : 0,
+                               32 * 256};
     // a net whose owner never runs large batches (a learner re-packs after every step) skips the two fc layouts
     // only large batches read: Bf (f32 fragments, N >= kFcSplitBelow) and Bff (bf16 fragments, N >= kFastMinN)
-    int64_t el[16];
-    for (int jn = 0; jn < 16; ++jn) el[jn] = elems[jn];
+    int64_t el[17];
+    for (int jn = 0; jn < 17; ++jn) el[jn] = elems[jn];
     if (n->max_rows > 0 && n->max_rows < kFcSplitBelow) el[4] = 0;
     if (n->max_rows > 0 && n->max_rows < kFastTrunkMinN) el[10] = 0;  // (the split-K fc_bf16s serves 128 rows and up)
     a.first[0] = 0;
-    for (int jn = 0; jn < 16; ++jn) a.first[jn + 1] = a.first[jn] + (int)ceil_div(el[jn], 256);
-    hipLaunchKernelGGL(pack_ffnet_all, dim3(a.first[16]), dim3(256), 0, s, a);
+    for (int jn = 0; jn < 17; ++jn) a.first[jn + 1] = a.first[jn] + (int)ceil_div(el[jn], 256);
+    hipLaunchKernelGGL(pack_ffnet_all, dim3(a.first[17]), dim3(256), 0, s, a);
   }
   RELA_LAUNCH_CHECK();
   if (tmp) {
@@ -2869,8 +3309,13 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
       ProfScope prof(name12, s);
+      if (d.W1d && conv12_i8_on()) {
+        note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
+                           (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
+      } else {
       note_launch("conv12_bf16s"); hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
+      }
     }
     {
       ProfScope prof(names[2], s);
@@ -2918,8 +3363,13 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
                          n->pipe_tmo);
     } else if (fuse_mode == 1) {
       ProfScope prof(name12, s);
+      if (d.W1d && conv12_i8_on()) {
+        note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
+                           (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
+      } else {
       note_launch("conv12_bf16s"); hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
+      }
     } else {
     {
       ProfScope prof(names[0], s);
@@ -3057,6 +3507,7 @@ int ffnet_learner_forward(const rela_ffnet* on, const rela_ffnet* tg, int B, con
   j0.in0 = s_obs, j0.in1 = s_next, j0.n_in0 = B;
   j0.B1 = (const uint4*)on->d.B1p, j0.B2 = (const uint4*)on->d.B2f, j0.B3 = (const uint4*)on->d.B3f;
   j0.b1 = on->d.b1, j0.b2 = on->d.b2, j0.b3 = on->d.b3;
+  j0.W1d = on->d.W1d, j0.s1q = on->d.s1q, j0.b1q = on->d.b1q;
   j0.a1_out = reinterpret_cast<uint8_t*>(w.a1), j0.a1_lo = 0, j0.n_a1 = B;
   j0.a2 = reinterpret_cast<uint8_t*>(w.a2), j0.a3 = reinterpret_cast<uint8_t*>(w.a3);
   j0.N = 2 * B, j0.block0 = 0, j0.nblocks = nb0;
@@ -3064,13 +3515,19 @@ int ffnet_learner_forward(const rela_ffnet* on, const rela_ffnet* tg, int B, con
   j1.in0 = s_next, j1.in1 = s_next, j1.n_in0 = B;
   j1.B1 = (const uint4*)tg->d.B1p, j1.B2 = (const uint4*)tg->d.B2f, j1.B3 = (const uint4*)tg->d.B3f;
   j1.b1 = tg->d.b1, j1.b2 = tg->d.b2, j1.b3 = tg->d.b3;
+  j1.W1d = tg->d.W1d, j1.s1q = tg->d.s1q, j1.b1q = tg->d.b1q;
   j1.a1_out = nullptr, j1.a1_lo = 0, j1.n_a1 = 0;
   j1.a2 = reinterpret_cast<uint8_t*>(wt.a2), j1.a3 = reinterpret_cast<uint8_t*>(wt.a3);
   j1.N = B, j1.block0 = nb0, j1.nblocks = total - nb0;
   {
     ProfScope prof("learner_fwd_conv12", s);
-    note_launch("conv12_bf16s_jobs");
-    hipLaunchKernelGGL(conv12_bf16s_jobs, dim3(total), dim3(kThreads), Conv12::LDS_TOTAL, s, jobs);
+    if (j0.W1d && j1.W1d && conv12_i8_on()) {
+      note_launch("conv12_i8_jobs");
+      hipLaunchKernelGGL(conv12_i8_jobs, dim3(total), dim3(kThreads), Conv12I::LDS_TOTAL, s, jobs);
+    } else {
+      note_launch("conv12_bf16s_jobs");
+      hipLaunchKernelGGL(conv12_bf16s_jobs, dim3(total), dim3(kThreads), Conv12::LDS_TOTAL, s, jobs);
+    }
   }
   {
     // conv3 walks groups of Conv3F::S frames: the same block ranges serve (a job never has more blocks than groups
@@ -3182,6 +3639,13 @@ extern "C" int rela_lstmnet_create(rela_lstmnet** out, int num_action, int devic
   RELA_HIP(hipMalloc(&n->Bl, sizeof(float) * (size_t)GemmLstm::CT * GemmLstm::KS * 64));
   RELA_HIP(hipMalloc(&n->Wrec, (size_t)2048 * 49 * 256));
   RELA_HIP(hipMalloc(&n->bl, sizeof(float) * 2048));
+  RELA_HIP(hipMalloc(&d.W1d, sizeof(uint4) * Conv12I::W1_UINT4));
+  RELA_HIP(hipMalloc(&d.s1q, sizeof(float) * 32));
+  RELA_HIP(hipMalloc(&d.b1q, sizeof(float) * 32));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_i8), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               Conv12I::LDS_TOTAL));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_i8_jobs), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               Conv12I::LDS_TOTAL));
   RELA_HIP(hipMalloc(&d.B1p, sizeof(uint4) * Conv1B::FRAG_UINT4));
   RELA_HIP(hipMalloc(&d.B2f, sizeof(uint4) * Conv2F::CT * Conv2F::KS * 2 * 64));
   RELA_HIP(hipMalloc(&d.B3f, sizeof(uint4) * Conv3F::CT * Conv3F::KS * 2 * 64));
@@ -3208,7 +3672,7 @@ extern "C" void rela_lstmnet_destroy(rela_lstmnet* n) {
   DeviceGuard g(n->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bh, n->d.bh, n->Bl, n->bl,
-                n->d.B1p, n->d.B2f, n->d.B3f, n->Wrec};
+                n->d.B1p, n->d.B2f, n->d.B3f, n->Wrec, n->d.W1d, n->d.s1q, n->d.b1q};
   for (void* p : ps) (void)hipFree(p);
   delete n;
 }
@@ -3270,6 +3734,8 @@ extern "C" int rela_lstmnet_load(rela_lstmnet* n, const rela_lstmnet_params* p, 
   pack(kPackHeads, dv[12], dv[10], n->d.Bh, 2, 128);
   hipLaunchKernelGGL(pack_conv1_bf16x3, dim3(ceil_div(2 * 8 * 64 * 8, 256)), dim3(256), 0, s, dv[0],
                      reinterpret_cast<uint16_t*>(n->d.B1p), 1);
+  hipLaunchKernelGGL(pack_conv1_i8, dim3(32), dim3(256), 0, s, dv[0], dv[1], reinterpret_cast<uint8_t*>(n->d.W1d), n->d.s1q,
+                     n->d.b1q);
   hipLaunchKernelGGL(pack_frags_bf16s, dim3(ceil_div((int64_t)Conv2F::CT * Conv2F::KS * 64 * 8, 256)), dim3(256), 0, s, 1,
                      dv[2], reinterpret_cast<uint16_t*>(n->d.B2f), Conv2F::CT, Conv2F::KS);
   hipLaunchKernelGGL(pack_frags_bf16s, dim3(ceil_div((int64_t)Conv3F::CT * Conv3F::KS * 64 * 8, 256)), dim3(256), 0, s, 2,
@@ -3300,8 +3766,13 @@ bool lstm_trunk_launch(const FFNetDev& d, int N, const uint8_t* s_dev, float* a1
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
       ProfScope prof(names[1], s);
+      if (d.W1d && conv12_i8_on()) {
+        note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
+                           (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
+      } else {
       note_launch("conv12_bf16s"); hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
+      }
     }
     ProfScope prof(names[2], s);
     note_launch("conv_bf16s<Conv3F>"); hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
@@ -3421,13 +3892,19 @@ int lstmnet_trunk_records(const rela_lstmnet* n, int N, const uint8_t* s_dev, fl
   j0.in0 = s_dev, j0.in1 = s_dev, j0.n_in0 = N;
   j0.B1 = (const uint4*)d.B1p, j0.B2 = (const uint4*)d.B2f, j0.B3 = (const uint4*)d.B3f;
   j0.b1 = d.b1, j0.b2 = d.b2, j0.b3 = d.b3;
+  j0.W1d = d.W1d, j0.s1q = d.s1q, j0.b1q = d.b1q;
   j0.a1_out = reinterpret_cast<uint8_t*>(a1), j0.a1_lo = a1_lo, j0.n_a1 = N - a1_lo;
   j0.a2 = reinterpret_cast<uint8_t*>(a2), j0.a3 = reinterpret_cast<uint8_t*>(a3);
   j0.N = N, j0.block0 = 0, j0.nblocks = std::min(kNumCU, N);
   {
     ProfScope prof(names[1], s);
-    note_launch("conv12_bf16s_jobs");
-    hipLaunchKernelGGL(conv12_bf16s_jobs, dim3(j0.nblocks), dim3(kThreads), Conv12::LDS_TOTAL, s, jobs);
+    if (j0.W1d && conv12_i8_on()) {
+      note_launch("conv12_i8_jobs");
+      hipLaunchKernelGGL(conv12_i8_jobs, dim3(j0.nblocks), dim3(kThreads), Conv12I::LDS_TOTAL, s, jobs);
+    } else {
+      note_launch("conv12_bf16s_jobs");
+      hipLaunchKernelGGL(conv12_bf16s_jobs, dim3(j0.nblocks), dim3(kThreads), Conv12::LDS_TOTAL, s, jobs);
+    }
   }
   {
     ProfScope prof(names[2], s);

@@ -9,6 +9,8 @@ import os
 import numpy as np
 import pytest
 
+from kernel_names import CONV12
+
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -67,7 +69,7 @@ FAST_TRUNK_MIN_N, FAST_FC_MIN_N = 128, 1024
 
 def expected_kernels(N, precision):
     if precision == "bf16x2" and N >= FAST_TRUNK_MIN_N:
-        trunk = {"conv12_bf16s", "conv_bf16s<Conv3F>"}
+        trunk = {CONV12, "conv_bf16s<Conv3F>"}
         return trunk | ({"fc_bf16s"} if N >= FAST_FC_MIN_N else {"fc_bf16s (split-K)"})
     return {"conv1_bf16x3", "conv_mfma<Conv2> (f32)", "conv_mfma<Conv3> (f32)"}
 

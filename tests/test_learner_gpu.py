@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+from kernel_names import CONV12, CONV12_JOBS  # noqa: F401
+
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -91,11 +93,11 @@ def _assert_fast_learner_kernels(counts, B):
     gradients on bf16 MFMA -- so a silent fall-back to the f32 kernels cannot pass for a test of the fast ones."""
     want = {"wgrad_conv1_bf16", "dgrad_conv2_bf16", "dgrad_conv3_bf16"}
     if MERGED_MIN_B <= B <= MERGED_MAX_B:
-        want |= {"conv12_bf16s_jobs", "conv3_bf16s_jobs", "fc_bf16s (split-K)", "unsplit_trunk_rows"}
+        want |= {CONV12_JOBS, "conv3_bf16s_jobs", "fc_bf16s (split-K)", "unsplit_trunk_rows"}
     assert want <= set(counts), "B=%d: launched %s, expected %s" % (B, sorted(counts), sorted(want))
     if MERGED_MIN_B <= B <= MERGED_MAX_B:
         assert not ({"conv1_bf16x3", "conv_mfma<Conv2> (f32)", "conv_mfma<Conv3> (f32)"} & set(counts)), sorted(counts)
-        assert counts["conv12_bf16s_jobs"] == 1 and counts["fc_bf16s (split-K)"] == 2
+        assert counts[CONV12_JOBS] == 1 and counts["fc_bf16s (split-K)"] == 2
 
 
 def _relu_pattern_disagreement(a, b):
@@ -422,7 +424,7 @@ def test_learner_step_matches_the_reference_golden(path, precision):
     if precision == "bf16x2":
         _assert_fast_learner_kernels(census.counts, B)
     else:
-        assert not ({"wgrad_conv1_bf16", "dgrad_conv2_bf16", "conv12_bf16s"} & set(census.counts)), census.counts
+        assert not ({"wgrad_conv1_bf16", "dgrad_conv2_bf16", "conv12_bf16s", "conv12_i8"} & set(census.counts)), census.counts
     np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(prio.cpu().numpy(), np.array(g["priority"]), rtol=1e-4, atol=1e-4)
 

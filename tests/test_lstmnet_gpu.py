@@ -6,6 +6,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+from kernel_names import CONV12, CONV12_JOBS  # noqa: F401
+
 pytestmark = pytest.mark.gpu
 
 KEYS = ["net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
@@ -70,7 +72,7 @@ def test_lstm_step_vs_torch(N, A, precision):
     net.capi.check(net.capi.lib.rela_lstmnet_set_precision(net.h, 1 if precision == "bf16x2" else 0), "set_precision")
     with net.capi.launch_census() as census:
         h, c, q, adv = net.step(s, legal, h_in, c_in)
-    fast = {"conv12_bf16s", "conv_bf16s<Conv3F>"} | ({"gemm_rec64_nt"} if N >= 1024 else set())
+    fast = {CONV12, "conv_bf16s<Conv3F>"} | ({"gemm_rec64_nt"} if N >= 1024 else set())
     if precision == "bf16x2" and N >= 128:
         assert fast <= set(census.counts), sorted(census.counts)
     else:

@@ -16,6 +16,8 @@ from types import SimpleNamespace
 import numpy as np
 import pytest
 
+from kernel_names import CONV12, CONV12_JOBS  # noqa: F401
+
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -103,10 +105,10 @@ def _synth_batch(g, device):
 
 
 # kernels a bf16x2 R2D2 learner step must launch once T * B >= 128 frames (csrc/learner_r2d2.hip)
-R2D2_FAST_KERNELS = {"conv12_bf16s", "conv_bf16s<Conv3F>", "gemm_rec64_nt", "wgrad_conv1_bf16", "dgrad_conv2_bf16",
+R2D2_FAST_KERNELS = {CONV12, "conv_bf16s<Conv3F>", "gemm_rec64_nt", "wgrad_conv1_bf16", "dgrad_conv2_bf16",
                      "dgrad_conv3_bf16",
                      # r3: the ONLINE trunk too (conv1's records kept for the backward, then turned back into f32)
-                     "conv12_bf16s_jobs", "conv3_bf16s_jobs", "unsplit_trunk_rows"}
+                     CONV12_JOBS, "conv3_bf16s_jobs", "unsplit_trunk_rows"}
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16x2"])
