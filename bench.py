@@ -72,9 +72,9 @@ BYTES_PER_SAMPLE = {"conv1_bf16x3": 28224 + 400 * 32 * 4, "conv2_mfma": 400 * 32
                     "conv3_mfma": 81 * 64 * 4 + 49 * 64 * 4, "fc_mfma": 49 * 64 * 4 + 512 * 4, "heads_mfma": 512 * 4 + 32 * 4,
                     "conv12_fused": 28224 + 81 * 64 * 4}
 PEAK_HBM_GBS = 8000.0
-DTYPE_NOTE = ("f32 results from split-bf16 MFMA (bf16 hi + lo operands = 16 significant bits, 2-3 bf16 products per product, "
-              "f32 accumulate): |dQ| < 2e-5 * max|Q| against the exact f32 mode (measured 6e-7 at max|Q| = 0.4, 8.7e-4 at "
-              "max|Q| = 56; tests/test_ffnet_gpu.py)")
+DTYPE_NOTE = ("f32 results from split-bf16 MFMA (bf16 hi + lo operands = 16 significant bits, 3 bf16 products per product, "
+              "f32 accumulate; conv1: u8 frames x 24-bit fixed-point weights as three int8 digit products, exact i32 sums): "
+              "|dQ| < 2e-5 * max|Q| against the exact f32 mode (tests/test_ffnet_gpu.py)")
 # what the HIP Ape-X learner step computes in, per --precision (csrc/learner.hip)
 LEARNER_PRECISION_NOTE = {
     "f32": "f32 throughout (exact f32 MFMA forwards, f32 MFMA GEMM backward, f32 clip + RMSprop)",
@@ -93,7 +93,7 @@ def generate_eps(base_eps, alpha, num_actor):
 
 
 # rela_prof label -> substring of the HIP kernel name in the rocprofv3 CSVs
-PMC_KERNEL_OF = {"conv12_fused": "conv12_bf16s", "conv3_mfma": "conv_bf16s<", "fc_mfma": "fc_bf16s",
+PMC_KERNEL_OF = {"conv12_fused": "conv12_", "conv3_mfma": "conv_bf16s<", "fc_mfma": "fc_bf16s",
                  "conv1_bf16x3": "conv1_bf16x3", "conv2_mfma": "ConvCfg<32", "replay_scatter_rows": "replay_scatter_rows"}
 
 
@@ -1022,15 +1022,20 @@ def main():
             # in 3 bf16 pieces (f32 mode: exact) or 2 (bf16x2 mode); the other layers 3 in bf16x2 mode
             fast = args.precision == "bf16x2"
             products = (2 if fast else 3) if name == "conv1_bf16x3" else (3 if fast else 0)
-            if name == "conv12_fused":  # 2 products for conv1's FLOPs, 3 for conv2's
+            conv1_i8 = os.environ.get("RELA_CONV12") != "bf16"
+            if name == "conv12_fused":
+                # conv2: 3 bf16 products per product.  conv1: 3 int8 digit products (csrc/ffnet.hip: conv12_i8) on
+                # v_mfma_i32_16x16x64_i8, which runs at twice the bf16 rate = 1.5 bf16-MFMA-equivalents; with
+                # RELA_CONV12=bf16 the half-frame kernel's 2 bf16 products
                 f1, f2 = FLOP["conv1_bf16x3"], FLOP["conv2_mfma"]
-                products = (2 * f1 + 3 * f2) / (f1 + f2)
+                products = ((1.5 if conv1_i8 else 2) * f1 + 3 * f2) / (f1 + f2)
             peak_mfma = PEAK_BF16_MFMA_TFLOPS / products if products else PEAK_F32_MFMA_TFLOPS
             nbytes = BYTES_PER_SAMPLE[name] * ROWS
             mfma = {"achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": peak_mfma, "unit": "TFLOP/s",
                     "algorithmic_flop_per_launch": flops,
-                    "instruction": ("v_mfma_f32_16x16x32_bf16 x%.3g (split operands)" % products) if products
-                    else "v_mfma_f32_16x16x4_f32"}
+                    "instruction": ("v_mfma_f32_16x16x32_bf16 x%.3g (split operands%s)" % (
+                        products, "; conv1: three int8 digit products on v_mfma_i32_16x16x64_i8, counted as 1.5 bf16 products"
+                        if name == "conv12_fused" and conv1_i8 else "")) if products else "v_mfma_f32_16x16x4_f32"}
             mfma["frac"] = mfma["achieved"] / peak_mfma
             hbm = {"achieved": nbytes / (avg_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "algorithmic_bytes_per_launch": nbytes}

@@ -1240,7 +1240,7 @@ __global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restri
 // three digit products cost 0.75 of the two bf16 products (hi, mid) they replace -- and carry 24 bits of every weight
 // relative to its channel's largest instead of 16, so conv1 of the split-bf16 mode is now within an f32 rounding or
 // two of the exact mode and independent of summation order.  The float part is fixed (tests mirror it bit for bit):
-//     u = f32(S_hi) * 65536 + f32(S_mid) * 256;  u = u + f32(S_lo);  y = u * s_c + b'_c      (no fused multiply-add)
+//     u = f32(S_hi) * 65536 + f32(S_mid * 256 + S_lo);  y = u * s_c + b'_c      (the integer sum exact, no fused multiply-add)
 //
 // Layout.  K = 4 taps x 64: the 8 x 8 stride-4 kernel is a 2 x 2 stride-1 kernel over the 4 x 4 space-to-depth image
 // (21 x 21 cells of [plane 4][yy 4][xx 4] bytes).  LDS holds the WHOLE frame as [plane][cell 441][16 B] (28 KB; the
@@ -1343,21 +1343,17 @@ __device__ __forceinline__ void conv12i_body(const uint8_t* __restrict__ in, con
     loff = pl * F::PLANE1 + P * 16;
   };
   uint32_t st[F::IT][4];
-  auto g_load = [&](int n) {
+  int st_loff[F::IT];  // (the cell's LDS address travels with its bytes from the load to the store)
+  auto g_load1 = [&](int n, int j) {
     const uint8_t* src = (!JOBS || n < n_in0) ? in + (size_t)n * F::IN_ELEMS : in1 + (size_t)(n - n_in0) * F::IN_ELEMS;
+    int goff;
+    cell_of(j, goff, st_loff[j]);
 #pragma unroll
-    for (int j = 0; j < F::IT; ++j) {
-      int goff, loff;
-      cell_of(j, goff, loff);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) st[j][r] = *reinterpret_cast<const uint32_t*>(src + goff + r * 84);
-    }
+    for (int r = 0; r < 4; ++r) st[j][r] = *reinterpret_cast<const uint32_t*>(src + goff + r * 84);
   };
   auto s_store = [&](int j) {  // x -> x - 128 as int8: flip the sign bits
-    int goff, loff;
-    cell_of(j, goff, loff);
-    *reinterpret_cast<uint4*>(t1 + loff) = make_uint4(st[j][0] ^ 0x80808080u, st[j][1] ^ 0x80808080u,
-                                                      st[j][2] ^ 0x80808080u, st[j][3] ^ 0x80808080u);
+    *reinterpret_cast<uint4*>(t1 + st_loff[j]) = make_uint4(st[j][0] ^ 0x80808080u, st[j][1] ^ 0x80808080u,
+                                                            st[j][2] ^ 0x80808080u, st[j][3] ^ 0x80808080u);
   };
 
   // ---- conv1 over the tiles [T0, T0 + NT) of this wave: T1 -> split records in T2 ----
@@ -1409,8 +1405,8 @@ __device__ __forceinline__ void conv12i_body(const uint8_t* __restrict__ in, con
       if (rt >= F::RT) continue;  // (wave-uniform: only the group rg = 0 has a seventh tile)
       const int m = rt * 16 + li;
       const int y = m / 20, xx = m - y * 20;
-      f32x4 u = __builtin_convertvector(s_hi[t], f32x4) * 65536.0f + __builtin_convertvector(s_mid[t], f32x4) * 256.0f;
-      u = u + __builtin_convertvector(s_lo[t], f32x4);
+      const i32x4 ml = s_mid[t] * 256 + s_lo[t];  // exact: |S_mid * 256 + S_lo| < 2^31
+      const f32x4 u = __builtin_convertvector(s_hi[t], f32x4) * 65536.0f + __builtin_convertvector(ml, f32x4);
       const f32x4 v = u * sc1 + bv1;
       split_store_lds4((m < 400) ? t2 + (size_t)(y * C2::RQ + xx * C2::Q) * 16 : spare, 32, ch1, v);
     }
@@ -1418,7 +1414,8 @@ __device__ __forceinline__ void conv12i_body(const uint8_t* __restrict__ in, con
 
   int n = bid;
   if (n >= N) return;
-  g_load(n);
+#pragma unroll
+  for (int j = 0; j < F::IT; ++j) g_load1(n, j);
 #pragma unroll
   for (int j = 0; j < F::IT; ++j) s_store(j);
 #pragma unroll
@@ -1459,7 +1456,6 @@ __device__ __forceinline__ void conv12i_body(const uint8_t* __restrict__ in, con
     stamp(1);
     __syncthreads();  // T2 complete, T1 and O free
     stamp(2);
-    g_load(nn);
     if constexpr (JOBS) {
       if (a1_out && (unsigned)(n - a1_lo) < (unsigned)n_a1) {  // (block-uniform) conv1's records: [400 pixels][32 hi | 32 lo]
         uint4* dst = reinterpret_cast<uint4*>(a1_out + (size_t)n * (400 * 128));
@@ -1498,9 +1494,12 @@ __device__ __forceinline__ void conv12i_body(const uint8_t* __restrict__ in, con
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[ks], xh, acc[t], 0, 0, 0);
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xh, acc[t], 0, 0, 0);
         if (idx + D < TOT) a_issue(idx + D, slot);
+        // the next frame's cells: loaded behind pairs 1, 4, 7, 10, stored (sign bits flipped) in the second half
 #pragma unroll
-        for (int j = 0; j < F::IT; ++j)
+        for (int j = 0; j < F::IT; ++j) {
+          if (idx == 1 + 3 * j) g_load1(nn, j);
           if (idx == TOT / 2 + 6 * j) s_store(j);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       stamp(3);

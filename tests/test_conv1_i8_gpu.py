@@ -1,7 +1,7 @@
 """conv1 of the split-bf16 mode on the int8 matrix cores (csrc/ffnet.hip: conv12_i8): the kernel's arithmetic is
 integer up to one fixed sequence of f32 operations, so conv1's records can be checked BIT FOR BIT against a numpy
 restatement -- digits of the 24-bit fixed-point weights, exact i64 sums, then
-    u = f32(S_hi) * 65536 + f32(S_mid) * 256;  u = u + f32(S_lo);  y = u * s_c + b'_c;  relu;  bf16 hi (RNE), bf16 lo of y - hi
+    u = f32(S_hi) * 65536 + f32(S_mid * 256 + S_lo);  y = u * s_c + b'_c;  relu;  bf16 hi (RNE), bf16 lo of y - hi
 and against the exact f32 convolution within the bound the quantisation gives (2^-24 of the channel's largest weight
 per weight)."""
 import ctypes as C
@@ -54,9 +54,8 @@ def patches(frames):
 def expected_records(frames, w, b):
     sc, q, bq, (hi, mid, lo) = quantise(w, b)
     P = patches(frames)
-    f = lambda d: np.einsum("npk,ck->npc", P, d).astype(np.float32)  # exact: |S| <= 2^22
-    u = f(hi) * np.float32(65536) + f(mid) * np.float32(256)
-    u = u + f(lo)
+    S = lambda d: np.einsum("npk,ck->npc", P, d)  # exact: |S| <= 2^22
+    u = S(hi).astype(np.float32) * np.float32(65536) + (S(mid) * 256 + S(lo)).astype(np.float32)  # (int64 -> f32: RNE)
     y = u * sc[None, None, :] + bq[None, None, :]
     y = np.maximum(y, np.float32(0))
     hb, hv = bf16_rne(y)

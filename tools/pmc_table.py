@@ -17,7 +17,7 @@ import sys
 
 def short(n):
     # split-bf16 path (names = the rela_prof labels bench.py looks traffic up by)
-    if "conv12_bf16s" in n or "conv12_pipe" in n:
+    if "conv12_bf16s" in n or "conv12_pipe" in n or "conv12_i8" in n:
         return "conv12_fused"
     m = re.search(r"conv_bf16s<.*?ConvFastCfg<(\d+)", n)
     if m:
