@@ -264,6 +264,9 @@ int rela_ffnet_debug_conv12_stamps(const rela_ffnet* net, int n, const uint8_t* 
  * (csrc/ffnet.hip: conv12_i8), zeros otherwise. */
 int rela_ffnet_debug_conv12_records(const rela_ffnet* net, int n, const uint8_t* s_dev, uint8_t* a1_records,
                                     uint8_t* a2_records, float* scale_host, float* bias_host, void* stream);
+/* The same for conv3 of the split-bf16 mode (the first 8 groups of two frames of block 0; 5 points per group). */
+int rela_ffnet_debug_conv3_stamps(const rela_ffnet* net, int n, const uint8_t* a2_records, unsigned long long* out_host,
+                                  void* stream);
 /* The same for fc_bf16s (positions 8..15 of block 0; 5 points per position). */
 int rela_ffnet_debug_fc_stamps(const rela_ffnet* net, int n, const uint8_t* a3_records, unsigned long long* out_host,
                                void* stream);

@@ -815,12 +815,20 @@ using Conv2F = ConvFastCfg<32, 20, 20, 4, 4, 2, 9, 9, 1, 9, 185, 20 * 185>;
 // conv3: 9x9x64 -> 7x7x64, stride 1: Q = 2, RQ = 14 (7 positions per row), SQ = 98 = 2 (mod 16)
 using Conv3F = ConvFastCfg<64, 9, 9, 3, 3, 1, 7, 7, 2, 18, 174, 1570>;
 
-template <class C>
+constexpr int kStampFrames = 8, kStampPoints = 12;
+template <class C, bool STAMPS = false>
 __device__ __forceinline__ void conv_bf16s_body(const uint8_t* __restrict__ in, const uint4* __restrict__ Bfrag,
                                                 const float* __restrict__ bias, uint8_t* __restrict__ out, int N, int bid,
-                                                int nblk) {
+                                                int nblk, unsigned long long* stamps = nullptr) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x;
+  int stamp_frame = 0;
+  auto stamp = [&](int point) {  // (diagnostic build only: rela_ffnet_debug_conv3_stamps)
+    if constexpr (STAMPS) {
+      if (bid == 0 && (threadIdx.x == 0 || threadIdx.x == 448) && stamp_frame < kStampFrames)
+        stamps[((threadIdx.x == 0 ? 0 : 1) * kStampFrames + stamp_frame) * kStampPoints + point] = __builtin_amdgcn_s_memtime();
+    }
+  };
   const int wave = tid >> 6, lane = tid & 63;
   const int ct = wave % C::CT, rg = wave / C::CT;
   const int li = lane & 15, g = lane >> 4;
@@ -886,73 +894,122 @@ __device__ __forceinline__ void conv_bf16s_body(const uint8_t* __restrict__ in, 
     pin_loaded(bl[ks]);
   }
   __syncthreads();
-  int buf = 0;
   constexpr int LO = C::CIN * 2;  // byte offset of the lo part inside a pixel record
-  for (; grp < ngroups; grp += nblk) {
-    const bool has_next = grp + nblk < ngroups;
-    if (has_next) stage_load(grp + nblk, 0);
-    const uint8_t* tile = smem + buf * C::LDS_BYTES;
-    f32x4 acc[C::RPW];  // starts at the bias
-#pragma unroll
-    for (int t = 0; t < C::RPW; ++t) acc[t] = bv;
-    // A fragments run D (hi, lo) pairs ahead of the MFMAs that consume them, in a register ring over the
-    // flattened (k-step, row tile) sequence: with two waves per SIMD nothing else hides the LDS latency.
-    constexpr int TOT = C::KS * C::RPW, D = C::DEPTH;
-    uint4 ah[D], al[D];
-    auto a_issue = [&](int idx, int slot) {
-      const int ks = idx / C::RPW, t = idx - ks * C::RPW;
-      const int tap = ks / C::KSUB, sub = ks - tap * C::KSUB;
-      const int kh = tap / C::KW, kw = tap - kh * C::KW;
-      const uint8_t* ap = tile + abase[t] + (kh * C::RQ + kw * C::Q) * 16 + sub * 64;
-      ah[slot] = *reinterpret_cast<const uint4*>(ap);
-      al[slot] = *reinterpret_cast<const uint4*>(ap + LO);
+  uint8_t* const obase = smem + 2 * C::LDS_BYTES;
+  uint8_t* const spare = obase + 2 * C::OUT_BYTES;  // rows past the group's last pixel land here
+  // A row group whose LAST tile lies wholly past the group's pixels (conv3: 98 pixels = 7 tiles over RG = 2 row groups
+  // of RPW = 4) skips that tile's fragment reads and MFMAs (wave-uniform): the two waves of a SIMD belong to different
+  // row groups, so the SIMD issues 7 tiles' MFMAs where it issued 8.
+  constexpr int RT_REAL = (C::M + 15) / 16;
+  static_assert(C::RPW >= 2 && (RT_REAL - (C::RG - 1) + C::RG - 1) / C::RG >= C::RPW - 1, "at most the last tile of a row group is empty");
+  const bool full = (RT_REAL - __builtin_amdgcn_readfirstlane(rg) + C::RG - 1) / C::RG >= C::RPW;
+  {
+    constexpr int NT = C::RPW;
+    int buf = 0;
+    int prev_n0 = 0, prev_nv = 0;  // the group whose records wait in the other output buffer, its 16-byte chunks
+    constexpr int OV = C::S * C::P * (C::OC * 4 / 16), OIT = (OV + kThreads - 1) / kThreads;
+    static_assert(OIT <= 4, "named chunk registers below");
+    uint4 oc0, oc1, oc2, oc3;
+    // chunk j of the previous group's records: read from LDS behind pair RD(j), stored to HBM behind pair RD(j) + 2 --
+    // in the shadow of this group's MFMAs (after the loop, on all eight waves at once, the copy took 8 % of a group)
+    auto o_read = [&](int j) {
+      const uint8_t* ot = obase + (buf ^ 1) * C::OUT_BYTES;
+      const int i = min(tid + j * kThreads, OV - 1);
+      return *reinterpret_cast<const uint4*>(ot + (i >> 4) * C::OROW + (i & 15) * 16);
     };
+    auto o_write = [&](int j, const uint4& val) {
+      const int i = tid + j * kThreads;
+      if (i < prev_nv) reinterpret_cast<uint4*>(out + (size_t)prev_n0 * C::P * (C::OC * 4))[i] = val;
+    };
+    for (; grp < ngroups; grp += nblk) {
+      const bool has_next = grp + nblk < ngroups;
+      stamp(0);
+      if (has_next) stage_load(grp + nblk, 0);
+      const uint8_t* tile = smem + buf * C::LDS_BYTES;
+      f32x4 acc[NT];  // starts at the bias
 #pragma unroll
-    for (int i = 0; i < D; ++i) a_issue(i, i);
-    __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < NT; ++t) acc[t] = bv;
+      // A fragments run D (hi, lo) pairs ahead of the MFMAs that consume them, in a register ring over the
+      // flattened (k-step, row tile) sequence: with two waves per SIMD nothing else hides the LDS latency.
+      constexpr int TOT = C::KS * NT, D = C::DEPTH;
+      uint4 ah[D], al[D];
+      auto a_issue = [&](int idx, int slot) {
+        const int ks = idx / NT, t = idx - ks * NT;
+        const int tap = ks / C::KSUB, sub = ks - tap * C::KSUB;
+        const int kh = tap / C::KW, kw = tap - kh * C::KW;
+        const uint8_t* ap = tile + abase[t] + (kh * C::RQ + kw * C::Q) * 16 + sub * 64;
+        ah[slot] = *reinterpret_cast<const uint4*>(ap);
+        al[slot] = *reinterpret_cast<const uint4*>(ap + LO);
+      };
 #pragma unroll
-    for (int idx = 0; idx < TOT; ++idx) {
-      const int ks = idx / C::RPW, t = idx - ks * C::RPW;
-      const int slot = idx % D;
-      const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[slot]);
-      const bf16x8 xl = __builtin_bit_cast(bf16x8, al[slot]);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xl, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[ks], xh, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xh, acc[t], 0, 0, 0);
-      if (idx + D < TOT) a_issue(idx + D, slot);
-      __builtin_amdgcn_sched_barrier(0);  // keep the reads where they are (the scheduler sinks them to their use)
-      // the other buffer was last read one group ago (barrier since): fill it while this group computes
-      if (has_next) {
-        if (idx == TOT / 3) {
-          stage_store(buf ^ 1, 0);
-          stage_load(grp + nblk, 1);
-        } else if (idx == (2 * TOT) / 3) {
-          stage_store(buf ^ 1, 1);
+      for (int i = 0; i < D; ++i)
+        if (i % NT < NT - 1 || full) a_issue(i, i);
+      __builtin_amdgcn_sched_barrier(0);
+      static_assert(3 + 4 * (OIT - 1) < TOT, "copy-out slots inside the loop");
+      // (two loops of TOT / 2: as ONE loop the body is too large for the unroller's full-unroll budget, it unrolls by
+      // half the trip count instead, k-steps become run-time indices and the resident fragments move to scratch memory)
+      auto pair = [&](int idx) {
+        const int ks = idx / NT, t = idx - ks * NT;
+        const int slot = idx % D;
+        if (t < NT - 1 || full) {
+          const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[slot]);
+          const bf16x8 xl = __builtin_bit_cast(bf16x8, al[slot]);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xl, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[ks], xh, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xh, acc[t], 0, 0, 0);
         }
-      }
-    }
-    // epilogue: bias + ReLU + hi/lo split into an LDS copy of the group's output records, then ONE coalesced
-    // 16-byte-per-lane copy to HBM (a wave's own 16 channels are only 32 contiguous bytes per pixel).  The output
-    // tile is double buffered like the input, so ONE barrier per group orders everything: it publishes this
-    // group's records and the next group's staged input, and the records of two groups ago were copied out
-    // before the barrier in between.
-    const int n0 = grp * C::S;
-    const int mlim = min(C::S, N - n0) * C::P;
-    uint8_t* otile = smem + 2 * C::LDS_BYTES + buf * C::OUT_BYTES;
-    uint8_t* spare = smem + 2 * C::LDS_BYTES + 2 * C::OUT_BYTES;  // rows past the group's last pixel land here
+        if (idx + D < TOT && ((idx + D) % NT < NT - 1 || full)) a_issue(idx + D, slot);
+        if (idx == 1) oc0 = o_read(0);
+        if (idx == 3) o_write(0, oc0);
+        if (OIT > 1 && idx == 5) oc1 = o_read(1);
+        if (OIT > 1 && idx == 7) o_write(1, oc1);
+        if (OIT > 2 && idx == 9) oc2 = o_read(2);
+        if (OIT > 2 && idx == 11) o_write(2, oc2);
+        if (OIT > 3 && idx == 13) oc3 = o_read(3);
+        if (OIT > 3 && idx == 15) o_write(3, oc3);
+        __builtin_amdgcn_sched_barrier(0);  // keep the reads where they are (the scheduler sinks them to their use)
+        // the other buffer was last read one group ago (barrier since): fill it while this group computes
+        if (has_next) {
+          if (idx == TOT / 3) {
+            stage_store(buf ^ 1, 0);
+            stage_load(grp + nblk, 1);
+          } else if (idx == (2 * TOT) / 3) {
+            stage_store(buf ^ 1, 1);
+          }
+        }
+            };
+      static_assert(TOT % 2 == 0, "two halves");
 #pragma unroll
-    for (int t = 0; t < C::RPW; ++t) {
-      const int m = (rg + t * C::RG) * 16 + li;  // this lane's pixel of the tile
-      split_store_lds4((m < C::M) ? otile + (size_t)m * C::OROW : spare, C::OC, ch0, acc[t]);
+      for (int idx = 0; idx < TOT / 2; ++idx) pair(idx);
+#pragma unroll
+      for (int idx = TOT / 2; idx < TOT; ++idx) pair(idx);
+      // epilogue: bias + ReLU + hi/lo split into an LDS copy of the group's output records; they leave for HBM as
+      // coalesced 16-byte-per-lane copies during the NEXT group's MFMA loop (a wave's own 16 channels are only 32
+      // contiguous bytes per pixel).  The output tile is double buffered like the input, so ONE barrier per group
+      // orders everything: it publishes this group's records and the next group's staged input, and the records of
+      // two groups ago were read out before the barrier in between.
+      stamp(1);
+      uint8_t* otile = obase + buf * C::OUT_BYTES;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int m = (rg + t * C::RG) * 16 + li;  // this lane's pixel of the tile
+        split_store_lds4((m < C::M) ? otile + (size_t)m * C::OROW : spare, C::OC, ch0, acc[t]);
+      }
+      stamp(2);
+      __syncthreads();
+      stamp(3);
+      prev_n0 = grp * C::S;
+      prev_nv = min(C::S, N - prev_n0) * C::P * (C::OC * 4 / 16);
+      stamp(4);
+      stamp_frame += 1;
+      buf ^= 1;
     }
-    __syncthreads();
-    {
-      uint4* dst = reinterpret_cast<uint4*>(out + (size_t)n0 * C::P * (C::OC * 4));
-      const int nv = mlim * (C::OC * 4 / 16);
-      for (int i = tid; i < nv; i += kThreads)
-        dst[i] = *reinterpret_cast<const uint4*>(otile + (i >> 4) * C::OROW + (i & 15) * 16);
+    {  // the last group's records
+      const uint8_t* ot = obase + (buf ^ 1) * C::OUT_BYTES;
+      uint4* dst = reinterpret_cast<uint4*>(out + (size_t)prev_n0 * C::P * (C::OC * 4));
+      for (int i = tid; i < prev_nv; i += kThreads)
+        dst[i] = *reinterpret_cast<const uint4*>(ot + (i >> 4) * C::OROW + (i & 15) * 16);
     }
-    buf ^= 1;
   }
 }
 
@@ -961,6 +1018,12 @@ __global__ __launch_bounds__(kThreads) void conv_bf16s(const uint8_t* __restrict
                                                        const float* __restrict__ bias, uint8_t* __restrict__ out,
                                                        int N) {
   conv_bf16s_body<C>(in, Bfrag, bias, out, N, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(kThreads) void conv3_bf16s_stamps(const uint8_t* __restrict__ in, const uint4* __restrict__ Bfrag,
+                                                               const float* __restrict__ bias, uint8_t* __restrict__ out,
+                                                               int N, unsigned long long* stamps) {
+  conv_bf16s_body<Conv3F, true>(in, Bfrag, bias, out, N, blockIdx.x, gridDim.x, stamps);
 }
 
 // conv1 -> conv2 fused per frame: conv1's output (400 pixels x 32 channels of split records) is written straight
@@ -984,7 +1047,6 @@ struct Conv12 {
   static constexpr int IT = (C1::V16 + kThreads - 1) / kThreads;  // 2
 };
 
-constexpr int kStampFrames = 8, kStampPoints = 12;
 // The body of the kernel, shared by conv12_bf16s (one net, blocks = the whole grid) and conv12_bf16s_jobs (the
 // learner's forwards: several nets / batches in ONE launch, each job on its own range of blocks).  JOBS adds: rows
 // from two source buffers (rows >= n_in0 come from in1), and a copy of conv1's records (a1, which otherwise never
@@ -3101,6 +3163,33 @@ extern "C" int rela_ffnet_debug_conv12_stamps(const rela_ffnet* n, int N, const 
   RELA_HIP(hipStreamSynchronize(s));
   RELA_HIP(hipMemcpy(out_host, st, nst * 8, hipMemcpyDeviceToHost));
   (void)hipFree(a2);
+  (void)hipFree(st);
+  return RELA_OK;
+}
+
+// Diagnostic: conv3 of the split-bf16 mode with shader-clock stamps (block 0, waves 0 and 7, its first 8 groups of two
+// frames): out_host [2][8][12] u64, points 0 group start | 1 MFMA loop (+ staging) done | 2 epilogue stored | 3 barrier |
+// 4 copy-out issued.  a2_records: [N][81][hi 64 | lo 64] (any bytes do for timing).
+extern "C" int rela_ffnet_debug_conv3_stamps(const rela_ffnet* n, int N, const uint8_t* a2_records, unsigned long long* out_host,
+                                             void* stream_) {
+  RELA_CHECK(n && n->loaded && N >= 2 && a2_records && out_host, RELA_EINVAL, "rela_ffnet_debug_conv3_stamps: bad arguments");
+  DeviceGuard g(n->device);
+  hipStream_t s = (hipStream_t)stream_;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3_bf16s_stamps),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Conv3F::LDS_TOTAL);
+  RELA_HIP(attr);
+  uint8_t* a3 = nullptr;
+  unsigned long long* st = nullptr;
+  const size_t nst = (size_t)2 * kStampFrames * kStampPoints;
+  RELA_HIP(hipMalloc(&a3, (size_t)N * 49 * 256));
+  RELA_HIP(hipMalloc(&st, nst * 8));
+  RELA_HIP(hipMemsetAsync(st, 0, nst * 8, s));
+  const FFNetDev& d = n->d;
+  hipLaunchKernelGGL(conv3_bf16s_stamps, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads), Conv3F::LDS_TOTAL, s,
+                     a2_records, (const uint4*)d.B3f, (const float*)d.b3, a3, N, st);
+  RELA_HIP(hipStreamSynchronize(s));
+  RELA_HIP(hipMemcpy(out_host, st, nst * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(a3);
   (void)hipFree(st);
   return RELA_OK;
 }
