@@ -10,6 +10,7 @@ cp $F/bench.json profiles/r03_bench_latest.json
 cp $F/bench_prof.json profiles/r03_bench_under_rocprof.json
 cp $F/bench_r2d2.json profiles/r03_bench_r2d2_latest.json
 cp $F/forward_modes.log profiles/r03_forward_modes.log
+[ -f $F/phase_stamps.log ] && cp $F/phase_stamps.log profiles/r03_phase_stamps.log || true
 cp $F/time_sample.json profiles/r03_time_sample_isolated.json
 cp $F/r2d2_learner.log profiles/r03_r2d2_learner_isolated.log
 cp $F/bench_only_learner.json profiles/r03_bench_only_learner.json

@@ -36,7 +36,10 @@ RELA_BENCH_ONLY=actor timeout -k 10 200 python bench.py --no-cpu-baseline --no-t
 {
   for n in 512 6400; do TAG="N=$n f32" N=$n PRECISION=f32 timeout -k 10 120 python tools/time_forward.py 2>&1 | tail -1; done
   for n in 512 1024 6400; do TAG="N=$n bf16x2" N=$n PRECISION=bf16x2 timeout -k 10 120 python tools/time_forward.py 2>&1 | tail -1; done
+  TAG="N=6400 bf16x2, conv1 on bf16 MFMA in half frames (RELA_CONV12=bf16: the kernel up to mid r3)" RELA_CONV12=bf16 N=6400 PRECISION=bf16x2 timeout -k 10 120 python tools/time_forward.py 2>&1 | tail -1
+  TAG="N=6400 bf16x2 (again)" N=6400 PRECISION=bf16x2 timeout -k 10 120 python tools/time_forward.py 2>&1 | tail -1
 } > $O/forward_modes.log
+{ echo "== tools/conv12_phases.py (conv12_i8)"; timeout -k 10 100 python tools/conv12_phases.py 2>/dev/null; echo "== RELA_CONV12=bf16 tools/conv12_phases.py (conv12_bf16s)"; RELA_CONV12=bf16 timeout -k 10 100 python tools/conv12_phases.py 2>/dev/null; echo "== tools/conv3_phases.py"; timeout -k 10 100 python tools/conv3_phases.py 2>/dev/null; echo "== tools/fc_phases.py"; timeout -k 10 100 python tools/fc_phases.py 2>/dev/null; } > $O/phase_stamps.log
 cat $O/forward_modes.log
 timeout -k 10 300 python tools/time_sample.py > $O/time_sample.json 2> $O/time_sample.err || exit 14
 { TAG="bf16x2 (bench default), persistent" PRECISION=bf16x2 timeout -k 10 200 python tools/time_r2d2_learner.py 2>&1 | tail -1; TAG="bf16x2, online trunk f32 (r2)" RELA_R2D2_ONLINE_F32=1 PRECISION=bf16x2 timeout -k 10 200 python tools/time_r2d2_learner.py 2>&1 | tail -1; TAG="f32, persistent" timeout -k 10 200 python tools/time_r2d2_learner.py 2>&1 | tail -1; } > $O/r2d2_learner.log
