@@ -221,6 +221,7 @@ struct RecArgs {
   const uint8_t* term;  // [T][Bn]
   unsigned* tmo;        // timeout word (0 = none)
   int T, Bn, burn;
+  unsigned long long* stamps;  // diagnostic (RELA_R2D2_STAMPS=1): [8 steps][8 points] shader clocks of block 0, or NULL
 };
 
 // (r3: a row split as in the BPTT kernel below was built and measured for this kernel too -- a row tile at a time with the
@@ -251,7 +252,13 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
     for (int q = 0; q < 4; ++q) gpre[q] = *reinterpret_cast<const float4*>(grow + q * kHid);
   };
   if (one_chunk && tid < a.Bn) gx_fetch(0, tid);
+  // points: 0 step start | 1 h loaded, MFMAs done, partials in LDS | 2 (after the workgroup barrier) | 3 cell done, stores
+  // issued | 4 stores drained + workgroup barrier | 5 arrival counted, all blocks seen | 6 acquire done | 7 released
+  auto stamp = [&](int t, int point) {
+    if (a.stamps && blockIdx.x == 0 && tid == 0 && t >= 20 && t < 28) a.stamps[(t - 20) * 8 + point] = __builtin_amdgcn_s_memtime();
+  };
   for (int t = 0; t < a.T; ++t) {
+    stamp(t, 0);
     for (int row0 = 0; row0 < a.Bn; row0 += kRecChunk) {
       const int row = row0 + tid;
       if (!one_chunk && tid < kRecChunk && row < a.Bn) gx_fetch(t, row);
@@ -279,7 +286,9 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
       for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][rt * 16 + 4 * g + r][li] = acc[rt][r];
+      stamp(t, 1);
       __syncthreads();
+      stamp(t, 2);
       if (tid < kRecChunk && row < a.Bn) {
         float* grow = nt.gx + ((size_t)t * a.Bn + row) * kGates + 4 * j;
         float pre[4][4];
@@ -317,12 +326,14 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
           *reinterpret_cast<float4*>(grow + 3 * kHid) = make_float4(go[0], go[1], go[2], go[3]);
         }
       }
+      stamp(t, 3);
       __syncthreads();
     }
     if (t + 1 == a.T) break;
     // grid barrier: every storing wave drains its stores, then ONE lane signals and polls
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    stamp(t, 4);
     if (one_chunk && tid < a.Bn) gx_fetch(t + 1, tid);  // in flight across the wait
     if (tid == 0) {
       gu32* cnt = (gu32*)(nt.bar + t);
@@ -336,10 +347,137 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
           break;
         }
       }
+      stamp(t, 5);
       if constexpr (!SC1) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      stamp(t, 6);
+      alive = ok ? 1 : 0;
+    }
+    __syncthreads();
+    stamp(t, 7);
+    if (!alive) return;
+  }
+}
+
+// ---- persistent recurrent forward, XCD-local chains (late r3; batches of up to 64 rows) ------------------------
+// The step above spends 14 us: ~5 in the loads of h_{t-1} + 64 f32 MFMAs, 2 in the cell, and 5-6 in the grid barrier
+// and the acquire (in-kernel stamps, RELA_R2D2_STAMPS=1).  Its 128 blocks per net sit on all eight XCDs, so every step's
+// h travels CU -> memory -> another XCD's L2 -> CU, and 128 arrivals queue on one counter.  Here the work is cut the
+// other way: a CHAIN is one net x one tile of 16 batch rows (2 x 4 chains), run by the 32 blocks whose ids are equal
+// mod 8 -- the dispatcher deals blocks round-robin over the XCDs, so they share an L2 -- each owning 16 hidden units
+// (64 gate columns: W_hh's slice is 64 registers per lane).  The protocol is unchanged and placement-INDEPENDENT
+// (write-through h, agent-scope arrival counter, one acquire per step): co-location only decides whether the h a block
+// reads is still in its XCD's L2 and how many arrivals a counter takes (32).  The sums are formed in the order of the
+// kernel above -- wave w multiplies k in [64 w, 64 w + 64) in the same MFMA sequence, the eight partials are added in
+// wave order onto the x-part -- so H, C and the saved gates are bit-identical to it.  One thread per (row, unit) runs
+// the cell and keeps c_t in a register for the next step.
+struct ChainArgs2 {
+  RecNet net[2];
+  const uint8_t* term;
+  unsigned* tmo;
+  unsigned* bar;  // [8 chains][Tpad] arrival counters
+  int T, Tpad, Bn, burn;
+};
+constexpr int kChainBlocks = 32, kChainUnits = kHid / kChainBlocks;  // 16 units per block
+static_assert(kChainUnits == 16, "tile shapes below");
+__global__ __launch_bounds__(kRecThreads) void lstm_rec_chain(ChainArgs2 a) {
+  __shared__ float red[8][16][65];
+  __shared__ int alive;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4;
+  const int chain = blockIdx.x & 7, j = blockIdx.x >> 3;  // chain = (net, row tile); j = unit block
+  const RecNet nt = a.net[chain >> 2];
+  const int row0 = (chain & 3) * 16;
+  if (row0 >= a.Bn) return;  // (the whole chain leaves: its counters are its own)
+  const int nrow = min(16, a.Bn - row0);
+  // B fragments: column tile c = gate c, column li = unit 16 j + li; wave w: k in [64 w, 64 w + 64)
+  float bfr[4][16];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) bfr[c][ks] = nt.whhT[(size_t)(wave * 64 + 16 * g + ks) * kGates + c * kHid + 16 * j + li];
+  const size_t blk = (size_t)a.Bn * kHid;
+  // the cell's thread: unit u = tid & 15, row r = tid >> 4 (threads 0..255)
+  const int cu = tid & 15, cr = tid >> 4;
+  const bool cell = tid < 256 && cr < nrow;
+  const int crow = row0 + cr;
+  float c_reg = 0.f;
+  if (cell) c_reg = nt.C[(size_t)crow * kHid + 16 * j + cu];  // slot 0 = the initial state
+  float gpre[4];
+  auto gx_fetch = [&](int t) {
+    const float* grow = nt.gx + ((size_t)t * a.Bn + crow) * kGates + 16 * j + cu;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gpre[q] = grow[q * kHid];
+  };
+  if (cell) gx_fetch(0);
+  unsigned* bar = a.bar + (size_t)chain * a.Tpad;
+  for (int t = 0; t < a.T; ++t) {
+    // h_{t-1} of the chain's rows (rows past the batch re-read its last row; their results are never stored)
+    float4 hv[4];
+    {
+      const int arow = row0 + min(li, nrow - 1);
+      const float* hp = nt.H + (size_t)t * blk + (size_t)arow * kHid + wave * 64 + 16 * g;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp + 4 * q);
+    }
+    const float av[16] = {hv[0].x, hv[0].y, hv[0].z, hv[0].w, hv[1].x, hv[1].y, hv[1].z, hv[1].w,
+                          hv[2].x, hv[2].y, hv[2].z, hv[2].w, hv[3].x, hv[3].y, hv[3].z, hv[3].w};
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bfr[c][ks], acc[c], 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][4 * g + r][c * 16 + li] = acc[c][r];
+    __syncthreads();
+    if (cell) {
+      float pre[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        pre[q] = gpre[q];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) pre[q] += red[w][cr][q * 16 + cu];
+      }
+      // the state that ENTERS the first training step is zeroed where the burn-in was a dummy (r2d2.py:149-154)
+      const bool zero = a.burn > 0 && t + 1 == a.burn && a.term[(size_t)(a.burn - 1) * a.Bn + crow] != 0;
+      const float gi = sigm(pre[0]), gf = sigm(pre[1]), gg = tanhf(pre[2]), go = sigm(pre[3]);
+      float c = gf * c_reg + gi * gg;
+      float h = go * tanhf(c);
+      if (zero) c = 0.f, h = 0.f;
+      c_reg = c;
+      const size_t o = (size_t)(t + 1) * blk + (size_t)crow * kHid + 16 * j + cu;
+      __hip_atomic_store((gu32*)(nt.H + o), __float_as_uint(h), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
+      nt.C[o] = c;
+      if (nt.save && t >= a.burn) {
+        float* grow = nt.gx + ((size_t)t * a.Bn + crow) * kGates + 16 * j + cu;
+        grow[0] = gi, grow[kHid] = gf, grow[2 * kHid] = gg, grow[3 * kHid] = go;
+      }
+    }
+    if (t + 1 == a.T) break;
+    // grid barrier of the chain: every storing wave drains its stores, then ONE lane signals and polls
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (cell) gx_fetch(t + 1);  // in flight across the wait
+    if (tid == 0) {
+      gu32* cnt = (gu32*)(bar + t);
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool ok = true;
+      for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)kChainBlocks;) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kRecSpinLimit || __hip_atomic_load((gu32*)a.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store((gu32*)a.tmo, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = false;
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       alive = ok ? 1 : 0;
     }
     __syncthreads();
@@ -481,6 +619,118 @@ __global__ __launch_bounds__(kRecThreads) void lstm_bptt_persist(BpttArgs a) {
     __syncthreads();
     if (!alive) return;
   }
+}
+
+// The same backward recurrence as XCD-local chains (late r3; see lstm_rec_chain): chain = row tile (blocks equal mod 8
+// share an XCD; 32 unit blocks each), its own arrival counters, the cell as above with the
+// recurrent cell-state gradient in registers.  Same sums in the same order: bit-identical gate gradients.
+__global__ __launch_bounds__(kRecThreads) void lstm_bptt_chain(BpttArgs a, int Tpad) {
+  __shared__ float red[8][16][17];
+  __shared__ int alive;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, g = lane >> 4, chain = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int row0 = chain * 16;
+  if (row0 >= a.Bn) return;  // (the whole chain leaves)
+  float bfr[64];
+#pragma unroll
+  for (int ks = 0; ks < 64; ++ks) bfr[ks] = a.whh[(size_t)(256 * wave + 64 * g + ks) * kHid + 16 * j + li];
+  const size_t blk = (size_t)a.Bn * kHid;
+  // cell backward for (row, units 16 j + 4 q .. + 3): threads 0 .. 63, as in the kernel above (16-byte loads, 8-byte
+  // write-through stores: one thread per (row, unit) with 4-byte stores was 20 % slower)
+  const int r = tid >> 2, q = tid & 3, row = row0 + r;
+  const bool cell = tid < 4 * 16 && row < a.Bn;
+  const size_t u0 = (size_t)row * kHid + 16 * j + 4 * q;
+  float dcr[4] = {0.f, 0.f, 0.f, 0.f};
+  if (cell) {
+    const float4 d4 = *reinterpret_cast<const float4*>(a.dc_rec + u0);
+    dcr[0] = d4.x, dcr[1] = d4.y, dcr[2] = d4.z, dcr[3] = d4.w;
+  }
+  unsigned* bar = a.bar + (size_t)chain * Tpad;
+  for (int t = a.Tt - 1; t >= 0; --t) {
+    const bool rec = t + 1 < a.Tt;  // the newest step has no recurrent term
+    float* ga_t = a.ga + (size_t)t * a.Bn * kGates;
+    if (rec) {
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int arow = min(row0 + li, a.Bn - 1);  // (rows past the batch repeat the last one, unread)
+      const float* dp = a.ga + (size_t)(t + 1) * a.Bn * kGates + (size_t)arow * kGates + 256 * wave + 64 * g;
+      float4 v[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) v[c] = *reinterpret_cast<const float4*>(dp + 4 * c);  // all in flight before the first MFMA
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c].x, bfr[4 * c], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c].y, bfr[4 * c + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c].z, bfr[4 * c + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c].w, bfr[4 * c + 3], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) red[wave][4 * g + rr][li] = acc[rr];
+    }
+    __syncthreads();
+    if (cell) {
+      const int gs = a.burn + t;
+      const float4 d_o4 = *reinterpret_cast<const float4*>(a.d_o + (size_t)t * blk + u0);
+      float dh[4] = {d_o4.x, d_o4.y, d_o4.z, d_o4.w};
+      if (rec) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int w = 0; w < 8; ++w) dh[u] += red[w][r][4 * q + u];
+      }
+      float* grow = ga_t + (size_t)row * kGates + 16 * j + 4 * q;
+      const float4 gi4 = *reinterpret_cast<const float4*>(grow), gf4 = *reinterpret_cast<const float4*>(grow + kHid);
+      const float4 gg4 = *reinterpret_cast<const float4*>(grow + 2 * kHid), go4 = *reinterpret_cast<const float4*>(grow + 3 * kHid);
+      const float4 cn4 = *reinterpret_cast<const float4*>(a.C + (size_t)(gs + 1) * blk + u0);
+      const float4 cp4 = *reinterpret_cast<const float4*>(a.C + (size_t)gs * blk + u0);
+      const float gi[4] = {gi4.x, gi4.y, gi4.z, gi4.w}, gf[4] = {gf4.x, gf4.y, gf4.z, gf4.w};
+      const float gg[4] = {gg4.x, gg4.y, gg4.z, gg4.w}, go[4] = {go4.x, go4.y, go4.z, go4.w};
+      const float cn[4] = {cn4.x, cn4.y, cn4.z, cn4.w}, cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+      float di[4], df[4], dgg[4], dgo[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float tc = tanhf(cn[u]);
+        const float dc = dcr[u] + dh[u] * go[u] * (1.0f - tc * tc);
+        di[u] = dc * gg[u] * gi[u] * (1.0f - gi[u]);
+        df[u] = dc * cp[u] * gf[u] * (1.0f - gf[u]);
+        dgg[u] = dc * gi[u] * (1.0f - gg[u] * gg[u]);
+        dgo[u] = dh[u] * tc * go[u] * (1.0f - go[u]);
+        dcr[u] = dc * gf[u];
+      }
+      auto store_wt = [&](float* dst, const float* v) {  // write-through: read by the chain's other blocks in the next step
+        gu64* p = (gu64*)dst;
+        __hip_atomic_store(p, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 1, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      store_wt(grow, di);
+      store_wt(grow + kHid, df);
+      store_wt(grow + 2 * kHid, dgg);
+      store_wt(grow + 3 * kHid, dgo);
+    }
+    if (t == 0) break;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      gu32* cnt = (gu32*)(bar + t);
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool ok = true;
+      for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)kBpttBlocks;) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kRecSpinLimit || __hip_atomic_load((gu32*)a.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store((gu32*)a.tmo, (unsigned)(1000 + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = false;
+          break;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      alive = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!alive) return;
+  }
+  if (cell) *reinterpret_cast<float4*>(a.dc_rec + u0) = make_float4(dcr[0], dcr[1], dcr[2], dcr[3]);  // (as the kernel above leaves it)
 }
 
 // hid *= 1 - terminal[burn_in - 1]   (r2d2.py:149-154)
@@ -626,6 +876,8 @@ struct rela_r2d2_learner {
   float *Hs[2] = {nullptr, nullptr}, *Cs[2] = {nullptr, nullptr};     // [(T+1)*B][512] per net
   float* rec_part = nullptr;                                          // split-K partials of the recurrent GEMMs
   unsigned* rec_bar = nullptr;                                        // [0] timeout word, [4 ..] per-step arrival counters
+  unsigned* rec_chain_bar = nullptr;                                  // lstm_rec_chain: [8 chains][Tpad]
+  bool rec_chains_fit = true;                                         // its 256 blocks are resident at once (checked at create)
   bool rec_persist = true;
   // 1: the target net's conv trunk (no gradient, activations never read back) and the three large GEMMs of the LSTM's
   //    input side (gate GEMM of both nets, its data and weight gradients) on split-bf16 MFMA (gemm_bf16s.h)
@@ -813,10 +1065,36 @@ int forward_both(rela_r2d2_learner* l, int Bn, const uint8_t* obs, const float* 
       ra.net[w].bar = l->rec_bar + 4 + w * Tpad, ra.net[w].save = w == 0 ? 1 : 0;
     }
     ra.term = term, ra.tmo = l->rec_bar, ra.T = T, ra.Bn = Bn, ra.burn = burn;
-    ProfScope prof("learner_lstm_rec_persist", s);
-    if (sc1_handoff()) hipLaunchKernelGGL(lstm_rec_persist<true>, dim3(2 * kRecBlocks), dim3(kRecThreads), 0, s, ra);
-    else hipLaunchKernelGGL(lstm_rec_persist<false>, dim3(2 * kRecBlocks), dim3(kRecThreads), 0, s, ra);
+    static const bool want_stamps = getenv("RELA_R2D2_STAMPS") && atoi(getenv("RELA_R2D2_STAMPS")) != 0;
+    static unsigned long long* stamp_buf = nullptr;
+    if (want_stamps && !stamp_buf) RELA_HIP(hipMalloc(&stamp_buf, 64 * sizeof(unsigned long long)));
+    ra.stamps = want_stamps ? stamp_buf : nullptr;
+    static const bool chains = !(getenv("RELA_R2D2_REC_CHAINS") && atoi(getenv("RELA_R2D2_REC_CHAINS")) == 0);
+    if (chains && l->rec_chains_fit && Bn <= 64 && !want_stamps && !sc1_handoff()) {
+      RELA_HIP(hipMemsetAsync(l->rec_chain_bar, 0, sizeof(unsigned) * (size_t)(8 * Tpad), s));
+      ChainArgs2 ca{};
+      ca.net[0] = ra.net[0], ca.net[1] = ra.net[1];
+      ca.term = term, ca.tmo = l->rec_bar, ca.bar = l->rec_chain_bar, ca.T = T, ca.Tpad = Tpad, ca.Bn = Bn, ca.burn = burn;
+      ProfScope prof("learner_lstm_rec_persist", s);
+      hipLaunchKernelGGL(lstm_rec_chain, dim3(8 * kChainBlocks), dim3(kRecThreads), 0, s, ca);
+    } else {
+      ProfScope prof("learner_lstm_rec_persist", s);
+      if (sc1_handoff()) hipLaunchKernelGGL(lstm_rec_persist<true>, dim3(2 * kRecBlocks), dim3(kRecThreads), 0, s, ra);
+      else hipLaunchKernelGGL(lstm_rec_persist<false>, dim3(2 * kRecBlocks), dim3(kRecThreads), 0, s, ra);
+    }
     RELA_LAUNCH_CHECK();
+    if (want_stamps) {  // diagnostic: per-phase cycles of steps 20..27 of block 0 (synchronises)
+      unsigned long long h[64];
+      RELA_HIP(hipStreamSynchronize(s));
+      RELA_HIP(hipMemcpy(h, stamp_buf, sizeof(h), hipMemcpyDeviceToHost));
+      double d[8] = {0};
+      for (int k = 0; k < 7; ++k) {
+        for (int pnt = 0; pnt < 7; ++pnt) d[pnt] += (double)(h[k * 8 + pnt + 1] - h[k * 8 + pnt]) / 7.0;
+        d[7] += (double)(h[(k + 1) * 8] - h[k * 8]) / 7.0;
+      }
+      fprintf(stderr, "lstm_rec_persist step %.0f cycles: loads+MFMA %.0f | wg barrier %.0f | cell+stores %.0f | drain %.0f | grid barrier %.0f | acquire %.0f | release %.0f\n",
+              d[7], d[0], d[1], d[2], d[3], d[4], d[5], d[6]);
+    }
   } else {
     rc = forward_rec_steps(l, 1, Bn, term, false, s);
     if (rc != RELA_OK) return rc;
@@ -916,6 +1194,7 @@ extern "C" int rela_r2d2_learner_create(rela_r2d2_learner** out, int num_action,
   }
   RELA_HIP(hipMalloc(&l->rec_bar, sizeof(unsigned) * (size_t)(8 + 2 * ((T + 3) / 4 * 4))));
   RELA_HIP(hipMemset(l->rec_bar, 0, sizeof(unsigned) * (size_t)(8 + 2 * ((T + 3) / 4 * 4))));
+  RELA_HIP(hipMalloc(&l->rec_chain_bar, sizeof(unsigned) * (size_t)(8 * ((T + 3) / 4 * 4))));
   l->rec_persist = !(getenv("RELA_R2D2_REC") && strcmp(getenv("RELA_R2D2_REC"), "steps") == 0);
   if (l->rec_persist) {
     // The persistent kernels spin on a grid barrier: every block must be resident at once.  A plain launch checks
@@ -929,6 +1208,12 @@ extern "C" int rela_r2d2_learner_create(rela_r2d2_learner** out, int num_action,
     // (the query's known over-report concerns kernels near an SGPR allocation step at several blocks per CU: take one
     // block per CU off from four up; these kernels use < 80 SGPRs and need two blocks per CU at most)
     const int64_t room_f = (int64_t)cus * (occ_f >= 4 ? occ_f - 1 : occ_f), room_b = (int64_t)cus * (occ_b >= 4 ? occ_b - 1 : occ_b);
+    int occ_c = 0;
+    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, lstm_rec_chain, kRecThreads, 0));
+    int occ_d = 0;
+    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_d, lstm_bptt_chain, kRecThreads, 0));
+    if ((int64_t)cus * (occ_c >= 4 ? occ_c - 1 : occ_c) < 8 * kChainBlocks || (int64_t)cus * (occ_d >= 4 ? occ_d - 1 : occ_d) < 8 * kBpttBlocks)
+      l->rec_chains_fit = false;
     if (room_f < 2 * kRecBlocks || room_b < kBpttBlocks * kBpttRowSplit) {
       fprintf(stderr, "rela_r2d2_learner_create: %d CUs x (%d, %d) resident blocks cannot hold the persistent recurrent "
                       "grids (%d, %d): using the per-step launches\n", cus, occ_f, occ_b, 2 * kRecBlocks, kBpttBlocks * kBpttRowSplit);
@@ -972,6 +1257,7 @@ extern "C" void rela_r2d2_learner_destroy(rela_r2d2_learner* l) {
                 l->d_a1,   l->col,    l->part,    l->cpart,   l->s32,     l->npart,   l->norm,  l->loss,    l->loss_seq};
   for (void* p : ps) (void)hipFree(p);
   (void)hipFree(l->rec_bar);
+  (void)hipFree(l->rec_chain_bar);
   (void)hipFree(l->gxs[1]);
   (void)hipFree(l->wrec[0]);
   (void)hipFree(l->wrec[1]);
@@ -1176,9 +1462,15 @@ extern "C" int rela_r2d2_learner_grad(rela_r2d2_learner* l, void* stream_) {
     ba.ga = ga_tr, ba.d_o = l->d_o, ba.whh = P.w_hh, ba.C = Cc, ba.dc_rec = l->dc_rec;
     ba.bar = l->rec_bar + 4, ba.tmo = l->rec_bar, ba.Tt = Tt, ba.Bn = Bn, ba.burn = burn;
     ProfScope prof("learner_lstm_bptt_persist", s);
+    static const bool chains = !(getenv("RELA_R2D2_REC_CHAINS") && atoi(getenv("RELA_R2D2_REC_CHAINS")) == 0);
     // (a batch of fewer row tiles than the split leaves the surplus copies idle at the barrier: they still arrive)
     static const int rsplit = getenv("RELA_BPTT_ROW_SPLIT") ? std::max(1, std::min(8, atoi(getenv("RELA_BPTT_ROW_SPLIT")))) : kBpttRowSplit;
-    if (sc1_handoff()) hipLaunchKernelGGL(lstm_bptt_persist<true>, dim3(kBpttBlocks * rsplit), dim3(kRecThreads), 0, s, ba);
+    if (chains && l->rec_chains_fit && Bn <= 128 && Tt <= l->T && !sc1_handoff()) {
+      const int Tpad_c = (l->T + 3) / 4 * 4;
+      RELA_HIP(hipMemsetAsync(l->rec_chain_bar, 0, sizeof(unsigned) * (size_t)(8 * Tpad_c), s));
+      ba.bar = l->rec_chain_bar;
+      hipLaunchKernelGGL(lstm_bptt_chain, dim3(8 * kBpttBlocks), dim3(kRecThreads), 0, s, ba, Tpad_c);
+    } else if (sc1_handoff()) hipLaunchKernelGGL(lstm_bptt_persist<true>, dim3(kBpttBlocks * rsplit), dim3(kRecThreads), 0, s, ba);
     else hipLaunchKernelGGL(lstm_bptt_persist<false>, dim3(kBpttBlocks * rsplit), dim3(kRecThreads), 0, s, ba);
   } else
   for (int t = Tt - 1; t >= 0; --t) {
