@@ -75,16 +75,44 @@ struct TileCfg {
   static constexpr int A_IT = (A_V4 + kT - 1) / kT, B_IT = (B_V4 + kT - 1) / kT;
 };
 
+// Block -> (N tile, M tile, K split).  Workgroups are dealt round-robin over the 8 XCDs by linear id, so on the plain 3-D
+// grid the blocks that read the SAME operand bytes -- the tiles of one K split (they share the split's slice of A and
+// B), or, without splits, the M tiles of one N tile (they share B's column block) -- sit on eight different L2s and each
+// fetches those bytes from the Infinity Cache / HBM again.  The 1-D maps give such blocks ids that are equal mod 8 and
+// consecutive in id / 8 (for speed only: any placement computes the same thing).  Ids past the last tile leave at once.
+struct GridMap {
+  int gx, gy, gz;
+  int mode;  // 0: plain (blockIdx.x / y / z) | 1: splits grouped (gz >= 8) | 2: M tiles of an N tile grouped
+};
+__device__ __forceinline__ bool grid_map(const GridMap& gm, int& bx, int& by, int& bz) {
+  if (gm.mode == 0) {
+    bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    return true;
+  }
+  const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+  if (gm.mode == 1) {
+    const int tiles = gm.gx * gm.gy;
+    bz = (i / tiles) * 8 + xcd;
+    const int t = i % tiles;
+    bx = t % gm.gx, by = t / gm.gx;
+    return bz < gm.gz;
+  }
+  bx = (i / gm.gy) * 8 + xcd, by = i % gm.gy, bz = 0;
+  return bx < gm.gx;
+}
+
 template <class T, class P>
-__global__ __launch_bounds__(kT) void gemm_bf16x3(const P p) {
+__global__ __launch_bounds__(kT) void gemm_bf16x3(const P p, const GridMap gm) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int bx, by, bz;
+  if (!grid_map(gm, bx, by, bz)) return;  // (block-uniform, before any barrier)
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
   const int wm = wave / T::WN, wn = wave % T::WN;
-  const int m0 = blockIdx.y * T::BM, n0 = blockIdx.x * T::BN;
+  const int m0 = by * T::BM, n0 = bx * T::BN;
   const int nch = (p.K + BK - 1) / BK;
-  const int c0 = blockIdx.z * p.kslice;
+  const int c0 = bz * p.kslice;
   const int c1 = min(nch, c0 + p.kslice);
 
   // Staging registers: D chunks in flight.  A chunk is 24 (or fewer) MFMAs per wave -- far less than one load's
@@ -227,7 +255,7 @@ __global__ __launch_bounds__(kT) void gemm_bf16x3(const P p) {
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + (wm * T::TM + t) * 16 + g * 4 + r;
         const int n = n0 + (wn * T::TN + u) * 16 + li;
-        if (m < p.M && n < p.N) p.store(blockIdx.z, m, n, acc[t][u][r]);
+        if (m < p.M && n < p.N) p.store(bz, m, n, acc[t][u][r]);
       }
 }
 
@@ -241,8 +269,17 @@ int launch_gemm(P p, int splits, hipStream_t s, const char* name) {
   p.kslice = ceil_div(nch, splits);
   ProfScope prof(name, s);
   note_launch("gemm_bf16x3");
-  hipLaunchKernelGGL((gemm_bf16x3<T, P>), dim3(ceil_div(p.N, T::BN), ceil_div(p.M, T::BM), splits), dim3(kT), T::LDS_BYTES, s,
-                     p);
+  static const bool xmap = !(getenv("RELA_GEMM_XCD_MAP") && atoi(getenv("RELA_GEMM_XCD_MAP")) == 0);
+  GridMap gm{ceil_div(p.N, T::BN), ceil_div(p.M, T::BM), splits, 0};
+  dim3 grid(gm.gx, gm.gy, gm.gz);
+  if (xmap && gm.gz >= 8) {
+    gm.mode = 1;
+    grid = dim3(8 * gm.gx * gm.gy * ceil_div(gm.gz, 8));
+  } else if (xmap && gm.gz == 1 && gm.gy > 1 && gm.gx >= 8) {
+    gm.mode = 2;
+    grid = dim3(8 * gm.gy * ceil_div(gm.gx, 8));
+  }
+  hipLaunchKernelGGL((gemm_bf16x3<T, P>), grid, dim3(kT), T::LDS_BYTES, s, p, gm);
   return RELA_OK;
 }
 
