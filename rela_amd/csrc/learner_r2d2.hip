@@ -627,8 +627,8 @@ __global__ __launch_bounds__(kRecThreads) void lstm_bptt_persist(BpttArgs a) {
 // share an XCD; 32 unit blocks each), its own arrival counters, the cell as above with the
 // recurrent cell-state gradient in registers.  Same sums in the same order: bit-identical gate gradients.  (Requesting
 // the cell's own inputs of step t - 1 before the wait at the grid barrier, as the forward kernel does with its x-part,
-// made this kernel SLOWER, 0.79 -> 1.05 ms: the poll of the lane that waits sits behind those loads in its wave's
-// in-order return queue.)
+// made this kernel SLOWER, 0.79 -> 1.05 ms; the cause is not established -- polling from a lane of another wave, so that
+// no load is queued ahead of the polls, changed nothing in the forward kernel.)
 __global__ __launch_bounds__(kRecThreads) void lstm_bptt_chain(BpttArgs a, int Tpad) {
   __shared__ float red[8][16][17];
   __shared__ int alive;
