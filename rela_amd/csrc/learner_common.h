@@ -694,7 +694,7 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     int blocks = 0;
     {
       ProfScope prof("learner_wgrad_conv1", s);
-      (void)w1fast::launch(t.obs, t.d_a1, Bn, t.part, s, &blocks);
+      (void)w1fast::launch(t.obs, t.d_a1, Bn, t.part, s, &blocks, lanes ? 128 : w1fast::kMaxBlocks);
     }
     hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(32 * 256, 256)), dim3(256), 0, s, (const float*)t.part, blocks, 32,
                        256, kRedConv1, t.g_c1w);

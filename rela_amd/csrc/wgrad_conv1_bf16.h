@@ -22,6 +22,9 @@
 #include "prof.h"
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 namespace rela_amd {
@@ -190,12 +193,18 @@ __global__ __launch_bounds__(kT) void wgrad_conv1_bf16(const uint8_t* __restrict
     reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(red)[i];
 }
 
-inline int launch(const uint8_t* obs, const float* d_a1, int frames, float* part, hipStream_t s, int* blocks_out) {
+// max_blocks < kMaxBlocks leaves CUs to kernels of another stream (the Ape-X learner's two-lane backward: with 128 of
+// the 256 CUs this kernel takes 66 us instead of 52 alone, but the side lane's conv2 weight gradient next to it 33
+// instead of 49, and the step 0.485 -> 0.458 ms; flat between 96 and 160 blocks)
+inline int launch(const uint8_t* obs, const float* d_a1, int frames, float* part, hipStream_t s, int* blocks_out,
+                  int max_blocks = kMaxBlocks) {
   // (initialised once, thread-safely: launches may come from several host threads)
   static const hipError_t attr_set =
       hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_conv1_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
   RELA_HIP(attr_set);
-  const int blocks = frames < kMaxBlocks ? frames : kMaxBlocks;
+  static const int env_cap = getenv("RELA_W1_BLOCKS") ? std::max(1, std::min(kMaxBlocks, atoi(getenv("RELA_W1_BLOCKS")))) : 0;
+  const int cap = env_cap ? env_cap : std::max(1, std::min(kMaxBlocks, max_blocks));
+  const int blocks = frames < cap ? frames : cap;
   note_launch("wgrad_conv1_bf16");
   hipLaunchKernelGGL(wgrad_conv1_bf16, dim3(blocks), dim3(kT), LDS_TOTAL, s, obs, d_a1, frames, part);
   *blocks_out = blocks;
