@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.h"
@@ -51,7 +52,13 @@ __device__ __forceinline__ uint16_t bf16_bits(float x) {  // RNE; exact for the 
 }
 
 __global__ __launch_bounds__(kT) void wgrad_conv1_bf16(const uint8_t* __restrict__ obs, const float* __restrict__ d_a1,
-                                                       int frames, float* __restrict__ part) {
+                                                       int frames, float* __restrict__ part,
+                                                       unsigned long long* __restrict__ stamps = nullptr) {
+  // diagnostic (RELA_W1_STAMPS=1): shader clocks of block 0 / thread 0 -> stamps[0..15]
+  int stamp_i = 0;
+  auto stamp = [&]() {
+    if (stamps && blockIdx.x == 0 && threadIdx.x == 0 && stamp_i < 16) stamps[stamp_i++] = __builtin_amdgcn_s_memtime();
+  };
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* img = smem;
   uint8_t* dt = smem + IMG_BYTES;
@@ -126,13 +133,17 @@ __global__ __launch_bounds__(kT) void wgrad_conv1_bf16(const uint8_t* __restrict
   const int b_off = li * SUB + (oyr * 24 + ox0) * 2;
 
   int f = blockIdx.x;
+  stamp();  // 0: kernel start (zero fill issued)
   W1_LOAD(f, 0);  // (blocks <= frames: f is a frame)
   __syncthreads();  // zero fill done
+  stamp();  // 1
   for (; f < frames; f += gridDim.x) {
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
+      stamp();  // half start
       put_img(ci0, im0);
       put_img(ci1, im1);
+      stamp();  // image staged
       put_d(di0, d0);
       put_d(di1, d1);
       put_d(di2, d2);
@@ -142,7 +153,9 @@ __global__ __launch_bounds__(kT) void wgrad_conv1_bf16(const uint8_t* __restrict
         const int hn = (h == 0) ? 1 : ((f + (int)gridDim.x < frames) ? 0 : 1);
         W1_LOAD(fn, hn);
       }
+      stamp();  // d staged, loads issued
       __syncthreads();
+      stamp();  // barrier
       uint4 af[2][2][2];  // [q][hi, lo][m tile]
 #pragma unroll
       for (int q = 0; q < 2; ++q)
@@ -165,9 +178,11 @@ __global__ __launch_bounds__(kT) void wgrad_conv1_bf16(const uint8_t* __restrict
               acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[q][0][m]), bf, acc[m][n], 0, 0, 0);
             }
         }
+      stamp();  // MFMAs issued
       __syncthreads();  // fragments read: the tiles may be overwritten
     }
   }
+  stamp();  // loop done
 #undef W1_LOAD
   // ---- fold the eight waves' sums in wave order (deterministic), then one coalesced store per block ----
   float* red = reinterpret_cast<float*>(dt);
@@ -206,7 +221,22 @@ inline int launch(const uint8_t* obs, const float* d_a1, int frames, float* part
   const int cap = env_cap ? env_cap : std::max(1, std::min(kMaxBlocks, max_blocks));
   const int blocks = frames < cap ? frames : cap;
   note_launch("wgrad_conv1_bf16");
-  hipLaunchKernelGGL(wgrad_conv1_bf16, dim3(blocks), dim3(kT), LDS_TOTAL, s, obs, d_a1, frames, part);
+  static const bool want_stamps = getenv("RELA_W1_STAMPS") && atoi(getenv("RELA_W1_STAMPS")) != 0;
+  static unsigned long long* sbuf = nullptr;
+  if (want_stamps && !sbuf) {
+    RELA_HIP(hipMalloc(&sbuf, 16 * sizeof(unsigned long long)));
+  }
+  if (want_stamps) RELA_HIP(hipMemsetAsync(sbuf, 0, 16 * sizeof(unsigned long long), s));
+  hipLaunchKernelGGL(wgrad_conv1_bf16, dim3(blocks), dim3(kT), LDS_TOTAL, s, obs, d_a1, frames, part,
+                     want_stamps ? sbuf : nullptr);
+  if (want_stamps) {
+    unsigned long long h[16];
+    RELA_HIP(hipStreamSynchronize(s));
+    RELA_HIP(hipMemcpy(h, sbuf, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "wgrad_conv1_bf16 stamps (cycles since start):");
+    for (int i = 1; i < 16 && h[i]; ++i) fprintf(stderr, " %llu", h[i] - h[0]);
+    fprintf(stderr, "\n");
+  }
   *blocks_out = blocks;
   return RELA_OK;
 }
