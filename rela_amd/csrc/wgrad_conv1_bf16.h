@@ -75,20 +75,44 @@ __global__ __launch_bounds__(kT) void wgrad_conv1_bf16(const uint8_t* __restrict
     for (int n = 0; n < 16; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- staging registers: the half frame after the one being multiplied ----
-  // image: 924 chunks of 16 u8 per half (4 planes x 44 rows x 84), two per thread (clamped: the last threads repeat
-  // chunk 923, writing the same values twice); d: 1,600 float4 (8 channel quads x 200 pixels), four per thread
-  // (threads past 1,600 repeat number 1,599).  Quad-major numbering: the 64 lanes of a wave hold 64 consecutive
+  // image: a thread takes 4 x 4 space-to-depth CELLS -- rows 4 y' .. 4 y' + 3, columns 4 x' .. 4 x' + 3 of one plane, four
+  // dword loads -- whose 16 pixels go to the SAME element (y', x') of the plane's 16 sub-images: sixteen 2-byte stores
+  // at constant offsets from one address (before late r3 a thread took 16 consecutive bytes of a row and derived
+  // sub-image, row and column per byte; the image part of the staging went from ~970 to ~830 cycles per half frame,
+  // but it is the 64 two-byte stores of d^T per thread that dominate a half's 7.3 k cycles: RELA_W1_STAMPS, ~2.5 k for
+  // d^T + 1.7 k waiting for the slowest wave, against 1.4 k of MFMAs).  924 cells per half (4 planes x 11 x 21), two per thread (clamped: the last
+  // threads repeat cell 923, writing the same values twice).  d: 1,600 float4 (8 channel quads x 200 pixels), four per
+  // thread (threads past 1,600 repeat number 1,599).  Quad-major numbering: the 64 lanes of a wave hold 64 consecutive
   // pixels of ONE channel quad, so their 2-byte LDS stores fall on 32 different banks (pixel-major numbering put a
   // wave's eight quads, whose rows are 2,176 B apart, on the same four banks: 8-way conflicts on every store).
-  uint4 im0, im1;
+  uint32_t im[2][4];
   float4 d0, d1, d2, d3;
-  const int ci0 = min(tid, 923), ci1 = min(tid + kT, 923);
+  int cell_g[2], cell_l[2];  // a cell's byte offset inside a half frame (plane, row 4 y', column 4 x') and in LDS
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = min(tid + j * kT, 923);
+    const int pl = c / 231, rem = c - pl * 231;
+    const int yq = rem / 21, xq = rem - yq * 21;
+    cell_g[j] = pl * 7056 + 4 * yq * 84 + 4 * xq;
+    cell_l[j] = pl * 16 * SUB + (yq * 24 + xq) * 2;
+  }
   const int di0 = tid, di1 = tid + kT, di2 = tid + 2 * kT, di3 = min(tid + 3 * kT, 1599);
+  int d_l[4];  // (channel quad, pixel) -> byte offset of its hi element in the q = 0 copy of d^T
+  {
+    const int dis[4] = {di0, di1, di2, di3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int px = dis[j] % 200, oc0 = (dis[j] / 200) * 4;
+      const int oy = px / 20, ox = px - oy * 20;
+      d_l[j] = oc0 * DT_PITCH + (oy * 24 + ox) * 2;
+    }
+  }
 #define W1_LOAD(F, H)                                                                                        \
   do {                                                                                                       \
     const uint8_t* fo__ = obs + (size_t)(F) * 28224 + (H) * (40 * 84);                                        \
-    im0 = *reinterpret_cast<const uint4*>(fo__ + (ci0 / 231) * 7056 + (ci0 % 231) * 16);                      \
-    im1 = *reinterpret_cast<const uint4*>(fo__ + (ci1 / 231) * 7056 + (ci1 % 231) * 16);                      \
+    _Pragma("unroll") for (int j__ = 0; j__ < 2; ++j__)                                                       \
+      _Pragma("unroll") for (int r__ = 0; r__ < 4; ++r__)                                                     \
+        im[j__][r__] = *reinterpret_cast<const uint32_t*>(fo__ + cell_g[j__] + r__ * 84);                      \
     const float* fd__ = d_a1 + ((size_t)(F) * 400 + (H) * 200) * 32;                                          \
     d0 = *reinterpret_cast<const float4*>(fd__ + (di0 % 200) * 32 + (di0 / 200) * 4);                         \
     d1 = *reinterpret_cast<const float4*>(fd__ + (di1 % 200) * 32 + (di1 / 200) * 4);                         \
@@ -96,33 +120,28 @@ __global__ __launch_bounds__(kT) void wgrad_conv1_bf16(const uint8_t* __restrict
     d3 = *reinterpret_cast<const float4*>(fd__ + (di3 % 200) * 32 + (di3 / 200) * 4);                         \
   } while (0)
 
-  auto put_img = [&](int ci, uint4 v) {
-    const int pl = ci / 231;
-    int e = (ci - pl * 231) * 16;
-    int row = e / 84, col = e - row * 84;
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  auto put_img = [&](int j) {
+    uint8_t* base = img + cell_l[j];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const uint32_t b = (w[t >> 2] >> ((t & 3) * 8)) & 0xffu;
-      const int ph = (row & 3) * 4 + (col & 3);
-      *reinterpret_cast<uint16_t*>(img + (pl * 16 + ph) * SUB + ((row >> 2) * 24 + (col >> 2)) * 2) = bf16_bits((float)b);
-      if (++col == 84) col = 0, ++row;
-    }
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float v = (float)((im[j][r] >> (8 * c)) & 0xffu);  // exact in bf16: its bits are the float's upper half
+        *reinterpret_cast<uint16_t*>(base + (r * 4 + c) * SUB) = (uint16_t)(__float_as_uint(v) >> 16);
+      }
   };
-  auto put_d = [&](int di, float4 v) {
-    const int px = di % 200, oc0 = (di / 200) * 4;
-    const int oy = px / 20, ox = px - oy * 20;
-    const int k0 = oy * 24 + ox;
+  auto put_d = [&](int j, float4 v) {
     const float x[4] = {v.x, v.y, v.z, v.w};
+    uint8_t* r0 = dt + d_l[j];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const uint16_t hi = bf16_bits(x[t]);
       const uint16_t lo = bf16_bits(x[t] - __uint_as_float((uint32_t)hi << 16));
-      uint8_t* r0 = dt + (size_t)(oc0 + t) * DT_PITCH + k0 * 2;  // copy q = 0, hi
-      *reinterpret_cast<uint16_t*>(r0) = hi;
-      *reinterpret_cast<uint16_t*>(r0 + 32 * DT_PITCH) = lo;          // q = 0, lo
-      *reinterpret_cast<uint16_t*>(r0 + 64 * DT_PITCH + 2) = hi;      // q = 1 (shifted by one pixel), hi
-      *reinterpret_cast<uint16_t*>(r0 + 96 * DT_PITCH + 2) = lo;      // q = 1, lo
+      uint8_t* rt = r0 + t * DT_PITCH;                                // copy q = 0, hi
+      *reinterpret_cast<uint16_t*>(rt) = hi;
+      *reinterpret_cast<uint16_t*>(rt + 32 * DT_PITCH) = lo;          // q = 0, lo
+      *reinterpret_cast<uint16_t*>(rt + 64 * DT_PITCH + 2) = hi;      // q = 1 (shifted by one pixel), hi
+      *reinterpret_cast<uint16_t*>(rt + 96 * DT_PITCH + 2) = lo;      // q = 1, lo
     }
   };
 
@@ -141,13 +160,13 @@ __global__ __launch_bounds__(kT) void wgrad_conv1_bf16(const uint8_t* __restrict
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
       stamp();  // half start
-      put_img(ci0, im0);
-      put_img(ci1, im1);
+      put_img(0);
+      put_img(1);
       stamp();  // image staged
-      put_d(di0, d0);
-      put_d(di1, d1);
-      put_d(di2, d2);
-      put_d(di3, d3);
+      put_d(0, d0);
+      put_d(1, d1);
+      put_d(2, d2);
+      put_d(3, d3);
       {  // the half after this one (the last one re-reads itself)
         const int fn = (h == 0) ? f : ((f + (int)gridDim.x < frames) ? f + (int)gridDim.x : f);
         const int hn = (h == 0) ? 1 : ((f + (int)gridDim.x < frames) ? 0 : 1);
