@@ -331,7 +331,10 @@ def bench_r2d2(args, world, rank, device):
     reward = rng.integers(-1, 2, R2_ROWS).astype(np.float32)
     phase = rng.integers(0, R2_EPISODE, R2_ROWS)
     actor_stream = torch.cuda.Stream(device=device)
-    main_stream = torch.cuda.Stream(device=device, priority=-1)
+    # (the learner's stream: high priority unless RELA_BENCH_PRIO=2 -- its persistent chain kernels need every block
+    # resident before the first grid barrier releases)
+    main_stream = (torch.cuda.Stream(device=device) if os.environ.get("RELA_BENCH_PRIO", "1") == "2"
+                   else torch.cuda.Stream(device=device, priority=-1))
     tick_idx, step_idx = [0], [0]
 
     def actor_tick():
@@ -781,10 +784,15 @@ def main():
     # the learner step stays on torch's default stream; they meet only through the replay, whose
     # private stream serialises insert / sample / update in commit order.
     actor_stream = torch.cuda.Stream(device=device)
-    # the learner's ~170 short eager kernels go to a HIGH-priority stream so they are not queued
-    # behind the tick's chip-filling kernels; RELA_BENCH_PRIO=0 keeps the default stream
-    if os.environ.get("RELA_BENCH_PRIO", "1") == "1":
+    # The learner's launches go to their own stream.  With the eager PyTorch learner of round 1 (~170 short kernels) a
+    # HIGH-priority stream kept them from queueing behind the tick's chip-filling kernels; with the HIP learner (a few
+    # dozen launches, two lanes) normal priority is ~1 % faster (interleaved on one box: 5.36-5.37 M against 5.31-5.32 M
+    # env-steps/s; the legacy default stream 5.36-5.40).  RELA_BENCH_PRIO=1: high priority, 0: torch's default stream.
+    prio = os.environ.get("RELA_BENCH_PRIO", "2")
+    if prio == "1":
         main_stream = torch.cuda.Stream(device=device, priority=-1)
+    elif prio == "2":
+        main_stream = torch.cuda.Stream(device=device)
     else:
         main_stream = torch.cuda.current_stream(device)
 
