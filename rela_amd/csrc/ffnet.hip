@@ -3041,6 +3041,10 @@ struct rela_ffnet {
   int precision = 0;  // 0 = exact f32 MFMA (parity mode), 1 = split-bf16 MFMA for conv2 / conv3 / fc
   unsigned* pipe_tmo = nullptr;  // sticky: a wave of conv12_pipe gave up waiting (never observed)
   int max_rows = 0;  // > 0: the owner never runs more rows (a learner's batch): layouts only larger batches read are not packed
+  // BfT (the f32 split-K fc's weights) of such a net in the split-bf16 mode: no kernel of that mode reads it from 128
+  // rows up, so the per-step re-pack skips it (6.4 MB) and the f32 path packs it on demand from the owner's buffer
+  mutable bool bft_stale = false;
+  const float* bft_src = nullptr;
 };
 
 
@@ -3344,6 +3348,12 @@ int rela_amd::ffnet_load_impl(rela_ffnet* n, const rela_ffnet_params* p, int on_
     for (int jn = 0; jn < 17; ++jn) el[jn] = elems[jn];
     if (n->max_rows > 0 && n->max_rows < kFcSplitBelow) el[4] = 0;
     if (n->max_rows > 0 && n->max_rows < kFastTrunkMinN) el[10] = 0;  // (the split-K fc_bf16s serves 128 rows and up)
+    n->bft_stale = false;
+    if (n->max_rows >= kFastTrunkMinN && on_device && n->precision == 1) {  // (the owner's buffer outlives this call)
+      el[5] = 0;
+      n->bft_stale = true;
+      n->bft_src = dv[6];
+    }
     a.first[0] = 0;
     for (int jn = 0; jn < 17; ++jn) a.first[jn + 1] = a.first[jn] + (int)ceil_div(el[jn], 256);
     hipLaunchKernelGGL(pack_ffnet_all, dim3(a.first[17]), dim3(256), 0, s, a);
@@ -3503,6 +3513,13 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     const int splits = fc_splits(N);
     float* part = ha + kHA * N;
     part += (64 - ((part - static_cast<float*>(ws)) & 63)) & 63;  // 256-byte aligned (float4 loads)
+    if (n->bft_stale) {  // (see rela_ffnet::bft_stale)
+      PackAllArgs a{};
+      a.p[6] = n->bft_src, a.BfT = d.BfT;
+      for (int jn = 0; jn < 17; ++jn) a.first[jn + 1] = a.first[jn] + (jn == 5 ? (int)ceil_div((int64_t)3136 * 512, 256) : 0);
+      hipLaunchKernelGGL(pack_ffnet_all, dim3(a.first[17]), dim3(256), 0, s, a);
+      n->bft_stale = false;
+    }
     ProbFcFwd p{};
     p.M = N, p.N = 512, p.K = 3136;
     p.a3 = a3, p.wt = d.BfT, p.part = part;

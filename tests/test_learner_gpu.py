@@ -489,3 +489,41 @@ def test_actor_net_loaded_from_flat_buffer_matches_publish():
     a.close()
     b.close()
     learner.close()
+
+
+def test_f32_fc_layout_is_packed_on_demand_after_a_fast_mode_step():
+    """In the split-bf16 mode no kernel reads the f32 split-K fc's weight layout (BfT) from 128 rows up, so a learner
+    whose batch can reach 128 rows skips it in the re-pack after every step and the f32 path packs it when it is next
+    needed (csrc/ffnet.hip: rela_ffnet::bft_stale).  After a fast-mode step at B = 256, a 64-row batch -- whose forwards
+    run the f32 kernels, BfT included -- must give exactly what a learner with the SAME parameters and a 64-row maximum
+    (which packs BfT eagerly) gives, and so must the f32 mode at 256 rows."""
+    import torch
+
+    from rela_amd.learner import HipApexLearner
+
+    A = 18
+    agent = make_agent(A, 11)
+    big = HipApexLearner.from_agent(agent, 256)
+    big.set_precision("bf16x2")
+    b256, w256 = make_batch(256, A, 31)
+    big.step(b256, w256)  # backward + optimiser + re-pack in the fast mode: BfT is now stale
+    on = {k: v.clone() for k, v in big.state_dict("online").items()}
+    tg = {k: v.clone() for k, v in big.state_dict("target").items()}
+    small = HipApexLearner(A, 64, agent.multi_step, agent.gamma)
+    small.load_state_dicts(on, tg)
+    small.set_precision("bf16x2")
+    b64, w64 = make_batch(64, A, 32)
+    loss_a, prio_a = big.backward(b64, w64)
+    loss_b, prio_b = small.backward(b64, w64)
+    assert torch.equal(prio_a, prio_b) and torch.equal(loss_a, loss_b)
+    ref = HipApexLearner(A, 256, agent.multi_step, agent.gamma)  # f32 from the start: every layout packed at load
+    ref.load_state_dicts(on, tg)
+    big.step(b256, w256)  # stale again ...
+    on2 = {k: v.clone() for k, v in big.state_dict("online").items()}
+    ref.load_state_dicts(on2, tg)
+    big.set_precision("f32")  # ... and now the f32 mode needs it at 256 rows
+    loss_c, prio_c = big.backward(b256, w256)
+    loss_d, prio_d = ref.backward(b256, w256)
+    assert torch.equal(prio_c, prio_d) and torch.equal(loss_c, loss_d)
+    for l in (big, small, ref):
+        l.close()
