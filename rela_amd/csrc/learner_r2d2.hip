@@ -368,7 +368,8 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
 // other way: a CHAIN is one net x one tile of 16 batch rows (2 x 4 chains), run by the 32 blocks whose ids are equal
 // mod 8 -- the dispatcher deals blocks round-robin over the XCDs, so they share an L2 -- each owning 16 hidden units
 // (64 gate columns: W_hh's slice is 64 registers per lane).  The protocol is unchanged and placement-INDEPENDENT
-// (write-through h, agent-scope arrival counter, one acquire per step): co-location only decides whether the h a block
+// (write-through h, agent-scope arrival counter, sc1 loads of h -- or plain loads behind one acquire per step):
+// co-location only decides whether the h a block
 // reads is still in its XCD's L2 and how many arrivals a counter takes (32).  The sums are formed in the order of the
 // kernel above -- wave w multiplies k in [64 w, 64 w + 64) in the same MFMA sequence, the eight partials are added in
 // wave order onto the x-part -- so H, C and the saved gates are bit-identical to it.  One thread per (row, unit) runs
@@ -384,6 +385,7 @@ struct ChainArgs2 {
 };
 constexpr int kChainBlocks = 32, kChainUnits = kHid / kChainBlocks;  // 16 units per block
 static_assert(kChainUnits == 16, "tile shapes below");
+template <bool SC1>
 __global__ __launch_bounds__(kRecThreads) void lstm_rec_chain(ChainArgs2 a) {
   __shared__ float red[8][16][65];
   __shared__ int alive;
@@ -401,6 +403,7 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_chain(ChainArgs2 a) {
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) bfr[c][ks] = nt.whhT[(size_t)(wave * 64 + 16 * g + ks) * kGates + c * kHid + 16 * j + li];
   const size_t blk = (size_t)a.Bn * kHid;
+  const __amdgpu_buffer_rsrc_t rsH = sc1_rsrc(nt.H, (size_t)(a.T + 1) * blk * 4);
   // the cell's thread: unit u = tid & 15, row r = tid >> 4 (threads 0..255)
   const int cu = tid & 15, cr = tid >> 4;
   const bool cell = tid < 256 && cr < nrow;
@@ -420,9 +423,9 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_chain(ChainArgs2 a) {
     float4 hv[4];
     {
       const int arow = row0 + min(li, nrow - 1);
-      const float* hp = nt.H + (size_t)t * blk + (size_t)arow * kHid + wave * 64 + 16 * g;
+      const size_t hoff = (size_t)t * blk + (size_t)arow * kHid + wave * 64 + 16 * g;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp + 4 * q);
+      for (int q = 0; q < 4; ++q) hv[q] = ld4_shared<SC1>(rsH, nt.H, hoff + 4 * q);
     }
     const float av[16] = {hv[0].x, hv[0].y, hv[0].z, hv[0].w, hv[1].x, hv[1].y, hv[1].z, hv[1].w,
                           hv[2].x, hv[2].y, hv[2].z, hv[2].w, hv[3].x, hv[3].y, hv[3].z, hv[3].w};
@@ -478,8 +481,10 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_chain(ChainArgs2 a) {
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (!SC1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       alive = ok ? 1 : 0;
     }
     __syncthreads();
@@ -629,6 +634,7 @@ __global__ __launch_bounds__(kRecThreads) void lstm_bptt_persist(BpttArgs a) {
 // the cell's own inputs of step t - 1 before the wait at the grid barrier, as the forward kernel does with its x-part,
 // made this kernel SLOWER, 0.79 -> 1.05 ms; the cause is not established -- polling from a lane of another wave, so that
 // no load is queued ahead of the polls, changed nothing in the forward kernel.)
+template <bool SC1>
 __global__ __launch_bounds__(kRecThreads) void lstm_bptt_chain(BpttArgs a, int Tpad) {
   __shared__ float red[8][16][17];
   __shared__ int alive;
@@ -640,6 +646,7 @@ __global__ __launch_bounds__(kRecThreads) void lstm_bptt_chain(BpttArgs a, int T
 #pragma unroll
   for (int ks = 0; ks < 64; ++ks) bfr[ks] = a.whh[(size_t)(256 * wave + 64 * g + ks) * kHid + 16 * j + li];
   const size_t blk = (size_t)a.Bn * kHid;
+  const __amdgpu_buffer_rsrc_t rsG = sc1_rsrc(a.ga, (size_t)a.Tt * a.Bn * kGates * 4);
   // cell backward for (row, units 16 j + 4 q .. + 3): threads 0 .. 63, as in the kernel above (16-byte loads, 8-byte
   // write-through stores: one thread per (row, unit) with 4-byte stores was 20 % slower)
   const int r = tid >> 2, q = tid & 3, row = row0 + r;
@@ -657,10 +664,10 @@ __global__ __launch_bounds__(kRecThreads) void lstm_bptt_chain(BpttArgs a, int T
     if (rec) {
       f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
       const int arow = min(row0 + li, a.Bn - 1);  // (rows past the batch repeat the last one, unread)
-      const float* dp = a.ga + (size_t)(t + 1) * a.Bn * kGates + (size_t)arow * kGates + 256 * wave + 64 * g;
+      const size_t doff = (size_t)(t + 1) * a.Bn * kGates + (size_t)arow * kGates + 256 * wave + 64 * g;
       float4 v[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) v[c] = *reinterpret_cast<const float4*>(dp + 4 * c);  // all in flight before the first MFMA
+      for (int c = 0; c < 16; ++c) v[c] = ld4_shared<SC1>(rsG, a.ga, doff + 4 * c);  // all in flight before the first MFMA
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c].x, bfr[4 * c], acc, 0, 0, 0);
@@ -728,8 +735,10 @@ __global__ __launch_bounds__(kRecThreads) void lstm_bptt_chain(BpttArgs a, int T
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (!SC1) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       alive = ok ? 1 : 0;
     }
     __syncthreads();
@@ -1081,7 +1090,14 @@ int forward_both(rela_r2d2_learner* l, int Bn, const uint8_t* obs, const float* 
       ca.net[0] = ra.net[0], ca.net[1] = ra.net[1];
       ca.term = term, ca.tmo = l->rec_bar, ca.bar = l->rec_chain_bar, ca.T = T, ca.Tpad = Tpad, ca.Bn = Bn, ca.burn = burn;
       ProfScope prof("learner_lstm_rec_persist", s);
-      hipLaunchKernelGGL(lstm_rec_chain, dim3(8 * kChainBlocks), dim3(kRecThreads), 0, s, ca);
+      // h_{t-1} is read with sc1 buffer loads and no acquire fence (default; RELA_R2D2_CHAIN_SC1=0: plain loads behind an
+      // agent-scope acquire per step): 0.79 -> 0.56 ms.  MI355X_MICROARCH.md's conditions for that form hold: h is stored
+      // write-through (agent-scope atomic stores), every storing wave drains its stores before the workgroup barrier that
+      // precedes the arrival, every load of those bytes is an sc1 load, one workgroup per CU.  The same switch makes BPTT
+      // SLOWER (0.82 -> 0.96-1.01 ms: its 128 KB of gate gradients per block and step), so it keeps the fence.
+      static const bool chain_sc1 = !(getenv("RELA_R2D2_CHAIN_SC1") && atoi(getenv("RELA_R2D2_CHAIN_SC1")) == 0);
+      if (chain_sc1) hipLaunchKernelGGL(lstm_rec_chain<true>, dim3(8 * kChainBlocks), dim3(kRecThreads), 0, s, ca);
+      else hipLaunchKernelGGL(lstm_rec_chain<false>, dim3(8 * kChainBlocks), dim3(kRecThreads), 0, s, ca);
     } else {
       ProfScope prof("learner_lstm_rec_persist", s);
       if (sc1_handoff()) hipLaunchKernelGGL(lstm_rec_persist<true>, dim3(2 * kRecBlocks), dim3(kRecThreads), 0, s, ra);
@@ -1214,9 +1230,9 @@ extern "C" int rela_r2d2_learner_create(rela_r2d2_learner** out, int num_action,
     // block per CU off from four up; these kernels use < 80 SGPRs and need two blocks per CU at most)
     const int64_t room_f = (int64_t)cus * (occ_f >= 4 ? occ_f - 1 : occ_f), room_b = (int64_t)cus * (occ_b >= 4 ? occ_b - 1 : occ_b);
     int occ_c = 0;
-    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, lstm_rec_chain, kRecThreads, 0));
+    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, lstm_rec_chain<false>, kRecThreads, 0));
     int occ_d = 0;
-    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_d, lstm_bptt_chain, kRecThreads, 0));
+    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_d, lstm_bptt_chain<false>, kRecThreads, 0));
     if ((int64_t)cus * (occ_c >= 4 ? occ_c - 1 : occ_c) < 8 * kChainBlocks || (int64_t)cus * (occ_d >= 4 ? occ_d - 1 : occ_d) < 8 * kBpttBlocks)
       l->rec_chains_fit = false;
     if (room_f < 2 * kRecBlocks || room_b < kBpttBlocks * kBpttRowSplit) {
@@ -1474,7 +1490,9 @@ extern "C" int rela_r2d2_learner_grad(rela_r2d2_learner* l, void* stream_) {
       const int Tpad_c = (l->T + 3) / 4 * 4;
       RELA_HIP(hipMemsetAsync(l->rec_chain_bar, 0, sizeof(unsigned) * (size_t)(8 * Tpad_c), s));
       ba.bar = l->rec_chain_bar;
-      hipLaunchKernelGGL(lstm_bptt_chain, dim3(8 * kBpttBlocks), dim3(kRecThreads), 0, s, ba, Tpad_c);
+      static const bool bptt_sc1 = getenv("RELA_R2D2_BPTT_SC1") && atoi(getenv("RELA_R2D2_BPTT_SC1")) != 0;
+      if (bptt_sc1) hipLaunchKernelGGL(lstm_bptt_chain<true>, dim3(8 * kBpttBlocks), dim3(kRecThreads), 0, s, ba, Tpad_c);
+      else hipLaunchKernelGGL(lstm_bptt_chain<false>, dim3(8 * kBpttBlocks), dim3(kRecThreads), 0, s, ba, Tpad_c);
     } else if (sc1_handoff()) hipLaunchKernelGGL(lstm_bptt_persist<true>, dim3(kBpttBlocks * rsplit), dim3(kRecThreads), 0, s, ba);
     else hipLaunchKernelGGL(lstm_bptt_persist<false>, dim3(kBpttBlocks * rsplit), dim3(kRecThreads), 0, s, ba);
   } else
