@@ -24,16 +24,19 @@ One STEP = what the reference does per env-step of every actor thread plus one l
       -> clip 40 -> RMSprop -> update_priority, hand-written HIP (csrc/learner.hip; RELA_BENCH_LEARNER=torch
       runs PyTorch autograd instead); actor weights re-published every 20 steps, target net every 2,500.
 
-Precision of the actor's trunk forwards: `--precision bf16x2` (default) runs them on split-bf16 MFMA (every operand
-as bf16 hi + lo, f32 accumulation, conv1 -> conv2 fused through LDS; Q within 2e-6 of the f32 path, DESIGN 4.3b);
-`--precision f32` is the exact f32-MFMA parity mode.  The learner step computes in f32 in both.
+Arithmetic: `--precision f32` (the default since round 4) is the reference's arithmetic -- exact f32 MFMA for the actors'
+forwards and the whole learner step -- and is what `value` reports; `--precision bf16x2` is the fast mode (split-bf16
+MFMA: every operand as bf16 hi + lo, f32 accumulation, conv1 on the int8 matrix cores fused with conv2 through LDS;
+|dQ| < 2e-5 max|Q| against the f32 path).  Either way ONE run times four regions of the same K steps:
+f32_mode, strict (f32 AND all 4 forwards of the reference), fast_mode, fast_no_reuse.
 
-Prints ONE JSON line (rank 0).  `value` = env-steps/s summed over ranks.  Extra keys carry the
-learner rate, the live roofline of the dominant kernel (HIP events around the heavy forward kernels
-inside the timed region; the full per-kernel table comes from an untimed pass), the HBM-side roofline
-of the replay sample path and insert, three more timed regions of the same K steps -- `no_reuse` (all 4 forwards
-of the reference per tick), `reuse_next_only` (3) and `f32_mode` (actor nets in the f32 mode) -- and the CPU baseline (the
-reference's own CPU-thread actor path from oracle/_ref when present, else the oracle's plain-C port).
+Output (rank 0): ONE compact JSON line on stdout (<= 1,900 characters: the driver keeps the last 2,000 of stdout) with the
+contract's keys, `roofline` (live HIP events around the dominant forward kernel inside the timed region, both the
+algorithmic and the issued-MFMA fraction where they differ, the sampled shader clock), `cpu_baseline` (the reference's
+own CPU-thread actor path from oracle/_ref, pinned to the cgroup's CPU share) and `summary` (the four regions and the
+threaded leg through rela.Context); the full record -- per-kernel table, every region's repeats and rooflines, the HBM
+rooflines of the replay sample path and insert -- goes to gpurun_out/bench_detail_<tag>.json and to stderr.
+`python bench.py --gpus N` without a launcher spawns its N ranks itself (before any GPU call).
 `--algo r2d2` is the second line: config C4's per-GPU shape with the HIP R2D2 learner.
 """
 import argparse
@@ -90,6 +93,180 @@ def generate_eps(base_eps, alpha, num_actor):
     if num_actor == 1:
         return [base_eps]
     return [base_eps ** (1 + i / (num_actor - 1) * alpha) for i in range(num_actor)]
+
+
+def host_cores():
+    """CPUs this process may really use: the scheduler affinity capped by the cgroup quota (`cpu.max` of cgroup v2 or
+    cfs_quota / cfs_period of v1).  -> (cores, {"affinity": n, "cgroup_quota": q or None})"""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    cores = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    return cores, {"affinity": aff, "cgroup_quota": quota}
+
+
+def pin_to_cores(n):
+    """-> preexec_fn that pins a CHILD process (it never touches the GPU) to the first n CPUs of this process's affinity
+    set, so that `cpu_baseline.cores` is what its threads really ran on"""
+    cpus = sorted(os.sched_getaffinity(0))[:n]
+
+    def fn():
+        os.sched_setaffinity(0, cpus)
+    return fn
+
+
+class ClockSampler:
+    """Samples the GPU's shader clock and socket power from sysfs (hwmon freq1_input / power1_average, else the starred
+    level of pp_dpm_sclk) on a background thread while a timed region runs: the same kernel takes 156-204 us on
+    different boxes of the pool, and without the sustained clock two rounds' lines cannot be compared.  Best effort:
+    summary() is {} when the files are not readable."""
+
+    def __init__(self, pci_bus_id=None, period=0.02):
+        import glob
+        import threading
+
+        self.freq_file = self.dpm_file = self.power_file = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        if pci_bus_id:
+            want = [c for c in cards if os.path.basename(os.path.realpath(c)).lower() == pci_bus_id.lower()]
+            cards = want or cards
+        for c in cards:
+            f = sorted(glob.glob(os.path.join(c, "hwmon", "hwmon*", "freq1_input")))
+            pw = sorted(glob.glob(os.path.join(c, "hwmon", "hwmon*", "power1_average"))
+                        + glob.glob(os.path.join(c, "hwmon", "hwmon*", "power1_input")))
+            dpm = os.path.join(c, "pp_dpm_sclk")
+            if f or os.path.exists(dpm):
+                self.freq_file = f[0] if f else None
+                self.dpm_file = dpm if os.path.exists(dpm) else None
+                self.power_file = pw[0] if pw else None
+                break
+        self.period, self.mhz, self.watts = period, [], []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        try:
+            if self.freq_file:
+                self.mhz.append(int(open(self.freq_file).read()) / 1e6)
+            elif self.dpm_file:
+                for ln in open(self.dpm_file).read().splitlines():
+                    if ln.rstrip().endswith("*"):
+                        self.mhz.append(float(ln.split(":")[1].strip().split("M")[0]))
+            if self.power_file:
+                self.watts.append(int(open(self.power_file).read()) / 1e6)
+        except (OSError, ValueError, IndexError):
+            pass
+
+    def _run(self):
+        while not self._stop.is_set():
+            self._read()
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        if self.freq_file or self.dpm_file:
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._th.is_alive():
+            self._th.join()
+
+    def summary(self):
+        out = {}
+        if self.mhz:
+            out["sclk_mhz"] = round(float(np.median(self.mhz)), 0)
+            out["sclk_mhz_min_max"] = [round(min(self.mhz)), round(max(self.mhz))]
+        if self.watts:
+            out["power_w"] = round(float(np.median(self.watts)), 0)
+        return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks as fresh child
+    processes of THIS process, which has not touched the GPU (no torch.cuda call yet, nothing re-executes a GPU process),
+    hand them RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would, and exit with the worst code.
+    Rank 0 prints the JSON line on the inherited stdout."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RELA_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0:
+                    rc = rc or code
+                    for q in procs:  # one rank died: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            p.kill()
+    return rc
+
+
+LINE_BUDGET = 1900  # the driver stores the last 2,000 characters of stdout: the whole JSON line must fit
+
+
+def rnd(x, sig=5):
+    """floats to `sig` significant digits (keeps the JSON line short); passes everything else through"""
+    if isinstance(x, float):
+        return float("%.*g" % (sig, x))
+    if isinstance(x, dict):
+        return {k: rnd(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [rnd(v, sig) for v in x]
+    return x
+
+
+def emit(line, detail, tag):
+    """Prints the ONE compact JSON line (rank 0) and keeps the long record next to it: the driver stores only the last
+    2,000 characters of stdout, so every number that must be seen goes into the compact line (<= LINE_BUDGET
+    characters, optional keys dropped from the end of `optional` until it fits) and the full record -- per-kernel
+    table, every region's repeats, notes -- goes to gpurun_out/bench_detail_<tag>.json and to stderr."""
+    path = None
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        path = os.path.join(d, "bench_detail_%s.json" % tag)
+        with open(path, "w") as f:
+            json.dump(detail, f, indent=1)
+        line["detail"] = os.path.relpath(path, ROOT)
+    except OSError:
+        pass
+    print(json.dumps(detail), file=sys.stderr, flush=True)
+    line = rnd(line)
+    for k in ("detail", "clock", "grad_steps_per_s", "train_samples_per_s"):  # dropped in this order if it ever gets too long
+        if len(json.dumps(line)) <= LINE_BUDGET:
+            break
+        line.pop(k, None)
+    s = json.dumps(line)
+    assert len(s) <= LINE_BUDGET, "bench line is %d characters: the driver would cut it" % len(s)
+    print(s, flush=True)
+    return s
 
 
 # rela_prof label -> substring of the HIP kernel name in the rocprofv3 CSVs
@@ -151,7 +328,8 @@ def threaded_leg(seconds=2.0, epochs=2, threads=64, games=100):
     return {"metric": "env-steps/s = d(sum of DQNActor.num_act())/dt through rela.Context / BasicThreadLoop / DQNActor "
                       "(pyrela/benchmark.py:73-109), host envs + H2D upload included",
             "without_sampler": without, "with_sampler": with_, "unit": "env-steps/s", "threads": threads,
-            "games_per_thread": games, "host_cores_visible": len(os.sched_getaffinity(0)), "window_s": seconds,
+            "games_per_thread": games, "host_cores": host_cores()[0], "host_cores_source": host_cores()[1],
+            "window_s": seconds,
             "windows": epochs,
             "sampler": "unthrottled B=512 sample + update_priority loop on the Python thread", "wall_s": time.time() - t0,
             "note": "bounded sample of the reference's 6 x 30 s protocol; mean of the last half of the windows"}
@@ -168,13 +346,16 @@ def cpu_baseline_reference():
 
     if not glob.glob(os.path.join(ROOT, "oracle", "_ref", "rela*.so")):
         return None
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    # cores = the scheduler affinity capped by the cgroup's CPU quota (a box shows 256 CPUs and grants 16); the child is
+    # PINNED to that many CPUs, so the label is what its threads ran on
+    cores, core_info = host_cores()
     env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
 
     def run(threads, games, seconds, warmup):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_actor_bench.py"), "--threads",
                               str(threads), "--games", str(games), "--seconds", str(seconds), "--warmup", str(warmup),
-                              "--num_action", str(NUM_ACTION)], env=env, capture_output=True, text=True, timeout=240)
+                              "--num_action", str(NUM_ACTION)], env=env, capture_output=True, text=True, timeout=240,
+                             preexec_fn=pin_to_cores(cores))
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
 
     try:
@@ -182,6 +363,7 @@ def cpu_baseline_reference():
     except Exception:  # noqa: BLE001  (any failure -> fall back to the port)
         return None
     res = {"value": rec["env_steps_per_s"], "unit": "env-steps/s", "cores": cores, "kind": "reference",
+           "cores_source": dict(core_info, pinned=True),
            "sample": "the reference's own C++ actor threads (oracle/_ref/rela, g++ -O2) with a CPU TorchScript Ape-X "
                      "agent at the headline's shape: %d threads x %d synthetic envs on %d host cores, OMP_NUM_THREADS=1, "
                      "A=%d, n=3, %.1f s window after 6 s warm-up, light B=32 sampler evicting the overflow "
@@ -196,6 +378,35 @@ def cpu_baseline_reference():
     return res
 
 
+
+def cpu_baseline_reference_r2d2():
+    """The REAL reference's R2D2 CPU-thread actor path (oracle/_ref/h6/rela*.so: the reference compiled from a scratch copy
+    with SURVEY H6's one-line torch-version fix) timed by oracle/ref_actor_bench.py --algo r2d2 in a child process pinned
+    to the box's CPU share.  Bounded shape: one thread per core x 20 envs (every env holds a window of 123 frame stacks on
+    the host; C4's 3,200 envs would need 11 GB).  None if the prebuilt module is absent or fails."""
+    import glob
+
+    if not glob.glob(os.path.join(ROOT, "oracle", "_ref", "h6", "rela*.so")):
+        return None
+    cores, core_info = host_cores()
+    env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "ref_actor_bench.py"), "--algo", "r2d2",
+                              "--threads", str(cores), "--games", "20", "--seconds", "14", "--warmup", "6",
+                              "--num_action", str(NUM_ACTION)], env=env, capture_output=True, text=True, timeout=240,
+                             preexec_fn=pin_to_cores(cores))
+        rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    except Exception as e:  # noqa: BLE001  (reported, never fatal)
+        return {"value": None, "unit": "env-steps/s", "cores": cores, "kind": "reference",
+                "sample": "failed: %s: %s" % (type(e).__name__, str(e)[:200])}
+    return {"value": rec["env_steps_per_s"], "unit": "env-steps/s", "cores": cores, "kind": "reference",
+            "cores_source": dict(core_info, pinned=True),
+            "sample": "the reference's own C++ R2D2 actor threads (oracle/_ref/h6/rela, g++ -O2, H6 fix) with a CPU "
+                      "TorchScript R2D2 agent: %d threads x %d synthetic envs on %d host cores, OMP_NUM_THREADS=1, A=%d, "
+                      "seq 80 / burn-in 40 / n 3, %.1f s window after 6 s warm-up"
+                      % (rec["threads"], rec["games"], cores, rec["num_action"], rec["seconds"])}
+
+
 def cpu_baseline(budget_s=15.0):
     """The oracle (plain-C port of the same path) timed on this box's host cores: one actor tick
     (act + n-step + TD priority + replay insert) over a bounded number of envs."""
@@ -208,7 +419,7 @@ def cpu_baseline(budget_s=15.0):
     subprocess.run(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-ffp-contract=off", "-shared", "-o", so] + srcs
                    + ["-lm", "-lpthread"], check=True)
     lib = C.CDLL(so)
-    cores = min(len(os.sched_getaffinity(0)), 16)  # the GPU box's CPU share for one GPU
+    cores = host_cores()[0]  # affinity capped by the cgroup quota: the GPU box's CPU share for one GPU
     lib.oracle_set_threads.argtypes = [C.c_int]
     lib.oracle_set_threads(cores)
     A = NUM_ACTION
@@ -401,24 +612,65 @@ def bench_r2d2(args, world, rank, device):
     for _ in range(args.warmup):
         one_step()
     sync_all()
-    capi.lib.rela_prof_set_filter(b"lstm_gates_mfma,lstm_gates_x_bf16,conv1_bf16x3,conv2_mfma,conv3_mfma")
-    capi.lib.rela_prof_enable(1)
-    add0 = replay.num_add()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    sync_all()
-    dt = time.perf_counter() - t0
-    capi.lib.rela_prof_enable(0)
-    adds = replay.num_add() - add0
-    if world > 1:
-        t = torch.tensor([dt, float(adds)], device=device, dtype=torch.float64)
-        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
-        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
-        dt, adds = float(t[0]), float(t[1])
     buf = C.create_string_buffer(1 << 16)
-    capi.check(capi.lib.rela_prof_summary_json(buf, len(buf)), "rela_prof_summary_json")
-    prof = json.loads(buf.value.decode())
+
+    def prof_summary():
+        capi.check(capi.lib.rela_prof_summary_json(buf, len(buf)), "rela_prof_summary_json")
+        return json.loads(buf.value.decode())
+
+    cur_prec = [args.precision]
+
+    def set_all_precision(mode):
+        if mode == cur_prec[0]:  # (setting a mode bumps the nets' weight version: memoised forwards would be recomputed)
+            return
+        cur_prec[0] = mode
+        online.set_precision(mode)
+        target.set_precision(mode)
+        learner.set_precision(mode)
+
+    try:
+        pr = torch.cuda.get_device_properties(torch.device(device))
+        pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:  # noqa: BLE001
+        pci = None
+
+    def bracketed(k):
+        """EXACTLY k steps between barrier + synchronize on both sides; MAX over ranks; -> seconds"""
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            one_step()
+        sync_all()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    def timed_region(precision, reuse, settle_steps):
+        set_all_precision(precision)
+        engine.set_reuse(reuse)
+        for _ in range(settle_steps):
+            one_step()
+        sync_all()
+        capi.lib.rela_prof_set_filter(b"lstm_gates_mfma,lstm_gates_x_bf16,conv1_bf16x3,conv2_mfma,conv3_mfma")
+        capi.lib.rela_prof_enable(1)
+        add0 = replay.num_add()
+        with ClockSampler(pci) as clk:
+            ms = [bracketed(args.steps) / args.steps * 1e3 for _ in range(args.repeats)]
+        capi.lib.rela_prof_enable(0)
+        adds = replay.num_add() - add0
+        if world > 1:
+            a = torch.tensor([float(adds)], device=device, dtype=torch.float64)
+            dist.all_reduce(a, op=dist.ReduceOp.SUM)
+            adds = float(a.item())
+        med = float(np.median(ms))
+        return {"precision": precision, "reuse": reuse, "ms": ms, "ms_per_step": med, "prof": prof_summary(),
+                "adds_per_s": adds / (sum(ms) * 1e-3 * args.steps), "clock": clk.summary(),
+                "env_steps_per_s": R2_ROWS * world / (med * 1e-3)}
+
+    head = timed_region(args.precision, 1, 0)
     capi.lib.rela_prof_set_filter(None)
     capi.lib.rela_prof_enable(1)
     k_all = max(5, args.steps // 10)
@@ -426,35 +678,57 @@ def bench_r2d2(args, world, rank, device):
         one_step()
     sync_all()
     capi.lib.rela_prof_enable(0)
-    capi.check(capi.lib.rela_prof_summary_json(buf, len(buf)), "rela_prof_summary_json")
-    prof_all = json.loads(buf.value.decode())
+    prof_all = prof_summary()
+    # further regions of the same run, as in the Ape-X line: the reference's work (all forwards recomputed) in the
+    # headline's arithmetic, and the other arithmetic with the forwards memoised
+    other = "bf16x2" if args.precision == "f32" else "f32"
+    name_of = {("f32", 1): "f32_mode", ("f32", 0): "strict", ("bf16x2", 1): "fast_mode", ("bf16x2", 0): "fast_no_reuse"}
+    regions = {name_of[(args.precision, 1)]: head}
+    settle = 2 * (MULTI_STEP + 1)
+    regions[name_of[(args.precision, 0)]] = timed_region(args.precision, 0, settle)
+    regions[name_of[(other, 1)]] = timed_region(other, 1, settle)
+    set_all_precision(args.precision)
+    engine.set_reuse(1)
     st = replay.debug_state()
     assert st["dev_error"] == 0
     learner.check()  # raises if a grid barrier of the persistent recurrent kernels ever gave up (updates were skipped)
-    if rank == 0:
+
+    def roofline_of(region):
         # the actors' gate GEMM: one f32 MFMA kernel over [x | h] (f32 mode), or (bf16x2 mode, >= 1,024 rows) the x part as a
         # split-bf16 GEMM (three bf16 MFMAs per product) followed by the f32 kernel over h only: the roofline is the x part's
+        prof = region["prof"]
         split_gates = "lstm_gates_x_bf16" in prof
         roof_name = "lstm_gates_x_bf16" if split_gates else "lstm_gates_mfma"
         rec = prof.get(roof_name, {"total_ms": 0.0, "count": 1})
         avg_ms = rec["total_ms"] / max(rec["count"], 1)
         flops = (2 * 3136 * 2048 if split_gates else FLOP_LSTM_GATES) * R2_ROWS
-        roof_peak = PEAK_BF16_MFMA_TFLOPS / 3 if split_gates else PEAK_F32_MFMA_TFLOPS
+        peak = PEAK_BF16_MFMA_TFLOPS if split_gates else PEAK_F32_MFMA_TFLOPS
         ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else None
+        traffic, src = traffic_from_profiles(roof_name)
+        roof = {"kernel": roof_name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                "frac": None if ach is None else ach / peak, "traffic": traffic, "traffic_source": src,
+                "avg_launch_ms": avg_ms, "launches": rec["count"], "algorithmic_flop_per_launch": flops,
+                "instruction": "v_mfma_f32_16x16x32_bf16 x3 (split operands)" if split_gates else "v_mfma_f32_16x16x4_f32"}
+        if split_gates and ach is not None:
+            roof["frac_issued"] = 3 * ach / peak  # three bf16 products issued per algorithmic product
+        roof.update(region["clock"])
+        return roof
+
+    if rank == 0:
+        roof = roofline_of(head)
         sample_ms = sum(v["total_ms"] for k, v in prof_all.items() if k.startswith("seq_") or k.startswith("replay_gather")
                         or k in ("replay_targets", "replay_search", "replay_pop", "replay_is_weights")) / k_all
         sample_bytes = 4 * st["safe_size"] + B_LOCAL * sum(replay.row_bytes)
         learner_ms = sum(v["total_ms"] for k, v in prof_all.items() if k.startswith("learner_")) / k_all
-        out = {
+        ms_med = head["ms_per_step"]
+        dtype = "f32" if args.precision == "f32" else (
+            "f32 results from split-bf16 MFMA (bf16 hi+lo operands, f32 accumulate): the actors' conv trunks and gate GEMM "
+            "(h, c, Q within 4e-6), the learner's trunks, LSTM GEMMs and conv gradients; recurrences, cells, heads in f32")
+        detail = {
             "metric": "env-steps/s (R2D2 Atari 84x84x4, seq 80 / burn-in 40 / n 3, actor tick + learner grad-step)",
-            "value": R2_ROWS * world * args.steps / dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else "f32 results from split-bf16 MFMA (bf16 hi+lo operands, f32 accumulate): "
-                                                           "the actors' conv trunks and gate GEMM (h, c, Q within 4e-6), the "
-                                                           "learner's target trunk, LSTM GEMMs and conv gradients (gradients "
-                                                           "within 2e-4); recurrences, cells, heads and the online trunk in f32",
-            "data": "synthetic",
+            "value": head["env_steps_per_s"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_med, "repeats": args.repeats, "ms_per_step_repeats": head["ms"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "R2D2 LSTM (BASELINE config C4's shapes), 40 threads x 80 games (3200 envs) per GPU, "
                                    "actor + learner on one MI355X, sequence replay of %d x 3.47 MB device-resident, A=18, "
                                    "seq 80 / burn-in 40 / n 3, ONE learner batch of 64 sequences per step for the whole "
@@ -463,24 +737,45 @@ def bench_r2d2(args, world, rank, device):
                        "envs_per_gpu": R2_ROWS, "replay_capacity": args.replay_cap, "learner_batch": R2_BATCH,
                        "learner_batch_per_gpu": B_LOCAL, "parallelism": "single" if world == 1 else
                        "actor-shards%d+replay-partitions+grad-allreduce" % world},
-            "grad_steps_per_s": args.steps / dt, "train_samples_per_s": args.steps * R2_BATCH / dt,
-            "buffer_add_per_s": adds / dt, "learner": "hip (csrc/learner_r2d2.hip)",
+            "grad_steps_per_s": 1e3 / ms_med, "train_samples_per_s": R2_BATCH * 1e3 / ms_med,
+            "buffer_add_per_s": head["adds_per_s"], "learner": "hip (csrc/learner_r2d2.hip)",
             "learner_kernel_ms_per_step": learner_ms,
             # R2D2 grad-step (B = 64) ~ 0.80 TFLOP algorithmic
             "learner_tflops": 0.80 * (B_LOCAL / 64.0) / (learner_ms * 1e-3) if learner_ms > 0 else None,
+            "regions": {k: {"precision": r["precision"], "reuse": r["reuse"], "ms_per_step": r["ms_per_step"],
+                            "ms_per_step_repeats": r["ms"], "env_steps_per_s": r["env_steps_per_s"],
+                            "grad_steps_per_s": 1e3 / r["ms_per_step"], "clock": r["clock"], "roofline": roofline_of(r)}
+                        for k, r in regions.items()},
             "kernels_ms_per_step": {k: v["total_ms"] / k_all for k, v in sorted(prof_all.items())},
-            "roofline": {"kernel": roof_name, "bound": "mfma", "achieved": ach, "peak": roof_peak,
-                         "unit": "TFLOP/s", "frac": None if ach is None else ach / roof_peak, "traffic": None,
-                         "avg_launch_ms": avg_ms, "launches": rec["count"], "algorithmic_flop_per_launch": flops,
-                         "instruction": "v_mfma_f32_16x16x32_bf16 x3 (split operands)" if split_gates
-                         else "v_mfma_f32_16x16x4_f32"},
+            "roofline": roof,
             "roofline_hbm": None if sample_ms <= 0 else {
                 "kernel": "rela_replay_sample (scan + time-major gather of 64 x 3.47 MB)", "bound": "hbm", "unit": "GB/s",
                 "peak": PEAK_HBM_GBS, "achieved": sample_bytes / (sample_ms * 1e-3) / 1e9,
                 "frac": sample_bytes / (sample_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                 "algorithmic_bytes_per_call": sample_bytes, "ms_per_call": sample_ms},
         }
-        print(json.dumps(out))
+        if world == 1 and not args.no_cpu_baseline:
+            replay.close()
+            torch.cuda.empty_cache()
+            detail["cpu_baseline"] = cpu_baseline_reference_r2d2()
+        line = {"metric": detail["metric"], "value": detail["value"], "unit": "env-steps/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_med, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32" if args.precision == "f32" else "f32 results from split-bf16 MFMA (16-bit significands)",
+                "data": "synthetic",
+                "config": {"workload": "R2D2 LSTM 40x80 envs/GPU (C4 shapes), seq 80 / burn-in 40 / n 3, B=64, A=18; "
+                                       "device-resident static frames", "parallelism": detail["config"]["parallelism"]},
+                "grad_steps_per_s": 1e3 / ms_med,
+                "roofline": {k: roof.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                      "avg_launch_ms", "frac_issued", "sclk_mhz") if roof.get(k) is not None
+                             or k == "traffic"}}
+        cb = detail.get("cpu_baseline")
+        if cb is not None:
+            line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                    "sample": cb["sample"][:150]}
+        line["summary"] = {k: round(r["env_steps_per_s"]) for k, r in regions.items()}
+        line["summary"]["grad_steps_per_s"] = {k: 1e3 / r["ms_per_step"] for k, r in regions.items()}
+        emit(line, detail, "r2d2_n%d" % world)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -665,7 +960,15 @@ def bench_reference_layout(args, world, rank, device, rehearsal):
                                              "(partition size) + MAX (IS-weight maximum) among the actor ranks; 2 broadcasts "
                                              "of 6.8 MB + 1 command word every %d steps" % cycle},
         }
-        print(json.dumps(out))
+        line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "data", "grad_steps_per_s")}
+        line["dtype"] = "f32" if args.precision == "f32" else "f32 results from split-bf16 MFMA (16-bit significands)"
+        line["config"] = {"workload": "Ape-X, reference layout: 1 learner GPU (B=512) + %d actor GPUs x 6400 envs, replay "
+                                      "partitions of 2^20/%d; device-resident static frames" % (G, G),
+                          "layout": "reference", "parallelism": out["config"]["parallelism"]}
+        line["comm"] = {"backend": out["comm"]["backend"], "rccl_ranks": out["comm"]["rccl_ranks"]}
+        line["env_steps_per_s_repeats"] = [round(e) for e in envs]
+        emit(line, out, "apex_reference_layout_n%d" % world)
     dist.barrier(group=ctrl)
     dist.destroy_process_group()
 
@@ -685,10 +988,12 @@ def main():
                     help="frame-stack de-duplication in the replay (SURVEY 8f-3): stack = 28,224 B per env-step, plane = "
                          "7,056 B (the frames of this bench are static, so only the byte traffic is representative); "
                          "default: s and next_s stored in full (56,448 B), as in round 1's headline")
-    ap.add_argument("--precision", default="bf16x2", choices=["f32", "bf16x2"],
-                    help="arithmetic of the actors' conv2 / conv3 / fc: bf16x2 = split-bf16 MFMA (hi + lo bf16 operands, "
-                         "three products, f32 accumulation; Q within 1e-6 of the f32 path in tests/test_ffnet_gpu.py, stated "
-                         "tolerance 1e-4), f32 = exact f32 MFMA (the parity mode, round 1's headline)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x2"],
+                    help="arithmetic of the headline region (`value`): f32 (default) = the reference's arithmetic, exact "
+                         "f32 MFMA for actors and learner; bf16x2 = the fast mode, split-bf16 MFMA (hi + lo bf16 operands, "
+                         "three products, f32 accumulation; |dQ| < 2e-5 max|Q| against the f32 path, tests/test_ffnet_gpu.py). "
+                         "Whichever is chosen, the other one is timed as a further region of the same run "
+                         "(`summary.fast_mode` / `summary.f32_mode`)")
     ap.add_argument("--layout", default="replicated", choices=["replicated", "reference"],
                     help="N > 1: replicated (default) = actors + replay partition + learner replica on every rank, gradient "
                          "all-reduce; reference = the reference's own layout, ONE learner rank + N - 1 actor-only ranks "
@@ -699,6 +1004,9 @@ def main():
     if args.replay_cap is None:
         args.replay_cap = REPLAY_CAP if args.algo == "apex" else R2_REPLAY_CAP
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: this process becomes the launcher (it has made no GPU call) and its children the ranks
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -941,179 +1249,193 @@ def main():
             dt = float(t.item())
         return dt
 
-    def region(settle):
-        """a timed region: `settle` untimed steps, then the K-step bracket repeated args.repeats times (with
-        --steps 20 one bracket is 30 ms: too short to be a measurement on its own) -> ms per step of every repeat"""
-        run_steps(settle)
-        return [bracketed(args.steps) / args.steps * 1e3 for _ in range(args.repeats)]
-
-    median = lambda xs: float(np.median(xs))
-
     run_steps(args.warmup)
     sync_all()
     # Live roofline: HIP events around the four heavy forward kernels only (the dominant kernel is one
     # of them); timing all ~100 kernels of a step costs 0.37 ms of the step itself, so the full
     # per-kernel table comes from a short untimed pass after the timed region.
-    capi.lib.rela_prof_set_filter(b"conv12_fused,conv1_bf16x3,conv2_mfma,conv3_mfma,fc_mfma")
-    capi.lib.rela_prof_enable(0 if os.environ.get("RELA_BENCH_NOPROF") == "1" else 1)
-    add0 = replay.num_add()
-    ms_head = region(0)
-    capi.lib.rela_prof_enable(0)
-    adds = replay.num_add() - add0
-    dt_total = sum(ms_head) * 1e-3 * args.steps
-    if world > 1:
-        a = torch.tensor([adds], device=device, dtype=torch.float64)
-        dist.all_reduce(a, op=dist.ReduceOp.SUM)
-        adds = float(a.item())
-    n_head_steps = args.steps * args.repeats
-
+    ROOF_FILTER = b"conv12_fused,conv1_bf16x3,conv2_mfma,conv3_mfma,fc_mfma"
+    NOPROF = os.environ.get("RELA_BENCH_NOPROF") == "1"
     buf = C.create_string_buffer(1 << 16)
-    capi.check(capi.lib.rela_prof_summary_json(buf, len(buf)), "rela_prof_summary_json")
-    prof = json.loads(buf.value.decode())
-    # untimed: the same step with every kernel timed, for the kernels_ms_per_step table
-    capi.lib.rela_prof_set_filter(None)
-    capi.lib.rela_prof_enable(1)
-    k_all = max(5, min(100, n_head_steps // 3))
-    run_steps(k_all)
-    sync_all()
-    capi.lib.rela_prof_enable(0)
-    capi.check(capi.lib.rela_prof_summary_json(buf, len(buf)), "rela_prof_summary_json")
-    prof_all = json.loads(buf.value.decode())
 
-    # More timed regions of the same K steps x repeats, bracketed the same way, so that the line carries the
-    # reference-style accountings next to the headline:
-    #   reuse_next_only  only the same-tick reuse: 3 trunk forwards per env-step (rounds 1-2's headline accounting)
-    #   no_reuse         reuse off: the reference's 4 trunk forwards per env-step (SURVEY 8d's unit: 74.8 MFLOP)
-    #   f32_mode         actor nets and learner in the exact f32 mode, reuse on
-    #   strict           BOTH: the reference's arithmetic (f32) and the reference's work (4 forwards)
+    def prof_summary():
+        capi.check(capi.lib.rela_prof_summary_json(buf, len(buf)), "rela_prof_summary_json")
+        return json.loads(buf.value.decode())
+
+    cur_prec = [args.precision]
+
     def set_all_precision(mode):
+        if mode == cur_prec[0]:  # (setting a mode bumps the nets' weight version: memoised forwards would be recomputed)
+            return
+        cur_prec[0] = mode
         online.set_precision(mode)
         target.set_precision(mode)
         if hip_learner is not None:
             hip_learner.set_precision(mode)
 
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        pci = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:  # noqa: BLE001
+        pci = None
+
     settle = min(args.warmup, 3) + MULTI_STEP + 1  # (+ n + 1 ticks so every history slot is of the region's mode)
-    ms_4fwd = ms_3fwd = ms_f32 = ms_strict = None
+
+    def timed_region(precision, reuse, settle_steps):
+        """One timed region: `settle_steps` untimed steps in the region's mode, then the K-step bracket (barrier +
+        synchronize on both sides, MAX over ranks) repeated args.repeats times back to back, with live HIP events
+        around the heavy forward kernels and the shader clock sampled next to it."""
+        set_all_precision(precision)
+        engine.set_reuse(reuse)
+        run_steps(settle_steps)
+        sync_all()
+        capi.lib.rela_prof_set_filter(ROOF_FILTER)
+        capi.lib.rela_prof_enable(0 if NOPROF else 1)
+        add0 = replay.num_add()
+        with ClockSampler(pci) as clk:
+            ms = [bracketed(args.steps) / args.steps * 1e3 for _ in range(args.repeats)]
+        capi.lib.rela_prof_enable(0)
+        adds = replay.num_add() - add0
+        if world > 1:
+            a = torch.tensor([adds], device=device, dtype=torch.float64)
+            dist.all_reduce(a, op=dist.ReduceOp.SUM)
+            adds = float(a.item())
+        prof = prof_summary()
+        fwd_cnt = prof.get("conv12_fused", prof.get("conv1_bf16x3", {"count": 0}))["count"]
+        return {"precision": precision, "reuse": reuse, "ms": ms, "ms_per_step": float(np.median(ms)), "prof": prof,
+                "adds_per_s": adds / (sum(ms) * 1e-3 * args.steps), "clock": clk.summary(),
+                "env_steps_per_s": ROWS * world / (float(np.median(ms)) * 1e-3),
+                "forwards_per_tick": fwd_cnt / (args.steps * args.repeats) if ONLY != "learner" else 0}
+
+    head = timed_region(args.precision, 1, 0)
+
+    # untimed: the same step with every kernel timed, for the kernels_ms_per_step table
+    capi.lib.rela_prof_set_filter(None)
+    capi.lib.rela_prof_enable(1)
+    k_all = max(5, min(100, args.steps * args.repeats // 3))
+    run_steps(k_all)
+    sync_all()
+    capi.lib.rela_prof_enable(0)
+    prof_all = prof_summary()
+
+    # More timed regions of the same K steps x repeats, bracketed the same way, so that ONE run carries the four
+    # accountings (the headline is f32_mode or fast_mode, whichever --precision names):
+    #   f32_mode        the reference's arithmetic (exact f32 MFMA for actors and learner), act()'s forwards memoised
+    #   strict          the reference's arithmetic AND the reference's work: f32 + all 4 trunk forwards per env-step
+    #   fast_mode       split-bf16 MFMA (stated tolerance), forwards memoised
+    #   fast_no_reuse   split-bf16 MFMA, 4 forwards (SURVEY 8d's unit of work)
+    other = "bf16x2" if args.precision == "f32" else "f32"
+    name_of = {("f32", 1): "f32_mode", ("f32", 0): "strict", ("bf16x2", 1): "fast_mode", ("bf16x2", 0): "fast_no_reuse"}
+    regions = {name_of[(args.precision, 1)]: head}
     if not ONLY:
-        engine.set_reuse(0)
-        ms_4fwd = region(settle)
-        engine.set_reuse(2)
-        ms_3fwd = region(settle)
+        for prec, reuse in ((args.precision, 0), (other, 1), (other, 0)):
+            regions[name_of[(prec, reuse)]] = timed_region(prec, reuse, settle)
+        set_all_precision(args.precision)
         engine.set_reuse(1)
-        if args.precision == "bf16x2":
-            set_all_precision("f32")
-            ms_f32 = region(settle)
-            engine.set_reuse(0)
-            ms_strict = region(settle)
-            engine.set_reuse(1)
-            set_all_precision("bf16x2")
-        else:
-            ms_strict = ms_4fwd
     st = replay.debug_state()
     assert st["dev_error"] == 0, "replay reported device error %d" % st["dev_error"]
 
-    if rank == 0:
-        ms_med = median(ms_head)
-        # dominant kernel = largest total time among the timed hot-path kernels
-        if not prof:  # RELA_BENCH_NOPROF=1 diagnosis run: no per-kernel events were recorded
-            prof = {"(profiling off)": {"total_ms": 0.0, "count": 1}}
+    def roofline_of(region):
+        """Both rooflines of the region's dominant kernel (largest total time among the timed forward kernels);
+        `bound` = the one it sits closer to.  MFMA: algorithmic FLOPs (2 * MACs) per launch over (i) the dense
+        peak of the instruction class the kernel issues -- v_mfma_f32_16x16x4_f32 157.3 TFLOP/s, bf16 2,500 TFLOP/s --
+        = `frac_algorithmic`, and for the split-bf16 kernels also over (ii) that peak divided by the bf16 products
+        ISSUED per algorithmic product = `frac_issued` (MFMA issue utilisation, what PMC SQ_VALU_MFMA_BUSY sees).
+        HBM: algorithmic bytes (input + output tensors, 4 B per activation) over 8 TB/s."""
+        prof = region["prof"] or {"(profiling off)": {"total_ms": 0.0, "count": 1}}
         name, rec = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
-        avg_ms = rec["total_ms"] / rec["count"]
-        if name in FLOP:
-            # Both rooflines of the dominant kernel; `bound` = the one it sits closer to.  MFMA: algorithmic FLOPs
-            # (SURVEY 8a: 2 * MACs) over the dense peak of the instruction the kernel issues -- f32 mode:
-            # v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s; bf16x2 mode: v_mfma_f32_16x16x32_bf16, 2,500 TFLOP/s divided by
-            # the bf16 products issued per algorithmic product.  HBM: algorithmic bytes (input + output tensors,
-            # 4 B per activation) over 8 TB/s.
+        avg_ms = rec["total_ms"] / max(rec["count"], 1)
+        roof = {"kernel": name, "bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None, "avg_launch_ms": avg_ms, "launches": rec["count"]}
+        if name in FLOP and avg_ms > 0:
+            fast = region["precision"] == "bf16x2"
             flops = FLOP[name] * ROWS
             # bf16 MFMA products issued per algorithmic product: conv1 multiplies exact u8 inputs by weights split
-            # in 3 bf16 pieces (f32 mode: exact) or 2 (bf16x2 mode); the other layers 3 in bf16x2 mode
-            fast = args.precision == "bf16x2"
+            # in 3 bf16 pieces (f32 mode: exact) or 2 (bf16x2 mode); the other layers 3 in bf16x2 mode, f32 MFMA else
             products = (2 if fast else 3) if name == "conv1_bf16x3" else (3 if fast else 0)
             conv1_i8 = os.environ.get("RELA_CONV12") != "bf16"
             if name == "conv12_fused":
                 # conv2: 3 bf16 products per product.  conv1: 3 int8 digit products (csrc/ffnet.hip: conv12_i8) on
-                # v_mfma_i32_16x16x64_i8, which runs at twice the bf16 rate = 1.5 bf16-MFMA-equivalents; with
-                # RELA_CONV12=bf16 the half-frame kernel's 2 bf16 products
+                # v_mfma_i32_16x16x64_i8, which runs at twice the bf16 rate = 1.5 bf16-MFMA-equivalents
                 f1, f2 = FLOP["conv1_bf16x3"], FLOP["conv2_mfma"]
                 products = ((1.5 if conv1_i8 else 2) * f1 + 3 * f2) / (f1 + f2)
-            peak_mfma = PEAK_BF16_MFMA_TFLOPS / products if products else PEAK_F32_MFMA_TFLOPS
-            nbytes = BYTES_PER_SAMPLE[name] * ROWS
-            mfma = {"achieved": flops / (avg_ms * 1e-3) / 1e12, "peak": peak_mfma, "unit": "TFLOP/s",
-                    "algorithmic_flop_per_launch": flops,
+            peak_class = PEAK_BF16_MFMA_TFLOPS if products else PEAK_F32_MFMA_TFLOPS
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            mfma = {"achieved": ach, "peak": peak_class, "unit": "TFLOP/s", "frac_algorithmic": ach / peak_class,
+                    "frac_issued": ach * products / peak_class if products else ach / peak_class,
+                    "products_per_product": products or 1, "algorithmic_flop_per_launch": flops,
                     "instruction": ("v_mfma_f32_16x16x32_bf16 x%.3g (split operands%s)" % (
                         products, "; conv1: three int8 digit products on v_mfma_i32_16x16x64_i8, counted as 1.5 bf16 products"
                         if name == "conv12_fused" and conv1_i8 else "")) if products else "v_mfma_f32_16x16x4_f32"}
-            mfma["frac"] = mfma["achieved"] / peak_mfma
+            nbytes = BYTES_PER_SAMPLE[name] * ROWS
             hbm = {"achieved": nbytes / (avg_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "algorithmic_bytes_per_launch": nbytes}
             hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
-            pick = mfma if mfma["frac"] >= hbm["frac"] else hbm
-            roof = {"kernel": name, "bound": "mfma" if pick is mfma else "hbm", "achieved": pick["achieved"],
-                    "peak": pick["peak"], "unit": pick["unit"], "traffic": None, "avg_launch_ms": avg_ms,
-                    "launches": rec["count"], "mfma": mfma, "hbm": hbm}
-        else:
-            roof = {"kernel": name, "bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "traffic": None, "avg_launch_ms": avg_ms, "launches": rec["count"]}
-        if roof["achieved"] is not None:
-            roof["frac"] = roof["achieved"] / roof["peak"]
+            if mfma["frac_algorithmic"] >= hbm["frac"]:
+                roof.update(bound="mfma", achieved=ach, peak=peak_class, unit="TFLOP/s", frac=mfma["frac_algorithmic"])
+            else:
+                roof.update(bound="hbm", achieved=hbm["achieved"], frac=hbm["frac"])
+            roof["mfma"], roof["hbm"] = mfma, hbm
         roof["traffic"], roof["traffic_source"] = traffic_from_profiles(name)
+        roof.update(region["clock"])
+        return roof
+
+    if rank == 0:
+        ms_med = head["ms_per_step"]
+        roof = roofline_of(head)
+        prof = head["prof"]
         fwd_ms = sum(prof[k]["total_ms"] for k in FLOP if k in prof)
         fwd_cnt = prof.get("conv12_fused", prof.get("conv1_bf16x3", {"count": 1}))["count"]
-
-        def sub_region(ms, forwards, note):
-            return None if ms is None else {"forwards_per_tick": forwards, "steps": args.steps, "repeats": len(ms),
-                                            "ms_per_step": median(ms), "ms_per_step_repeats": ms,
-                                            "env_steps_per_s": ROWS * world / (median(ms) * 1e-3), "note": note}
         scan_ms = sum(v["total_ms"] for k, v in prof_all.items() if k.startswith("seq_") or k in (
             "replay_targets", "replay_search", "replay_pop", "replay_is_weights"))
-        out = {
+        notes = {"f32_mode": "actor nets and learner in the exact f32 MFMA mode (the reference's arithmetic); act()'s forwards "
+                             "memoised (bit-identical to recomputing them, tests/test_agent_ops_gpu.py)",
+                 "strict": "the reference's arithmetic AND the reference's work: exact f32 MFMA mode for actors and learner, "
+                           "all 4 trunk forwards per env-step (SURVEY 8d: 74.8 MFLOP)",
+                 "fast_mode": "split-bf16 MFMA (|dQ| < 2e-5 max|Q|, tests/test_ffnet_gpu.py), forwards memoised",
+                 "fast_no_reuse": "split-bf16 MFMA, all 4 trunk forwards per env-step"}
+        detail_regions = {k: {"precision": r["precision"], "forwards_per_tick": r["forwards_per_tick"], "steps": args.steps,
+                              "repeats": len(r["ms"]), "ms_per_step": r["ms_per_step"], "ms_per_step_repeats": r["ms"],
+                              "env_steps_per_s": r["env_steps_per_s"], "grad_steps_per_s": 1e3 / r["ms_per_step"],
+                              "clock": r["clock"], "roofline": roofline_of(r), "note": notes[k]}
+                          for k, r in regions.items()}
+        workload = ("Ape-X DQN, 80 threads x 80 games (6400 envs) per GPU, actor+learner on one MI355X, replay 2^20 per GPU "
+                    "device-resident, A=18, n=3, ONE learner batch of 512 per step for the whole job (B/G sampled per replay "
+                    "partition); device-resident static frames: no env stepping and no H2D inside the timed region")
+        dtype = "f32" if args.precision == "f32" else DTYPE_NOTE
+        comm = None if world == 1 else {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size()
+                                        if dist.get_backend() == "nccl" else 0, "ranks": dist.get_world_size(),
+                                        "collectives_per_step": "all-reduce SUM of the flat 6.8 MB gradient buffer; "
+                                                                "IS weights: SUM of the partition size + MAX of the weight maximum"}
+        detail = {
             "metric": "env-steps/s (Ape-X Atari 84x84x4, actor tick + learner grad-step)",
-            "value": ROWS * world / (ms_med * 1e-3), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_med, "repeats": args.repeats, "ms_per_step_repeats": ms_head,
+            "value": head["env_steps_per_s"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_med, "repeats": args.repeats, "ms_per_step_repeats": head["ms"],
             "ms_per_step_note": "the K-step region (barrier + synchronize on both sides, MAX over ranks) is timed "
                                 "`repeats` times back to back; ms_per_step and value are the MEDIAN repeat",
-            "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else DTYPE_NOTE,
-            "data": "synthetic",
-            "config": {"workload": "Ape-X DQN, 80 threads x 80 games (6400 envs) per GPU, actor+learner on one "
-                                   "MI355X, replay 2^20 per GPU device-resident, A=18, n=3, ONE learner batch of 512 per "
-                                   "step for the whole job (B/G sampled per replay partition); device-resident static "
-                                   "frames: no env stepping and no H2D inside the timed region",
-                       "envs_per_gpu": ROWS, "replay_capacity": args.replay_cap, "learner_batch": BATCH,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": workload, "envs_per_gpu": ROWS, "replay_capacity": args.replay_cap, "learner_batch": BATCH,
                        "learner_batch_per_gpu": B_LOCAL, "replay_dedup": args.dedup, "actor_precision": args.precision,
                        "learner_precision": LEARNER_PRECISION_NOTE[args.precision] if hip_learner is not None
                        else "f32 (PyTorch autograd)",
                        "replay_frame_bytes_per_transition": {None: 56448, "stack": 28224, "plane": 7056}[args.dedup],
                        "parallelism": ("actor-shards%d+replay-partitions+grad-allreduce" % world) if world > 1
                        else "single"},
-            # the communicator the collectives of this run went through (None: single process, no collective)
-            "comm": None if world == 1 else {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size()
-                                             if dist.get_backend() == "nccl" else 0, "ranks": dist.get_world_size(),
-                                             "collectives_per_step": "all-reduce SUM of the flat 6.8 MB gradient buffer; "
-                                                                     "IS weights: SUM of the partition size + MAX of the weight maximum"},
+            "comm": comm,
             "grad_steps_per_s": 1e3 / ms_med, "train_samples_per_s": BATCH * 1e3 / ms_med,
-            "buffer_add_per_s": adds / dt_total,
+            "buffer_add_per_s": head["adds_per_s"],
             "learner": "hip (csrc/learner.hip)" if hip_learner is not None else "torch autograd",
             **({"diagnostic_only": ONLY} if ONLY else {}),
             # act + compute_priority's target(next_obs); online(next_obs) and online(obs) are act's own forwards
             # of this tick and of n ticks ago (same weights, same batch), reused bit-identically -> 2, else 3-4
-            "forwards_per_tick": fwd_cnt / n_head_steps if ONLY != "learner" else 0,
-            "reuse_next_only": sub_region(ms_3fwd, 3, "only the same-tick reuse (online(next_obs) = act()'s forward): 3 trunk "
-                                          "forwards per env-step, the headline's accounting in rounds 1-2"),
-            "no_reuse": sub_region(ms_4fwd, 4, "act-forward reuse off: the reference's 4 trunk forwards per env-step "
-                                   "(SURVEY 8d: 74.8 MFLOP), split-bf16 arithmetic"),
-            "f32_mode": sub_region(ms_f32, fwd_cnt / n_head_steps, "actor nets and learner in the exact f32 MFMA mode "
-                                   "(the reference's arithmetic), forwards memoised as in the headline"),
-            "strict": sub_region(ms_strict, 4, "the reference's arithmetic AND the reference's work: exact f32 MFMA mode for "
-                                 "actors and learner, all 4 trunk forwards per env-step (--precision f32 + reuse off)"),
+            "forwards_per_tick": head["forwards_per_tick"],
+            "regions": detail_regions,
             "forward_ms_per_6400": fwd_ms / max(fwd_cnt, 1),
             "forward_tflops": sum(v for k, v in FLOP.items() if k != "conv12_fused") * ROWS
             / (max(fwd_ms, 1e-9) / max(fwd_cnt, 1) * 1e-3) / 1e12,
             "replay_sample_scan_ms": scan_ms / k_all,
             "kernels_ms_per_step": {k: v["total_ms"] / k_all for k, v in sorted(prof_all.items())},
-            "kernels_ms_per_step_note": "untimed pass of %d steps with every kernel timed; the timed region times "
+            "kernels_ms_per_step_note": "untimed pass of %d steps with every kernel timed; the timed regions time "
                                         "only conv1/conv2/conv3/fc (roofline)" % k_all,
             "roofline": roof,
             # the HBM-bound side of the path.  (i) the sample call, SURVEY 8d: 4*N + B*56,448 algorithmic bytes
@@ -1137,14 +1459,52 @@ def main():
             # the drop-in's own metric; the big device buffers of this process go first (the child owns a replay too)
             replay.close()
             torch.cuda.empty_cache()
-            out["threaded"] = threaded_leg()
+            detail["threaded"] = threaded_leg()
         if world == 1 and not args.no_cpu_baseline:
             port = cpu_baseline()
             ref = cpu_baseline_reference()
-            out["cpu_baseline"] = ref if ref is not None else port
+            detail["cpu_baseline"] = ref if ref is not None else port
             if ref is not None:
-                out["cpu_baseline"]["port"] = {k: port[k] for k in ("value", "cores", "sample")}
-        print(json.dumps(out))
+                detail["cpu_baseline"]["port"] = {k: port[k] for k in ("value", "cores", "sample")}
+
+        # ---- the compact line: everything the driver must see, inside its 2,000-character tail ----
+        def short_roof(r):
+            m = r.get("mfma")
+            out = {"kernel": r["kernel"], "bound": r["bound"], "achieved": r["achieved"], "peak": r["peak"], "unit": r["unit"],
+                   "frac": r["frac"], "traffic": r["traffic"], "avg_launch_ms": r["avg_launch_ms"]}
+            if m is not None and m["products_per_product"] != 1:
+                out["frac_issued"] = m["frac_issued"]  # MFMA issue utilisation (bf16 products issued per product counted)
+            if "sclk_mhz" in r:
+                out["sclk_mhz"] = r["sclk_mhz"]
+            return out
+        summary = {k: round(r["env_steps_per_s"]) for k, r in regions.items()}
+        if "fast_mode" in regions and args.precision == "f32":
+            fr = roofline_of(regions["fast_mode"])
+            summary["fast_roofline"] = {"kernel": fr["kernel"], "frac": fr["frac"],
+                                        "frac_issued": (fr.get("mfma") or {}).get("frac_issued"),
+                                        "avg_launch_ms": fr["avg_launch_ms"]}
+        th = detail.get("threaded")
+        if th is not None:
+            summary["threaded"] = th.get("error", [round(th.get("without_sampler", 0)), round(th.get("with_sampler", 0))])
+        line = {"metric": detail["metric"], "value": detail["value"], "unit": "env-steps/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_med, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32" if args.precision == "f32" else "f32 results from split-bf16 MFMA (16-bit significands)",
+                "data": "synthetic",
+                "config": {"workload": "Ape-X DQN 80x80 envs/GPU, actor+learner on one MI355X, replay 2^20, B=512, A=18, n=3; "
+                                       "device-resident static frames", "forwards_per_tick": round(head["forwards_per_tick"], 2),
+                           "parallelism": detail["config"]["parallelism"]},
+                "grad_steps_per_s": 1e3 / ms_med, "roofline": short_roof(roof)}
+        if comm is not None:
+            line["comm"] = {"backend": comm["backend"], "rccl_ranks": comm["rccl_ranks"]}
+        cb = detail.get("cpu_baseline")
+        if cb is not None:
+            line["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                    "sample": cb["sample"][:150]}
+        if ONLY:
+            line["diagnostic_only"] = ONLY
+        line["summary"] = summary
+        emit(line, detail, "apex_n%d" % world)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

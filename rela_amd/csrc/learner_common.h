@@ -632,7 +632,7 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     p.d_out = t.d_a3, p.in = t.a2, p.part = partw;
     // (a few hundred frames: 3 x the splits = 3-4 blocks per CU instead of one; a block alone on its CU waits out
     // every chunk's load latency with two waves per SIMD)
-    static const int mul = getenv("RELA_WGRAD_SPLIT_MUL") ? atoi(getenv("RELA_WGRAD_SPLIT_MUL")) : 3;
+    static const int mul = getenv("RELA_WGRAD_SPLIT_MUL") ? std::max(1, std::min(8, atoi(getenv("RELA_WGRAD_SPLIT_MUL")))) : 3  /* clamped to what kTrunkPartFloats holds */;
     const int split3 = Bn <= 1024 ? kSplitW3 * mul : kSplitW3;
     if (t.fast && gemm_bf16x3_on()) (void)gemm3::launch_gemm<Tile3W64>(p, split3, sw, "learner_wgrad_conv3");
     else launch_gemm<TileW64>(p, split3, sw, "learner_wgrad_conv3");
@@ -665,7 +665,7 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     ProbW2 p{};
     p.M = 64, p.N = 512, p.K = Bn * 81;
     p.d_out = t.d_a2, p.in = t.a1, p.part = partw;
-    static const int mul = getenv("RELA_WGRAD_SPLIT_MUL") ? atoi(getenv("RELA_WGRAD_SPLIT_MUL")) : 3;
+    static const int mul = getenv("RELA_WGRAD_SPLIT_MUL") ? std::max(1, std::min(8, atoi(getenv("RELA_WGRAD_SPLIT_MUL")))) : 3  /* clamped to what kTrunkPartFloats holds */;
     const int split2 = Bn <= 1024 ? kSplitW2 * mul : kSplitW2;
     if (t.fast && gemm_bf16x3_on()) (void)gemm3::launch_gemm<Tile3W64>(p, split2, sw, "learner_wgrad_conv2");
     else launch_gemm<TileW64>(p, split2, sw, "learner_wgrad_conv2");

@@ -1222,22 +1222,30 @@ extern "C" int rela_r2d2_learner_create(rela_r2d2_learner** out, int num_action,
     // nothing, so check here -- blocks per CU the occupancy query admits x the CUs this process sees (a CU-masked or
     // partitioned device reports fewer) against the grids, with the query's known over-report of one block per CU
     // taken off -- and fall back to the per-step launches (split-K GEMM + cell kernel) when they would not fit.
-    int cus = 0, occ_f = 0, occ_b = 0;
+    int cus = 0;
     RELA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, lstm_rec_persist<true>, kRecThreads, 0));
-    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, lstm_bptt_persist<true>, kRecThreads, 0));
+    //  query the instantiations that can really be launched -- register use, and with it the occupancy, differs
+    // between the SC1 variants -- and take the minimum over both; the BPTT grid is checked for the row split that will
+    // be used (RELA_BPTT_ROW_SPLIT, clamped to 1..8 where it is read)
+    auto occ_of = [](auto kern_a, auto kern_b) {
+      int a = 0, b = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, kern_a, kRecThreads, 0) != hipSuccess) a = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kern_b, kRecThreads, 0) != hipSuccess) b = 0;
+      return a < b ? a : b;
+    };
+    const int occ_f = occ_of(lstm_rec_persist<true>, lstm_rec_persist<false>);
+    const int occ_b = occ_of(lstm_bptt_persist<true>, lstm_bptt_persist<false>);
+    const int occ_c = occ_of(lstm_rec_chain<true>, lstm_rec_chain<false>);
+    const int occ_d = occ_of(lstm_bptt_chain<true>, lstm_bptt_chain<false>);
     // (the query's known over-report concerns kernels near an SGPR allocation step at several blocks per CU: take one
     // block per CU off from four up; these kernels use < 80 SGPRs and need two blocks per CU at most)
-    const int64_t room_f = (int64_t)cus * (occ_f >= 4 ? occ_f - 1 : occ_f), room_b = (int64_t)cus * (occ_b >= 4 ? occ_b - 1 : occ_b);
-    int occ_c = 0;
-    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, lstm_rec_chain<false>, kRecThreads, 0));
-    int occ_d = 0;
-    RELA_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_d, lstm_bptt_chain<false>, kRecThreads, 0));
-    if ((int64_t)cus * (occ_c >= 4 ? occ_c - 1 : occ_c) < 8 * kChainBlocks || (int64_t)cus * (occ_d >= 4 ? occ_d - 1 : occ_d) < 8 * kBpttBlocks)
-      l->rec_chains_fit = false;
-    if (room_f < 2 * kRecBlocks || room_b < kBpttBlocks * kBpttRowSplit) {
+    auto room = [cus](int occ) { return (int64_t)cus * (occ >= 4 ? occ - 1 : occ); };
+    const int64_t room_f = room(occ_f), room_b = room(occ_b);
+    const int rsplit_env = getenv("RELA_BPTT_ROW_SPLIT") ? std::max(1, std::min(8, atoi(getenv("RELA_BPTT_ROW_SPLIT")))) : kBpttRowSplit;
+    if (room(occ_c) < 8 * kChainBlocks || room(occ_d) < 8 * kBpttBlocks) l->rec_chains_fit = false;
+    if (room_f < 2 * kRecBlocks || room_b < (int64_t)kBpttBlocks * rsplit_env) {
       fprintf(stderr, "rela_r2d2_learner_create: %d CUs x (%d, %d) resident blocks cannot hold the persistent recurrent "
-                      "grids (%d, %d): using the per-step launches\n", cus, occ_f, occ_b, 2 * kRecBlocks, kBpttBlocks * kBpttRowSplit);
+                      "grids (%d, %d): using the per-step launches\n", cus, occ_f, occ_b, 2 * kRecBlocks, kBpttBlocks * rsplit_env);
       l->rec_persist = false;
     }
   }

@@ -16,6 +16,8 @@
 #include <torch/extension.h>
 
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -56,6 +58,40 @@ void* torchCurrentStream(int device) {
 }
 
 constexpr int64_t kObsBytes = 4 * 84 * 84;
+
+// RELA_THREADED_STATS=1: where the actor threads' wall time goes (summed over threads, printed when the Context dies):
+// the drop-in's throughput is bound by host work per env-step, which no GPU profiler sees.
+struct ThreadedStats {
+  std::atomic<int64_t> envStep{0}, envReset{0}, actPrep{0}, actWait{0}, actLead{0}, postWait{0}, postLead{0}, setRT{0};
+  std::atomic<int64_t> envSteps{0}, ticks{0};
+  const bool on = [] {
+    const char* e = std::getenv("RELA_THREADED_STATS");
+    return e && e[0] == '1';
+  }();
+  static int64_t now() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
+  void print() const {
+    if (!on || envSteps.load() == 0) return;
+    const double n = (double)envSteps.load();
+    auto us = [n](const std::atomic<int64_t>& v) { return v.load() * 1e-3 / n; };
+    std::fprintf(stderr,
+                 "[rela threaded stats] env-steps %lld, cohort ticks %lld; thread-us per env-step: env.step %.2f, env.reset %.2f, "
+                 "act: prep+upload %.2f, barrier wait %.2f, leader launch+sync %.2f; setRewardAndTerminal %.2f; "
+                 "postStep: barrier wait %.2f, leader launch %.2f\n",
+                 (long long)envSteps.load(), (long long)ticks.load(), us(envStep), us(envReset), us(actPrep), us(actWait),
+                 us(actLead), us(setRT), us(postWait), us(postLead));
+  }
+};
+ThreadedStats gStats;
+struct StatTimer {
+  std::atomic<int64_t>& acc;
+  const int64_t t0;
+  explicit StatTimer(std::atomic<int64_t>& a) : acc(a), t0(gStats.on ? ThreadedStats::now() : 0) {}
+  ~StatTimer() {
+    if (gStats.on) acc += ThreadedStats::now() - t0;
+  }
+};
 
 }  // namespace
 
@@ -630,6 +666,7 @@ class ActorCohort {
     if (s.size(0) != K_ || s.numel() != (int64_t)K_ * kObsBytes || s.dtype() != torch::kUInt8)
       throw std::runtime_error("DQNActor.act: obs['s'] must be uint8 [batchsize,4,84,84]");
     const int A = (int)legal.size(1);
+    const int64_t tPrep = gStats.on ? ThreadedStats::now() : 0;
     std::unique_lock<std::mutex> lk(m_);
     if (draining_) return drained();
     if (!created_) create(A);
@@ -650,6 +687,7 @@ class ActorCohort {
       std::memcpy(ld, l.data_ptr(), l.nbytes());
       constsDirty_ = true;
     }
+    if (gStats.on) gStats.actPrep += ThreadedStats::now() - tPrep;
     rendezvous(lk, [&] {
       check(rela_stream_wait_stream(compute_, upload_, locker_->deviceIndex), "rela_stream_wait_stream");
       auto lease = locker_->getModel();
@@ -663,7 +701,8 @@ class ActorCohort {
       check(rc, lstm_ ? "R2D2Actor.act (batched)" : "DQNActor.act (batched)");
       constsDirty_ = false;
       constsValid_ = true;
-    });
+      gStats.ticks += 1;
+    }, gStats.actWait, gStats.actLead);
     if (draining_) return drained();
     numAct_[member] += K_;
     return TensorDict{{"a", actionAll_.narrow(0, (int64_t)member * K_, K_)}};
@@ -697,7 +736,7 @@ class ActorCohort {
       // The next round's frames land in the history slot this tick just read (the ring reuses
       // slot `head`): uploads must start after the tick's queued kernels and row copies.
       check(rela_stream_wait_stream(upload_, compute_, locker_->deviceIndex), "rela_stream_wait_stream");
-    });
+    }, gStats.postWait, gStats.postLead);
   }
 
   void shutdown() {
@@ -719,9 +758,11 @@ class ActorCohort {
 
  private:
   template <class F>
-  void rendezvous(std::unique_lock<std::mutex>& lk, F&& leaderWork) {
+  void rendezvous(std::unique_lock<std::mutex>& lk, F&& leaderWork, std::atomic<int64_t>& waitAcc,
+                  std::atomic<int64_t>& leadAcc) {
     const uint64_t gen = generation_;
     if (++arrived_ == T_) {
+      StatTimer st(leadAcc);
       try {
         leaderWork();
       } catch (...) {
@@ -735,6 +776,7 @@ class ActorCohort {
       ++generation_;
       cv_.notify_all();
     } else {
+      StatTimer st(waitAcc);
       cv_.wait(lk, [&] { return generation_ != gen || draining_; });
     }
   }
@@ -1102,13 +1144,23 @@ class BasicThreadLoop : public ThreadLoop {
     TensorDict obs;
     torch::Tensor r, t;
     while (!terminated()) {
-      obs = env_->reset(obs);
+      {
+        StatTimer st(gStats.envReset);
+        obs = env_->reset(obs);
+      }
       while (!env_->anyTerminated() && !terminated()) {
         pauseGate();
         TensorDict action = actor_->act(obs);
-        std::tie(obs, r, t) = env_->step(action);
+        {
+          StatTimer st(gStats.envStep);
+          std::tie(obs, r, t) = env_->step(action);
+        }
+        gStats.envSteps += env_->size();
         if (eval_) continue;
-        actor_->setRewardAndTerminal(r, t);
+        {
+          StatTimer st(gStats.setRT);
+          actor_->setRewardAndTerminal(r, t);
+        }
         actor_->postStep();
       }
       if (eval_) break;  // one episode
@@ -1137,6 +1189,7 @@ class Context {
       if (auto a = l->actor()) a->onShutdown();  // ... nor one parked on a full replay ring
     for (auto& th : threads_)
       if (th.joinable()) th.join();
+    gStats.print();
   }
 
   int pushThreadLoop(std::shared_ptr<ThreadLoop> loop) {

@@ -17,6 +17,40 @@ namespace py = pybind11;
 
 namespace {
 
+// n bytes of the LCG stream (x <- 1664525 x + 1013904223, top byte of every state) starting AFTER `state`; returns the
+// last state.  The recurrence is a serial dependency chain (~4 cycles per byte: 28,224 bytes = 37-40 us per frame
+// stack, which bounded the threaded benchmark at ~430 k env-steps/s on 16 cores), so 32 consecutive states are carried
+// in four 8-lane vectors and advanced by the 32-step jump x_{k+32} = A32 x_k + C32: the same bytes in the same order,
+// bit for bit (6 us per frame stack).  Vector k, lane j holds x_{i+4j+k+1}: the top bytes of lane j of the four
+// vectors are four CONSECUTIVE output bytes, so the packed word is stored as it is.
+typedef uint32_t v8u __attribute__((vector_size(32)));
+__attribute__((target_clones("avx2", "default"))) uint32_t lcgFill(uint32_t state, uint8_t* out, int n) {
+  constexpr uint32_t a = 1664525u, c = 1013904223u;
+  v8u l[4];
+  uint32_t A32 = 1, C32 = 0;
+  for (int p = 0; p < 32; ++p) {
+    state = state * a + c;
+    l[p & 3][p >> 2] = state;
+    C32 = C32 * a + c;
+    A32 *= a;
+  }
+  int i = 0;
+  for (; i + 32 <= n; i += 32) {
+    const v8u w = (l[0] >> 24) | ((l[1] >> 24) << 8) | ((l[2] >> 24) << 16) | (l[3] & 0xFF000000u);
+    std::memcpy(out + i, &w, 32);
+    for (int k = 0; k < 4; ++k) l[k] = l[k] * A32 + C32;
+  }
+  // l[0][0] is x_{i+1}: the serial tail (n not a multiple of 32) and the returned state continue from
+  // x_i = (x_{i+1} - c) * a^-1 (mod 2^32)
+  constexpr uint32_t aInv = 4276115653u;  // a * aInv == 1 (mod 2^32)
+  uint32_t last = (l[0][0] - c) * aInv;
+  for (; i < n; ++i) {
+    last = last * a + c;
+    out[i] = (uint8_t)(last >> 24);
+  }
+  return last;
+}
+
 class SyntheticAtariEnv : public rela::Env {
  public:
   // slidingStack: the observation is a stack of four planes of which ONE is new per step and the first plane of
@@ -65,11 +99,11 @@ class SyntheticAtariEnv : public rela::Env {
     uint8_t* p = frame_.data_ptr<uint8_t>();
     constexpr int kPlane = 84 * 84;
     if (!sliding_) {
-      for (int i = 0; i < 4 * kPlane; ++i) p[i] = (uint8_t)(next() >> 24);
+      state_ = lcgFill(state_, p, 4 * kPlane);
       return;
     }
     if (!episodeStart) std::memmove(p, p + kPlane, 3 * kPlane);
-    for (int i = 0; i < kPlane; ++i) p[3 * kPlane + i] = (uint8_t)(next() >> 24);
+    state_ = lcgFill(state_, p + 3 * kPlane, kPlane);
     if (episodeStart)
       for (int k = 0; k < 3; ++k) std::memcpy(p + k * kPlane, p + 3 * kPlane, kPlane);
   }
@@ -81,6 +115,37 @@ class SyntheticAtariEnv : public rela::Env {
   int steps_;
   bool terminal_;
   float episodeReward_;
+  torch::Tensor eps_, legal_, frame_;
+};
+
+// Zero-cost env for measuring the ENGINE's own ceiling through rela.Context / BasicThreadLoop / DQNActor (the
+// observation is a constant frame stack, the reward 0, episodes end after episode_len steps): whatever rate the
+// threaded benchmark reaches with it is what the runtime -- thread loop, VectorEnv, upload, cohort barrier, device
+// tick -- can do when the env costs nothing.
+class NullAtariEnv : public rela::Env {
+ public:
+  NullAtariEnv(float eps, int numAction, int episodeLen) : numAction_(numAction), episodeLen_(episodeLen) {
+    eps_ = torch::full({1}, eps, torch::kFloat32);
+    legal_ = torch::ones({numAction}, torch::kFloat32);
+    frame_ = torch::full({4, 84, 84}, 17, torch::kUInt8);
+  }
+  int numAction() const { return numAction_; }
+  rela::TensorDict reset() final {
+    steps_ = 0;
+    terminal_ = false;
+    return {{"s", frame_}, {"eps", eps_}, {"legal_move", legal_}};
+  }
+  std::tuple<rela::TensorDict, float, bool> step(const rela::TensorDict& action) final {
+    (void)action;
+    if (++steps_ >= episodeLen_) terminal_ = true;
+    return std::make_tuple(rela::TensorDict{{"s", frame_}, {"eps", eps_}, {"legal_move", legal_}}, 0.f, terminal_);
+  }
+  bool terminated() const final { return terminal_; }
+
+ private:
+  const int numAction_, episodeLen_;
+  int steps_ = 0;
+  bool terminal_ = true;
   torch::Tensor eps_, legal_, frame_;
 };
 
@@ -96,4 +161,10 @@ PYBIND11_MODULE(synth_atari, m) {
       .def("step", &SyntheticAtariEnv::step)
       .def("terminated", &SyntheticAtariEnv::terminated)
       .def("get_episode_reward", &SyntheticAtariEnv::getEpisodeReward);
+  py::class_<NullAtariEnv, rela::Env, std::shared_ptr<NullAtariEnv>>(m, "NullAtariEnv")
+      .def(py::init<float, int, int>(), py::arg("eps"), py::arg("num_action"), py::arg("episode_len"))
+      .def("num_action", &NullAtariEnv::numAction)
+      .def("reset", &NullAtariEnv::reset)
+      .def("step", &NullAtariEnv::step)
+      .def("terminated", &NullAtariEnv::terminated);
 }

@@ -91,7 +91,14 @@ def main(argv=None):
     p.add_argument("--epoch_sec", type=float, default=30)
     p.add_argument("--num_epoch", type=int, default=6)
     p.add_argument("--grid", default="80x20,80x40,80x80,80x160", help="threads x games per thread")
+    p.add_argument("--env", default=None, choices=[None, "fresh", "sliding", "null"],
+                   help="synthetic env flavour: fresh = four new LCG planes per step (SURVEY 8d, the default), sliding = "
+                        "ONE new plane per step, Atari's frame stacking (atari/game_state.h:53-82), null = constant frames "
+                        "and zero host cost (the runtime's own ceiling); default: what RELA_SYNTH_SLIDING / RELA_SYNTH_ENV say")
     args = p.parse_args(argv)
+    if args.env is not None:
+        os.environ["RELA_SYNTH_SLIDING"] = "1" if args.env == "sliding" else "0"
+        os.environ["RELA_SYNTH_ENV"] = "null" if args.env == "null" else ""
     rows = []
     for cell in args.grid.split(","):
         t, k = (int(v) for v in cell.split("x"))

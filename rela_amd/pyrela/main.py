@@ -116,7 +116,7 @@ def train(args, on_epoch=None):
     for epoch in range(args.num_epoch):
         tach.start()
         t0 = time.time()
-        loss_sum = torch.zeros((), device=args.train_device)
+        watch = _LearnerWatch(learner, args.train_device)
         for batch_idx in range(args.epoch_len):
             num_update = batch_idx + epoch * args.epoch_len
             if num_update % args.num_update_between_sync == 0:
@@ -125,6 +125,7 @@ def train(args, on_epoch=None):
                 else:
                     agent.sync_target_with_online()
             if num_update % args.actor_sync_freq == 0:
+                watch.poll()
                 if learner is not None:  # ModelLocker reads the Python model: hand it the current weights
                     agent.online_net.load_state_dict(learner.state_dict("online"))
                     agent.target_net.load_state_dict(learner.state_dict("target"))
@@ -142,14 +143,15 @@ def train(args, on_epoch=None):
                 optim.step()
                 optim.zero_grad()
             replay_buffer.update_priority(priority)
-            loss_sum += loss.detach()
+            watch.add(loss.detach())
         torch.cuda.synchronize()
-        _check_learner(learner)
+        mean_loss = watch.mean_loss()
         dt = time.time() - t0
-        print("epoch: %d, time: %.1fs, loss: %.5f" % (epoch, dt, float(loss_sum) / args.epoch_len))
+        print("epoch: %d, time: %.1fs, loss: %.5f%s" % (epoch, dt, mean_loss, (
+            " (%d steps skipped after a learner timeout)" % watch.skipped) if watch.skipped else ""))
         rates = tach.lap(actors, replay_buffer, args.epoch_len * args.batchsize)
         history.append(dict(epoch=epoch, seconds=dt, train=rates[0], act=rates[1], buffer_add=rates[2],
-                            loss=float(loss_sum) / args.epoch_len))
+                            loss=mean_loss, skipped_steps=watch.skipped))
         if on_epoch is not None:
             on_epoch(history[-1])
         print("****************************************")
@@ -251,24 +253,25 @@ def _multi_worker(rank, world, args, port, results):
         history = []
         for epoch in range(args.num_epoch):
             t0 = time.time()
-            loss_sum = torch.zeros((), device=my_device)
+            watch = _LearnerWatch(learner, my_device)
             for batch_idx in range(args.epoch_len):
                 num_update = batch_idx + epoch * args.epoch_len
                 if num_update % args.num_update_between_sync == 0:
                     learner.sync_target_with_online()
                 if num_update % args.actor_sync_freq == 0:  # ONE broadcast per flat buffer instead of load_state_dict
+                    watch.poll()
                     replay.publish(learner.flat()[0].to(exch_device), learner.flat_target().to(exch_device),
                                    steps=min(args.actor_sync_freq, total_updates - num_update))
                 fields, weight = replay.sample()
                 batch = to_namespace({k: v.to(my_device) for k, v in fields.items()})
                 loss, priority = learner.step(batch, weight.to(my_device))
                 replay.update_priority(priority)
-                loss_sum += loss[0]
+                watch.add(loss[0])
             torch.cuda.synchronize()
-            _check_learner(learner)
+            mean_loss = watch.mean_loss()
             dt = time.time() - t0
             history.append(dict(epoch=epoch, seconds=dt, train=args.epoch_len * args.batchsize / dt,
-                                loss=float(loss_sum) / args.epoch_len))
+                                loss=mean_loss, skipped_steps=watch.skipped))
             print("epoch: %d, time: %.1fs, loss: %.5f, train: %.1f samples/s" % (
                 epoch, dt, history[-1]["loss"], history[-1]["train"]), flush=True)
         replay.stop()
@@ -327,15 +330,46 @@ def _multi_worker(rank, world, args, port, results):
 
 
 
-def _check_learner(learner):
-    """Once per epoch: a HIP learner whose persistent kernels gave up on a grid barrier (rela_r2d2_learner_check)
-    has skipped its optimiser updates since and now runs the per-step launches; say so loudly and carry on."""
-    if learner is None or not hasattr(learner, "check"):
-        return
-    try:
-        learner.check()
-    except RuntimeError as e:
-        print("WARNING: %s" % e, flush=True)
+class _LearnerWatch:
+    """Keeps an epoch's loss statistics honest when a HIP learner's persistent kernels give up on a grid barrier
+    (rela_r2d2_learner_check): after a timeout the word stays set, every later persistent launch leaves at its first
+    barrier and every apply() is skipped on the device until the word is read.  The word is therefore polled at a BOUNDED
+    interval -- with every weight publish (actor_sync_freq steps, where the loop synchronises anyway) and at the end
+    of an epoch -- instead of once per epoch.  A hit clears the word and switches the learner to its per-step launches
+    (inside check()), the steps since the last clean poll are counted as skipped and their losses are left out of the
+    epoch's average; their priorities (<= actor_sync_freq batches, from a forward that did not finish) were already
+    written to the replay and are overwritten the next time those slots are sampled."""
+
+    def __init__(self, learner, device):
+        self.learner = learner
+        self.good = torch.zeros((), device=device)
+        self.pending = torch.zeros((), device=device)
+        self.n_good = self.n_pending = self.skipped = 0
+
+    def add(self, loss):
+        self.pending += loss
+        self.n_pending += 1
+
+    def poll(self):
+        ok = True
+        if self.learner is not None and hasattr(self.learner, "check") and self.n_pending:
+            try:
+                self.learner.check()
+            except RuntimeError as e:
+                ok = False
+                self.skipped += self.n_pending
+                print("WARNING: %s -- %d learner steps since the last clean poll are excluded from the loss average "
+                      "(%d skipped so far)" % (e, self.n_pending, self.skipped), flush=True)
+        if ok:
+            self.good += self.pending
+            self.n_good += self.n_pending
+        self.pending.zero_()
+        self.n_pending = 0
+        return ok
+
+    def mean_loss(self):
+        self.poll()
+        return float(self.good) / max(self.n_good, 1)
 
 
 def train_multi(args):
@@ -378,7 +412,10 @@ def train_multi(args):
                 stop_all()
                 raise SystemExit("rank %d exited with code %s before the run finished; the other ranks were stopped" % dead[0])
             if all(q.exitcode == 0 for q in procs):
-                raise SystemExit("every rank exited without a result")
+                try:  # the learner may have put its result and every rank exited between the timed-out get and here
+                    res = results.get(timeout=1)
+                except queue.Empty:
+                    raise SystemExit("every rank exited without a result")
     for r, q in enumerate(procs):
         q.join(timeout=120)
         if q.exitcode is None:  # still running two minutes after the result: stop it, the run itself succeeded

@@ -570,6 +570,47 @@ print("RESULT" + json.dumps(rounds))
     save(out_name, [], json.loads(line[len("RESULT"):]), cfg=getattr(e2e_lockstep, cfg_name))
 
 
+def e2e_big_cases(cfg_name="CFG_BIG", out_name="e2e_lockstep_apex_k128"):
+    """r4: the lock-step run at K = 128 rows (one reference actor thread, one TorchScript call per 128 envs), recorded
+    from the REAL reference on the CPU, plus what justifies exact comparison of the greedy actions under the split-bf16
+    mode's tolerance: over every frame the run can see (the first 24 observations of each env; the run acts on 15) the reference's own
+    online net gives max|Q| and the smallest gap between the two best legal Q-values."""
+    code = r"""
+import json, sys
+sys.dont_write_bytecode = True
+sys.path[:0] = [%r, %r, "/root/reference/pyrela"]
+import numpy as np
+import torch
+torch.set_num_threads(8)
+import rela, synth_atari
+assert "_ref" in rela.__file__
+from apex import ApexAgent
+from net import AtariFFNet
+from e2e_lockstep import %s as CFG, run_lockstep, load_agent_params, frames_of_run
+agent = load_agent_params(ApexAgent(lambda: AtariFFNet(CFG["num_action"]), CFG["multi_step"], CFG["gamma"]), CFG)
+rounds = run_lockstep(rela, synth_atari, agent, "cpu", "cpu", CFG)
+frames = frames_of_run(synth_atari, CFG, 24)
+gap, qmax = float("inf"), 0.0
+with torch.no_grad():
+    for t in range(frames.shape[0]):
+        obs = {"s": torch.from_numpy(frames[t]), "legal_move": torch.ones(CFG["K"], CFG["num_action"])}
+        q = agent.online_net(obs)
+        top = q.topk(2, dim=1)[0]
+        gap = min(gap, float((top[:, 0] - top[:, 1]).min()))
+        qmax = max(qmax, float(q.abs().max()))
+print("RESULT" + json.dumps({"rounds": rounds, "min_top2_gap": gap, "max_abs_q": qmax, "frames_checked": int(frames.shape[0])}))
+""" % (REFBIN, os.path.dirname(HERE), cfg_name)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    if out.returncode != 0:
+        print(out.stdout[-2000:], out.stderr[-4000:])
+        raise SystemExit(1)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1]
+    import e2e_lockstep
+    rec = json.loads(line[len("RESULT"):])
+    save(out_name, [], rec["rounds"], cfg=getattr(e2e_lockstep, cfg_name), min_top2_gap=rec["min_top2_gap"],
+         max_abs_q=rec["max_abs_q"], frames_checked=rec["frames_checked"])
+
+
 def e2e_r2d2_cases(cfg_name="CFG_R2D2", out_name="e2e_lockstep_r2d2", quiet=1.0):
     """The REAL reference's R2D2 path end to end (H6-shimmed module, see oracle/Makefile)."""
     code = r"""
@@ -612,6 +653,8 @@ if __name__ == "__main__":
         r2d2agg_cases()
     if "e2e" in which:
         e2e_cases()
+    if "e2e_big" in which:  # r4: K = 128 rows, reaches the split-bf16 kernels; ~1 minute
+        e2e_big_cases()
     if "e2e_sliding" in which:  # Atari-like sliding frame stacks (for the de-duplicating replay)
         e2e_cases("CFG_SLIDING", "e2e_lockstep_apex_sliding")
     if "replay" in which:

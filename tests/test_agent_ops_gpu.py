@@ -137,8 +137,11 @@ def test_eps_greedy_statistics():
     assert hist.min() > 0.5 * hist.mean()
 
 
-def test_post_step_reuses_act_forward_bit_identically():
-    """post_step skips the online forwards on obs and next_obs when act() already ran them with the same
+@pytest.mark.parametrize("A,R,K,precision", [(6, 16, 8, "f32"), (18, 256, 128, "f32"), (18, 256, 128, "bf16x2")])
+def test_post_step_reuses_act_forward_bit_identically(A, R, K, precision):
+    """(r4: also at 256 rows in groups of 128 in BOTH precision modes -- the memoised Q tables of the bf16x2 engine
+    at >= 128 rows are what the bench's fast mode runs; the launch census asserts the split-bf16 kernels ran.)
+    post_step skips the online forwards on obs and next_obs when act() already ran them with the same
     weights (dqn_actor.h:84,161 and apex.py:38,41 evaluate the same network on the same batches, n ticks ago
     and this tick).  Twin actors -- one whose weights are re-loaded (same values, new version) before every
     post_step, one with the reuse switched off, one that reuses only the next_obs forward -- must take the
@@ -151,7 +154,9 @@ def test_post_step_reuses_act_forward_bit_identically():
     from rela_amd.replay import FFReplay
     from synth import synth_obs, synth_params
 
-    A, R, K, n = 6, 16, 8, 3
+    from kernel_names import CONV12
+
+    n = 3
     params = {k: torch.from_numpy(v) for k, v in synth_params(A, 5).items()}
     tparams = {k: torch.from_numpy(v) for k, v in synth_params(A, 6).items()}
     params2 = {k: torch.from_numpy(v) for k, v in synth_params(A, 7).items()}
@@ -161,8 +166,11 @@ def test_post_step_reuses_act_forward_bit_identically():
         online, target = FFNetHandle(A, "cuda:0"), FFNetHandle(A, "cuda:0")
         online.load_state_dict(params)
         target.load_state_dict(tparams)
-        replay = FFReplay(256, 3, 0.6, 0.4, 0, A, "cuda:0")
+        online.set_precision(precision)
+        target.set_precision(precision)
+        replay = FFReplay(16 * R, 3, 0.6, 0.4, 0, A, "cuda:0")
         eng = ApexActorEngine(R, K, A, n, 0.99, replay, eps, "cuda:0", seed=11)
+        capi.check(capi.lib.rela_prof_count_enable(1), "census")
         eng.legal.fill_(1.0)
         if reload_between == "switch":
             eng.set_reuse(False)
@@ -185,6 +193,12 @@ def test_post_step_reuses_act_forward_bit_identically():
             if eng.post_step(rew, term, online, target):
                 prios.append(eng.prio.cpu().numpy().copy())
         torch.cuda.synchronize()
+        cbuf = C.create_string_buffer(1 << 16)
+        capi.check(capi.lib.rela_prof_counts_json(cbuf, len(cbuf)), "census")
+        capi.lib.rela_prof_count_enable(0)
+        ran = set(json.loads(cbuf.value.decode()))
+        fast = {CONV12, "conv_bf16s<Conv3F>", "fc_bf16s (split-K)"}
+        assert (fast <= ran) if (precision == "bf16x2" and R >= 128) else not (fast & ran), (precision, sorted(ran))
         ring = replay.debug_state()["ring"]
         w, ev = np.zeros(ring, np.float32), np.zeros(ring, np.uint8)
         capi.check(capi.lib.rela_replay_debug_weights(replay.h, w.ctypes.data_as(C.c_void_p),

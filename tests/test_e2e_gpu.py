@@ -100,6 +100,94 @@ def test_lockstep_sliding_env_matches_reference(mods, dedup_env, dedup):
     _check_apex_rounds(run_lockstep(rela, synth, agent, "cuda:0", "cuda:0", C), gold)
 
 
+@pytest.fixture
+def precision_env():
+    """RELA_PRECISION for the duration of one test (read when a ModelLocker creates its device nets)."""
+    def set_(mode):
+        os.environ["RELA_PRECISION"] = mode
+    yield set_
+    os.environ.pop("RELA_PRECISION", None)
+
+
+FAST_KERNELS = {"conv_bf16s<Conv3F>", "fc_bf16s (split-K)"}
+F32_KERNELS = {"conv1_bf16x3", "conv_mfma<Conv2> (f32)", "conv_mfma<Conv3> (f32)"}
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x2"])
+def test_lockstep_k128_matches_reference_in_both_precision_modes(mods, dedup_env, precision_env, precision):
+    """the configuration the headline runs -- the engine in bf16x2 mode WITH memoised Q tables at
+    >= 128 rows -- pinned at ENGINE level.  One actor thread x 128 envs through rela.Context / BasicThreadLoop /
+    DQNActor / FFPrioritizedReplay (alpha 0.6 / beta 0.4), driven exactly like the REAL reference was when
+    tests/golden/e2e_lockstep_apex_k128.json was recorded (its C++ actor, its TorchScript ApexAgent on the CPU:
+    rela/dqn_actor.h:153-203, pyrela/apex.py:30-78).  Integer fields, frames, n-step rewards: exact; IS weights (the
+    TD priorities through pow and the scan): 1e-4 relative in f32 mode, 2e-3 in bf16x2 mode (priorities within
+    6e-5 x max|Q| of the f32 ones, tests/test_ffnet_gpu.py).  Exact greedy actions are a CHECKED expectation: the
+    golden records that the two best legal Q-values of every decision of the run are 1.39e-4 apart, 8 x the fast
+    mode's |dQ| bound.  The launch census asserts which kernels really ran."""
+    from e2e_lockstep import CFG_BIG as C, load_agent_params, run_lockstep
+    from kernel_names import CONV12
+    from rela_amd import _capi as capi
+    from rela_amd.pyrela.apex import ApexAgent
+    from rela_amd.pyrela.net import AtariFFNet
+
+    rela, synth = mods
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_lockstep_apex_k128.json")))
+    assert gold["cfg"] == C
+    tol_q = 2e-5 * gold["max_abs_q"]
+    assert gold["min_top2_gap"] > 4 * tol_q, "the golden's decisions are too close for an exact action comparison"
+    dedup_env(None)
+    precision_env(precision)
+    agent = load_agent_params(ApexAgent(lambda: AtariFFNet(C["num_action"]), C["multi_step"], C["gamma"]), C)
+    with capi.launch_census() as census:
+        rounds = run_lockstep(rela, synth, agent, "cuda:0", "cuda:0", C)
+    ran = set(census.counts)
+    if precision == "bf16x2":
+        assert FAST_KERNELS | {CONV12} <= ran and not (F32_KERNELS & ran), census.counts
+    else:
+        assert F32_KERNELS <= ran and not ((FAST_KERNELS | {CONV12}) & ran), census.counts
+    assert len(rounds) == len(gold["expect"])
+    for r, (got, exp) in enumerate(zip(rounds, gold["expect"])):
+        for key in ("s_sum", "s_head", "next_s_sum", "s_planes", "next_s_planes", "a", "terminal", "bootstrap", "eps",
+                    "legal_sum", "num_add"):
+            assert got[key] == exp[key], (precision, r, key)
+        assert np.array_equal(np.float32(got["reward"]), np.float32(exp["reward"])), (precision, r)
+        np.testing.assert_allclose(got["weight"], exp["weight"], rtol=1e-4 if precision == "f32" else 2e-3,
+                                   err_msg="IS weights, round %d, %s" % (r, precision))
+
+
+def test_cohort_in_fast_mode_agrees_with_the_f32_cohort(mods, dedup_env, precision_env):
+    """The ActorCohort (2 threads x 64 envs = ONE 128-row shard: every thread runs the reference loop on its 64 envs,
+    the last arriver launches the batched act / post_step; q.min() and replay blocks per group of 64) in bf16x2 mode
+    against the same cohort in f32 mode, in lock step: every sampled batch holds the same rows (frames), actions,
+    n-step rewards and flags; IS weights within the fast mode's priority tolerance.  The envs are the K = 128 golden's
+    (same seeds), so the decisions of the run are the ones whose gaps the golden recorded."""
+    from e2e_lockstep import CFG_COHORT as C, load_agent_params, run_lockstep
+    from kernel_names import CONV12
+    from rela_amd import _capi as capi
+    from rela_amd.pyrela.apex import ApexAgent
+    from rela_amd.pyrela.net import AtariFFNet
+
+    rela, synth = mods
+    dedup_env(None)
+    runs = {}
+    for precision in ("f32", "bf16x2"):
+        precision_env(precision)
+        agent = load_agent_params(ApexAgent(lambda: AtariFFNet(18), 3, 0.997), C)
+        with capi.launch_census() as census:
+            runs[precision] = run_lockstep(rela, synth, agent, "cuda:0", "cuda:0", C)
+        ran = set(census.counts)
+        if precision == "bf16x2":
+            assert FAST_KERNELS | {CONV12} <= ran and not (F32_KERNELS & ran), census.counts
+        else:
+            assert F32_KERNELS <= ran and not ((FAST_KERNELS | {CONV12}) & ran), census.counts
+    assert len(runs["f32"]) == len(runs["bf16x2"]) == C["rounds"]
+    for r, (a, b) in enumerate(zip(runs["f32"], runs["bf16x2"])):
+        for key in ("s_sum", "s_head", "next_s_sum", "a", "terminal", "bootstrap", "eps", "legal_sum", "num_add"):
+            assert a[key] == b[key], (r, key)
+        assert np.array_equal(np.float32(a["reward"]), np.float32(b["reward"])), r
+        np.testing.assert_allclose(a["weight"], b["weight"], rtol=2e-3, err_msg="IS weights, round %d" % r)
+
+
 @pytest.mark.parametrize("hip_learner", [1, 0])
 def test_training_entry_point_runs(mods, capsys, hip_learner):
     """pyrela-style main loop on 2 threads x 8 envs for two tiny epochs: actors insert from C++

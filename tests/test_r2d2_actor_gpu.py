@@ -27,7 +27,7 @@ def _net(capi, A, seed):
     return h, (p, keep)
 
 
-def _run(mode):
+def _run(mode, R=8, K=4, precision="f32"):
     """mode: "reuse" | "switch" (set_reuse(0)) | "reload" (same weights re-loaded before every post_step)."""
     import torch
 
@@ -35,12 +35,14 @@ def _run(mode):
     from rela_amd.engine import dev_view
     from synth import synth_obs
 
-    R, K, A, n, seq, burn = 8, 4, 6, 2, 6, 2
+    A, n, seq, burn = 6, 2, 6, 2
     T = burn + seq + n
     online, keep_on = _net(capi, A, 1)
     target, _keep_tg = _net(capi, A, 2)
+    for net in (online, target):
+        capi.check(capi.lib.rela_lstmnet_set_precision(net, {"f32": 0, "bf16x2": 1}[precision]), "set_precision")
     replay = C.c_void_p()
-    capi.check(capi.lib.rela_replay_create(C.byref(replay), 64, 7, 0.9, 0.6, 0, 0), "rela_replay_create")
+    capi.check(capi.lib.rela_replay_create(C.byref(replay), 8 * R, 7, 0.9, 0.6, 0, 0), "rela_replay_create")
     rb = (C.c_int64 * 10)(T * 28224, T * 4, T * 4 * A, T * 8, T * 4, T, T * 4, 2048, 2048, 4)
     st = (C.c_int32 * 10)(T, T, T, T, T, T, T, 1, 1, 1)
     capi.check(capi.lib.rela_replay_set_schema_seq(replay, 10, rb, st), "schema")
@@ -88,11 +90,21 @@ def _run(mode):
     return np.array(acts), np.array(prios), w, size, nseq_total
 
 
-def test_post_step_reuses_the_act_step_bit_identically():
-    base = _run("reuse")
+@pytest.mark.parametrize("R,K,precision", [(8, 4, "f32"), (128, 64, "f32"), (128, 64, "bf16x2")])
+def test_post_step_reuses_the_act_step_bit_identically(R, K, precision):
+    """(r4: also at 128 rows in BOTH precision modes: from 128 rows up the bf16x2 LSTM net runs its conv trunk on the
+    split-bf16 kernels -- asserted through the launch census -- and the memoised step must still be bit-identical)"""
+    from kernel_names import CONV12
+    from rela_amd import _capi as capi
+
+    with capi.launch_census() as census:
+        base = _run("reuse", R, K, precision)
+    fast = {CONV12, "conv_bf16s<Conv3F>"}
+    ran = set(census.counts)
+    assert (fast <= ran) if (precision == "bf16x2" and R >= 128) else not (fast & ran), (precision, sorted(ran))
     assert base[3] > 0 and base[4] == base[3]
     for mode in ("switch", "reload"):
-        other = _run(mode)
+        other = _run(mode, R, K, precision)
         assert other[3] == base[3] and other[4] == base[4]
         assert np.array_equal(base[0], other[0])
         assert np.array_equal(base[1].view(np.uint32), other[1].view(np.uint32)), mode
