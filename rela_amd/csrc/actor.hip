@@ -52,6 +52,7 @@ struct rela_apex_actor {
   std::vector<uint8_t> refs_valid;   // [n+1] the slot's units were stored
   std::vector<int64_t> tick_seq;     // first unit sequence number of the last kTickWin ticks (ring by tick)
   int64_t tick = 0, key_tick = -1;   // ticks stored so far; tick of the last keyframe (all planes stored)
+  uint8_t* restart = nullptr;        // [R] rela_apex_actor_slide_stacks: 1 = the row's stack restarts with its new plane
 };
 
 namespace {
@@ -148,7 +149,7 @@ extern "C" void rela_apex_actor_destroy(rela_apex_actor* a) {
   DeviceGuard g(a->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {a->obs, a->act, a->rew, a->term, a->eps, a->legal, a->q, a->out_r, a->out_b, a->prio, a->out_t, a->ws,
-                a->eps_hist, a->legal_hist, a->ref_hist, a->q_hist};
+                a->eps_hist, a->legal_hist, a->ref_hist, a->q_hist, a->restart};
   for (void* p : ps) (void)hipFree(p);
   delete a;
 }
@@ -157,6 +158,17 @@ static inline int next_slot(const rela_apex_actor* a) { return (a->head + a->cou
 
 extern "C" void* rela_apex_actor_obs_slot(rela_apex_actor* a) {
   return a ? a->obs + (size_t)next_slot(a) * a->R * kObs : nullptr;
+}
+extern "C" int rela_apex_actor_slide_stacks(rela_apex_actor* a, const uint8_t* restart_host, void* stream_) {
+  RELA_CHECK(a && restart_host, RELA_EINVAL, "rela_apex_actor_slide_stacks: bad arguments");
+  RELA_CHECK(a->act_calls > 0, RELA_ESTATE, "rela_apex_actor_slide_stacks: the first observation must be uploaded whole");
+  RELA_CHECK(a->count <= a->n, RELA_ESTATE, "rela_apex_actor_slide_stacks: act() twice without post_step()");
+  hipStream_t s = (hipStream_t)stream_;
+  DeviceGuard g(a->device);
+  if (!a->restart) RELA_HIP(hipMalloc(&a->restart, (size_t)a->R));
+  RELA_HIP(hipMemcpyAsync(a->restart, restart_host, (size_t)a->R, hipMemcpyHostToDevice, s));
+  const int H = a->n + 1, slot = next_slot(a), prev = (slot + H - 1) % H;
+  return slide_stacks(a->obs + (size_t)slot * a->R * kObs, a->obs + (size_t)prev * a->R * kObs, a->restart, a->R, s);
 }
 extern "C" int rela_apex_actor_set_reuse(rela_apex_actor* a, int on) {
   RELA_CHECK(a, RELA_EINVAL, "rela_apex_actor_set_reuse: bad arguments");

@@ -15,6 +15,7 @@
 #include <pybind11/stl.h>
 #include <torch/extension.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -100,23 +101,58 @@ struct StatTimer {
 // =====================================================================================
 namespace rela {
 
-void VectorEnv::storeRow(const TensorDict& obs, int row) {
+void VectorEnv::append(std::shared_ptr<Env> env) {
+  if (!batch_.empty()) throw std::runtime_error("VectorEnv.append after the first reset()");
+  frameEnvs_.push_back(dynamic_cast<FrameRowEnv*>(env.get()));
+  envs_.push_back(std::move(env));
+}
+
+// Allocates the persistent batch (one page-locked tensor per observation key, shaped [K, ...] like the first
+// observation) and caches the raw row addresses; binds the rows of envs that render in place.
+void VectorEnv::createBatch(const TensorDict& firstObs) {
   const int K = (int)envs_.size();
+  auto pin = [](torch::Tensor t) { return torch::cuda::is_available() ? t.pin_memory() : t; };
+  for (const auto& kv : firstObs) {
+    std::vector<int64_t> shape{K};
+    for (auto d : kv.second.sizes()) shape.push_back(d);
+    auto t = pin(torch::zeros(shape, kv.second.options().device(torch::kCPU)));
+    batch_.emplace(kv.first, t);
+    KeyRows kr;
+    kr.key = kv.first;
+    kr.base = static_cast<uint8_t*>(t.data_ptr());
+    kr.rowBytes = K > 0 ? (int64_t)t.nbytes() / K : 0;
+    kr.dtype = t.scalar_type();
+    rows_.push_back(kr);
+  }
+  sliding_ = K > 0;
+  for (auto* f : frameEnvs_) sliding_ = sliding_ && f && f->slidingStack();
+  if (sliding_ && batch_.count("s")) {
+    auto flags = pin(torch::ones({K}, torch::kUInt8));
+    restart_ = flags.data_ptr<uint8_t>();
+    batch_.emplace("__stack_restart", flags);
+  } else {
+    sliding_ = false;
+  }
+}
+
+void VectorEnv::storeRow(const TensorDict& obs, int row) {
+  const bool first = batch_.empty();
+  if (first) createBatch(obs);
   for (const auto& kv : obs) {
-    auto it = batch_.find(kv.first);
-    if (it == batch_.end()) {
-      std::vector<int64_t> shape{K};
-      for (auto d : kv.second.sizes()) shape.push_back(d);
-      auto t = torch::zeros(shape, kv.second.options().device(torch::kCPU));
-      if (torch::cuda::is_available()) t = t.pin_memory();
-      it = batch_.emplace(kv.first, t).first;
-    }
-    auto dst = it->second[row];
+    const KeyRows* kr = nullptr;
+    for (const auto& r : rows_)
+      if (r.key == kv.first) {
+        kr = &r;
+        break;
+      }
+    if (!kr) throw std::runtime_error("VectorEnv: observation key '" + kv.first + "' was not in the first observation");
     const auto& src = kv.second;
-    if (src.is_contiguous() && src.device().is_cpu() && src.dtype() == dst.dtype() && src.numel() == dst.numel()) {
-      std::memcpy(dst.data_ptr(), src.data_ptr(), (size_t)src.nbytes());
+    uint8_t* dst = kr->base + (int64_t)row * kr->rowBytes;
+    if (src.data_ptr() == dst) continue;  // rendered in place (FrameRowEnv)
+    if (src.is_contiguous() && src.device().is_cpu() && src.scalar_type() == kr->dtype && (int64_t)src.nbytes() == kr->rowBytes) {
+      std::memcpy(dst, src.data_ptr(), (size_t)kr->rowBytes);
     } else {
-      dst.copy_(src);
+      batch_.at(kv.first)[row].copy_(src);
     }
   }
 }
@@ -124,7 +160,16 @@ void VectorEnv::storeRow(const TensorDict& obs, int row) {
 TensorDict VectorEnv::reset(const TensorDict& previous) {
   const bool first = previous.empty();
   for (size_t i = 0; i < envs_.size(); ++i) {
-    if (first || envs_[i]->terminated()) storeRow(envs_[i]->reset(), (int)i);
+    if (first || envs_[i]->terminated()) {
+      storeRow(envs_[i]->reset(), (int)i);
+      if (restart_) restart_[i] = 1;
+    }
+  }
+  if (first) {  // the rows hold every env's first observation: envs that can, render into them from now on
+    for (const auto& r : rows_)
+      if (r.key == "s" && r.rowBytes == kObsBytes)
+        for (size_t i = 0; i < envs_.size(); ++i)
+          if (frameEnvs_[i]) frameEnvs_[i]->bindFrameRow(r.base + (int64_t)i * r.rowBytes);
   }
   return batch_;
 }
@@ -134,17 +179,33 @@ std::tuple<TensorDict, torch::Tensor, torch::Tensor> VectorEnv::step(const Tenso
   if (!reward_.defined()) {
     reward_ = torch::zeros({K}, torch::kFloat32);
     terminal_ = torch::zeros({K}, torch::kBool);
+    // per-env action dicts over ONE persistent buffer: {"a": 0-dim int64 view of actionBuf_[i]}
+    actionBuf_ = torch::zeros({K}, torch::kInt64);
+    envAction_.resize(K);
+    for (int i = 0; i < K; ++i)
+      envAction_[i].emplace("a", torch::from_blob(actionBuf_.data_ptr<int64_t>() + i, {}, torch::kInt64));
   }
   float* r = reward_.data_ptr<float>();
   bool* t = terminal_.data_ptr<bool>();
+  // the common case -- one key "a", int64[K] on the host -- needs no tensor operation per env
+  const torch::Tensor* a = nullptr;
+  if (action.size() == 1) {
+    auto it = action.find("a");
+    if (it != action.end() && it->second.scalar_type() == torch::kInt64 && it->second.device().is_cpu() &&
+        it->second.is_contiguous() && it->second.numel() == K)
+      a = &it->second;
+  }
+  if (a) std::memcpy(actionBuf_.data_ptr<int64_t>(), a->data_ptr<int64_t>(), (size_t)K * sizeof(int64_t));
   for (int i = 0; i < K; ++i) {
-    TensorDict a;
-    for (const auto& kv : action) a.emplace(kv.first, kv.second[i]);
+    TensorDict sliced;
+    if (!a)
+      for (const auto& kv : action) sliced.emplace(kv.first, kv.second[i]);
     TensorDict obs;
     float reward;
     bool terminal;
-    std::tie(obs, reward, terminal) = envs_[i]->step(a);
+    std::tie(obs, reward, terminal) = envs_[i]->step(a ? envAction_[i] : sliced);
     storeRow(obs, i);
+    if (restart_) restart_[i] = 0;
     r[i] = reward;
     t[i] = terminal;
   }
@@ -194,15 +255,20 @@ class ModelLocker {
     const void* target;
   };
 
+  // A "cpu" locker (the eval locker of pyrela/main.py:116, BASELINE C1's CPU-actor plumbing, pyrela/eval.py:9-36) keeps
+  // its Python replicas on the host exactly as the reference does, and its ACTORS run on the GPU `execDevice`
+  // (RELA_CPU_LOCKER_DEVICE, default 0) in the exact f32 parity mode whatever RELA_PRECISION says: there is no CPU
+  // execution path in this engine, and the f32 mode is the one pinned to the reference's CPU results.
   ModelLocker(std::vector<py::object> pyModels, const std::string& device)
-      : device(device), deviceIndex(parseDevice(device)), pyModels_(std::move(pyModels)) {
+      : device(device), deviceIndex(parseDevice(device)), execDevice(deviceIndex >= 0 ? deviceIndex : cpuLockerDevice()),
+        pyModels_(std::move(pyModels)) {
     if (pyModels_.empty()) throw std::invalid_argument("ModelLocker needs at least one model");
     const size_t n = pyModels_.size();
     online_.assign(n, nullptr);
     target_.assign(n, nullptr);
     inFlight_.assign(n, 0);
     if (py::hasattr(pyModels_[0], "eta")) eta_ = pyModels_[0].attr("eta").cast<double>();
-    if (deviceIndex >= 0) loadSlot(0, pyModels_[0]);
+    if (deviceIndex >= 0 || torch::cuda::is_available()) loadSlot(0, pyModels_[0]);
   }
 
   ~ModelLocker() {
@@ -217,19 +283,17 @@ class ModelLocker {
       id = (latest_ + 1) % (int)inFlight_.size();
       cv_.wait(lk, [&] { return inFlight_[id] == 0; });  // model_locker.h:27-28
     }
-    if (deviceIndex >= 0) {
-      loadSlot(id, pyModel);
-    } else {
-      pyModels_[id].attr("load_state_dict")(pyModel.attr("state_dict")());  // cpu locker: bookkeeping only
-    }
+    if (deviceIndex < 0) pyModels_[id].attr("load_state_dict")(pyModel.attr("state_dict")());  // model_locker.h:31
+    if (deviceIndex >= 0 || torch::cuda::is_available()) loadSlot(id, pyModel);
     std::lock_guard<std::mutex> lk(m_);
     latest_ = id;
   }
 
   Lease getModel() {
-    if (deviceIndex < 0)
-      throw std::runtime_error("ModelLocker('cpu'): this engine has no CPU actor path; use a cuda device");
     std::lock_guard<std::mutex> lk(m_);
+    if (!online_[latest_])
+      throw std::runtime_error("ModelLocker('cpu'): its actors run on a GPU in f32 mode and no HIP device is visible; "
+                               "this engine has no CPU actor path");
     ++inFlight_[latest_];
     return Lease{latest_, kind_, online_[latest_], target_[latest_]};
   }
@@ -243,10 +307,15 @@ class ModelLocker {
   Kind kind() const { return kind_; }
   double eta() const { return eta_; }
 
-  const std::string device;
-  const int deviceIndex;
+  const std::string device;  // what the caller asked for (public member of the reference class, model_locker.h:54)
+  const int deviceIndex;     // -1 for "cpu"
+  const int execDevice;      // the GPU this locker's nets live on and its actors run on
 
  private:
+  static int cpuLockerDevice() {
+    const char* e = std::getenv("RELA_CPU_LOCKER_DEVICE");
+    return e ? std::atoi(e) : 0;
+  }
   void destroyNet(void* p) {
     if (!p) return;
     if (kind_ == kFF) rela_ffnet_destroy(static_cast<rela_ffnet*>(p));
@@ -259,20 +328,20 @@ class ModelLocker {
       const std::string key = prefix + k;
       if (!sd.contains(py::str(key))) throw std::runtime_error("ModelLocker: state_dict has no '" + key + "'");
       auto t = sd[py::str(key)].cast<torch::Tensor>().detach();
-      out.push_back(t.to(torch::Device(torch::kCUDA, (c10::DeviceIndex)deviceIndex), torch::kFloat32).contiguous());
+      out.push_back(t.to(torch::Device(torch::kCUDA, (c10::DeviceIndex)execDevice), torch::kFloat32).contiguous());
     }
     return out;
   }
 
   // RELA_PRECISION=bf16x2: the actors' conv trunks on split-bf16 MFMA (Q within 2e-6 of the default exact f32 mode,
   // DESIGN 4.3b); anything else keeps the parity mode
-  static bool fastPrecision() {
+  bool fastPrecision() const {
     const char* e = std::getenv("RELA_PRECISION");
-    return e && std::string(e) == "bf16x2";
+    return deviceIndex >= 0 && e && std::string(e) == "bf16x2";  // ("cpu" lockers: always the f32 parity mode)
   }
 
   void loadNet(void*& net, py::dict& sd, const std::string& prefix) {
-    void* stream = torchCurrentStream(deviceIndex);
+    void* stream = torchCurrentStream(execDevice);
     std::vector<torch::Tensor> t;
     if (kind_ == kFF) {
       t = fetch(sd, prefix, {"net.0.weight", "net.0.bias", "net.2.weight", "net.2.bias", "net.4.weight", "net.4.bias",
@@ -281,7 +350,7 @@ class ModelLocker {
       checkActions(A);
       auto* n = static_cast<rela_ffnet*>(net);
       if (!n) {
-        check(rela_ffnet_create(&n, A, deviceIndex), "rela_ffnet_create");
+        check(rela_ffnet_create(&n, A, execDevice), "rela_ffnet_create");
         check(rela_ffnet_set_precision(n, fastPrecision() ? 1 : 0), "rela_ffnet_set_precision");
       }
       net = n;
@@ -296,7 +365,7 @@ class ModelLocker {
       checkActions(A);
       auto* n = static_cast<rela_lstmnet*>(net);
       if (!n) {
-        check(rela_lstmnet_create(&n, A, deviceIndex), "rela_lstmnet_create");
+        check(rela_lstmnet_create(&n, A, execDevice), "rela_lstmnet_create");
         check(rela_lstmnet_set_precision(n, fastPrecision() ? 1 : 0), "rela_lstmnet_set_precision");
       }
       net = n;
@@ -305,7 +374,7 @@ class ModelLocker {
       check(rela_lstmnet_load(n, &p, 1, stream), "rela_lstmnet_load");
     }
     // the packing kernels read `t` on torch's stream: finish them before the tensors die
-    py::module_::import("torch").attr("cuda").attr("current_stream")(deviceIndex).attr("synchronize")();
+    py::module_::import("torch").attr("cuda").attr("current_stream")(execDevice).attr("synchronize")();
   }
 
   void checkActions(int A) {
@@ -316,7 +385,7 @@ class ModelLocker {
   void loadSlot(int id, py::object& pyModel) {
     // Leases are released when an actor has QUEUED its kernels; drain the device so nothing that
     // still reads this slot's old weights is in flight (the reference's model call is synchronous).
-    py::module_::import("torch").attr("cuda").attr("synchronize")(deviceIndex);
+    py::module_::import("torch").attr("cuda").attr("synchronize")(execDevice);
     py::dict sd = pyModel.attr("state_dict")();
     if (!kindKnown_) {
       kind_ = sd.contains(py::str("online_net.lstm.weight_ih_l0")) ? kLSTM : kFF;
@@ -338,9 +407,146 @@ class ModelLocker {
   std::condition_variable cv_;
 };
 
-// Not in the reference's surface: what a replay PARTITION contributes to the importance weights of a batch
-// drawn over several partitions -- the un-normalised weights w_i of the last sample, the float
-// sum they were drawn against and the size its weights used (prioritized_replay.h:289,261,312).
+// =====================================================================================
+// One Python replay object = one PARTITION per ModelLocker that feeds it.
+//
+// The reference builds one ModelLocker per act device in ONE process and deals the actor threads round-robin onto
+// them, all inserting into the single host-RAM replay (pyrela/main.py:131-136,155,166).  Here a replay partition
+// lives in the HBM of the GPU whose actors fill it, so the one Python object owns one partition per locker (= per act
+// device in the reference's wiring; two lockers on one device give two partitions on it, which is how a one-GPU box
+// tests the path): capacity / G slots each, generator seed + g.  sample(B) draws B / G rows from every partition --
+// each bit-identical to a reference PrioritizedReplay(capacity / G, seed + g) fed that partition's insertion stream
+// and asked for B / G -- concatenates them on the requested device (peer copies over xGMI between GPUs) and
+// normalises the importance weights over ALL partitions:  w_i = (N_total p_i / (G sum_g))^-beta / max  (every
+// partition contributes exactly B / G of the B draws, so item i of partition g is drawn with probability
+// p_i / (G sum_g); equal to prioritized_replay.h:320-322 when G = 1, where the library's own weights are returned
+// untouched).  update_priority routes slice g of the priorities to partition g.  Context.start() announces the
+// lockers (plan); a replay nobody planned has one partition.
+// =====================================================================================
+class ReplayParts {
+ public:
+  struct Part {
+    rela_replay* h = nullptr;
+    int device = -1;
+    const void* key = nullptr;
+  };
+
+  ReplayParts(int capacity, int seed, float alpha, float beta, int prefetch)
+      : capacity_(capacity), seed_(seed), alpha_(alpha), beta_(beta), prefetch_(prefetch) {}
+  ~ReplayParts() {
+    for (auto& p : parts_) rela_replay_destroy(p.h);
+  }
+
+  void plan(const std::vector<const void*>& keys) {
+    std::lock_guard<std::mutex> lk(m_);
+    if (!parts_.empty()) return;  // (a second Context on the same replay: the partitions exist already)
+    planned_ = keys;
+  }
+
+  // the partition of the locker `key` on `device`, created by its first actor; setSchema(h) fixes the row layout
+  template <class F>
+  rela_replay* handle(const void* key, int device, F&& setSchema) {
+    std::lock_guard<std::mutex> lk(m_);
+    for (auto& p : parts_)
+      if (p.key == key) {
+        if (p.device != device) throw std::runtime_error("replay partition: one ModelLocker lives on one device");
+        return p.h;
+      }
+    const int G = planned_.empty() ? 1 : (int)planned_.size();
+    if ((int)parts_.size() >= G)
+      throw std::runtime_error("replay: an actor of a ModelLocker the Context did not announce (one partition per "
+                               "locker; all actors must be pushed before Context.start())");
+    if (capacity_ / G < 1) throw std::runtime_error("replay: capacity smaller than the number of partitions");
+    Part p;
+    p.key = key;
+    p.device = device;
+    check(rela_replay_create(&p.h, capacity_ / G, seed_ + (int)parts_.size(), alpha_, beta_, prefetch_, device),
+          "rela_replay_create");
+    try {
+      setSchema(p.h);
+    } catch (...) {
+      rela_replay_destroy(p.h);
+      throw;
+    }
+    parts_.push_back(p);
+    return p.h;
+  }
+
+  int size() const {
+    std::lock_guard<std::mutex> lk(m_);
+    int n = 0;
+    for (auto& p : parts_) n += rela_replay_size(p.h);
+    return n;
+  }
+  int numAdd() const {
+    std::lock_guard<std::mutex> lk(m_);
+    int64_t n = 0;
+    for (auto& p : parts_) n += rela_replay_num_add(p.h);
+    return (int)n;
+  }
+  void shutdown() {
+    std::lock_guard<std::mutex> lk(m_);
+    for (auto& p : parts_) rela_replay_shutdown(p.h);
+  }
+  std::vector<Part> parts() const {
+    std::lock_guard<std::mutex> lk(m_);
+    return parts_;
+  }
+  int expected() const {
+    std::lock_guard<std::mutex> lk(m_);
+    return planned_.empty() ? 1 : (int)planned_.size();
+  }
+
+  // importance weights of a batch drawn over G partitions (see the class comment); raw[g] / sum[g] on `target`
+  torch::Tensor globalWeights(const std::vector<torch::Tensor>& raw, const std::vector<torch::Tensor>& sum,
+                              const std::vector<int>& size) const {
+    const int G = (int)raw.size();
+    double total = 0;
+    for (int n : size) total += n;
+    std::vector<torch::Tensor> w;
+    for (int g = 0; g < G; ++g) w.push_back((raw[g] * (float)total / (sum[g] * (float)G)).pow(-beta_));
+    auto all = torch::cat(w, 0);
+    return all / all.max();
+  }
+
+  void updatePriority(const torch::Tensor& priority, const std::vector<int>& counts, const char* where) {
+    auto ps = parts();
+    auto p = priority.detach().to(torch::kFloat32).contiguous();
+    int64_t total = 0;
+    for (int c : counts) total += c;
+    if (counts.size() != ps.size() || p.numel() != total)
+      throw std::runtime_error(std::string(where) + ": expected the priorities of the last batch");
+    int64_t off = 0;
+    keep_.clear();
+    for (size_t g = 0; g < ps.size(); ++g) {
+      auto chunk = ps.size() == 1 ? p : p.narrow(0, off, counts[g]);
+      off += counts[g];
+      if (chunk.is_cuda()) {
+        if (chunk.device().index() != ps[g].device) chunk = chunk.to(torch::Device(torch::kCUDA, (c10::DeviceIndex)ps[g].device));
+        chunk = chunk.contiguous();
+        check(rela_replay_update_priority(ps[g].h, (int)chunk.numel(), chunk.data_ptr<float>(), 1, torchCurrentStream(ps[g].device)), where);
+        keep_.push_back(chunk);  // consumed asynchronously on the replay's stream
+      } else {
+        chunk = chunk.contiguous();
+        check(rela_replay_update_priority(ps[g].h, (int)chunk.numel(), chunk.data_ptr<float>(), 0, nullptr), where);
+      }
+    }
+  }
+
+  const int capacity_, seed_;
+  const float alpha_, beta_;
+  const int prefetch_;
+
+ private:
+  mutable std::mutex m_;
+  std::vector<Part> parts_;
+  std::vector<const void*> planned_;
+  std::vector<torch::Tensor> keep_;
+};
+
+// what a PARTITION contributes to the importance weights of a batch drawn over several: the un-normalised
+// weights w_i of its last sample, the float sum they were drawn against and the size its weights used
+// (prioritized_replay.h:289,261,312)
 static std::tuple<torch::Tensor, torch::Tensor, int> lastSampleRaw(rela_replay* h, int device, int n) {
   if (!h || n <= 0) throw std::runtime_error("last_sample_raw: nothing was sampled");
   const float* raw = nullptr;
@@ -353,21 +559,27 @@ static std::tuple<torch::Tensor, torch::Tensor, int> lastSampleRaw(rela_replay* 
   return std::make_tuple(w, s, rela_replay_last_sample_size(h));
 }
 
+static torch::Device deviceOf(const std::string& device) {
+  const int want = parseDevice(device);
+  return want < 0 ? torch::Device(torch::kCPU) : torch::Device(torch::kCUDA, (c10::DeviceIndex)want);
+}
+
 // =====================================================================================
 // FFPrioritizedReplay (rela/prioritized_replay.h:173-348 as bound in pybind.cc:37-47)
 // =====================================================================================
 class FFPrioritizedReplay {
  public:
   FFPrioritizedReplay(int capacity, int seed, float alpha, float beta, int prefetch)
-      : capacity_(capacity), seed_(seed), alpha_(alpha), beta_(beta), prefetch_(prefetch) {}
+      : core_(capacity, seed, alpha, beta, prefetch) {}
 
-  ~FFPrioritizedReplay() { rela_replay_destroy(h_); }
+  ReplayParts& core() { return core_; }
 
-  // created lazily by the first actor that knows the device and the action count
-  rela_replay* handle(int device, int numAction) {
-    std::lock_guard<std::mutex> lk(m_);
-    if (!h_) {
-      check(rela_replay_create(&h_, capacity_, seed_, alpha_, beta_, prefetch_, device), "rela_replay_create");
+  // the partition of `lockerKey`, created lazily by the first actor that knows the device and the action count
+  rela_replay* handle(const void* lockerKey, int device, int numAction) {
+    if (numAction_ != 0 && numAction != numAction_)
+      throw std::runtime_error("FFPrioritizedReplay: actors disagree on the action count");
+    numAction_ = numAction;
+    return core_.handle(lockerKey, device, [&](rela_replay* h) {
       const int64_t A = numAction;
       const int64_t rb[10] = {kObsBytes, kObsBytes, 4, 4, 4 * A, 4 * A, 8, 4, 1, 4};
       // RELA_REPLAY_DEDUP=stack|plane: frame-stack de-duplication (include/rela_amd.h).  "stack" is
@@ -378,26 +590,16 @@ class FFPrioritizedReplay {
       if (ups > 0) {
         const char* gd = std::getenv("RELA_REPLAY_DEDUP_GUARD");
         const int64_t guard = gd ? std::atoll(gd) : 131072;  // units stored ahead of their transitions
-        check(rela_replay_set_schema_dedup(h_, 10, rb, 0, 1, kObsBytes / ups, ups, guard), "rela_replay_set_schema_dedup");
+        check(rela_replay_set_schema_dedup(h, 10, rb, 0, 1, kObsBytes / ups, ups, guard), "rela_replay_set_schema_dedup");
       } else {
-        check(rela_replay_set_schema(h_, 10, rb), "rela_replay_set_schema");
+        check(rela_replay_set_schema(h, 10, rb), "rela_replay_set_schema");
       }
-      device_ = device;
-      numAction_ = numAction;
-    } else if (device != device_ || numAction != numAction_) {
-      throw std::runtime_error(
-          "FFPrioritizedReplay: one replay partition lives on one GPU; actors on another device need their own "
-          "partition (SURVEY 8e)");
-    }
-    return h_;
+    });
   }
 
-  int size() const { return h_ ? rela_replay_size(h_) : 0; }
-  int numAdd() const { return h_ ? (int)rela_replay_num_add(h_) : 0; }
-  void shutdown() {
-    std::lock_guard<std::mutex> lk(m_);
-    if (h_) rela_replay_shutdown(h_);
-  }
+  int size() const { return core_.size(); }
+  int numAdd() const { return core_.numAdd(); }
+  void shutdown() { core_.shutdown(); }
 
   // prefetch > 0 (rela/prioritized_replay.h:223-230: sampler futures that run next to the learner): here a DEVICE-side
   // prefetch -- update_priority k queues sample k + 1 right behind itself on the replay's stream, so its latency-bound
@@ -414,12 +616,12 @@ class FFPrioritizedReplay {
     return sampleNow(batchsize, device);
   }
 
-  std::tuple<FFTransition, torch::Tensor> sampleNow(int batchsize, const std::string& device) {
-    if (!h_) throw std::runtime_error("FFPrioritizedReplay.sample: the replay is empty");
-    const auto dev = torch::Device(torch::kCUDA, (c10::DeviceIndex)device_);
+  // B rows of one partition, on the partition's own device
+  std::tuple<FFTransition, torch::Tensor> samplePart(const ReplayParts::Part& p, int B_) {
+    const auto dev = torch::Device(torch::kCUDA, (c10::DeviceIndex)p.device);
     auto u8 = torch::TensorOptions().dtype(torch::kUInt8).device(dev);
     auto f32 = torch::TensorOptions().dtype(torch::kFloat32).device(dev);
-    const int64_t B = batchsize, A = numAction_;
+    const int64_t B = B_, A = numAction_;
     FFTransition b;
     b.obs["s"] = torch::empty({B, 4, 84, 84}, u8);
     b.nextObs["s"] = torch::empty({B, 4, 84, 84}, u8);
@@ -436,40 +638,79 @@ class FFPrioritizedReplay {
                       b.nextObs["eps"].data_ptr(),    b.obs["legal_move"].data_ptr(),     b.nextObs["legal_move"].data_ptr(),
                       b.action["a"].data_ptr(),       b.reward.data_ptr(),                b.terminal.data_ptr(),
                       b.bootstrap.data_ptr()};
-    check(rela_replay_sample(h_, batchsize, rows, weight.data_ptr<float>(), torchCurrentStream(device_)),
+    check(rela_replay_sample(p.h, B_, rows, weight.data_ptr<float>(), torchCurrentStream(p.device)),
           "FFPrioritizedReplay.sample");
-    lastBatch_ = batchsize;
-    lastDevice_ = device;
-    const int want = parseDevice(device);
-    if (want != device_) {  // learner on another GPU (or the cpu): move the batch, types.cc:34-43
-      const auto target = want < 0 ? torch::Device(torch::kCPU) : torch::Device(torch::kCUDA, (c10::DeviceIndex)want);
-      auto mv = [&](torch::Tensor& t) { t = t.to(target); };
-      for (auto* d : {&b.obs, &b.action, &b.nextObs})
-        for (auto& kv : *d) mv(kv.second);
-      mv(b.reward);
-      mv(b.terminal);
-      mv(b.bootstrap);
-      mv(weight);
-    }
     return std::make_tuple(std::move(b), weight);
   }
 
-  std::tuple<torch::Tensor, torch::Tensor, int> lastSampleRaw_() { return lastSampleRaw(h_, device_, lastBatch_); }
+  std::tuple<FFTransition, torch::Tensor> sampleNow(int batchsize, const std::string& device) {
+    auto parts = core_.parts();
+    if (parts.empty()) throw std::runtime_error("FFPrioritizedReplay.sample: the replay is empty");
+    const int G = (int)parts.size();
+    if (G != core_.expected())
+      throw std::runtime_error("FFPrioritizedReplay.sample: only " + std::to_string(G) + " of " +
+                               std::to_string(core_.expected()) + " partitions have received data yet");
+    if (batchsize % G != 0)
+      throw std::runtime_error("FFPrioritizedReplay.sample: the batch must split evenly over the " + std::to_string(G) +
+                               " partitions (one per ModelLocker)");
+    const auto target = deviceOf(device);
+    lastBatch_ = batchsize;
+    lastDevice_ = device;
+    lastCounts_.assign(G, batchsize / G);
+    if (G == 1) {
+      FFTransition b;
+      torch::Tensor weight;
+      std::tie(b, weight) = samplePart(parts[0], batchsize);
+      if (target != torch::Device(torch::kCUDA, (c10::DeviceIndex)parts[0].device)) {  // learner elsewhere: types.cc:34-43
+        auto mv = [&](torch::Tensor& t) { t = t.to(target); };
+        for (auto* d : {&b.obs, &b.action, &b.nextObs})
+          for (auto& kv : *d) mv(kv.second);
+        mv(b.reward);
+        mv(b.terminal);
+        mv(b.bootstrap);
+        mv(weight);
+      }
+      return std::make_tuple(std::move(b), weight);
+    }
+    std::vector<FFTransition> sub(G);
+    std::vector<torch::Tensor> raw, sum;
+    std::vector<int> size;
+    for (int g = 0; g < G; ++g) {
+      torch::Tensor w;
+      std::tie(sub[g], w) = samplePart(parts[g], batchsize / G);
+      auto r = lastSampleRaw(parts[g].h, parts[g].device, batchsize / G);
+      raw.push_back(std::get<0>(r).to(target));
+      sum.push_back(std::get<1>(r).to(target));
+      size.push_back(std::get<2>(r));
+    }
+    auto catOf = [&](auto get) {
+      std::vector<torch::Tensor> v;
+      for (int g = 0; g < G; ++g) v.push_back(get(sub[g]).to(target));
+      return torch::cat(v, 0);
+    };
+    FFTransition b;
+    for (const char* k : {"s", "eps", "legal_move"}) {
+      b.obs[k] = catOf([&](FFTransition& t) { return t.obs.at(k); });
+      b.nextObs[k] = catOf([&](FFTransition& t) { return t.nextObs.at(k); });
+    }
+    b.action["a"] = catOf([](FFTransition& t) { return t.action.at("a"); });
+    b.reward = catOf([](FFTransition& t) { return t.reward; });
+    b.terminal = catOf([](FFTransition& t) { return t.terminal; });
+    b.bootstrap = catOf([](FFTransition& t) { return t.bootstrap; });
+    return std::make_tuple(std::move(b), core_.globalWeights(raw, sum, size));
+  }
+
+  std::tuple<torch::Tensor, torch::Tensor, int> lastSampleRaw_() {
+    auto parts = core_.parts();
+    if (parts.size() != 1) throw std::runtime_error("last_sample_raw: this replay has several partitions of its own");
+    return lastSampleRaw(parts[0].h, parts[0].device, lastBatch_);
+  }
 
   void updatePriority(const torch::Tensor& priority) {
-    if (!h_) throw std::runtime_error("FFPrioritizedReplay.update_priority: nothing was sampled");
+    if (lastBatch_ == 0) throw std::runtime_error("FFPrioritizedReplay.update_priority: nothing was sampled");
     if (priority.dim() != 1) throw std::invalid_argument("update_priority expects a 1-D tensor");  // :236
-    auto p = priority.detach().to(torch::kFloat32).contiguous();
-    if (p.is_cuda()) {
-      if (p.device().index() != device_) p = p.to(torch::Device(torch::kCUDA, (c10::DeviceIndex)device_));
-      check(rela_replay_update_priority(h_, (int)p.numel(), p.data_ptr<float>(), 1, torchCurrentStream(device_)),
-            "FFPrioritizedReplay.update_priority");
-      keep_ = p;  // consumed asynchronously on the replay's stream
-    } else {
-      check(rela_replay_update_priority(h_, (int)p.numel(), p.data_ptr<float>(), 0, nullptr),
-            "FFPrioritizedReplay.update_priority");
-    }
-    if (prefetch_ > 0 && lastBatch_ > 0 && rela_replay_size(h_) >= lastBatch_) {
+    core_.updatePriority(priority, lastCounts_, "FFPrioritizedReplay.update_priority");
+    if (core_.prefetch_ > 0 && core_.size() >= lastBatch_) {
       prefetched_.emplace(sampleNow(lastBatch_, lastDevice_));
       prefetchedBatch_ = lastBatch_;
       prefetchedDevice_ = lastDevice_;
@@ -477,15 +718,11 @@ class FFPrioritizedReplay {
   }
 
  private:
-  const int capacity_, seed_;
-  const float alpha_, beta_;
-  const int prefetch_;
-  std::mutex m_;
-  rela_replay* h_ = nullptr;
-  int device_ = -1, numAction_ = 0;
+  ReplayParts core_;
+  int numAction_ = 0;
   int lastBatch_ = 0;
+  std::vector<int> lastCounts_;
   std::string lastDevice_;
-  torch::Tensor keep_;
   std::optional<std::tuple<FFTransition, torch::Tensor>> prefetched_;
   int prefetchedBatch_ = 0;
   std::string prefetchedDevice_;
@@ -498,32 +735,26 @@ class FFPrioritizedReplay {
 class RNNPrioritizedReplay {
  public:
   RNNPrioritizedReplay(int capacity, int seed, float alpha, float beta, int prefetch)
-      : capacity_(capacity), seed_(seed), alpha_(alpha), beta_(beta), prefetch_(prefetch) {}
-  ~RNNPrioritizedReplay() { rela_replay_destroy(h_); }
+      : core_(capacity, seed, alpha, beta, prefetch) {}
 
-  rela_replay* handle(int device, int numAction, int T) {
-    std::lock_guard<std::mutex> lk(m_);
-    if (!h_) {
-      check(rela_replay_create(&h_, capacity_, seed_, alpha_, beta_, prefetch_, device), "rela_replay_create");
+  ReplayParts& core() { return core_; }
+
+  rela_replay* handle(const void* lockerKey, int device, int numAction, int T) {
+    if (numAction_ != 0 && (numAction != numAction_ || T != T_))
+      throw std::runtime_error("RNNPrioritizedReplay: actors disagree on action count / window length");
+    numAction_ = numAction;
+    T_ = T;
+    return core_.handle(lockerKey, device, [&](rela_replay* h) {
       const int64_t A = numAction, t = T;
       const int64_t rb[10] = {t * kObsBytes, t * 4, t * 4 * A, t * 8, t * 4, t, t * 4, 2048, 2048, 4};
       const int32_t st[10] = {T, T, T, T, T, T, T, 1, 1, 1};
-      check(rela_replay_set_schema_seq(h_, 10, rb, st), "rela_replay_set_schema_seq");
-      device_ = device;
-      numAction_ = numAction;
-      T_ = T;
-    } else if (device != device_ || numAction != numAction_ || T != T_) {
-      throw std::runtime_error("RNNPrioritizedReplay: actors disagree on device / action count / window length");
-    }
-    return h_;
+      check(rela_replay_set_schema_seq(h, 10, rb, st), "rela_replay_set_schema_seq");
+    });
   }
 
-  int size() const { return h_ ? rela_replay_size(h_) : 0; }
-  int numAdd() const { return h_ ? (int)rela_replay_num_add(h_) : 0; }
-  void shutdown() {
-    std::lock_guard<std::mutex> lk(m_);
-    if (h_) rela_replay_shutdown(h_);
-  }
+  int size() const { return core_.size(); }
+  int numAdd() const { return core_.numAdd(); }
+  void shutdown() { core_.shutdown(); }
 
   // (prefetch: as FFPrioritizedReplay::sample)
   std::tuple<RNNTransition, torch::Tensor> sample(int batchsize, const std::string& device) {
@@ -536,11 +767,10 @@ class RNNPrioritizedReplay {
     return sampleNow(batchsize, device);
   }
 
-  std::tuple<RNNTransition, torch::Tensor> sampleNow(int batchsize, const std::string& device) {
-    if (!h_) throw std::runtime_error("RNNPrioritizedReplay.sample: the replay is empty");
-    const auto dev = torch::Device(torch::kCUDA, (c10::DeviceIndex)device_);
+  std::tuple<RNNTransition, torch::Tensor> samplePart(const ReplayParts::Part& p, int B_) {
+    const auto dev = torch::Device(torch::kCUDA, (c10::DeviceIndex)p.device);
     auto opt = [&](torch::ScalarType t) { return torch::TensorOptions().dtype(t).device(dev); };
-    const int64_t B = batchsize, A = numAction_, T = T_;
+    const int64_t B = B_, A = numAction_, T = T_;
     RNNTransition b;
     b.obs["s"] = torch::empty({T, B, 4, 84, 84}, opt(torch::kUInt8));
     b.obs["eps"] = torch::empty({T, B, 1}, opt(torch::kFloat32));
@@ -556,61 +786,94 @@ class RNNPrioritizedReplay {
     void* rows[10] = {b.obs["s"].data_ptr(), b.obs["eps"].data_ptr(), b.obs["legal_move"].data_ptr(),
                       b.action["a"].data_ptr(), b.reward.data_ptr(), b.terminal.data_ptr(), b.bootstrap.data_ptr(),
                       b.h0["h0"].data_ptr(), b.h0["c0"].data_ptr(), b.seqLen.data_ptr()};
-    check(rela_replay_sample(h_, batchsize, rows, weight.data_ptr<float>(), torchCurrentStream(device_)),
+    check(rela_replay_sample(p.h, B_, rows, weight.data_ptr<float>(), torchCurrentStream(p.device)),
           "RNNPrioritizedReplay.sample");
-    lastBatch_ = batchsize;
-    lastDevice_ = device;
-    const int want = parseDevice(device);
-    if (want != device_) {
-      const auto target = want < 0 ? torch::Device(torch::kCPU) : torch::Device(torch::kCUDA, (c10::DeviceIndex)want);
-      auto mv = [&](torch::Tensor& t) { t = t.to(target); };
-      for (auto* d : {&b.obs, &b.action, &b.h0})
-        for (auto& kv : *d) mv(kv.second);
-      mv(b.reward);
-      mv(b.terminal);
-      mv(b.bootstrap);
-      mv(b.seqLen);
-      mv(weight);
-    }
     return std::make_tuple(std::move(b), weight);
   }
 
-  void updatePriority(const torch::Tensor& priority) {
-    if (!h_) throw std::runtime_error("RNNPrioritizedReplay.update_priority: nothing was sampled");
-    if (priority.dim() != 1) throw std::invalid_argument("update_priority expects a 1-D tensor");
-    auto p = priority.detach().to(torch::kFloat32).contiguous();
-    if (p.is_cuda()) {
-      if (p.device().index() != device_) p = p.to(torch::Device(torch::kCUDA, (c10::DeviceIndex)device_));
-      check(rela_replay_update_priority(h_, (int)p.numel(), p.data_ptr<float>(), 1, torchCurrentStream(device_)),
-            "RNNPrioritizedReplay.update_priority");
-      keep_ = p;
-    } else {
-      check(rela_replay_update_priority(h_, (int)p.numel(), p.data_ptr<float>(), 0, nullptr),
-            "RNNPrioritizedReplay.update_priority");
+  std::tuple<RNNTransition, torch::Tensor> sampleNow(int batchsize, const std::string& device) {
+    auto parts = core_.parts();
+    if (parts.empty()) throw std::runtime_error("RNNPrioritizedReplay.sample: the replay is empty");
+    const int G = (int)parts.size();
+    if (G != core_.expected())
+      throw std::runtime_error("RNNPrioritizedReplay.sample: only " + std::to_string(G) + " of " +
+                               std::to_string(core_.expected()) + " partitions have received data yet");
+    if (batchsize % G != 0)
+      throw std::runtime_error("RNNPrioritizedReplay.sample: the batch must split evenly over the " + std::to_string(G) +
+                               " partitions (one per ModelLocker)");
+    const auto target = deviceOf(device);
+    lastBatch_ = batchsize;
+    lastDevice_ = device;
+    lastCounts_.assign(G, batchsize / G);
+    if (G == 1) {
+      RNNTransition b;
+      torch::Tensor weight;
+      std::tie(b, weight) = samplePart(parts[0], batchsize);
+      if (target != torch::Device(torch::kCUDA, (c10::DeviceIndex)parts[0].device)) {
+        auto mv = [&](torch::Tensor& t) { t = t.to(target); };
+        for (auto* d : {&b.obs, &b.action, &b.h0})
+          for (auto& kv : *d) mv(kv.second);
+        mv(b.reward);
+        mv(b.terminal);
+        mv(b.bootstrap);
+        mv(b.seqLen);
+        mv(weight);
+      }
+      return std::make_tuple(std::move(b), weight);
     }
-    if (prefetch_ > 0 && lastBatch_ > 0 && rela_replay_size(h_) >= lastBatch_) {
+    std::vector<RNNTransition> sub(G);
+    std::vector<torch::Tensor> raw, sum;
+    std::vector<int> size;
+    for (int g = 0; g < G; ++g) {
+      torch::Tensor w;
+      std::tie(sub[g], w) = samplePart(parts[g], batchsize / G);
+      auto r = lastSampleRaw(parts[g].h, parts[g].device, batchsize / G);
+      raw.push_back(std::get<0>(r).to(target));
+      sum.push_back(std::get<1>(r).to(target));
+      size.push_back(std::get<2>(r));
+    }
+    auto catOf = [&](auto get, int dim) {  // time-major fields stack along their batch axis (types.cc:140-182: dim 1)
+      std::vector<torch::Tensor> v;
+      for (int g = 0; g < G; ++g) v.push_back(get(sub[g]).to(target));
+      return torch::cat(v, dim);
+    };
+    RNNTransition b;
+    for (const char* k : {"s", "eps", "legal_move"}) b.obs[k] = catOf([&](RNNTransition& t) { return t.obs.at(k); }, 1);
+    b.action["a"] = catOf([](RNNTransition& t) { return t.action.at("a"); }, 1);
+    b.reward = catOf([](RNNTransition& t) { return t.reward; }, 1);
+    b.terminal = catOf([](RNNTransition& t) { return t.terminal; }, 1);
+    b.bootstrap = catOf([](RNNTransition& t) { return t.bootstrap; }, 1);
+    for (const char* k : {"h0", "c0"}) b.h0[k] = catOf([&](RNNTransition& t) { return t.h0.at(k); }, 1);
+    b.seqLen = catOf([](RNNTransition& t) { return t.seqLen; }, 0);
+    return std::make_tuple(std::move(b), core_.globalWeights(raw, sum, size));
+  }
+
+  void updatePriority(const torch::Tensor& priority) {
+    if (lastBatch_ == 0) throw std::runtime_error("RNNPrioritizedReplay.update_priority: nothing was sampled");
+    if (priority.dim() != 1) throw std::invalid_argument("update_priority expects a 1-D tensor");
+    core_.updatePriority(priority, lastCounts_, "RNNPrioritizedReplay.update_priority");
+    if (core_.prefetch_ > 0 && core_.size() >= lastBatch_) {
       prefetched_.emplace(sampleNow(lastBatch_, lastDevice_));
       prefetchedBatch_ = lastBatch_;
       prefetchedDevice_ = lastDevice_;
     }
   }
 
+  std::tuple<torch::Tensor, torch::Tensor, int> lastSampleRaw_() {
+    auto parts = core_.parts();
+    if (parts.size() != 1) throw std::runtime_error("last_sample_raw: this replay has several partitions of its own");
+    return lastSampleRaw(parts[0].h, parts[0].device, lastBatch_);
+  }
+
  private:
-  const int capacity_, seed_;
-  const float alpha_, beta_;
-  const int prefetch_;
-  std::mutex m_;
-  rela_replay* h_ = nullptr;
-  int device_ = -1, numAction_ = 0, T_ = 0;
+  ReplayParts core_;
+  int numAction_ = 0, T_ = 0;
   int lastBatch_ = 0;
+  std::vector<int> lastCounts_;
   std::string lastDevice_;
-  torch::Tensor keep_;
   std::optional<std::tuple<RNNTransition, torch::Tensor>> prefetched_;
   int prefetchedBatch_ = 0;
   std::string prefetchedDevice_;
-
- public:
-  std::tuple<torch::Tensor, torch::Tensor, int> lastSampleRaw_() { return lastSampleRaw(h_, device_, lastBatch_); }
 };
 
 // the actor side of a de-duplicating replay (RELA_REPLAY_DEDUP, see FFPrioritizedReplay::handle)
@@ -652,7 +915,7 @@ class ActorCohort {
   ~ActorCohort() {
     rela_apex_actor_destroy(h_);
     rela_r2d2_actor_destroy(hr_);
-    const int dev = locker_->deviceIndex;
+    const int dev = locker_->execDevice;
     if (compute_) rela_stream_destroy(compute_, dev);
     if (upload_) rela_stream_destroy(upload_, dev);
   }
@@ -667,19 +930,40 @@ class ActorCohort {
       throw std::runtime_error("DQNActor.act: obs['s'] must be uint8 [batchsize,4,84,84]");
     const int A = (int)legal.size(1);
     const int64_t tPrep = gStats.on ? ThreadedStats::now() : 0;
-    std::unique_lock<std::mutex> lk(m_);
-    if (draining_) return drained();
-    if (!created_) create(A);
-    // this member's rows: frames go straight to the HBM history slot on the upload stream,
-    // the per-env constants to the host staging (uploaded by the leader when they changed)
+    void* slot = nullptr;
+    bool planes = false;
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      if (draining_) return drained();
+      if (!created_) create(A);
+      // (the slot moves only inside the leader's work, which every member of the round has left by now)
+      slot = lstm_ ? rela_r2d2_actor_obs_slot(hr_) : rela_apex_actor_obs_slot(h_);
+      // a VectorEnv whose envs all slide their frame stack marks its batch (rela/env.h): only plane 3 of every row is
+      // new; the very first observation has no predecessor on the device and goes up whole
+      planes = planeUpload_ && !firstRound_ && obs.count("__stack_restart") != 0;
+    }
+    // this member's rows: frames go to the HBM history slot on the upload stream -- outside the cohort's lock, the
+    // rows of different members are disjoint -- the per-env constants to the host staging under it
     auto sc = s.contiguous();
-    void* slot = lstm_ ? rela_r2d2_actor_obs_slot(hr_) : rela_apex_actor_obs_slot(h_);
-    check(rela_memcpy_h2d_async(static_cast<uint8_t*>(slot) + (int64_t)member * K_ * kObsBytes,
-                                sc.data_ptr(), (int64_t)K_ * kObsBytes, upload_, locker_->deviceIndex),
-          "rela_memcpy_h2d_async");
-    keepObs_[member] = sc;
+    const int dev = locker_->execDevice;
+    uint8_t* dst = static_cast<uint8_t*>(slot) + (int64_t)member * K_ * kObsBytes;
+    uint8_t* flags = restartAll_.data_ptr<uint8_t>() + (int64_t)member * K_;
+    if (planes) {
+      constexpr int64_t kPlane = 84 * 84;
+      check(rela_memcpy2d_h2d_async(dst + 3 * kPlane, kObsBytes, sc.data_ptr<uint8_t>() + 3 * kPlane, kObsBytes, kPlane, K_,
+                                    upload_, dev),
+            "rela_memcpy2d_h2d_async");
+      std::memcpy(flags, obs.at("__stack_restart").data_ptr<uint8_t>(), (size_t)K_);
+    } else {
+      check(rela_memcpy_h2d_async(dst, sc.data_ptr(), (int64_t)K_ * kObsBytes, upload_, dev), "rela_memcpy_h2d_async");
+      std::memset(flags, 2, (size_t)K_);  // 2 = the row went up whole: slide_stacks leaves it alone
+    }
     auto e = eps.reshape({K_}).to(torch::kFloat32).contiguous();
     auto l = legal.to(torch::kFloat32).contiguous();
+    std::unique_lock<std::mutex> lk(m_);
+    if (draining_) return drained();
+    keepObs_[member] = sc;
+    if (planes) planesThisRound_ = true;
     float* ed = epsAll_.data_ptr<float>() + (int64_t)member * K_;
     float* ld = legalAll_.data_ptr<float>() + (int64_t)member * K_ * A;
     if (!constsValid_ || std::memcmp(ed, e.data_ptr(), e.nbytes()) != 0 || std::memcmp(ld, l.data_ptr(), l.nbytes()) != 0) {
@@ -689,7 +973,12 @@ class ActorCohort {
     }
     if (gStats.on) gStats.actPrep += ThreadedStats::now() - tPrep;
     rendezvous(lk, [&] {
-      check(rela_stream_wait_stream(compute_, upload_, locker_->deviceIndex), "rela_stream_wait_stream");
+      check(rela_stream_wait_stream(compute_, upload_, dev), "rela_stream_wait_stream");
+      if (planesThisRound_) {  // complete the stacks on the device (atari/game_state.h:53-82) before the forward
+        const uint8_t* f = restartAll_.data_ptr<uint8_t>();
+        check(lstm_ ? rela_r2d2_actor_slide_stacks(hr_, f, compute_) : rela_apex_actor_slide_stacks(h_, f, compute_),
+              "slide_stacks");
+      }
       auto lease = locker_->getModel();
       const float* e = constsDirty_ ? epsAll_.data_ptr<float>() : nullptr;
       const float* l = constsDirty_ ? legalAll_.data_ptr<float>() : nullptr;
@@ -701,6 +990,8 @@ class ActorCohort {
       check(rc, lstm_ ? "R2D2Actor.act (batched)" : "DQNActor.act (batched)");
       constsDirty_ = false;
       constsValid_ = true;
+      planesThisRound_ = false;
+      firstRound_ = false;
       gStats.ticks += 1;
     }, gStats.actWait, gStats.actLead);
     if (draining_) return drained();
@@ -735,7 +1026,7 @@ class ActorCohort {
       if (rc != RELA_EWOULDBLOCK) check(rc, "postStep (batched)");  // dropped block after shutdown
       // The next round's frames land in the history slot this tick just read (the ring reuses
       // slot `head`): uploads must start after the tick's queued kernels and row copies.
-      check(rela_stream_wait_stream(upload_, compute_, locker_->deviceIndex), "rela_stream_wait_stream");
+      check(rela_stream_wait_stream(upload_, compute_, locker_->execDevice), "rela_stream_wait_stream");
     }, gStats.postWait, gStats.postLead);
   }
 
@@ -787,7 +1078,7 @@ class ActorCohort {
     if (locker_->kind() != (lstm_ ? ModelLocker::kLSTM : ModelLocker::kFF))
       throw std::runtime_error(lstm_ ? "R2D2Actor needs an AtariLSTMNet-shaped agent in its ModelLocker"
                                      : "DQNActor needs an AtariFFNet-shaped agent in its ModelLocker");
-    const int dev = locker_->deviceIndex;
+    const int dev = locker_->execDevice;
     static std::atomic<uint64_t> counter{0};
     check(rela_stream_create(&compute_, dev), "rela_stream_create");
     check(rela_stream_create(&upload_, dev), "rela_stream_create");
@@ -795,12 +1086,12 @@ class ActorCohort {
       // one pop of the shard commits the sequences of all members as ONE block, in row (= member)
       // order; the reference would issue one block per thread (only the float block-sum grouping of
       // sum_ differs, far below the fp tolerance of the priorities themselves)
-      rela_replay* rep = rnnReplay_->handle(dev, A, burnin_ + seqLen_ + n_);
+      rela_replay* rep = rnnReplay_->handle(locker_.get(), dev, A, burnin_ + seqLen_ + n_);
       check(rela_r2d2_actor_create(&hr_, T_ * K_, K_, A, n_, gamma_, seqLen_, burnin_, locker_->eta(), rep,
                                    0xC2B2AE3D27D4EB4Full * (++counter), dev),
             "rela_r2d2_actor_create");
     } else {
-      rela_replay* rep = replay_->handle(dev, A);
+      rela_replay* rep = replay_->handle(locker_.get(), dev, A);
       check(rela_apex_actor_create(&h_, T_ * K_, K_, A, n_, gamma_, rep, 0xA24BAED4963EE407ull * (++counter), dev),
             "rela_apex_actor_create");
       enableDedup(h_, rep);
@@ -813,7 +1104,11 @@ class ActorCohort {
     legalAll_ = pin(torch::zeros({R, A}, torch::kFloat32));
     rewardAll_ = pin(torch::zeros({R}, torch::kFloat32));
     terminalAll_ = pin(torch::zeros({R}, torch::kBool));
+    restartAll_ = pin(torch::full({R}, 2, torch::kUInt8));
     keepObs_.resize(T_);
+    // RELA_PLANE_UPLOAD=0: always upload whole frame stacks (A/B switch of the sliding-stack path)
+    const char* pu = std::getenv("RELA_PLANE_UPLOAD");
+    planeUpload_ = !(pu && pu[0] == '0');
   }
 
   std::shared_ptr<ModelLocker> locker_;
@@ -828,10 +1123,11 @@ class ActorCohort {
   rela_r2d2_actor* hr_ = nullptr;
   bool created_ = false;
   void *compute_ = nullptr, *upload_ = nullptr;
-  torch::Tensor actionAll_, epsAll_, legalAll_, rewardAll_, terminalAll_;
+  torch::Tensor actionAll_, epsAll_, legalAll_, rewardAll_, terminalAll_, restartAll_;
   std::vector<torch::Tensor> keepObs_;
   std::vector<std::atomic<int64_t>> numAct_;
   bool constsValid_ = false, constsDirty_ = false, draining_ = false;
+  bool planeUpload_ = true, firstRound_ = true, planesThisRound_ = false;
   std::mutex m_;
   std::condition_variable cv_;
   int arrived_ = 0;
@@ -854,7 +1150,7 @@ class DQNActor : public Actor {
 
   ~DQNActor() override {
     rela_apex_actor_destroy(h_);
-    if (stream_) rela_stream_destroy(stream_, locker_->deviceIndex);
+    if (stream_) rela_stream_destroy(stream_, locker_->execDevice);
   }
 
   int numAct() const {
@@ -893,10 +1189,10 @@ class DQNActor : public Actor {
     const int A = (int)legal.size(1);
     if (!h_) {
       static std::atomic<uint64_t> counter{0};
-      rela_replay* rep = replay_ ? replay_->handle(locker_->deviceIndex, A) : nullptr;
-      check(rela_stream_create(&stream_, locker_->deviceIndex), "rela_stream_create");
+      rela_replay* rep = replay_ ? replay_->handle(locker_.get(), locker_->execDevice, A) : nullptr;
+      check(rela_stream_create(&stream_, locker_->execDevice), "rela_stream_create");
       check(rela_apex_actor_create(&h_, batchsize_, batchsize_, A, multiStep_, gamma_, rep,
-                                   0x9E3779B97F4A7C15ull * (++counter), locker_->deviceIndex),
+                                   0x9E3779B97F4A7C15ull * (++counter), locker_->execDevice),
             "rela_apex_actor_create");
       enableDedup(h_, rep);
       action_ = torch::zeros({batchsize_}, torch::kInt64);
@@ -983,7 +1279,7 @@ class R2D2Actor : public Actor {
 
   ~R2D2Actor() override {
     rela_r2d2_actor_destroy(h_);
-    if (stream_) rela_stream_destroy(stream_, locker_->deviceIndex);
+    if (stream_) rela_stream_destroy(stream_, locker_->execDevice);
   }
 
   int numAct() const {
@@ -1024,10 +1320,10 @@ class R2D2Actor : public Actor {
     if (!h_) {
       static std::atomic<uint64_t> counter{0};
       const int T = burnin_ + seqLen_ + multiStep_;
-      rela_replay* rep = replay_ ? replay_->handle(locker_->deviceIndex, A, T) : nullptr;
-      check(rela_stream_create(&stream_, locker_->deviceIndex), "rela_stream_create");
+      rela_replay* rep = replay_ ? replay_->handle(locker_.get(), locker_->execDevice, A, T) : nullptr;
+      check(rela_stream_create(&stream_, locker_->execDevice), "rela_stream_create");
       check(rela_r2d2_actor_create(&h_, batchsize_, batchsize_, A, multiStep_, gamma_, seqLen_, burnin_,
-                                   locker_->eta(), rep, 0xD1B54A32D192ED03ull * (++counter), locker_->deviceIndex),
+                                   locker_->eta(), rep, 0xD1B54A32D192ED03ull * (++counter), locker_->execDevice),
             "rela_r2d2_actor_create");
       action_ = torch::zeros({batchsize_}, torch::kInt64);
       if (torch::cuda::is_available()) action_ = action_.pin_memory();
@@ -1265,14 +1561,44 @@ class Context {
       }
       if (!placed) buckets.push_back({a});
     }
+    // RELA_COHORT_SPLIT (default 2): a bucket of >= 16 threads becomes that many cohorts of consecutive threads, each
+    // with its own device shard and streams, so that one cohort's env stepping and upload (host, PCIe) overlap the
+    // other's batched forward (GPU): with ONE cohort the tick is host phase + device phase, and each idles in turn.
+    int split = 2;
+    if (const char* e = std::getenv("RELA_COHORT_SPLIT")) split = std::max(1, std::atoi(e));
     for (auto& b : buckets) {
       if (b.size() < 2) continue;
-      auto cohort = make(*b.front(), (int)b.size());
-      for (size_t i = 0; i < b.size(); ++i) b[i]->joinCohort(cohort, (int)i);
+      const size_t parts = std::max<size_t>(1, std::min<size_t>((size_t)split, b.size() / 8));
+      for (size_t p = 0; p < parts; ++p) {
+        const size_t lo = b.size() * p / parts, hi = b.size() * (p + 1) / parts;
+        auto cohort = make(*b[lo], (int)(hi - lo));
+        for (size_t i = lo; i < hi; ++i) b[i]->joinCohort(cohort, (int)(i - lo));
+      }
     }
   }
 
+  // one replay partition per ModelLocker that feeds the replay (ReplayParts): announce them before any actor acts
+  template <class ActorT>
+  void planPartitionsOf() {
+    std::vector<std::pair<decltype(std::declval<ActorT>().replay()), std::vector<const void*>>> seen;
+    for (auto& l : loops_) {
+      auto a = std::dynamic_pointer_cast<ActorT>(l->actor());
+      if (!a || !a->trainable()) continue;
+      auto rep = a->replay();
+      auto it = std::find_if(seen.begin(), seen.end(), [&](auto& e) { return e.first.get() == rep.get(); });
+      if (it == seen.end()) {
+        seen.push_back({rep, {}});
+        it = seen.end() - 1;
+      }
+      if (std::find(it->second.begin(), it->second.end(), a->lockerKey()) == it->second.end())
+        it->second.push_back(a->lockerKey());
+    }
+    for (auto& e : seen) e.first->core().plan(e.second);
+  }
+
   void formCohorts() {
+    planPartitionsOf<DQNActor>();
+    planPartitionsOf<R2D2Actor>();
     if (const char* off = std::getenv("RELA_NO_COHORT"))
       if (off[0] == '1') return;
     formCohortsOf<DQNActor>(

@@ -12,6 +12,16 @@
 #include <torch/extension.h>
 
 #include "rela/env.h"
+// this repo's optional in-place rendering extension; absent when this file is compiled against the REFERENCE's
+// rela/env.h for the oracle (oracle/Makefile: _ref/synth_atari), where the env is a plain three-virtual rela::Env
+#if __has_include("rela/frame_row_env.h")
+#include "rela/frame_row_env.h"
+#define RELA_HAS_FRAME_ROW 1
+#define RELA_FRAME_ROW_BASE , public rela::FrameRowEnv
+#else
+#define RELA_HAS_FRAME_ROW 0
+#define RELA_FRAME_ROW_BASE
+#endif
 
 namespace py = pybind11;
 
@@ -51,7 +61,7 @@ __attribute__((target_clones("avx2", "default"))) uint32_t lcgFill(uint32_t stat
   return last;
 }
 
-class SyntheticAtariEnv : public rela::Env {
+class SyntheticAtariEnv : public rela::Env RELA_FRAME_ROW_BASE {
  public:
   // slidingStack: the observation is a stack of four planes of which ONE is new per step and the first plane of
   // an episode is repeated four times -- GameState::computeFeature's stacking (atari/game_state.h:53-82).  The
@@ -76,7 +86,10 @@ class SyntheticAtariEnv : public rela::Env {
   }
 
   std::tuple<rela::TensorDict, float, bool> step(const rela::TensorDict& action) final {
-    const int64_t a = action.at("a").item<int64_t>();
+    const auto& at = action.at("a");
+    const int64_t a = (at.device().is_cpu() && at.scalar_type() == torch::kInt64 && at.numel() == 1)
+                          ? *at.data_ptr<int64_t>()  // (item() costs a dispatcher round trip per env-step)
+                          : at.item<int64_t>();
     if (a < 0 || a >= numAction_) throw std::out_of_range("SyntheticAtariEnv: action out of range");
     fillFrame(false);
     const uint32_t x = next();
@@ -89,6 +102,12 @@ class SyntheticAtariEnv : public rela::Env {
   }
 
   bool terminated() const final { return terminal_; }
+
+#if RELA_HAS_FRAME_ROW
+  // render into the VectorEnv's page-locked row from now on (it already holds the current observation)
+  void bindFrameRow(uint8_t* row) final { frame_ = torch::from_blob(row, {4, 84, 84}, torch::kUInt8); }
+  bool slidingStack() const final { return sliding_; }
+#endif
 
  private:
   uint32_t next() {
@@ -122,7 +141,7 @@ class SyntheticAtariEnv : public rela::Env {
 // observation is a constant frame stack, the reward 0, episodes end after episode_len steps): whatever rate the
 // threaded benchmark reaches with it is what the runtime -- thread loop, VectorEnv, upload, cohort barrier, device
 // tick -- can do when the env costs nothing.
-class NullAtariEnv : public rela::Env {
+class NullAtariEnv : public rela::Env RELA_FRAME_ROW_BASE {
  public:
   NullAtariEnv(float eps, int numAction, int episodeLen) : numAction_(numAction), episodeLen_(episodeLen) {
     eps_ = torch::full({1}, eps, torch::kFloat32);
@@ -141,6 +160,10 @@ class NullAtariEnv : public rela::Env {
     return std::make_tuple(rela::TensorDict{{"s", frame_}, {"eps", eps_}, {"legal_move", legal_}}, 0.f, terminal_);
   }
   bool terminated() const final { return terminal_; }
+#if RELA_HAS_FRAME_ROW
+  void bindFrameRow(uint8_t* row) final { frame_ = torch::from_blob(row, {4, 84, 84}, torch::kUInt8); }
+  bool slidingStack() const final { return true; }  // a constant frame is a stack that slides onto itself
+#endif
 
  private:
   const int numAction_, episodeLen_;

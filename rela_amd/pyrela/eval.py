@@ -1,7 +1,8 @@
 """Evaluation on the `rela` module (counterpart of pyrela/eval.py:9-36): `num_thread` single-env
 eval threads (BasicThreadLoop(actor, env, True): one episode each, no replay, thread_loop.h:66-71,
 92-103) driven by evaluation actors (DQNActor(locker) / R2D2Actor(locker)) with eps = 0; returns the
-mean episode reward.  The locker must live on a cuda device (this engine has no CPU actor path)."""
+mean episode reward.  The locker may live on "cpu" as upstream's eval locker does (pyrela/main.py:116): its actors then
+run on the GPU in the exact f32 parity mode (rela module, ModelLocker)."""
 import time
 
 import numpy as np

@@ -4,9 +4,13 @@ Flag names, defaults and the loop shape follow pyrela/main.py:23-82,197-251: act
 replay from C++ threads, the learner samples / steps / updates priorities, actor weights are
 re-published every --actor_sync_freq updates, the target net every --num_update_between_sync.
 Differences, all on purpose:
-  * envs are synthetic (create_env.py); --game only names the run; evaluation is out of scope;
+  * envs are synthetic (create_env.py); --game only names the run;
   * the priority stays on the GPU between loss() and update_priority() (no per-step host sync);
-  * one replay partition per actor GPU: several --act_device values need one process each.
+  * several --act_device values: by default one PROCESS per device (train_multi, rela_amd/parallel.py);
+    --single_process 1 keeps the reference's own wiring (main.py:131-136,155,166): one ModelLocker per act device in
+    THIS process, threads dealt round-robin onto them, all feeding the one replay object, which then owns one
+    partition per locker (rela module, ReplayParts).  The eval locker lives on "cpu" as in main.py:116 and
+    --num_eval_game > 0 runs the reference's eval cadence (main.py:264-278) after every epoch.
 """
 import argparse
 import os
@@ -59,6 +63,9 @@ def parse_args(argv=None):
     p.add_argument("--act_eps_alpha", type=float, default=7)
     p.add_argument("--act_device", type=str, default="cuda:0")
     p.add_argument("--actor_sync_freq", type=int, default=20)
+    p.add_argument("--num_eval_game", type=int, default=0, help="eval threads after every epoch (pyrela/main.py:264-278); 0 = off")
+    p.add_argument("--single_process", type=int, default=0,
+                   help="several --act_device values in ONE process, as the reference wires them (main.py:131-136)")
     p.add_argument("--hip_learner", type=int, default=1,
                    help="run loss / backward / clip / optimiser through the hand-written HIP learner step "
                         "(csrc/learner.hip for apex, csrc/learner_r2d2.hip for r2d2) instead of PyTorch autograd")
@@ -89,10 +96,13 @@ def train(args, on_epoch=None):
         cls = HipR2D2Learner if args.algo == "r2d2" else HipApexLearner
         learner = cls.from_agent(agent, args.batchsize, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip)
 
+    # create eval locker here, as upstream (main.py:115-116): replicas on the host, device string "cpu"
+    eval_locker = rela.ModelLocker([type(agent).clone(agent, "cpu")], "cpu")
     act_devices = args.act_device.split(",")
-    if len(act_devices) != 1:  # the caller should have gone through train_multi (see __main__)
-        raise SystemExit("several --act_device values: use rela_amd.pyrela.main.train_multi (one process per GPU)")
-    lockers = [rela.ModelLocker([agent, agent, agent], d) for d in act_devices]  # 3 weight versions per device
+    if len(act_devices) != 1 and not getattr(args, "single_process", 0):  # (see __main__: train_multi)
+        raise SystemExit("several --act_device values: use --single_process 1 (the reference's wiring) or "
+                         "rela_amd.pyrela.main.train_multi (one process per GPU)")
+    lockers = [rela.ModelLocker([agent, agent, agent], d) for d in act_devices]  # 3 weight versions per device (:131-136)
 
     replay_buffer = replay_class(args.replay_buffer_size, args.seed, args.priority_exponent,
                                  args.importance_exponent, args.prefetch)
@@ -152,6 +162,19 @@ def train(args, on_epoch=None):
         rates = tach.lap(actors, replay_buffer, args.epoch_len * args.batchsize)
         history.append(dict(epoch=epoch, seconds=dt, train=rates[0], act=rates[1], buffer_add=rates[2],
                             loss=mean_loss, skipped_steps=watch.skipped))
+        if getattr(args, "num_eval_game", 0) > 0:  # main.py:264-278
+            from rela_amd.pyrela.eval import evaluate
+
+            context.pause()
+            if learner is not None:
+                agent.online_net.load_state_dict(learner.state_dict("online"))
+                agent.target_net.load_state_dict(learner.state_dict("target"))
+            eval_locker.update_model(agent)
+            actor_cls = rela.R2D2Actor if args.algo == "r2d2" else rela.DQNActor
+            score = evaluate(args.num_eval_game, eval_locker, actor_cls, epoch * args.num_eval_game + 1, args.episode_len, 0)
+            print("epoch %d, eval score: %f" % (epoch, score))
+            history[-1]["eval_score"] = score
+            context.resume()
         if on_epoch is not None:
             on_epoch(history[-1])
         print("****************************************")
@@ -429,7 +452,7 @@ def train_multi(args):
 
 if __name__ == "__main__":
     _args = parse_args()
-    if len(_args.act_device.split(",")) > 1 or _args.act_device != _args.train_device:
+    if (len(_args.act_device.split(",")) > 1 or _args.act_device != _args.train_device) and not _args.single_process:
         print(train_multi(_args))
     else:
         train(_args)

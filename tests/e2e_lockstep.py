@@ -65,17 +65,30 @@ def frames_of_run(synth_atari, cfg, steps):
     return out
 
 
+# the reference's multi-device wiring on one GPU: 2 lockers x 1 thread x 4 envs, capacity 32 = 2 partitions of 16 with
+# seeds 5 and 6, batch 16 = 8 + 8.  Partition 0 sees exactly the stream of the single-replay golden (CFG).
+CFG_TWO_LOCKERS = dict(CFG, threads=2, lockers=2, capacity=32, batch=16)
+
+# the sliding-stack golden's four envs as a cohort of this repo's module (2 threads x 2 envs): the path on which only
+# the newest plane of every row crosses PCIe and the device completes the stacks (rela_apex_actor_slide_stacks)
+CFG_SLIDING_COHORT = dict(CFG_SLIDING, K=2, threads=2)
+
+
 def run_lockstep(rela, synth_atari, agent, act_device, sample_device, cfg=CFG, prefetch=0):
     """agent: an ApexAgent-shaped module whose state_dict carries online_net.* / target_net.*."""
     ring = int(1.25 * cfg["capacity"])
     replay = rela.FFPrioritizedReplay(cfg["capacity"], cfg["seed"], cfg["alpha"], cfg["beta"], prefetch)
-    locker = rela.ModelLocker([agent], act_device)
+    # cfg["lockers"] = L > 1 (this repo's module only): the reference's multi-device wiring, one ModelLocker per act
+    # device and thread t on locker t % L (pyrela/main.py:131-136,155,166) -- here all on `act_device`, so the replay
+    # owns L partitions of capacity / L on one GPU; the batch is L slices of batch / L rows, partition 0 first
+    L = cfg.get("lockers", 1)
+    lockers = [rela.ModelLocker([agent], act_device) for _ in range(L)]
     ctx = rela.Context()
     games, actors = [], []
     # cfg["threads"] > 1 (this repo's module only: its cohort commits the members' blocks in member order, the
     # reference's threads would race for the slots, SURVEY H5): T threads x K envs, env seeds numbered through
     for t in range(cfg.get("threads", 1)):
-        actor = rela.DQNActor(locker, cfg["multi_step"], cfg["K"], cfg["gamma"], replay)
+        actor = rela.DQNActor(lockers[t % L], cfg["multi_step"], cfg["K"], cfg["gamma"], replay)
         vec = rela.VectorEnv()
         for g in range(cfg["K"]):
             seed = cfg["env_seed"] + t * cfg["K"] + g
@@ -104,7 +117,7 @@ def run_lockstep(rela, synth_atari, agent, act_device, sample_device, cfg=CFG, p
             eps=batch.obs["eps"].cpu().reshape(-1).tolist(),
             legal_sum=batch.obs["legal_move"].cpu().sum(1).tolist(),
             weight=w.cpu().double().tolist(), num_add=replay.num_add()))
-        newp = torch.linspace(0.5, 2.0, cfg["batch"]) * (1 + 0.25 * r)
+        newp = torch.linspace(0.5, 2.0, cfg["batch"] // L).repeat(L) * (1 + 0.25 * r)
         replay.update_priority(newp)
     ctx.terminate()
     ctx.resume()

@@ -155,6 +155,84 @@ def test_lockstep_k128_matches_reference_in_both_precision_modes(mods, dedup_env
                                    err_msg="IS weights, round %d, %s" % (r, precision))
 
 
+@pytest.mark.parametrize("plane_upload", ["1", "0"])
+def test_cohort_plane_upload_matches_reference_sliding_golden(mods, dedup_env, plane_upload):
+    """r4: a VectorEnv whose envs all declare a sliding frame stack (rela::FrameRowEnv) uploads only the NEWEST 84x84
+    plane of every row and the actor shard completes the stacks on the device (rela_apex_actor_slide_stacks; restart
+    flags on episode starts: atari/game_state.h:53-82).  The four envs of the sliding golden, driven as a cohort of
+    2 threads x 2 envs, must reproduce what the REAL reference (one thread x four envs, whole frames through its own
+    VectorEnv, rela/env.h:45-82) sampled: every frame stack (per-plane sums of s and next_s), action, n-step reward and
+    flag exactly, IS weights to 1e-4.  RELA_PLANE_UPLOAD=0 runs the same cohort with whole-frame uploads; the launch
+    census says which path ran."""
+    from e2e_lockstep import CFG_SLIDING, CFG_SLIDING_COHORT as C, load_agent_params, run_lockstep
+    from rela_amd import _capi as capi
+    from rela_amd.pyrela.apex import ApexAgent
+    from rela_amd.pyrela.net import AtariFFNet
+
+    rela, synth = mods
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_lockstep_apex_sliding.json")))
+    assert gold["cfg"] == CFG_SLIDING
+    dedup_env(None)
+    os.environ["RELA_PLANE_UPLOAD"] = plane_upload
+    try:
+        agent = load_agent_params(ApexAgent(lambda: AtariFFNet(C["num_action"]), C["multi_step"], C["gamma"]), C)
+        with capi.launch_census() as census:
+            rounds = run_lockstep(rela, synth, agent, "cuda:0", "cuda:0", C)
+    finally:
+        os.environ.pop("RELA_PLANE_UPLOAD", None)
+    assert ("slide_stacks" in census.counts) == (plane_upload == "1"), census.counts
+    _check_apex_rounds(rounds, gold)
+
+
+def test_two_lockers_in_one_process_give_two_partitions_with_reference_parity(mods, dedup_env):
+    """The reference's single-process multi-device wiring (pyrela/main.py:131-136,155,166: one ModelLocker per act
+    device, threads dealt round-robin, ONE replay object) with two lockers on cuda:0: the replay owns one partition per
+    locker (capacity / 2, seeds 5 and 6) and a batch of 16 is 8 rows of each.  Partition 0 is fed by thread 0 -- the
+    very envs, capacity, seed and per-round priorities of the single-replay golden recorded from the REAL reference --
+    so rows 0..7 of every batch must be that golden's batch (SURVEY 8e's parity definition: each partition
+    bit-identical to a reference PrioritizedReplay(capacity / G, seed_g) fed the same stream and asked for B / G), and
+    their importance weights the golden's up to the common factor of the global normalisation."""
+    from e2e_lockstep import CFG, CFG_TWO_LOCKERS as C, load_agent_params, run_lockstep
+    from rela_amd.pyrela.apex import ApexAgent
+    from rela_amd.pyrela.net import AtariFFNet
+
+    rela, synth = mods
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_lockstep_apex.json")))
+    assert gold["cfg"] == CFG
+    dedup_env(None)
+    agent = load_agent_params(ApexAgent(lambda: AtariFFNet(C["num_action"]), C["multi_step"], C["gamma"]))
+    rounds = run_lockstep(rela, synth, agent, "cuda:0", "cuda:0", C)
+    assert len(rounds) == len(gold["expect"])
+    for r, (got, exp) in enumerate(zip(rounds, gold["expect"])):
+        for key in ("s_sum", "s_head", "next_s_sum", "a", "terminal", "bootstrap", "eps", "legal_sum"):
+            assert got[key][:8] == exp[key], (r, key)
+            assert len(got[key]) == 16
+        assert got["num_add"] == 2 * exp["num_add"], r
+        assert np.array_equal(np.float32(got["reward"][:8]), np.float32(exp["reward"])), r
+        w = np.asarray(got["weight"])
+        assert w.max() == 1.0 and (w > 0).all()
+        np.testing.assert_allclose(w[:8] / w[:8].max(), np.asarray(exp["weight"]) / max(exp["weight"]), rtol=1e-4,
+                                   err_msg="IS weights of partition 0, round %d" % r)
+
+
+def test_reference_main_wiring_runs_in_one_process(mods, capsys):
+    """pyrela/main.py's own control flow in ONE process: two act lockers (`--act_device
+    cuda:0,cuda:0`: one ModelLocker per entry, threads dealt round-robin, main.py:131-136,155,166) feeding one replay
+    object, the eval locker on "cpu" (main.py:116) and the eval cadence after every epoch (main.py:264-278) with
+    evaluation actors on that "cpu" locker -- which run on the GPU in the f32 parity mode."""
+    from rela_amd.pyrela import main as entry
+
+    args = entry.parse_args(["--num_thread", "4", "--num_game_per_thread", "8", "--batchsize", "32", "--epoch_len", "20",
+                             "--num_epoch", "2", "--burn_in_frames", "128", "--replay_buffer_size", "1024",
+                             "--episode_len", "25", "--actor_sync_freq", "5", "--act_device", "cuda:0,cuda:0",
+                             "--single_process", "1", "--num_eval_game", "2"])
+    hist = entry.train(args)
+    out = capsys.readouterr().out
+    assert "Speed: train: " in out and "eval score:" in out
+    assert len(hist) == 2 and all(np.isfinite(h["loss"]) and np.isfinite(h["eval_score"]) for h in hist)
+    assert hist[-1]["act"] > 0 and hist[-1]["buffer_add"] > 0
+
+
 def test_cohort_in_fast_mode_agrees_with_the_f32_cohort(mods, dedup_env, precision_env):
     """The ActorCohort (2 threads x 64 envs = ONE 128-row shard: every thread runs the reference loop on its 64 envs,
     the last arriver launches the batched act / post_step; q.min() and replay blocks per group of 64) in bf16x2 mode
