@@ -43,9 +43,6 @@ int rela_stream_synchronize(void* stream, int device);
 int rela_stream_wait_stream(void* waiter, void* signaler, int device);
 /* asynchronous host->device copy on `stream` (page-locked sources overlap with compute) */
 int rela_memcpy_h2d_async(void* dst_dev, const void* src_host, int64_t bytes, void* stream, int device);
-/* the same for `height` rows of `width` bytes, `src_pitch` / `dst_pitch` bytes apart (one plane of every frame stack) */
-int rela_memcpy2d_h2d_async(void* dst_dev, int64_t dst_pitch, const void* src_host, int64_t src_pitch, int64_t width,
-                            int64_t height, void* stream, int device);
 
 /* ===================================================================================
  * Prioritized replay  --  rela/prioritized_replay.h:173-348 (PrioritizedReplay<T>) over
@@ -358,14 +355,16 @@ void rela_apex_actor_destroy(rela_apex_actor* a);
  * directly (then pass obs_host = NULL to act).                                              */
 void* rela_apex_actor_obs_slot(rela_apex_actor* a);
 /* Sliding frame stacks (GameState::computeFeature, atari/game_state.h:53-82: every step shifts the stack by one 84x84
- * plane and appends the new frame; the first frame of an episode is repeated four times).  When the env layer uploaded
- * only the NEWEST plane of every row -- plane 3 of rela_apex_actor_obs_slot(), 7,056 B instead of 28,224 B across PCIe --
- * this call completes planes 0..2 on the device before act(): plane k = plane k + 1 of the previous observation slot,
- * or the row's own new plane where restart_host[row] == 1 (u8[rows] on the host: the row's episode just began); rows
- * flagged 2 were uploaded whole and are left alone.
- * Stream-ordered after the plane uploads the caller made `stream` wait for.  The very first observation has no
- * predecessor and must be uploaded whole (RELA_ESTATE otherwise).  What it replaces: the host-side stacking the
- * reference's env does before VectorEnv::step stacks K observations (rela/env.h:63-82).                          */
+ * plane and appends the new frame; the first frame of an episode is repeated four times).  The env layer uploads only
+ * the NEWEST plane of every row -- 7,056 B instead of 28,224 B across PCIe -- into rela_apex_actor_plane_stage()
+ * ([rows][84*84] u8 on the device, contiguous: one plain 1-D copy per actor thread), and rela_apex_actor_slide_stacks
+ * writes the stacks of rela_apex_actor_obs_slot() on the device before act(): plane 3 = the new plane, plane k < 3 =
+ * plane k + 1 of the previous observation slot, or the new plane again where restart_host[row] == 1 (u8[rows] on the
+ * host: the row's episode just began); rows flagged 2 were uploaded whole into the slot and are left alone.
+ * Stream-ordered after the uploads the caller made `stream` wait for.  The very first observation has no predecessor
+ * and must be uploaded whole (RELA_ESTATE otherwise).  What it replaces: the host-side stacking the reference's env
+ * does before VectorEnv::step stacks K observations (rela/env.h:63-82).                                          */
+void* rela_apex_actor_plane_stage(rela_apex_actor* a);
 int rela_apex_actor_slide_stacks(rela_apex_actor* a, const uint8_t* restart_host, void* stream);
 /* Device addresses of the CURRENT obs["eps"] f32[rows] and obs["legal_move"] f32[rows][A]; act()
  * snapshots them into the history slot of the step, so a transition's obs side carries the values
@@ -426,6 +425,7 @@ int rela_r2d2_actor_create(rela_r2d2_actor** out, int rows, int group_rows, int 
                            rela_replay* replay, uint64_t seed, int device);
 void rela_r2d2_actor_destroy(rela_r2d2_actor* a);
 void* rela_r2d2_actor_obs_slot(rela_r2d2_actor* a);
+void* rela_r2d2_actor_plane_stage(rela_r2d2_actor* a);                                          /* as rela_apex_actor_plane_stage */
 int rela_r2d2_actor_slide_stacks(rela_r2d2_actor* a, const uint8_t* restart_host, void* stream); /* as rela_apex_actor_slide_stacks */
 /* R2D2Actor::act  r2d2_actor.h:221-249; arguments as rela_apex_actor_act */
 int rela_r2d2_actor_act(rela_r2d2_actor* a, const rela_lstmnet* online, const uint8_t* obs_host,

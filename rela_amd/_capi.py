@@ -63,7 +63,6 @@ _sig("rela_stream_destroy", None, [vp, i32])
 _sig("rela_stream_synchronize", i32, [vp, i32])
 _sig("rela_stream_wait_stream", i32, [vp, vp, i32])
 _sig("rela_memcpy_h2d_async", i32, [vp, vp, i64, vp, i32])
-_sig("rela_memcpy2d_h2d_async", i32, [vp, i64, vp, i64, i64, i64, vp, i32])
 _sig("rela_replay_create", i32, [P(vp), i32, i32, f32, f32, i32, i32])
 _sig("rela_replay_destroy", None, [vp])
 _sig("rela_replay_set_schema", i32, [vp, i32, P(i64)])
@@ -125,6 +124,7 @@ _sig("rela_apex_td_from_q", i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, f32
 _sig("rela_apex_actor_create", i32, [P(vp), i32, i32, i32, i32, f32, vp, u64, i32])
 _sig("rela_apex_actor_destroy", None, [vp])
 _sig("rela_apex_actor_obs_slot", vp, [vp])
+_sig("rela_apex_actor_plane_stage", vp, [vp])
 _sig("rela_apex_actor_slide_stacks", i32, [vp, vp, vp])
 _sig("rela_apex_actor_eps_dev", vp, [vp])
 _sig("rela_apex_actor_legal_dev", vp, [vp])
@@ -138,6 +138,7 @@ _sig("rela_apex_actor_last_priority_dev", vp, [vp])
 _sig("rela_r2d2_actor_create", i32, [P(vp), i32, i32, i32, i32, f32, i32, i32, f64, vp, u64, i32])
 _sig("rela_r2d2_actor_destroy", None, [vp])
 _sig("rela_r2d2_actor_obs_slot", vp, [vp])
+_sig("rela_r2d2_actor_plane_stage", vp, [vp])
 _sig("rela_r2d2_actor_slide_stacks", i32, [vp, vp, vp])
 _sig("rela_r2d2_actor_act", i32, [vp, vp, vp, vp, vp, vp, P(vp), vp])
 _sig("rela_r2d2_actor_post_step", i32, [vp, vp, vp, vp, vp, i32, P(i32), vp])

@@ -52,7 +52,8 @@ struct rela_apex_actor {
   std::vector<uint8_t> refs_valid;   // [n+1] the slot's units were stored
   std::vector<int64_t> tick_seq;     // first unit sequence number of the last kTickWin ticks (ring by tick)
   int64_t tick = 0, key_tick = -1;   // ticks stored so far; tick of the last keyframe (all planes stored)
-  uint8_t* restart = nullptr;        // [R] rela_apex_actor_slide_stacks: 1 = the row's stack restarts with its new plane
+  uint8_t* restart = nullptr;
+  uint8_t* fresh_planes = nullptr;  // [R][7056] staging of the newest plane of every row (rela_apex_actor_plane_stage)        // [R] rela_apex_actor_slide_stacks: 1 = the row's stack restarts with its new plane
 };
 
 namespace {
@@ -149,7 +150,7 @@ extern "C" void rela_apex_actor_destroy(rela_apex_actor* a) {
   DeviceGuard g(a->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {a->obs, a->act, a->rew, a->term, a->eps, a->legal, a->q, a->out_r, a->out_b, a->prio, a->out_t, a->ws,
-                a->eps_hist, a->legal_hist, a->ref_hist, a->q_hist, a->restart};
+                a->eps_hist, a->legal_hist, a->ref_hist, a->q_hist, a->restart, a->fresh_planes};
   for (void* p : ps) (void)hipFree(p);
   delete a;
 }
@@ -159,8 +160,17 @@ static inline int next_slot(const rela_apex_actor* a) { return (a->head + a->cou
 extern "C" void* rela_apex_actor_obs_slot(rela_apex_actor* a) {
   return a ? a->obs + (size_t)next_slot(a) * a->R * kObs : nullptr;
 }
+extern "C" void* rela_apex_actor_plane_stage(rela_apex_actor* a) {
+  if (!a) return nullptr;
+  if (!a->fresh_planes) {
+    DeviceGuard g(a->device);
+    if (hipMalloc(&a->fresh_planes, (size_t)a->R * 84 * 84) != hipSuccess) a->fresh_planes = nullptr;
+  }
+  return a->fresh_planes;
+}
 extern "C" int rela_apex_actor_slide_stacks(rela_apex_actor* a, const uint8_t* restart_host, void* stream_) {
   RELA_CHECK(a && restart_host, RELA_EINVAL, "rela_apex_actor_slide_stacks: bad arguments");
+  RELA_CHECK(a->fresh_planes, RELA_ESTATE, "rela_apex_actor_slide_stacks: no plane was staged (rela_apex_actor_plane_stage)");
   RELA_CHECK(a->act_calls > 0, RELA_ESTATE, "rela_apex_actor_slide_stacks: the first observation must be uploaded whole");
   RELA_CHECK(a->count <= a->n, RELA_ESTATE, "rela_apex_actor_slide_stacks: act() twice without post_step()");
   hipStream_t s = (hipStream_t)stream_;
@@ -168,7 +178,8 @@ extern "C" int rela_apex_actor_slide_stacks(rela_apex_actor* a, const uint8_t* r
   if (!a->restart) RELA_HIP(hipMalloc(&a->restart, (size_t)a->R));
   RELA_HIP(hipMemcpyAsync(a->restart, restart_host, (size_t)a->R, hipMemcpyHostToDevice, s));
   const int H = a->n + 1, slot = next_slot(a), prev = (slot + H - 1) % H;
-  return slide_stacks(a->obs + (size_t)slot * a->R * kObs, a->obs + (size_t)prev * a->R * kObs, a->restart, a->R, s);
+  return slide_stacks(a->obs + (size_t)slot * a->R * kObs, a->obs + (size_t)prev * a->R * kObs, a->fresh_planes, a->restart,
+                      a->R, s);
 }
 extern "C" int rela_apex_actor_set_reuse(rela_apex_actor* a, int on) {
   RELA_CHECK(a, RELA_EINVAL, "rela_apex_actor_set_reuse: bad arguments");

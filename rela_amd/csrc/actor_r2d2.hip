@@ -212,7 +212,8 @@ struct rela_r2d2_actor {
   int32_t *d_slot = nullptr, *d_ranges = nullptr, *d_emits = nullptr, *d_envs = nullptr;
   int32_t* d_gather = nullptr;  // [2][3R]: destination offsets, source envs and emit indices of one batch
   uint8_t* d_flags = nullptr;
-  uint8_t* restart = nullptr;  // [R] rela_r2d2_actor_slide_stacks
+  uint8_t* restart = nullptr;
+  uint8_t* fresh_planes = nullptr;  // [R][7056] staging of the newest plane of every row (rela_r2d2_actor_plane_stage)  // [R] rela_r2d2_actor_slide_stacks
   void* ws = nullptr;
   int64_t ws_bytes = 0;
   std::vector<uint8_t> h_term;  // [n+1][R] host copy: the bookkeeping needs the flags
@@ -336,7 +337,7 @@ extern "C" void rela_r2d2_actor_destroy(rela_r2d2_actor* a) {
                 a->tmp_c, a->eps,    a->legal,  a->eps_hist, a->legal_hist, a->q,         a->out_r,  a->out_b,  a->prio_step, a->out_t, a->w.s,
                 a->w.eps, a->w.legal, a->w.a,   a->w.reward,  a->w.term, a->w.boot, a->w.prio, a->w.h0,   a->w.c0,
                 a->w.nh0, a->w.nc0,  a->prow,   a->lens,      a->agg,    a->d_slot, a->d_flags, a->d_ranges, a->d_emits, a->d_gather,
-                a->d_envs, a->ws, a->q_hist, a->restart};
+                a->d_envs, a->ws, a->q_hist, a->restart, a->fresh_planes};
   for (void* p : ps) (void)hipFree(p);
   a->stage.destroy();
   delete a->book;
@@ -348,15 +349,26 @@ static inline int next_slot(const rela_r2d2_actor* a) { return (a->head + a->cou
 extern "C" void* rela_r2d2_actor_obs_slot(rela_r2d2_actor* a) {
   return a ? a->obs + (size_t)next_slot(a) * a->R * kObs : nullptr;
 }
+extern "C" void* rela_r2d2_actor_plane_stage(rela_r2d2_actor* a) {
+  if (!a) return nullptr;
+  if (!a->fresh_planes) {
+    DeviceGuard g(a->device);
+    if (hipMalloc(&a->fresh_planes, (size_t)a->R * 84 * 84) != hipSuccess) a->fresh_planes = nullptr;
+  }
+  return a->fresh_planes;
+}
 extern "C" int rela_r2d2_actor_slide_stacks(rela_r2d2_actor* a, const uint8_t* restart_host, void* stream_) {
   RELA_CHECK(a && restart_host, RELA_EINVAL, "rela_r2d2_actor_slide_stacks: bad arguments");
+  RELA_CHECK(a->fresh_planes, RELA_ESTATE, "rela_r2d2_actor_slide_stacks: no plane was staged (rela_r2d2_actor_plane_stage)");
   RELA_CHECK(a->act_calls > 0, RELA_ESTATE, "rela_r2d2_actor_slide_stacks: the first observation must be uploaded whole");
+  RELA_CHECK(a->count <= a->n, RELA_ESTATE, "rela_r2d2_actor_slide_stacks: act() twice without post_step()");
   hipStream_t s = (hipStream_t)stream_;
   DeviceGuard g(a->device);
   if (!a->restart) RELA_HIP(hipMalloc(&a->restart, (size_t)a->R));
   RELA_HIP(hipMemcpyAsync(a->restart, restart_host, (size_t)a->R, hipMemcpyHostToDevice, s));
   const int H = a->n + 1, slot = next_slot(a), prev = (slot + H - 1) % H;
-  return slide_stacks(a->obs + (size_t)slot * a->R * kObs, a->obs + (size_t)prev * a->R * kObs, a->restart, a->R, s);
+  return slide_stacks(a->obs + (size_t)slot * a->R * kObs, a->obs + (size_t)prev * a->R * kObs, a->fresh_planes, a->restart,
+                      a->R, s);
 }
 extern "C" int rela_r2d2_actor_set_reuse(rela_r2d2_actor* a, int on) {
   RELA_CHECK(a, RELA_EINVAL, "rela_r2d2_actor_set_reuse: bad arguments");

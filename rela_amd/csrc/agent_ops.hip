@@ -215,29 +215,32 @@ extern "C" int rela_apex_td_from_q(int n, int num_action, int group_rows, const 
 // ---------------------------------------------------------------------------------------------------------------
 // Sliding frame stacks on the device (GameState::computeFeature, atari/game_state.h:53-82: a step shifts the stack by
 // one 84x84 plane and appends the new frame; the first frame of an episode is repeated four times).  The env layer
-// uploads only the NEWEST plane of every row (plane 3 of the observation slot, 7,056 B instead of 28,224 B across
-// PCIe); this kernel completes planes 0..2 of the slot: plane k = the previous observation's plane k + 1, or the
-// row's own new plane where restart[row] == 1; rows flagged 2 were uploaded whole and are left alone.  HBM bound:
-// 21 KB read + 21 KB written per row.
+// uploads only the NEWEST plane of every row into a contiguous staging array ([rows][7056]: 7,056 B instead of
+// 28,224 B across PCIe, one plain 1-D copy per actor thread); this kernel writes the whole stack of the observation
+// slot: plane 3 = the new plane, plane k < 3 = the previous observation's plane k + 1, or the new plane again where
+// restart[row] == 1 (episode start); rows flagged 2 were uploaded whole and are left alone.  HBM bound: 28 KB read +
+// 28 KB written per row.
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void slide_stacks_kernel(uint8_t* __restrict__ cur, const uint8_t* __restrict__ prev,
+                                                           const uint8_t* __restrict__ fresh,
                                                            const uint8_t* __restrict__ restart, int rows) {
   constexpr int kPlane16 = 84 * 84 / 16;  // 441 sixteen-byte units per plane
-  const int row = blockIdx.x, k = blockIdx.y;  // k = destination plane 0..2
-  if (row >= rows || restart[row] == 2) return;  // 2 = the row was uploaded whole
+  const int row = blockIdx.x, k = blockIdx.y;  // k = destination plane 0..3
+  if (row >= rows || restart[row] == 2) return;
   uint4* dst = reinterpret_cast<uint4*>(cur + ((size_t)row * 4 + k) * 7056);
-  const uint4* src = restart[row] == 1 ? reinterpret_cast<const uint4*>(cur + ((size_t)row * 4 + 3) * 7056)
-                                  : reinterpret_cast<const uint4*>(prev + ((size_t)row * 4 + k + 1) * 7056);
+  const uint4* src = (k == 3 || restart[row] == 1) ? reinterpret_cast<const uint4*>(fresh + (size_t)row * 7056)
+                                                   : reinterpret_cast<const uint4*>(prev + ((size_t)row * 4 + k + 1) * 7056);
   for (int i = threadIdx.x; i < kPlane16; i += 256) dst[i] = src[i];
 }
 }  // namespace
 
 namespace rela_amd {
-int slide_stacks(uint8_t* cur_slot, const uint8_t* prev_slot, const uint8_t* restart_dev, int rows, hipStream_t s) {
+int slide_stacks(uint8_t* cur_slot, const uint8_t* prev_slot, const uint8_t* fresh_planes, const uint8_t* restart_dev, int rows,
+                 hipStream_t s) {
   ProfScope prof("slide_stacks", s);
   note_launch("slide_stacks");
-  hipLaunchKernelGGL(slide_stacks_kernel, dim3(rows, 3), dim3(256), 0, s, cur_slot, prev_slot, restart_dev, rows);
+  hipLaunchKernelGGL(slide_stacks_kernel, dim3(rows, 4), dim3(256), 0, s, cur_slot, prev_slot, fresh_planes, restart_dev, rows);
   RELA_LAUNCH_CHECK();
   return RELA_OK;
 }

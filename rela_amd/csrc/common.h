@@ -109,6 +109,7 @@ struct HostStage {
 };
 
 // agent_ops.hip: completes sliding frame stacks of an observation slot from the previous slot (see there)
-int slide_stacks(uint8_t* cur_slot, const uint8_t* prev_slot, const uint8_t* restart_dev, int rows, hipStream_t s);
+int slide_stacks(uint8_t* cur_slot, const uint8_t* prev_slot, const uint8_t* fresh_planes, const uint8_t* restart_dev, int rows,
+                 hipStream_t s);
 
 }  // namespace rela_amd

@@ -192,14 +192,3 @@ extern "C" int rela_memcpy_h2d_async(void* dst_dev, const void* src_host, int64_
   RELA_HIP(hipMemcpyAsync(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
   return RELA_OK;
 }
-
-extern "C" int rela_memcpy2d_h2d_async(void* dst_dev, int64_t dst_pitch, const void* src_host, int64_t src_pitch, int64_t width,
-                                       int64_t height, void* stream, int device) {
-  RELA_CHECK(dst_dev && src_host && width >= 0 && height >= 0 && dst_pitch >= width && src_pitch >= width, RELA_EINVAL,
-             "rela_memcpy2d_h2d_async: bad arguments");
-  if (width == 0 || height == 0) return RELA_OK;
-  DeviceGuard g(device);
-  RELA_HIP(hipMemcpy2DAsync(dst_dev, (size_t)dst_pitch, src_host, (size_t)src_pitch, (size_t)width, (size_t)height,
-                            hipMemcpyHostToDevice, (hipStream_t)stream));
-  return RELA_OK;
-}

@@ -20,6 +20,7 @@
 // HBM layout: weights f32[ring], evicted u8[ring], field f rows at base_f + slot*row_bytes_f.
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <random>
 #include <vector>
@@ -492,6 +493,27 @@ struct rela_replay {
   int last_full_size = 0;  // size_ as re-read by the last sample_ (:312), the N of its IS weights
   hipStream_t stream = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_wait = nullptr;
+  // r4: the row copies of an insert (56 KB per transition -- all but a few bytes of its traffic) run on a second
+  // stream instead of queueing behind the sample path's latency-bound chain on `stream`: a block's slots belong to
+  // its producer alone between reserve and commit (prioritized_replay.h:58-66 copies them with the mutex released),
+  // so only the COMMIT -- weights and sum_, in slot order -- has to take its turn among sample / update.  The
+  // priorities travel through a small ring of staging buffers, so the producer never waits for `stream` at all.
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_cin = nullptr, ev_cout = nullptr;
+  static constexpr int kPrioStages = 8;
+  float* d_pstage[kPrioStages] = {};
+  int pstage_cap[kPrioStages] = {};
+  hipEvent_t ev_stage[kPrioStages] = {}, ev_done[kPrioStages] = {};
+  bool pstage_used[kPrioStages] = {};
+  int pstage_next = 0;
+  // slots evicted by a sample whose gathers may still be reading them (a sampled row can be evicted by the very call
+  // that drew it, :288-315): a row copy into such a slot waits for that sample's event
+  struct Eviction {
+    int start, count;
+    hipEvent_t done;
+  };
+  std::deque<Eviction> evictions;
+  std::vector<hipEvent_t> ev_pool;
   bool deferred_wait = false;  // rela_replay_set_deferred_wait: sample / update_priority do not stall the caller's stream
   float* d_w = nullptr;
   uint8_t* d_evicted = nullptr;
@@ -548,6 +570,13 @@ extern "C" int rela_replay_create(rela_replay** out, int capacity, int seed, flo
   RELA_HIP(hipEventCreateWithFlags(&r->ev_in, hipEventDisableTiming));
   RELA_HIP(hipEventCreateWithFlags(&r->ev_out, hipEventDisableTiming));
   RELA_HIP(hipEventCreateWithFlags(&r->ev_wait, hipEventDisableTiming));
+  RELA_HIP(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking));
+  RELA_HIP(hipEventCreateWithFlags(&r->ev_cin, hipEventDisableTiming));
+  RELA_HIP(hipEventCreateWithFlags(&r->ev_cout, hipEventDisableTiming));
+  for (int k = 0; k < rela_replay::kPrioStages; ++k) {
+    RELA_HIP(hipEventCreateWithFlags(&r->ev_stage[k], hipEventDisableTiming));
+    RELA_HIP(hipEventCreateWithFlags(&r->ev_done[k], hipEventDisableTiming));
+  }
   RELA_HIP(hipMalloc(&r->d_w, sizeof(float) * (size_t)r->ring));
   RELA_HIP(hipMalloc(&r->d_evicted, (size_t)r->ring));
   RELA_HIP(hipMalloc(&r->d_state, sizeof(ReplayDevState)));
@@ -572,7 +601,18 @@ extern "C" int rela_replay_create(rela_replay** out, int capacity, int seed, flo
 extern "C" void rela_replay_destroy(rela_replay* r) {
   if (!r) return;
   DeviceGuard g(r->device);
+  (void)hipStreamSynchronize(r->copy_stream);
   (void)hipStreamSynchronize(r->stream);
+  for (int k = 0; k < rela_replay::kPrioStages; ++k) {
+    (void)hipFree(r->d_pstage[k]);
+    (void)hipEventDestroy(r->ev_stage[k]);
+    (void)hipEventDestroy(r->ev_done[k]);
+  }
+  for (auto& e : r->evictions) (void)hipEventDestroy(e.done);
+  for (auto e : r->ev_pool) (void)hipEventDestroy(e);
+  (void)hipEventDestroy(r->ev_cin);
+  (void)hipEventDestroy(r->ev_cout);
+  (void)hipStreamDestroy(r->copy_stream);
   for (auto* p : r->d_fields) (void)hipFree(p);
   seq_index_free(&r->ix);
   r->stage.destroy();
@@ -725,6 +765,30 @@ static inline int vec16_ok(const void* a, const void* b, int64_t row_bytes) {
   return ((row_bytes & 15) == 0) && (((uintptr_t)a & 15) == 0) && (((uintptr_t)b & 15) == 0);
 }
 
+// (caller holds r->m) Opens a row copy of `count` slots from `start` on the copy stream: ordered after the producer's
+// queued work and after the gathers of every sample that evicted one of these slots and may still be reading it.
+static int copy_begin(rela_replay* r, hipStream_t producer, int start, int count) {
+  RELA_HIP(hipEventRecord(r->ev_cin, producer));
+  RELA_HIP(hipStreamWaitEvent(r->copy_stream, r->ev_cin, 0));
+  while (!r->evictions.empty() && hipEventQuery(r->evictions.front().done) == hipSuccess) {
+    r->ev_pool.push_back(r->evictions.front().done);
+    r->evictions.pop_front();
+  }
+  auto overlaps = [&](int a0, int an, int b0, int bn) {  // ring intervals [a0, a0 + an) and [b0, b0 + bn)
+    const int d = ((b0 - a0) % r->ring + r->ring) % r->ring;  // b0 relative to a0
+    return d < an || d + bn > r->ring;
+  };
+  for (auto& e : r->evictions)
+    if (overlaps(start, count, e.start, e.count)) RELA_HIP(hipStreamWaitEvent(r->copy_stream, e.done, 0));
+  return RELA_OK;
+}
+// ... and closes it: the producer may reuse its source rows once the copies ran
+static int copy_end(rela_replay* r, hipStream_t producer) {
+  RELA_HIP(hipEventRecord(r->ev_cout, r->copy_stream));
+  RELA_HIP(hipStreamWaitEvent(producer, r->ev_cout, 0));
+  return RELA_OK;
+}
+
 extern "C" int rela_replay_begin_add(rela_replay* r, int n, int nonblocking, int* first_slot) {
   RELA_CHECK(r && n > 0 && first_slot, RELA_EINVAL, "rela_replay_begin_add: bad arguments");
   RELA_CHECK(n <= r->ring, RELA_EINVAL, "rela_replay_begin_add: block of %d exceeds the ring (%d)", n, r->ring);
@@ -754,10 +818,12 @@ extern "C" int rela_replay_write_rows(rela_replay* r, int first_slot, int offset
   DeviceGuard g(r->device);
   std::lock_guard<std::mutex> lk(r->m);
   const int start = (int)(((int64_t)first_slot + offset) % r->ring);
-  // order after the producer's queued work, run on the replay stream, then let the producer
-  // continue only after its rows were consumed
-  RELA_HIP(hipEventRecord(r->ev_in, producer));
-  RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
+  // order after the producer's queued work, run on the COPY stream (the block's slots are the producer's alone until
+  // commit), then let the producer continue only after its rows were consumed
+  {
+    const int rc = copy_begin(r, producer, start, count);
+    if (rc != RELA_OK) return rc;
+  }
   SmallFields small{};
   for (size_t f = 0; f < r->d_fields.size(); ++f) {
     if (!rows_dev[f]) continue;
@@ -773,20 +839,18 @@ extern "C" int rela_replay_write_rows(rela_replay* r, int first_slot, int offset
     const int64_t units = v16 ? (rb >> 4) : rb;
     int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (units + kThreads - 1) / kThreads), 64);
     {
-      ProfScope prof("replay_scatter_rows", r->stream);
-      hipLaunchKernelGGL(replay_scatter_rows, dim3(gx, std::min(count, 32768)), dim3(kThreads), 0, r->stream,
+      ProfScope prof("replay_scatter_rows", r->copy_stream);
+      hipLaunchKernelGGL(replay_scatter_rows, dim3(gx, std::min(count, 32768)), dim3(kThreads), 0, r->copy_stream,
                          (const uint8_t*)rows_dev[f], r->d_fields[f], rb, count, r->ring, start, v16);
     }
   }
   if (small.n > 0) {
-    ProfScope prof("replay_scatter_small", r->stream);
-    hipLaunchKernelGGL(replay_scatter_small, dim3(ceil_div(count, 256)), dim3(256), 0, r->stream, small, count, r->ring,
+    ProfScope prof("replay_scatter_small", r->copy_stream);
+    hipLaunchKernelGGL(replay_scatter_small, dim3(ceil_div(count, 256)), dim3(256), 0, r->copy_stream, small, count, r->ring,
                        start);
   }
   RELA_LAUNCH_CHECK();
-  RELA_HIP(hipEventRecord(r->ev_out, r->stream));
-  RELA_HIP(hipStreamWaitEvent(producer, r->ev_out, 0));
-  return RELA_OK;
+  return copy_end(r, producer);
 }
 
 extern "C" int rela_replay_write_rows_gather(rela_replay* r, int first_slot, int count,
@@ -797,8 +861,10 @@ extern "C" int rela_replay_write_rows_gather(rela_replay* r, int first_slot, int
   hipStream_t producer = (hipStream_t)stream_;
   DeviceGuard g(r->device);
   std::lock_guard<std::mutex> lk(r->m);
-  RELA_HIP(hipEventRecord(r->ev_in, producer));
-  RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
+  {
+    const int rc = copy_begin(r, producer, first_slot, count);
+    if (rc != RELA_OK) return rc;
+  }
   for (size_t f = 0; f < r->d_fields.size(); ++f) {
     if (!bases_dev[f]) continue;
     RELA_CHECK(src_index_dev[f], RELA_EINVAL, "rela_replay_write_rows_gather: field %d has no source index", (int)f);
@@ -807,16 +873,14 @@ extern "C" int rela_replay_write_rows_gather(rela_replay* r, int first_slot, int
     const int64_t units = v16 ? (rb >> 4) : rb;
     int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (units + kThreads - 1) / kThreads), 64);
     {
-      ProfScope prof("replay_scatter_rows", r->stream);
-      hipLaunchKernelGGL(replay_scatter_rows_indexed, dim3(gx, std::min(count, 32768)), dim3(kThreads), 0, r->stream,
+      ProfScope prof("replay_scatter_rows", r->copy_stream);
+      hipLaunchKernelGGL(replay_scatter_rows_indexed, dim3(gx, std::min(count, 32768)), dim3(kThreads), 0, r->copy_stream,
                          (const uint8_t*)bases_dev[f], src_index_dev[f], dst_offset_dev, r->d_fields[f], rb, count,
                          r->ring, first_slot, v16);
     }
   }
   RELA_LAUNCH_CHECK();
-  RELA_HIP(hipEventRecord(r->ev_out, r->stream));
-  RELA_HIP(hipStreamWaitEvent(producer, r->ev_out, 0));
-  return RELA_OK;
+  return copy_end(r, producer);
 }
 
 extern "C" int rela_replay_commit_add(rela_replay* r, int first_slot, int n, const float* priority_dev,
@@ -832,8 +896,28 @@ extern "C" int rela_replay_commit_add_grouped(rela_replay* r, int first_slot, in
   std::unique_lock<std::mutex> lk(r->m);
   r->cv_tail.wait(lk, [&] { return r->shut || r->safe_tail == first_slot; });  // in-order commit :69
   if (r->safe_tail != first_slot) return RELA_EWOULDBLOCK;  // shut down while an earlier block never committed
-  RELA_HIP(hipEventRecord(r->ev_in, producer));
-  RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_in, 0));
+  // The priorities go through a staging buffer filled on the copy stream -- behind the block's row copies, so its
+  // event also says "the rows are written" -- and the weights / sum_ update takes its turn on the replay stream;
+  // the producer waits for the staging copy only, never for the replay stream.
+  const int k = r->pstage_next;
+  r->pstage_next = (k + 1) % rela_replay::kPrioStages;
+  if (r->pstage_used[k]) RELA_HIP(hipStreamWaitEvent(r->copy_stream, r->ev_done[k], 0));  // its last reader finished
+  if (r->pstage_cap[k] < n) {
+    RELA_HIP(hipStreamSynchronize(r->copy_stream));
+    RELA_HIP(hipStreamSynchronize(r->stream));
+    (void)hipFree(r->d_pstage[k]);
+    r->d_pstage[k] = nullptr;
+    r->pstage_cap[k] = 0;
+    RELA_HIP(hipMalloc(&r->d_pstage[k], sizeof(float) * (size_t)n));
+    r->pstage_cap[k] = n;
+  }
+  RELA_HIP(hipEventRecord(r->ev_cin, producer));
+  RELA_HIP(hipStreamWaitEvent(r->copy_stream, r->ev_cin, 0));
+  RELA_HIP(hipMemcpyAsync(r->d_pstage[k], priority_dev, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, r->copy_stream));
+  RELA_HIP(hipEventRecord(r->ev_stage[k], r->copy_stream));
+  RELA_HIP(hipStreamWaitEvent(producer, r->ev_stage[k], 0));
+  RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_stage[k], 0));
+  const float* staged = r->d_pstage[k];
   // large grouped blocks (a batched shard's tick): parallel pow + ordered sums; the single-workgroup kernel otherwise
   // (an ungrouped block is ONE float sum over all its rows: nothing to parallelise but the pow, and small blocks
   // gain nothing from a second launch)
@@ -847,18 +931,18 @@ extern "C" int rela_replay_commit_add_grouped(rela_replay* r, int first_slot, in
       r->tmpw_cap = n;
     }
     ProfScope prof("replay_append_weights", r->stream);
-    hipLaunchKernelGGL(replay_append_pow, dim3((n + 255) / 256), dim3(256), 0, r->stream, priority_dev, n, r->alpha,
+    hipLaunchKernelGGL(replay_append_pow, dim3((n + 255) / 256), dim3(256), 0, r->stream, staged, n, r->alpha,
                        r->d_w, r->ring, first_slot, group_rows, r->d_tmpw);
     hipLaunchKernelGGL(replay_append_sums, dim3(1), dim3(kThreads), 0, r->stream, (const float*)r->d_tmpw, n,
                        group_rows, r->d_state);
   } else {
     ProfScope prof("replay_append_weights", r->stream);
-    hipLaunchKernelGGL(replay_append_weights, dim3(1), dim3(kThreads), 0, r->stream, priority_dev, n, r->alpha,
+    hipLaunchKernelGGL(replay_append_weights, dim3(1), dim3(kThreads), 0, r->stream, staged, n, r->alpha,
                        r->d_w, r->ring, first_slot, group_rows, r->d_state);
   }
   RELA_LAUNCH_CHECK();
-  RELA_HIP(hipEventRecord(r->ev_out, r->stream));
-  RELA_HIP(hipStreamWaitEvent(producer, r->ev_out, 0));
+  RELA_HIP(hipEventRecord(r->ev_done[k], r->stream));
+  r->pstage_used[k] = true;
   r->safe_tail = (first_slot + n) % r->ring;  // :70-73
   r->safe_size += n;
   r->num_add += n;  // :190
@@ -941,6 +1025,7 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
     hipLaunchKernelGGL(replay_search, dim3(batch + pop_blocks), dim3(64), 0, r->stream, v, r->d_eff, batch,
                        r->d_ids, r->d_raw_w, r->d_evicted, r->d_state, n_pop);
   }
+  const int evict_start = r->head;
   if (n_pop > 0) {
     r->head = (r->head + n_pop) % r->ring;
     r->size -= n_pop;
@@ -1002,6 +1087,17 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
                        (const int32_t*)r->d_ids, batch);
   }
   RELA_LAUNCH_CHECK();
+  if (n_pop > 0) {  // the slots just evicted may be read by the gathers above until this point of the stream
+    hipEvent_t ev = nullptr;
+    if (!r->ev_pool.empty()) {
+      ev = r->ev_pool.back();
+      r->ev_pool.pop_back();
+    } else {
+      RELA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    RELA_HIP(hipEventRecord(ev, r->stream));
+    r->evictions.push_back({evict_start, n_pop, ev});
+  }
   if (!r->deferred_wait) {
     RELA_HIP(hipEventRecord(r->ev_out, r->stream));
     RELA_HIP(hipStreamWaitEvent(consumer, r->ev_out, 0));
@@ -1142,6 +1238,7 @@ extern "C" int rela_replay_debug_read_rows(rela_replay* r, int field, int slot, 
   DeviceGuard g(r->device);
   std::lock_guard<std::mutex> lk(r->m);
   const size_t rb = (size_t)r->row_bytes[field];
+  RELA_HIP(hipStreamSynchronize(r->copy_stream));
   RELA_HIP(hipMemcpyAsync(rows_host, r->d_fields[field] + (size_t)slot * rb, rb * (size_t)count, hipMemcpyDeviceToHost,
                           r->stream));
   RELA_HIP(hipStreamSynchronize(r->stream));

@@ -443,54 +443,67 @@ class ReplayParts {
     planned_ = keys;
   }
 
-  // the partition of the locker `key` on `device`, created by its first actor; setSchema(h) fixes the row layout
+  // the partition of the locker `key` on `device`, created by its first actor; setSchema(h) fixes the row layout.
+  // Partition g = the g-th locker in the order the Context met them (thread order), whichever thread acts first:
+  // its generator seed is seed + g.
   template <class F>
   rela_replay* handle(const void* key, int device, F&& setSchema) {
     std::lock_guard<std::mutex> lk(m_);
-    for (auto& p : parts_)
-      if (p.key == key) {
-        if (p.device != device) throw std::runtime_error("replay partition: one ModelLocker lives on one device");
-        return p.h;
-      }
-    const int G = planned_.empty() ? 1 : (int)planned_.size();
-    if ((int)parts_.size() >= G)
+    if (planned_.empty()) planned_.push_back(key);  // nobody planned: one partition, the first locker's
+    const int G = (int)planned_.size();
+    if (parts_.empty()) parts_.resize(G);
+    int g = -1;
+    for (int i = 0; i < G; ++i)
+      if (planned_[i] == key) g = i;
+    if (g < 0)
       throw std::runtime_error("replay: an actor of a ModelLocker the Context did not announce (one partition per "
                                "locker; all actors must be pushed before Context.start())");
+    Part& p = parts_[g];
+    if (p.h) {
+      if (p.device != device) throw std::runtime_error("replay partition: one ModelLocker lives on one device");
+      return p.h;
+    }
     if (capacity_ / G < 1) throw std::runtime_error("replay: capacity smaller than the number of partitions");
-    Part p;
-    p.key = key;
-    p.device = device;
-    check(rela_replay_create(&p.h, capacity_ / G, seed_ + (int)parts_.size(), alpha_, beta_, prefetch_, device),
-          "rela_replay_create");
+    rela_replay* h = nullptr;
+    check(rela_replay_create(&h, capacity_ / G, seed_ + g, alpha_, beta_, prefetch_, device), "rela_replay_create");
     try {
-      setSchema(p.h);
+      setSchema(h);
     } catch (...) {
-      rela_replay_destroy(p.h);
+      rela_replay_destroy(h);
       throw;
     }
-    parts_.push_back(p);
-    return p.h;
+    p.key = key;
+    p.device = device;
+    p.h = h;
+    return h;
   }
 
   int size() const {
     std::lock_guard<std::mutex> lk(m_);
     int n = 0;
-    for (auto& p : parts_) n += rela_replay_size(p.h);
+    for (auto& p : parts_)
+      if (p.h) n += rela_replay_size(p.h);
     return n;
   }
   int numAdd() const {
     std::lock_guard<std::mutex> lk(m_);
     int64_t n = 0;
-    for (auto& p : parts_) n += rela_replay_num_add(p.h);
+    for (auto& p : parts_)
+      if (p.h) n += rela_replay_num_add(p.h);
     return (int)n;
   }
   void shutdown() {
     std::lock_guard<std::mutex> lk(m_);
-    for (auto& p : parts_) rela_replay_shutdown(p.h);
+    for (auto& p : parts_)
+      if (p.h) rela_replay_shutdown(p.h);
   }
+  // the partitions created so far, in partition order
   std::vector<Part> parts() const {
     std::lock_guard<std::mutex> lk(m_);
-    return parts_;
+    std::vector<Part> out;
+    for (auto& p : parts_)
+      if (p.h) out.push_back(p);
+    return out;
   }
   int expected() const {
     std::lock_guard<std::mutex> lk(m_);
@@ -949,10 +962,15 @@ class ActorCohort {
     uint8_t* dst = static_cast<uint8_t*>(slot) + (int64_t)member * K_ * kObsBytes;
     uint8_t* flags = restartAll_.data_ptr<uint8_t>() + (int64_t)member * K_;
     if (planes) {
+      // the newest plane of each of this member's rows, packed into the cohort's page-locked staging (a strided 2-D
+      // DMA of K planes costs the issuing thread 2-3 x a plain copy), then ONE 1-D copy to the shard's plane stage
       constexpr int64_t kPlane = 84 * 84;
-      check(rela_memcpy2d_h2d_async(dst + 3 * kPlane, kObsBytes, sc.data_ptr<uint8_t>() + 3 * kPlane, kObsBytes, kPlane, K_,
-                                    upload_, dev),
-            "rela_memcpy2d_h2d_async");
+      uint8_t* host = planeHost_.data_ptr<uint8_t>() + (int64_t)member * K_ * kPlane;
+      const uint8_t* src = sc.data_ptr<uint8_t>() + 3 * kPlane;
+      for (int i = 0; i < K_; ++i) std::memcpy(host + i * kPlane, src + (int64_t)i * kObsBytes, (size_t)kPlane);
+      check(rela_memcpy_h2d_async(static_cast<uint8_t*>(planeStage_) + (int64_t)member * K_ * kPlane, host, (int64_t)K_ * kPlane,
+                                  upload_, dev),
+            "rela_memcpy_h2d_async");
       std::memcpy(flags, obs.at("__stack_restart").data_ptr<uint8_t>(), (size_t)K_);
     } else {
       check(rela_memcpy_h2d_async(dst, sc.data_ptr(), (int64_t)K_ * kObsBytes, upload_, dev), "rela_memcpy_h2d_async");
@@ -1105,6 +1123,9 @@ class ActorCohort {
     rewardAll_ = pin(torch::zeros({R}, torch::kFloat32));
     terminalAll_ = pin(torch::zeros({R}, torch::kBool));
     restartAll_ = pin(torch::full({R}, 2, torch::kUInt8));
+    planeHost_ = pin(torch::zeros({R, 84 * 84}, torch::kUInt8));
+    planeStage_ = lstm_ ? rela_r2d2_actor_plane_stage(hr_) : rela_apex_actor_plane_stage(h_);
+    if (!planeStage_) throw std::runtime_error("ActorCohort: could not allocate the plane stage");
     keepObs_.resize(T_);
     // RELA_PLANE_UPLOAD=0: always upload whole frame stacks (A/B switch of the sliding-stack path)
     const char* pu = std::getenv("RELA_PLANE_UPLOAD");
@@ -1123,7 +1144,8 @@ class ActorCohort {
   rela_r2d2_actor* hr_ = nullptr;
   bool created_ = false;
   void *compute_ = nullptr, *upload_ = nullptr;
-  torch::Tensor actionAll_, epsAll_, legalAll_, rewardAll_, terminalAll_, restartAll_;
+  torch::Tensor actionAll_, epsAll_, legalAll_, rewardAll_, terminalAll_, restartAll_, planeHost_;
+  void* planeStage_ = nullptr;  // device [R][7056]: the newest plane of every row
   std::vector<torch::Tensor> keepObs_;
   std::vector<std::atomic<int64_t>> numAct_;
   bool constsValid_ = false, constsDirty_ = false, draining_ = false;

@@ -46,12 +46,23 @@ def benchmark_fps(num_thread, num_game_per_thread, args):
         time.sleep(0.2)
     seen = utils.total_acts(actors)
     rates = {"without": [], "with": []}
+    ring = int(1.25 * args.replay_buffer_size)
+    rows = num_thread * num_game_per_thread
     for mode in ("without", "with"):
         for epoch in range(args.num_epoch):
             t0 = time.time()
             n_sample = 0
             if mode == "without":
-                time.sleep(args.epoch_sec)
+                # Nobody evicts in this mode (sampling does, prioritized_replay.h:311-315), so the actors park on
+                # back-pressure once the ring is full; at ~2 M env-steps/s a 2^21 replay fills within two
+                # seconds, where the reference's CPU actors never got there in 6 x 30 s.  A window counts only while
+                # the ring had room for every tick of it; it ends early when the ring is about to fill.
+                while time.time() - t0 < args.epoch_sec and replay_buffer.size() + 4 * rows < ring:
+                    time.sleep(0.005)
+                if time.time() - t0 < 0.25 * args.epoch_sec:
+                    print("without sample: epoch %d skipped (ring full: %d of %d)" % (epoch, replay_buffer.size(), ring), flush=True)
+                    seen = utils.total_acts(actors)
+                    continue
             else:
                 while time.time() - t0 <= args.epoch_sec:
                     _, weight = replay_buffer.sample(batch, args.device)
@@ -75,7 +86,8 @@ def benchmark_fps(num_thread, num_game_per_thread, args):
             replay_buffer.update_priority(weight)
         time.sleep(0.01)
     half = args.num_epoch // 2
-    return float(np.mean(rates["without"][-half or None:])), float(np.mean(rates["with"][-half or None:]))
+    tail = lambda xs: float(np.mean(xs[-max(1, min(half, len(xs))):])) if xs else float("nan")
+    return tail(rates["without"]), tail(rates["with"])
 
 
 def main(argv=None):
