@@ -308,31 +308,36 @@ def traffic_from_profiles(label):
     return None, None
 
 
-def threaded_leg(seconds=2.0, epochs=2, threads=64, games=100):
+def threaded_leg(seconds=1.0, epochs=3, threads=64, games=100):
     """The metric as the reference defines it (pyrela/benchmark.py:73-109): sum of DQNActor.num_act() deltas per
     second through rela.Context + BasicThreadLoop + DQNActor + FFPrioritizedReplay of the drop-in `rela` module --
-    C++ actor threads stepping HOST envs, per-step host -> HBM observation upload -- without and with a concurrent
-    unthrottled B = 512 sample / update_priority loop, in a child process on this box's host cores (bounded: the
-    reference protocol is 6 x 30 s windows per mode, this leg runs `epochs` x `seconds`; the replay holds 2^21
-    transitions as in pyrela/benchmark.py:161, so the windows without a sampler end before its ring is full and the
-    actors never park on back-pressure)."""
-    cmd = [sys.executable, os.path.join(ROOT, "rela_amd", "pyrela", "benchmark.py"), "--grid", "%dx%d" % (threads, games),
-           "--epoch_sec", str(seconds), "--num_epoch", str(epochs), "--replay_buffer_size", str(1 << 21)]
+    C++ actor threads stepping HOST envs, per-step host -> HBM observation upload, f32 arithmetic -- without and with a
+    concurrent unthrottled B = 512 sample / update_priority loop, in a child process on this box's host cores.  Bounded:
+    the reference protocol is 6 x 30 s windows per mode, this leg runs `epochs` x `seconds` (windows without a sampler
+    end before the 2^21 replay's ring is full -- nothing evicts in that mode); tools/threaded_protocol.sh
+    runs the full protocol once per round (profiles/).  Two env flavours: `fresh` = four new LCG planes per env-step
+    (SURVEY 8d), `sliding` = Atari's frame stacking, ONE new plane per step (atari/game_state.h:53-82), for which only
+    that plane crosses PCIe."""
+    out = {"metric": "env-steps/s = d(sum of DQNActor.num_act())/dt through rela.Context / BasicThreadLoop / DQNActor "
+                     "(pyrela/benchmark.py:73-109), host envs + H2D upload included", "unit": "env-steps/s",
+           "threads": threads, "games_per_thread": games, "host_cores": host_cores()[0],
+           "host_cores_source": host_cores()[1], "window_s": seconds, "windows": epochs,
+           "sampler": "unthrottled B=512 sample + update_priority loop on the Python thread",
+           "note": "bounded sample of the reference's 6 x 30 s protocol; mean of the last half of the valid windows"}
     t0 = time.time()
-    try:
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-        line = [l for l in out.stdout.splitlines() if l.startswith("act rate: without sample:")][-1]
-        without, with_ = (float(x.split(":")[-1]) for x in line[len("act rate: "):].split(","))
-    except Exception as e:  # noqa: BLE001  (reported, never fatal for the headline)
-        return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
-    return {"metric": "env-steps/s = d(sum of DQNActor.num_act())/dt through rela.Context / BasicThreadLoop / DQNActor "
-                      "(pyrela/benchmark.py:73-109), host envs + H2D upload included",
-            "without_sampler": without, "with_sampler": with_, "unit": "env-steps/s", "threads": threads,
-            "games_per_thread": games, "host_cores": host_cores()[0], "host_cores_source": host_cores()[1],
-            "window_s": seconds,
-            "windows": epochs,
-            "sampler": "unthrottled B=512 sample + update_priority loop on the Python thread", "wall_s": time.time() - t0,
-            "note": "bounded sample of the reference's 6 x 30 s protocol; mean of the last half of the windows"}
+    for env in ("fresh", "sliding"):
+        cmd = [sys.executable, os.path.join(ROOT, "rela_amd", "pyrela", "benchmark.py"), "--grid", "%dx%d" % (threads, games),
+               "--epoch_sec", str(seconds), "--num_epoch", str(epochs), "--replay_buffer_size", str(1 << 21), "--env", env]
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = [l for l in res.stdout.splitlines() if l.startswith("act rate: without sample:")][-1]
+            without, with_ = (float(x.split(":")[-1]) for x in line[len("act rate: "):].split(","))
+        except Exception as e:  # noqa: BLE001  (reported, never fatal for the headline)
+            out[env] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            continue
+        out[env] = {"without_sampler": without, "with_sampler": with_}
+    out["wall_s"] = time.time() - t0
+    return out
 
 
 def cpu_baseline_reference():
@@ -1484,8 +1489,10 @@ def main():
                                         "frac_issued": (fr.get("mfma") or {}).get("frac_issued"),
                                         "avg_launch_ms": fr["avg_launch_ms"]}
         th = detail.get("threaded")
-        if th is not None:
-            summary["threaded"] = th.get("error", [round(th.get("without_sampler", 0)), round(th.get("with_sampler", 0))])
+        if th is not None:  # [without sampler, with sampler] per env flavour
+            for env in ("fresh", "sliding"):
+                e = th.get(env, {})
+                summary["threaded_" + env] = e.get("error", [round(e.get("without_sampler", 0)), round(e.get("with_sampler", 0))])
         line = {"metric": detail["metric"], "value": detail["value"], "unit": "env-steps/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_med, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None,

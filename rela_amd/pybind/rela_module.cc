@@ -72,6 +72,31 @@ struct ThreadedStats {
   static int64_t now() {
     return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
   }
+  // {"env_steps": n, "ticks": n, "<phase>_us": thread-microseconds per env-step since the last reset}; reset = true
+  // zeroes the counters (diagnostics for rela_amd/pyrela/benchmark.py; not part of the reference's surface)
+  py::dict snapshot(bool reset) {
+    py::dict d;
+    const double n = std::max<double>(1.0, (double)envSteps.load());
+    d["env_steps"] = envSteps.load();
+    d["ticks"] = ticks.load();
+    auto put = [&](const char* k, std::atomic<int64_t>& v) {
+      d[k] = v.load() * 1e-3 / n;
+      if (reset) v.store(0);
+    };
+    put("env_step_us", envStep);
+    put("env_reset_us", envReset);
+    put("act_prep_upload_us", actPrep);
+    put("act_barrier_wait_us", actWait);
+    put("act_leader_us", actLead);
+    put("set_reward_terminal_us", setRT);
+    put("post_barrier_wait_us", postWait);
+    put("post_leader_us", postLead);
+    if (reset) {
+      envSteps.store(0);
+      ticks.store(0);
+    }
+    return d;
+  }
   void print() const {
     if (!on || envSteps.load() == 0) return;
     const double n = (double)envSteps.load();
@@ -1655,6 +1680,9 @@ class Context {
 
 PYBIND11_MODULE(rela, m) {
   m.doc() = "MI355X-native drop-in for facebookresearch/rela's `rela` module (C ABI: include/rela_amd.h)";
+
+  m.def("threaded_stats", [](bool reset) { return gStats.snapshot(reset); }, py::arg("reset") = false,
+        "RELA_THREADED_STATS=1: where the actor threads' wall time went since the last reset (diagnostic)");
 
   py::class_<FFTransition, std::shared_ptr<FFTransition>>(m, "FFTransition")
       .def_readwrite("obs", &FFTransition::obs)

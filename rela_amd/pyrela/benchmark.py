@@ -75,6 +75,10 @@ def benchmark_fps(num_thread, num_game_per_thread, args):
             seen = now
             print("%s sample: epoch %d, act rate: %d, buffer size: %d, sample rate: %d/s" % (
                 mode, epoch, rates[mode][-1], replay_buffer.size(), n_sample / dt), flush=True)
+            if os.environ.get("RELA_THREADED_STATS") == "1":
+                st = rela.threaded_stats(True)
+                print("   thread-us per env-step: " + ", ".join("%s %.2f" % (k[:-3], v) for k, v in st.items() if k.endswith("_us")),
+                      flush=True)
     context.terminate()
     context.resume()
     t_drain = time.time()
