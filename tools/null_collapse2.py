@@ -18,7 +18,8 @@ cap = int(os.environ.get("CAP", str(1 << 16)))
 prio = float(os.environ.get("PRIO", "0.0043"))
 feed = os.environ.get("FEED", "weight")  # what update_priority gets: the IS weights, or ones
 rep = FFReplay(cap, 7, 0.6, 0.4, 0, A, "cuda:0")
-rows = 4096
+rows = int(os.environ.get("ROWS", "4096"))
+add_rows = int(os.environ.get("ADD", str(rows)))
 obs = torch.randint(0, 256, (rows, 4, 84, 84), dtype=torch.uint8, device="cuda")
 z = torch.zeros(rows, device="cuda")
 zi = torch.zeros(rows, dtype=torch.int64, device="cuda")
@@ -46,5 +47,5 @@ for r in range(int(os.environ.get("ROUNDS", "12"))):
                       "ids": [int(ids.min()), int(ids.max()), int(len(set(ids.tolist())))], "sum": st.sum,
                       "size": st.size, "dev_error": st.dev_error}), flush=True)
     rep.update_priority(w if feed == "weight" else torch.ones(B, device="cuda"))
-    rep.add_rows(rows, ptrs, const, nonblocking=True)
+    rep.add_rows(add_rows, ptrs, const[:add_rows], nonblocking=True)
     torch.cuda.synchronize()
