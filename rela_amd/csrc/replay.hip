@@ -249,6 +249,14 @@ __global__ __launch_bounds__(kThreads) void replay_scatter_rows_indexed(const ui
   }
 }
 
+// what a failed scan leaves in host memory (see replay_search)
+struct ScanFailure {
+  int32_t code;
+  int32_t size;
+  float sum_f;
+  double target;
+};
+
 // ---- sample ---------------------------------------------------------------------------
 // The stratified targets (:261-280) are computed by the chain kernel of the scan index (seqsum.hip).
 // Blocks [0, batch): one wavefront per stratum (seq_find_wave: three coalesced loads over the exact prefix
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(kThreads) void replay_scatter_rows_indexed(const ui
 __global__ __launch_bounds__(64) void replay_search(SeqView v, const double* __restrict__ eff, int batch,
                                                     int32_t* __restrict__ ids, float* __restrict__ raw_w,
                                                     uint8_t* __restrict__ evicted, ReplayDevState* __restrict__ st,
-                                                    int n_pop) {
+                                                    int n_pop, ScanFailure* __restrict__ fail_host) {
   const int i = blockIdx.x;
   if (i >= batch) {
     const int pb = i - batch, npb = gridDim.x - batch;
@@ -278,6 +286,12 @@ __global__ __launch_bounds__(64) void replay_search(SeqView v, const double* __r
   if (!h.found) {  // :297-302 (the reference aborts here)
     st->err = RELA_ESCAN;
     k = v.size > 0 ? v.size - 1 : 0;
+    // tell the host without a synchronisation: a page-locked record the next replay call reads (what the
+    // reference prints before its assert(false): the target and where the scan ended)
+    fail_host->target = eff[i];
+    fail_host->size = (int32_t)v.size;
+    fail_host->sum_f = st->sum_f;
+    __hip_atomic_store(&fail_host->code, (int32_t)RELA_ESCAN, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   const int64_t p = seq_phys(v, k);
   ids[i] = (int32_t)p;
@@ -498,6 +512,9 @@ struct rela_replay {
   // its producer alone between reserve and commit (prioritized_replay.h:58-66 copies them with the mutex released),
   // so only the COMMIT -- weights and sum_, in slot order -- has to take its turn among sample / update.  The
   // priorities travel through a small ring of staging buffers, so the producer never waits for `stream` at all.
+  // page-locked record a scan that ran off the end of the ring writes (prioritized_replay.h:297-302: the reference
+  // prints it and aborts); read at the next sample / update_priority, which then fail with RELA_ESCAN
+  ScanFailure* scan_failure = nullptr;
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_cin = nullptr, ev_cout = nullptr;
   static constexpr int kPrioStages = 8;
@@ -570,6 +587,8 @@ extern "C" int rela_replay_create(rela_replay** out, int capacity, int seed, flo
   RELA_HIP(hipEventCreateWithFlags(&r->ev_in, hipEventDisableTiming));
   RELA_HIP(hipEventCreateWithFlags(&r->ev_out, hipEventDisableTiming));
   RELA_HIP(hipEventCreateWithFlags(&r->ev_wait, hipEventDisableTiming));
+  RELA_HIP(hipHostMalloc(reinterpret_cast<void**>(&r->scan_failure), sizeof(ScanFailure), hipHostMallocDefault));
+  memset(r->scan_failure, 0, sizeof(ScanFailure));
   RELA_HIP(hipStreamCreateWithFlags(&r->copy_stream, hipStreamNonBlocking));
   RELA_HIP(hipEventCreateWithFlags(&r->ev_cin, hipEventDisableTiming));
   RELA_HIP(hipEventCreateWithFlags(&r->ev_cout, hipEventDisableTiming));
@@ -610,6 +629,7 @@ extern "C" void rela_replay_destroy(rela_replay* r) {
   }
   for (auto& e : r->evictions) (void)hipEventDestroy(e.done);
   for (auto e : r->ev_pool) (void)hipEventDestroy(e);
+  (void)hipHostFree(r->scan_failure);
   (void)hipEventDestroy(r->ev_cin);
   (void)hipEventDestroy(r->ev_cout);
   (void)hipStreamDestroy(r->copy_stream);
@@ -988,6 +1008,19 @@ extern "C" int rela_replay_add(rela_replay* r, int n, const void* const* rows_de
   return rela_replay_commit_add(r, slot, n, priority_dev, stream_);
 }
 
+// (caller holds r->m) A previous sample's scan ran off the end of the ring: the reference prints the state and aborts
+// (prioritized_replay.h:297-302).  It happens when sum_ -- block sums accumulated in FLOAT on append, exact
+// differences on pop / update (:58-66,85-95) -- has drifted more than the 0.2 guard of :280 above the sum of the stored
+// weights, e.g. with identical priorities, whose block sums all round the same way.  Sticky.
+static int scan_failed(rela_replay* r, const char* where) {
+  if (!r->scan_failure || __atomic_load_n(&r->scan_failure->code, __ATOMIC_ACQUIRE) == 0) return RELA_OK;
+  set_last_error("%s: a stratified target of an earlier sample ran off the end of the ring -- nextIdx: %d/%d, sum: %.10g, "
+                 "rand: %.10g (the reference aborts here, rela/prioritized_replay.h:297-302): sum_ has drifted above the "
+                 "sum of the stored weights", where, r->scan_failure->size, r->scan_failure->size,
+                 (double)r->scan_failure->sum_f, r->scan_failure->target);
+  return RELA_ESCAN;
+}
+
 extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_rows_dev, float* out_weight_dev,
                                   void* stream_) {
   RELA_CHECK(r && batch > 0 && batch <= kMaxBatch && out_weight_dev, RELA_EINVAL,
@@ -997,6 +1030,7 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
   std::unique_lock<std::mutex> lk(r->m);
   RELA_CHECK(r->n_sampled == 0, RELA_ESTATE,
              "Error: previous samples' priority has not been updated.");  // :203-206
+  if (int rc = scan_failed(r, "rela_replay_sample")) return rc;
   RELA_CHECK(r->safe_size > 0, RELA_ESTATE, "rela_replay_sample: replay is empty");
   // raw 32-bit draws, one per sample (generate_canonical<float,24> consumes exactly one)
   std::vector<uint32_t> draws(batch);
@@ -1023,7 +1057,7 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
     const int pop_blocks = n_pop > 0 ? std::min(ceil_div(n_pop, 256), 128) : 0;
     ProfScope prof("replay_search", r->stream);
     hipLaunchKernelGGL(replay_search, dim3(batch + pop_blocks), dim3(64), 0, r->stream, v, r->d_eff, batch,
-                       r->d_ids, r->d_raw_w, r->d_evicted, r->d_state, n_pop);
+                       r->d_ids, r->d_raw_w, r->d_evicted, r->d_state, n_pop, r->scan_failure);
   }
   const int evict_start = r->head;
   if (n_pop > 0) {
@@ -1116,6 +1150,7 @@ extern "C" int rela_replay_update_priority(rela_replay* r, int n, const float* p
   std::unique_lock<std::mutex> lk(r->m);
   RELA_CHECK(n == r->n_sampled && n > 0, RELA_ESTATE,
              "rela_replay_update_priority: %d priorities for an outstanding batch of %d", n, r->n_sampled);  // :237
+  if (int rc = scan_failed(r, "rela_replay_update_priority")) return rc;
   const float* p = priority;
   if (on_device) {
     RELA_HIP(hipEventRecord(r->ev_in, producer));

@@ -140,10 +140,14 @@ class SyntheticAtariEnv : public rela::Env RELA_FRAME_ROW_BASE {
 // Zero-cost env for measuring the ENGINE's own ceiling through rela.Context / BasicThreadLoop / DQNActor (the
 // observation is a constant frame stack, the reward 0, episodes end after episode_len steps): whatever rate the
 // threaded benchmark reaches with it is what the runtime -- thread loop, VectorEnv, upload, cohort barrier, device
-// tick -- can do when the env costs nothing.
+// tick -- can do when the env costs nothing.  The reward is a cheap pseudo-random FLOAT in [-0.5, 0.5): with constant
+// frames the Q-values are constant, and constant TD priorities make every float block sum of the replay round the
+// same way, so sum_ drifts systematically above the stored weights until a scan runs off the ring -- where the
+// reference aborts (prioritized_replay.h:297-302) and this engine raises.
 class NullAtariEnv : public rela::Env RELA_FRAME_ROW_BASE {
  public:
-  NullAtariEnv(float eps, int numAction, int episodeLen) : numAction_(numAction), episodeLen_(episodeLen) {
+  NullAtariEnv(float eps, int numAction, int episodeLen, int seed = 1)
+      : numAction_(numAction), episodeLen_(episodeLen), state_((uint32_t)seed * 2654435761u + 12345u) {
     eps_ = torch::full({1}, eps, torch::kFloat32);
     legal_ = torch::ones({numAction}, torch::kFloat32);
     frame_ = torch::full({4, 84, 84}, 17, torch::kUInt8);
@@ -157,7 +161,9 @@ class NullAtariEnv : public rela::Env RELA_FRAME_ROW_BASE {
   std::tuple<rela::TensorDict, float, bool> step(const rela::TensorDict& action) final {
     (void)action;
     if (++steps_ >= episodeLen_) terminal_ = true;
-    return std::make_tuple(rela::TensorDict{{"s", frame_}, {"eps", eps_}, {"legal_move", legal_}}, 0.f, terminal_);
+    state_ = state_ * 1664525u + 1013904223u;
+    const float reward = (float)(state_ >> 8) * (1.0f / 16777216.0f) - 0.5f;
+    return std::make_tuple(rela::TensorDict{{"s", frame_}, {"eps", eps_}, {"legal_move", legal_}}, reward, terminal_);
   }
   bool terminated() const final { return terminal_; }
 #if RELA_HAS_FRAME_ROW
@@ -167,6 +173,7 @@ class NullAtariEnv : public rela::Env RELA_FRAME_ROW_BASE {
 
  private:
   const int numAction_, episodeLen_;
+  uint32_t state_;
   int steps_ = 0;
   bool terminal_ = true;
   torch::Tensor eps_, legal_, frame_;
@@ -185,7 +192,7 @@ PYBIND11_MODULE(synth_atari, m) {
       .def("terminated", &SyntheticAtariEnv::terminated)
       .def("get_episode_reward", &SyntheticAtariEnv::getEpisodeReward);
   py::class_<NullAtariEnv, rela::Env, std::shared_ptr<NullAtariEnv>>(m, "NullAtariEnv")
-      .def(py::init<float, int, int>(), py::arg("eps"), py::arg("num_action"), py::arg("episode_len"))
+      .def(py::init<float, int, int, int>(), py::arg("eps"), py::arg("num_action"), py::arg("episode_len"), py::arg("seed") = 1)
       .def("num_action", &NullAtariEnv::numAction)
       .def("reset", &NullAtariEnv::reset)
       .def("step", &NullAtariEnv::step)

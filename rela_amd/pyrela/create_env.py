@@ -25,7 +25,7 @@ def get_num_action(game_name):
 def create_game(seed, eps, episode_len):
     # RELA_SYNTH_ENV=null: the zero-cost env (constant frames, reward 0): the runtime's own ceiling
     if os.environ.get("RELA_SYNTH_ENV") == "null":
-        return synth_atari.NullAtariEnv(eps, NUM_ACTION, episode_len)
+        return synth_atari.NullAtariEnv(eps, NUM_ACTION, episode_len, seed)
     # RELA_SYNTH_SLIDING=1: Atari-like frame stacks (ONE new 84x84 plane per step, the first plane of an episode
     # repeated four times: atari/game_state.h:53-82) instead of four fresh planes per step -- a quarter of the host
     # work per env-step, and the stacks a de-duplicating replay (RELA_REPLAY_DEDUP=plane) expects

@@ -221,6 +221,39 @@ def test_update_with_heavy_duplicates():
         g.close()
 
 
+def test_scan_running_off_the_ring_fails_loudly_like_the_reference():
+    """prioritized_replay.h:297-302: when sum_ -- float block sums on append (:58-66), exact differences on pop /
+    update -- has drifted more than the 0.2 guard (:280) above the sum of the stored weights, a stratified target is
+    never reached and the reference prints `nextIdx: size/size ...` and aborts.  65,536 identical priorities per block
+    make every float block sum round the same way (sum_ 12,471.8 against 12,460.1 stored): the oracle reports the
+    abort (-3) and the device path must not carry on silently -- the failing sample leaves a page-locked record, and
+    the next update_priority / sample returns RELA_ESCAN with the reference's diagnostics."""
+    import torch
+
+    from gpu_util import GpuReplay
+    from oracle_lib import OracleReplay
+    from rela_amd import _capi as capi
+
+    cap, block = 1 << 18, 1 << 16
+    g = GpuReplay(cap, 3, 1.0, 0.4)
+    o = OracleReplay(cap, 3, 1.0, 0.4)
+    prio = np.full(block, 0.03802603483200073, np.float32)
+    for k in range(int(1.25 * cap) // block):
+        tags = np.arange(k * block, (k + 1) * block)
+        assert g.add_tags(tags, prio) == 0
+        assert o.add(tags, prio) == 0
+    rc_o, _, _, _ = o.sample(512)
+    assert rc_o == -3  # the reference's assert(false)
+    rc, _, _ = g.sample(512)  # queued; the scan fails on the device
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert g.state()["dev_error"] == capi.ESCAN
+    assert g.update(np.ones(512, np.float32)) == capi.ESCAN
+    msg = capi.lib.rela_last_error()
+    assert b"ran off the end of the ring" in msg and b"nextIdx: %d/%d" % (int(1.25 * cap), int(1.25 * cap)) in msg, msg
+    g.close()
+
+
 def test_protocol_errors():
     from gpu_util import GpuReplay
     from rela_amd import _capi as capi
