@@ -1358,7 +1358,7 @@ def main():
             # bf16 MFMA products issued per algorithmic product: conv1 multiplies exact u8 inputs by weights split
             # in 3 bf16 pieces (f32 mode: exact) or 2 (bf16x2 mode); the other layers 3 in bf16x2 mode, f32 MFMA else
             products = (2 if fast else 3) if name == "conv1_bf16x3" else (3 if fast else 0)
-            conv1_i8 = os.environ.get("RELA_CONV12") != "bf16"
+            conv1_i8 = True  # (the half-frame bf16 conv1 -> conv2 kernel was removed in r4)
             if name == "conv12_fused":
                 # conv2: 3 bf16 products per product.  conv1: 3 int8 digit products (csrc/ffnet.hip: conv12_i8) on
                 # v_mfma_i32_16x16x64_i8, which runs at twice the bf16 rate = 1.5 bf16-MFMA-equivalents

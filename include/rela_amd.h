@@ -260,8 +260,8 @@ int rela_ffnet_debug_conv12_stamps(const rela_ffnet* net, int n, const uint8_t* 
                                    void* stream);
 /* Test hook: conv1 -> conv2 of the split-bf16 mode for n frames through the job form of the kernel.  a1_records
  * [n][400][hi 32 | lo 32] bf16 and a2_records [n][81][hi 64 | lo 64] bf16 are device buffers; scale_host / bias_host
- * (32 floats each, or NULL) receive conv1's packed per-channel scales and biases when conv1 runs on the int8 matrix cores
- * (csrc/ffnet.hip: conv12_i8), zeros otherwise. */
+ * (32 floats each, or NULL) receive conv1's packed per-channel scales and biases (conv1 runs on the int8 matrix cores,
+ * csrc/ffnet.hip: conv12_i8). */
 int rela_ffnet_debug_conv12_records(const rela_ffnet* net, int n, const uint8_t* s_dev, uint8_t* a1_records,
                                     uint8_t* a2_records, float* scale_host, float* bias_host, void* stream);
 /* The same for conv3 of the split-bf16 mode (the first 8 groups of two frames of block 0; 5 points per group). */
@@ -270,7 +270,6 @@ int rela_ffnet_debug_conv3_stamps(const rela_ffnet* net, int n, const uint8_t* a
 /* The same for fc_bf16s (positions 8..15 of block 0; 5 points per position). */
 int rela_ffnet_debug_fc_stamps(const rela_ffnet* net, int n, const uint8_t* a3_records, unsigned long long* out_host,
                                void* stream);
-int rela_ffnet_debug_pipe_timeout(rela_ffnet* net, unsigned* out);
 /* bytes of scratch rela_ffnet_forward needs for a batch of n */
 int64_t rela_ffnet_workspace_bytes(const rela_ffnet* net, int n);
 

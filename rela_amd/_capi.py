@@ -103,7 +103,6 @@ _sig("rela_ffnet_num_action", i32, [vp])
 _sig("rela_ffnet_version", C.c_uint64, [vp])
 _sig("rela_ffnet_set_precision", i32, [vp, i32])
 _sig("rela_ffnet_precision", i32, [vp])
-_sig("rela_ffnet_debug_pipe_timeout", i32, [vp, P(C.c_uint)])
 _sig("rela_ffnet_debug_conv12_stamps", i32, [vp, i32, vp, vp, vp])
 _sig("rela_ffnet_debug_fc_stamps", i32, [vp, i32, vp, vp, vp])
 _sig("rela_ffnet_debug_conv3_stamps", i32, [vp, i32, vp, vp, vp])

@@ -47,7 +47,6 @@ struct FFNetDev {
   float *Bh = nullptr, *bh = nullptr;  // heads frags [2][128][64], bias[32]  (cols 0..A-1 = fc_a, col 31 = fc_v)
   // split-bf16 fast path: [ct][ks][hi, lo][lane] x 8 bf16 (see "Split-bf16" below)
   uint4 *B2f = nullptr, *B3f = nullptr, *Bff = nullptr;
-  uint4* B1p = nullptr;  // conv1 frags as B1, k-steps plane-major (conv1_persist)
   float* Bhp = nullptr;  // heads weights [ct 2][wave 4][j 32][lane 64] in the k order of heads_duel
   // conv1 for the int8 matrix cores (conv12_i8): digits [hi, mid, lo][ct 2][tap 4][lane 64] x 16 int8, the channels'
   // scales s_c and the biases b_c + 128 s_c sum_k q_k
@@ -524,7 +523,7 @@ __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_floa
 
 // conv1 weights (32,4,8,8)/255 -> three bf16 planes in MFMA 16x16x32 fragment order.
 // w == hi + mid + lo exactly for every finite fp32 weight (each residual is exact in fp32).
-// plane_major: k-step ks = kernel row ks of all four planes (lane group g = plane), the order conv1_persist reads
+// plane_major: k-step ks = kernel row ks of all four planes (lane group g = plane; unused since the half-frame kernels went in r4)
 // its LDS image in; otherwise k runs (c, kh, kw) linearly (conv1_bf16x3).
 __device__ __forceinline__ void pack_conv1_bf16x3_at(int idx, const float* __restrict__ w, uint16_t* __restrict__ frag, int plane_major) {
   if (idx >= 2 * 8 * 64 * 8) return;
@@ -597,190 +596,6 @@ __device__ __forceinline__ void split_store_lds2(uint8_t* rec0, uint8_t* rec1, i
   *reinterpret_cast<uint16_t*>(rec1 + col * 2) = hb[1];
   *reinterpret_cast<uint16_t*>(rec0 + C * 2 + col * 2) = lb[0];
   *reinterpret_cast<uint16_t*>(rec1 + C * 2 + col * 2) = lb[1];
-}
-
-// conv1, persistent and weight-stationary.  Differences from conv1_bf16x3 above, which it replaces for batches
-// that fill the chip:
-//   * the u8 frame is converted to bf16 ONCE, on its way into LDS (every input byte feeds 4 output pixels and
-//     both channel tiles; converting per fragment made the kernel VALU-bound: 12 conversions per 6 MFMAs);
-//   * a wave owns ONE 16-channel tile with its 3 x 8 weight fragments resident in registers, and reads its A
-//     fragments (8 consecutive bf16 = two ds_read_b64) D steps ahead of the MFMAs in a register ring;
-//   * the output tile is staged in LDS and leaves as whole 16-byte-per-lane rows;
-//   * the unit of work is HALF a frame (10 output rows = 200 pixels, 44 input rows) and a block is 4 waves, so
-//     that TWO blocks share a CU (60 KB of LDS each): a block's phases are serial (load/convert, MFMA, split +
-//     stage, copy out: measured 10 + 67 + 25 + 29 us of a 163 us launch when one 8-wave block per CU ran them
-//     in lockstep), and the second block's MFMAs fill the first one's other phases.
-// k-steps are plane-major (pack_conv1_bf16x3 plane_major = 1); per output element the k-steps ascend and the
-// weight pieces go lo, mid, hi.
-struct Conv1P {
-  static constexpr int THREADS = 256;
-  static constexpr int HP = 200, RT = 13, OC = 32, KS = 8, RG = 2, RPW = 7, D = 6;  // 12.5 row tiles per half
-  static constexpr int IN_ELEMS = 4 * 84 * 84, PLANE_ELEMS = 84 * 84;
-  static constexpr int HROWS = 44, HPLANE_ELEMS = HROWS * 84;  // input rows 40h .. 40h+43 of each plane
-  // bf16 image of a half frame; the plane stride is 128 (mod 256) bytes, so that the two planes a ds_read_b64
-  // pass serves (lanes 0-31 = lane groups 0 and 1) fall on complementary halves of the banks
-  static constexpr int PLANE_BYTES = HPLANE_ELEMS * 2 + 160;
-  static_assert(PLANE_BYTES % 256 == 128 && PLANE_BYTES % 16 == 0, "plane stride");
-  static constexpr int TILE_BYTES = 4 * PLANE_BYTES;
-  static constexpr int OUT_BYTES = HP * OC * 4;    // f32 rows or split records: 128 B per pixel either way
-  static constexpr int OROW = OC * 4 + 16;         // staged row stride: rows 4 apart (lane groups) on different banks
-  static constexpr int LDS_BYTES = TILE_BYTES + RT * 16 * OROW;  // (the 13th tile's rows 200..207 are never copied)
-  static constexpr int PV16 = HPLANE_ELEMS / 16;   // 231 16-byte chunks of u8 per plane and half
-  static constexpr int V16 = 4 * PV16;
-  static constexpr int IT = (V16 + THREADS - 1) / THREADS;
-  static constexpr int OV16 = OUT_BYTES / 16;
-  static_assert(HPLANE_ELEMS % 16 == 0 && (40 * 84) % 16 == 0 && PLANE_ELEMS % 16 == 0, "chunk alignment");
-};
-
-template <bool SPLIT, int PIECES>
-__global__ __launch_bounds__(Conv1P::THREADS, 2) void conv1_persist(const uint8_t* __restrict__ in,
-                                                                    const uint4* __restrict__ Bfrag,
-                                                                    const float* __restrict__ bias,
-                                                                    float* __restrict__ out, int N) {
-  using C = Conv1P;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* tile = smem;
-  uint8_t* ostage = smem + C::TILE_BYTES;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, g = lane >> 4;
-  const int ct = wave & 1, rg = wave >> 1;
-
-  // PIECES = 3: exact f32 weights (hi + mid + lo); 2: the 16 leading mantissa bits, as the other fast layers
-  bf16x8 b[PIECES][C::KS];
-#pragma unroll
-  for (int p = 0; p < PIECES; ++p)
-#pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks)
-      b[p][ks] = __builtin_bit_cast(bf16x8, Bfrag[((p * 2 + ct) * C::KS + ks) * 64 + lane]);
-  int abase[C::RPW], abase2[C::RPW];
-#pragma unroll
-  for (int t = 0; t < C::RPW; ++t) {
-    const int rt = min(rg + t * C::RG, C::RT - 1);  // (the odd waves' 7th tile repeats the 13th, unstored)
-    const int m = min(rt * 16 + li, C::HP - 1);
-    const int oy = m / 20, ox = m - oy * 20;
-    abase[t] = g * C::PLANE_BYTES + (4 * oy * 84 + 4 * ox) * 2;
-    // The second half of a fragment is addressed through a register of its own, opaque to the compiler:
-    // with a common base it fuses the two 8-byte reads into ds_read2_b64 (8 LDS cycles, 128 B/clk) where two
-    // ds_read_b64 take 2 + 2 (256 B/clk).
-    abase2[t] = abase[t] + 8;
-    asm volatile("" : "+v"(abase2[t]));
-  }
-  const int col = ct * 16 + li;
-  const float bv = bias[col];
-
-  // unpredicated staging (clamped chunk index: the spare lanes repeat the last chunk), so that the compiler can
-  // count vmcnt instead of draining it
-  uint4 st[C::IT];
-  auto g_load = [&](int unit) {
-    const int n = unit >> 1, h = unit & 1;
-    const uint8_t* src = in + (size_t)n * C::IN_ELEMS + h * (40 * 84);
-#pragma unroll
-    for (int j = 0; j < C::IT; ++j) {
-      const int i = min(tid + j * C::THREADS, C::V16 - 1);
-      const int pl = i / C::PV16, r = i - pl * C::PV16;
-      st[j] = *reinterpret_cast<const uint4*>(src + pl * C::PLANE_ELEMS + r * 16);
-    }
-  };
-  auto cvt_store = [&]() {
-#pragma unroll
-    for (int j = 0; j < C::IT; ++j) {
-      const int i = min(tid + j * C::THREADS, C::V16 - 1);
-      const int pl = i / C::PV16, r = i - pl * C::PV16;
-      uint4* dst = reinterpret_cast<uint4*>(tile + pl * C::PLANE_BYTES + r * 32);
-      dst[0] = u8x8_to_bf16x8(st[j].x, st[j].y);
-      dst[1] = u8x8_to_bf16x8(st[j].z, st[j].w);
-    }
-  };
-
-  const int units = 2 * N;
-  int unit = blockIdx.x;
-  if (unit >= units) return;
-  g_load(unit);
-  cvt_store();
-#pragma unroll
-  for (int p = 0; p < PIECES; ++p)
-#pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) pin_loaded(b[p][ks]);
-  __syncthreads();
-  for (; unit < units; unit += gridDim.x) {
-    const int nxt = unit + (int)gridDim.x;
-    g_load(nxt < units ? nxt : unit);  // (the last round re-reads its own half: no branch around the loads)
-    f32x4 acc[C::RPW];  // starts at the bias
-#pragma unroll
-    for (int t = 0; t < C::RPW; ++t) acc[t] = f32x4{bv, bv, bv, bv};
-    // k-step ks = kernel row ks of the four planes: lane group g owns plane g, its 8 k's are 8 CONSECUTIVE
-    // pixels of image row 4*oy + ks (8-byte aligned in the bf16 image)
-    constexpr int TOT = C::KS * C::RPW;
-    uint2 a0[C::D], a1[C::D];
-    auto a_issue = [&](int idx, int slot) {
-      const int ks = idx / C::RPW, t = idx - ks * C::RPW;
-      const int koff = ks * 84 * 2;
-      a0[slot] = *reinterpret_cast<const uint2*>(tile + abase[t] + koff);
-      a1[slot] = *reinterpret_cast<const uint2*>(tile + abase2[t] + koff);
-    };
-#pragma unroll
-    for (int i = 0; i < C::D; ++i) a_issue(i, i);
-    __builtin_amdgcn_sched_barrier(0);
-    // Row tiles go through the MFMAs in PAIRS with their three weight pieces interleaved (smallest piece first so
-    // the big one is added last): consecutive MFMAs never feed each other, which matters whenever the wave has
-    // the SIMD to itself (the other block in its staging phases).
-    auto frag = [&](int slot) {
-      return __builtin_bit_cast(bf16x8, make_uint4(a0[slot].x, a0[slot].y, a1[slot].x, a1[slot].y));
-    };
-#pragma unroll
-    for (int ks = 0; ks < C::KS; ++ks) {
-#pragma unroll
-      for (int t = 0; t + 1 < C::RPW; t += 2) {
-        const int idx = ks * C::RPW + t;
-        const int slot = idx % C::D, slot1 = (idx + 1) % C::D;
-        const bf16x8 x0 = frag(slot), x1 = frag(slot1);
-#pragma unroll
-        for (int p = PIECES - 1; p >= 0; --p) {
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, b[p][ks], acc[t], 0, 0, 0);
-          acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, b[p][ks], acc[t + 1], 0, 0, 0);
-        }
-        if (idx + C::D < TOT) a_issue(idx + C::D, slot);
-        if (idx + 1 + C::D < TOT) a_issue(idx + 1 + C::D, slot1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (C::RPW & 1) {
-        const int t = C::RPW - 1, idx = ks * C::RPW + t, slot = idx % C::D;
-        const bf16x8 x0 = frag(slot);
-#pragma unroll
-        for (int p = PIECES - 1; p >= 0; --p)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, b[p][ks], acc[t], 0, 0, 0);
-        if (idx + C::D < TOT) a_issue(idx + C::D, slot);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    __syncthreads();  // everyone is done with this half frame: the next one replaces it
-    cvt_store();
-#pragma unroll
-    for (int t = 0; t < C::RPW; ++t) {
-      const int rt = min(rg + t * C::RG, C::RT - 1);  // (a repeated 13th tile is staged twice, same values)
-      const int m0 = rt * 16 + g * 4;
-#pragma unroll
-      for (int r = 0; r < 4; r += 2) {
-        const float v0 = acc[t][r], v1 = acc[t][r + 1];
-        const float o0 = v0 > 0.f ? v0 : 0.f, o1 = v1 > 0.f ? v1 : 0.f;
-        uint8_t* rec0 = ostage + (size_t)(m0 + r) * C::OROW;
-        uint8_t* rec1 = rec0 + C::OROW;
-        if constexpr (SPLIT) {
-          split_store_lds2(rec0, rec1, C::OC, col, o0, o1);
-        } else {
-          reinterpret_cast<float*>(rec0)[col] = o0;
-          reinterpret_cast<float*>(rec1)[col] = o1;
-        }
-      }
-    }
-    __syncthreads();  // output rows complete, next half frame in place
-    {
-      uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(out) + (size_t)unit * C::OUT_BYTES);
-      for (int i = tid; i < C::OV16; i += C::THREADS)
-        dst[i] = *reinterpret_cast<const uint4*>(ostage + (i >> 3) * C::OROW + (i & 7) * 16);
-    }
-  }
 }
 
 // conv on split records, weight-stationary and persistent (one block per CU walks over its sample groups with
@@ -1024,273 +839,6 @@ __global__ __launch_bounds__(kThreads) void conv3_bf16s_stamps(const uint8_t* __
                                                                const float* __restrict__ bias, uint8_t* __restrict__ out,
                                                                int N, unsigned long long* stamps) {
   conv_bf16s_body<Conv3F, true>(in, Bfrag, bias, out, N, blockIdx.x, gridDim.x, stamps);
-}
-
-// conv1 -> conv2 fused per frame: conv1's output (400 pixels x 32 channels of split records) is written straight
-// into conv2's padded LDS input tile and never travels to HBM (-328 MB written and -328 MB read per 6,400 frames;
-// staging that read alone took 82 of conv2's 123 us, the copy-out 29 of conv1's 133).  One 8-wave block per CU:
-//   LDS = half-frame bf16 image T1 (30 KB) | conv2 input tile T2 (59 KB) | conv2 output rows O (21 KB) | conv1's
-//         weight fragments (32 KB: conv2's 128 fragment registers per lane leave no room for them)
-//   per frame: conv1 on half 0 -> T2[0..199] | barrier | convert half 1 into T1 | barrier | conv1 on half 1 ->
-//         T2[200..399] | barrier | conv2 from T2 -> O (the next frame's first half is converted into T1 meanwhile)
-//         | barrier | O -> HBM (overlaps the next frame's conv1)
-// conv1 waves: 2 channel tiles x 4 row groups (13 row tiles per half, 4 per group); conv2 waves: 4 x 2 as in
-// conv_bf16s.  Raw u8 chunks of the next half frame wait in registers (issued one stage early).
-struct Conv12 {
-  using C1 = Conv1P;
-  using C2 = Conv2F;
-  static constexpr int RPW1 = 4, RG1 = 4, D1 = 4;
-  static constexpr int T1_BYTES = C1::TILE_BYTES, T2_BYTES = C2::LDS_BYTES, O_BYTES = C2::OUT_BYTES + 256;
-  static constexpr int B1_UINT4 = 2 * 2 * C1::KS * 64;  // [piece 2][ct 2][ks 8][lane 64]
-  static constexpr int LDS_TOTAL = T1_BYTES + T2_BYTES + O_BYTES + B1_UINT4 * 16;
-  static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
-  static constexpr int IT = (C1::V16 + kThreads - 1) / kThreads;  // 2
-};
-
-// The body of the kernel, shared by conv12_bf16s (one net, blocks = the whole grid) and conv12_bf16s_jobs (the
-// learner's forwards: several nets / batches in ONE launch, each job on its own range of blocks).  JOBS adds: rows
-// from two source buffers (rows >= n_in0 come from in1), and a copy of conv1's records (a1, which otherwise never
-// leaves LDS) to a1_out for the rows < n_a1 -- the pass whose activations the backward kernels read.
-template <bool JOBS, bool STAMPS = false>
-__device__ __forceinline__ void conv12_body(const uint8_t* __restrict__ in, const uint8_t* __restrict__ in1, int n_in0,
-                                            const uint4* __restrict__ B1frag, const float* __restrict__ bias1,
-                                            const uint4* __restrict__ B2frag, const float* __restrict__ bias2,
-                                            uint8_t* __restrict__ out, uint8_t* __restrict__ a1_out, int a1_lo, int n_a1,
-                                            int N, int bid, int nblk, unsigned long long* stamps = nullptr) {
-  using F = Conv12;
-  // STAMPS (diagnostic build of the kernel only, rela_ffnet_debug_conv12_stamps): lane 0 of waves 0 and 7 of block 0
-  // writes the shader clock at every phase boundary of its first frames to `stamps` [2 waves][kStampFrames][kStampPoints]
-  int stamp_frame = 0;
-  auto stamp = [&](int point) {
-    if constexpr (STAMPS) {
-      if (bid == 0 && (threadIdx.x == 0 || threadIdx.x == 448) && stamp_frame < kStampFrames)
-        stamps[((threadIdx.x == 0 ? 0 : 1) * kStampFrames + stamp_frame) * kStampPoints + point] = __builtin_amdgcn_s_memtime();
-    }
-  };
-  using C1 = Conv1P;
-  using C2 = Conv2F;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* t1 = smem;
-  uint8_t* t2 = smem + F::T1_BYTES;
-  uint8_t* otile = t2 + F::T2_BYTES;
-  uint8_t* spare = otile + C2::OUT_BYTES;  // 256 B: rows past the last pixel of either layer land here
-  uint4* b1s = reinterpret_cast<uint4*>(otile + F::O_BYTES);
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, g = lane >> 4;
-
-  // ---- residents ----
-  for (int i = tid; i < F::B1_UINT4; i += kThreads) b1s[i] = B1frag[i];  // pieces hi, mid of [3][2][8][64]
-  const int ct1 = wave & 1, rg1 = wave >> 1;
-  const int ct2 = wave % C2::CT, rg2 = wave / C2::CT;
-  bf16x8 bh[C2::KS], bl[C2::KS];
-  {
-    const uint4* bp = B2frag + (size_t)ct2 * C2::KS * 2 * 64 + lane;
-#pragma unroll
-    for (int ks = 0; ks < C2::KS; ++ks) {
-      bh[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2) * 64]);
-      bl[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2 + 1) * 64]);
-    }
-  }
-  // operands swapped (weights as the A operand): a lane holds four consecutive channels of one pixel
-  const int ch1 = ct1 * 16 + 4 * g, ch2 = ct2 * 16 + 4 * g;
-  const f32x4 bv1 = *reinterpret_cast<const f32x4*>(bias1 + ch1), bv2 = *reinterpret_cast<const f32x4*>(bias2 + ch2);
-  // conv1 A fragments: lane group g = plane, 8 consecutive pixels of image row 4*oy + ks (see conv1_persist)
-  int a1base[F::RPW1], a1base2[F::RPW1];
-#pragma unroll
-  for (int t = 0; t < F::RPW1; ++t) {
-    const int rt = min(rg1 + t * F::RG1, C1::RT - 1);
-    const int m = min(rt * 16 + li, C1::HP - 1);
-    const int oy = m / 20, ox = m - oy * 20;
-    a1base[t] = g * C1::PLANE_BYTES + (4 * oy * 84 + 4 * ox) * 2;
-    a1base2[t] = a1base[t] + 8;
-    asm volatile("" : "+v"(a1base2[t]));  // keeps the two 8-byte reads apart (ds_read2_b64 is half rate)
-  }
-  int a2base[C2::RPW];
-#pragma unroll
-  for (int t = 0; t < C2::RPW; ++t) {
-    const int m = (rg2 + t * C2::RG) * 16 + li;
-    const int mm = (m < C2::M) ? m : 0;
-    const int oy = mm / C2::OW, ox = mm - oy * C2::OW;
-    a2base[t] = (oy * C2::STRIDE * C2::RQ + ox * C2::STRIDE * C2::Q + g) * 16;
-  }
-
-  // ---- staging of u8 half frames (unpredicated, clamped chunk index) ----
-  uint4 st[F::IT];
-  auto g_load = [&](int n, int h) {
-    const uint8_t* src = (!JOBS || n < n_in0 ? in + (size_t)n * C1::IN_ELEMS : in1 + (size_t)(n - n_in0) * C1::IN_ELEMS) +
-                         h * (40 * 84);
-#pragma unroll
-    for (int j = 0; j < F::IT; ++j) {
-      const int i = min(tid + j * kThreads, C1::V16 - 1);
-      const int pl = i / C1::PV16, r = i - pl * C1::PV16;
-      st[j] = *reinterpret_cast<const uint4*>(src + pl * C1::PLANE_ELEMS + r * 16);
-    }
-  };
-  auto cvt_store = [&]() {
-#pragma unroll
-    for (int j = 0; j < F::IT; ++j) {
-      const int i = min(tid + j * kThreads, C1::V16 - 1);
-      const int pl = i / C1::PV16, r = i - pl * C1::PV16;
-      uint4* dst = reinterpret_cast<uint4*>(t1 + pl * C1::PLANE_BYTES + r * 32);
-      dst[0] = u8x8_to_bf16x8(st[j].x, st[j].y);
-      dst[1] = u8x8_to_bf16x8(st[j].z, st[j].w);
-    }
-  };
-
-  // ---- conv1 on the half frame in T1 -> split records of pixels [200 h, 200 h + 200) in T2 ----
-  auto conv1_half = [&](int h) {
-    f32x4 acc[F::RPW1];
-#pragma unroll
-    for (int t = 0; t < F::RPW1; ++t) acc[t] = bv1;
-    constexpr int TOT = C1::KS * F::RPW1;
-    uint2 a0[F::D1], a1[F::D1];
-    auto a_issue = [&](int idx, int slot) {
-      const int ks = idx / F::RPW1, t = idx - ks * F::RPW1;
-      a0[slot] = *reinterpret_cast<const uint2*>(t1 + a1base[t] + ks * 168);
-      a1[slot] = *reinterpret_cast<const uint2*>(t1 + a1base2[t] + ks * 168);
-    };
-    uint4 wlo[2], whi[2];  // this wave's two weight pieces of k-step ks (double buffered)
-    auto w_issue = [&](int ks, int slot) {
-      whi[slot] = b1s[((0 * 2 + ct1) * C1::KS + ks) * 64 + lane];
-      wlo[slot] = b1s[((1 * 2 + ct1) * C1::KS + ks) * 64 + lane];
-    };
-    w_issue(0, 0);
-#pragma unroll
-    for (int i = 0; i < F::D1; ++i) a_issue(i, i);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ks = 0; ks < C1::KS; ++ks) {
-      if (ks + 1 < C1::KS) w_issue(ks + 1, (ks + 1) & 1);
-      const bf16x8 blo = __builtin_bit_cast(bf16x8, wlo[ks & 1]), bhi = __builtin_bit_cast(bf16x8, whi[ks & 1]);
-#pragma unroll
-      for (int t = 0; t < F::RPW1; t += 2) {
-        const int idx = ks * F::RPW1 + t;
-        const int s0 = idx % F::D1, s1 = (idx + 1) % F::D1;
-        const bf16x8 x0 = __builtin_bit_cast(bf16x8, make_uint4(a0[s0].x, a0[s0].y, a1[s0].x, a1[s0].y));
-        const bf16x8 x1 = __builtin_bit_cast(bf16x8, make_uint4(a0[s1].x, a0[s1].y, a1[s1].x, a1[s1].y));
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo, x0, acc[t], 0, 0, 0);
-        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo, x1, acc[t + 1], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi, x0, acc[t], 0, 0, 0);
-        acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi, x1, acc[t + 1], 0, 0, 0);
-        if (idx + F::D1 < TOT) a_issue(idx + F::D1, s0);
-        if (idx + 1 + F::D1 < TOT) a_issue(idx + 1 + F::D1, s1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    // ReLU + split into conv2's input tile: pixel P = 200 h + m at (y, x) = (P / 20, P % 20).  The record addresses
-    // are derived here from an opaque copy of h: hoisted out of the frame loop they would pin 32 registers.
-    int hh = h;
-    asm volatile("" : "+v"(hh));
-#pragma unroll
-    for (int t = 0; t < F::RPW1; ++t) {
-      const int rt = rg1 + t * F::RG1;
-      if (rt >= C1::RT) continue;  // (wave-uniform: a group's tiles past the 13th were only computed)
-      const int m = rt * 16 + li;  // this lane's pixel of the tile
-      const int P = hh * C1::HP + m;
-      const int y = P / 20, x = P - y * 20;
-      split_store_lds4((m < C1::HP) ? t2 + (size_t)(y * C2::RQ + x * C2::Q) * 16 : spare, 32, ch1, acc[t]);
-    }
-  };
-
-  int n = bid;
-  if (n >= N) return;
-  g_load(n, 0);
-  cvt_store();
-  g_load(n, 1);
-#pragma unroll
-  for (int ks = 0; ks < C2::KS; ++ks) {
-    pin_loaded(bh[ks]);
-    pin_loaded(bl[ks]);
-  }
-  __syncthreads();
-  constexpr int LO = C2::CIN * 2;
-  for (; n < N; n += nblk) {
-    const int nn = (n + nblk < N) ? n + nblk : n;  // (the last round re-reads its own frame)
-    stamp(0);
-    conv1_half(0);
-    stamp(1);
-    __syncthreads();  // T1 free
-    stamp(2);
-    cvt_store();      // half 1 of this frame
-    g_load(nn, 0);
-    stamp(3);
-    __syncthreads();  // T1 ready
-    stamp(4);
-    conv1_half(1);
-    stamp(5);
-    __syncthreads();  // T2 complete, T1 free
-    stamp(6);
-    if constexpr (JOBS) {
-      if (a1_out && (unsigned)(n - a1_lo) < (unsigned)n_a1) {  // (block-uniform) conv1's records: [400 pixels][32 hi | 32 lo]
-        uint4* dst = reinterpret_cast<uint4*>(a1_out + (size_t)n * (400 * 128));
-        for (int i = tid; i < 400 * 8; i += kThreads) {
-          const int px = i >> 3, u = i & 7;
-          const int y = px / 20, x = px - y * 20;
-          dst[i] = *reinterpret_cast<const uint4*>(t2 + (size_t)(y * C2::RQ + x * C2::Q + u) * 16);
-        }
-      }
-    }
-    // ---- conv2 from T2; the next frame's first half goes into T1 meanwhile ----
-    {
-      f32x4 acc[C2::RPW];
-#pragma unroll
-      for (int t = 0; t < C2::RPW; ++t) acc[t] = bv2;
-      constexpr int TOT = C2::KS * C2::RPW, D = 3;
-      uint4 ah[D], al[D];
-      auto a_issue = [&](int idx, int slot) {
-        const int ks = idx / C2::RPW, t = idx - ks * C2::RPW;
-        const int kh = ks / C2::KW, kw = ks - kh * C2::KW;  // KSUB = 1: one k-step per tap
-        const uint8_t* ap = t2 + a2base[t] + (kh * C2::RQ + kw * C2::Q) * 16;
-        ah[slot] = *reinterpret_cast<const uint4*>(ap);
-        al[slot] = *reinterpret_cast<const uint4*>(ap + LO);
-      };
-#pragma unroll
-      for (int i = 0; i < D; ++i) a_issue(i, i);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int idx = 0; idx < TOT; ++idx) {
-        const int ks = idx / C2::RPW, t = idx - ks * C2::RPW;
-        const int slot = idx % D;
-        const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[slot]);
-        const bf16x8 xl = __builtin_bit_cast(bf16x8, al[slot]);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xl, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[ks], xh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xh, acc[t], 0, 0, 0);
-        if (idx + D < TOT) a_issue(idx + D, slot);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      stamp(7);
-      cvt_store();  // half 0 of the next frame (its loads were issued two stages ago; the ring registers are free)
-      g_load(nn, 1);
-      stamp(8);
-#pragma unroll
-      for (int t = 0; t < C2::RPW; ++t) {
-        const int m = (rg2 + t * C2::RG) * 16 + li;
-        split_store_lds4((m < C2::M) ? otile + (size_t)m * C2::OROW : spare, C2::OC, ch2, acc[t]);
-      }
-    }
-    stamp(9);
-    __syncthreads();  // O complete, T1 ready, T2 free
-    stamp(10);
-    {
-      uint4* dst = reinterpret_cast<uint4*>(out + (size_t)n * C2::P * (C2::OC * 4));
-      constexpr int nv = C2::P * (C2::OC * 4 / 16);
-      for (int i = tid; i < nv; i += kThreads)
-        dst[i] = *reinterpret_cast<const uint4*>(otile + (i >> 4) * C2::OROW + (i & 15) * 16);
-    }
-    stamp(11);
-    stamp_frame += 1;
-  }
-}
-
-__global__ __launch_bounds__(kThreads) void conv12_bf16s(const uint8_t* __restrict__ in,
-                                                         const uint4* __restrict__ B1frag,
-                                                         const float* __restrict__ bias1,
-                                                         const uint4* __restrict__ B2frag,
-                                                         const float* __restrict__ bias2, uint8_t* __restrict__ out,
-                                                         int N) {
-  conv12_body<false>(in, nullptr, N, B1frag, bias1, B2frag, bias2, out, nullptr, 0, 0, N, blockIdx.x, gridDim.x);
 }
 
 // ---- conv1 on the INT8 matrix cores, whole frame at a time (r3) ----------------------------------------------------
@@ -1596,9 +1144,9 @@ __global__ __launch_bounds__(kThreads) void conv12_i8(const uint8_t* __restrict_
 struct TrunkJob {
   const uint8_t *in0, *in1;  // rows [0, n_in0) of in0, then rows of in1
   int n_in0;
-  const uint4 *B1, *B2, *B3;  // conv1 / conv2 / conv3 fragments of the job's net
-  const float *b1, *b2, *b3;
-  const uint4* W1d;  // conv1 for the int8 matrix cores (conv12_i8_jobs), or NULL
+  const uint4 *B2, *B3;  // conv2 / conv3 fragments of the job's net
+  const float *b2, *b3;
+  const uint4* W1d;  // conv1 for the int8 matrix cores (conv12_i8_jobs)
   const float *s1q, *b1q;
   uint8_t *a1_out;  // conv1's records [N][400][128 B], written for the rows [a1_lo, a1_lo + n_a1); or NULL
   int a1_lo, n_a1;
@@ -1610,13 +1158,6 @@ struct TrunkJobs {
   TrunkJob j[kMaxTrunkJobs];
   int n;
 };
-__global__ __launch_bounds__(kThreads) void conv12_bf16s_jobs(TrunkJobs jobs) {
-  int k = 0;
-  while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].block0) ++k;
-  const TrunkJob& t = jobs.j[k];
-  conv12_body<true>(t.in0, t.in1, t.n_in0, t.B1, t.b1, t.B2, t.b2, t.a2, t.a1_out, t.a1_lo, t.n_a1, t.N,
-                    (int)blockIdx.x - t.block0, t.nblocks);
-}
 __global__ __launch_bounds__(kThreads) void conv12_i8_stamps(const uint8_t* __restrict__ in, const uint4* __restrict__ W1d,
                                                              const float* __restrict__ scale1, const float* __restrict__ bias1q,
                                                              const uint4* __restrict__ B2frag, const float* __restrict__ bias2,
@@ -1630,632 +1171,11 @@ __global__ __launch_bounds__(kThreads) void conv12_i8_jobs(TrunkJobs jobs) {
   conv12i_body<true>(t.in0, t.in1, t.n_in0, t.W1d, t.s1q, t.b1q, t.B2, t.b2, t.a2, t.a1_out, t.a1_lo, t.n_a1, t.N,
                      (int)blockIdx.x - t.block0, t.nblocks);
 }
-__global__ __launch_bounds__(kThreads) void conv12_bf16s_stamps(const uint8_t* __restrict__ in, const uint4* __restrict__ B1frag,
-                                                                const float* __restrict__ bias1, const uint4* __restrict__ B2frag,
-                                                                const float* __restrict__ bias2, uint8_t* __restrict__ out, int N,
-                                                                unsigned long long* stamps) {
-  conv12_body<false, true>(in, nullptr, N, B1frag, bias1, B2frag, bias2, out, nullptr, 0, 0, N, blockIdx.x, gridDim.x, stamps);
-}
 __global__ __launch_bounds__(kThreads) void conv3_bf16s_jobs(TrunkJobs jobs) {
   int k = 0;
   while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].block0) ++k;
   const TrunkJob& t = jobs.j[k];
   conv_bf16s_body<Conv3F>(t.a2, t.B3, t.b3, t.a3, t.N, (int)blockIdx.x - t.block0, t.nblocks);
-}
-
-// conv1 -> conv2 as a TWO-STAGE PIPELINE inside one block (wave specialisation by layer).  The symmetric fused
-// kernel above runs its phases in lock-step on all eight waves, so the MFMA pipe idles during every epilogue,
-// conversion and copy-out (MFMA 41 % busy).  Here waves 0-3 only run conv1 (frame n + 1) and waves 4-7 only conv2
-// (frame n); a SIMD hosts one wave of each, so one layer's MFMAs fill the other's non-MFMA phases, and the two
-// layers carry about the same MFMA work (224 and 288 instructions per wave and frame).
-//   LDS = half-frame bf16 image T1 (30 KB) | conv2 input tiles T2[0], T2[1] (59 KB each) | spare record | flags.
-//   conv1 waves (2 channel tiles x 2 row groups, both weight pieces resident: 64 registers): wait until T2[b] is
-//     free -> half 0 -> T2[b][0..199] -> half 1 -> T2[b][200..399] -> full[b]++; T1 is refilled between the halves
-//     behind a barrier of the four conv1 waves.
-//   conv2 waves (one channel tile each, all six row tiles, 128 weight registers): wait full[b] -> MFMAs from T2[b]
-//     -> barrier of the four -> ReLU + split into the first 21 KB of T2[b] (its input is consumed) -> barrier ->
-//     whole rows to HBM -> free[b]++.
-// The hand-offs are monotone counters in LDS (ds_add / ds_read polls, one lane adds per wave); every spin is
-// bounded and a wave that gives up sets `*tmo` and leaves, so the launch always ends.
-// Measured (N = 6,400): 210 us against 218 us for the symmetric kernel, so it is opt-in (RELA_FUSE12=2), not the
-// default.  In-kernel stamps show why the gain is small: the hand-off locks the two stages IN phase (conv2 of frame
-// n starts when conv1 of frame n ends, which is when conv1 of frame n + 1 starts), so both layers' MFMA phases
-// coincide (the pipe is full for 8.3 k cycles per frame) and so do their other phases (7 k cycles: sub-barriers 2.3 k,
-// conversion 1.5 k, epilogue 3 k on the conv1 side); the conv1 stage alone needs 10.6 k cycles per frame.
-struct Conv12P {
-  using C1 = Conv1P;
-  using C2 = Conv2F;
-  static constexpr int RPW1 = 7, RG1 = 2, D1 = 4, D2 = 3;
-  static constexpr int T1_BYTES = C1::TILE_BYTES, T2_BYTES = C2::LDS_BYTES;
-  static constexpr int LDS_TOTAL = T1_BYTES + 2 * T2_BYTES + 256 + 64;
-  static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
-  static constexpr int PTHREADS = 256;
-  static constexpr int IT = (C1::V16 + PTHREADS - 1) / PTHREADS;  // 4
-  static constexpr unsigned SPIN_LIMIT = 1u << 22;
-};
-
-__device__ __forceinline__ unsigned lds_ld(const unsigned* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-// waits until *p >= target; false after SPIN_LIMIT polls or once another wave gave up
-__device__ __forceinline__ bool lds_wait_ge(const unsigned* p, unsigned target, const unsigned* dead, unsigned* tmo,
-                                            unsigned code) {
-  asm volatile("" ::: "memory");
-  for (unsigned spins = 0; (int)(lds_ld(p) - target) < 0; ++spins) {
-    __builtin_amdgcn_s_sleep(1);
-    if (spins > Conv12P::SPIN_LIMIT || lds_ld(dead) != 0) {
-      __hip_atomic_store(const_cast<unsigned*>(dead), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      if ((threadIdx.x & 63) == 0) atomicMax(tmo, code);
-      return false;
-    }
-  }
-  asm volatile("" ::: "memory");
-  return true;
-}
-// this wave's LDS operations are complete, then ONE lane bumps the counter
-__device__ __forceinline__ void lds_signal(unsigned* p) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-__global__ __launch_bounds__(kThreads) void conv12_pipe(const uint8_t* __restrict__ in,
-                                                        const uint4* __restrict__ B1frag,
-                                                        const float* __restrict__ bias1,
-                                                        const uint4* __restrict__ B2frag,
-                                                        const float* __restrict__ bias2, uint8_t* __restrict__ out,
-                                                        int N, unsigned* tmo) {
-  using F = Conv12P;
-  using C1 = Conv1P;
-  using C2 = Conv2F;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* t1 = smem;
-  uint8_t* t2base = smem + F::T1_BYTES;
-  uint8_t* spare = t2base + 2 * F::T2_BYTES;
-  unsigned* flags = reinterpret_cast<unsigned*>(spare + 256);  // full[2], free[2], pbar, cbar, dead
-  unsigned *full = flags, *freed = flags + 2, *pbar = flags + 4, *cbar = flags + 5, *dead = flags + 6;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, g = lane >> 4;
-  if (tid < 16) flags[tid] = 0;
-  __syncthreads();
-  if ((int)blockIdx.x >= N) return;
-  const int nframes = (N - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;  // frames of this block
-
-  if (wave < 4) {
-    // ======================= conv1 waves =======================
-    const int ptid = tid;  // 0 .. 255
-    const int ct1 = wave & 1, rg1 = wave >> 1;
-    bf16x8 b1[2][C1::KS];  // [piece: hi, mid][ks]
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int ks = 0; ks < C1::KS; ++ks)
-        b1[p][ks] = __builtin_bit_cast(bf16x8, B1frag[((p * 2 + ct1) * C1::KS + ks) * 64 + lane]);
-    const int col1 = ct1 * 16 + li;
-    const float bv1 = bias1[col1];
-    int a1base[F::RPW1], a1base2[F::RPW1];
-#pragma unroll
-    for (int t = 0; t < F::RPW1; ++t) {
-      const int rt = min(rg1 + t * F::RG1, C1::RT - 1);
-      const int m = min(rt * 16 + li, C1::HP - 1);
-      const int oy = m / 20, ox = m - oy * 20;
-      a1base[t] = g * C1::PLANE_BYTES + (4 * oy * 84 + 4 * ox) * 2;
-      a1base2[t] = a1base[t] + 8;
-      asm volatile("" : "+v"(a1base2[t]));  // keeps the two 8-byte reads apart (ds_read2_b64 is half rate)
-    }
-    uint4 st[F::IT];
-    auto g_load = [&](int n, int h) {
-      const uint8_t* src = in + (size_t)n * C1::IN_ELEMS + h * (40 * 84);
-#pragma unroll
-      for (int j = 0; j < F::IT; ++j) {
-        const int i = min(ptid + j * F::PTHREADS, C1::V16 - 1);
-        const int pl = i / C1::PV16, r = i - pl * C1::PV16;
-        st[j] = *reinterpret_cast<const uint4*>(src + pl * C1::PLANE_ELEMS + r * 16);
-      }
-    };
-    auto cvt_store = [&]() {
-#pragma unroll
-      for (int j = 0; j < F::IT; ++j) {
-        const int i = min(ptid + j * F::PTHREADS, C1::V16 - 1);
-        const int pl = i / C1::PV16, r = i - pl * C1::PV16;
-        uint4* dst = reinterpret_cast<uint4*>(t1 + pl * C1::PLANE_BYTES + r * 32);
-        dst[0] = u8x8_to_bf16x8(st[j].x, st[j].y);
-        dst[1] = u8x8_to_bf16x8(st[j].z, st[j].w);
-      }
-    };
-    unsigned pgen = 0;
-    auto p_barrier = [&]() -> bool {
-      pgen += 4;
-      lds_signal(pbar);
-      return lds_wait_ge(pbar, pgen, dead, tmo, 1);
-    };
-    auto conv1_half = [&](int h, uint8_t* t2) {
-      f32x4 acc[F::RPW1];
-#pragma unroll
-      for (int t = 0; t < F::RPW1; ++t) acc[t] = f32x4{bv1, bv1, bv1, bv1};
-      constexpr int TOT = C1::KS * F::RPW1;
-      uint2 a0[F::D1], a1[F::D1];
-      auto a_issue = [&](int idx, int slot) {
-        const int ks = idx / F::RPW1, t = idx - ks * F::RPW1;
-        a0[slot] = *reinterpret_cast<const uint2*>(t1 + a1base[t] + ks * 168);
-        a1[slot] = *reinterpret_cast<const uint2*>(t1 + a1base2[t] + ks * 168);
-      };
-      auto frag = [&](int slot) {
-        return __builtin_bit_cast(bf16x8, make_uint4(a0[slot].x, a0[slot].y, a1[slot].x, a1[slot].y));
-      };
-#pragma unroll
-      for (int i = 0; i < F::D1; ++i) a_issue(i, i);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < C1::KS; ++ks) {
-#pragma unroll
-        for (int t = 0; t + 1 < F::RPW1; t += 2) {
-          const int idx = ks * F::RPW1 + t;
-          const int s0 = idx % F::D1, s1 = (idx + 1) % F::D1;
-          const bf16x8 x0 = frag(s0), x1 = frag(s1);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, b1[1][ks], acc[t], 0, 0, 0);
-          acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, b1[1][ks], acc[t + 1], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, b1[0][ks], acc[t], 0, 0, 0);
-          acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, b1[0][ks], acc[t + 1], 0, 0, 0);
-          if (idx + F::D1 < TOT) a_issue(idx + F::D1, s0);
-          if (idx + 1 + F::D1 < TOT) a_issue(idx + 1 + F::D1, s1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        {
-          const int t = F::RPW1 - 1, idx = ks * F::RPW1 + t, s0 = idx % F::D1;
-          const bf16x8 x0 = frag(s0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, b1[1][ks], acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, b1[0][ks], acc[t], 0, 0, 0);
-          if (idx + F::D1 < TOT) a_issue(idx + F::D1, s0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      int hh = h;
-      asm volatile("" : "+v"(hh));  // (addresses derived inside the loop: hoisted they would pin registers)
-#pragma unroll
-      for (int t = 0; t < F::RPW1; ++t) {
-        const int rt = rg1 + t * F::RG1;
-        if (rt >= C1::RT) continue;  // wave-uniform
-        const int m0 = rt * 16 + g * 4;  // four consecutive pixels of one image row
-        const int P0 = hh * C1::HP + m0;
-        const int y = P0 / 20, x = P0 - y * 20;
-        uint8_t* rec = (m0 < C1::HP) ? t2 + (size_t)(y * C2::RQ + x * C2::Q) * 16 : spare;
-        const int step = (m0 < C1::HP) ? C2::Q * 16 : 0;
-#pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-          const float v0 = acc[t][r], v1 = acc[t][r + 1];
-          split_store_lds2(rec + r * step, rec + (r + 1) * step, 32, col1, v0 > 0.f ? v0 : 0.f, v1 > 0.f ? v1 : 0.f);
-        }
-      }
-    };
-
-    int n = blockIdx.x;
-    g_load(n, 0);
-    cvt_store();
-    g_load(n, 1);
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int ks = 0; ks < C1::KS; ++ks) pin_loaded(b1[p][ks]);
-    if (!p_barrier()) return;
-    for (int k = 0; k < nframes; ++k, n += gridDim.x) {
-      const int b = k & 1;
-      uint8_t* t2 = t2base + b * F::T2_BYTES;
-      const int nn = (k + 1 < nframes) ? n + (int)gridDim.x : n;  // (the last round re-reads its own frame)
-      if (!lds_wait_ge(freed + b, 4u * (unsigned)(k >> 1), dead, tmo, 2)) return;
-      conv1_half(0, t2);
-      if (!p_barrier()) return;  // T1 free
-      cvt_store();               // half 1 of this frame
-      g_load(nn, 0);
-      if (!p_barrier()) return;  // T1 ready
-      conv1_half(1, t2);
-      lds_signal(full + b);      // this wave's share of T2[b] is written
-      if (!p_barrier()) return;  // T1 free
-      cvt_store();               // half 0 of the next frame
-      g_load(nn, 1);
-      if (!p_barrier()) return;  // T1 ready
-    }
-  } else {
-    // ======================= conv2 waves =======================
-    const int ctid = tid - 256;
-    const int ct2 = wave - 4;
-    bf16x8 bh[C2::KS], bl[C2::KS];
-    {
-      const uint4* bp = B2frag + (size_t)ct2 * C2::KS * 2 * 64 + lane;
-#pragma unroll
-      for (int ks = 0; ks < C2::KS; ++ks) {
-        bh[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2) * 64]);
-        bl[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2 + 1) * 64]);
-      }
-    }
-    const int col2 = ct2 * 16 + li;
-    const float bv2 = bias2[col2];
-    constexpr int RT2 = C2::RT;  // 6 row tiles, all on this wave
-    int a2base[RT2];
-#pragma unroll
-    for (int t = 0; t < RT2; ++t) {
-      const int m = t * 16 + li;
-      const int mm = (m < C2::M) ? m : 0;
-      const int oy = mm / C2::OW, ox = mm - oy * C2::OW;
-      a2base[t] = (oy * C2::STRIDE * C2::RQ + ox * C2::STRIDE * C2::Q + g) * 16;
-    }
-#pragma unroll
-    for (int ks = 0; ks < C2::KS; ++ks) {
-      pin_loaded(bh[ks]);
-      pin_loaded(bl[ks]);
-    }
-    unsigned cgen = 0;
-    auto c_barrier = [&]() -> bool {
-      cgen += 4;
-      lds_signal(cbar);
-      return lds_wait_ge(cbar, cgen, dead, tmo, 3);
-    };
-    constexpr int LO = C2::CIN * 2;
-    int n = blockIdx.x;
-    for (int k = 0; k < nframes; ++k, n += gridDim.x) {
-      const int b = k & 1;
-      uint8_t* t2 = t2base + b * F::T2_BYTES;
-      if (!lds_wait_ge(full + b, 4u * (unsigned)((k >> 1) + 1), dead, tmo, 4)) return;
-      f32x4 acc[RT2];
-#pragma unroll
-      for (int t = 0; t < RT2; ++t) acc[t] = f32x4{bv2, bv2, bv2, bv2};
-      constexpr int TOT = C2::KS * RT2, D = F::D2;
-      uint4 ah[D], al[D];
-      auto a_issue = [&](int idx, int slot) {
-        const int ks = idx / RT2, t = idx - ks * RT2;
-        const int kh = ks / C2::KW, kw = ks - kh * C2::KW;  // one k-step per tap
-        const uint8_t* ap = t2 + a2base[t] + (kh * C2::RQ + kw * C2::Q) * 16;
-        ah[slot] = *reinterpret_cast<const uint4*>(ap);
-        al[slot] = *reinterpret_cast<const uint4*>(ap + LO);
-      };
-#pragma unroll
-      for (int i = 0; i < D; ++i) a_issue(i, i);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int idx = 0; idx < TOT; ++idx) {
-        const int ks = idx / RT2, t = idx - ks * RT2;
-        const int slot = idx % D;
-        const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[slot]);
-        const bf16x8 xl = __builtin_bit_cast(bf16x8, al[slot]);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, bh[ks], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bl[ks], acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, bh[ks], acc[t], 0, 0, 0);
-        if (idx + D < TOT) a_issue(idx + D, slot);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (!c_barrier()) return;  // every conv2 wave has read its last fragment of T2[b]
-      uint8_t* otile = t2;       // the output records take the place of the consumed input
-#pragma unroll
-      for (int t = 0; t < RT2; ++t) {
-#pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-          const int m = t * 16 + g * 4 + r;
-          const float v0 = acc[t][r], v1 = acc[t][r + 1];
-          uint8_t* rec0 = (m < C2::M) ? otile + (size_t)m * (C2::OC * 4) : spare;
-          uint8_t* rec1 = (m + 1 < C2::M) ? otile + (size_t)(m + 1) * (C2::OC * 4) : spare;
-          split_store_lds2(rec0, rec1, C2::OC, col2, v0 > 0.f ? v0 : 0.f, v1 > 0.f ? v1 : 0.f);
-        }
-      }
-      if (!c_barrier()) return;  // records complete
-      {
-        const uint4* src = reinterpret_cast<const uint4*>(otile);
-        uint4* dst = reinterpret_cast<uint4*>(out + (size_t)n * C2::P * (C2::OC * 4));
-        constexpr int nv = C2::P * (C2::OC * 4 / 16);
-        for (int i = ctid; i < nv; i += 256) dst[i] = src[i];
-      }
-      lds_signal(freed + b);  // (waits for this wave's LDS reads first)
-    }
-  }
-}
-
-// conv1 -> conv2 with the waves specialised by KIND OF WORK: waves 0-3 ("MFMA waves", one per SIMD) only read
-// fragments and issue MFMAs -- conv1 on both half frames, then conv2 -- and hand their raw f32 accumulator tiles over
-// through LDS; waves 4-7 ("service waves", the second wave of every SIMD) do everything else: u8 -> bf16 conversion
-// into T1, bias-less ReLU + hi/lo split of the dumped tiles into T2 (conv1) or straight to HBM (conv2).  In the
-// symmetric kernel both waves of a SIMD run the same phase at the same time, so the ~2,900 VALU instructions per
-// frame of the non-MFMA phases (4 cycles of issue each, twice per SIMD) are paid on top of the MFMA time; here the
-// service wave's VALU issue overlaps the MFMA wave's asynchronous matrix work (an MFMA holds the issue port for 8
-// of its 16 cycles).
-//   LDS = T1 half-frame image (30 KB) | T2 conv2 input (59 KB) | accumulator dump, 26 tiles x 1 KB | conv1 weight
-//         fragments (32 KB) | spare record | counters.
-//   MFMA wave w: conv1 channel tile w & 1, row tiles (w >> 1) + 2t of each half; conv2 channel tile w, all six row
-//   tiles (128 weight registers).  Hand-offs are monotone LDS counters (bounded spins, `*tmo` on give-up).
-// Measured (N = 6,400): 251 us against 218 us for the symmetric kernel: opt-in (RELA_FUSE12=3).  In-kernel stamps of an
-// MFMA wave, per frame: conv1 5.1 k cycles (23 per MFMA: its weight fragments come from LDS too), conv2 5.05 k (17.5
-// per MFMA, the instruction's rate), and 7.7 k cycles WAITING -- for T2 (the service waves' split of the second half:
-// 2.4 k), for the dump to be consumed (1.8 k), for T1 refills (1.7 k), dumps and polls (1.8 k).  With ONE T1, ONE T2
-// and ONE dump region (LDS holds no second copy of any of them) the two kinds of waves depend on each other phase by
-// phase, and the chain of hand-offs costs more than the VALU work it takes off the MFMA waves.
-struct Conv12S {
-  using C1 = Conv1P;
-  using C2 = Conv2F;
-  static constexpr int RPW1 = 7, RG1 = 2, D1 = 4, D2 = 3;
-  static constexpr int T1_BYTES = C1::TILE_BYTES, T2_BYTES = C2::LDS_BYTES;
-  static constexpr int UNITS1 = C1::RT * 2, UNITS2 = C2::RT * C2::CT;  // 26, 24 accumulator tiles per phase
-  static constexpr int DUMP_BYTES = UNITS1 * 1024;
-  static constexpr int B1_UINT4 = 2 * 2 * C1::KS * 64;
-  static constexpr int LDS_TOTAL = T1_BYTES + T2_BYTES + DUMP_BYTES + B1_UINT4 * 16 + 256 + 64;
-  static_assert(LDS_TOTAL <= 160 * 1024 && UNITS2 <= UNITS1, "LDS budget");
-  static constexpr int STHREADS = 256;
-  static constexpr int IT = (C1::V16 + STHREADS - 1) / STHREADS;  // 4
-};
-
-__global__ __launch_bounds__(kThreads) void conv12_ms(const uint8_t* __restrict__ in, const uint4* __restrict__ B1frag,
-                                                      const float* __restrict__ bias1,
-                                                      const uint4* __restrict__ B2frag,
-                                                      const float* __restrict__ bias2, uint8_t* __restrict__ out,
-                                                      int N, unsigned* tmo) {
-  using F = Conv12S;
-  using C1 = Conv1P;
-  using C2 = Conv2F;
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* t1 = smem;
-  uint8_t* t2 = smem + F::T1_BYTES;
-  uint4* dump = reinterpret_cast<uint4*>(t2 + F::T2_BYTES);  // [unit][lane] f32x4
-  uint4* b1s = dump + F::UNITS1 * 64;
-  uint8_t* spare = reinterpret_cast<uint8_t*>(b1s + F::B1_UINT4);
-  unsigned* flags = reinterpret_cast<unsigned*>(spare + 256);
-  unsigned *t1_ready = flags, *t1_free = flags + 1, *dfull = flags + 2, *dfree = flags + 3, *t2_ready = flags + 4,
-           *t2_free = flags + 5, *dead = flags + 6;
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, g = lane >> 4;
-  if (tid < 16) flags[tid] = 0;
-  for (int i = tid; i < F::B1_UINT4; i += kThreads) b1s[i] = B1frag[i];
-  __syncthreads();
-  if ((int)blockIdx.x >= N) return;
-  const int nframes = (N - 1 - (int)blockIdx.x) / (int)gridDim.x + 1;
-
-  if (wave < 4) {
-    // ============================ MFMA waves ============================
-    const int ct1 = wave & 1, rg1 = wave >> 1, ct2 = wave;
-    bf16x8 bh[C2::KS], bl[C2::KS];
-    {
-      const uint4* bp = B2frag + (size_t)ct2 * C2::KS * 2 * 64 + lane;
-#pragma unroll
-      for (int ks = 0; ks < C2::KS; ++ks) {
-        bh[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2) * 64]);
-        bl[ks] = __builtin_bit_cast(bf16x8, bp[(size_t)(ks * 2 + 1) * 64]);
-      }
-    }
-    int a1base[F::RPW1], a1base2[F::RPW1];
-#pragma unroll
-    for (int t = 0; t < F::RPW1; ++t) {
-      const int rt = min(rg1 + t * F::RG1, C1::RT - 1);
-      const int m = min(rt * 16 + li, C1::HP - 1);
-      const int oy = m / 20, ox = m - oy * 20;
-      a1base[t] = g * C1::PLANE_BYTES + (4 * oy * 84 + 4 * ox) * 2;
-      a1base2[t] = a1base[t] + 8;
-      asm volatile("" : "+v"(a1base2[t]));  // keeps the two 8-byte reads apart (ds_read2_b64 is half rate)
-    }
-    constexpr int RT2 = C2::RT;
-    int a2base[RT2];
-#pragma unroll
-    for (int t = 0; t < RT2; ++t) {
-      const int m = t * 16 + li;
-      const int mm = (m < C2::M) ? m : 0;
-      const int oy = mm / C2::OW, ox = mm - oy * C2::OW;
-      a2base[t] = (oy * C2::STRIDE * C2::RQ + ox * C2::STRIDE * C2::Q + g) * 16;
-    }
-#pragma unroll
-    for (int ks = 0; ks < C2::KS; ++ks) {
-      pin_loaded(bh[ks]);
-      pin_loaded(bl[ks]);
-    }
-    auto conv1_half = [&](f32x4 (&acc)[F::RPW1]) {
-#pragma unroll
-      for (int t = 0; t < F::RPW1; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      constexpr int TOT = C1::KS * F::RPW1;
-      uint2 a0[F::D1], a1[F::D1];
-      auto a_issue = [&](int idx, int slot) {
-        const int ks = idx / F::RPW1, t = idx - ks * F::RPW1;
-        a0[slot] = *reinterpret_cast<const uint2*>(t1 + a1base[t] + ks * 168);
-        a1[slot] = *reinterpret_cast<const uint2*>(t1 + a1base2[t] + ks * 168);
-      };
-      auto frag = [&](int slot) {
-        return __builtin_bit_cast(bf16x8, make_uint4(a0[slot].x, a0[slot].y, a1[slot].x, a1[slot].y));
-      };
-      uint4 wlo[2], whi[2];
-      auto w_issue = [&](int ks, int slot) {
-        whi[slot] = b1s[((0 * 2 + ct1) * C1::KS + ks) * 64 + lane];
-        wlo[slot] = b1s[((1 * 2 + ct1) * C1::KS + ks) * 64 + lane];
-      };
-      w_issue(0, 0);
-#pragma unroll
-      for (int i = 0; i < F::D1; ++i) a_issue(i, i);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ks = 0; ks < C1::KS; ++ks) {
-        if (ks + 1 < C1::KS) w_issue(ks + 1, (ks + 1) & 1);
-        const bf16x8 blo = __builtin_bit_cast(bf16x8, wlo[ks & 1]), bhi = __builtin_bit_cast(bf16x8, whi[ks & 1]);
-#pragma unroll
-        for (int t = 0; t + 1 < F::RPW1; t += 2) {
-          const int idx = ks * F::RPW1 + t;
-          const int s0 = idx % F::D1, s1 = (idx + 1) % F::D1;
-          const bf16x8 x0 = frag(s0), x1 = frag(s1);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo, x0, acc[t], 0, 0, 0);
-          acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo, x1, acc[t + 1], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi, x0, acc[t], 0, 0, 0);
-          acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi, x1, acc[t + 1], 0, 0, 0);
-          if (idx + F::D1 < TOT) a_issue(idx + F::D1, s0);
-          if (idx + 1 + F::D1 < TOT) a_issue(idx + 1 + F::D1, s1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        {
-          const int t = F::RPW1 - 1, idx = ks * F::RPW1 + t, s0 = idx % F::D1;
-          const bf16x8 x0 = frag(s0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo, x0, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi, x0, acc[t], 0, 0, 0);
-          if (idx + F::D1 < TOT) a_issue(idx + F::D1, s0);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    };
-    constexpr int LO = C2::CIN * 2;
-    for (int k = 0; k < nframes; ++k) {
-      const unsigned uk = (unsigned)k;
-#pragma unroll 1
-      for (int h = 0; h < 2; ++h) {
-        if (!lds_wait_ge(t1_ready, 4u * (2u * uk + 1u + h), dead, tmo, 11)) return;
-        f32x4 acc[F::RPW1];
-        conv1_half(acc);
-        lds_signal(t1_free);
-        if (!lds_wait_ge(dfree, 4u * (3u * uk + h), dead, tmo, 12)) return;
-#pragma unroll
-        for (int t = 0; t < F::RPW1; ++t) {
-          const int rt = rg1 + t * F::RG1;
-          if (rt < C1::RT) dump[(rt * 2 + ct1) * 64 + lane] = __builtin_bit_cast(uint4, acc[t]);
-        }
-        lds_signal(dfull);
-      }
-      if (!lds_wait_ge(t2_ready, 4u * (uk + 1u), dead, tmo, 13)) return;
-      {
-        f32x4 acc[RT2];
-#pragma unroll
-        for (int t = 0; t < RT2; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        constexpr int TOT = C2::KS * RT2, D = F::D2;
-        uint4 ah[D], al[D];
-        auto a_issue = [&](int idx, int slot) {
-          const int ks = idx / RT2, t = idx - ks * RT2;
-          const int kh = ks / C2::KW, kw = ks - kh * C2::KW;
-          const uint8_t* ap = t2 + a2base[t] + (kh * C2::RQ + kw * C2::Q) * 16;
-          ah[slot] = *reinterpret_cast<const uint4*>(ap);
-          al[slot] = *reinterpret_cast<const uint4*>(ap + LO);
-        };
-#pragma unroll
-        for (int i = 0; i < D; ++i) a_issue(i, i);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int idx = 0; idx < TOT; ++idx) {
-          const int ks = idx / RT2, t = idx - ks * RT2;
-          const int slot = idx % D;
-          const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[slot]);
-          const bf16x8 xl = __builtin_bit_cast(bf16x8, al[slot]);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xl, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[ks], xh, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[ks], xh, acc[t], 0, 0, 0);
-          if (idx + D < TOT) a_issue(idx + D, slot);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        lds_signal(t2_free);
-        if (!lds_wait_ge(dfree, 4u * (3u * uk + 2u), dead, tmo, 14)) return;
-#pragma unroll
-        for (int t = 0; t < RT2; ++t) dump[(t * C2::CT + ct2) * 64 + lane] = __builtin_bit_cast(uint4, acc[t]);
-        lds_signal(dfull);
-      }
-    }
-  } else {
-    // ============================ service waves ============================
-    const int stid = tid - 256, sw = wave - 4;
-    uint4 st[F::IT];
-    auto g_load = [&](int n, int h) {
-      const uint8_t* src = in + (size_t)n * C1::IN_ELEMS + h * (40 * 84);
-#pragma unroll
-      for (int j = 0; j < F::IT; ++j) {
-        const int i = min(stid + j * F::STHREADS, C1::V16 - 1);
-        const int pl = i / C1::PV16, r = i - pl * C1::PV16;
-        st[j] = *reinterpret_cast<const uint4*>(src + pl * C1::PLANE_ELEMS + r * 16);
-      }
-    };
-    uint4 cv[F::IT][2];  // the converted chunks wait in registers for T1 to be free
-    auto convert = [&]() {
-#pragma unroll
-      for (int j = 0; j < F::IT; ++j) {
-        cv[j][0] = u8x8_to_bf16x8(st[j].x, st[j].y);
-        cv[j][1] = u8x8_to_bf16x8(st[j].z, st[j].w);
-      }
-    };
-    auto store_t1 = [&]() {
-#pragma unroll
-      for (int j = 0; j < F::IT; ++j) {
-        const int i = min(stid + j * F::STHREADS, C1::V16 - 1);
-        const int pl = i / C1::PV16, r = i - pl * C1::PV16;
-        uint4* dst = reinterpret_cast<uint4*>(t1 + pl * C1::PLANE_BYTES + r * 32);
-        dst[0] = cv[j][0];
-        dst[1] = cv[j][1];
-      }
-    };
-    // biases of this lane's four channels 4g .. 4g+3 in every channel tile (kept in registers: a global load per
-    // dumped tile put its latency into every hand-off)
-    f32x4 bias1v[2], bias2v[C2::CT];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) bias1v[c] = *reinterpret_cast<const f32x4*>(bias1 + c * 16 + 4 * g);
-#pragma unroll
-    for (int c = 0; c < C2::CT; ++c) bias2v[c] = *reinterpret_cast<const f32x4*>(bias2 + c * 16 + 4 * g);
-    constexpr int UPW1 = (F::UNITS1 + 3) / 4, UPW2 = F::UNITS2 / 4;  // dumped tiles per service wave and phase: 7, 6
-    int n = blockIdx.x;
-    g_load(n, 0);
-    convert();
-    store_t1();
-    lds_signal(t1_ready);
-    g_load(n, 1);
-    for (int k = 0; k < nframes; ++k, n += gridDim.x) {
-      const unsigned uk = (unsigned)k;
-      const bool more = k + 1 < nframes;
-      const int nn = more ? n + (int)gridDim.x : n;
-#pragma unroll 1
-      for (int h = 0; h < 2; ++h) {
-        // T1 <- the other half (h = 0: half 1 of this frame; h = 1: half 0 of the next frame)
-        convert();
-        if (h == 0 || more) g_load(nn, h == 0 ? 0 : 1);  // (re-reads its own frame at the very end: harmless)
-        if (!lds_wait_ge(t1_free, 4u * (2u * uk + 1u + h), dead, tmo, 21)) return;
-        if (h == 0 || more) {
-          store_t1();
-          lds_signal(t1_ready);
-        }
-        // conv1's dumped tiles of half h -> split records in T2
-        if (!lds_wait_ge(dfull, 4u * (3u * uk + 1u + h), dead, tmo, 22)) return;
-        if (h == 0 && !lds_wait_ge(t2_free, 4u * uk, dead, tmo, 23)) return;
-        {
-          f32x4 tv[UPW1];  // all of this wave's tiles are read before the first is used
-#pragma unroll
-          for (int i = 0; i < UPW1; ++i) tv[i] = __builtin_bit_cast(f32x4, dump[min(sw + 4 * i, F::UNITS1 - 1) * 64 + lane]);
-#pragma unroll
-          for (int i = 0; i < UPW1; ++i) {
-            const int u = sw + 4 * i;
-            if (u >= F::UNITS1) break;  // wave-uniform
-            const int rt = u >> 1, ct = u & 1;  // (sw + 4 i) & 1 == sw & 1: the channel tile is fixed per wave
-            const int m = rt * 16 + li;
-            const int P = h * C1::HP + m;
-            const int y = P / 20, x = P - y * 20;
-            split_store_lds4((m < C1::HP) ? t2 + (size_t)(y * C2::RQ + x * C2::Q) * 16 : spare, 32, ct * 16 + 4 * g,
-                             tv[i] + bias1v[sw & 1]);
-          }
-        }
-        lds_signal(dfree);
-        if (h == 1) lds_signal(t2_ready);
-      }
-      // conv2's dumped tiles -> ReLU + split -> HBM (8 bytes of hi and 8 of lo per lane)
-      if (!lds_wait_ge(dfull, 4u * (3u * uk + 3u), dead, tmo, 24)) return;
-      uint8_t* orow = out + (size_t)n * C2::P * (C2::OC * 4);
-      f32x4 tv2[UPW2];
-#pragma unroll
-      for (int i = 0; i < UPW2; ++i) tv2[i] = __builtin_bit_cast(f32x4, dump[(sw + 4 * i) * 64 + lane]);
-#pragma unroll
-      for (int i = 0; i < UPW2; ++i) {
-        const int u = sw + 4 * i;
-        const int rt = u / C2::CT, ct = sw;  // u % 4 == sw
-        const int m = rt * 16 + li;
-        f32x4 bsel = bias2v[0];
-#pragma unroll
-        for (int c = 1; c < C2::CT; ++c) bsel = (sw == c) ? bias2v[c] : bsel;
-        const f32x4 v = tv2[i] + bsel;
-        typedef float f32x2_ __attribute__((ext_vector_type(2)));
-        typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
-        const f32x2_ a = {v[0] > 0.f ? v[0] : 0.f, v[1] > 0.f ? v[1] : 0.f}, b = {v[2] > 0.f ? v[2] : 0.f, v[3] > 0.f ? v[3] : 0.f};
-        const bf16x2_ ha = __builtin_convertvector(a, bf16x2_), hb = __builtin_convertvector(b, bf16x2_);
-        const bf16x2_ la = __builtin_convertvector(a - __builtin_convertvector(ha, f32x2_), bf16x2_);
-        const bf16x2_ lb = __builtin_convertvector(b - __builtin_convertvector(hb, f32x2_), bf16x2_);
-        if (m < C2::M) {
-          uint8_t* rec = orow + (size_t)m * (C2::OC * 4) + (ct * 16 + 4 * g) * 2;
-          *reinterpret_cast<uint2*>(rec) = make_uint2(__builtin_bit_cast(uint32_t, ha), __builtin_bit_cast(uint32_t, hb));
-          *reinterpret_cast<uint2*>(rec + C2::OC * 2) =
-              make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
-        }
-      }
-      lds_signal(dfree);
-    }
-  }
 }
 
 // fc on split records: out[N][512] = relu(A x W + b), A = a3 records [N][49][hi 64 | lo 64], k = pos*64 + c.
@@ -2279,17 +1199,8 @@ using FcFast = FcFastT<112>;
 // SPLIT (batches of a few hundred rows, where 4 x ceil(N / BM) blocks would leave most CUs idle): blockIdx.z owns the
 // positions [z * per, z * per + per) of the contraction and writes its raw partial sums to out[z][N][512]; fc_reduce adds
 // them up in z order with the bias and the ReLU.  Without SPLIT the range is the compile-time [0, 49).
-// conv1 of the split-bf16 mode on the int8 matrix cores (conv12_i8); RELA_CONV12=bf16 keeps the half-frame bf16 kernel
-inline bool conv12_i8_on() {
-  static const bool on = !(getenv("RELA_CONV12") && strcmp(getenv("RELA_CONV12"), "bf16") == 0);
-  return on;
-}
-// grid of fc_bf16s for `units` (row block, slice) pairs: XCD-aware 1-D form, or (RELA_FC_XCD_MAP=0) the plain (4, rb, slices)
-inline dim3 fc_grid_xcd(int rb, int slices) {
-  static const bool xmap = !(getenv("RELA_FC_XCD_MAP") && atoi(getenv("RELA_FC_XCD_MAP")) == 0);
-  if (!xmap) return dim3(4, rb, slices);
-  return dim3(32 * ceil_div(rb * slices, 8));
-}
+// grid of fc_bf16s for `units` (row block, slice) pairs: the XCD-aware 1-D form (see the block map in the kernel)
+inline dim3 fc_grid_xcd(int rb, int slices) { return dim3(32 * ceil_div(rb * slices, 8)); }
 // Loads stay ordinary (compiler-tracked) loads.  Tried in r3 and dropped: issuing them through inline asm with
 // hand-placed `s_waitcnt vmcnt(N)` (hipcc drains the loads in flight across the loop's back-edge every other position,
 // vmcnt(4), i.e. a prefetch distance of one position where the source asks for two).  With the copy-behind-the-wait
@@ -2975,7 +1886,7 @@ __global__ __launch_bounds__(256) void pack_conv1_i8(const float* __restrict__ w
 // table of first-block indices; the job bodies are the *_at functions of the separate kernels.
 struct PackAllArgs {
   const float* p[12];  // rela_ffnet_params order
-  uint16_t *B1, *B1p, *B2f, *B3f, *Bff;
+  uint16_t *B1, *B2f, *B3f, *Bff;
   float *B2, *B3, *Bf, *BfT, *Bh, *Bhp, *b1, *b2, *b3, *bf, *bh;
   int A;
   float *w2p, *w3p, *wfcp;  // the learner's dgrad operand copies (ffnet_layout.h), or NULL
@@ -2990,7 +1901,7 @@ __global__ void pack_ffnet_all(PackAllArgs a) {
   const int64_t idx = (int64_t)(b - a.first[j]) * 256 + threadIdx.x;
   switch (j) {
     case 0: pack_conv1_bf16x3_at((int)idx, a.p[0], a.B1, 0); break;
-    case 1: pack_conv1_bf16x3_at((int)idx, a.p[0], a.B1p, 1); break;
+    case 1: break;  // (was: plane-major conv1 fragments of the half-frame bf16 kernels, removed in r4; zero blocks)
     case 2: pack_frags_at(idx, kPackConv2, a.p[2], nullptr, a.A, a.B2, 4, 128); break;
     case 3: pack_frags_at(idx, kPackConv3, a.p[4], nullptr, a.A, a.B3, 4, 144); break;
     case 4: pack_frags_at(idx, kPackFc, a.p[6], nullptr, a.A, a.Bf, 32, 784); break;
@@ -3039,7 +1950,6 @@ struct rela_ffnet {
   uint64_t version = 0;  // bumped by every load
   const char* const* prof_names = nullptr;  // per-kernel timing labels (actor-side by default)
   int precision = 0;  // 0 = exact f32 MFMA (parity mode), 1 = split-bf16 MFMA for conv2 / conv3 / fc
-  unsigned* pipe_tmo = nullptr;  // sticky: a wave of conv12_pipe gave up waiting (never observed)
   int max_rows = 0;  // > 0: the owner never runs more rows (a learner's batch): layouts only larger batches read are not packed
   // BfT (the f32 split-K fc's weights) of such a net in the split-bf16 mode: no kernel of that mode reads it from 128
   // rows up, so the per-step re-pack skips it (6.4 MB) and the f32 path packs it on demand from the owner's buffer
@@ -3072,7 +1982,6 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
   RELA_HIP(hipMalloc(&d.bf, sizeof(float) * 512));
   RELA_HIP(hipMalloc(&d.Bh, sizeof(float) * 2 * 128 * 64));
   RELA_HIP(hipMalloc(&d.bh, sizeof(float) * 32));
-  RELA_HIP(hipMalloc(&d.B1p, sizeof(uint4) * Conv1B::FRAG_UINT4));
   RELA_HIP(hipMalloc(&d.W1d, sizeof(uint4) * Conv12I::W1_UINT4));
   RELA_HIP(hipMalloc(&d.s1q, sizeof(float) * 32));
   RELA_HIP(hipMalloc(&d.b1q, sizeof(float) * 32));
@@ -3084,21 +1993,9 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
   RELA_HIP(hipMalloc(&d.B2f, sizeof(uint4) * Conv2F::CT * Conv2F::KS * 2 * 64));
   RELA_HIP(hipMalloc(&d.B3f, sizeof(uint4) * Conv3F::CT * Conv3F::KS * 2 * 64));
   RELA_HIP(hipMalloc(&d.Bff, sizeof(uint4) * 32 * FcFast::KS * 2 * 64));
-  RELA_HIP(hipMalloc(&n->pipe_tmo, 16));
-  RELA_HIP(hipMemset(n->pipe_tmo, 0, 16));
   // opt in to > 64 KB of dynamic LDS once per process/device
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv1B::LDS_BYTES));
-  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_persist<true, 2>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv1P::LDS_BYTES));
-  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv2F>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv2F::LDS_TOTAL));
-  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_bf16s),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv12::LDS_TOTAL));
-  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_pipe),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv12P::LDS_TOTAL));
-  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_ms),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv12S::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv3F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv3F::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&fc_bf16s<FcFast, true>),
@@ -3122,32 +2019,19 @@ extern "C" void rela_ffnet_destroy(rela_ffnet* n) {
   DeviceGuard g(n->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bf, n->d.bf, n->d.Bh, n->d.bh,
-                n->d.BfT, n->d.B2f, n->d.B3f, n->d.Bff, n->d.B1p, n->d.Bhp, n->d.W1d, n->d.s1q, n->d.b1q};
+                n->d.BfT, n->d.B2f, n->d.B3f, n->d.Bff, n->d.Bhp, n->d.W1d, n->d.s1q, n->d.b1q};
   for (void* p : ps) (void)hipFree(p);
-  (void)hipFree(n->pipe_tmo);
   delete n;
 }
 
-extern "C" int rela_ffnet_debug_pipe_timeout(rela_ffnet* n, unsigned* out) {
-  RELA_CHECK(n && out, RELA_EINVAL, "rela_ffnet_debug_pipe_timeout: null argument");
-  DeviceGuard g(n->device);
-  RELA_HIP(hipDeviceSynchronize());
-  RELA_HIP(hipMemcpy(out, n->pipe_tmo, sizeof(unsigned), hipMemcpyDeviceToHost));
-  return RELA_OK;
-}
-
-// Diagnostic: the fused conv1 -> conv2 kernel with shader-clock stamps at its phase boundaries (block 0, waves 0 and 7,
-// first 8 frames): out_host receives [2][8][12] u64.  Points: 0 frame start | 1 conv1 half 0 done | 2 barrier | 3 convert
-// half 1 + loads issued | 4 barrier | 5 conv1 half 1 done | 6 barrier | 7 conv2 MFMAs done | 8 convert next half 0 + loads |
-// 9 conv2 epilogue stored | 10 barrier | 11 copy-out issued.
+// Diagnostic: the fused conv1 -> conv2 kernel (conv12_i8) with shader-clock stamps at its phase boundaries (block 0,
+// waves 0 and 7, first 8 frames): out_host receives [2][8][12] u64.  Points: 0 frame start | 1 conv1 done | 2 barrier |
+// 3 conv2 MFMAs done | 4 epilogue | 5 barrier.
 extern "C" int rela_ffnet_debug_conv12_stamps(const rela_ffnet* n, int N, const uint8_t* s_dev, unsigned long long* out_host,
                                               void* stream_) {
   RELA_CHECK(n && n->loaded && N >= 1 && s_dev && out_host, RELA_EINVAL, "rela_ffnet_debug_conv12_stamps: bad arguments");
   DeviceGuard g(n->device);
   hipStream_t s = (hipStream_t)stream_;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_bf16s_stamps),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, Conv12::LDS_TOTAL);
-  RELA_HIP(attr);
   uint8_t* a2 = nullptr;
   unsigned long long* st = nullptr;
   const size_t nst = (size_t)2 * kStampFrames * kStampPoints;
@@ -3155,15 +2039,11 @@ extern "C" int rela_ffnet_debug_conv12_stamps(const rela_ffnet* n, int N, const 
   RELA_HIP(hipMalloc(&st, nst * 8));
   RELA_HIP(hipMemsetAsync(st, 0, nst * 8, s));
   const FFNetDev& d = n->d;
-  if (d.W1d && conv12_i8_on()) {  // points: 0 frame start | 1 conv1 done | 2 barrier | 3 conv2 MFMAs done | 4 epilogue | 5 barrier
-    static const hipError_t attr8 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_i8_stamps),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, Conv12I::LDS_TOTAL);
-    RELA_HIP(attr8);
-    hipLaunchKernelGGL(conv12_i8_stamps, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
-                       (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, a2, N, st);
-  } else
-  hipLaunchKernelGGL(conv12_bf16s_stamps, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
-                     (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, a2, N, st);
+  static const hipError_t attr8 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_i8_stamps),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, Conv12I::LDS_TOTAL);
+  RELA_HIP(attr8);
+  hipLaunchKernelGGL(conv12_i8_stamps, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
+                     (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, a2, N, st);
   RELA_HIP(hipStreamSynchronize(s));
   RELA_HIP(hipMemcpy(out_host, st, nst * 8, hipMemcpyDeviceToHost));
   (void)hipFree(a2);
@@ -3239,32 +2119,17 @@ extern "C" int rela_ffnet_debug_conv12_records(const rela_ffnet* n, int N, const
   jobs.n = 1;
   TrunkJob& j0 = jobs.j[0];
   j0.in0 = s_dev, j0.in1 = s_dev, j0.n_in0 = N;
-  j0.B1 = (const uint4*)d.B1p, j0.B2 = (const uint4*)d.B2f, j0.B3 = (const uint4*)d.B3f;
-  j0.b1 = d.b1, j0.b2 = d.b2, j0.b3 = d.b3;
+  j0.B2 = (const uint4*)d.B2f, j0.B3 = (const uint4*)d.B3f;
+  j0.b2 = d.b2, j0.b3 = d.b3;
   j0.W1d = d.W1d, j0.s1q = d.s1q, j0.b1q = d.b1q;
   j0.a1_out = a1_records, j0.a1_lo = 0, j0.n_a1 = N;
   j0.a2 = a2_records, j0.a3 = nullptr;
   j0.N = N, j0.block0 = 0, j0.nblocks = std::min(kNumCU, N);
-  const bool i8 = d.W1d && conv12_i8_on();
-  if (i8) {
-    note_launch("conv12_i8_jobs");
-    hipLaunchKernelGGL(conv12_i8_jobs, dim3(j0.nblocks), dim3(kThreads), Conv12I::LDS_TOTAL, s, jobs);
-  } else {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_bf16s_jobs),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, Conv12::LDS_TOTAL);
-    RELA_HIP(attr);
-    note_launch("conv12_bf16s_jobs");
-    hipLaunchKernelGGL(conv12_bf16s_jobs, dim3(j0.nblocks), dim3(kThreads), Conv12::LDS_TOTAL, s, jobs);
-  }
+  note_launch("conv12_i8_jobs");
+  hipLaunchKernelGGL(conv12_i8_jobs, dim3(j0.nblocks), dim3(kThreads), Conv12I::LDS_TOTAL, s, jobs);
   RELA_HIP(hipStreamSynchronize(s));
-  if (scale_host) {
-    if (i8) RELA_HIP(hipMemcpy(scale_host, d.s1q, 32 * sizeof(float), hipMemcpyDeviceToHost));
-    else memset(scale_host, 0, 32 * sizeof(float));
-  }
-  if (bias_host) {
-    if (i8) RELA_HIP(hipMemcpy(bias_host, d.b1q, 32 * sizeof(float), hipMemcpyDeviceToHost));
-    else memset(bias_host, 0, 32 * sizeof(float));
-  }
+  if (scale_host) RELA_HIP(hipMemcpy(scale_host, d.s1q, 32 * sizeof(float), hipMemcpyDeviceToHost));
+  if (bias_host) RELA_HIP(hipMemcpy(bias_host, d.b1q, 32 * sizeof(float), hipMemcpyDeviceToHost));
   RELA_LAUNCH_CHECK();
   return RELA_OK;
 }
@@ -3329,14 +2194,14 @@ int rela_amd::ffnet_load_impl(rela_ffnet* n, const rela_ffnet_params* p, int on_
   {
     PackAllArgs a{};
     for (int i = 0; i < 12; ++i) a.p[i] = dv[i];
-    a.B1 = reinterpret_cast<uint16_t*>(n->d.B1), a.B1p = reinterpret_cast<uint16_t*>(n->d.B1p);
+    a.B1 = reinterpret_cast<uint16_t*>(n->d.B1);
     a.B2f = reinterpret_cast<uint16_t*>(n->d.B2f), a.B3f = reinterpret_cast<uint16_t*>(n->d.B3f);
     a.Bff = reinterpret_cast<uint16_t*>(n->d.Bff);
     a.B2 = n->d.B2, a.B3 = n->d.B3, a.Bf = n->d.Bf, a.BfT = n->d.BfT, a.Bh = n->d.Bh, a.Bhp = n->d.Bhp;
     a.b1 = n->d.b1, a.b2 = n->d.b2, a.b3 = n->d.b3, a.bf = n->d.bf, a.bh = n->d.bh, a.A = A;
     a.w2p = extra.w2p, a.w3p = extra.w3p, a.wfcp = extra.wfcp;
     a.W1d = reinterpret_cast<uint8_t*>(n->d.W1d), a.s1q = n->d.s1q, a.b1q = n->d.b1q;
-    const int64_t elems[17] = {2 * 8 * 64 * 8, 2 * 8 * 64 * 8, 4 * 128 * 64, 4 * 144 * 64, (int64_t)32 * 784 * 64,
+    const int64_t elems[17] = {2 * 8 * 64 * 8, 0, 4 * 128 * 64, 4 * 144 * 64, (int64_t)32 * 784 * 64,
                                (int64_t)3136 * 512, 2 * 128 * 64, 2 * 4 * 32 * 64,
                                (int64_t)Conv2F::CT * Conv2F::KS * 64 * 8, (int64_t)Conv3F::CT * Conv3F::KS * 64 * 8,
                                (int64_t)32 * FcFast::KS * 64 * 8, 672, 32,
@@ -3392,28 +2257,21 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
   const char* name12 = n->prof_names ? "learner_fwd_conv12" : "conv12_fused";  // conv1 -> conv2 in one launch
   RELA_CHECK(n->max_rows <= 0 || N <= n->max_rows, RELA_EINVAL,
              "rela_ffnet_forward: batch %d on a net whose owner declared at most %d rows", N, n->max_rows);
-  static const int fast_min_env = getenv("RELA_FAST_MIN_N") ? atoi(getenv("RELA_FAST_MIN_N")) : kFastMinN;
   // (a net packed for small batches only has no bf16 fc fragments: it keeps the f32 fc whatever the threshold says)
-  const int fast_min_n = (n->max_rows > 0 && n->max_rows < kFastMinN) ? n->max_rows + 1 : fast_min_env;
+  const int fast_min_n = (n->max_rows > 0 && n->max_rows < kFastMinN) ? n->max_rows + 1 : kFastMinN;
   const int precision = mode < 0 ? n->precision : mode;
   // Between kFastTrunkMinN and kFastMinN rows the convolutions still win on split-bf16 MFMA (N = 512: 39 us against
   // 90 us in f32) but fc_bf16s has too few blocks (55 us against the 24 us of the f32 split-K GEMM): the trunk runs
   // fast, a3 is turned back into f32 in place and fc takes the f32 path.
   const bool fast_trunk_only = precision == 1 && N < fast_min_n && N >= kFastTrunkMinN;
   // ... and (r3) fc too, as a split-K launch of fc_bf16s, when this net packs the bf16 fc fragments
-  static const int fc_split_env = getenv("RELA_FC_SPLIT_BF16") ? atoi(getenv("RELA_FC_SPLIT_BF16")) : 1;
-  const bool fc_split_bf16 = fast_trunk_only && fc_split_env && !(n->max_rows > 0 && n->max_rows < kFastTrunkMinN);
+  const bool fc_split_bf16 = fast_trunk_only && !(n->max_rows > 0 && n->max_rows < kFastTrunkMinN);
   if (fast_trunk_only) {
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
       ProfScope prof(name12, s);
-      if (d.W1d && conv12_i8_on()) {
-        note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
-                           (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
-      } else {
-      note_launch("conv12_bf16s"); hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
-                         (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
-      }
+      note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
+                         (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
     }
     {
       ProfScope prof(names[2], s);
@@ -3445,40 +2303,11 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
   }
   if (precision == 1 && N >= fast_min_n) {
     // split-bf16 fast path: a1 / a2 / a3 hold split records (same bytes as the f32 tensors they replace)
-    uint8_t *r1 = reinterpret_cast<uint8_t*>(a1), *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
-    // 0: separate conv1 / conv2 kernels, 1: fused, all waves symmetric (default), 2: fused, layer-specialised waves,
-    // 3: fused, MFMA waves + service waves
-    static const int fuse_mode = getenv("RELA_FUSE12") ? atoi(getenv("RELA_FUSE12")) : 1;
-    if (fuse_mode == 3) {
+    uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
+    {  // conv1 (int8 matrix cores) -> conv2 (split-bf16), fused per frame through LDS
       ProfScope prof(name12, s);
-      note_launch("conv12_ms"); hipLaunchKernelGGL(conv12_ms, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12S::LDS_TOTAL, s, s_dev,
-                         (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N,
-                         n->pipe_tmo);
-    } else if (fuse_mode == 2) {
-      ProfScope prof(name12, s);
-      note_launch("conv12_pipe"); hipLaunchKernelGGL(conv12_pipe, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12P::LDS_TOTAL, s, s_dev,
-                         (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N,
-                         n->pipe_tmo);
-    } else if (fuse_mode == 1) {
-      ProfScope prof(name12, s);
-      if (d.W1d && conv12_i8_on()) {
-        note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
-                           (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
-      } else {
-      note_launch("conv12_bf16s"); hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
-                         (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
-      }
-    } else {
-    {
-      ProfScope prof(names[0], s);
-      note_launch("conv1_persist"); hipLaunchKernelGGL((conv1_persist<true, 2>), dim3(std::min(2 * kNumCU, 2 * N)), dim3(Conv1P::THREADS),
-                         Conv1P::LDS_BYTES, s, s_dev, d.B1p, d.b1, a1, N);
-      }
-      {
-      ProfScope prof(names[1], s);
-      note_launch("conv_bf16s<Conv2F>"); hipLaunchKernelGGL(conv_bf16s<Conv2F>, dim3(std::min(kNumCU, ceil_div(N, Conv2F::S))), dim3(kThreads),
-                         Conv2F::LDS_TOTAL, s, (const uint8_t*)r1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
-      }
+      note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
+                         (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
     }
     {
       ProfScope prof(names[2], s);
@@ -3587,9 +2416,8 @@ __global__ void unsplit_trunk_rows(uint8_t* __restrict__ a1, uint8_t* __restrict
 }  // namespace
 
 bool ffnet_learner_forward_ok(const rela_ffnet* on, const rela_ffnet* tg, int B) {
-  static const int off = getenv("RELA_LEARNER_MERGED_FWD") ? !atoi(getenv("RELA_LEARNER_MERGED_FWD")) : 0;
   const auto packs_bf16_fc = [](const rela_ffnet* n) { return !(n->max_rows > 0 && n->max_rows < kFastTrunkMinN); };
-  return !off && on && tg && on->loaded && tg->loaded && B >= kFastTrunkMinN && 2 * B < kFcSplitBelow && packs_bf16_fc(on) &&
+  return on && tg && on->loaded && tg->loaded && B >= kFastTrunkMinN && 2 * B < kFcSplitBelow && packs_bf16_fc(on) &&
          packs_bf16_fc(tg);
 }
 
@@ -3610,29 +2438,24 @@ int ffnet_learner_forward(const rela_ffnet* on, const rela_ffnet* tg, int B, con
   const int nb0 = std::max(1, std::min(total - 1, (int)((int64_t)total * 2 / 3)));
   TrunkJob& j0 = jobs.j[0];
   j0.in0 = s_obs, j0.in1 = s_next, j0.n_in0 = B;
-  j0.B1 = (const uint4*)on->d.B1p, j0.B2 = (const uint4*)on->d.B2f, j0.B3 = (const uint4*)on->d.B3f;
-  j0.b1 = on->d.b1, j0.b2 = on->d.b2, j0.b3 = on->d.b3;
+  j0.B2 = (const uint4*)on->d.B2f, j0.B3 = (const uint4*)on->d.B3f;
+  j0.b2 = on->d.b2, j0.b3 = on->d.b3;
   j0.W1d = on->d.W1d, j0.s1q = on->d.s1q, j0.b1q = on->d.b1q;
   j0.a1_out = reinterpret_cast<uint8_t*>(w.a1), j0.a1_lo = 0, j0.n_a1 = B;
   j0.a2 = reinterpret_cast<uint8_t*>(w.a2), j0.a3 = reinterpret_cast<uint8_t*>(w.a3);
   j0.N = 2 * B, j0.block0 = 0, j0.nblocks = nb0;
   TrunkJob& j1 = jobs.j[1];
   j1.in0 = s_next, j1.in1 = s_next, j1.n_in0 = B;
-  j1.B1 = (const uint4*)tg->d.B1p, j1.B2 = (const uint4*)tg->d.B2f, j1.B3 = (const uint4*)tg->d.B3f;
-  j1.b1 = tg->d.b1, j1.b2 = tg->d.b2, j1.b3 = tg->d.b3;
+  j1.B2 = (const uint4*)tg->d.B2f, j1.B3 = (const uint4*)tg->d.B3f;
+  j1.b2 = tg->d.b2, j1.b3 = tg->d.b3;
   j1.W1d = tg->d.W1d, j1.s1q = tg->d.s1q, j1.b1q = tg->d.b1q;
   j1.a1_out = nullptr, j1.a1_lo = 0, j1.n_a1 = 0;
   j1.a2 = reinterpret_cast<uint8_t*>(wt.a2), j1.a3 = reinterpret_cast<uint8_t*>(wt.a3);
   j1.N = B, j1.block0 = nb0, j1.nblocks = total - nb0;
   {
     ProfScope prof("learner_fwd_conv12", s);
-    if (j0.W1d && j1.W1d && conv12_i8_on()) {
-      note_launch("conv12_i8_jobs");
-      hipLaunchKernelGGL(conv12_i8_jobs, dim3(total), dim3(kThreads), Conv12I::LDS_TOTAL, s, jobs);
-    } else {
-      note_launch("conv12_bf16s_jobs");
-      hipLaunchKernelGGL(conv12_bf16s_jobs, dim3(total), dim3(kThreads), Conv12::LDS_TOTAL, s, jobs);
-    }
+    note_launch("conv12_i8_jobs");
+    hipLaunchKernelGGL(conv12_i8_jobs, dim3(total), dim3(kThreads), Conv12I::LDS_TOTAL, s, jobs);
   }
   {
     // conv3 walks groups of Conv3F::S frames: the same block ranges serve (a job never has more blocks than groups
@@ -3751,11 +2574,8 @@ extern "C" int rela_lstmnet_create(rela_lstmnet** out, int num_action, int devic
                                Conv12I::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_i8_jobs), hipFuncAttributeMaxDynamicSharedMemorySize,
                                Conv12I::LDS_TOTAL));
-  RELA_HIP(hipMalloc(&d.B1p, sizeof(uint4) * Conv1B::FRAG_UINT4));
   RELA_HIP(hipMalloc(&d.B2f, sizeof(uint4) * Conv2F::CT * Conv2F::KS * 2 * 64));
   RELA_HIP(hipMalloc(&d.B3f, sizeof(uint4) * Conv3F::CT * Conv3F::KS * 2 * 64));
-  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv12_bf16s),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, Conv12::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv3F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv3F::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3),
@@ -3777,7 +2597,7 @@ extern "C" void rela_lstmnet_destroy(rela_lstmnet* n) {
   DeviceGuard g(n->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bh, n->d.bh, n->Bl, n->bl,
-                n->d.B1p, n->d.B2f, n->d.B3f, n->Wrec, n->d.W1d, n->d.s1q, n->d.b1q};
+                n->d.B2f, n->d.B3f, n->Wrec, n->d.W1d, n->d.s1q, n->d.b1q};
   for (void* p : ps) (void)hipFree(p);
   delete n;
 }
@@ -3837,8 +2657,6 @@ extern "C" int rela_lstmnet_load(rela_lstmnet* n, const rela_lstmnet_params* p, 
   pack(kPackLstm, dv[6], dv[7], n->Bl, GemmLstm::CT, GemmLstm::KS);
   hipLaunchKernelGGL(pack_wih_rec64_perm, dim3(ceil_div((int64_t)2048 * 3136 / 8, 256)), dim3(256), 0, s, dv[6], n->Wrec);
   pack(kPackHeads, dv[12], dv[10], n->d.Bh, 2, 128);
-  hipLaunchKernelGGL(pack_conv1_bf16x3, dim3(ceil_div(2 * 8 * 64 * 8, 256)), dim3(256), 0, s, dv[0],
-                     reinterpret_cast<uint16_t*>(n->d.B1p), 1);
   hipLaunchKernelGGL(pack_conv1_i8, dim3(32), dim3(256), 0, s, dv[0], dv[1], reinterpret_cast<uint8_t*>(n->d.W1d), n->d.s1q,
                      n->d.b1q);
   hipLaunchKernelGGL(pack_frags_bf16s, dim3(ceil_div((int64_t)Conv2F::CT * Conv2F::KS * 64 * 8, 256)), dim3(256), 0, s, 1,
@@ -3871,13 +2689,8 @@ bool lstm_trunk_launch(const FFNetDev& d, int N, const uint8_t* s_dev, float* a1
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
       ProfScope prof(names[1], s);
-      if (d.W1d && conv12_i8_on()) {
-        note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
-                           (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
-      } else {
-      note_launch("conv12_bf16s"); hipLaunchKernelGGL(conv12_bf16s, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12::LDS_TOTAL, s, s_dev,
-                         (const uint4*)d.B1p, (const float*)d.b1, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
-      }
+      note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
+                         (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
     }
     ProfScope prof(names[2], s);
     note_launch("conv_bf16s<Conv3F>"); hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
@@ -3995,21 +2808,16 @@ int lstmnet_trunk_records(const rela_lstmnet* n, int N, const uint8_t* s_dev, fl
   jobs.n = 1;
   TrunkJob& j0 = jobs.j[0];
   j0.in0 = s_dev, j0.in1 = s_dev, j0.n_in0 = N;
-  j0.B1 = (const uint4*)d.B1p, j0.B2 = (const uint4*)d.B2f, j0.B3 = (const uint4*)d.B3f;
-  j0.b1 = d.b1, j0.b2 = d.b2, j0.b3 = d.b3;
+  j0.B2 = (const uint4*)d.B2f, j0.B3 = (const uint4*)d.B3f;
+  j0.b2 = d.b2, j0.b3 = d.b3;
   j0.W1d = d.W1d, j0.s1q = d.s1q, j0.b1q = d.b1q;
   j0.a1_out = reinterpret_cast<uint8_t*>(a1), j0.a1_lo = a1_lo, j0.n_a1 = N - a1_lo;
   j0.a2 = reinterpret_cast<uint8_t*>(a2), j0.a3 = reinterpret_cast<uint8_t*>(a3);
   j0.N = N, j0.block0 = 0, j0.nblocks = std::min(kNumCU, N);
   {
     ProfScope prof(names[1], s);
-    if (j0.W1d && conv12_i8_on()) {
-      note_launch("conv12_i8_jobs");
-      hipLaunchKernelGGL(conv12_i8_jobs, dim3(j0.nblocks), dim3(kThreads), Conv12I::LDS_TOTAL, s, jobs);
-    } else {
-      note_launch("conv12_bf16s_jobs");
-      hipLaunchKernelGGL(conv12_bf16s_jobs, dim3(j0.nblocks), dim3(kThreads), Conv12::LDS_TOTAL, s, jobs);
-    }
+    note_launch("conv12_i8_jobs");
+    hipLaunchKernelGGL(conv12_i8_jobs, dim3(j0.nblocks), dim3(kThreads), Conv12I::LDS_TOTAL, s, jobs);
   }
   {
     ProfScope prof(names[2], s);

@@ -350,9 +350,8 @@ inline int launch_rec64_nt(const uint8_t* A, const uint8_t* B, int M, int N, int
   RELA_HIP(attr_set);
   // the small tile when the large one would leave most CUs without a block (dW_hh: 32 blocks -> 64 on twice the CUs,
   // 0.18 -> 0.11 ms); on the large GEMMs it loses to the large tile's operand reuse (gates_x 0.55 -> 0.59 ms) although
-  // two blocks per CU fill each other's barriers: they are bound by operand traffic.  RELA_GEMM_SMALL_TILE=0|1 forces.
-  static const int force = getenv("RELA_GEMM_SMALL_TILE") ? atoi(getenv("RELA_GEMM_SMALL_TILE")) : -1;
-  const bool small_tile = force >= 0 ? force != 0 : ceil_div(M, BM) * ceil_div(N, BN) < 128;
+  // two blocks per CU fill each other's barriers: they are bound by operand traffic.
+  const bool small_tile = ceil_div(M, BM) * ceil_div(N, BN) < 128;
   if (small_tile) {
     // (initialised once, thread-safely: launches may come from several host threads)
     static const hipError_t attr_s =

@@ -321,8 +321,7 @@ extern "C" int rela_apex_learner_loss(rela_apex_learner* l, int batch, const voi
     rc = ffnet_forward_mode(l->online, Bn, obs, legal, q_on, l->ws_on, l->ws_bytes, s, 0);  // f32: the backward reads a1..h
     if (rc != RELA_OK) return rc;
   }
-  static const bool fuse_td = !(getenv("RELA_LEARNER_FUSE_TD") && atoi(getenv("RELA_LEARNER_FUSE_TD")) == 0);
-  if (fuse_td && Bn <= 1024) {
+  if (Bn <= 1024) {
     ProfScope prof("learner_loss_grad", s);
     hipLaunchKernelGGL(learner_td_loss_grad, dim3(1), dim3(1024), 0, s, Bn, A, (const float*)q_on, (const float*)q_no,
                        (const float*)q_nt, nlegal, act, reward, boot, l->gamma_n, weight_dev, legal, l->td, priority_dev,

@@ -27,15 +27,12 @@ using TileWfc = TileCfg<128, 64, 4, 2, true>;     // fc weight gradient (M = 512
 using TileW64 = TileCfg<64, 64, 2, 4, true>;      // conv2 / conv3 weight gradients (M = 64 channels)
 using TileW32 = TileCfg<32, 64, 2, 4, true>;      // conv1 / head weight gradients (M = 32)
 // the same shapes on the bf16 matrix cores (gemm_bf16x3.h: operands split into bf16 hi + lo on the way into LDS, three
-// MFMAs per product): the learners' bf16x2 mode.  RELA_LEARNER_GEMM=f32 keeps the f32 MFMA GEMMs.
+// MFMAs per product): the learners' bf16x2 mode.
 using Tile3Dgrad = gemm3::TileCfg<128, 64, 4, 2, false>;
 using Tile3Wfc = gemm3::TileCfg<128, 64, 4, 2, true>;
 using Tile3W64 = gemm3::TileCfg<64, 64, 2, 4, true>;
 using Tile3W32 = gemm3::TileCfg<32, 64, 2, 4, true>;
-inline bool gemm_bf16x3_on() {
-  static const bool off = getenv("RELA_LEARNER_GEMM") && strcmp(getenv("RELA_LEARNER_GEMM"), "f32") == 0;
-  return !off;
-}
+inline bool gemm_bf16x3_on() { return true; }
 
 
 // d_h[b][u] = relu'(h) * sum_k d_ha[b][k] * Wh[k][u]      Wh rows: 0..A-1 = fc_a.weight, 31 = fc_v.weight
@@ -632,7 +629,7 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     p.d_out = t.d_a3, p.in = t.a2, p.part = partw;
     // (a few hundred frames: 3 x the splits = 3-4 blocks per CU instead of one; a block alone on its CU waits out
     // every chunk's load latency with two waves per SIMD)
-    static const int mul = getenv("RELA_WGRAD_SPLIT_MUL") ? std::max(1, std::min(8, atoi(getenv("RELA_WGRAD_SPLIT_MUL")))) : 3  /* clamped to what kTrunkPartFloats holds */;
+    static const int mul = 3  /* (<= 8: what kTrunkPartFloats holds; flat between 2 and 4 in the r3 sweep) */;
     const int split3 = Bn <= 1024 ? kSplitW3 * mul : kSplitW3;
     if (t.fast && gemm_bf16x3_on()) (void)gemm3::launch_gemm<Tile3W64>(p, split3, sw, "learner_wgrad_conv3");
     else launch_gemm<TileW64>(p, split3, sw, "learner_wgrad_conv3");
@@ -665,7 +662,7 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     ProbW2 p{};
     p.M = 64, p.N = 512, p.K = Bn * 81;
     p.d_out = t.d_a2, p.in = t.a1, p.part = partw;
-    static const int mul = getenv("RELA_WGRAD_SPLIT_MUL") ? std::max(1, std::min(8, atoi(getenv("RELA_WGRAD_SPLIT_MUL")))) : 3  /* clamped to what kTrunkPartFloats holds */;
+    static const int mul = 3  /* (<= 8: what kTrunkPartFloats holds; flat between 2 and 4 in the r3 sweep) */;
     const int split2 = Bn <= 1024 ? kSplitW2 * mul : kSplitW2;
     if (t.fast && gemm_bf16x3_on()) (void)gemm3::launch_gemm<Tile3W64>(p, split2, sw, "learner_wgrad_conv2");
     else launch_gemm<TileW64>(p, split2, sw, "learner_wgrad_conv2");

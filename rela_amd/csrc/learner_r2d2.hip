@@ -166,11 +166,11 @@ __global__ void lstm_cell_fwd(float* __restrict__ gx, const float* __restrict__ 
   }
 }
 
-// Reads of bytes another CU wrote inside this launch (see sc1_handoff below).  With the acquire fence (`buffer_inv sc1` + the wait for it:
-// ~1.7 us per grid barrier) plain loads are fine; WITHOUT it every such load must bypass this CU's L1: a buffer load with
-// the sc1 bit.  MI355X_MICROARCH.md measured that form for exactly this hand-off -- sc1 stores of 8 bytes, every storing
-// wave drained, ONE lane of each workgroup adding to an agent-scope counter behind a workgroup barrier, the consumer's
-// lane polling it with sc1 loads and the other waves loading behind a workgroup barrier, one workgroup per CU.
+// Reads of bytes another CU wrote inside this launch.  With an acquire fence (`buffer_inv sc1` + the wait for it: ~1.7 us
+// per barrier) plain loads are fine (SC1 = false: BPTT); WITHOUT it every such load must bypass this CU's L1: a buffer
+// load with the sc1 bit (SC1 = true: the forward chains) -- sc1 stores, every storing wave drained, ONE lane of each
+// workgroup adding to an agent-scope counter behind a workgroup barrier, the consumer's lane polling it and the other
+// waves loading behind a workgroup barrier.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sc1_rsrc(const void* base, size_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
@@ -185,197 +185,36 @@ __device__ __forceinline__ float4 ld4_shared(__amdgpu_buffer_rsrc_t rs, const fl
   }
 }
 
-// ---- persistent recurrent forward ---------------------------------------------------------------------
-// The T recurrent steps of one net in ONE launch (2 x 123 x 3 launches of ~13 us each before: launch-bound).
-// Block j owns hidden units 4j .. 4j+3 (16 gate columns: i, f, g, o of each) for the whole batch; its slice of
-// W_hh^T stays in registers (wave w: k in [64w, 64w + 64), one f32 MFMA B-fragment register per k-step).  Per step:
-// every wave multiplies its k-slice of h_{t-1} (plain loads behind the acquire of the grid barrier) into a
-// partial [rows x 16] tile on v_mfma_f32_16x16x4_f32, the eight partials meet in LDS, one thread per batch row
-// runs the cell for the block's four units and stores c_t (plain; only this block reads it back) and h_t
-// WRITE-THROUGH (sc1 via agent-scope atomic stores: visible to the other XCDs without a release fence).  Steps are
-// separated by a grid barrier: one arrival counter per step (zeroed by a memset ahead of the launch), ONE lane
-// polls it relaxed, ONE agent-scope acquire, workgroup barrier, plain loads.  Every spin is bounded: a block
-// that gives up sets the timeout word and leaves, and the host reports it (rela_r2d2_learner_check).
+// ---- persistent recurrent forward: XCD-local chains (batches of up to 64 rows) ---------------------------------
+// The T recurrent steps of BOTH nets in ONE launch (2 x 123 x 3 launches of ~13 us each before r2: launch-bound).
+// A CHAIN is one net x one tile of 16 batch rows (2 x 4 chains), run by the 32 blocks whose ids are equal mod 8 -- the
+// dispatcher deals blocks round-robin over the XCDs, so a chain shares an L2 -- each block owning 16 hidden units (64
+// gate columns: i, f, g, o of each) with its slice of W_hh^T in registers (wave w: k in [64 w, 64 w + 64), one f32 MFMA
+// B-fragment register per k-step).  Per step every wave multiplies its k-slice of h_{t-1} into a partial [16 x 16]
+// tile on v_mfma_f32_16x16x4_f32, the eight partials are added in wave order onto the x-part in LDS, one thread per
+// (row, unit) runs the cell with c_t in a register and stores h_t WRITE-THROUGH (agent-scope atomic stores: visible
+// to the other CUs without a release fence).  Steps are separated by a chain barrier: one arrival counter per chain
+// and step (zeroed ahead of the launch, 32 arrivals), ONE lane polls it relaxed, then h_{t-1} is read with sc1 buffer
+// loads and no acquire fence (every storing wave drained its stores before the workgroup barrier that precedes the
+// arrival; 0.79 -> 0.56 ms against plain loads behind an agent-scope acquire).  The protocol is placement-
+// INDEPENDENT: co-location only decides whether the h a block reads is still in its XCD's L2, never correctness, and
+// the sc1 loads never allocate in the per-CU L1, so a second chain block on the same CU cannot read a stale line
+// (the hand-off form and its measured envelope: the CDNA4 guide shipped with the build image, "hand-offs measured
+// with sc1 loads"; checked here by the bit-reproducibility-under-load test).  Every spin is bounded: a block that
+// gives up sets the timeout word and leaves, and the host reports it (rela_r2d2_learner_check) and falls back to
+// per-step launches.  History (r2-r3): a one-block-per-4-units kernel over all eight XCDs (14 us per step, 5-6 of
+// them in a 128-arrival grid barrier and its acquire) was replaced by these chains (6.4 us per step) and removed in r4.
 typedef __attribute__((address_space(1))) unsigned gu32;
 typedef __attribute__((address_space(1))) unsigned long long gu64;
-constexpr int kRecBlocks = kHid / 4, kRecThreads = 512, kRecChunk = 64;
+constexpr int kRecThreads = 512;
 constexpr unsigned kRecSpinLimit = 1u << 22;
-// How a block reads what other CUs wrote in the previous step: plain loads behind an agent-scope acquire fence per grid
-// barrier (default), or -- RELA_R2D2_ACQUIRE=sc1 -- sc1 buffer loads and no fence.  The second form was built and measured
-// in r3 (one workgroup per CU, the envelope MI355X_MICROARCH.md gives for it; bit-reproducible under uneven load, same
-// results): the forward launch 1.73 -> 1.70 ms, but BPTT 0.88 -> 1.02 ms (its 128 KB of gate gradients per block and step
-// then bypass L1): 6.07 -> 6.14 ms per learner step.  Not the default.
-inline bool sc1_handoff() {
-  static const bool sc1 = getenv("RELA_R2D2_ACQUIRE") && strcmp(getenv("RELA_R2D2_ACQUIRE"), "sc1") == 0;
-  return sc1;
-}
 struct RecNet {
   float* gx;          // [T][Bn][2048] pre-activations of the input half (+ bias); saved steps get the activated gates
   const float* whhT;  // [512][2048]
   float *H, *C;       // [(T + 1)][Bn][512], slot 0 = initial state
-  unsigned* bar;      // [T] arrival counters of this net's blocks
+  unsigned* bar;      // (unused by the chains: their counters are ChainArgs2::bar)
   int save;
 };
-struct RecArgs {
-  RecNet net[2];        // blocks [0, 128) run net[0], blocks [128, 256) net[1]: two independent latency chains
-  const uint8_t* term;  // [T][Bn]
-  unsigned* tmo;        // timeout word (0 = none)
-  int T, Bn, burn;
-  unsigned long long* stamps;  // diagnostic (RELA_R2D2_STAMPS=1): [8 steps][8 points] shader clocks of block 0, or NULL
-};
-
-// (r3: a row split as in the BPTT kernel below was built and measured for this kernel too -- a row tile at a time with the
-// cell on one thread per (row, unit), two copies of every unit block = 512 blocks at two per CU -- and is SLOWER: 1.75 ->
-// 2.27 ms with one copy, 3.09 ms with two.  The forward step is a latency chain (load h, MFMAs, LDS reduce, the cell's
-// sigmoid / tanh chain, write-through stores), and handling the four row tiles of a batch of 64 in ONE pass, as this
-// kernel does, pays that chain once per step instead of once per tile.)
-template <bool SC1>
-__global__ __launch_bounds__(kRecThreads) void lstm_rec_persist(RecArgs a) {
-  __shared__ float red[8][kRecChunk][17];
-  __shared__ int alive;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, g = lane >> 4, j = blockIdx.x % kRecBlocks;
-  const RecNet nt = a.net[blockIdx.x / kRecBlocks];
-  const int gcol = (li >> 2) * kHid + 4 * j + (li & 3);  // column li of the block's tile = gate li/4 of unit 4j + li%4
-  float bfr[16];
-#pragma unroll
-  for (int ks = 0; ks < 16; ++ks) bfr[ks] = nt.whhT[(size_t)(wave * 64 + 16 * g + ks) * kGates + gcol];
-  const size_t blk = (size_t)a.Bn * kHid;
-  const __amdgpu_buffer_rsrc_t rsH = sc1_rsrc(nt.H, (size_t)(a.T + 1) * blk * 4), rsC = sc1_rsrc(nt.C, (size_t)(a.T + 1) * blk * 4);
-  const bool one_chunk = a.Bn <= kRecChunk;
-  // x-part of the gates of (step, row = tid): independent of the other blocks, so it is fetched BEFORE the
-  // wait for h_{t-1} (batches of more than one chunk fetch per chunk instead)
-  float4 gpre[4];
-  auto gx_fetch = [&](int t, int row) {
-    const float* grow = nt.gx + ((size_t)t * a.Bn + row) * kGates + 4 * j;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) gpre[q] = *reinterpret_cast<const float4*>(grow + q * kHid);
-  };
-  if (one_chunk && tid < a.Bn) gx_fetch(0, tid);
-  // points: 0 step start | 1 h loaded, MFMAs done, partials in LDS | 2 (after the workgroup barrier) | 3 cell done, stores
-  // issued | 4 stores drained + workgroup barrier | 5 arrival counted, all blocks seen | 6 acquire done | 7 released
-  auto stamp = [&](int t, int point) {
-    if (a.stamps && blockIdx.x == 0 && tid == 0 && t >= 20 && t < 28) a.stamps[(t - 20) * 8 + point] = __builtin_amdgcn_s_memtime();
-  };
-  for (int t = 0; t < a.T; ++t) {
-    stamp(t, 0);
-    for (int row0 = 0; row0 < a.Bn; row0 += kRecChunk) {
-      const int row = row0 + tid;
-      if (!one_chunk && tid < kRecChunk && row < a.Bn) gx_fetch(t, row);
-      f32x4 acc[4];
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int arow = row0 + rt * 16 + li;
-        float av[16];
-        if (arow < a.Bn) {
-          const size_t hoff = (size_t)t * blk + (size_t)arow * kHid + wave * 64 + 16 * g;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float4 v = ld4_shared<SC1>(rsH, nt.H, hoff + 4 * q);
-            av[4 * q] = v.x, av[4 * q + 1] = v.y, av[4 * q + 2] = v.z, av[4 * q + 3] = v.w;
-          }
-        } else {
-#pragma unroll
-          for (int q = 0; q < 16; ++q) av[q] = 0.f;
-        }
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bfr[ks], acc[rt], 0, 0, 0);
-      }
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][rt * 16 + 4 * g + r][li] = acc[rt][r];
-      stamp(t, 1);
-      __syncthreads();
-      stamp(t, 2);
-      if (tid < kRecChunk && row < a.Bn) {
-        float* grow = nt.gx + ((size_t)t * a.Bn + row) * kGates + 4 * j;
-        float pre[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          pre[q][0] = gpre[q].x, pre[q][1] = gpre[q].y, pre[q][2] = gpre[q].z, pre[q][3] = gpre[q].w;
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int w = 0; w < 8; ++w) pre[q][u] += red[w][tid][q * 4 + u];
-        }
-        const float4 cp4 = ld4_shared<SC1>(rsC, nt.C, (size_t)t * blk + (size_t)row * kHid + 4 * j);
-        const float cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
-        float gi[4], gf[4], gg[4], go[4], c[4], h[4];
-        // the state that ENTERS the first training step is zeroed where the burn-in was a dummy (r2d2.py:149-154)
-        const bool zero = a.burn > 0 && t + 1 == a.burn && a.term[(size_t)(a.burn - 1) * a.Bn + row] != 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          gi[u] = sigm(pre[0][u]), gf[u] = sigm(pre[1][u]), gg[u] = tanhf(pre[2][u]), go[u] = sigm(pre[3][u]);
-          c[u] = gf[u] * cp[u] + gi[u] * gg[u];
-          h[u] = go[u] * tanhf(c[u]);
-          if (zero) c[u] = 0.f, h[u] = 0.f;
-        }
-        const size_t o = (size_t)(t + 1) * blk + (size_t)row * kHid + 4 * j;
-        gu64* hp = (gu64*)(nt.H + o);
-        __hip_atomic_store(hp, ((unsigned long long)__float_as_uint(h[1]) << 32) | __float_as_uint(h[0]),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(hp + 1, ((unsigned long long)__float_as_uint(h[3]) << 32) | __float_as_uint(h[2]),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *reinterpret_cast<float4*>(nt.C + o) = make_float4(c[0], c[1], c[2], c[3]);
-        if (nt.save && t >= a.burn) {
-          *reinterpret_cast<float4*>(grow) = make_float4(gi[0], gi[1], gi[2], gi[3]);
-          *reinterpret_cast<float4*>(grow + kHid) = make_float4(gf[0], gf[1], gf[2], gf[3]);
-          *reinterpret_cast<float4*>(grow + 2 * kHid) = make_float4(gg[0], gg[1], gg[2], gg[3]);
-          *reinterpret_cast<float4*>(grow + 3 * kHid) = make_float4(go[0], go[1], go[2], go[3]);
-        }
-      }
-      stamp(t, 3);
-      __syncthreads();
-    }
-    if (t + 1 == a.T) break;
-    // grid barrier: every storing wave drains its stores, then ONE lane signals and polls
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    stamp(t, 4);
-    if (one_chunk && tid < a.Bn) gx_fetch(t + 1, tid);  // in flight across the wait
-    if (tid == 0) {
-      gu32* cnt = (gu32*)(nt.bar + t);
-      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      bool ok = true;
-      for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)kRecBlocks;) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kRecSpinLimit || __hip_atomic_load((gu32*)a.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          __hip_atomic_store((gu32*)a.tmo, (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = false;
-          break;
-        }
-      }
-      stamp(t, 5);
-      if constexpr (!SC1) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      stamp(t, 6);
-      alive = ok ? 1 : 0;
-    }
-    __syncthreads();
-    stamp(t, 7);
-    if (!alive) return;
-  }
-}
-
-// ---- persistent recurrent forward, XCD-local chains (late r3; batches of up to 64 rows) ------------------------
-// The step above spends 14 us: ~5 in the loads of h_{t-1} + 64 f32 MFMAs, 2 in the cell, and 5-6 in the grid barrier
-// and the acquire (in-kernel stamps, RELA_R2D2_STAMPS=1).  Its 128 blocks per net sit on all eight XCDs, so every step's
-// h travels CU -> memory -> another XCD's L2 -> CU, and 128 arrivals queue on one counter.  Here the work is cut the
-// other way: a CHAIN is one net x one tile of 16 batch rows (2 x 4 chains), run by the 32 blocks whose ids are equal
-// mod 8 -- the dispatcher deals blocks round-robin over the XCDs, so they share an L2 -- each owning 16 hidden units
-// (64 gate columns: W_hh's slice is 64 registers per lane).  The protocol is unchanged and placement-INDEPENDENT
-// (write-through h, agent-scope arrival counter, sc1 loads of h -- or plain loads behind one acquire per step):
-// co-location only decides whether the h a block
-// reads is still in its XCD's L2 and how many arrivals a counter takes (32).  The sums are formed in the order of the
-// kernel above -- wave w multiplies k in [64 w, 64 w + 64) in the same MFMA sequence, the eight partials are added in
-// wave order onto the x-part -- so H, C and the saved gates are bit-identical to it.  One thread per (row, unit) runs
-// the cell and keeps c_t in a register for the next step (four units per thread with 16-byte accesses, as above: 0.94 ms
-// against 0.80 -- the forward cell's sigmoid / tanh chain is what a thread's step waits for; in BPTT, whose cell has one
-// tanh, the four-unit form with 8-byte write-through stores is the faster one).
 struct ChainArgs2 {
   RecNet net[2];
   const uint8_t* term;
@@ -492,14 +331,19 @@ __global__ __launch_bounds__(kRecThreads) void lstm_rec_chain(ChainArgs2 a) {
   }
 }
 
-// ---- persistent BPTT ---------------------------------------------------------------------------------
-// The seq_len + n backward steps of the online net in ONE launch (2 launches per step before: a split-K GEMM for
-// dh = dgates_{t+1} x W_hh and the cell kernel; launch gaps alone cost ~1 ms per learner step).  Block j owns hidden
-// units 16j .. 16j+15: its [2048 x 16] slice of W_hh stays in registers (wave w: gate columns [256w, 256w + 256), one
-// f32 MFMA B-fragment register per k-step), every step the eight waves multiply their slices of dgates_{t+1} (read
-// behind the acquire of the grid barrier) into partial [rows x 16] tiles that meet in LDS, a thread per (row, four
-// units) runs the cell backward and writes the gate gradients of the block's 64 gate columns WRITE-THROUGH, in
-// place of the activated gates.  Grid barrier per step as in lstm_rec_persist (bounded spins, timeout word).
+// ---- persistent BPTT: XCD-local chains (batches of up to 128 rows) ---------------------------------------------
+// The seq_len + n backward steps of the online net in ONE launch (2 launches per step before r2: a split-K GEMM for
+// dh = dgates_{t+1} x W_hh and the cell kernel; launch gaps alone cost ~1 ms per learner step).  chain = tile of 16
+// batch rows, run by the 32 blocks whose ids are equal mod 8 (one XCD, see lstm_rec_chain); block j of a chain owns
+// hidden units 16j .. 16j+15: its [2048 x 16] slice of W_hh stays in registers (wave w: gate columns [256w, 256w +
+// 256), one f32 MFMA B-fragment register per k-step), every step the eight waves multiply their slices of
+// dgates_{t+1} -- plain loads behind ONE agent-scope acquire per step: sc1 loads are SLOWER here (0.82 -> 0.96-1.01
+// ms), the 128 KB of gate gradients a block reads per step then bypass L1 -- into partial [16 x 16] tiles that meet in
+// LDS, a thread per (row, four units) runs the cell backward with the recurrent cell-state gradient in registers and
+// writes the gate gradients of the block's 64 gate columns WRITE-THROUGH, in place of the activated gates.  Chain
+// barrier per step as in lstm_rec_chain (bounded spins, timeout word).  (Requesting the cell's own inputs of step
+// t - 1 before the wait at the barrier, as the forward kernel does with its x-part, made this kernel SLOWER, 0.79 ->
+// 1.05 ms; the cause is not established.)
 constexpr int kBpttBlocks = kHid / 16;
 
 struct BpttArgs {
@@ -508,132 +352,11 @@ struct BpttArgs {
   const float* whh;    // [2048][512] weight_hh_l0 (gate-major rows)
   const float* C;      // [(T + 1)][Bn][512] cell states, slot 0 = initial
   float* dc_rec;       // [Bn][512] running dL/dc (zeroed before the launch)
-  unsigned* bar;       // [Tt] arrival counters
+  unsigned* bar;       // [chains][Tpad] arrival counters
   unsigned* tmo;
   int Tt, Bn, burn;
 };
 
-// r3: the batch rows are split over kBpttRowSplit copies of every unit block (grid = 32 x 4 = 128): a block re-reads
-// the step's gate gradients of ITS row tiles only -- 128 KB instead of 512 KB per step from L2 (at ~70 GB/s per CU the
-// 512 KB alone were 7 us of a 21-us step) -- and issues a quarter of the f32 MFMAs; W_hh's slice is simply resident
-// in four blocks instead of one.  Block b: units 16 (b % 32) .. + 15, row tiles (b / 32), (b / 32) + 4, ...
-constexpr int kBpttRowSplit = 4;
-template <bool SC1>
-__global__ __launch_bounds__(kRecThreads) void lstm_bptt_persist(BpttArgs a) {
-  __shared__ float red[8][16][17];
-  __shared__ int alive;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, g = lane >> 4, j = blockIdx.x % kBpttBlocks, rs = blockIdx.x / kBpttBlocks;
-  const int nsplit = gridDim.x / kBpttBlocks;
-  // B fragments: k-step s of lane group g is gate column 256 wave + 64 g + s; column li of the tile = unit 16 j + li
-  float bfr[64];
-#pragma unroll
-  for (int ks = 0; ks < 64; ++ks) bfr[ks] = a.whh[(size_t)(256 * wave + 64 * g + ks) * kHid + 16 * j + li];
-  const size_t blk = (size_t)a.Bn * kHid;
-  const __amdgpu_buffer_rsrc_t rsG = sc1_rsrc(a.ga, (size_t)a.Tt * a.Bn * kGates * 4), rsD = sc1_rsrc(a.dc_rec, blk * 4);
-  for (int t = a.Tt - 1; t >= 0; --t) {
-    const bool rec = t + 1 < a.Tt;  // the newest step has no recurrent term
-    float* ga_t = a.ga + (size_t)t * a.Bn * kGates;
-    for (int row0 = rs * 16; row0 < a.Bn; row0 += 16 * nsplit) {
-      if (rec) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int arow = min(row0 + li, a.Bn - 1);  // (rows past the batch repeat the last one, unread)
-        const size_t doff = (size_t)(t + 1) * a.Bn * kGates + (size_t)arow * kGates + 256 * wave + 64 * g;
-        float4 v[16];
-#pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = ld4_shared<SC1>(rsG, a.ga, doff + 4 * c);  // all in flight before the first MFMA
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {  // every lane takes part in every MFMA: no MFMA under a lane mask
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c].x, bfr[4 * c], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c].y, bfr[4 * c + 1], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c].z, bfr[4 * c + 2], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c].w, bfr[4 * c + 3], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][4 * g + r][li] = acc[r];
-      }
-      __syncthreads();
-      // cell backward (lstm_cell_bwd) for (row, units 16 j + 4 q .. + 3): threads 0 .. 63
-      const int r = tid >> 2, q = tid & 3, row = row0 + r;
-      if (tid < 4 * 16 && row < a.Bn) {
-        const size_t u0 = (size_t)row * kHid + 16 * j + 4 * q;
-        const int gs = a.burn + t;
-        const float4 d_o4 = *reinterpret_cast<const float4*>(a.d_o + (size_t)t * blk + u0);
-        float dh[4] = {d_o4.x, d_o4.y, d_o4.z, d_o4.w};
-        if (rec) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int w = 0; w < 8; ++w) dh[u] += red[w][r][4 * q + u];
-        }
-        float* grow = ga_t + (size_t)row * kGates + 16 * j + 4 * q;
-        const float4 gi4 = *reinterpret_cast<const float4*>(grow), gf4 = *reinterpret_cast<const float4*>(grow + kHid);
-        const float4 gg4 = *reinterpret_cast<const float4*>(grow + 2 * kHid), go4 = *reinterpret_cast<const float4*>(grow + 3 * kHid);
-        const float4 cn4 = *reinterpret_cast<const float4*>(a.C + (size_t)(gs + 1) * blk + u0);
-        const float4 cp4 = *reinterpret_cast<const float4*>(a.C + (size_t)gs * blk + u0);
-        const float4 dcr4 = ld4_shared<SC1>(rsD, a.dc_rec, u0);
-        const float gi[4] = {gi4.x, gi4.y, gi4.z, gi4.w}, gf[4] = {gf4.x, gf4.y, gf4.z, gf4.w};
-        const float gg[4] = {gg4.x, gg4.y, gg4.z, gg4.w}, go[4] = {go4.x, go4.y, go4.z, go4.w};
-        const float cn[4] = {cn4.x, cn4.y, cn4.z, cn4.w}, cp[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
-        const float dcr[4] = {dcr4.x, dcr4.y, dcr4.z, dcr4.w};
-        float di[4], df[4], dgg[4], dgo[4], dcn[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float tc = tanhf(cn[u]);
-          const float dc = dcr[u] + dh[u] * go[u] * (1.0f - tc * tc);
-          di[u] = dc * gg[u] * gi[u] * (1.0f - gi[u]);
-          df[u] = dc * cp[u] * gf[u] * (1.0f - gf[u]);
-          dgg[u] = dc * gi[u] * (1.0f - gg[u] * gg[u]);
-          dgo[u] = dh[u] * tc * go[u] * (1.0f - go[u]);
-          dcn[u] = dc * gf[u];
-        }
-        *reinterpret_cast<float4*>(a.dc_rec + u0) = make_float4(dcn[0], dcn[1], dcn[2], dcn[3]);
-        auto store_wt = [&](float* dst, const float* v) {  // write-through: read by every block in the next step
-          gu64* p = (gu64*)dst;
-          __hip_atomic_store(p, ((unsigned long long)__float_as_uint(v[1]) << 32) | __float_as_uint(v[0]),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(p + 1, ((unsigned long long)__float_as_uint(v[3]) << 32) | __float_as_uint(v[2]),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
-        store_wt(grow, di);
-        store_wt(grow + kHid, df);
-        store_wt(grow + 2 * kHid, dgg);
-        store_wt(grow + 3 * kHid, dgo);
-      }
-      __syncthreads();
-    }
-    if (t == 0) break;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      gu32* cnt = (gu32*)(a.bar + t);
-      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      bool ok = true;
-      for (unsigned spins = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x;) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > kRecSpinLimit || __hip_atomic_load((gu32*)a.tmo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          __hip_atomic_store((gu32*)a.tmo, (unsigned)(1000 + t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = false;
-          break;
-        }
-      }
-      if constexpr (!SC1) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      alive = ok ? 1 : 0;
-    }
-    __syncthreads();
-    if (!alive) return;
-  }
-}
-
-// The same backward recurrence as XCD-local chains (late r3; see lstm_rec_chain): chain = row tile (blocks equal mod 8
-// share an XCD; 32 unit blocks each), its own arrival counters, the cell as above with the
-// recurrent cell-state gradient in registers.  Same sums in the same order: bit-identical gate gradients.  (Requesting
-// the cell's own inputs of step t - 1 before the wait at the grid barrier, as the forward kernel does with its x-part,
-// made this kernel SLOWER, 0.79 -> 1.05 ms; the cause is not established -- polling from a lane of another wave, so that
-// no load is queued ahead of the polls, changed nothing in the forward kernel.)
 template <bool SC1>
 __global__ __launch_bounds__(kRecThreads) void lstm_bptt_chain(BpttArgs a, int Tpad) {
   __shared__ float red[8][16][17];
@@ -995,7 +718,7 @@ int forward_pre(rela_r2d2_learner* l, int which, int Bn, const uint8_t* obs, con
   // backward kernels: its conv1 records are copied out (they never leave LDS otherwise), a3's records feed the gate GEMM
   // directly, then the training rows are turned back into f32 in place (below) -- the backward differentiates the
   // forward that really ran, ReLU pattern included.  RELA_R2D2_ONLINE_F32=1 keeps the online trunk in f32 (r2).
-  static const bool online_f32 = getenv("RELA_R2D2_ONLINE_F32") && atoi(getenv("RELA_R2D2_ONLINE_F32")) != 0;
+  constexpr bool online_f32 = false;  // (r2's f32 online trunk in bf16x2 mode: an A/B switch until r4)
   const bool fast_target = which == 1 && l->precision == 1;
   const bool fast_online = which == 0 && l->precision == 1 && !online_f32 && rowsAll >= 128;
   bool a3_records = false;  // a fast trunk hands a3 over as the split records the gate GEMM reads
@@ -1069,53 +792,19 @@ int forward_both(rela_r2d2_learner* l, int Bn, const uint8_t* obs, const float* 
   if (rc != RELA_OK) return rc;
   rc = forward_pre(l, 0, Bn, obs, h0, c0, s);
   if (rc != RELA_OK) return rc;
-  if (l->rec_persist) {
-    // arrival counters of this launch: words [4, 4 + 2 * Tpad) (the timeout word [0] is sticky until ..._check)
+  if (l->rec_persist && l->rec_chains_fit && Bn <= 64) {
+    // arrival counters of this launch: [8 chains][Tpad] (the timeout word rec_bar[0] is sticky until ..._check)
     const int Tpad = (T + 3) / 4 * 4;
-    RELA_HIP(hipMemsetAsync(l->rec_bar + 4, 0, sizeof(unsigned) * (size_t)(2 * Tpad), s));
-    RecArgs ra{};
+    RELA_HIP(hipMemsetAsync(l->rec_chain_bar, 0, sizeof(unsigned) * (size_t)(8 * Tpad), s));
+    ChainArgs2 ca{};
     for (int w = 0; w < 2; ++w) {
-      ra.net[w].gx = l->gxs[w], ra.net[w].whhT = l->whhT[w], ra.net[w].H = l->Hs[w], ra.net[w].C = l->Cs[w];
-      ra.net[w].bar = l->rec_bar + 4 + w * Tpad, ra.net[w].save = w == 0 ? 1 : 0;
+      ca.net[w].gx = l->gxs[w], ca.net[w].whhT = l->whhT[w], ca.net[w].H = l->Hs[w], ca.net[w].C = l->Cs[w];
+      ca.net[w].bar = nullptr, ca.net[w].save = w == 0 ? 1 : 0;
     }
-    ra.term = term, ra.tmo = l->rec_bar, ra.T = T, ra.Bn = Bn, ra.burn = burn;
-    static const bool want_stamps = getenv("RELA_R2D2_STAMPS") && atoi(getenv("RELA_R2D2_STAMPS")) != 0;
-    static unsigned long long* stamp_buf = nullptr;
-    if (want_stamps && !stamp_buf) RELA_HIP(hipMalloc(&stamp_buf, 64 * sizeof(unsigned long long)));
-    ra.stamps = want_stamps ? stamp_buf : nullptr;
-    static const bool chains = !(getenv("RELA_R2D2_REC_CHAINS") && atoi(getenv("RELA_R2D2_REC_CHAINS")) == 0);
-    if (chains && l->rec_chains_fit && Bn <= 64 && !want_stamps && !sc1_handoff()) {
-      RELA_HIP(hipMemsetAsync(l->rec_chain_bar, 0, sizeof(unsigned) * (size_t)(8 * Tpad), s));
-      ChainArgs2 ca{};
-      ca.net[0] = ra.net[0], ca.net[1] = ra.net[1];
-      ca.term = term, ca.tmo = l->rec_bar, ca.bar = l->rec_chain_bar, ca.T = T, ca.Tpad = Tpad, ca.Bn = Bn, ca.burn = burn;
-      ProfScope prof("learner_lstm_rec_persist", s);
-      // h_{t-1} is read with sc1 buffer loads and no acquire fence (default; RELA_R2D2_CHAIN_SC1=0: plain loads behind an
-      // agent-scope acquire per step): 0.79 -> 0.56 ms.  MI355X_MICROARCH.md's conditions for that form hold: h is stored
-      // write-through (agent-scope atomic stores), every storing wave drains its stores before the workgroup barrier that
-      // precedes the arrival, every load of those bytes is an sc1 load, one workgroup per CU.  The same switch makes BPTT
-      // SLOWER (0.82 -> 0.96-1.01 ms: its 128 KB of gate gradients per block and step), so it keeps the fence.
-      static const bool chain_sc1 = !(getenv("RELA_R2D2_CHAIN_SC1") && atoi(getenv("RELA_R2D2_CHAIN_SC1")) == 0);
-      if (chain_sc1) hipLaunchKernelGGL(lstm_rec_chain<true>, dim3(8 * kChainBlocks), dim3(kRecThreads), 0, s, ca);
-      else hipLaunchKernelGGL(lstm_rec_chain<false>, dim3(8 * kChainBlocks), dim3(kRecThreads), 0, s, ca);
-    } else {
-      ProfScope prof("learner_lstm_rec_persist", s);
-      if (sc1_handoff()) hipLaunchKernelGGL(lstm_rec_persist<true>, dim3(2 * kRecBlocks), dim3(kRecThreads), 0, s, ra);
-      else hipLaunchKernelGGL(lstm_rec_persist<false>, dim3(2 * kRecBlocks), dim3(kRecThreads), 0, s, ra);
-    }
+    ca.term = term, ca.tmo = l->rec_bar, ca.bar = l->rec_chain_bar, ca.T = T, ca.Tpad = Tpad, ca.Bn = Bn, ca.burn = burn;
+    ProfScope prof("learner_lstm_rec_persist", s);
+    hipLaunchKernelGGL(lstm_rec_chain<true>, dim3(8 * kChainBlocks), dim3(kRecThreads), 0, s, ca);
     RELA_LAUNCH_CHECK();
-    if (want_stamps) {  // diagnostic: per-phase cycles of steps 20..27 of block 0 (synchronises)
-      unsigned long long h[64];
-      RELA_HIP(hipStreamSynchronize(s));
-      RELA_HIP(hipMemcpy(h, stamp_buf, sizeof(h), hipMemcpyDeviceToHost));
-      double d[8] = {0};
-      for (int k = 0; k < 7; ++k) {
-        for (int pnt = 0; pnt < 7; ++pnt) d[pnt] += (double)(h[k * 8 + pnt + 1] - h[k * 8 + pnt]) / 7.0;
-        d[7] += (double)(h[(k + 1) * 8] - h[k * 8]) / 7.0;
-      }
-      fprintf(stderr, "lstm_rec_persist step %.0f cycles: loads+MFMA %.0f | wg barrier %.0f | cell+stores %.0f | drain %.0f | grid barrier %.0f | acquire %.0f | release %.0f\n",
-              d[7], d[0], d[1], d[2], d[3], d[4], d[5], d[6]);
-    }
   } else {
     rc = forward_rec_steps(l, 1, Bn, term, false, s);
     if (rc != RELA_OK) return rc;
@@ -1224,29 +913,17 @@ extern "C" int rela_r2d2_learner_create(rela_r2d2_learner** out, int num_action,
     // taken off -- and fall back to the per-step launches (split-K GEMM + cell kernel) when they would not fit.
     int cus = 0;
     RELA_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-    //  query the instantiations that can really be launched -- register use, and with it the occupancy, differs
-    // between the SC1 variants -- and take the minimum over both; the BPTT grid is checked for the row split that will
-    // be used (RELA_BPTT_ROW_SPLIT, clamped to 1..8 where it is read)
-    auto occ_of = [](auto kern_a, auto kern_b) {
-      int a = 0, b = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, kern_a, kRecThreads, 0) != hipSuccess) a = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kern_b, kRecThreads, 0) != hipSuccess) b = 0;
-      return a < b ? a : b;
-    };
-    const int occ_f = occ_of(lstm_rec_persist<true>, lstm_rec_persist<false>);
-    const int occ_b = occ_of(lstm_bptt_persist<true>, lstm_bptt_persist<false>);
-    const int occ_c = occ_of(lstm_rec_chain<true>, lstm_rec_chain<false>);
-    const int occ_d = occ_of(lstm_bptt_chain<true>, lstm_bptt_chain<false>);
+    //  the instantiations that are really launched: lstm_rec_chain<true>, lstm_bptt_chain<false>
+    int occ_c = 0, occ_d = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_c, lstm_rec_chain<true>, kRecThreads, 0) != hipSuccess) occ_c = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_d, lstm_bptt_chain<false>, kRecThreads, 0) != hipSuccess) occ_d = 0;
     // (the query's known over-report concerns kernels near an SGPR allocation step at several blocks per CU: take one
     // block per CU off from four up; these kernels use < 80 SGPRs and need two blocks per CU at most)
     auto room = [cus](int occ) { return (int64_t)cus * (occ >= 4 ? occ - 1 : occ); };
-    const int64_t room_f = room(occ_f), room_b = room(occ_b);
-    const int rsplit_env = getenv("RELA_BPTT_ROW_SPLIT") ? std::max(1, std::min(8, atoi(getenv("RELA_BPTT_ROW_SPLIT")))) : kBpttRowSplit;
-    if (room(occ_c) < 8 * kChainBlocks || room(occ_d) < 8 * kBpttBlocks) l->rec_chains_fit = false;
-    if (room_f < 2 * kRecBlocks || room_b < (int64_t)kBpttBlocks * rsplit_env) {
+    if (room(occ_c) < 8 * kChainBlocks || room(occ_d) < 8 * kBpttBlocks) {
       fprintf(stderr, "rela_r2d2_learner_create: %d CUs x (%d, %d) resident blocks cannot hold the persistent recurrent "
-                      "grids (%d, %d): using the per-step launches\n", cus, occ_f, occ_b, 2 * kRecBlocks, kBpttBlocks * rsplit_env);
-      l->rec_persist = false;
+                      "grids (%d, %d): using the per-step launches\n", cus, occ_c, occ_d, 8 * kChainBlocks, 8 * kBpttBlocks);
+      l->rec_chains_fit = false;
     }
   }
   R2_ALLOC(l->ha, rowsTr * 32, false);
@@ -1484,25 +1161,14 @@ extern "C" int rela_r2d2_learner_grad(rela_r2d2_learner* l, void* stream_) {
   RELA_HIP(hipMemsetAsync(l->dc_rec, 0, blk * sizeof(float), s));
   const int cell_grid = ceil_div((int64_t)Bn * kHid, 256);
   float* ga_tr = l->gx + tr0 * kGates;
-  if (l->rec_persist) {
-    const int Tpad = (T + 3) / 4 * 4;
-    RELA_HIP(hipMemsetAsync(l->rec_bar + 4, 0, sizeof(unsigned) * (size_t)Tpad, s));
+  if (l->rec_persist && l->rec_chains_fit && Bn <= 128 && Tt <= l->T) {
+    const int Tpad_c = (l->T + 3) / 4 * 4;
+    RELA_HIP(hipMemsetAsync(l->rec_chain_bar, 0, sizeof(unsigned) * (size_t)(8 * Tpad_c), s));
     BpttArgs ba{};
     ba.ga = ga_tr, ba.d_o = l->d_o, ba.whh = P.w_hh, ba.C = Cc, ba.dc_rec = l->dc_rec;
-    ba.bar = l->rec_bar + 4, ba.tmo = l->rec_bar, ba.Tt = Tt, ba.Bn = Bn, ba.burn = burn;
+    ba.bar = l->rec_chain_bar, ba.tmo = l->rec_bar, ba.Tt = Tt, ba.Bn = Bn, ba.burn = burn;
     ProfScope prof("learner_lstm_bptt_persist", s);
-    static const bool chains = !(getenv("RELA_R2D2_REC_CHAINS") && atoi(getenv("RELA_R2D2_REC_CHAINS")) == 0);
-    // (a batch of fewer row tiles than the split leaves the surplus copies idle at the barrier: they still arrive)
-    static const int rsplit = getenv("RELA_BPTT_ROW_SPLIT") ? std::max(1, std::min(8, atoi(getenv("RELA_BPTT_ROW_SPLIT")))) : kBpttRowSplit;
-    if (chains && l->rec_chains_fit && Bn <= 128 && Tt <= l->T && !sc1_handoff()) {
-      const int Tpad_c = (l->T + 3) / 4 * 4;
-      RELA_HIP(hipMemsetAsync(l->rec_chain_bar, 0, sizeof(unsigned) * (size_t)(8 * Tpad_c), s));
-      ba.bar = l->rec_chain_bar;
-      static const bool bptt_sc1 = getenv("RELA_R2D2_BPTT_SC1") && atoi(getenv("RELA_R2D2_BPTT_SC1")) != 0;
-      if (bptt_sc1) hipLaunchKernelGGL(lstm_bptt_chain<true>, dim3(8 * kBpttBlocks), dim3(kRecThreads), 0, s, ba, Tpad_c);
-      else hipLaunchKernelGGL(lstm_bptt_chain<false>, dim3(8 * kBpttBlocks), dim3(kRecThreads), 0, s, ba, Tpad_c);
-    } else if (sc1_handoff()) hipLaunchKernelGGL(lstm_bptt_persist<true>, dim3(kBpttBlocks * rsplit), dim3(kRecThreads), 0, s, ba);
-    else hipLaunchKernelGGL(lstm_bptt_persist<false>, dim3(kBpttBlocks * rsplit), dim3(kRecThreads), 0, s, ba);
+    hipLaunchKernelGGL(lstm_bptt_chain<false>, dim3(8 * kBpttBlocks), dim3(kRecThreads), 0, s, ba, Tpad_c);
   } else
   for (int t = Tt - 1; t >= 0; --t) {
     const int gs = burn + t;  // global step

@@ -236,26 +236,10 @@ inline int launch(const uint8_t* obs, const float* d_a1, int frames, float* part
   static const hipError_t attr_set =
       hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_conv1_bf16), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
   RELA_HIP(attr_set);
-  static const int env_cap = getenv("RELA_W1_BLOCKS") ? std::max(1, std::min(kMaxBlocks, atoi(getenv("RELA_W1_BLOCKS")))) : 0;
-  const int cap = env_cap ? env_cap : std::max(1, std::min(kMaxBlocks, max_blocks));
+  const int cap = std::max(1, std::min(kMaxBlocks, max_blocks));
   const int blocks = frames < cap ? frames : cap;
   note_launch("wgrad_conv1_bf16");
-  static const bool want_stamps = getenv("RELA_W1_STAMPS") && atoi(getenv("RELA_W1_STAMPS")) != 0;
-  static unsigned long long* sbuf = nullptr;
-  if (want_stamps && !sbuf) {
-    RELA_HIP(hipMalloc(&sbuf, 16 * sizeof(unsigned long long)));
-  }
-  if (want_stamps) RELA_HIP(hipMemsetAsync(sbuf, 0, 16 * sizeof(unsigned long long), s));
-  hipLaunchKernelGGL(wgrad_conv1_bf16, dim3(blocks), dim3(kT), LDS_TOTAL, s, obs, d_a1, frames, part,
-                     want_stamps ? sbuf : nullptr);
-  if (want_stamps) {
-    unsigned long long h[16];
-    RELA_HIP(hipStreamSynchronize(s));
-    RELA_HIP(hipMemcpy(h, sbuf, sizeof(h), hipMemcpyDeviceToHost));
-    fprintf(stderr, "wgrad_conv1_bf16 stamps (cycles since start):");
-    for (int i = 1; i < 16 && h[i]; ++i) fprintf(stderr, " %llu", h[i] - h[0]);
-    fprintf(stderr, "\n");
-  }
+  hipLaunchKernelGGL(wgrad_conv1_bf16, dim3(blocks), dim3(kT), LDS_TOTAL, s, obs, d_a1, frames, part, nullptr);
   *blocks_out = blocks;
   return RELA_OK;
 }

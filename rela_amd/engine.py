@@ -51,14 +51,6 @@ class FFNetHandle:
         Q within 1e-6 of the f32 path; include/rela_amd.h rela_ffnet_set_precision)."""
         capi.check(capi.lib.rela_ffnet_set_precision(self.h, {"f32": 0, "bf16x2": 1}[mode]), "rela_ffnet_set_precision")
 
-    def pipe_timeout(self):
-        """Synchronises; 0 unless a wave of the pipelined conv1 -> conv2 kernel ever gave up on a hand-off."""
-        import ctypes as C
-
-        out = C.c_uint(0)
-        capi.check(capi.lib.rela_ffnet_debug_pipe_timeout(self.h, C.byref(out)), "rela_ffnet_debug_pipe_timeout")
-        return out.value
-
     def close(self):
         if getattr(self, "h", None):
             capi.lib.rela_ffnet_destroy(self.h)

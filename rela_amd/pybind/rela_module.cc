@@ -1591,7 +1591,7 @@ class Context {
  private:
   // Training DQNActors (R2D2Actors) of this context that share (locker, replay, K, n, gamma[, seq_len,
   // burn_in]) are batched into one device shard (ActorCohort); a lone actor keeps its private shard.
-  // RELA_NO_COHORT=1 opts out.
+  // RELA_COHORT_SPLIT=0 opts out.
   template <class ActorT, class Same, class Make>
   void formCohortsOf(Same same, Make make) {
     std::vector<std::vector<std::shared_ptr<ActorT>>> buckets;
@@ -1646,8 +1646,8 @@ class Context {
   void formCohorts() {
     planPartitionsOf<DQNActor>();
     planPartitionsOf<R2D2Actor>();
-    if (const char* off = std::getenv("RELA_NO_COHORT"))
-      if (off[0] == '1') return;
+    if (const char* e = std::getenv("RELA_COHORT_SPLIT"))
+      if (std::atoi(e) <= 0) return;  // RELA_COHORT_SPLIT=0: no cohorts, one private shard per actor thread
     formCohortsOf<DQNActor>(
         [](const DQNActor& f, const DQNActor& a) {
           return f.lockerKey() == a.lockerKey() && f.replayKey() == a.replayKey() && f.batchsize() == a.batchsize() &&

@@ -63,7 +63,6 @@ def expected_records(frames, w, b):
     return np.concatenate([hb, lb], axis=2), y, (sc, q, bq)
 
 
-@pytest.mark.skipif(os.environ.get("RELA_CONV12") == "bf16", reason="RELA_CONV12=bf16 selects the bf16 kernel")
 @pytest.mark.parametrize("N,seed,gain", [(3, 1, 1.0), (257, 2, 1.0), (300, 3, 2.6)])
 def test_conv1_records_bit_exact(N, seed, gain):
     import torch

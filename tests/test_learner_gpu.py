@@ -88,7 +88,7 @@ MERGED_MIN_B, MERGED_MAX_B = 128, 1023  # batches the merged split-bf16 forward 
 
 def _assert_fast_learner_kernels(counts, B):
     """The kernels a bf16x2 learner step of B rows must launch (csrc/learner.hip, ffnet.hip, learner_common.h): from
-    128 rows the three forwards of td_err as ONE split-bf16 launch per layer (conv12_bf16s_jobs, conv3_bf16s_jobs,
+    128 rows the three forwards of td_err as ONE split-bf16 launch per layer (conv12_i8_jobs, conv3_bf16s_jobs,
     fc_bf16s split-K) and no f32 trunk kernel at all; at every size conv1's weight gradient and the conv2 / conv3 data
     gradients on bf16 MFMA -- so a silent fall-back to the f32 kernels cannot pass for a test of the fast ones."""
     want = {"wgrad_conv1_bf16", "dgrad_conv2_bf16", "dgrad_conv3_bf16"}
@@ -424,7 +424,7 @@ def test_learner_step_matches_the_reference_golden(path, precision):
     if precision == "bf16x2":
         _assert_fast_learner_kernels(census.counts, B)
     else:
-        assert not ({"wgrad_conv1_bf16", "dgrad_conv2_bf16", "conv12_bf16s", "conv12_i8"} & set(census.counts)), census.counts
+        assert not ({"wgrad_conv1_bf16", "dgrad_conv2_bf16", "conv12_i8"} & set(census.counts)), census.counts
     np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(prio.cpu().numpy(), np.array(g["priority"]), rtol=1e-4, atol=1e-4)
 

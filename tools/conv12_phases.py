@@ -23,7 +23,7 @@ s = torch.randint(0, 256, (N, 4, 84, 84), dtype=torch.uint8, device="cuda")
 out = np.zeros((2, 8, 12), np.uint64)
 for _ in range(3):
     capi.check(capi.lib.rela_ffnet_debug_conv12_stamps(net.h, N, C.c_void_p(s.data_ptr()), out.ctypes.data_as(C.c_void_p), None), "stamps")
-I8 = os.environ.get("RELA_CONV12") != "bf16"
+I8 = True  # (the bf16 half-frame kernel was removed in r4)
 names8 = ["conv1 (3 passes: MFMAs, epilogues, previous tile's copy-out)", "barrier", "conv2 MFMA loop (+ loads, staging stores)", "conv2 epilogue", "barrier"]
 names = ["conv1 half 0 (MFMA + epilogue)", "barrier", "convert half 1 + issue loads", "barrier", "conv1 half 1", "barrier",
          "conv2 MFMA loop (+ a1 copy-out in job form)", "convert next half 0 + issue loads", "conv2 epilogue", "barrier", "copy-out issue"]
