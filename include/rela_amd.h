@@ -575,6 +575,46 @@ int rela_prof_summary_json(char* out, int64_t cap);
 int rela_prof_count_enable(int on);
 int rela_prof_counts_json(char* out, int64_t cap);
 
+/* ===================================================================================
+ * Native partition exchange over HIP IPC (the reference has no counterpart: its one replay lives in host
+ * RAM, rela/prioritized_replay.h:156,339, and batches cross to the learner's GPU inside makeBatch, types.cc:34-43).
+ *
+ * With one replay partition per actor GPU and the learner in another process, the learner maps the partition -- its
+ * field arrays, the ids / raw weights of its last sample and its device state -- through IPC handles and gathers the
+ * B / G sampled rows ITSELF: a kernel on the learner's GPU reads the owner's HBM directly (peer reads over xGMI
+ * between GPUs), writing straight into the learner's batch tensors.  No packing on the owner, no collective, no
+ * staging copy.  Protocol per learner step (the ordering signals -- a few bytes -- stay with the caller, e.g.
+ * torch.distributed; rela_amd/parallel.py):
+ *   owner:    rela_replay_sample(part, B / G, NULL, weight_scratch, stream); synchronize; signal the learner
+ *   learner:  rela_replay_remote_gather(remote, B / G, rows, raw_w, sum_f, stream); ... loss ...; synchronize; signal
+ *   owner:    rela_replay_update_priority(part, ...)
+ * The owner must not sample / update between its signal and the learner's.
+ * =================================================================================== */
+#define RELA_IPC_MAX_FIELDS 16
+typedef struct rela_replay_ipc_desc { /* plain bytes: send it to the importing process by any means */
+  int32_t abi, nfields, ring, device, max_batch, pad;
+  int64_t row_bytes[RELA_IPC_MAX_FIELDS];
+  int32_t steps[RELA_IPC_MAX_FIELDS];
+  unsigned char field_handle[RELA_IPC_MAX_FIELDS][64]; /* hipIpcMemHandle_t of every field array */
+  unsigned char ids_handle[64], raw_w_handle[64], state_handle[64];
+} rela_replay_ipc_desc;
+typedef struct rela_replay_remote rela_replay_remote;
+int rela_replay_export_ipc(rela_replay* r, rela_replay_ipc_desc* out);
+int rela_replay_import_ipc(rela_replay_remote** out, const rela_replay_ipc_desc* desc, int device);
+void rela_replay_remote_close(rela_replay_remote* rr);
+/* rows of the partition's LAST sample into out_rows_dev[f] (on this process's device, NULL = skip the field; sequence
+ * fields come out time-major as from rela_replay_sample), its un-normalised weights into raw_w_out[batch] and the float
+ * sum they were drawn against into sum_f_out[1] (either may be NULL).  The output tensors hold out_batch rows per (time)
+ * step and this partition fills rows [out_offset, out_offset + batch): its share of a batch drawn over several
+ * partitions (out_batch = 0: the outputs hold exactly this batch). */
+int rela_replay_remote_gather(rela_replay_remote* rr, int batch, void* const* out_rows_dev, float* raw_w_out,
+                              float* sum_f_out, int out_batch, int out_offset, void* stream);
+/* the same mapping for a device buffer this library allocated (e.g. rela_apex_learner_flat's parameter buffer): the
+ * weight publish across processes -- actors load their nets straight from the learner's mapped buffer */
+int rela_ipc_export_buffer(const void* dev_ptr, unsigned char handle_out[64]);
+int rela_ipc_import_buffer(const unsigned char handle[64], void** dev_ptr_out, int device);
+int rela_ipc_close_buffer(void* dev_ptr, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,13 @@ _sig("rela_stream_destroy", None, [vp, i32])
 _sig("rela_stream_synchronize", i32, [vp, i32])
 _sig("rela_stream_wait_stream", i32, [vp, vp, i32])
 _sig("rela_memcpy_h2d_async", i32, [vp, vp, i64, vp, i32])
+_sig("rela_replay_export_ipc", i32, [vp, vp])
+_sig("rela_replay_import_ipc", i32, [P(vp), vp, i32])
+_sig("rela_replay_remote_close", None, [vp])
+_sig("rela_replay_remote_gather", i32, [vp, i32, vp, vp, vp, i32, i32, vp])
+_sig("rela_ipc_export_buffer", i32, [vp, vp])
+_sig("rela_ipc_import_buffer", i32, [vp, P(vp), i32])
+_sig("rela_ipc_close_buffer", i32, [vp, i32])
 _sig("rela_replay_create", i32, [P(vp), i32, i32, f32, f32, i32, i32])
 _sig("rela_replay_destroy", None, [vp])
 _sig("rela_replay_set_schema", i32, [vp, i32, P(i64)])

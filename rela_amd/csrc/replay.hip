@@ -399,6 +399,9 @@ struct BigFields {
   int64_t slot_bytes[kMaxBigFields];
   int32_t steps[kMaxBigFields];
   int32_t vec16[kMaxBigFields];
+  // the batch may be a SLICE of a larger output: rows [out_off, out_off + batch) of tensors with out_batch rows per
+  // (time) step -- one partition's share of a batch drawn over several (0 = the output holds exactly this batch)
+  int32_t out_batch, out_off;
 };
 __global__ __launch_bounds__(kThreads) void replay_gather_big(BigFields t, const int32_t* __restrict__ ids, int batch) {
   const int f = blockIdx.z;
@@ -408,7 +411,8 @@ __global__ __launch_bounds__(kThreads) void replay_gather_big(BigFields t, const
   for (int y = blockIdx.y; y < batch * steps; y += gridDim.y) {
     const int b = y % batch, ts = y / batch;
     const uint8_t* s = t.field[f] + (int64_t)ids[b] * t.slot_bytes[f] + (int64_t)ts * row_bytes;
-    uint8_t* d = t.out[f] + ((int64_t)ts * batch + b) * row_bytes;
+    const int ob = t.out_batch > 0 ? t.out_batch : batch;
+    uint8_t* d = t.out[f] + ((int64_t)ts * ob + t.out_off + b) * row_bytes;
     if (t.vec16[f]) {
       const int64_t nv = row_bytes >> 4;
       const uint4* s4 = reinterpret_cast<const uint4*>(s);
@@ -483,6 +487,29 @@ __global__ __launch_bounds__(1024) void replay_update(const float* __restrict__ 
       for (int e = 0; e < cnt; ++e) diff += (double)rl_f(mine, e);
     }
     if (lane == 0) st->sum += diff;
+  }
+}
+
+// ---- remote partitions (rela_replay_remote_gather): the small fields, raw weights and float sum of a sample whose
+// ids, field arrays and state live in ANOTHER process's memory (IPC mappings: peer reads over xGMI between GPUs)
+__global__ __launch_bounds__(256) void replay_gather_small_remote(SmallFields t, const int32_t* __restrict__ ids, int batch,
+                                                                   const float* __restrict__ raw_w,
+                                                                   const ReplayDevState* __restrict__ st,
+                                                                   float* __restrict__ raw_w_out, float* __restrict__ sum_out,
+                                                                   int out_off) {
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < batch; i += blockDim.x)
+      if (raw_w_out) raw_w_out[i] = raw_w[i];
+    if (threadIdx.x == 0 && sum_out) sum_out[0] = st->sum_f;
+    return;
+  }
+  const int f = blockIdx.x - 1;
+  const int rb = t.row_bytes[f];
+  const uint8_t* __restrict__ src = t.src[f];
+  uint8_t* __restrict__ dst = t.dst[f];
+  for (int idx = threadIdx.x; idx < batch * rb; idx += blockDim.x) {
+    const int row = idx / rb;
+    dst[(int64_t)out_off * rb + idx] = src[(int64_t)ids[row] * rb + (idx - row * rb)];
   }
 }
 
@@ -1295,5 +1322,173 @@ extern "C" int rela_debug_pow(const float* x_dev, int n, float exponent, float* 
     hipLaunchKernelGGL(debug_pow_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream_, x_dev, n, exponent,
                        out_dev);
   RELA_LAUNCH_CHECK();
+  return RELA_OK;
+}
+
+
+// =====================================================================================================================
+// Native partition exchange (rela_amd/parallel.py): the learner process maps a partition's field arrays, the
+// ids / raw weights of its last sample and its device state through HIP IPC handles and GATHERS the sampled rows
+// itself -- a kernel on the learner's GPU reading the owner's HBM directly (xGMI peer reads between GPUs, plain reads
+// when both processes share a GPU) -- instead of the owner packing the rows and a collective moving them (28.9 MB per
+// Ape-X step, 222 MB per R2D2 step).  Ordering between the two processes stays with the caller: the owner's sample
+// (rela_replay_sample with out_rows_dev = NULL: ids, raw weights, eviction; no gather) must have completed before the
+// gather starts, and the owner must not sample or update again before the gather completed.
+// =====================================================================================================================
+struct rela_replay_remote {
+  int device = 0;
+  int nfields = 0, ring = 0, max_batch = 0;
+  int64_t row_bytes[RELA_IPC_MAX_FIELDS] = {};
+  int32_t steps[RELA_IPC_MAX_FIELDS] = {};
+  uint8_t* fields[RELA_IPC_MAX_FIELDS] = {};
+  int32_t* ids = nullptr;
+  float* raw_w = nullptr;
+  ReplayDevState* state = nullptr;
+};
+
+extern "C" int rela_replay_export_ipc(rela_replay* r, rela_replay_ipc_desc* out) {
+  RELA_CHECK(r && out, RELA_EINVAL, "rela_replay_export_ipc: bad arguments");
+  RELA_CHECK(!r->d_fields.empty() && (int)r->d_fields.size() <= RELA_IPC_MAX_FIELDS, RELA_ESTATE,
+             "rela_replay_export_ipc: set the schema first (at most %d fields)", RELA_IPC_MAX_FIELDS);
+  RELA_CHECK(r->dd_ups == 0, RELA_EINVAL, "rela_replay_export_ipc: de-duplicated partitions are not exported");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+  DeviceGuard g(r->device);
+  std::lock_guard<std::mutex> lk(r->m);
+  memset(out, 0, sizeof(*out));
+  out->abi = 1;
+  out->nfields = (int32_t)r->d_fields.size();
+  out->ring = r->ring;
+  out->device = r->device;
+  out->max_batch = kMaxBatch;
+  for (size_t f = 0; f < r->d_fields.size(); ++f) {
+    out->row_bytes[f] = r->row_bytes[f];
+    out->steps[f] = r->steps[f];
+    RELA_HIP(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(out->field_handle[f]), r->d_fields[f]));
+  }
+  RELA_HIP(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(out->ids_handle), r->d_ids));
+  RELA_HIP(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(out->raw_w_handle), r->d_raw_w));
+  RELA_HIP(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(out->state_handle), r->d_state));
+  return RELA_OK;
+}
+
+extern "C" int rela_replay_import_ipc(rela_replay_remote** out, const rela_replay_ipc_desc* desc, int device) {
+  RELA_CHECK(out && desc && desc->abi == 1 && desc->nfields >= 1 && desc->nfields <= RELA_IPC_MAX_FIELDS, RELA_EINVAL,
+             "rela_replay_import_ipc: bad descriptor");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+    set_last_error("rela_replay_import_ipc: HIP device %d not available (%d visible); there is no CPU path", device, ndev);
+    return RELA_ENODEV;
+  }
+  DeviceGuard g(device);
+  auto* rr = new rela_replay_remote();
+  rr->device = device;
+  rr->nfields = desc->nfields, rr->ring = desc->ring, rr->max_batch = desc->max_batch;
+  auto open = [&](const unsigned char* h, void** p) {
+    hipIpcMemHandle_t mh;
+    memcpy(&mh, h, sizeof(mh));
+    return hipIpcOpenMemHandle(p, mh, hipIpcMemLazyEnablePeerAccess);
+  };
+  hipError_t e = hipSuccess;
+  for (int f = 0; f < desc->nfields && e == hipSuccess; ++f) {
+    rr->row_bytes[f] = desc->row_bytes[f];
+    rr->steps[f] = desc->steps[f];
+    e = open(desc->field_handle[f], reinterpret_cast<void**>(&rr->fields[f]));
+  }
+  if (e == hipSuccess) e = open(desc->ids_handle, reinterpret_cast<void**>(&rr->ids));
+  if (e == hipSuccess) e = open(desc->raw_w_handle, reinterpret_cast<void**>(&rr->raw_w));
+  if (e == hipSuccess) e = open(desc->state_handle, reinterpret_cast<void**>(&rr->state));
+  if (e != hipSuccess) {
+    set_last_error("rela_replay_import_ipc: hipIpcOpenMemHandle failed: %s", hipGetErrorString(e));
+    rela_replay_remote_close(rr);
+    return RELA_ENODEV;
+  }
+  *out = rr;
+  return RELA_OK;
+}
+
+extern "C" void rela_replay_remote_close(rela_replay_remote* rr) {
+  if (!rr) return;
+  DeviceGuard g(rr->device);
+  (void)hipDeviceSynchronize();
+  for (int f = 0; f < rr->nfields; ++f)
+    if (rr->fields[f]) (void)hipIpcCloseMemHandle(rr->fields[f]);
+  if (rr->ids) (void)hipIpcCloseMemHandle(rr->ids);
+  if (rr->raw_w) (void)hipIpcCloseMemHandle(rr->raw_w);
+  if (rr->state) (void)hipIpcCloseMemHandle(rr->state);
+  delete rr;
+}
+
+extern "C" int rela_replay_remote_gather(rela_replay_remote* rr, int batch, void* const* out_rows_dev, float* raw_w_out,
+                                         float* sum_f_out, int out_batch, int out_offset, void* stream_) {
+  RELA_CHECK(rr && batch > 0 && batch <= rr->max_batch && out_rows_dev, RELA_EINVAL, "rela_replay_remote_gather: bad arguments");
+  if (out_batch <= 0) out_batch = batch, out_offset = 0;
+  RELA_CHECK(out_offset >= 0 && out_offset + batch <= out_batch, RELA_EINVAL,
+             "rela_replay_remote_gather: rows [%d, %d) do not fit an output of %d", out_offset, out_offset + batch, out_batch);
+  hipStream_t s = (hipStream_t)stream_;
+  DeviceGuard g(rr->device);
+  SmallFields small{};
+  BigFields big{};
+  int nbig = 0, max_y = 1;
+  int64_t max_units = 1;
+  for (int f = 0; f < rr->nfields; ++f) {
+    if (!out_rows_dev[f]) continue;
+    const int64_t rb = rr->row_bytes[f];
+    const int st = rr->steps[f];
+    if (st == 1 && rb <= kSmallRowBytes && small.n < kMaxSmallFields) {
+      small.src[small.n] = rr->fields[f];
+      small.dst[small.n] = (uint8_t*)out_rows_dev[f];
+      small.row_bytes[small.n] = (int32_t)rb;
+      small.n += 1;
+      continue;
+    }
+    RELA_CHECK(nbig < kMaxBigFields, RELA_EINVAL, "rela_replay_remote_gather: more than %d large fields", kMaxBigFields);
+    const int64_t sub = rb / st;
+    const int v16 = vec16_ok(out_rows_dev[f], rr->fields[f], sub) && (rb % 16 == 0);
+    big.out_batch = out_batch, big.out_off = out_offset;
+    big.field[nbig] = rr->fields[f];
+    big.out[nbig] = (uint8_t*)out_rows_dev[f];
+    big.slot_bytes[nbig] = rb;
+    big.steps[nbig] = st;
+    big.vec16[nbig] = v16;
+    max_units = std::max<int64_t>(max_units, v16 ? (sub >> 4) : sub);
+    max_y = std::max(max_y, batch * st);
+    nbig += 1;
+  }
+  {
+    ProfScope prof("replay_gather_remote", s);
+    hipLaunchKernelGGL(replay_gather_small_remote, dim3(1 + small.n), dim3(256), 0, s, small, (const int32_t*)rr->ids, batch,
+                       (const float*)rr->raw_w, (const ReplayDevState*)rr->state, raw_w_out, sum_f_out, out_offset);
+    if (nbig > 0) {
+      const int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (max_units + kThreads - 1) / kThreads), 64);
+      hipLaunchKernelGGL(replay_gather_big, dim3(gx, std::min(max_y, 32768), nbig), dim3(kThreads), 0, s, big,
+                         (const int32_t*)rr->ids, batch);
+    }
+  }
+  RELA_LAUNCH_CHECK();
+  return RELA_OK;
+}
+
+
+// Generic form for buffers this library allocated (the learners' flat parameter buffers): the weight publish of
+// rela_amd/parallel.py maps the learner's buffer into every actor process, which then loads its nets straight from it
+// (rela_ffnet_load / rela_lstmnet_load with on_device = 1: a peer read over xGMI) instead of receiving a broadcast.
+extern "C" int rela_ipc_export_buffer(const void* dev_ptr, unsigned char handle_out[64]) {
+  RELA_CHECK(dev_ptr && handle_out, RELA_EINVAL, "rela_ipc_export_buffer: bad arguments");
+  RELA_HIP(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(handle_out), const_cast<void*>(dev_ptr)));
+  return RELA_OK;
+}
+extern "C" int rela_ipc_import_buffer(const unsigned char handle[64], void** dev_ptr_out, int device) {
+  RELA_CHECK(handle && dev_ptr_out, RELA_EINVAL, "rela_ipc_import_buffer: bad arguments");
+  DeviceGuard g(device);
+  RELA_CHECK(g.ok, RELA_ENODEV, "rela_ipc_import_buffer: HIP device %d not available; there is no CPU path", device);
+  hipIpcMemHandle_t mh;
+  memcpy(&mh, handle, sizeof(mh));
+  RELA_HIP(hipIpcOpenMemHandle(dev_ptr_out, mh, hipIpcMemLazyEnablePeerAccess));
+  return RELA_OK;
+}
+extern "C" int rela_ipc_close_buffer(void* dev_ptr, int device) {
+  if (!dev_ptr) return RELA_OK;
+  DeviceGuard g(device);
+  RELA_HIP(hipIpcCloseMemHandle(dev_ptr));
   return RELA_OK;
 }

@@ -29,6 +29,15 @@ exchange is backend-agnostic: a partition is any object with
 
 so the CPU tests drive it over gloo with partitions built on the oracle (tests/test_dist_cpu.py) and the
 GPU paths with rela_amd.replay.FFReplay / the `rela` module's replays (FFPartition below).
+
+r4, NATIVE data plane (NativePartitionedReplay / NativePartitionServer, partitions = rela_amd.replay.FFReplay /
+RNNReplay): the sampled ROWS no longer travel through a collective.  Every partition is exported once through HIP IPC
+(include/rela_amd.h: rela_replay_export_ipc) and mapped into the learner process; per step the owner only SAMPLES
+(ids, raw weights, eviction -- no gather), the learner's own gather kernel reads the B / G rows of every partition out
+of the owner's HBM (peer reads over xGMI between GPUs) straight into its batch tensors, and the weight publish maps
+the learner's flat parameter buffers into the actor processes, which load their nets from them directly.  What is left
+on torch.distributed: rendezvous, the command words, the B / G importance weights (the gather of 4 B / G bytes per rank
+doubles as "my sample has completed") and the B / G priorities back (doubles as "the learner has read your rows").
 """
 import torch
 import torch.distributed as dist
@@ -314,3 +323,139 @@ def ff_batch_namespace(fields):
         obs={"s": fields["s"], "eps": fields["eps"], "legal_move": fields["legal_move"]}, action={"a": fields["a"]},
         reward=fields["reward"], terminal=fields["terminal"].bool(), bootstrap=fields["bootstrap"],
         next_obs={"s": fields["next_s"], "eps": fields["next_eps"], "legal_move": fields["next_legal_move"]})
+
+
+# ---- r4: native data plane over HIP IPC ---------------------------------------------------------------------------
+def _export_desc(replay_handle):
+    import ctypes as C
+
+    from . import _capi as capi
+
+    buf = (C.c_ubyte * 4096)()
+    capi.check(capi.lib.rela_replay_export_ipc(replay_handle, buf), "rela_replay_export_ipc")
+    return bytes(buf)
+
+
+class NativePartitionedReplay(PartitionedReplay):
+    """Learner side of the native exchange: as PartitionedReplay, but a sample gathers the rows itself out of the
+    partitions' memory (rela_replay_remote_gather); only the importance weights arrive through the collective."""
+
+    def __init__(self, specs, batch, beta, device, learner_rank=0, group=None, scheduled=False, flats=()):
+        import ctypes as C
+
+        from . import _capi as capi
+
+        super().__init__(specs, batch, beta, device, learner_rank, group, scheduled)
+        self._C, self._capi = C, capi
+        # rendezvous of the descriptors: every actor rank contributes its partition's, the learner its flat buffers'
+        mine = {"flats": []}
+        for f in flats:  # device buffers of the learner (rela_*_learner_flat): mapped by the actor ranks for publish
+            h = (C.c_ubyte * 64)()
+            capi.check(capi.lib.rela_ipc_export_buffer(C.c_void_p(f.data_ptr()), h), "rela_ipc_export_buffer")
+            mine["flats"].append((bytes(h), f.numel()))
+        descs = [None] * self.world
+        dist.all_gather_object(descs, mine, group=group)
+        self._remote = []
+        dev_index = self.device.index or 0
+        for r in self.actor_ranks:
+            buf = (C.c_ubyte * 4096).from_buffer_copy(descs[r]["partition"])
+            rr = C.c_void_p()
+            capi.check(capi.lib.rela_replay_import_ipc(C.byref(rr), buf, dev_index), "rela_replay_import_ipc")
+            self._remote.append(rr)
+        # the packed record of a rank shrinks to its importance weights
+        self._layout, self._w_off = [], 0
+        self.rank_bytes = _pad16(4 * self.b_local)
+        self._recv = [torch.empty(self.world * self.rank_bytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.native = True
+
+    def _unpack(self, slot):
+        C, capi = self._C, self._capi
+        out = self._out[slot]
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        rows = (C.c_void_p * len(self.specs))(*[out[sp.name].data_ptr() for sp in self.specs])
+        for g, rr in enumerate(self._remote):  # peer reads of B / G rows per partition, straight into the batch
+            capi.check(capi.lib.rela_replay_remote_gather(rr, self.b_local, rows, None, None, self.batch, g * self.b_local,
+                                                          stream), "rela_replay_remote_gather")
+        w = self._recv[slot].view(self.world, self.rank_bytes)
+        w = w[self.actor_ranks[0]:self.actor_ranks[0] + self.G] if self._contig else w[self.actor_ranks]
+        self._w[slot].view(self.G, self.b_local).copy_(w[:, :4 * self.b_local].view(torch.float32))
+        return out, self._w[slot]
+
+    def publish(self, *flats, steps=0):
+        """the actor ranks read the exported flat buffers themselves: the command word is all that travels"""
+        assert not self.scheduled or self._left == 0, "scheduled mode: %d announced steps are still to run" % self._left
+        torch.cuda.synchronize(self.device)  # the buffers hold the weights to publish before the actors are told
+        self._bcast_cmd(CMD_PUBLISH, len(flats) + 1000 * int(steps))
+        self._left = int(steps)
+        # (the actors signal completion of their reads with the first collective of the cycle; a learner that
+        # overwrites its parameters before that -- its next apply() -- waits for the barrier below)
+        dist.barrier(group=self.group)
+
+    def close(self):
+        for rr in self._remote:
+            self._capi.lib.rela_replay_remote_close(rr)
+        self._remote = []
+
+
+class NativePartitionServer(PartitionServer):
+    """Actor-rank side of the native exchange: `replay` is a rela_amd.replay.FFReplay / RNNReplay."""
+
+    def __init__(self, replay, specs, batch, beta, device, flat_sizes=(), on_weights=None, learner_rank=0, group=None,
+                 scheduled=False):
+        import ctypes as C
+
+        from . import _capi as capi
+        from .engine import dev_view
+
+        super().__init__(None, specs, batch, beta, device, flat_sizes=(), on_weights=on_weights, learner_rank=learner_rank,
+                         group=group, scheduled=scheduled)
+        self._C, self._capi, self._dev_view = C, capi, dev_view
+        self.replay = replay
+        descs = [None] * self.world
+        dist.all_gather_object(descs, {"partition": _export_desc(replay.h)}, group=group)
+        dev_index = self.device.index or 0
+        self._flat_ptrs, self._flats = [], []
+        for h, n in descs[learner_rank]["flats"]:  # map the learner's flat parameter buffers
+            p = C.c_void_p()
+            capi.check(capi.lib.rela_ipc_import_buffer((C.c_ubyte * 64).from_buffer_copy(h), C.byref(p), dev_index),
+                       "rela_ipc_import_buffer")
+            self._flat_ptrs.append(p)
+            self._flats.append(dev_view(p.value, (n,), torch.float32, self.device))
+        self._layout, self._w_off = [], 0
+        self.rank_bytes = _pad16(4 * self.b_local)
+        self._send = torch.zeros(self.rank_bytes, dtype=torch.uint8, device=self.device)
+        self._w_scratch = torch.empty(self.b_local, dtype=torch.float32, device=self.device)
+
+    def _sample_step(self):
+        C, capi = self._C, self._capi
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # ids, raw weights and eviction only: the rows stay where they are, the learner reads them
+        capi.check(capi.lib.rela_replay_sample(self.replay.h, self.b_local, None, C.c_void_p(self._w_scratch.data_ptr()),
+                                               stream), "rela_replay_sample")
+        raw_p, sum_p = C.c_void_p(), C.c_void_p()
+        capi.check(capi.lib.rela_replay_last_sample_dev(self.replay.h, C.byref(raw_p), C.byref(sum_p)), "last_sample")
+        raw_w = self._dev_view(raw_p.value, (self.b_local,), torch.float32, self.device)
+        part_sum = self._dev_view(sum_p.value, (1,), torch.float32, self.device)
+        size = capi.lib.rela_replay_last_sample_size(self.replay.h)
+        weight = global_is_weights(raw_w, part_sum, size, self.beta, group=self.actor_group)
+        self._send[:4 * self.b_local].view(torch.float32).copy_(weight.float())
+        torch.cuda.current_stream(self.device).synchronize()  # the sample has COMPLETED before the learner hears of it
+        dist.gather(self._send, None, dst=self.learner_rank, group=self.group)
+        self.served += 1
+
+    def _update_step(self):
+        dist.scatter(self._prio_recv, None, src=self.learner_rank, group=self.group)  # = "your rows were read"
+        self.replay.update_priority(self._prio_recv)
+
+    def _publish_step(self, arg):
+        assert arg % 1000 == len(self._flats), "publish of %d buffers, %d expected" % (arg % 1000, len(self._flats))
+        if self.on_weights is not None:
+            self.on_weights(*self._flats)  # loads the nets straight from the learner's mapped buffers
+            torch.cuda.synchronize(self.device)
+        dist.barrier(group=self.group)
+        return arg // 1000
+
+    def close(self):
+        for p in self._flat_ptrs:
+            self._capi.lib.rela_ipc_close_buffer(p, self.device.index or 0)
+        self._flat_ptrs = []

@@ -1,0 +1,104 @@
+"""Native partition exchange over HIP IPC (include/rela_amd.h: rela_replay_export_ipc / _import_ipc /
+_remote_gather): a partition OWNED BY ANOTHER PROCESS is mapped here and the rows of its last sample are
+gathered by a kernel of THIS process straight out of the owner's memory -- on a multi-GPU node those reads go over
+xGMI; with both processes on the one GPU of the test box the address arithmetic, the descriptor and the protocol are
+the same.  Two processes on cuda:0."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _payload_of(tags, width):
+    col = np.arange(width, dtype=np.int64)[None, :]
+    return ((np.asarray(tags, np.int64)[:, None] * 31 + col) % 251).astype(np.uint8)
+
+
+def test_remote_gather_reads_the_owners_partition():
+    import torch
+
+    from rela_amd import _capi as capi
+
+    B, SEQ = 64, 3
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    child = subprocess.Popen([sys.executable, os.path.join(HERE, "ipc_owner_child.py")], stdin=subprocess.PIPE,
+                             stdout=subprocess.PIPE, text=True, env=env)
+    try:
+        line = child.stdout.readline()
+        assert line.startswith("DESC "), line
+        desc = (C.c_ubyte * 4096).from_buffer_copy(bytes.fromhex(line[5:].strip()))
+        rr = C.c_void_p()
+        capi.check(capi.lib.rela_replay_import_ipc(C.byref(rr), desc, 0), "rela_replay_import_ipc")
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for round_ in range(3):
+            child.stdin.write("sample\n")
+            child.stdin.flush()
+            line = child.stdout.readline()
+            assert line.startswith("SAMPLED "), line
+            exp = json.loads(line[8:])
+            tags = torch.zeros(B, dtype=torch.int64, device="cuda")
+            pay = torch.zeros((B, 4096), dtype=torch.uint8, device="cuda")
+            seq = torch.zeros((SEQ, B, 1024), dtype=torch.uint8, device="cuda")  # time-major, as rela_replay_sample
+            raw = torch.zeros(B, device="cuda")
+            sm = torch.zeros(1, device="cuda")
+            rows = (C.c_void_p * 3)(tags.data_ptr(), pay.data_ptr(), seq.data_ptr())
+            capi.check(capi.lib.rela_replay_remote_gather(rr, B, rows, C.c_void_p(raw.data_ptr()),
+                                                          C.c_void_p(sm.data_ptr()), 0, 0, stream), "rela_replay_remote_gather")
+            torch.cuda.synchronize()
+            got_tags = tags.cpu().numpy()
+            assert got_tags.tolist() == exp["tags"], round_
+            assert np.array_equal(pay.cpu().numpy(), _payload_of(got_tags, 4096)), round_
+            want_seq = _payload_of(got_tags + 1000003, SEQ * 1024).reshape(B, SEQ, 1024).transpose(1, 0, 2)
+            assert np.array_equal(seq.cpu().numpy(), want_seq), round_
+            assert np.array_equal(raw.cpu().numpy(), np.float32(exp["raw_w"])), round_
+            assert float(sm.item()) == float(np.float32(exp["sum"])), round_
+            child.stdin.write("update\n")
+            child.stdin.flush()
+            assert child.stdout.readline().startswith("UPDATED")
+        capi.lib.rela_replay_remote_close(rr)
+        child.stdin.write("quit\n")
+        child.stdin.flush()
+        assert child.wait(timeout=60) == 0
+    finally:
+        if child.poll() is None:
+            child.kill()
+
+
+def test_native_exchange_three_processes():
+    """rela_amd.parallel's native data plane end to end with ONE learner process and TWO actor processes (all on
+    cuda:0, gloo for the few control bytes): partitions exported through HIP IPC, every sampled row gathered by the
+    learner's own kernel out of the owners' memory into the right slice of the batch (tags checked per partition, in
+    sync and asynchronous sampling), importance weights normalised over both partitions, priorities back, and the
+    weight publish read by the actors straight from the learner's mapped flat buffers."""
+    import socket
+
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(3):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "native_exchange_child.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    try:
+        for p in procs:
+            o, e = p.communicate(timeout=300)
+            outs.append((p.returncode, o, e))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0, "rank %d: %s\n%s" % (r, o[-1500:], e[-3000:])
+    assert "LEARNER OK" in outs[0][1] and "ACTOR 1 OK" in outs[1][1] and "ACTOR 2 OK" in outs[2][1]
