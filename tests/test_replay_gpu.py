@@ -247,7 +247,7 @@ def test_scan_running_off_the_ring_fails_loudly_like_the_reference():
     rc, _, _ = g.sample(512)  # queued; the scan fails on the device
     assert rc == 0
     torch.cuda.synchronize()
-    assert g.state()["dev_error"] == capi.ESCAN
+    assert g.state(512)["dev_error"] == capi.ESCAN  # (n = the outstanding batch: debug_state copies that many ids)
     assert g.update(np.ones(512, np.float32)) == capi.ESCAN
     msg = capi.lib.rela_last_error()
     assert b"ran off the end of the ring" in msg and b"nextIdx: %d/%d" % (int(1.25 * cap), int(1.25 * cap)) in msg, msg
