@@ -803,7 +803,8 @@ def bench_reference_layout(args, world, rank, device, rehearsal):
     from rela_amd import _capi as capi
     from rela_amd.engine import ApexActorEngine, FFNetHandle
     from rela_amd.learner import HipApexLearner, ffnet_flat_layout, load_net_from_flat
-    from rela_amd.parallel import FFPartition, PartitionedReplay, PartitionServer, ff_batch_namespace, ff_field_specs
+    from rela_amd.parallel import (FFPartition, NativePartitionedReplay, NativePartitionServer, PartitionedReplay,
+                                   PartitionServer, ff_batch_namespace, ff_field_specs)
     from rela_amd.pyrela.apex import ApexAgent
     from rela_amd.pyrela.net import AtariFFNet
     from rela_amd.replay import FFReplay
@@ -825,9 +826,14 @@ def bench_reference_layout(args, world, rank, device, rehearsal):
     if rank == 0:
         learner = HipApexLearner.from_agent(agent, BATCH, lr=6.25e-5, eps=1.5e-4, grad_clip=40.0)
         learner.set_precision(args.precision)
-        rep = PartitionedReplay(specs, BATCH, BETA, exch, scheduled=True)
         flat_on, flat_tg = learner.flat()[0], learner.flat_target()
-        on_exch = (lambda t: t) if exch == device else (lambda t: t.to(exch))
+        # native data plane (default; --exchange packed = r3's packed gather through the collective): partitions mapped
+        # through HIP IPC, rows gathered by the learner's own kernel over xGMI, weights read by the actors directly
+        if args.exchange == "native":
+            rep = NativePartitionedReplay(specs, BATCH, BETA, exch, scheduled=True, flats=(flat_on, flat_tg), data_device=device)
+        else:
+            rep = PartitionedReplay(specs, BATCH, BETA, exch, scheduled=True)
+        on_exch = (lambda t: t) if (exch == device or args.exchange == "native") else (lambda t: t.to(exch))
         times = []
 
         def run(n_steps, pending):
@@ -912,8 +918,12 @@ def bench_reference_layout(args, world, rank, device, rehearsal):
             try:
                 torch.cuda.set_device(device)
                 with torch.cuda.stream(server_stream):
-                    srv = PartitionServer(FFPartition(part), specs, BATCH, BETA, exch, flat_sizes=(total, total),
-                                          on_weights=on_weights, scheduled=True)
+                    if args.exchange == "native":
+                        srv = NativePartitionServer(part, specs, BATCH, BETA, exch, on_weights=on_weights, scheduled=True,
+                                                    data_device=device)
+                    else:
+                        srv = PartitionServer(FFPartition(part), specs, BATCH, BETA, exch, flat_sizes=(total, total),
+                                              on_weights=on_weights, scheduled=True)
                     srv.serve_forever()
             except BaseException as e:  # noqa: BLE001  (re-raised on the main thread)
                 failure.append(e)
@@ -961,6 +971,7 @@ def bench_reference_layout(args, world, rank, device, rehearsal):
                        "replay_capacity_total": args.replay_cap, "parallelism": "1 learner + %d actor shards / replay partitions" % G},
             "grad_steps_per_s": 1e3 / ms[med], "learner": "hip (csrc/learner.hip)",
             "comm": {"backend": dist.get_backend(), "rccl_ranks": world if dist.get_backend() == "nccl" else 0, "ranks": world,
+                     "exchange": args.exchange,
                      "collectives_per_step": "1 packed gather (B/G rows per partition), 1 priority scatter, all-reduce SUM "
                                              "(partition size) + MAX (IS-weight maximum) among the actor ranks; 2 broadcasts "
                                              "of 6.8 MB + 1 command word every %d steps" % cycle},
@@ -1003,6 +1014,10 @@ def main():
                     help="N > 1: replicated (default) = actors + replay partition + learner replica on every rank, gradient "
                          "all-reduce; reference = the reference's own layout, ONE learner rank + N - 1 actor-only ranks "
                          "with replay partitions (pyrela/main.py:131-166, BASELINE C3 / C4)")
+    ap.add_argument("--exchange", default="native", choices=["native", "packed"],
+                    help="--layout reference: how sampled rows and weights cross processes: native = partitions and flat "
+                         "buffers mapped through HIP IPC, the learner's own gather kernel reads the rows over xGMI "
+                         "(rela_amd/parallel.py, r4); packed = one packed gather / two broadcasts through the collective (r3)")
     ap.add_argument("--algo", default="apex", help="apex (BASELINE.json's metric, the default) | r2d2 (config C4's "
                                                    "sequence shape: seq 80 / burn-in 40 / n 3, 3200 envs, B = 64)")
     args = ap.parse_args()

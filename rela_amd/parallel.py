@@ -340,13 +340,19 @@ class NativePartitionedReplay(PartitionedReplay):
     """Learner side of the native exchange: as PartitionedReplay, but a sample gathers the rows itself out of the
     partitions' memory (rela_replay_remote_gather); only the importance weights arrive through the collective."""
 
-    def __init__(self, specs, batch, beta, device, learner_rank=0, group=None, scheduled=False, flats=()):
+    def __init__(self, specs, batch, beta, device, learner_rank=0, group=None, scheduled=False, flats=(), data_device=None):
+        """device: where the few control tensors of the collectives live (the GPU under RCCL, "cpu" under gloo);
+        data_device: the learner's GPU, where the batch tensors live and the gather kernels run (default: device)"""
         import ctypes as C
 
         from . import _capi as capi
 
         super().__init__(specs, batch, beta, device, learner_rank, group, scheduled)
         self._C, self._capi = C, capi
+        self.data_device = torch.device(data_device if data_device is not None else device)
+        assert self.data_device.type == "cuda", "the native exchange gathers on a GPU"
+        if self.data_device != self.device:
+            self._out = [{sp.name: sp.empty(self.batch, self.data_device) for sp in specs} for _ in range(2)]
         # rendezvous of the descriptors: every actor rank contributes its partition's, the learner its flat buffers'
         mine = {"flats": []}
         for f in flats:  # device buffers of the learner (rela_*_learner_flat): mapped by the actor ranks for publish
@@ -356,7 +362,7 @@ class NativePartitionedReplay(PartitionedReplay):
         descs = [None] * self.world
         dist.all_gather_object(descs, mine, group=group)
         self._remote = []
-        dev_index = self.device.index or 0
+        dev_index = self.data_device.index or 0
         for r in self.actor_ranks:
             buf = (C.c_ubyte * 4096).from_buffer_copy(descs[r]["partition"])
             rr = C.c_void_p()
@@ -371,7 +377,7 @@ class NativePartitionedReplay(PartitionedReplay):
     def _unpack(self, slot):
         C, capi = self._C, self._capi
         out = self._out[slot]
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = C.c_void_p(torch.cuda.current_stream(self.data_device).cuda_stream)
         rows = (C.c_void_p * len(self.specs))(*[out[sp.name].data_ptr() for sp in self.specs])
         for g, rr in enumerate(self._remote):  # peer reads of B / G rows per partition, straight into the batch
             capi.check(capi.lib.rela_replay_remote_gather(rr, self.b_local, rows, None, None, self.batch, g * self.b_local,
@@ -379,12 +385,12 @@ class NativePartitionedReplay(PartitionedReplay):
         w = self._recv[slot].view(self.world, self.rank_bytes)
         w = w[self.actor_ranks[0]:self.actor_ranks[0] + self.G] if self._contig else w[self.actor_ranks]
         self._w[slot].view(self.G, self.b_local).copy_(w[:, :4 * self.b_local].view(torch.float32))
-        return out, self._w[slot]
+        return out, (self._w[slot] if self.data_device == self.device else self._w[slot].to(self.data_device))
 
     def publish(self, *flats, steps=0):
         """the actor ranks read the exported flat buffers themselves: the command word is all that travels"""
         assert not self.scheduled or self._left == 0, "scheduled mode: %d announced steps are still to run" % self._left
-        torch.cuda.synchronize(self.device)  # the buffers hold the weights to publish before the actors are told
+        torch.cuda.synchronize(self.data_device)  # the buffers hold the weights to publish before the actors are told
         self._bcast_cmd(CMD_PUBLISH, len(flats) + 1000 * int(steps))
         self._left = int(steps)
         # (the actors signal completion of their reads with the first collective of the cycle; a learner that
@@ -401,7 +407,7 @@ class NativePartitionServer(PartitionServer):
     """Actor-rank side of the native exchange: `replay` is a rela_amd.replay.FFReplay / RNNReplay."""
 
     def __init__(self, replay, specs, batch, beta, device, flat_sizes=(), on_weights=None, learner_rank=0, group=None,
-                 scheduled=False):
+                 scheduled=False, data_device=None):
         import ctypes as C
 
         from . import _capi as capi
@@ -411,35 +417,37 @@ class NativePartitionServer(PartitionServer):
                          group=group, scheduled=scheduled)
         self._C, self._capi, self._dev_view = C, capi, dev_view
         self.replay = replay
+        self.data_device = torch.device(data_device if data_device is not None else device)
         descs = [None] * self.world
         dist.all_gather_object(descs, {"partition": _export_desc(replay.h)}, group=group)
-        dev_index = self.device.index or 0
+        dev_index = self.data_device.index or 0
         self._flat_ptrs, self._flats = [], []
         for h, n in descs[learner_rank]["flats"]:  # map the learner's flat parameter buffers
             p = C.c_void_p()
             capi.check(capi.lib.rela_ipc_import_buffer((C.c_ubyte * 64).from_buffer_copy(h), C.byref(p), dev_index),
                        "rela_ipc_import_buffer")
             self._flat_ptrs.append(p)
-            self._flats.append(dev_view(p.value, (n,), torch.float32, self.device))
+            self._flats.append(dev_view(p.value, (n,), torch.float32, self.data_device))
         self._layout, self._w_off = [], 0
         self.rank_bytes = _pad16(4 * self.b_local)
         self._send = torch.zeros(self.rank_bytes, dtype=torch.uint8, device=self.device)
-        self._w_scratch = torch.empty(self.b_local, dtype=torch.float32, device=self.device)
+        self._w_scratch = torch.empty(self.b_local, dtype=torch.float32, device=self.data_device)
 
     def _sample_step(self):
         C, capi = self._C, self._capi
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        dd = self.data_device
+        stream = C.c_void_p(torch.cuda.current_stream(dd).cuda_stream)
         # ids, raw weights and eviction only: the rows stay where they are, the learner reads them
         capi.check(capi.lib.rela_replay_sample(self.replay.h, self.b_local, None, C.c_void_p(self._w_scratch.data_ptr()),
                                                stream), "rela_replay_sample")
         raw_p, sum_p = C.c_void_p(), C.c_void_p()
         capi.check(capi.lib.rela_replay_last_sample_dev(self.replay.h, C.byref(raw_p), C.byref(sum_p)), "last_sample")
-        raw_w = self._dev_view(raw_p.value, (self.b_local,), torch.float32, self.device)
-        part_sum = self._dev_view(sum_p.value, (1,), torch.float32, self.device)
+        raw_w = self._dev_view(raw_p.value, (self.b_local,), torch.float32, dd).to(self.device)
+        part_sum = self._dev_view(sum_p.value, (1,), torch.float32, dd).to(self.device)
         size = capi.lib.rela_replay_last_sample_size(self.replay.h)
         weight = global_is_weights(raw_w, part_sum, size, self.beta, group=self.actor_group)
         self._send[:4 * self.b_local].view(torch.float32).copy_(weight.float())
-        torch.cuda.current_stream(self.device).synchronize()  # the sample has COMPLETED before the learner hears of it
+        torch.cuda.current_stream(dd).synchronize()  # the sample has COMPLETED before the learner hears of it
         dist.gather(self._send, None, dst=self.learner_rank, group=self.group)
         self.served += 1
 
@@ -451,11 +459,11 @@ class NativePartitionServer(PartitionServer):
         assert arg % 1000 == len(self._flats), "publish of %d buffers, %d expected" % (arg % 1000, len(self._flats))
         if self.on_weights is not None:
             self.on_weights(*self._flats)  # loads the nets straight from the learner's mapped buffers
-            torch.cuda.synchronize(self.device)
+            torch.cuda.synchronize(self.data_device)
         dist.barrier(group=self.group)
         return arg // 1000
 
     def close(self):
         for p in self._flat_ptrs:
-            self._capi.lib.rela_ipc_close_buffer(p, self.device.index or 0)
+            self._capi.lib.rela_ipc_close_buffer(p, self.data_device.index or 0)
         self._flat_ptrs = []
