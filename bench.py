@@ -271,7 +271,8 @@ def emit(line, detail, tag):
 
 # rela_prof label -> substring of the HIP kernel name in the rocprofv3 CSVs
 PMC_KERNEL_OF = {"conv12_fused": "conv12_", "conv3_mfma": "conv_bf16s<", "fc_mfma": "fc_bf16s",
-                 "conv1_bf16x3": "conv1_bf16x3", "conv2_mfma": "ConvCfg<32", "replay_scatter_rows": "replay_scatter_rows"}
+                 "conv1_bf16x3": "conv1_bf16x3", "conv2_mfma": "ConvCfg<32", "replay_scatter_rows": "replay_scatter_rows",
+                 "lstm_gates_mfma": "GemmCfg<3648", "lstm_gates_x_bf16": "gemm_rec64_nt"}
 
 
 def traffic_from_profiles(label):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 PMC passes of tools/final_evidence.sh into the table of profiles/README.md and
+"""Turns the rocprofv3 PMC passes of tools/final_evidence_r4b.sh into the table of profiles/README.md and
 into profiles/r02_traffic.json (HBM bytes per launch, which bench.py reports as roofline.traffic).
 
   python tools/pmc_table.py gpurun_out/final profiles/r02_traffic.json
@@ -17,14 +17,18 @@ import sys
 
 def short(n):
     # split-bf16 path (names = the rela_prof labels bench.py looks traffic up by)
-    if "conv12_bf16s" in n or "conv12_pipe" in n or "conv12_i8" in n:
+    if "conv12_i8" in n:
         return "conv12_fused"
+    if "GemmCfg<3648" in n:
+        return "lstm_gates_mfma"
+    if "gemm_rec64_nt" in n:
+        return "lstm_gates_x_bf16"
     m = re.search(r"conv_bf16s<.*?ConvFastCfg<(\d+)", n)
     if m:
         return "conv2_mfma" if m.group(1) == "32" else "conv3_mfma"
     if "fc_bf16s" in n:
         return "fc_mfma"
-    if "conv1_persist" in n:
+    if "conv1_bf16x3" in n:
         return "conv1_bf16x3"
     m = re.search(r"conv_mfma_bstat<.*?ConvCfg<(\d+)", n)
     if m:
@@ -51,7 +55,8 @@ def main(root, out_json):
         if name == "pmc_sq":
             for k, v in dur.items():
                 res.setdefault(k, {})["us"] = [x / 1e3 for x in v]
-    keep = ("conv12_fused", "conv1_bf16x3", "conv2_mfma", "conv3_mfma", "fc_mfma", "heads_mfma", "replay_scatter_rows",
+    keep = ("conv12_fused", "conv1_bf16x3", "conv2_mfma", "conv3_mfma", "fc_mfma", "heads_mfma", "lstm_gates_mfma",
+            "lstm_gates_x_bf16", "slide_stacks", "replay_scatter_rows",
             "replay_gather_big", "seq_chain", "replay_search", "replay_finish", "replay_update", "replay_append_weights")
     traffic = {}
     print("| kernel | us | GHz | MFMA busy | HBM read MB | HBM write MB | LDS bank-conflict cycles |")
