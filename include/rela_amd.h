@@ -149,6 +149,13 @@ int rela_replay_sample(rela_replay* r, int batch, void* const* out_rows_dev, flo
 int rela_replay_update_priority(rela_replay* r, int n, const float* priority, int on_device,
                                 void* stream);
 
+/* Where the bulk of an insert runs (no reference counterpart: ConcurrentQueue::blockAppend copies its block with the
+ * mutex released, rela/prioritized_replay.h:58-66, i.e. concurrently with a running sample_).  on = 0 (default): on the
+ * replay's stream, in commit order with sample / update_priority -- right when one host thread drives actors and
+ * learner and pipelines the sample path itself (bench.py).  on = 1: the row copies (56 KB per transition) and the
+ * priority staging run on a second stream and only the weight / sum_ commit takes its turn -- right when an
+ * independent sampler keeps the replay's stream busy (the threaded `rela` module, which turns it on).  Same results. */
+int rela_replay_set_decoupled_insert(rela_replay* r, int on);
 /* Learners that overlap the sample path with their own backward pass (rela_apex_learner_loss / _grad):
  * with on = 1, rela_replay_sample and a device-side rela_replay_update_priority no longer make the caller's
  * stream wait for the replay's stream; the caller inserts that wait itself with rela_replay_wait(r, stream)

@@ -63,6 +63,7 @@ _sig("rela_stream_destroy", None, [vp, i32])
 _sig("rela_stream_synchronize", i32, [vp, i32])
 _sig("rela_stream_wait_stream", i32, [vp, vp, i32])
 _sig("rela_memcpy_h2d_async", i32, [vp, vp, i64, vp, i32])
+_sig("rela_replay_set_decoupled_insert", i32, [vp, i32])
 _sig("rela_replay_export_ipc", i32, [vp, vp])
 _sig("rela_replay_import_ipc", i32, [P(vp), vp, i32])
 _sig("rela_replay_remote_close", None, [vp])

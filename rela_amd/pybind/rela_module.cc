@@ -493,6 +493,8 @@ class ReplayParts {
     check(rela_replay_create(&h, capacity_ / G, seed_ + g, alpha_, beta_, prefetch_, device), "rela_replay_create");
     try {
       setSchema(h);
+      // actors and the Python sampler are independent threads here: keep inserts off the sample chain's stream
+      check(rela_replay_set_decoupled_insert(h, 1), "rela_replay_set_decoupled_insert");
     } catch (...) {
       rela_replay_destroy(h);
       throw;

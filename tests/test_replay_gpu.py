@@ -254,6 +254,44 @@ def test_scan_running_off_the_ring_fails_loudly_like_the_reference():
     g.close()
 
 
+def test_decoupled_insert_is_bit_identical_to_in_order():
+    """rela_replay_set_decoupled_insert(1) -- row copies and priority staging on a second stream, only the commit in order
+    (what the threaded `rela` module uses) -- against the default in-order form, on a wrap-around / eviction / duplicate
+    scenario with payload rows: sampled ids, gathered rows, weights and the f64 sum_ after every call must be equal."""
+    import torch
+
+    from gpu_util import GpuReplay, capi, dev
+
+    def run(decoupled):
+        rng = np.random.default_rng(17)
+        g = GpuReplay(512, 9, 0.6, 0.4, row_bytes=(8, 4096))
+        capi.check(capi.lib.rela_replay_set_decoupled_insert(g.h, int(decoupled)), "set_decoupled_insert")
+        trace, tag = [], 0
+        for r in range(40):
+            n = int(rng.integers(16, 97))
+            tags = np.arange(tag, tag + n, dtype=np.int64)
+            pay = ((tags[:, None] * 131 + np.arange(4096)[None, :]) % 251).astype(np.uint8)
+            rc = g.add([dev(tags), dev(pay)], rng.uniform(0.05, 3.0, n).astype(np.float32))
+            if rc == 0:
+                tag += n
+            if g.state()["safe_size"] >= 64 and r % 2 == 1:
+                rc, outs, w = g.sample(64)
+                assert rc == 0
+                torch.cuda.synchronize()
+                st = g.state(64)
+                trace.append((st["ids"].tolist(), outs[0].cpu().numpy().tobytes(), outs[1].cpu().numpy().tobytes(),
+                              w.cpu().numpy().tobytes(), st["sum"], st["size"], st["head"]))
+                assert g.update(rng.uniform(0.05, 3.0, 64).astype(np.float32)) == 0
+        torch.cuda.synchronize()
+        trace.append((g.state()["sum"], g.weights()[0].tobytes()))
+        g.close()
+        return trace
+
+    a, b = run(False), run(True)
+    assert len(a) == len(b) > 10
+    assert a == b
+
+
 def test_protocol_errors():
     from gpu_util import GpuReplay
     from rela_amd import _capi as capi
