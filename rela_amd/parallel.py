@@ -403,8 +403,57 @@ class NativePartitionedReplay(PartitionedReplay):
         self._remote = []
 
 
+class _CapiNativePartition:
+    """rela_amd.replay.FFReplay / RNNReplay (a rela_replay* behind ctypes) as the owner side of the native exchange"""
+
+    def __init__(self, replay):
+        import ctypes as C
+
+        from . import _capi as capi
+        from .engine import dev_view
+
+        self.replay, self._C, self._capi, self._dev_view = replay, C, capi, dev_view
+        self._scratch = None
+
+    def export_desc(self):
+        return _export_desc(self.replay.h)
+
+    def sample_ids(self, n):
+        C, capi, dd = self._C, self._capi, self.replay.device
+        if self._scratch is None or self._scratch.numel() != n:
+            self._scratch = torch.empty(n, dtype=torch.float32, device=dd)
+        stream = C.c_void_p(torch.cuda.current_stream(dd).cuda_stream)
+        capi.check(capi.lib.rela_replay_sample(self.replay.h, n, None, C.c_void_p(self._scratch.data_ptr()), stream),
+                   "rela_replay_sample")
+        raw_p, sum_p = C.c_void_p(), C.c_void_p()
+        capi.check(capi.lib.rela_replay_last_sample_dev(self.replay.h, C.byref(raw_p), C.byref(sum_p)), "last_sample")
+        return (self._dev_view(raw_p.value, (n,), torch.float32, dd), self._dev_view(sum_p.value, (1,), torch.float32, dd),
+                capi.lib.rela_replay_last_sample_size(self.replay.h))
+
+    def update_priority(self, p):
+        self.replay.update_priority(p)
+
+
+class _ModuleNativePartition:
+    """the `rela` module's FFPrioritizedReplay / RNNPrioritizedReplay (one partition in this process) as the owner side"""
+
+    def __init__(self, replay, device):
+        self.replay, self.device = replay, device
+
+    def export_desc(self):
+        return self.replay.export_ipc()
+
+    def sample_ids(self, n):
+        return self.replay.sample_ids(n)
+
+    def update_priority(self, p):
+        self.replay.update_priority(p.to(self.device))
+
+
 class NativePartitionServer(PartitionServer):
-    """Actor-rank side of the native exchange: `replay` is a rela_amd.replay.FFReplay / RNNReplay."""
+    """Actor-rank side of the native exchange: `replay` is a rela_amd.replay.FFReplay / RNNReplay, or an adapter with
+    export_desc() / sample_ids(n) -> (raw weights, float sum, size) / update_priority(p) (the `rela` module's replays:
+    _ModuleNativePartition)."""
 
     def __init__(self, replay, specs, batch, beta, device, flat_sizes=(), on_weights=None, learner_rank=0, group=None,
                  scheduled=False, data_device=None):
@@ -416,10 +465,10 @@ class NativePartitionServer(PartitionServer):
         super().__init__(None, specs, batch, beta, device, flat_sizes=(), on_weights=on_weights, learner_rank=learner_rank,
                          group=group, scheduled=scheduled)
         self._C, self._capi, self._dev_view = C, capi, dev_view
-        self.replay = replay
+        self.replay = replay if hasattr(replay, "sample_ids") else _CapiNativePartition(replay)
         self.data_device = torch.device(data_device if data_device is not None else device)
         descs = [None] * self.world
-        dist.all_gather_object(descs, {"partition": _export_desc(replay.h)}, group=group)
+        dist.all_gather_object(descs, {"partition": self.replay.export_desc()}, group=group)
         dev_index = self.data_device.index or 0
         self._flat_ptrs, self._flats = [], []
         for h, n in descs[learner_rank]["flats"]:  # map the learner's flat parameter buffers
@@ -431,20 +480,12 @@ class NativePartitionServer(PartitionServer):
         self._layout, self._w_off = [], 0
         self.rank_bytes = _pad16(4 * self.b_local)
         self._send = torch.zeros(self.rank_bytes, dtype=torch.uint8, device=self.device)
-        self._w_scratch = torch.empty(self.b_local, dtype=torch.float32, device=self.data_device)
 
     def _sample_step(self):
-        C, capi = self._C, self._capi
         dd = self.data_device
-        stream = C.c_void_p(torch.cuda.current_stream(dd).cuda_stream)
         # ids, raw weights and eviction only: the rows stay where they are, the learner reads them
-        capi.check(capi.lib.rela_replay_sample(self.replay.h, self.b_local, None, C.c_void_p(self._w_scratch.data_ptr()),
-                                               stream), "rela_replay_sample")
-        raw_p, sum_p = C.c_void_p(), C.c_void_p()
-        capi.check(capi.lib.rela_replay_last_sample_dev(self.replay.h, C.byref(raw_p), C.byref(sum_p)), "last_sample")
-        raw_w = self._dev_view(raw_p.value, (self.b_local,), torch.float32, dd).to(self.device)
-        part_sum = self._dev_view(sum_p.value, (1,), torch.float32, dd).to(self.device)
-        size = capi.lib.rela_replay_last_sample_size(self.replay.h)
+        raw_w, part_sum, size = self.replay.sample_ids(self.b_local)
+        raw_w, part_sum = raw_w.to(self.device), part_sum.to(self.device)
         weight = global_is_weights(raw_w, part_sum, size, self.beta, group=self.actor_group)
         self._send[:4 * self.b_local].view(torch.float32).copy_(weight.float())
         torch.cuda.current_stream(dd).synchronize()  # the sample has COMPLETED before the learner hears of it

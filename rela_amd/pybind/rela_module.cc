@@ -448,6 +448,8 @@ class ModelLocker {
 // untouched).  update_priority routes slice g of the priorities to partition g.  Context.start() announces the
 // lockers (plan); a replay nobody planned has one partition.
 // =====================================================================================
+static std::tuple<torch::Tensor, torch::Tensor, int> lastSampleRaw(rela_replay* h, int device, int n);
+
 class ReplayParts {
  public:
   struct Part {
@@ -571,6 +573,25 @@ class ReplayParts {
         check(rela_replay_update_priority(ps[g].h, (int)chunk.numel(), chunk.data_ptr<float>(), 0, nullptr), where);
       }
     }
+  }
+
+  // ---- native partition exchange (include/rela_amd.h, rela_amd/parallel.py): this process owns ONE partition that a
+  // learner in another process maps through HIP IPC and gathers from itself
+  py::bytes exportIpc() const {
+    auto ps = parts();
+    if (ps.size() != 1) throw std::runtime_error("export_ipc: the replay must hold exactly one partition");
+    rela_replay_ipc_desc d;
+    check(rela_replay_export_ipc(ps[0].h, &d), "rela_replay_export_ipc");
+    return py::bytes(reinterpret_cast<const char*>(&d), sizeof(d));
+  }
+  // sample WITHOUT gathering: ids, raw weights and eviction only; -> (raw weights [n], float sum [1], size)
+  std::tuple<torch::Tensor, torch::Tensor, int> sampleIds(int n) {
+    auto ps = parts();
+    if (ps.size() != 1) throw std::runtime_error("sample_ids: the replay must hold exactly one partition");
+    auto opt = torch::TensorOptions().dtype(torch::kFloat32).device(torch::Device(torch::kCUDA, (c10::DeviceIndex)ps[0].device));
+    auto scratch = torch::empty({n}, opt);
+    check(rela_replay_sample(ps[0].h, n, nullptr, scratch.data_ptr<float>(), torchCurrentStream(ps[0].device)), "sample_ids");
+    return lastSampleRaw(ps[0].h, ps[0].device, n);
   }
 
   const int capacity_, seed_;
@@ -740,6 +761,15 @@ class FFPrioritizedReplay {
     return std::make_tuple(std::move(b), core_.globalWeights(raw, sum, size));
   }
 
+  // native partition exchange (not in the reference's surface): see ReplayParts::exportIpc / sampleIds
+  py::bytes exportIpc() { return core_.exportIpc(); }
+  std::tuple<torch::Tensor, torch::Tensor, int> sampleIds(int n) {
+    auto r = core_.sampleIds(n);
+    lastBatch_ = n;
+    lastCounts_.assign(1, n);
+    return r;
+  }
+
   std::tuple<torch::Tensor, torch::Tensor, int> lastSampleRaw_() {
     auto parts = core_.parts();
     if (parts.size() != 1) throw std::runtime_error("last_sample_raw: this replay has several partitions of its own");
@@ -897,6 +927,15 @@ class RNNPrioritizedReplay {
       prefetchedBatch_ = lastBatch_;
       prefetchedDevice_ = lastDevice_;
     }
+  }
+
+  // native partition exchange (not in the reference's surface): see ReplayParts::exportIpc / sampleIds
+  py::bytes exportIpc() { return core_.exportIpc(); }
+  std::tuple<torch::Tensor, torch::Tensor, int> sampleIds(int n) {
+    auto r = core_.sampleIds(n);
+    lastBatch_ = n;
+    lastCounts_.assign(1, n);
+    return r;
   }
 
   std::tuple<torch::Tensor, torch::Tensor, int> lastSampleRaw_() {
@@ -1709,7 +1748,9 @@ PYBIND11_MODULE(rela, m) {
       .def("num_add", &FFPrioritizedReplay::numAdd)
       .def("sample", &FFPrioritizedReplay::sample)
       .def("update_priority", &FFPrioritizedReplay::updatePriority)
-      .def("last_sample_raw", &FFPrioritizedReplay::lastSampleRaw_);  // partition exchange only
+      .def("last_sample_raw", &FFPrioritizedReplay::lastSampleRaw_)  // partition exchange only
+      .def("export_ipc", &FFPrioritizedReplay::exportIpc)            // native exchange: this partition's IPC descriptor
+      .def("sample_ids", &FFPrioritizedReplay::sampleIds);           // ... and a sample that leaves the rows in place
 
   py::class_<RNNPrioritizedReplay, std::shared_ptr<RNNPrioritizedReplay>>(m, "RNNPrioritizedReplay")
       .def(py::init<int, int, float, float, int>())
@@ -1717,7 +1758,9 @@ PYBIND11_MODULE(rela, m) {
       .def("num_add", &RNNPrioritizedReplay::numAdd)
       .def("sample", &RNNPrioritizedReplay::sample)
       .def("update_priority", &RNNPrioritizedReplay::updatePriority)
-      .def("last_sample_raw", &RNNPrioritizedReplay::lastSampleRaw_);  // partition exchange only
+      .def("last_sample_raw", &RNNPrioritizedReplay::lastSampleRaw_)  // partition exchange only
+      .def("export_ipc", &RNNPrioritizedReplay::exportIpc)
+      .def("sample_ids", &RNNPrioritizedReplay::sampleIds);
 
   py::class_<Env, std::shared_ptr<Env>>(m, "Env");
 

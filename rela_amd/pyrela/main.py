@@ -64,6 +64,10 @@ def parse_args(argv=None):
     p.add_argument("--act_device", type=str, default="cuda:0")
     p.add_argument("--actor_sync_freq", type=int, default=20)
     p.add_argument("--num_eval_game", type=int, default=0, help="eval threads after every epoch (pyrela/main.py:264-278); 0 = off")
+    p.add_argument("--exchange", type=str, default="native",
+                   help="several processes (train_multi): native = replay partitions and flat weight buffers mapped through "
+                        "HIP IPC, the learner gathers the sampled rows itself over xGMI (rela_amd/parallel.py); packed = one "
+                        "packed gather / two broadcasts through the collective")
     p.add_argument("--single_process", type=int, default=0,
                    help="several --act_device values in ONE process, as the reference wires them (main.py:131-136)")
     p.add_argument("--hip_learner", type=int, default=1,
@@ -238,8 +242,11 @@ def _multi_worker(rank, world, args, port, results):
     import torch.distributed as dist
 
     from rela_amd.learner import HipApexLearner, HipR2D2Learner, ffnet_flat_layout, lstmnet_flat_layout
-    from rela_amd.parallel import (PartitionedReplay, PartitionServer, ff_batch_namespace, ff_field_specs,
-                                   rnn_batch_namespace, rnn_field_specs)
+    from rela_amd.parallel import (NativePartitionedReplay, NativePartitionServer, PartitionedReplay, PartitionServer,
+                                   _ModuleNativePartition, ff_batch_namespace, ff_field_specs, rnn_batch_namespace,
+                                   rnn_field_specs)
+
+    native = getattr(args, "exchange", "native") == "native"
 
     act_devices = args.act_device.split(",")
     G = len(act_devices)
@@ -271,7 +278,11 @@ def _multi_worker(rank, world, args, port, results):
         learner = learner_cls.from_agent(agent, args.batchsize, lr=args.lr, eps=args.eps, grad_clip=args.grad_clip)
         # scheduled exchange: command words (a host synchronisation on every rank) only with the weight publish every
         # actor_sync_freq steps; the sample / update_priority pairs in between follow the announced cycle
-        replay = PartitionedReplay(specs, args.batchsize, args.importance_exponent, exch_device, scheduled=True)
+        if native:  # partitions and flat buffers mapped through HIP IPC: rows and weights never enter a collective
+            replay = NativePartitionedReplay(specs, args.batchsize, args.importance_exponent, exch_device, scheduled=True,
+                                             flats=(learner.flat()[0], learner.flat_target()), data_device=my_device)
+        else:
+            replay = PartitionedReplay(specs, args.batchsize, args.importance_exponent, exch_device, scheduled=True)
         total_updates = args.num_epoch * args.epoch_len
         history = []
         for epoch in range(args.num_epoch):
@@ -283,8 +294,12 @@ def _multi_worker(rank, world, args, port, results):
                     learner.sync_target_with_online()
                 if num_update % args.actor_sync_freq == 0:  # ONE broadcast per flat buffer instead of load_state_dict
                     watch.poll()
-                    replay.publish(learner.flat()[0].to(exch_device), learner.flat_target().to(exch_device),
-                                   steps=min(args.actor_sync_freq, total_updates - num_update))
+                    if native:  # (the actors read the mapped buffers themselves)
+                        replay.publish(learner.flat()[0], learner.flat_target(),
+                                       steps=min(args.actor_sync_freq, total_updates - num_update))
+                    else:
+                        replay.publish(learner.flat()[0].to(exch_device), learner.flat_target().to(exch_device),
+                                       steps=min(args.actor_sync_freq, total_updates - num_update))
                 fields, weight = replay.sample()
                 batch = to_namespace({k: v.to(my_device) for k, v in fields.items()})
                 loss, priority = learner.step(batch, weight.to(my_device))
@@ -298,6 +313,8 @@ def _multi_worker(rank, world, args, port, results):
             print("epoch: %d, time: %.1fs, loss: %.5f, train: %.1f samples/s" % (
                 epoch, dt, history[-1]["loss"], history[-1]["train"]), flush=True)
         replay.stop()
+        if native:
+            replay.close()
         counts = torch.zeros(2, dtype=torch.float64, device=exch_device)
         dist.all_reduce(counts)
         results.put(dict(history=history, act=float(counts[0]), buffer_add=float(counts[1])))
@@ -333,10 +350,17 @@ def _multi_worker(rank, world, args, port, results):
             agent.load_state_dict(sd)
             locker.update_model(agent)
 
-        srv = PartitionServer((_RelaRNNPartition if r2d2 else _RelaFFPartition)(part, my_device), specs, args.batchsize,
-                              args.importance_exponent,
-                              exch_device, flat_sizes=(total, total), on_weights=on_weights, scheduled=True)
+        if native:
+            srv = NativePartitionServer(_ModuleNativePartition(part, my_device), specs, args.batchsize,
+                                        args.importance_exponent, exch_device, on_weights=on_weights, scheduled=True,
+                                        data_device=my_device)
+        else:
+            srv = PartitionServer((_RelaRNNPartition if r2d2 else _RelaFFPartition)(part, my_device), specs, args.batchsize,
+                                  args.importance_exponent,
+                                  exch_device, flat_sizes=(total, total), on_weights=on_weights, scheduled=True)
         srv.serve_forever()
+        if native:
+            srv.close()
         counts = torch.tensor([float(utils.total_acts(actors)), float(part.num_add())], dtype=torch.float64,
                               device=exch_device)
         dist.all_reduce(counts)
