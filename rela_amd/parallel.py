@@ -364,7 +364,9 @@ class NativePartitionedReplay(PartitionedReplay):
         self._remote = []
         dev_index = self.data_device.index or 0
         for r in self.actor_ranks:
-            buf = (C.c_ubyte * 4096).from_buffer_copy(descs[r]["partition"])
+            raw = descs[r]["partition"]  # (sizeof(rela_replay_ipc_desc) bytes, or a padded buffer)
+            buf = (C.c_ubyte * max(4096, len(raw)))()
+            C.memmove(buf, raw, len(raw))
             rr = C.c_void_p()
             capi.check(capi.lib.rela_replay_import_ipc(C.byref(rr), buf, dev_index), "rela_replay_import_ipc")
             self._remote.append(rr)
