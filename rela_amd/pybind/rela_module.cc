@@ -767,6 +767,7 @@ class FFPrioritizedReplay {
     auto r = core_.sampleIds(n);
     lastBatch_ = n;
     lastCounts_.assign(1, n);
+    lastDevice_.clear();  // (no device-side prefetch behind the next update_priority: the rows stay where they are)
     return r;
   }
 
@@ -780,7 +781,7 @@ class FFPrioritizedReplay {
     if (lastBatch_ == 0) throw std::runtime_error("FFPrioritizedReplay.update_priority: nothing was sampled");
     if (priority.dim() != 1) throw std::invalid_argument("update_priority expects a 1-D tensor");  // :236
     core_.updatePriority(priority, lastCounts_, "FFPrioritizedReplay.update_priority");
-    if (core_.prefetch_ > 0 && core_.size() >= lastBatch_) {
+    if (core_.prefetch_ > 0 && !lastDevice_.empty() && core_.size() >= lastBatch_) {
       prefetched_.emplace(sampleNow(lastBatch_, lastDevice_));
       prefetchedBatch_ = lastBatch_;
       prefetchedDevice_ = lastDevice_;
@@ -922,7 +923,7 @@ class RNNPrioritizedReplay {
     if (lastBatch_ == 0) throw std::runtime_error("RNNPrioritizedReplay.update_priority: nothing was sampled");
     if (priority.dim() != 1) throw std::invalid_argument("update_priority expects a 1-D tensor");
     core_.updatePriority(priority, lastCounts_, "RNNPrioritizedReplay.update_priority");
-    if (core_.prefetch_ > 0 && core_.size() >= lastBatch_) {
+    if (core_.prefetch_ > 0 && !lastDevice_.empty() && core_.size() >= lastBatch_) {
       prefetched_.emplace(sampleNow(lastBatch_, lastDevice_));
       prefetchedBatch_ = lastBatch_;
       prefetchedDevice_ = lastDevice_;
@@ -935,6 +936,7 @@ class RNNPrioritizedReplay {
     auto r = core_.sampleIds(n);
     lastBatch_ = n;
     lastCounts_.assign(1, n);
+    lastDevice_.clear();  // (no device-side prefetch behind the next update_priority: the rows stay where they are)
     return r;
   }
 
