@@ -75,12 +75,17 @@ BYTES_PER_SAMPLE = {"conv1_bf16x3": 28224 + 400 * 32 * 4, "conv2_mfma": 400 * 32
                     "conv3_mfma": 81 * 64 * 4 + 49 * 64 * 4, "fc_mfma": 49 * 64 * 4 + 512 * 4, "heads_mfma": 512 * 4 + 32 * 4,
                     "conv12_fused": 28224 + 81 * 64 * 4}
 PEAK_HBM_GBS = 8000.0
+DTYPE_F32X3 = ("f32 (conv2 / conv3 / fc of the actors' forwards: every f32 operand split EXACTLY in three bf16 parts, six "
+               "products each on v_mfma_f32_16x16x32_bf16, f32 accumulation -- error against f64 <= the f32 MFMA kernels' "
+               "and torch CPU f32's, tests/test_ffnet_gpu.py::test_ffnet_f32x3_is_f32_accurate; everything else f32)")
 DTYPE_NOTE = ("f32 results from split-bf16 MFMA (bf16 hi + lo operands = 16 significant bits, 3 bf16 products per product, "
               "f32 accumulate; conv1: u8 frames x 24-bit fixed-point weights as three int8 digit products, exact i32 sums): "
               "|dQ| < 2e-5 * max|Q| against the exact f32 mode (tests/test_ffnet_gpu.py)")
 # what the HIP Ape-X learner step computes in, per --precision (csrc/learner.hip)
 LEARNER_PRECISION_NOTE = {
     "f32": "f32 throughout (exact f32 MFMA forwards, f32 MFMA GEMM backward, f32 clip + RMSprop)",
+    "f32x3": "f32 throughout (exact f32 MFMA forwards, f32 MFMA GEMM backward, f32 clip + RMSprop): the f32x3 kernels serve "
+             "the actors' batches; a learner batch of 512 rows stays on the f32 MFMA kernels",
     "bf16x2": "mixed: td_err's two gradient-free forwards (online(s'), target(s')) with conv trunk on split-bf16 MFMA; "
               "conv1 weight gradient and conv2 / conv3 data gradients on bf16 MFMA (hi + lo operands, f32 accumulate); "
               "online(s) forward whose activations / ReLU masks feed the backward, fc and head GEMMs, conv2 / conv3 weight "
@@ -1005,7 +1010,7 @@ def main():
                     help="frame-stack de-duplication in the replay (SURVEY 8f-3): stack = 28,224 B per env-step, plane = "
                          "7,056 B (the frames of this bench are static, so only the byte traffic is representative); "
                          "default: s and next_s stored in full (56,448 B), as in round 1's headline")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16x2"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "f32x3", "bf16x2"],
                     help="arithmetic of the headline region (`value`): f32 (default) = the reference's arithmetic, exact "
                          "f32 MFMA for actors and learner; bf16x2 = the fast mode, split-bf16 MFMA (hi + lo bf16 operands, "
                          "three products, f32 accumulation; |dQ| < 2e-5 max|Q| against the f32 path, tests/test_ffnet_gpu.py). "
@@ -1345,11 +1350,14 @@ def main():
     #   strict          the reference's arithmetic AND the reference's work: f32 + all 4 trunk forwards per env-step
     #   fast_mode       split-bf16 MFMA (stated tolerance), forwards memoised
     #   fast_no_reuse   split-bf16 MFMA, 4 forwards (SURVEY 8d's unit of work)
-    other = "bf16x2" if args.precision == "f32" else "f32"
-    name_of = {("f32", 1): "f32_mode", ("f32", 0): "strict", ("bf16x2", 1): "fast_mode", ("bf16x2", 0): "fast_no_reuse"}
+    #   f32x3_mode      f32 operands as three bf16 parts on the bf16 MFMA (f32 accuracy, csrc/gemm_f32emu.h), memoised
+    #   f32x3_strict    the same arithmetic, all 4 trunk forwards
+    name_of = {("f32", 1): "f32_mode", ("f32", 0): "strict", ("bf16x2", 1): "fast_mode", ("bf16x2", 0): "fast_no_reuse",
+               ("f32x3", 1): "f32x3_mode", ("f32x3", 0): "f32x3_strict"}
     regions = {name_of[(args.precision, 1)]: head}
     if not ONLY:
-        for prec, reuse in ((args.precision, 0), (other, 1), (other, 0)):
+        order = [(args.precision, 0)] + [(q, r) for q in ("f32x3", "f32", "bf16x2") if q != args.precision for r in (1, 0)]
+        for prec, reuse in order:
             regions[name_of[(prec, reuse)]] = timed_region(prec, reuse, settle)
         set_all_precision(args.precision)
         engine.set_reuse(1)
@@ -1374,6 +1382,8 @@ def main():
             # bf16 MFMA products issued per algorithmic product: conv1 multiplies exact u8 inputs by weights split
             # in 3 bf16 pieces (f32 mode: exact) or 2 (bf16x2 mode); the other layers 3 in bf16x2 mode, f32 MFMA else
             products = (2 if fast else 3) if name == "conv1_bf16x3" else (3 if fast else 0)
+            if region["precision"] == "f32x3" and name in ("conv2_mfma", "conv3_mfma", "fc_mfma"):
+                products = 6  # both operands in three bf16 parts, the six products with i + j <= 2
             conv1_i8 = True  # (the half-frame bf16 conv1 -> conv2 kernel was removed in r4)
             if name == "conv12_fused":
                 # conv2: 3 bf16 products per product.  conv1: 3 int8 digit products (csrc/ffnet.hip: conv12_i8) on
@@ -1414,7 +1424,11 @@ def main():
                  "strict": "the reference's arithmetic AND the reference's work: exact f32 MFMA mode for actors and learner, "
                            "all 4 trunk forwards per env-step (SURVEY 8d: 74.8 MFLOP)",
                  "fast_mode": "split-bf16 MFMA (|dQ| < 2e-5 max|Q|, tests/test_ffnet_gpu.py), forwards memoised",
-                 "fast_no_reuse": "split-bf16 MFMA, all 4 trunk forwards per env-step"}
+                 "fast_no_reuse": "split-bf16 MFMA, all 4 trunk forwards per env-step",
+                 "f32x3_mode": "f32 accuracy on the bf16 matrix cores: conv2 / conv3 / fc with every f32 operand split exactly "
+                               "in three bf16 parts and six products each (error against f64 no larger than the exact-f32-MFMA "
+                               "mode's and torch-CPU-f32's, tests/test_ffnet_gpu.py); learner in exact f32 MFMA; forwards memoised",
+                 "f32x3_strict": "the same arithmetic, all 4 trunk forwards per env-step"}
         detail_regions = {k: {"precision": r["precision"], "forwards_per_tick": r["forwards_per_tick"], "steps": args.steps,
                               "repeats": len(r["ms"]), "ms_per_step": r["ms_per_step"], "ms_per_step_repeats": r["ms"],
                               "env_steps_per_s": r["env_steps_per_s"], "grad_steps_per_s": 1e3 / r["ms_per_step"],
@@ -1423,7 +1437,7 @@ def main():
         workload = ("Ape-X DQN, 80 threads x 80 games (6400 envs) per GPU, actor+learner on one MI355X, replay 2^20 per GPU "
                     "device-resident, A=18, n=3, ONE learner batch of 512 per step for the whole job (B/G sampled per replay "
                     "partition); device-resident static frames: no env stepping and no H2D inside the timed region")
-        dtype = "f32" if args.precision == "f32" else DTYPE_NOTE
+        dtype = {"f32": "f32", "f32x3": DTYPE_F32X3}.get(args.precision, DTYPE_NOTE)
         comm = None if world == 1 else {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size()
                                         if dist.get_backend() == "nccl" else 0, "ranks": dist.get_world_size(),
                                         "collectives_per_step": "all-reduce SUM of the flat 6.8 MB gradient buffer; "
@@ -1512,7 +1526,8 @@ def main():
         line = {"metric": detail["metric"], "value": detail["value"], "unit": "env-steps/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_med, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32" if args.precision == "f32" else "f32 results from split-bf16 MFMA (16-bit significands)",
+                "dtype": {"f32": "f32", "f32x3": "f32 (f32 operands as 3 exact bf16 parts on bf16 MFMA; f32-accurate)"}.get(
+                    args.precision, "f32 results from split-bf16 MFMA (16-bit significands)"),
                 "data": "synthetic",
                 "config": {"workload": "Ape-X DQN 80x80 envs/GPU, actor+learner on one MI355X, replay 2^20, B=512, A=18, n=3; "
                                        "device-resident static frames", "forwards_per_tick": round(head["forwards_per_tick"], 2),

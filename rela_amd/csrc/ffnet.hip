@@ -29,6 +29,7 @@
 
 #include "common.h"
 #include "gemm_bf16s.h"
+#include "gemm_f32emu.h"
 #include "ffnet_layout.h"
 #include "gemm_lds.h"
 #include "prof.h"
@@ -52,6 +53,8 @@ struct FFNetDev {
   // scales s_c and the biases b_c + 128 s_c sum_k q_k
   uint4* W1d = nullptr;
   float *s1q = nullptr, *b1q = nullptr;
+  // f32-accurate mode on the bf16 matrix cores (gemm_f32emu.h): bf16 triples in fragment order [cg][ks][u][part][lane]
+  uint4 *B2e = nullptr, *B3e = nullptr, *Bfe = nullptr;
 };
 
 namespace {
@@ -625,6 +628,9 @@ struct ConvFastCfg {
 };
 constexpr int kFastMinN = 1024;  // below this fc_bf16s has too few blocks and the f32 split-K fc is faster
 constexpr int kFastTrunkMinN = 128;  // from here up the split-bf16 convolutions beat the f32 ones
+// f32-accurate bf16 mode (precision 2, gemm_f32emu.h): its kernels want >= ~1 row tile per wave of the chip; smaller
+// batches run the exact f32 MFMA kernels (same accuracy).  Byte offsets inside a1 are 32-bit: 51,200 B per sample.
+constexpr int kEmuMinN = 2048, kEmuMaxN = 80000;
 // conv2: 20x20x32 -> 9x9x64, stride 2: 2*Q = 2, 2*RQ = 18 = 2 (mod 16)
 using Conv2F = ConvFastCfg<32, 20, 20, 4, 4, 2, 9, 9, 1, 9, 185, 20 * 185>;
 // conv3: 9x9x64 -> 7x7x64, stride 1: Q = 2, RQ = 14 (7 positions per row), SQ = 98 = 2 (mod 16)
@@ -1892,7 +1898,8 @@ struct PackAllArgs {
   float *w2p, *w3p, *wfcp;  // the learner's dgrad operand copies (ffnet_layout.h), or NULL
   uint8_t* W1d;             // conv1 for the int8 matrix cores (pack_conv1_i8_block)
   float *s1q, *b1q;
-  int first[18];  // first block of job j; first[17] = total
+  uint16_t *B2e, *B3e, *Bfe;  // bf16 triples of the f32-accurate mode (f32emu::pack_f32emu_at)
+  int first[21];  // first block of job j; first[20] = total
 };
 __global__ void pack_ffnet_all(PackAllArgs a) {
   const int b = blockIdx.x;
@@ -1927,7 +1934,10 @@ __global__ void pack_ffnet_all(PackAllArgs a) {
     case 13: if (idx < 64 * 512) permute_weight_at(kPermConv2, (int)idx, a.p[2], a.w2p); break;
     case 14: if (idx < 64 * 576) permute_weight_at(kPermConv3, (int)idx, a.p[4], a.w3p); break;
     case 15: if (idx < 512 * 3136) permute_weight_at(kPermFc, (int)idx, a.p[6], a.wfcp); break;
-    default: pack_conv1_i8_block(b - a.first[16], a.p[0], a.p[1], a.W1d, a.s1q, a.b1q); break;  // (block-uniform: it synchronises)
+    case 16: pack_conv1_i8_block(b - a.first[16], a.p[0], a.p[1], a.W1d, a.s1q, a.b1q); break;  // (block-uniform: it synchronises)
+    case 17: f32emu::pack_f32emu_at(idx, 1, a.p[2], a.B2e, f32emu::ProbConv2::NCG, f32emu::ProbConv2::KS); break;
+    case 18: f32emu::pack_f32emu_at(idx, 2, a.p[4], a.B3e, f32emu::ProbConv3::NCG, f32emu::ProbConv3::KS); break;
+    default: f32emu::pack_f32emu_at(idx, 3, a.p[6], a.Bfe, f32emu::ProbFc::NCG, f32emu::ProbFc::KS); break;
   }
 }
 
@@ -1949,7 +1959,9 @@ struct rela_ffnet {
   bool loaded = false;
   uint64_t version = 0;  // bumped by every load
   const char* const* prof_names = nullptr;  // per-kernel timing labels (actor-side by default)
-  int precision = 0;  // 0 = exact f32 MFMA (parity mode), 1 = split-bf16 MFMA for conv2 / conv3 / fc
+  // 0 = exact f32 MFMA | 1 = split-bf16 MFMA for conv2 / conv3 / fc (two bf16 parts per operand: 16-bit significands, the
+  // "fast" mode) | 2 = f32 operands as THREE bf16 parts on the bf16 MFMA (gemm_f32emu.h: f32 accuracy)
+  int precision = 0;
   int max_rows = 0;  // > 0: the owner never runs more rows (a learner's batch): layouts only larger batches read are not packed
   // BfT (the f32 split-K fc's weights) of such a net in the split-bf16 mode: no kernel of that mode reads it from 128
   // rows up, so the per-step re-pack skips it (6.4 MB) and the f32 path packs it on demand from the owner's buffer
@@ -1993,6 +2005,9 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
   RELA_HIP(hipMalloc(&d.B2f, sizeof(uint4) * Conv2F::CT * Conv2F::KS * 2 * 64));
   RELA_HIP(hipMalloc(&d.B3f, sizeof(uint4) * Conv3F::CT * Conv3F::KS * 2 * 64));
   RELA_HIP(hipMalloc(&d.Bff, sizeof(uint4) * 32 * FcFast::KS * 2 * 64));
+  RELA_HIP(hipMalloc(&d.B2e, sizeof(uint4) * f32emu::packed_u4<f32emu::ProbConv2>()));
+  RELA_HIP(hipMalloc(&d.B3e, sizeof(uint4) * f32emu::packed_u4<f32emu::ProbConv3>()));
+  RELA_HIP(hipMalloc(&d.Bfe, sizeof(uint4) * f32emu::packed_u4<f32emu::ProbFc>()));
   // opt in to > 64 KB of dynamic LDS once per process/device
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv1B::LDS_BYTES));
@@ -2019,7 +2034,7 @@ extern "C" void rela_ffnet_destroy(rela_ffnet* n) {
   DeviceGuard g(n->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bf, n->d.bf, n->d.Bh, n->d.bh,
-                n->d.BfT, n->d.B2f, n->d.B3f, n->d.Bff, n->d.Bhp, n->d.W1d, n->d.s1q, n->d.b1q};
+                n->d.BfT, n->d.B2f, n->d.B3f, n->d.Bff, n->d.Bhp, n->d.W1d, n->d.s1q, n->d.b1q, n->d.B2e, n->d.B3e, n->d.Bfe};
   for (void* p : ps) (void)hipFree(p);
   delete n;
 }
@@ -2142,7 +2157,8 @@ void ffnet_set_max_rows(rela_ffnet* n, int rows) { n->max_rows = rows; }
 }  // namespace rela_amd
 extern "C" uint64_t rela_ffnet_version(const rela_ffnet* n) { return n ? n->version : 0; }
 extern "C" int rela_ffnet_set_precision(rela_ffnet* n, int mode) {
-  RELA_CHECK(n && (mode == 0 || mode == 1), RELA_EINVAL, "rela_ffnet_set_precision: mode must be 0 (f32) or 1 (split-bf16)");
+  RELA_CHECK(n && mode >= 0 && mode <= 2, RELA_EINVAL,
+             "rela_ffnet_set_precision: mode must be 0 (f32 MFMA), 1 (split-bf16, 16-bit operands) or 2 (f32 as three bf16 parts)");
   n->precision = mode;
   n->version += 1;  // results of the two modes differ in the last bits: a cached forward must not be reused across them
   return RELA_OK;
@@ -2201,16 +2217,23 @@ int rela_amd::ffnet_load_impl(rela_ffnet* n, const rela_ffnet_params* p, int on_
     a.b1 = n->d.b1, a.b2 = n->d.b2, a.b3 = n->d.b3, a.bf = n->d.bf, a.bh = n->d.bh, a.A = A;
     a.w2p = extra.w2p, a.w3p = extra.w3p, a.wfcp = extra.wfcp;
     a.W1d = reinterpret_cast<uint8_t*>(n->d.W1d), a.s1q = n->d.s1q, a.b1q = n->d.b1q;
-    const int64_t elems[17] = {2 * 8 * 64 * 8, 0, 4 * 128 * 64, 4 * 144 * 64, (int64_t)32 * 784 * 64,
+    a.B2e = reinterpret_cast<uint16_t*>(n->d.B2e), a.B3e = reinterpret_cast<uint16_t*>(n->d.B3e);
+    a.Bfe = reinterpret_cast<uint16_t*>(n->d.Bfe);
+    // (one thread per bf16 TRIPLE of the f32-accurate layouts: a third of their 2-byte elements)
+    const int64_t emu2 = f32emu::packed_u4<f32emu::ProbConv2>() * 8 / 3, emu3 = f32emu::packed_u4<f32emu::ProbConv3>() * 8 / 3,
+                  emuf = f32emu::packed_u4<f32emu::ProbFc>() * 8 / 3;
+    const int64_t elems[20] = {2 * 8 * 64 * 8, 0, 4 * 128 * 64, 4 * 144 * 64, (int64_t)32 * 784 * 64,
                                (int64_t)3136 * 512, 2 * 128 * 64, 2 * 4 * 32 * 64,
                                (int64_t)Conv2F::CT * Conv2F::KS * 64 * 8, (int64_t)Conv3F::CT * Conv3F::KS * 64 * 8,
                                (int64_t)32 * FcFast::KS * 64 * 8, 672, 32,
                                extra.w2p ? 64 * 512 : 0, extra.w3p ? 64 * 576 : 0, extra.wfcp ? (int64_t)512 * 3136 : 0,
-                               32 * 256};
+                               32 * 256, emu2, emu3, emuf};
     // a net whose owner never runs large batches (a learner re-packs after every step) skips the two fc layouts
     // only large batches read: Bf (f32 fragments, N >= kFcSplitBelow) and Bff (bf16 fragments, N >= kFastMinN)
-    int64_t el[17];
-    for (int jn = 0; jn < 17; ++jn) el[jn] = elems[jn];
+    int64_t el[20];
+    for (int jn = 0; jn < 20; ++jn) el[jn] = elems[jn];
+    // (... nor the layouts of the f32-accurate bf16 mode, which serves kEmuMinN rows and up)
+    if (n->max_rows > 0 && n->max_rows < kEmuMinN) el[17] = el[18] = el[19] = 0;
     if (n->max_rows > 0 && n->max_rows < kFcSplitBelow) el[4] = 0;
     if (n->max_rows > 0 && n->max_rows < kFastTrunkMinN) el[10] = 0;  // (the split-K fc_bf16s serves 128 rows and up)
     n->bft_stale = false;
@@ -2220,8 +2243,8 @@ int rela_amd::ffnet_load_impl(rela_ffnet* n, const rela_ffnet_params* p, int on_
       n->bft_src = dv[6];
     }
     a.first[0] = 0;
-    for (int jn = 0; jn < 17; ++jn) a.first[jn + 1] = a.first[jn] + (int)ceil_div(el[jn], 256);
-    hipLaunchKernelGGL(pack_ffnet_all, dim3(a.first[17]), dim3(256), 0, s, a);
+    for (int jn = 0; jn < 20; ++jn) a.first[jn + 1] = a.first[jn] + (int)ceil_div(el[jn], 256);
+    hipLaunchKernelGGL(pack_ffnet_all, dim3(a.first[20]), dim3(256), 0, s, a);
   }
   RELA_LAUNCH_CHECK();
   if (tmp) {
@@ -2320,6 +2343,29 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
       hipLaunchKernelGGL(fc_bf16s<FcFast>, fc_grid_xcd(ceil_div(N, FcFast::BM), 1), dim3(kThreads), FcFast::LDS_BYTES, s,
                            (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, h, N, 0);
     }
+  } else if (precision == 2 && N >= kEmuMinN && N <= kEmuMaxN && !(n->max_rows > 0 && n->max_rows < kEmuMinN)) {
+    // f32-accurate mode: conv1 exact as in the f32 mode (u8 frames x three-part weights), conv2 / conv3 / fc with BOTH
+    // operands in three bf16 parts and six products each; activations stay channel-last f32 between the layers
+    {
+      ProfScope prof(names[0], s);
+      note_launch("conv1_bf16x3"); hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
+                         d.B1, d.b1, a1, N);
+    }
+    {
+      ProfScope prof(names[1], s);
+      note_launch("gemm_f32emu<conv2>");
+      f32emu::launch<f32emu::ProbConv2, 6, 1>(a1, d.B2e, d.b2, a2, N * 81, s);
+    }
+    {
+      ProfScope prof(names[2], s);
+      note_launch("gemm_f32emu<conv3>");
+      f32emu::launch<f32emu::ProbConv3, 6, 1>(a2, d.B3e, d.b3, a3, N * 49, s);
+    }
+    {
+      ProfScope prof(names[3], s);
+      note_launch("gemm_f32emu<fc>");
+      f32emu::launch<f32emu::ProbFc, 6, 1>(a3, d.Bfe, d.bf, h, N, s);
+    }
   } else {
   if (!fast_trunk_only) {
   {
@@ -2345,8 +2391,8 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     if (n->bft_stale) {  // (see rela_ffnet::bft_stale)
       PackAllArgs a{};
       a.p[6] = n->bft_src, a.BfT = d.BfT;
-      for (int jn = 0; jn < 17; ++jn) a.first[jn + 1] = a.first[jn] + (jn == 5 ? (int)ceil_div((int64_t)3136 * 512, 256) : 0);
-      hipLaunchKernelGGL(pack_ffnet_all, dim3(a.first[17]), dim3(256), 0, s, a);
+      for (int jn = 0; jn < 20; ++jn) a.first[jn + 1] = a.first[jn] + (jn == 5 ? (int)ceil_div((int64_t)3136 * 512, 256) : 0);
+      hipLaunchKernelGGL(pack_ffnet_all, dim3(a.first[20]), dim3(256), 0, s, a);
       n->bft_stale = false;
     }
     ProbFcFwd p{};

@@ -47,9 +47,11 @@ class FFNetHandle:
         self._keep = keep  # packing kernels are stream-ordered; keep sources alive until the next load
 
     def set_precision(self, mode):
-        """"f32" (default: exact f32 MFMA, the parity mode) or "bf16x2" (split-bf16 MFMA for the whole trunk,
-        Q within 1e-6 of the f32 path; include/rela_amd.h rela_ffnet_set_precision)."""
-        capi.check(capi.lib.rela_ffnet_set_precision(self.h, {"f32": 0, "bf16x2": 1}[mode]), "rela_ffnet_set_precision")
+        """"f32" (default: exact f32 MFMA), "f32x3" (conv2 / conv3 / fc with both f32 operands as three bf16 parts on
+        the bf16 matrix cores: f32 accuracy, csrc/gemm_f32emu.h) or "bf16x2" (the fast mode: two bf16 parts, 16-bit
+        significands, |dQ| < 2e-5 max|Q|); include/rela_amd.h rela_ffnet_set_precision."""
+        capi.check(capi.lib.rela_ffnet_set_precision(self.h, {"f32": 0, "bf16x2": 1, "f32x3": 2}[mode]),
+                   "rela_ffnet_set_precision")
 
     def close(self):
         if getattr(self, "h", None):
@@ -178,7 +180,8 @@ class LSTMNetHandle:
         """"f32" (default) or "bf16x2": the conv trunk on split-bf16 MFMA for batches of 128 rows and more and, from
         1,024 rows up, the input side of the LSTM gate GEMM (h x W_hh, the cell and the heads stay f32);
         rela_lstmnet_set_precision."""
-        capi.check(capi.lib.rela_lstmnet_set_precision(self.h, {"f32": 0, "bf16x2": 1}[mode]), "rela_lstmnet_set_precision")
+        capi.check(capi.lib.rela_lstmnet_set_precision(self.h, {"f32": 0, "bf16x2": 1, "f32x3": 0}[mode]),
+                   "rela_lstmnet_set_precision")  # ("f32x3" is an AtariFFNet mode: the recurrent net keeps exact f32)
 
     def close(self):
         if getattr(self, "h", None):

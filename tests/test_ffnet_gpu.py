@@ -36,7 +36,7 @@ class GpuNet:
         capi.check(capi.lib.rela_ffnet_load(h, C.byref(p), 0, None), "rela_ffnet_load")
 
     def set_precision(self, mode):
-        self.capi.check(self.capi.lib.rela_ffnet_set_precision(self.h, {"f32": 0, "bf16x2": 1}[mode]), "set_precision")
+        self.capi.check(self.capi.lib.rela_ffnet_set_precision(self.h, {"f32": 0, "bf16x2": 1, "f32x3": 2}[mode]), "set_precision")
 
     def forward(self, s, legal, precision=None):
         import torch
@@ -65,12 +65,16 @@ class GpuNet:
 # tests of the split-bf16 mode assert this through the launch census (rela_prof_count_enable), so a silent fall-back
 # to the f32 kernels -- what a batch below 128 rows gets, by design -- cannot pass for a test of the fast kernels.
 FAST_TRUNK_MIN_N, FAST_FC_MIN_N = 128, 1024
+EMU_MIN_N = 2048  # csrc/ffnet.hip kEmuMinN: below it the "f32x3" mode runs the exact f32 MFMA kernels
+EMU_KERNELS = {"gemm_f32emu<conv2>", "gemm_f32emu<conv3>", "gemm_f32emu<fc>"}
 
 
 def expected_kernels(N, precision):
     if precision == "bf16x2" and N >= FAST_TRUNK_MIN_N:
         trunk = {CONV12, "conv_bf16s<Conv3F>"}
         return trunk | ({"fc_bf16s"} if N >= FAST_FC_MIN_N else {"fc_bf16s (split-K)"})
+    if precision == "f32x3" and N >= EMU_MIN_N:
+        return {"conv1_bf16x3"} | EMU_KERNELS
     return {"conv1_bf16x3", "conv_mfma<Conv2> (f32)", "conv_mfma<Conv3> (f32)"}
 
 
@@ -79,7 +83,8 @@ def forward_checked(net, s, legal, precision):
     with net.capi.launch_census() as c:
         q = net.forward(s, legal, precision)
     want = expected_kernels(s.shape[0], precision)
-    other = (expected_kernels(s.shape[0], "f32") | expected_kernels(s.shape[0], "bf16x2")) - want
+    other = (expected_kernels(s.shape[0], "f32") | expected_kernels(s.shape[0], "bf16x2") |
+             expected_kernels(s.shape[0], "f32x3")) - want
     assert want <= set(c.counts), "N=%d %s: launched %s, expected %s" % (s.shape[0], precision, sorted(c.counts), sorted(want))
     assert not (other & set(c.counts)), "N=%d %s: kernels of the other mode ran: %s" % (s.shape[0], precision, sorted(c.counts))
     return q
@@ -206,6 +211,78 @@ def test_ffnet_vs_oracle_c(N, precision):
                              legal.ctypes.data_as(C.POINTER(C.c_float)), ref.ctypes.data_as(C.POINTER(C.c_float)))
     np.testing.assert_allclose(q, ref, rtol=RTOL, atol=ATOL)
     net.close()
+
+
+def _torch_cpu_forward(p, s, legal, dtype):
+    """the reference's own forward (pyrela/net.py:41-55) on the CPU in `dtype`: torch.float32 is the reference's
+    arithmetic, torch.float64 the ground truth both it and the GPU modes are measured against"""
+    import torch
+    import torch.nn.functional as F
+
+    N = s.shape[0]
+    t = {k: torch.from_numpy(v).to(dtype) for k, v in p.items()}
+    with torch.no_grad():
+        x = torch.from_numpy(s).to(dtype) / 255.0
+        x = F.relu(F.conv2d(x, t["net.0.weight"], t["net.0.bias"], stride=4))
+        x = F.relu(F.conv2d(x, t["net.2.weight"], t["net.2.bias"], stride=2))
+        x = F.relu(F.conv2d(x, t["net.4.weight"], t["net.4.bias"], stride=1))
+        h = F.relu(F.linear(x.reshape(N, 3136), t["linear.0.weight"], t["linear.0.bias"]))
+        v = F.linear(h, t["fc_v.weight"], t["fc_v.bias"])
+        a = F.linear(h, t["fc_a.weight"], t["fc_a.bias"]) * torch.from_numpy(legal).to(dtype)
+        return (v + a - a.mean(1, keepdim=True)).numpy()
+
+
+@pytest.mark.parametrize("N", [2048, 2051, 3000, 6400, 6554])
+def test_ffnet_f32x3_vs_torch_fp32(N):
+    """The f32-accurate bf16 mode (rela_ffnet_set_precision 2: conv2 / conv3 / fc with both operands as three bf16 parts,
+    gemm_f32emu.h) against torch-fp32 at the tolerance of the f32 mode, on ragged batch sizes from its first batch
+    size up (partial row tiles, waves with one tile less than their neighbours, the 4-then-3-tile pass mix), with
+    its kernels asserted through the launch census."""
+    from synth import synth_obs, synth_params
+
+    A = 18
+    p = synth_params(A, 79)
+    net = GpuNet(p, A)
+    s = synth_obs(N, 3000 + N)
+    rng = np.random.default_rng(N)
+    legal = (rng.uniform(size=(N, A)) < 0.8).astype(np.float32)
+    q = forward_checked(net, s, legal, "f32x3").cpu().numpy()
+    assert np.isfinite(q).all()
+    np.testing.assert_allclose(q, _torch_fp32_forward(p, s, legal), rtol=RTOL, atol=ATOL)
+    net.close()
+
+
+@pytest.mark.parametrize("scale", [1.0, 4.6])
+def test_ffnet_f32x3_is_f32_accurate(scale, record_property):
+    """What "f32-accurate" means, measured: against an f64 evaluation of the same network (torch CPU), the Q-values
+    of the f32x3 mode are as close as those of the exact-f32-MFMA mode AND as those of the reference's own f32 CPU
+    forward (torch CPU f32, pyrela/net.py:41-55) -- at a fresh initialisation and at a trained agent's |Q| of ~50
+    (every weight tensor x 4.6).  Measured r4 at |Q| <= 0.41: mean |error| 1.50e-8 (f32x3), 1.99e-8 (f32 MFMA), 1.49e-8
+    (torch CPU f32), 1.34e-7 (bf16x2).  The split-bf16 fast mode is several times further from f64 (asserted too, so
+    that this test would notice if "f32x3" silently ran the two-part kernels)."""
+    from synth import synth_obs, synth_params
+
+    A, N = 18, 2560
+    p = {k: (v * scale).astype(np.float32) for k, v in synth_params(A, 31).items()}
+    net = GpuNet(p, A)
+    s = synth_obs(N, 4242)
+    legal = np.ones((N, A), np.float32)
+    legal[::5, 3::4] = 0.0
+    q64 = _torch_cpu_forward(p, s, legal, __import__("torch").float64)
+    q32_cpu = _torch_cpu_forward(p, s, legal, __import__("torch").float32)
+    err = {"torch_cpu_f32": np.abs(q32_cpu - q64)}
+    for mode in ("f32", "f32x3", "bf16x2"):
+        err[mode] = np.abs(forward_checked(net, s, legal, mode).cpu().numpy().astype(np.float64) - q64)
+    net.close()
+    stats = {k: (float(v.max()), float(v.mean())) for k, v in err.items()}
+    for k, (mx, mean) in stats.items():
+        record_property("max_abs_err_vs_f64_" + k, mx)
+        record_property("mean_abs_err_vs_f64_" + k, mean)
+    record_property("max_abs_q", float(np.abs(q64).max()))
+    f32_like = max(stats["f32"][1], stats["torch_cpu_f32"][1])
+    assert stats["f32x3"][1] <= 1.25 * f32_like, stats  # mean error: no worse than f32 arithmetic's own
+    assert stats["f32x3"][0] <= 1.5 * max(stats["f32"][0], stats["torch_cpu_f32"][0]), stats
+    assert stats["bf16x2"][1] >= 4 * stats["f32x3"][1], stats  # the two-part mode is a different arithmetic (r4: 9 x)
 
 
 def test_ffnet_trained_scale_weights(record_property):
