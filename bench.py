@@ -84,8 +84,8 @@ DTYPE_NOTE = ("f32 results from split-bf16 MFMA (bf16 hi + lo operands = 16 sign
 # what the HIP Ape-X learner step computes in, per --precision (csrc/learner.hip)
 LEARNER_PRECISION_NOTE = {
     "f32": "f32 throughout (exact f32 MFMA forwards, f32 MFMA GEMM backward, f32 clip + RMSprop)",
-    "f32x3": "f32 throughout (exact f32 MFMA forwards, f32 MFMA GEMM backward, f32 clip + RMSprop): the f32x3 kernels serve "
-             "the actors' batches; a learner batch of 512 rows stays on the f32 MFMA kernels",
+    "f32x3": "f32 throughout: conv2 / conv3 of the three forwards on the f32-accurate three-part bf16 kernels (csrc/gemm_f32emu.h), "
+             "conv1 / fc / heads, f32 MFMA GEMM backward, clip + RMSprop as in the f32 mode",
     "bf16x2": "mixed: td_err's two gradient-free forwards (online(s'), target(s')) with conv trunk on split-bf16 MFMA; "
               "conv1 weight gradient and conv2 / conv3 data gradients on bf16 MFMA (hi + lo operands, f32 accumulate); "
               "online(s) forward whose activations / ReLU masks feed the backward, fc and head GEMMs, conv2 / conv3 weight "

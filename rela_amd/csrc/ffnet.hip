@@ -628,9 +628,11 @@ struct ConvFastCfg {
 };
 constexpr int kFastMinN = 1024;  // below this fc_bf16s has too few blocks and the f32 split-K fc is faster
 constexpr int kFastTrunkMinN = 128;  // from here up the split-bf16 convolutions beat the f32 ones
-// f32-accurate bf16 mode (precision 2, gemm_f32emu.h): its kernels want >= ~1 row tile per wave of the chip; smaller
-// batches run the exact f32 MFMA kernels (same accuracy).  Byte offsets inside a1 are 32-bit: 51,200 B per sample.
-constexpr int kEmuMinN = 2048, kEmuMaxN = 80000;
+// f32-accurate bf16 mode (precision 2, gemm_f32emu.h), per layer from the batch size at which it beats the exact f32 MFMA
+// kernel (measured r4, us emu / f32: conv2 25 / 33 and conv3 27 / 33 at 512 rows; fc is one 98-step pass per wave -- 95 us
+// at 512 rows, 115 at 3,200, 150 at 6,554 against 25 / 100 / 203); smaller batches run the f32 kernels (same accuracy,
+// same activation layout).  Byte offsets inside a1 are 32-bit: 51,200 B per sample.
+constexpr int kEmuConvMinN = 512, kEmuFcMinN = 4096, kEmuMaxN = 80000;
 // conv2: 20x20x32 -> 9x9x64, stride 2: 2*Q = 2, 2*RQ = 18 = 2 (mod 16)
 using Conv2F = ConvFastCfg<32, 20, 20, 4, 4, 2, 9, 9, 1, 9, 185, 20 * 185>;
 // conv3: 9x9x64 -> 7x7x64, stride 1: Q = 2, RQ = 14 (7 positions per row), SQ = 98 = 2 (mod 16)
@@ -2232,8 +2234,9 @@ int rela_amd::ffnet_load_impl(rela_ffnet* n, const rela_ffnet_params* p, int on_
     // only large batches read: Bf (f32 fragments, N >= kFcSplitBelow) and Bff (bf16 fragments, N >= kFastMinN)
     int64_t el[20];
     for (int jn = 0; jn < 20; ++jn) el[jn] = elems[jn];
-    // (... nor the layouts of the f32-accurate bf16 mode, which serves kEmuMinN rows and up)
-    if (n->max_rows > 0 && n->max_rows < kEmuMinN) el[17] = el[18] = el[19] = 0;
+    // (... nor the layouts of the f32x3 mode its batches are too small for)
+    if (n->max_rows > 0 && n->max_rows < kEmuConvMinN) el[17] = el[18] = 0;
+    if (n->max_rows > 0 && n->max_rows < kEmuFcMinN) el[19] = 0;
     if (n->max_rows > 0 && n->max_rows < kFcSplitBelow) el[4] = 0;
     if (n->max_rows > 0 && n->max_rows < kFastTrunkMinN) el[10] = 0;  // (the split-K fc_bf16s serves 128 rows and up)
     n->bft_stale = false;
@@ -2289,6 +2292,8 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
   const bool fast_trunk_only = precision == 1 && N < fast_min_n && N >= kFastTrunkMinN;
   // ... and (r3) fc too, as a split-K launch of fc_bf16s, when this net packs the bf16 fc fragments
   const bool fc_split_bf16 = fast_trunk_only && !(n->max_rows > 0 && n->max_rows < kFastTrunkMinN);
+  const bool emu_conv = precision == 2 && N >= kEmuConvMinN && N <= kEmuMaxN && !(n->max_rows > 0 && n->max_rows < kEmuConvMinN);
+  const bool emu_fc = precision == 2 && N >= kEmuFcMinN && N <= kEmuMaxN && !(n->max_rows > 0 && n->max_rows < kEmuFcMinN);
   if (fast_trunk_only) {
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
@@ -2343,29 +2348,6 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
       hipLaunchKernelGGL(fc_bf16s<FcFast>, fc_grid_xcd(ceil_div(N, FcFast::BM), 1), dim3(kThreads), FcFast::LDS_BYTES, s,
                            (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, h, N, 0);
     }
-  } else if (precision == 2 && N >= kEmuMinN && N <= kEmuMaxN && !(n->max_rows > 0 && n->max_rows < kEmuMinN)) {
-    // f32-accurate mode: conv1 exact as in the f32 mode (u8 frames x three-part weights), conv2 / conv3 / fc with BOTH
-    // operands in three bf16 parts and six products each; activations stay channel-last f32 between the layers
-    {
-      ProfScope prof(names[0], s);
-      note_launch("conv1_bf16x3"); hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
-                         d.B1, d.b1, a1, N);
-    }
-    {
-      ProfScope prof(names[1], s);
-      note_launch("gemm_f32emu<conv2>");
-      f32emu::launch<f32emu::ProbConv2, 6, 1>(a1, d.B2e, d.b2, a2, N * 81, s);
-    }
-    {
-      ProfScope prof(names[2], s);
-      note_launch("gemm_f32emu<conv3>");
-      f32emu::launch<f32emu::ProbConv3, 6, 1>(a2, d.B3e, d.b3, a3, N * 49, s);
-    }
-    {
-      ProfScope prof(names[3], s);
-      note_launch("gemm_f32emu<fc>");
-      f32emu::launch<f32emu::ProbFc, 6, 1>(a3, d.Bfe, d.bf, h, N, s);
-    }
   } else {
   if (!fast_trunk_only) {
   {
@@ -2373,17 +2355,34 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     note_launch("conv1_bf16x3"); hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
                        d.B1, d.b1, a1, N);
   }
+  // f32x3 mode (precision 2): conv2 / conv3 / fc with BOTH operands as three bf16 parts and six products each on the
+  // bf16 MFMA (gemm_f32emu.h), layer by layer from the batch size at which each beats its exact f32 MFMA kernel;
+  // activations stay channel-last f32 between the layers in either case, conv1 is exact as in the f32 mode
   {
     ProfScope prof(names[1], s);
-    launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
+    if (emu_conv) {
+      note_launch("gemm_f32emu<conv2>");
+      f32emu::launch<f32emu::ProbConv2, 6, 1>(a1, d.B2e, d.b2, a2, N * 81, s);
+    } else {
+      launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
+    }
   }
   {
     ProfScope prof(names[2], s);
-    launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
+    if (emu_conv) {
+      note_launch("gemm_f32emu<conv3>");
+      f32emu::launch<f32emu::ProbConv3, 6, 1>(a2, d.B3e, d.b3, a3, N * 49, s);
+    } else {
+      launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
+    }
   }
   }
   if (fc_split_bf16) {
     // (h is already there)
+  } else if (emu_fc) {
+    ProfScope prof(names[3], s);
+    note_launch("gemm_f32emu<fc>");
+    f32emu::launch<f32emu::ProbFc, 6, 1>(a3, d.Bfe, d.bf, h, N, s);
   } else if (N < kFcSplitBelow) {
     const int splits = fc_splits(N);
     float* part = ha + kHA * N;

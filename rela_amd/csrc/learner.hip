@@ -214,7 +214,7 @@ extern "C" int rela_apex_learner_load(rela_apex_learner* l, const rela_ffnet_par
 }
 
 extern "C" int rela_apex_learner_set_precision(rela_apex_learner* l, int mode) {
-  RELA_CHECK(l && (mode == 0 || mode == 1), RELA_EINVAL, "rela_apex_learner_set_precision: mode must be 0 or 1");
+  RELA_CHECK(l && mode >= 0 && mode <= 2, RELA_EINVAL, "rela_apex_learner_set_precision: mode must be 0, 1 or 2");
   int rc = rela_ffnet_set_precision(l->online, mode);
   if (rc != RELA_OK) return rc;
   return rela_ffnet_set_precision(l->target, mode);
@@ -318,7 +318,8 @@ extern "C" int rela_apex_learner_loss(rela_apex_learner* l, int batch, const voi
     if (rc != RELA_OK) return rc;
     rc = rela_ffnet_forward(l->target, Bn, nobs, nlegal, q_nt, l->ws_tmp, l->ws_bytes, s);
     if (rc != RELA_OK) return rc;
-    rc = ffnet_forward_mode(l->online, Bn, obs, legal, q_on, l->ws_on, l->ws_bytes, s, 0);  // f32: the backward reads a1..h
+    // f32 activations for the backward, which reads a1..h (the f32x3 mode keeps that layout: it may serve this pass too)
+    rc = ffnet_forward_mode(l->online, Bn, obs, legal, q_on, l->ws_on, l->ws_bytes, s, rela_ffnet_precision(l->online) == 2 ? 2 : 0);
     if (rc != RELA_OK) return rc;
   }
   if (Bn <= 1024) {

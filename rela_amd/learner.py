@@ -147,9 +147,9 @@ class HipApexLearner:
 
     def set_precision(self, mode):
         """"f32" (default) or "bf16x2": the arithmetic of the two gradient-free forwards of td_err (the pass whose
-        activations feed the backward kernels stays f32).  "f32x3" (the actors' f32-accurate bf16 mode, whose kernels
-        start at 2,048 rows) leaves the learner -- a batch of 512 -- on the exact f32 MFMA kernels."""
-        self._capi.check(self._capi.lib.rela_apex_learner_set_precision(self.h, {"f32": 0, "bf16x2": 1, "f32x3": 0}[mode]),
+        activations feed the backward kernels stays f32).  "f32x3": conv2 / conv3 of all three forwards on the f32-accurate
+        bf16 kernels (csrc/gemm_f32emu.h, from 512 rows); fc, heads, loss, backward and optimiser in exact f32."""
+        self._capi.check(self._capi.lib.rela_apex_learner_set_precision(self.h, {"f32": 0, "bf16x2": 1, "f32x3": 2}[mode]),
                          "rela_apex_learner_set_precision")
 
     def flat_target(self):

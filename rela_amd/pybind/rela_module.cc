@@ -358,11 +358,17 @@ class ModelLocker {
     return out;
   }
 
-  // RELA_PRECISION=bf16x2: the actors' conv trunks on split-bf16 MFMA (Q within 2e-6 of the default exact f32 mode,
-  // DESIGN 4.3b); anything else keeps the parity mode
-  bool fastPrecision() const {
+  // RELA_PRECISION: "f32x3" = conv2 / conv3 / fc of the AtariFFNet actors with f32 operands as three exact bf16 parts on the
+  // bf16 matrix cores (f32 accuracy, csrc/gemm_f32emu.h; batches below 2,048 rows and the recurrent net keep the f32
+  // MFMA kernels); "bf16x2" = the fast mode (two bf16 parts: 16-bit significands, |dQ| < 2e-5 max|Q|);
+  // anything else = exact f32 MFMA.  "cpu" lockers: always exact f32.
+  int precisionMode(bool recurrent) const {
     const char* e = std::getenv("RELA_PRECISION");
-    return deviceIndex >= 0 && e && std::string(e) == "bf16x2";  // ("cpu" lockers: always the f32 parity mode)
+    if (deviceIndex < 0 || !e) return 0;
+    const std::string m(e);
+    if (m == "bf16x2") return 1;
+    if (m == "f32x3") return recurrent ? 0 : 2;
+    return 0;
   }
 
   void loadNet(void*& net, py::dict& sd, const std::string& prefix) {
@@ -376,7 +382,7 @@ class ModelLocker {
       auto* n = static_cast<rela_ffnet*>(net);
       if (!n) {
         check(rela_ffnet_create(&n, A, execDevice), "rela_ffnet_create");
-        check(rela_ffnet_set_precision(n, fastPrecision() ? 1 : 0), "rela_ffnet_set_precision");
+        check(rela_ffnet_set_precision(n, precisionMode(false)), "rela_ffnet_set_precision");
       }
       net = n;
       auto f = [&](int i) { return t[i].data_ptr<float>(); };
@@ -391,7 +397,7 @@ class ModelLocker {
       auto* n = static_cast<rela_lstmnet*>(net);
       if (!n) {
         check(rela_lstmnet_create(&n, A, execDevice), "rela_lstmnet_create");
-        check(rela_lstmnet_set_precision(n, fastPrecision() ? 1 : 0), "rela_lstmnet_set_precision");
+        check(rela_lstmnet_set_precision(n, precisionMode(true)), "rela_lstmnet_set_precision");
       }
       net = n;
       auto f = [&](int i) { return t[i].data_ptr<float>(); };

@@ -65,16 +65,16 @@ class GpuNet:
 # tests of the split-bf16 mode assert this through the launch census (rela_prof_count_enable), so a silent fall-back
 # to the f32 kernels -- what a batch below 128 rows gets, by design -- cannot pass for a test of the fast kernels.
 FAST_TRUNK_MIN_N, FAST_FC_MIN_N = 128, 1024
-EMU_MIN_N = 2048  # csrc/ffnet.hip kEmuMinN: below it the "f32x3" mode runs the exact f32 MFMA kernels
-EMU_KERNELS = {"gemm_f32emu<conv2>", "gemm_f32emu<conv3>", "gemm_f32emu<fc>"}
+# csrc/ffnet.hip kEmuConvMinN / kEmuFcMinN: below them the "f32x3" mode runs that layer's exact f32 MFMA kernel
+EMU_CONV_MIN_N, EMU_FC_MIN_N = 512, 4096
 
 
 def expected_kernels(N, precision):
     if precision == "bf16x2" and N >= FAST_TRUNK_MIN_N:
         trunk = {CONV12, "conv_bf16s<Conv3F>"}
         return trunk | ({"fc_bf16s"} if N >= FAST_FC_MIN_N else {"fc_bf16s (split-K)"})
-    if precision == "f32x3" and N >= EMU_MIN_N:
-        return {"conv1_bf16x3"} | EMU_KERNELS
+    if precision == "f32x3" and N >= EMU_CONV_MIN_N:
+        return {"conv1_bf16x3", "gemm_f32emu<conv2>", "gemm_f32emu<conv3>"} | ({"gemm_f32emu<fc>"} if N >= EMU_FC_MIN_N else set())
     return {"conv1_bf16x3", "conv_mfma<Conv2> (f32)", "conv_mfma<Conv3> (f32)"}
 
 
@@ -232,7 +232,7 @@ def _torch_cpu_forward(p, s, legal, dtype):
         return (v + a - a.mean(1, keepdim=True)).numpy()
 
 
-@pytest.mark.parametrize("N", [2048, 2051, 3000, 6400, 6554])
+@pytest.mark.parametrize("N", [512, 515, 1000, 2051, 4096, 4100, 6400, 6554])
 def test_ffnet_f32x3_vs_torch_fp32(N):
     """The f32-accurate bf16 mode (rela_ffnet_set_precision 2: conv2 / conv3 / fc with both operands as three bf16 parts,
     gemm_f32emu.h) against torch-fp32 at the tolerance of the f32 mode, on ragged batch sizes from its first batch
@@ -262,7 +262,7 @@ def test_ffnet_f32x3_is_f32_accurate(scale, record_property):
     that this test would notice if "f32x3" silently ran the two-part kernels)."""
     from synth import synth_obs, synth_params
 
-    A, N = 18, 2560
+    A, N = 18, 4200
     p = {k: (v * scale).astype(np.float32) for k, v in synth_params(A, 31).items()}
     net = GpuNet(p, A)
     s = synth_obs(N, 4242)

@@ -57,8 +57,11 @@ def make_agent(A, seed, multi_step=3, gamma=0.99):
     return agent
 
 
+@pytest.mark.parametrize("precision", ["f32", "f32x3"])
 @pytest.mark.parametrize("B,A", [(32, 6), (512, 18), (100, 18)])
-def test_loss_priority_and_gradients_match_autograd(B, A):
+def test_loss_priority_and_gradients_match_autograd(B, A, precision):
+    """(f32x3: from 512 rows conv2 / conv3 of the three forwards run on the f32-accurate three-part bf16 kernels,
+    csrc/gemm_f32emu.h -- asserted through the launch census; same tolerances as the exact f32 mode.)"""
     import torch
 
     from rela_amd.learner import HipApexLearner
@@ -68,7 +71,16 @@ def test_loss_priority_and_gradients_match_autograd(B, A):
     agent = make_agent(A, 3)
     batch, w = make_batch(B, A, 11)
     learner = HipApexLearner.from_agent(agent, B)
-    loss, prio = learner.backward(batch, w)
+    learner.set_precision(precision)
+    from rela_amd import _capi as capi
+
+    with capi.launch_census() as census:
+        loss, prio = learner.backward(batch, w)
+    emu = {"gemm_f32emu<conv2>", "gemm_f32emu<conv3>"}
+    if precision == "f32x3" and B >= 512:
+        assert emu <= set(census.counts) and census.counts["gemm_f32emu<conv2>"] == 3, census.counts
+    else:
+        assert not (emu & set(census.counts)), census.counts
     per_sample, ref_prio = agent.loss(batch, sync_priority=False)
     ref_loss = (per_sample * w).mean()
     ref_loss.backward()
@@ -386,7 +398,7 @@ def test_learner_errors():
     learner.close()
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x2"])
+@pytest.mark.parametrize("precision", ["f32", "f32x3", "bf16x2"])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "learner_*.json"))), ids=os.path.basename)
 def test_learner_step_matches_the_reference_golden(path, precision):
     """One learner step against vectors recorded from the REAL reference on CPU
