@@ -45,6 +45,8 @@ CFG_BIG = dict(K=128, multi_step=3, gamma=0.997, capacity=512, alpha=0.6, beta=0
 # the same 128 envs as a COHORT of this repo's module: 2 threads x 64 envs (one 128-row device shard, q.min() and replay
 # blocks per group of 64)
 CFG_COHORT = dict(CFG_BIG, K=64, threads=2)
+# four threads x 128 envs: ONE 512-row shard -- the batch size from which the f32x3 mode's conv kernels run
+CFG_COHORT_512 = dict(CFG_BIG, K=128, threads=4, capacity=2048, batch=64, rounds=4)
 
 
 def frames_of_run(synth_atari, cfg, steps):

@@ -266,6 +266,40 @@ def test_cohort_in_fast_mode_agrees_with_the_f32_cohort(mods, dedup_env, precisi
         np.testing.assert_allclose(a["weight"], b["weight"], rtol=2e-3, err_msg="IS weights, round %d" % r)
 
 
+def test_cohort_in_f32x3_mode_agrees_with_the_f32_cohort(mods, dedup_env, precision_env):
+    """RELA_PRECISION=f32x3 end to end: a cohort of 4 threads x 128 envs (one 512-row shard: from there conv2 / conv3 of the
+    actors' forwards run on the three-part bf16 kernels, csrc/gemm_f32emu.h -- asserted through the launch census)
+    against the same cohort in the exact f32 mode, in lock step: every sampled batch holds the same rows, actions,
+    n-step rewards and flags, and the IS weights (functions of the TD priorities) agree to 1e-5 -- f32 round-off, not
+    the fast mode's 2e-3."""
+    from e2e_lockstep import CFG_COHORT_512 as C, load_agent_params, run_lockstep
+    from rela_amd import _capi as capi
+    from rela_amd.pyrela.apex import ApexAgent
+    from rela_amd.pyrela.net import AtariFFNet
+
+    rela, synth = mods
+    dedup_env(None)
+    emu = {"gemm_f32emu<conv2>", "gemm_f32emu<conv3>"}
+    runs = {}
+    for precision in ("f32", "f32x3"):
+        precision_env(precision)
+        agent = load_agent_params(ApexAgent(lambda: AtariFFNet(18), 3, 0.997), C)
+        with capi.launch_census() as census:
+            runs[precision] = run_lockstep(rela, synth, agent, "cuda:0", "cuda:0", C)
+        ran = set(census.counts)
+        f32_convs = F32_KERNELS - {"conv1_bf16x3"}  # (conv1 is the same exact kernel in both modes)
+        if precision == "f32x3":
+            assert emu <= ran and not (f32_convs & ran), census.counts
+        else:
+            assert F32_KERNELS <= ran and not (emu & ran), census.counts
+    assert len(runs["f32"]) == len(runs["f32x3"]) == C["rounds"]
+    for r, (a, b) in enumerate(zip(runs["f32"], runs["f32x3"])):
+        for key in ("s_sum", "s_head", "next_s_sum", "a", "terminal", "bootstrap", "eps", "legal_sum", "num_add"):
+            assert a[key] == b[key], (r, key)
+        assert np.array_equal(np.float32(a["reward"]), np.float32(b["reward"])), r
+        np.testing.assert_allclose(a["weight"], b["weight"], rtol=1e-5, err_msg="IS weights, round %d" % r)
+
+
 @pytest.mark.parametrize("hip_learner", [1, 0])
 def test_training_entry_point_runs(mods, capsys, hip_learner):
     """pyrela-style main loop on 2 threads x 8 envs for two tiny epochs: actors insert from C++
