@@ -55,12 +55,29 @@ __device__ __forceinline__ void split4(float4 v, uint2& hi, uint2& lo) {
   lo = make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
 }
 
+// four floats -> hi, mid, lo (each 4 bf16): x = hi + mid + lo up to 2^-26 |x| (both subtractions are exact in f32)
+__device__ __forceinline__ void split4x3(float4 v, uint2& hi, uint2& mid, uint2& lo) {
+  const f32x2 a = {v.x, v.y}, b = {v.z, v.w};
+  const bf16x2 ha = __builtin_convertvector(a, bf16x2), hb = __builtin_convertvector(b, bf16x2);
+  const f32x2 ra = a - __builtin_convertvector(ha, f32x2), rb = b - __builtin_convertvector(hb, f32x2);
+  const bf16x2 ma = __builtin_convertvector(ra, bf16x2), mb = __builtin_convertvector(rb, bf16x2);
+  const bf16x2 la = __builtin_convertvector(ra - __builtin_convertvector(ma, f32x2), bf16x2);
+  const bf16x2 lb = __builtin_convertvector(rb - __builtin_convertvector(mb, f32x2), bf16x2);
+  hi = make_uint2(__builtin_bit_cast(uint32_t, ha), __builtin_bit_cast(uint32_t, hb));
+  mid = make_uint2(__builtin_bit_cast(uint32_t, ma), __builtin_bit_cast(uint32_t, mb));
+  lo = make_uint2(__builtin_bit_cast(uint32_t, la), __builtin_bit_cast(uint32_t, lb));
+}
+
 // AMC as in gemm_lds.h: true = loadA(k, m) returns A[m..m+3][k] (m-contiguous, k-major image, transposed reads);
 // false = loadA(m, k) returns A[m][k..k+3] (k-contiguous, [m][k] image, row reads).  B: loadB(k, n) -> B[k][n..n+3].
-template <int BM_, int BN_, int WM_, int WN_, bool AMC_>
+// PARTS = 2: the split-bf16 fast arithmetic above.  PARTS = 3: every f32 operand as THREE bf16 parts (hi, mid, lo: an exact
+// split, see gemm_f32emu.h) and the six products with i + j <= 2, the five small ones in accumulators of their own:
+// f32 accuracy at 16 / 6 the f32 MFMA rate -- the learner's GEMMs of the f32x3 mode.
+template <int BM_, int BN_, int WM_, int WN_, bool AMC_, int PARTS_ = 2>
 struct TileCfg {
-  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, PARTS = PARTS_;
   static constexpr bool AMC = AMC_;
+  static_assert(PARTS == 2 || PARTS == 3, "two or three bf16 parts per operand");
   static_assert(WM * WN == 8, "8 wavefronts per block");
   static_assert(BM % 32 == 0 && BN % 32 == 0, "k-major row strides need multiples of 32 columns");
   static constexpr int TM = BM / 16 / WM, TN = BN / 16 / WN;  // 16x16 tiles per wave
@@ -69,7 +86,7 @@ struct TileCfg {
   static constexpr int A_HALF = AMC ? BK * LDA : BM * LDA;     // bytes of one of hi / lo
   static constexpr int LDB = BN * 2 + 32;
   static constexpr int B_HALF = BK * LDB;
-  static constexpr int BUF = 2 * A_HALF + 2 * B_HALF;          // one stage
+  static constexpr int BUF = PARTS * (A_HALF + B_HALF);        // one stage: A parts, then B parts
   static constexpr int LDS_BYTES = 2 * BUF;
   static constexpr int A_V4 = BM * BK / 4, B_V4 = BN * BK / 4;
   static constexpr int A_IT = (A_V4 + kT - 1) / kT, B_IT = (B_V4 + kT - 1) / kT;
@@ -148,8 +165,9 @@ __global__ __launch_bounds__(kT) void gemm_bf16x3(const P p, const GridMap gm) {
 #pragma unroll
     for (int j = 0; j < T::A_IT; ++j) {
       const int idx = min(tid + j * kT, T::A_V4 - 1);
-      uint2 hi, lo;
-      split4(ra[S][j], hi, lo);
+      uint2 hi, mid, lo;
+      if constexpr (T::PARTS == 3) split4x3(ra[S][j], hi, mid, lo);
+      else split4(ra[S][j], hi, lo);
       int off;
       if constexpr (T::AMC) {
         const int kr = idx / (T::BM / 4), q = idx % (T::BM / 4);
@@ -159,18 +177,21 @@ __global__ __launch_bounds__(kT) void gemm_bf16x3(const P p, const GridMap gm) {
         off = r * T::LDA + q * 8;
       }
       *reinterpret_cast<uint2*>(base + off) = hi;
-      *reinterpret_cast<uint2*>(base + T::A_HALF + off) = lo;
+      if constexpr (T::PARTS == 3) *reinterpret_cast<uint2*>(base + T::A_HALF + off) = mid;
+      *reinterpret_cast<uint2*>(base + (T::PARTS - 1) * T::A_HALF + off) = lo;
     }
-    uint8_t* bb = base + 2 * T::A_HALF;
+    uint8_t* bb = base + T::PARTS * T::A_HALF;
 #pragma unroll
     for (int j = 0; j < T::B_IT; ++j) {
       const int idx = min(tid + j * kT, T::B_V4 - 1);
       const int kr = idx / (T::BN / 4), q = idx % (T::BN / 4);
-      uint2 hi, lo;
-      split4(rb[S][j], hi, lo);
+      uint2 hi, mid, lo;
+      if constexpr (T::PARTS == 3) split4x3(rb[S][j], hi, mid, lo);
+      else split4(rb[S][j], hi, lo);
       const int off = krow(kr) * T::LDB + q * 8;
       *reinterpret_cast<uint2*>(bb + off) = hi;
-      *reinterpret_cast<uint2*>(bb + T::B_HALF + off) = lo;
+      if constexpr (T::PARTS == 3) *reinterpret_cast<uint2*>(bb + T::B_HALF + off) = mid;
+      *reinterpret_cast<uint2*>(bb + (T::PARTS - 1) * T::B_HALF + off) = lo;
     }
   };
 
@@ -190,10 +211,14 @@ __global__ __launch_bounds__(kT) void gemm_bf16x3(const P p, const GridMap gm) {
   };
 
   f32x4 acc[T::TM][T::TN];
+  f32x4 accs[T::PARTS == 3 ? T::TM : 1][T::PARTS == 3 ? T::TN : 1];  // (three parts: the five small terms)
 #pragma unroll
   for (int t = 0; t < T::TM; ++t)
 #pragma unroll
-    for (int u = 0; u < T::TN; ++u) acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < T::TN; ++u) {
+      acc[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (T::PARTS == 3) accs[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
@@ -211,30 +236,37 @@ __global__ __launch_bounds__(kT) void gemm_bf16x3(const P p, const GridMap gm) {
     const int buf = (cur - c0) & 1;
     if (cur + D < c1) gload(cur + D, cs);
     const uint8_t* base = smem + buf * T::BUF;
-    const uint8_t* bb = base + 2 * T::A_HALF;
-    bf16x8 bh[T::TN], bl[T::TN];
+    const uint8_t* bb = base + T::PARTS * T::A_HALF;
+    bf16x8 bp[T::TN][T::PARTS];  // [..][0] = hi ... [..][PARTS - 1] = lo
 #pragma unroll
     for (int u = 0; u < T::TN; ++u) {
       const int col0 = (wn * T::TN + u) * 16;
-      bh[u] = frag_tr(bb, T::LDB, col0);
-      bl[u] = frag_tr(bb + T::B_HALF, T::LDB, col0);
+#pragma unroll
+      for (int q = 0; q < T::PARTS; ++q) bp[u][q] = frag_tr(bb + q * T::B_HALF, T::LDB, col0);
     }
 #pragma unroll
     for (int t = 0; t < T::TM; ++t) {
       const int row0 = (wm * T::TM + t) * 16;
-      bf16x8 ah, al;
-      if constexpr (T::AMC) {
-        ah = frag_tr(base, T::LDA, row0);
-        al = frag_tr(base + T::A_HALF, T::LDA, row0);
-      } else {
-        ah = frag_row(base, row0 + li);
-        al = frag_row(base + T::A_HALF, row0 + li);
+      bf16x8 ap[T::PARTS];
+#pragma unroll
+      for (int q = 0; q < T::PARTS; ++q) {
+        if constexpr (T::AMC) ap[q] = frag_tr(base + q * T::A_HALF, T::LDA, row0);
+        else ap[q] = frag_row(base + q * T::A_HALF, row0 + li);
       }
 #pragma unroll
       for (int u = 0; u < T::TN; ++u) {
-        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[u], acc[t][u], 0, 0, 0);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[u], acc[t][u], 0, 0, 0);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[u], acc[t][u], 0, 0, 0);
+        if constexpr (T::PARTS == 2) {
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[1], bp[u][0], acc[t][u], 0, 0, 0);
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0], bp[u][1], acc[t][u], 0, 0, 0);
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0], bp[u][0], acc[t][u], 0, 0, 0);
+        } else {  // (a part, b part) with i + j <= 2, smallest first; hi * hi alone in the main accumulator
+          accs[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[2], bp[u][0], accs[t][u], 0, 0, 0);
+          accs[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0], bp[u][2], accs[t][u], 0, 0, 0);
+          accs[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[1], bp[u][1], accs[t][u], 0, 0, 0);
+          accs[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[1], bp[u][0], accs[t][u], 0, 0, 0);
+          accs[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0], bp[u][1], accs[t][u], 0, 0, 0);
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ap[0], bp[u][0], acc[t][u], 0, 0, 0);
+        }
       }
     }
     if (cur + 1 < c1) sstore(buf ^ 1, ns);
@@ -255,7 +287,10 @@ __global__ __launch_bounds__(kT) void gemm_bf16x3(const P p, const GridMap gm) {
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + (wm * T::TM + t) * 16 + g * 4 + r;
         const int n = n0 + (wn * T::TN + u) * 16 + li;
-        if (m < p.M && n < p.N) p.store(bz, m, n, acc[t][u][r]);
+        if (m < p.M && n < p.N) {
+          if constexpr (T::PARTS == 3) p.store(bz, m, n, acc[t][u][r] + accs[t][u][r]);
+          else p.store(bz, m, n, acc[t][u][r]);
+        }
       }
 }
 

@@ -358,6 +358,7 @@ extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
 
   ColsumJobs sums;  // the five bias gradients: queued here, one launch pair at the end of trunk_backward
   const bool g3 = rela_ffnet_precision(l->online) == 1 && gemm_bf16x3_on();  // bf16x2: the GEMMs on bf16 MFMA too
+  const bool g6 = rela_ffnet_precision(l->online) == 2;  // f32x3: ... with three-part operands (f32 accuracy)
   const bool lanes = l->side != nullptr;
   hipStream_t sw = lanes ? l->side : s;  // the weight-gradient lane
   if (lanes) lane_dep(l->ev[2], s, sw);  // d_ha and the forward's activations are ready
@@ -368,6 +369,7 @@ extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
     p.M = Bn, p.N = 512, p.K = 32;
     p.d_ha = l->d_ha, p.a_w = P.a_w, p.v_w = P.v_w, p.h = w.h, p.d_h = l->d_h, p.A = A;
     if (g3) (void)gemm3::launch_gemm<Tile3Dgrad>(p, 1, s, "learner_dgrad_heads");
+    else if (g6) (void)gemm3::launch_gemm<Tile6Dgrad>(p, 1, s, "learner_dgrad_heads");
     else launch_gemm<TileDgrad>(p, 1, s, "learner_dgrad_heads");
   }
   {
@@ -375,6 +377,7 @@ extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
     p.M = 32, p.N = 512, p.K = Bn;
     p.d_ha = l->d_ha, p.h = w.h, p.g_a_w = Gm[10], p.g_v_w = Gm[8], p.A = A;
     if (g3) (void)gemm3::launch_gemm<Tile3W32>(p, 1, sw, "learner_wgrad_heads");
+    else if (g6) (void)gemm3::launch_gemm<Tile6W32>(p, 1, sw, "learner_wgrad_heads");
     else launch_gemm<TileW32>(p, 1, sw, "learner_wgrad_heads");
   }
   sums.add(l->d_ha, Bn, 32, l->s32);
@@ -385,6 +388,7 @@ extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
     p.M = Bn, p.N = 3136, p.K = 512;
     p.d_h = l->d_h, p.wfcp = l->wfcp, p.a3 = w.a3, p.d_a3 = l->d_a3;
     if (g3) (void)gemm3::launch_gemm<Tile3Dgrad>(p, 1, s, "learner_dgrad_fc");
+    else if (g6) (void)gemm3::launch_gemm<Tile6Dgrad>(p, 1, s, "learner_dgrad_fc");
     else launch_gemm<TileDgrad>(p, 1, s, "learner_dgrad_fc");
   }
   {
@@ -392,6 +396,7 @@ extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
     p.M = 512, p.N = 3136, p.K = Bn;
     p.d_h = l->d_h, p.a3 = w.a3, p.g_fc_w = Gm[6];
     if (g3) (void)gemm3::launch_gemm<Tile3Wfc>(p, 1, sw, "learner_wgrad_fc");
+    else if (g6) (void)gemm3::launch_gemm<Tile6Wfc>(p, 1, sw, "learner_wgrad_fc");
     else launch_gemm<TileWfc>(p, 1, sw, "learner_wgrad_fc");
   }
   sums.add(l->d_h, Bn, 512, Gm[7]);
@@ -401,6 +406,7 @@ extern "C" int rela_apex_learner_grad(rela_apex_learner* l, void* stream_) {
     t.col = l->col, t.part = l->part, t.cpart = l->cpart, t.w2p = l->w2p, t.w3p = l->w3p;
     t.g_c1w = Gm[0], t.g_c1b = Gm[1], t.g_c2w = Gm[2], t.g_c2b = Gm[3], t.g_c3w = Gm[4], t.g_c3b = Gm[5];
     t.fast = rela_ffnet_precision(l->online) == 1;
+    t.emu = g6;
     if (lanes) {
       t.side = sw, t.ev_da3 = l->ev[4], t.ev_da2 = l->ev[5], t.ev_side = l->ev[6];
       t.part_side = l->part_side, t.cpart_side = l->cpart_side;

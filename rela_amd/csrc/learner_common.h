@@ -33,6 +33,12 @@ using Tile3Wfc = gemm3::TileCfg<128, 64, 4, 2, true>;
 using Tile3W64 = gemm3::TileCfg<64, 64, 2, 4, true>;
 using Tile3W32 = gemm3::TileCfg<32, 64, 2, 4, true>;
 inline bool gemm_bf16x3_on() { return true; }
+// ... and with every operand as THREE bf16 parts, six products (gemm_bf16x3.h, PARTS = 3): f32 accuracy on the bf16 MFMA --
+// the learners' f32x3 mode
+using Tile6Dgrad = gemm3::TileCfg<128, 64, 4, 2, false, 3>;
+using Tile6Wfc = gemm3::TileCfg<128, 64, 4, 2, true, 3>;
+using Tile6W64 = gemm3::TileCfg<64, 64, 2, 4, true, 3>;
+using Tile6W32 = gemm3::TileCfg<32, 64, 2, 4, true, 3>;
 
 
 // d_h[b][u] = relu'(h) * sum_k d_ha[b][k] * Wh[k][u]      Wh rows: 0..A-1 = fc_a.weight, 31 = fc_v.weight
@@ -563,6 +569,9 @@ struct TrunkBwd {
   const float *w2p, *w3p;  // conv2 / conv3 weights in dgrad k order (permute_weights)
   float *g_c1w, *g_c1b, *g_c2w, *g_c2b, *g_c3w, *g_c3b;  // gradients, state_dict layout
   bool fast = false;   // the learner's bf16x2 mode: conv1's weight gradient on bf16 MFMA
+  // the f32x3 mode: the weight-gradient GEMMs below (contraction over batch x positions) on the bf16 MFMA with three-part
+  // operands, f32 accuracy (r4 at 512 frames, us f32 -> three-part: conv3 49 -> 35, conv2 63 -> 52, conv1 110 -> 102)
+  bool emu = false;
   // Two-lane form (the Ape-X learner): conv3's and conv2's weight gradients, and the column sums of every tensor that
   // exists by then (the caller's pending jobs, d_a3, d_a2), run on `side` next to the data-gradient chain on the
   // caller's stream; the caller's stream waits for the side lane before trunk_backward returns.  Every kernel computes
@@ -632,6 +641,7 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     static const int mul = 3  /* (<= 8: what kTrunkPartFloats holds; flat between 2 and 4 in the r3 sweep) */;
     const int split3 = Bn <= 1024 ? kSplitW3 * mul : kSplitW3;
     if (t.fast && gemm_bf16x3_on()) (void)gemm3::launch_gemm<Tile3W64>(p, split3, sw, "learner_wgrad_conv3");
+    else if (t.emu) (void)gemm3::launch_gemm<Tile6W64>(p, split3, sw, "learner_wgrad_conv3");
     else launch_gemm<TileW64>(p, split3, sw, "learner_wgrad_conv3");
     hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 576, 256)), dim3(256), 0, sw, (const float*)partw, split3, 64,
                        576, kRedConv3, t.g_c3w);
@@ -644,7 +654,7 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     ProbConvDgrad p{};
     p.M = Bn * 49, p.N = 576, p.K = 64;
     p.d_out = t.d_a3, p.wp = t.w3p, p.col = t.col;
-    launch_gemm<TileDgrad>(p, 1, s, "learner_dgrad_conv3");
+    launch_gemm<TileDgrad>(p, 1, s, "learner_dgrad_conv3");  // (f32x3: K = 64 -- the three-part GEMM measured 89 against 62 us)
     ProfScope prof("learner_col2im", s);
     hipLaunchKernelGGL(col2im3, dim3(ceil_div((int64_t)Bn * 81 * 16, 256)), dim3(256), 0, s, (const float*)t.col, t.a2,
                        t.d_a2, Bn);
@@ -665,6 +675,7 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     static const int mul = 3  /* (<= 8: what kTrunkPartFloats holds; flat between 2 and 4 in the r3 sweep) */;
     const int split2 = Bn <= 1024 ? kSplitW2 * mul : kSplitW2;
     if (t.fast && gemm_bf16x3_on()) (void)gemm3::launch_gemm<Tile3W64>(p, split2, sw, "learner_wgrad_conv2");
+    else if (t.emu) (void)gemm3::launch_gemm<Tile6W64>(p, split2, sw, "learner_wgrad_conv2");
     else launch_gemm<TileW64>(p, split2, sw, "learner_wgrad_conv2");
     hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(64 * 512, 256)), dim3(256), 0, sw, (const float*)partw, split2, 64,
                        512, kRedConv2, t.g_c2w);
@@ -682,7 +693,7 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     ProbConvDgrad p{};
     p.M = Bn * 81, p.N = 512, p.K = 64;
     p.d_out = t.d_a2, p.wp = t.w2p, p.col = t.col;
-    launch_gemm<TileDgrad>(p, 1, s, "learner_dgrad_conv2");
+    launch_gemm<TileDgrad>(p, 1, s, "learner_dgrad_conv2");  // (f32x3: 88 against 77 us, as above)
     ProfScope prof("learner_col2im", s);
     hipLaunchKernelGGL(col2im2, dim3(ceil_div((int64_t)Bn * 400 * 8, 256)), dim3(256), 0, s, (const float*)t.col, t.a1,
                        t.d_a1, Bn);
@@ -699,7 +710,8 @@ inline void trunk_backward(const TrunkBwd& t, hipStream_t s, ColsumJobs* pending
     ProbW1 p{};
     p.M = 32, p.N = 256, p.K = Bn * 400;
     p.d_out = t.d_a1, p.obs = t.obs, p.part = t.part;
-    launch_gemm<TileW32>(p, kSplitW1, s, "learner_wgrad_conv1");
+    if (t.emu) (void)gemm3::launch_gemm<Tile6W32>(p, kSplitW1, s, "learner_wgrad_conv1");
+    else launch_gemm<TileW32>(p, kSplitW1, s, "learner_wgrad_conv1");
     hipLaunchKernelGGL(reduce_splits, dim3(ceil_div(32 * 256, 256)), dim3(256), 0, s, (const float*)t.part, kSplitW1, 32,
                        256, kRedConv1, t.g_c1w);
   }
