@@ -24,11 +24,15 @@ One STEP = what the reference does per env-step of every actor thread plus one l
       -> clip 40 -> RMSprop -> update_priority, hand-written HIP (csrc/learner.hip; RELA_BENCH_LEARNER=torch
       runs PyTorch autograd instead); actor weights re-published every 20 steps, target net every 2,500.
 
-Arithmetic: `--precision f32` (the default since round 4) is the reference's arithmetic -- exact f32 MFMA for the actors'
-forwards and the whole learner step -- and is what `value` reports; `--precision bf16x2` is the fast mode (split-bf16
-MFMA: every operand as bf16 hi + lo, f32 accumulation, conv1 on the int8 matrix cores fused with conv2 through LDS;
-|dQ| < 2e-5 max|Q| against the f32 path).  Either way ONE run times four regions of the same K steps:
-f32_mode, strict (f32 AND all 4 forwards of the reference), fast_mode, fast_no_reuse.
+Arithmetic: three modes, all timed by ONE run as regions of the same K steps (`summary`), `value` = the one `--precision`
+names.  `f32x3` (the default): f32 results at f32 accuracy from the bf16 matrix cores -- conv2 / conv3 / fc of the
+actors' forwards (and the learner's conv forwards and weight-gradient GEMMs) take every f32 operand as THREE exact bf16
+parts and six products with f32 accumulation (csrc/gemm_f32emu.h); against an f64 evaluation its Q-values are as close
+as the exact-f32-MFMA kernels' and as torch CPU f32's (tests/test_ffnet_gpu.py::test_ffnet_f32x3_is_f32_accurate).
+`f32`: exact f32 MFMA (v_mfma_f32_16x16x4_f32) for the actors' forwards and the whole learner step.  `bf16x2`: the fast
+mode (two bf16 parts per operand = 16-bit significands, conv1 on the int8 matrix cores fused with conv2 through LDS;
+|dQ| < 2e-5 max|Q| against the f32 path) -- a narrower arithmetic, never `value` unless asked for.
+Regions: f32x3_mode, f32x3_strict (all 4 forwards of the reference), f32_mode, strict, fast_mode, fast_no_reuse.
 
 Output (rank 0): ONE compact JSON line on stdout (<= 1,900 characters: the driver keeps the last 2,000 of stdout) with the
 contract's keys, `roofline` (live HIP events around the dominant forward kernel inside the timed region, both the
@@ -518,6 +522,8 @@ def bench_r2d2(args, world, rank, device):
     window bookkeeping branches on them (rela/r2d2_actor.h:29-87)."""
     import torch.distributed as dist
 
+    if args.precision == "f32x3":  # an AtariFFNet mode: the recurrent net's kernels have the exact f32 and the bf16x2 mode
+        args.precision = "f32"
     from rela_amd import _capi as capi
     from rela_amd.engine import LSTMNetHandle, R2D2ActorEngine
     from rela_amd.learner import HipR2D2Learner
@@ -1010,12 +1016,13 @@ def main():
                     help="frame-stack de-duplication in the replay (SURVEY 8f-3): stack = 28,224 B per env-step, plane = "
                          "7,056 B (the frames of this bench are static, so only the byte traffic is representative); "
                          "default: s and next_s stored in full (56,448 B), as in round 1's headline")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f32x3", "bf16x2"],
-                    help="arithmetic of the headline region (`value`): f32 (default) = the reference's arithmetic, exact "
-                         "f32 MFMA for actors and learner; bf16x2 = the fast mode, split-bf16 MFMA (hi + lo bf16 operands, "
-                         "three products, f32 accumulation; |dQ| < 2e-5 max|Q| against the f32 path, tests/test_ffnet_gpu.py). "
-                         "Whichever is chosen, the other one is timed as a further region of the same run "
-                         "(`summary.fast_mode` / `summary.f32_mode`)")
+    ap.add_argument("--precision", default="f32x3", choices=["f32", "f32x3", "bf16x2"],
+                    help="arithmetic of the headline region (`value`): f32x3 (default) = f32 results with f32 accuracy from "
+                         "the bf16 matrix cores (conv2 / conv3 / fc: every f32 operand split exactly in three bf16 parts, six "
+                         "products, f32 accumulation; error against f64 no larger than the f32 MFMA kernels' and torch CPU "
+                         "f32's, tests/test_ffnet_gpu.py); f32 = exact f32 MFMA for actors and learner; bf16x2 = the fast "
+                         "mode, split-bf16 MFMA (two bf16 parts, three products: 16-bit significands, |dQ| < 2e-5 max|Q|). "
+                         "Whichever is chosen, the others are timed as further regions of the same run (`summary`)")
     ap.add_argument("--layout", default="replicated", choices=["replicated", "reference"],
                     help="N > 1: replicated (default) = actors + replay partition + learner replica on every rank, gradient "
                          "all-reduce; reference = the reference's own layout, ONE learner rank + N - 1 actor-only ranks "
@@ -1391,6 +1398,14 @@ def main():
                 f1, f2 = FLOP["conv1_bf16x3"], FLOP["conv2_mfma"]
                 products = ((1.5 if conv1_i8 else 2) * f1 + 3 * f2) / (f1 + f2)
             peak_class = PEAK_BF16_MFMA_TFLOPS if products else PEAK_F32_MFMA_TFLOPS
+            if region["precision"] == "f32x3" and products == 6:
+                # an f32 product of this mode IS six bf16 MFMA products: the dense peak for f32 results is the bf16
+                # peak / 6 = 416.7 TFLOP/s (the f32 MFMA's own peak, 157.3, is reported next to it)
+                peak_class = PEAK_BF16_MFMA_TFLOPS / 6
+                products = 1
+                f32x3_note = True
+            else:
+                f32x3_note = False
             ach = flops / (avg_ms * 1e-3) / 1e12
             mfma = {"achieved": ach, "peak": peak_class, "unit": "TFLOP/s", "frac_algorithmic": ach / peak_class,
                     "frac_issued": ach * products / peak_class if products else ach / peak_class,
@@ -1398,6 +1413,10 @@ def main():
                     "instruction": ("v_mfma_f32_16x16x32_bf16 x%.3g (split operands%s)" % (
                         products, "; conv1: three int8 digit products on v_mfma_i32_16x16x64_i8, counted as 1.5 bf16 products"
                         if name == "conv12_fused" and conv1_i8 else "")) if products else "v_mfma_f32_16x16x4_f32"}
+            if f32x3_note:
+                mfma["instruction"] = ("v_mfma_f32_16x16x32_bf16, six products per f32 product (both operands as three exact "
+                                       "bf16 parts): peak = 2,500 / 6 TFLOP/s")
+                mfma["frac_of_f32_mfma_peak"] = ach / PEAK_F32_MFMA_TFLOPS
             nbytes = BYTES_PER_SAMPLE[name] * ROWS
             hbm = {"achieved": nbytes / (avg_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "algorithmic_bytes_per_launch": nbytes}

@@ -490,10 +490,12 @@ __global__ __launch_bounds__(kThreads) void conv1_bf16x3(const uint8_t* __restri
       const bf16x8 a = __builtin_bit_cast(bf16x8, u8x8_to_bf16x8(ap[0], ap[1]));
 #pragma unroll
       for (int c = 0; c < C::CT; ++c) {
-        // smallest piece first so the big one is added last
-        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[2][c], acc[t][c], 0, 0, 0);
-        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[1][c], acc[t][c], 0, 0, 0);
-        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[0][c], acc[t][c], 0, 0, 0);
+        // smallest piece first so the big one is added last.  Operands swapped (weights as the MFMA's A operand): a
+        // lane ends up with FOUR CONSECUTIVE CHANNELS of one pixel -- one 16-byte store where the pixel-major tile
+        // took four 4-byte ones (r4: the f32 output is two thirds of this kernel's HBM bytes)
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[2][c], a, acc[t][c], 0, 0, 0);
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[1][c], a, acc[t][c], 0, 0, 0);
+        acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[0][c], a, acc[t][c], 0, 0, 0);
       }
     }
   }
@@ -503,16 +505,15 @@ __global__ __launch_bounds__(kThreads) void conv1_bf16x3(const uint8_t* __restri
   for (int t = 0; t < C::RPW; ++t) {
     const int rt = wave + t * kWaves;
     if (rt >= C::RT) continue;
+    const int m = rt * 16 + li;  // this lane's pixel; its channels: 16 c + 4 g .. + 3
+    if (m >= mlim) continue;
 #pragma unroll
     for (int c = 0; c < C::CT; ++c) {
-      const int col = c * 16 + li;
-      const float bv = bias[col];
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + c * 16 + 4 * g);
+      f32x4 v = acc[t][c] + bv;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = rt * 16 + g * 4 + r;
-        const float v = acc[t][c][r] + bv;
-        if (m < mlim) out[((size_t)n0 * C::P + m) * C::OC + col] = v > 0.f ? v : 0.f;
-      }
+      for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      *reinterpret_cast<f32x4*>(out + ((size_t)n0 * C::P + m) * C::OC + c * 16 + 4 * g) = v;
     }
   }
 }
