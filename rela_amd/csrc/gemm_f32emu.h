@@ -8,30 +8,43 @@
 // where both subtractions are exact in f32 and what is left after x2 is below 2^-26 |x| (signed digits carry an extra
 // bit each).  A product of two bf16 numbers is exact in an f32 accumulator (16 significant bits), so
 //       x * w = sum_{i, j} x_i * w_j
-// can be accumulated term by term in the MFMA's f32 accumulators.  NPROD = 9 keeps all nine terms; NPROD = 6 keeps the
-// terms with i + j <= 2 and drops x1 w2 + x2 w1 + x2 w2 <= 2 * 2^-9 * 2^-18 |x w| = 2^-26 |x w|, a quarter of the 2^-24
-// rounding an f32 multiplier puts on the same product.  Either way the result carries f32 accuracy -- the error against
-// an f64 evaluation is that of an f32 FMA chain (accumulation rounding), which tests/test_f32emu_gpu.py measures next to
-// the exact-f32-MFMA kernels and a sequential f32 CPU chain -- at 16 / 6 = 2.7 x (or 16 / 9 = 1.8 x) the f32 MFMA rate.
-// (The "split-bf16" fast mode of gemm_bf16s.h keeps TWO parts and three products: 2^-16 per product.  That is a
-// different, narrower arithmetic; this one is not.)
+// can be accumulated term by term in the MFMA's f32 accumulators.  NPROD = 9 keeps all nine terms; NPROD = 6 (what the
+// library runs) keeps the terms with i + j <= 2 and drops x1 w2 + x2 w1 + x2 w2 <= 2 * 2^-9 * 2^-18 |x w| = 2^-26 |x w|,
+// a quarter of the 2^-24 rounding an f32 multiplier puts on the same product.  The five small terms have accumulators
+// of their own (added once per pass), so the running sum takes ONE rounding per 32 k where an f32 FMA chain takes 32.
+// Measured (tools/ubench/f32emu_probe.hip, random ReLU-like activations, mean |error| against f64): conv2 2.3e-8 with
+// six or nine products against 7.1e-8 for a sequential f32 FMA chain, conv3 2.6e-8 / 7.9e-8, fc 6.6e-8 / 1.8e-7; whole
+// network (tests/test_ffnet_gpu.py::test_ffnet_f32x3_is_f32_accurate): 1.50e-8 against 1.99e-8 for the exact f32 MFMA
+// kernels and 1.49e-8 for torch CPU f32.  (The "split-bf16" fast mode of gemm_bf16s.h keeps TWO parts and three
+// products: 2^-16 per product.  That is a different, narrower arithmetic; this one is not.)
 //
 // Tiling.  The bf16 MFMA is fast enough that operand delivery, not the matrix core, is what a kernel has to organise:
-//   * a wave owns a 64-pixel x 64-channel output tile (TM x TN = 4 x 4 MFMA tiles, 64 accumulator registers): per
-//     k-step of 32 it needs 4 x 3 activation fragments and 4 x 3 weight fragments for 96 (NPROD = 6) MFMAs of 16 cycles;
+//   * a wave owns a 64-pixel x 64-channel output tile (TM x TN = 4 x 4 MFMA tiles, 2 x 64 accumulator registers): per
+//     k-step of 32 it needs 4 x 3 activation fragments and 4 x 3 weight fragments for 96 MFMAs of 16 cycles;
 //   * ACTIVATIONS never touch LDS.  All 64 channels of a pixel belong to the same wave, so no other wave wants the same
 //     im2col row: lane (pixel li, k-group g) reads the 32 contiguous bytes X(m, 32 ks + 8 g .. + 7) straight from
-//     global memory (the im2col gather is index arithmetic; taps that overlap between neighbouring pixels hit in L2),
-//     two k-steps ahead of their use, and splits them into the three bf16 fragments in registers (9 VALU ops per pair
-//     of values, in the shadow of the MFMAs);
+//     global memory (the im2col gather is index arithmetic), two k-steps ahead of their use -- also across the end of
+//     a pass, from the next pass's rows -- and splits them into the three bf16 fragments in registers (9 VALU ops per
+//     pair of values) while the MFMAs of the tile before issue;
+//   * the k-steps of conv2 walk the taps one input-parity class at a time and those of conv3 in boustrophedon order, so
+//     that the pixels a wave fetches for one k-step are mostly those of the k-step before (L2 hits: 68 % for conv2);
 //   * WEIGHTS are split and laid out in fragment order once, at load time (pack_f32emu_at), and the four waves of a
 //     block share each k-step's 12 KB through a double-buffered LDS stage (one barrier per k-step): a lane's fragment
 //     is one conflict-free ds_read_b128;
 //   * operands are swapped (weights are the MFMA's A operand), so a lane ends up with FOUR CONSECUTIVE CHANNELS of one
 //     pixel: bias is the accumulators' initial value and the epilogue is ReLU + one 16-byte store per tile;
-//   * 2 blocks of 4 waves per CU; a block owns a contiguous range of 16-pixel row tiles, its waves a quarter each,
-//     walked in passes of 4 or 3 tiles chosen so that every block of the launch gets the same work to within one tile
-//     (a grid of whole 64-pixel tiles would quantise 33 180 row tiles over 2 048 wave slots to 5 rounds for 4.05).
+//   * one block of 4 waves per CU (OCC = 1: 256 + ~190 registers, no spills; at two blocks per CU the register budget
+//     of 256 leaves one activation set and spills); a block owns a contiguous range of 16-pixel row tiles, its waves
+//     a quarter each, walked in passes of 4 or 3 tiles chosen so that every block of the launch gets the same work to
+//     within one tile (a grid of whole 64-pixel tiles would quantise 33,180 row tiles to 5 rounds for 4.05).
+// Where the time goes (r4, N = 6,554, probe at ~1.95 GHz under load: conv2 263 us, conv3 153, fc 150 against 312 / 229
+// / 203 for the exact f32 MFMA kernels): SQ_VALU_MFMA_BUSY 40 %; MFMA time is ADDITIVE to the rest (nine products cost
+// +43 us = the MFMA time of the three extra ones).  Ablations: without the activation fetches 159 us, without the
+// weight stage + barrier 222, without the split 255, none of the three 127.  Tried without gain: activations coalesced
+// through per-wave LDS sets (277 us: the texture addresser is not the limit), every tap an L2 hit (271), one register
+// set (285), the staging instructions folded into the tiles' MFMA shadows with double-buffered weight fragments (277:
+// ~200 v_accvgpr moves per k-step pair -- the allocator parks operands in AGPRs and the VALU, not the matrix core,
+// sets the pace).  Next: the loop in ISA-level hands (AGPR-resident operands, counted vmcnt), or OCC = 2 with TM = 2.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -39,10 +52,6 @@
 #include <type_traits>
 
 #include "common.h"
-
-#ifndef F32EMU_DBG
-#define F32EMU_DBG 0  // probe builds only: 1 no weight staging / barrier | 2 no split | 4 no activation reloads
-#endif
 
 namespace rela_amd {
 namespace f32emu {
@@ -111,10 +120,6 @@ struct ProbFc {  // a3 [N][3136] (k = pos * 64 + c) -> h [N][512]
 
 // eight f32 (this lane's k-group of one pixel) -> the three bf16 fragments
 __device__ __forceinline__ void split3(const f32x4& a, const f32x4& b, bf16x8& p0, bf16x8& p1, bf16x8& p2) {
-  if (F32EMU_DBG & 2) {
-    p0 = __builtin_bit_cast(bf16x8, a), p1 = __builtin_bit_cast(bf16x8, b), p2 = __builtin_bit_cast(bf16x8, a + b);
-    return;
-  }
   const f32x2 v[4] = {{a[0], a[1]}, {a[2], a[3]}, {b[0], b[1]}, {b[2], b[3]}};
   uint32_t h[4], m[4], l[4];
 #pragma unroll
@@ -151,7 +156,6 @@ __device__ __forceinline__ void k_loop(const uint8_t* __restrict__ Xb, const uin
   const int tid = threadIdx.x, lane = tid & 63;
   auto reload = [&](auto set, int t, int k) {
     constexpr int S = decltype(set)::value;
-    if (F32EMU_DBG & 4) return;
     const bool nextp = k >= P::KS;  // (wave-uniform)
     const uint32_t ko = (uint32_t)P::koff(nextp ? k - P::KS : k) * 4u;
     const f32x4* p = reinterpret_cast<const f32x4*>(Xb + ((nextp ? xoffn[t] : xoff[t]) + ko));
@@ -185,7 +189,6 @@ __device__ __forceinline__ void k_loop(const uint8_t* __restrict__ Xb, const uin
       for (int u = 0; u < TN; ++u)
         acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[u][0], xf[cur][0], acc[t][u], 0, 0, 0);
     }
-    if (F32EMU_DBG & 1) return;
     // weights of k-step sidx + 1 (in registers since the step before) -> the other stage; then fetch k-step sidx + 2
     u32x4* nxts = reinterpret_cast<u32x4*>(wl + ((sidx + 1) & 1) * kStageU4) + tid;
     nxts[0] = wreg.r0;
