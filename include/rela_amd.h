@@ -256,7 +256,12 @@ uint64_t rela_ffnet_version(const rela_ffnet* net);
  * carried as hi + lo bf16 (16 mantissa bits) and a product is a_lo*b_hi + a_hi*b_lo + a_hi*b_hi with f32
  * accumulation: ~2^-16 relative error per product instead of 2^-24, 5.3x less matrix-core time.  Stated
  * tolerance: Q-values within 1e-4 (abs + rel) of the f32 path and of the reference goldens
- * (tests/test_ffnet_gpu.py reports the greedy-action agreement).  conv1 and the heads are exact in both. */
+ * (tests/test_ffnet_gpu.py reports the greedy-action agreement).  conv1 and the heads are exact in both.
+ * 2 ("f32x3"): f32 ACCURACY from the bf16 matrix cores -- conv2 / conv3 (batches of >= 512 rows) and fc (>= 4,096) take
+ * every f32 operand as three exact bf16 parts (24 significand bits) and the six products with i + j <= 2, f32
+ * accumulation, small terms in accumulators of their own (csrc/gemm_f32emu.h); against f64 its Q-values are as close
+ * as mode 0's and as torch CPU f32's (tests/test_ffnet_gpu.py::test_ffnet_f32x3_is_f32_accurate); smaller batches run
+ * mode 0's kernels, activations stay channel-last f32 between the layers. */
 int rela_ffnet_set_precision(rela_ffnet* net, int mode);
 int rela_ffnet_precision(const rela_ffnet* net);
 /* Test tap: synchronises the device and returns the sticky give-up word of the pipelined conv1 -> conv2 kernel
@@ -480,7 +485,10 @@ int rela_apex_learner_sync_target(rela_apex_learner* l, void* stream);
  * apex.py:38-42) on the split-bf16 MFMA trunk (rela_ffnet_set_precision), conv1's weight gradient and the conv2 /
  * conv3 data gradients on bf16 MFMA (hi + lo operands, f32 accumulation).  The online(obs) pass, whose activations
  * and ReLU masks the backward pass reads, always runs in f32: priorities and loss within 5e-6, every gradient within
- * 1e-4 of its largest entry of mode 0. */
+ * 1e-4 of its largest entry of mode 0.  2 = f32x3 (rela_ffnet_set_precision): conv2 / conv3 of all three forwards (from
+ * 512 rows) and the weight-gradient / fc / head GEMMs with three-part bf16 operands (csrc/gemm_bf16x3.h, PARTS = 3) --
+ * f32 accuracy, mode 0's tolerances (tests/test_learner_gpu.py); conv1, the conv data gradients, loss, clip and
+ * optimiser exactly as in mode 0. */
 int rela_apex_learner_set_precision(rela_apex_learner* l, int mode);
 /* loss + backward on one sampled batch.  rows_dev: the ten FFTransition fields in the order
  * rela_replay_sample fills them; weight_dev f32[batch] = the IS weights.  Leaves the gradient of
