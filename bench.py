@@ -284,7 +284,7 @@ PMC_KERNEL_OF = {"conv12_fused": "conv12_", "conv3_mfma": "conv_bf16s<", "fc_mfm
                  "lstm_gates_mfma": "GemmCfg<3648", "lstm_gates_x_bf16": "gemm_rec64_nt"}
 
 
-def traffic_from_profiles(label):
+def traffic_from_profiles(label, precision=None):
     """HBM-side bytes per launch of the kernel behind a rela_prof label, from the PMC passes TRACKED under profiles/
     (PMC counters cannot be read from inside this process): first a summary profiles/r0N_traffic.json, else straight
     from profiles/r0N_pmc/pmc_{fetch,write}_counter_collection.csv -- separate rocprofv3 --pmc FETCH_SIZE /
@@ -296,7 +296,13 @@ def traffic_from_profiles(label):
 
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
         try:
-            rec = json.load(open(path))["kernels"].get(label)
+            kernels = json.load(open(path))["kernels"]
+            # (the f32x3 mode's kernels share the rela_prof labels of the f32 mode's: their PMC records carry a suffix)
+            rec = kernels.get(label + "_f32x3") if precision == "f32x3" else None
+            if rec is None:
+                if precision == "f32x3" and label in ("conv2_mfma", "conv3_mfma", "fc_mfma"):
+                    continue  # never report another kernel's traffic for this one
+                rec = kernels.get(label)
         except (OSError, ValueError, KeyError):
             continue
         if rec is not None:
@@ -318,10 +324,12 @@ def traffic_from_profiles(label):
     return None, None
 
 
-def threaded_leg(seconds=1.0, epochs=3, threads=64, games=100):
+def threaded_leg(seconds=1.0, epochs=3, threads=64, games=100, precision="f32"):
     """The metric as the reference defines it (pyrela/benchmark.py:73-109): sum of DQNActor.num_act() deltas per
     second through rela.Context + BasicThreadLoop + DQNActor + FFPrioritizedReplay of the drop-in `rela` module --
-    C++ actor threads stepping HOST envs, per-step host -> HBM observation upload, f32 arithmetic -- without and with a
+    C++ actor threads stepping HOST envs, per-step host -> HBM observation upload, the headline's arithmetic
+    (RELA_PRECISION = --precision: f32x3 runs conv2 / conv3 of the 3,200-row cohorts on the three-part bf16 kernels, their
+    fc -- below 4,096 rows -- and everything else in exact f32) -- without and with a
     concurrent unthrottled B = 512 sample / update_priority loop, in a child process on this box's host cores.  Bounded:
     the reference protocol is 6 x 30 s windows per mode, this leg runs `epochs` x `seconds` (windows without a sampler
     end before the 2^21 replay's ring is full -- nothing evicts in that mode); tools/threaded_protocol.sh
@@ -332,14 +340,14 @@ def threaded_leg(seconds=1.0, epochs=3, threads=64, games=100):
                      "(pyrela/benchmark.py:73-109), host envs + H2D upload included", "unit": "env-steps/s",
            "threads": threads, "games_per_thread": games, "host_cores": host_cores()[0],
            "host_cores_source": host_cores()[1], "window_s": seconds, "windows": epochs,
-           "sampler": "unthrottled B=512 sample + update_priority loop on the Python thread",
+           "sampler": "unthrottled B=512 sample + update_priority loop on the Python thread", "RELA_PRECISION": precision,
            "note": "bounded sample of the reference's 6 x 30 s protocol; mean of the last half of the valid windows"}
     t0 = time.time()
     for env in ("fresh", "sliding"):
         cmd = [sys.executable, os.path.join(ROOT, "rela_amd", "pyrela", "benchmark.py"), "--grid", "%dx%d" % (threads, games),
                "--epoch_sec", str(seconds), "--num_epoch", str(epochs), "--replay_buffer_size", str(1 << 21), "--env", env]
         try:
-            res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, RELA_PRECISION=precision))
             line = [l for l in res.stdout.splitlines() if l.startswith("act rate: without sample:")][-1]
             without, with_ = (float(x.split(":")[-1]) for x in line[len("act rate: "):].split(","))
         except Exception as e:  # noqa: BLE001  (reported, never fatal for the headline)
@@ -1426,7 +1434,7 @@ def main():
             else:
                 roof.update(bound="hbm", achieved=hbm["achieved"], frac=hbm["frac"])
             roof["mfma"], roof["hbm"] = mfma, hbm
-        roof["traffic"], roof["traffic_source"] = traffic_from_profiles(name)
+        roof["traffic"], roof["traffic_source"] = traffic_from_profiles(name, region["precision"])
         roof.update(region["clock"])
         return roof
 
@@ -1513,7 +1521,7 @@ def main():
             # the drop-in's own metric; the big device buffers of this process go first (the child owns a replay too)
             replay.close()
             torch.cuda.empty_cache()
-            detail["threaded"] = threaded_leg()
+            detail["threaded"] = threaded_leg(precision=args.precision)
         if world == 1 and not args.no_cpu_baseline:
             port = cpu_baseline()
             ref = cpu_baseline_reference()

@@ -16,6 +16,10 @@ import sys
 
 
 def short(n):
+    # f32x3 kernels (csrc/gemm_f32emu.h): label + "_f32x3", what bench.py looks up for a region of that precision
+    m = re.search(r"gemm_f32emu<.*?Prob(Conv2|Conv3|Fc)", n)
+    if m:
+        return {"Conv2": "conv2_mfma_f32x3", "Conv3": "conv3_mfma_f32x3", "Fc": "fc_mfma_f32x3"}[m.group(1)]
     # split-bf16 path (names = the rela_prof labels bench.py looks traffic up by)
     if "conv12_i8" in n:
         return "conv12_fused"
@@ -55,7 +59,8 @@ def main(root, out_json):
         if name == "pmc_sq":
             for k, v in dur.items():
                 res.setdefault(k, {})["us"] = [x / 1e3 for x in v]
-    keep = ("conv12_fused", "conv1_bf16x3", "conv2_mfma", "conv3_mfma", "fc_mfma", "heads_mfma", "lstm_gates_mfma",
+    keep = ("conv12_fused", "conv1_bf16x3", "conv2_mfma", "conv3_mfma", "fc_mfma", "conv2_mfma_f32x3", "conv3_mfma_f32x3",
+            "fc_mfma_f32x3", "heads_mfma", "lstm_gates_mfma",
             "lstm_gates_x_bf16", "slide_stacks", "replay_scatter_rows",
             "replay_gather_big", "seq_chain", "replay_search", "replay_finish", "replay_update", "replay_append_weights")
     traffic = {}
