@@ -148,10 +148,10 @@ __device__ __forceinline__ void split3(const f32x4& a, const f32x4& b, bf16x8& p
 //   * the weight fragments of a k-step are read from LDS once, right behind the barrier that published them.
 // Invariant at the start of k-step ks (S = ks & 1): xa/xb[S][1..] hold k-step ks, [S][0] is in flight for ks + 2,
 // [S ^ 1][*] hold ks + 1, xf[(S * TMv) & 1] the split tile 0 of ks, wf the fragments of ks, wreg the weights of ks + 1.
-template <class P, int NPROD, int TMv>
+template <class P, int NPROD, int TMv, int TMX>
 __device__ __forceinline__ void k_loop(const uint8_t* __restrict__ Xb, const uint4* __restrict__ wsrc, uint4* wl,
-                                       const uint32_t (&xoff)[4], const uint32_t (&xoffn)[4], f32x4 (&xa)[2][4],
-                                       f32x4 (&xb)[2][4], bf16x8 (&wf)[TN][3], bf16x8 (&xf)[2][3], f32x4 (&acc)[4][TN], f32x4 (&accs)[4][TN],
+                                       const uint32_t (&xoff)[TMX], const uint32_t (&xoffn)[TMX], f32x4 (&xa)[2][TMX],
+                                       f32x4 (&xb)[2][TMX], bf16x8 (&wf)[TN][3], bf16x8 (&xf)[2][3], f32x4 (&acc)[TMX][TN], f32x4 (&accs)[TMX][TN],
                                        WRegs& wreg, int& step0) {
   const int tid = threadIdx.x, lane = tid & 63;
   auto reload = [&](auto set, int t, int k) {
@@ -236,19 +236,22 @@ __global__ __launch_bounds__(kT, OCC) void gemm_f32emu(const float* __restrict__
   if (cnt <= 0) return;  // (block-uniform)
   const int w0 = r0 + cnt * wave / 4, w1 = r0 + cnt * (wave + 1) / 4;
   const int myc = w1 - w0;
-  const int maxc = (cnt + 3) >> 2;                 // the largest share among the four waves
-  const int passes = (maxc + 3) >> 2;              // tiles per pass <= 4
-  const int n4 = max(maxc - 3 * passes, 0);        // passes of four tiles (the rest take three): capacity >= maxc
+  // tiles per pass: TMX or TMX - 1.  One block per CU (OCC = 1, 512 registers per wave): 4 / 3; two blocks per CU
+  // (256 registers): 2 / 1 -- twice the weight-stage traffic per MFMA, but a second wave per SIMD to fill the stalls
+  constexpr int TMX = OCC == 1 ? 4 : 2;
+  const int maxc = (cnt + 3) >> 2;                              // the largest share among the four waves
+  const int passes = (maxc + TMX - 1) / TMX;
+  const int n4 = max(maxc - (TMX - 1) * passes, 0);             // passes of TMX tiles (the rest take TMX - 1): capacity >= maxc
   // pass p of this wave: its first tile (clamped into the wave's range: a wave one tile short of the largest share
   // recomputes its last tile and stores nothing) and how many of the pass's tiles are its own
-  auto first_of = [&](int p) { return p < n4 ? 4 * p : 4 * n4 + 3 * (p - n4); };
+  auto first_of = [&](int p) { return p < n4 ? TMX * p : TMX * n4 + (TMX - 1) * (p - n4); };
   const uint8_t* Xb = reinterpret_cast<const uint8_t*>(X);
   const uint4* wsrc = Wp + (size_t)cg * P::KS * kStageU4;
-  uint32_t xoff[4], xoffn[4];  // byte offsets of the tiles' patch origins, this pass and the next (operand < 4 GB)
-  auto set_xoff = [&](uint32_t (&xo)[4], int p) {
+  uint32_t xoff[TMX], xoffn[TMX];  // byte offsets of the tiles' patch origins, this pass and the next (operand < 4 GB)
+  auto set_xoff = [&](uint32_t (&xo)[TMX], int p) {
     const int t0 = min(w0 + first_of(p), max(w1 - 1, w0));
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < TMX; ++t) {
       const int row = min((t0 + t) * 16 + li, M - 1);
       xo[t] = (uint32_t)(P::row_base(row) + g * 8) * 4u;
     }
@@ -266,11 +269,11 @@ __global__ __launch_bounds__(kT, OCC) void gemm_f32emu(const float* __restrict__
     wreg.r1 = src[kT];
     wreg.r2 = src[2 * kT];
   }
-  f32x4 xa[2][4], xb[2][4];
+  f32x4 xa[2][TMX], xb[2][TMX];
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < TMX; ++t) {
       const f32x4* p = reinterpret_cast<const f32x4*>(Xb + (xoff[t] + (uint32_t)P::koff(s2) * 4u));
       xa[s2][t] = p[0];
       xb[s2][t] = p[1];
@@ -287,14 +290,14 @@ __global__ __launch_bounds__(kT, OCC) void gemm_f32emu(const float* __restrict__
     xa[0][0] = p[0];
     xb[0][0] = p[1];
   }
-  f32x4 acc[4][TN];   // x0 w0 terms; start at the bias: this lane's channels are 16 u + 4 g .. + 3 of the column group
-  f32x4 accs[4][TN];  // the small terms
+  f32x4 acc[TMX][TN];   // x0 w0 terms; start at the bias: this lane's channels are 16 u + 4 g .. + 3 of the column group
+  f32x4 accs[TMX][TN];  // the small terms
   auto acc_init = [&]() {
 #pragma unroll
     for (int u = 0; u < TN; ++u) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + cg * 64 + 16 * u + 4 * g);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t][u] = bv, accs[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < TMX; ++t) acc[t][u] = bv, accs[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   acc_init();
@@ -303,14 +306,14 @@ __global__ __launch_bounds__(kT, OCC) void gemm_f32emu(const float* __restrict__
   for (int p = 0; p < passes; ++p) {
     const bool four = p < n4;  // (block-uniform)
     if (four)
-      k_loop<P, NPROD, 4>(Xb, wsrc, wl, xoff, xoffn, xa, xb, wf, xf, acc, accs, wreg, step0);
+      k_loop<P, NPROD, TMX, TMX>(Xb, wsrc, wl, xoff, xoffn, xa, xb, wf, xf, acc, accs, wreg, step0);
     else
-      k_loop<P, NPROD, 3>(Xb, wsrc, wl, xoff, xoffn, xa, xb, wf, xf, acc, accs, wreg, step0);
+      k_loop<P, NPROD, TMX - 1, TMX>(Xb, wsrc, wl, xoff, xoffn, xa, xb, wf, xf, acc, accs, wreg, step0);
     const int first = first_of(p);
     const int t0 = min(w0 + first, max(w1 - 1, w0));
-    const int nvalid = min(four ? 4 : 3, myc - first);
+    const int nvalid = min(four ? TMX : TMX - 1, myc - first);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < TMX; ++t) {
       const int row = (t0 + t) * 16 + li;
       if (t < nvalid && row < M) {
         float* o = out + (size_t)row * P::OC + cg * 64 + 4 * g;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(kT, OCC) void gemm_f32emu(const float* __restrict__
     }
     acc_init();
 #pragma unroll
-    for (int t = 0; t < 4; ++t) xoff[t] = xoffn[t];
+    for (int t = 0; t < TMX; ++t) xoff[t] = xoffn[t];
     set_xoff(xoffn, min(p + 2, passes - 1));
   }
 }

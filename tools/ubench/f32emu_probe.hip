@@ -134,9 +134,9 @@ static void run(const HostProb& hp, int N, int iters) {
   for (int np : {6, 9}) {
     auto go = [&]() {
       if (np == 6)
-        launch<P, 6, 1>(dX, dP, dB, dO, M, 0);
+        launch<P, 6, F32EMU_OCC>(dX, dP, dB, dO, M, 0);
       else
-        launch<P, 9, 1>(dX, dP, dB, dO, M, 0);
+        launch<P, 9, F32EMU_OCC>(dX, dP, dB, dO, M, 0);
     };
     CK(hipMemset(dO, 0xff, oe * 4));
     go();
