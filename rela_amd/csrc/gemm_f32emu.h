@@ -44,7 +44,9 @@
 // through per-wave LDS sets (277 us: the texture addresser is not the limit), every tap an L2 hit (271), one register
 // set (285), the staging instructions folded into the tiles' MFMA shadows with double-buffered weight fragments (277:
 // ~200 v_accvgpr moves per k-step pair -- the allocator parks operands in AGPRs and the VALU, not the matrix core,
-// sets the pace).  Next: the loop in ISA-level hands (AGPR-resident operands, counted vmcnt), or OCC = 2 with TM = 2.
+// sets the pace); two blocks per CU with passes of 2 / 1 tiles (OCC = 2: 284 us).  Kernel time scales with 1 / clock (215 us
+// inside bench.py at 2.37 GHz): cycle-bound at ~3,900 cycles per k-step for 1,536 of MFMA.  Next: the loop in ISA-level
+// hands (AGPR-resident operands, counted vmcnt).
 #pragma once
 #include <hip/hip_runtime.h>
 
