@@ -838,6 +838,13 @@ def bench_reference_layout(args, world, rank, device, rehearsal):
     _, total = ffnet_flat_layout(NUM_ACTION)
     K, R = args.steps, args.repeats
     cycle = 20  # actor_sync_freq, pyrela/main.py:213-215
+    # rows per partition.  Native exchange: the learner maps every partition's ring through HIP IPC, and on this pool's
+    # boxes hipIpcOpenMemHandle of ONE allocation of 74 GB (2^20 rows) did not return within 200 s where 37 GB (2^19) take
+    # under a second (r4 rehearsal) -- partitions are held to 2^19 rows there (only the 2-GPU case of the default
+    # 2^20 / G is affected)
+    part_cap = args.replay_cap // G
+    if args.exchange == "native":
+        part_cap = min(part_cap, 1 << 19)
     torch.manual_seed(SEED + 2)
     agent = ApexAgent(lambda: AtariFFNet(NUM_ACTION), MULTI_STEP, GAMMA).to(device)
     for p_ in agent.parameters():
@@ -897,7 +904,7 @@ def bench_reference_layout(args, world, rank, device, rehearsal):
         target.load_state_dict(agent.target_net.state_dict())
         online.set_precision(args.precision)
         target.set_precision(args.precision)
-        part = FFReplay(args.replay_cap // G, SEED + rank, ALPHA, BETA, 0, NUM_ACTION, device)
+        part = FFReplay(part_cap, SEED + rank, ALPHA, BETA, 0, NUM_ACTION, device)
         eps_all = generate_eps(0.4, 7, ROWS * G)
         engine = ApexActorEngine(ROWS, K_GAMES, NUM_ACTION, MULTI_STEP, GAMMA, part, eps_all[g * ROWS:(g + 1) * ROWS], device,
                                  seed=SEED + rank)
@@ -982,13 +989,13 @@ def bench_reference_layout(args, world, rank, device, rehearsal):
             "value": envs[med], "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": ms[med], "repeats": R, "ms_per_step_repeats": ms, "env_steps_per_s_repeats": envs,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "f32" else DTYPE_NOTE, "data": "synthetic",
+            "dtype": {"f32": "f32", "f32x3": DTYPE_F32X3}.get(args.precision, DTYPE_NOTE), "data": "synthetic",
             "config": {"workload": "Ape-X DQN in the reference's multi-GPU layout (pyrela/main.py:131-166, BASELINE C3): ONE "
                                    "learner GPU (batch 512) + %d actor-only GPUs x 80 threads x 80 games (6400 envs each), one "
                                    "replay partition of 2^20 / %d per actor GPU, B / G rows sampled per partition; "
                                    "device-resident static frames" % (G, G),
                        "layout": "reference", "actor_gpus": G, "envs_per_actor_gpu": ROWS, "learner_batch": BATCH,
-                       "replay_capacity_total": args.replay_cap, "parallelism": "1 learner + %d actor shards / replay partitions" % G},
+                       "replay_capacity_total": part_cap * G, "parallelism": "1 learner + %d actor shards / replay partitions" % G},
             "grad_steps_per_s": 1e3 / ms[med], "learner": "hip (csrc/learner.hip)",
             "comm": {"backend": dist.get_backend(), "rccl_ranks": world if dist.get_backend() == "nccl" else 0, "ranks": world,
                      "exchange": args.exchange,
@@ -998,9 +1005,10 @@ def bench_reference_layout(args, world, rank, device, rehearsal):
         }
         line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                     "scaling", "vs_baseline", "data", "grad_steps_per_s")}
-        line["dtype"] = "f32" if args.precision == "f32" else "f32 results from split-bf16 MFMA (16-bit significands)"
+        line["dtype"] = {"f32": "f32", "f32x3": "f32 (f32 operands as 3 exact bf16 parts on bf16 MFMA; f32-accurate)"}.get(
+            args.precision, "f32 results from split-bf16 MFMA (16-bit significands)")
         line["config"] = {"workload": "Ape-X, reference layout: 1 learner GPU (B=512) + %d actor GPUs x 6400 envs, replay "
-                                      "partitions of 2^20/%d; device-resident static frames" % (G, G),
+                                      "partitions of %d rows; device-resident static frames" % (G, part_cap),
                           "layout": "reference", "parallelism": out["config"]["parallelism"]}
         line["comm"] = {"backend": out["comm"]["backend"], "rccl_ranks": out["comm"]["rccl_ranks"]}
         line["env_steps_per_s_repeats"] = [round(e) for e in envs]
@@ -1056,6 +1064,10 @@ def main():
     # Rehearsal switch for a one-GPU box: all ranks share cuda:0 and talk over gloo (RCCL refuses two
     # ranks on one device).  The driver's real N > 1 runs use one GPU per rank and RCCL.
     rehearsal = os.environ.get("RELA_BENCH_REHEARSAL", "0") == "1"
+    if os.environ.get("RELA_BENCH_WATCHDOG"):  # diagnostic: every rank dumps its Python stacks and exits after N seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["RELA_BENCH_WATCHDOG"]), exit=True)
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     device = "cuda:%d" % dev_index

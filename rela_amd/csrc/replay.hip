@@ -1419,6 +1419,17 @@ extern "C" int rela_replay_export_ipc(rela_replay* r, rela_replay_ipc_desc* out)
   for (size_t f = 0; f < r->d_fields.size(); ++f) {
     out->row_bytes[f] = r->row_bytes[f];
     out->steps[f] = r->steps[f];
+    {
+      // r4, this pool's boxes: hipIpcOpenMemHandle of a 37 GB allocation (one frame-stack field of a 2^20-row partition)
+      // did not return within 200 s in the importing process, 18.5 GB (2^19 rows) maps in under a second: refuse loudly
+      hipDeviceptr_t base = nullptr;
+      size_t bytes = 0;
+      if (hipMemGetAddressRange(&base, &bytes, r->d_fields[f]) == hipSuccess)
+        RELA_CHECK(bytes <= ((size_t)24 << 30), RELA_EINVAL,
+                   "rela_replay_export_ipc: field %d is one allocation of %.1f GB; HIP IPC imports above ~24 GB do not return on "
+                   "this platform -- use a smaller partition (<= 2^19 frame-stack rows) or the packed exchange",
+                   (int)f, (double)bytes / 1e9);
+    }
     RELA_HIP(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(out->field_handle[f]), r->d_fields[f]));
   }
   RELA_HIP(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(out->ids_handle), r->d_ids));
