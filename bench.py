@@ -530,8 +530,6 @@ def bench_r2d2(args, world, rank, device):
     window bookkeeping branches on them (rela/r2d2_actor.h:29-87)."""
     import torch.distributed as dist
 
-    if args.precision == "f32x3":  # an AtariFFNet mode: the recurrent net's kernels have the exact f32 and the bf16x2 mode
-        args.precision = "f32"
     from rela_amd import _capi as capi
     from rela_amd.engine import LSTMNetHandle, R2D2ActorEngine
     from rela_amd.learner import HipR2D2Learner
@@ -706,12 +704,15 @@ def bench_r2d2(args, world, rank, device):
     prof_all = prof_summary()
     # further regions of the same run, as in the Ape-X line: the reference's work (all forwards recomputed) in the
     # headline's arithmetic, and the other arithmetic with the forwards memoised
-    other = "bf16x2" if args.precision == "f32" else "f32"
-    name_of = {("f32", 1): "f32_mode", ("f32", 0): "strict", ("bf16x2", 1): "fast_mode", ("bf16x2", 0): "fast_no_reuse"}
+    # (f32x3 for the recurrent net: conv2 / conv3 of the trunks on the three-part bf16 kernels, everything else exact f32)
+    name_of = {("f32", 1): "f32_mode", ("f32", 0): "strict", ("bf16x2", 1): "fast_mode", ("bf16x2", 0): "fast_no_reuse",
+               ("f32x3", 1): "f32x3_mode", ("f32x3", 0): "f32x3_strict"}
     regions = {name_of[(args.precision, 1)]: head}
     settle = 2 * (MULTI_STEP + 1)
     regions[name_of[(args.precision, 0)]] = timed_region(args.precision, 0, settle)
-    regions[name_of[(other, 1)]] = timed_region(other, 1, settle)
+    for other in ("f32x3", "f32", "bf16x2"):
+        if other != args.precision:
+            regions[name_of[(other, 1)]] = timed_region(other, 1, settle)
     set_all_precision(args.precision)
     engine.set_reuse(1)
     st = replay.debug_state()
@@ -746,7 +747,9 @@ def bench_r2d2(args, world, rank, device):
         sample_bytes = 4 * st["safe_size"] + B_LOCAL * sum(replay.row_bytes)
         learner_ms = sum(v["total_ms"] for k, v in prof_all.items() if k.startswith("learner_")) / k_all
         ms_med = head["ms_per_step"]
-        dtype = "f32" if args.precision == "f32" else (
+        dtype = {"f32": "f32", "f32x3": "f32 (conv2 / conv3 of every trunk forward with f32 operands as three exact bf16 parts on "
+                 "the bf16 MFMA, csrc/gemm_f32emu.h: f32 accuracy; gate GEMMs, recurrences, heads, backward in exact f32)"}.get(
+            args.precision,
             "f32 results from split-bf16 MFMA (bf16 hi+lo operands, f32 accumulate): the actors' conv trunks and gate GEMM "
             "(h, c, Q within 4e-6), the learner's trunks, LSTM GEMMs and conv gradients; recurrences, cells, heads in f32")
         detail = {
@@ -786,7 +789,8 @@ def bench_r2d2(args, world, rank, device):
         line = {"metric": detail["metric"], "value": detail["value"], "unit": "env-steps/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_med, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None,
-                "dtype": "f32" if args.precision == "f32" else "f32 results from split-bf16 MFMA (16-bit significands)",
+                "dtype": {"f32": "f32", "f32x3": "f32 (trunk conv2 / conv3: f32 operands as 3 exact bf16 parts on bf16 MFMA; "
+                          "f32-accurate)"}.get(args.precision, "f32 results from split-bf16 MFMA (16-bit significands)"),
                 "data": "synthetic",
                 "config": {"workload": "R2D2 LSTM 40x80 envs/GPU (C4 shapes), seq 80 / burn-in 40 / n 3, B=64, A=18; "
                                        "device-resident static frames", "parallelism": detail["config"]["parallelism"]},

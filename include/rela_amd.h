@@ -331,6 +331,8 @@ int rela_lstmnet_load(rela_lstmnet* net, const rela_lstmnet_params* params, int 
 /* 0 = exact f32 (default), 1 = split-bf16 MFMA conv trunk for batches of 128 rows and more (as
  * rela_ffnet_set_precision) and, from 1,024 rows up, the input side of the LSTM gate GEMM as well (h x W_hh, the
  * cell and the heads stay f32); h, c, Q within 4e-6 of mode 0.  Bumps the weight version. */
+/* (mode 2, "f32x3": conv2 / conv3 of the trunk on the three-part bf16 kernels of rela_ffnet_set_precision's mode 2, from 512
+ * rows; gate GEMM, cell and heads as in mode 0) */
 int rela_lstmnet_set_precision(rela_lstmnet* net, int mode);
 int rela_lstmnet_precision(const rela_lstmnet* net);
 int rela_lstmnet_num_action(const rela_lstmnet* net);
@@ -569,7 +571,8 @@ int rela_r2d2_learner_check(rela_r2d2_learner* l, void* stream);
  * of the LSTM's input side (gate GEMM of both nets, its data and weight gradients, dW_hh), the conv weight gradients
  * and the conv data gradients (hi + lo bf16 operands, f32 accumulation); the online net's conv trunk, whose
  * activations and ReLU masks the backward kernels read, stays f32.  Loss, priorities within 2e-5, gradients within
- * 2e-4 of their largest entry of mode 0.  0 (default): everything f32. */
+ * 2e-4 of their largest entry of mode 0.  0 (default): everything f32.  2 ("f32x3"): conv2 / conv3 of BOTH nets' trunk
+ * forwards on the three-part bf16 kernels (f32 accuracy, mode 0's tolerances); everything else as in mode 0. */
 int rela_r2d2_learner_set_precision(rela_r2d2_learner* l, int mode);
 
 /* ===================================================================================

@@ -1890,6 +1890,10 @@ __global__ __launch_bounds__(256) void pack_conv1_i8(const float* __restrict__ w
   pack_conv1_i8_block((int)blockIdx.x, w, b, W1d, s1q, b1q);
 }
 
+__global__ void pack_f32emu(int mode, const float* __restrict__ w, uint16_t* __restrict__ frag, int NCG, int KS) {
+  f32emu::pack_f32emu_at((int64_t)blockIdx.x * blockDim.x + threadIdx.x, mode, w, frag, NCG, KS);
+}
+
 // Every kernel-layout copy of an AtariFFNet's weights in ONE launch (a learner re-packs after every optimiser step:
 // twelve pack kernels, four device copies and the head bias were seventeen launches).  A block finds its job in a
 // table of first-block indices; the job bodies are the *_at functions of the separate kernels.
@@ -2581,7 +2585,8 @@ struct rela_lstmnet {
   bool loaded = false;
   uint64_t version = 0;  // bumped by every load
   // 0 = exact f32; 1 = split-bf16 conv trunk and, from kFastMinN rows up, the x part of the gate GEMM on split-bf16
-  // MFMA too (the recurrent part and the cell stay f32)
+  // MFMA too (the recurrent part and the cell stay f32); 2 = f32x3: conv2 / conv3 of the trunk on the three-part bf16
+  // kernels of gemm_f32emu.h from 512 rows up (f32 accuracy), everything else as in mode 0
   int precision = 0;
 };
 
@@ -2622,6 +2627,8 @@ extern "C" int rela_lstmnet_create(rela_lstmnet** out, int num_action, int devic
                                Conv12I::LDS_TOTAL));
   RELA_HIP(hipMalloc(&d.B2f, sizeof(uint4) * Conv2F::CT * Conv2F::KS * 2 * 64));
   RELA_HIP(hipMalloc(&d.B3f, sizeof(uint4) * Conv3F::CT * Conv3F::KS * 2 * 64));
+  RELA_HIP(hipMalloc(&d.B2e, sizeof(uint4) * f32emu::packed_u4<f32emu::ProbConv2>()));
+  RELA_HIP(hipMalloc(&d.B3e, sizeof(uint4) * f32emu::packed_u4<f32emu::ProbConv3>()));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv3F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv3F::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3),
@@ -2643,13 +2650,14 @@ extern "C" void rela_lstmnet_destroy(rela_lstmnet* n) {
   DeviceGuard g(n->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bh, n->d.bh, n->Bl, n->bl,
-                n->d.B2f, n->d.B3f, n->Wrec, n->d.W1d, n->d.s1q, n->d.b1q};
+                n->d.B2f, n->d.B3f, n->Wrec, n->d.W1d, n->d.s1q, n->d.b1q, n->d.B2e, n->d.B3e};
   for (void* p : ps) (void)hipFree(p);
   delete n;
 }
 
 extern "C" int rela_lstmnet_set_precision(rela_lstmnet* n, int mode) {
-  RELA_CHECK(n && (mode == 0 || mode == 1), RELA_EINVAL, "rela_lstmnet_set_precision: mode must be 0 (f32) or 1 (bf16x2)");
+  RELA_CHECK(n && mode >= 0 && mode <= 2, RELA_EINVAL,
+             "rela_lstmnet_set_precision: mode must be 0 (f32), 1 (bf16x2) or 2 (f32x3: conv2 / conv3 of the trunk with three-part operands)");
   if (n->precision != mode) n->version += 1;  // cached forwards of the other mode must not be reused
   n->precision = mode;
   return RELA_OK;
@@ -2700,6 +2708,10 @@ extern "C" int rela_lstmnet_load(rela_lstmnet* n, const rela_lstmnet_params* p, 
                      reinterpret_cast<uint16_t*>(n->d.B1), 0);
   pack(kPackConv2, dv[2], nullptr, n->d.B2, 4, 128);
   pack(kPackConv3, dv[4], nullptr, n->d.B3, 4, 144);
+  hipLaunchKernelGGL(pack_f32emu, dim3(ceil_div(f32emu::packed_u4<f32emu::ProbConv2>() * 8 / 3, 256)), dim3(256), 0, s, 1, dv[2],
+                     reinterpret_cast<uint16_t*>(n->d.B2e), f32emu::ProbConv2::NCG, f32emu::ProbConv2::KS);
+  hipLaunchKernelGGL(pack_f32emu, dim3(ceil_div(f32emu::packed_u4<f32emu::ProbConv3>() * 8 / 3, 256)), dim3(256), 0, s, 2, dv[4],
+                     reinterpret_cast<uint16_t*>(n->d.B3e), f32emu::ProbConv3::NCG, f32emu::ProbConv3::KS);
   pack(kPackLstm, dv[6], dv[7], n->Bl, GemmLstm::CT, GemmLstm::KS);
   hipLaunchKernelGGL(pack_wih_rec64_perm, dim3(ceil_div((int64_t)2048 * 3136 / 8, 256)), dim3(256), 0, s, dv[6], n->Wrec);
   pack(kPackHeads, dv[12], dv[10], n->d.Bh, 2, 128);
@@ -2730,7 +2742,7 @@ namespace {
 // records (with fast): a3 stays in split records (the rec64 operand of the learner's split-bf16 gate GEMM); returns
 // whether it did
 bool lstm_trunk_launch(const FFNetDev& d, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, bool fast,
-                       hipStream_t s, const char* const* names, bool records = false) {
+                       hipStream_t s, const char* const* names, bool records = false, bool emu = false) {
   if (fast && N >= kFastTrunkMinN) {
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
@@ -2750,13 +2762,24 @@ bool lstm_trunk_launch(const FFNetDev& d, int N, const uint8_t* s_dev, float* a1
     note_launch("conv1_bf16x3"); hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
                        d.b1, a1, N);
   }
+  const bool emu_conv = emu && N >= kEmuConvMinN && N <= kEmuMaxN;  // f32x3: as in ffnet_forward_mode
   {
     ProfScope prof(names[1], s);
-    launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
+    if (emu_conv) {
+      note_launch("gemm_f32emu<conv2>");
+      f32emu::launch<f32emu::ProbConv2, 6, 1>(a1, d.B2e, d.b2, a2, N * 81, s);
+    } else {
+      launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
+    }
   }
   {
     ProfScope prof(names[2], s);
-    launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
+    if (emu_conv) {
+      note_launch("gemm_f32emu<conv3>");
+      f32emu::launch<f32emu::ProbConv3, 6, 1>(a2, d.B3e, d.b3, a3, N * 49, s);
+    } else {
+      launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
+    }
   }
   return false;
 }
@@ -2784,7 +2807,8 @@ extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_
   // bf16x2 mode from kFastMinN rows up: a3 stays in split records, the x part of the gates is one split-bf16 GEMM
   // (gemm_bf16s.h: 41 GFLOP at 3,200 rows) and the f32 MFMA kernel only adds h x W_hh (K = 512) and runs the cell
   const bool fast_gates = n->precision == 1 && N >= kFastMinN;
-  const bool recs = lstm_trunk_launch(d, N, s_dev, a1, a2, a3, n->precision == 1, s, kLstmActorNames, fast_gates);
+  const bool recs = lstm_trunk_launch(d, N, s_dev, a1, a2, a3, n->precision == 1, s, kLstmActorNames, fast_gates,
+                                      n->precision == 2);
   if (fast_gates && recs) {
     int rc = gemm16::launch_rec64_nt(reinterpret_cast<const uint8_t*>(a3), n->Wrec, N, 2048, 49, gemm16::EpiPlain{gx, 2048}, s,
                                      "lstm_gates_x_bf16");
@@ -2835,7 +2859,8 @@ int lstmnet_trunk(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1,
                   const char* const* names, bool fast, bool* a3_records) {
   RELA_CHECK(n && n->loaded, RELA_ESTATE, "lstmnet_trunk: parameters were never loaded");
   RELA_CHECK(N >= 1 && s_dev && a1 && a2 && a3, RELA_EINVAL, "lstmnet_trunk: bad arguments");
-  const bool rec = lstm_trunk_launch(n->d, N, s_dev, a1, a2, a3, fast, s, names, a3_records != nullptr);
+  const bool rec = lstm_trunk_launch(n->d, N, s_dev, a1, a2, a3, fast, s, names, a3_records != nullptr,
+                                     !fast && n->precision == 2);
   if (a3_records) *a3_records = rec;
   RELA_LAUNCH_CHECK();
   return RELA_OK;

@@ -1034,9 +1034,13 @@ extern "C" int rela_r2d2_learner_flat(rela_r2d2_learner* l, float** params_dev, 
 extern "C" const float* rela_r2d2_learner_stats_dev(const rela_r2d2_learner* l) { return l ? l->norm : nullptr; }
 
 extern "C" int rela_r2d2_learner_set_precision(rela_r2d2_learner* l, int mode) {
-  RELA_CHECK(l && (mode == 0 || mode == 1), RELA_EINVAL, "rela_r2d2_learner_set_precision: mode must be 0 or 1");
+  RELA_CHECK(l && mode >= 0 && mode <= 2, RELA_EINVAL, "rela_r2d2_learner_set_precision: mode must be 0, 1 or 2");
   l->precision = mode;
-  return RELA_OK;
+  // 2 (f32x3): conv2 / conv3 of both nets' trunks on the three-part bf16 kernels (csrc/gemm_f32emu.h, f32 accuracy);
+  // everything else -- gate GEMMs, recurrences, backward -- as in mode 0.  (Mode 1 passes its choices per call.)
+  int rc = rela_lstmnet_set_precision(l->online, mode == 2 ? 2 : 0);
+  if (rc != RELA_OK) return rc;
+  return rela_lstmnet_set_precision(l->target, mode == 2 ? 2 : 0);
 }
 
 extern "C" int rela_r2d2_learner_check(rela_r2d2_learner* l, void* stream_) {

@@ -180,8 +180,8 @@ class LSTMNetHandle:
         """"f32" (default) or "bf16x2": the conv trunk on split-bf16 MFMA for batches of 128 rows and more and, from
         1,024 rows up, the input side of the LSTM gate GEMM (h x W_hh, the cell and the heads stay f32);
         rela_lstmnet_set_precision."""
-        capi.check(capi.lib.rela_lstmnet_set_precision(self.h, {"f32": 0, "bf16x2": 1, "f32x3": 0}[mode]),
-                   "rela_lstmnet_set_precision")  # ("f32x3" is an AtariFFNet mode: the recurrent net keeps exact f32)
+        capi.check(capi.lib.rela_lstmnet_set_precision(self.h, {"f32": 0, "bf16x2": 1, "f32x3": 2}[mode]),
+                   "rela_lstmnet_set_precision")  # (f32x3: conv2 / conv3 of the trunk, from 512 rows; the rest exact f32)
 
     def close(self):
         if getattr(self, "h", None):

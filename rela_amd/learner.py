@@ -355,8 +355,9 @@ class HipR2D2Learner:
         return dev_view(getattr(p, capi.LSTMNetParams._fields_[0][0]), (n.value,), torch.float32, self.device)
 
     def set_precision(self, mode):
-        """"f32" (default) or "bf16x2": the target net's conv trunk on split-bf16 MFMA (no gradient flows through it)."""
-        self._capi.check(self._capi.lib.rela_r2d2_learner_set_precision(self.h, {"f32": 0, "bf16x2": 1, "f32x3": 0}[mode]),
+        """"f32" (default); "bf16x2": the target net's conv trunk on split-bf16 MFMA (no gradient flows through it);
+        "f32x3": conv2 / conv3 of both trunks on the f32-accurate three-part bf16 kernels (csrc/gemm_f32emu.h)."""
+        self._capi.check(self._capi.lib.rela_r2d2_learner_set_precision(self.h, {"f32": 0, "bf16x2": 1, "f32x3": 2}[mode]),
                          "rela_r2d2_learner_set_precision")
 
     def check(self):

@@ -359,15 +359,15 @@ class ModelLocker {
   }
 
   // RELA_PRECISION: "f32x3" = conv2 / conv3 / fc of the AtariFFNet actors with f32 operands as three exact bf16 parts on the
-  // bf16 matrix cores (f32 accuracy, csrc/gemm_f32emu.h; batches below 2,048 rows and the recurrent net keep the f32
-  // MFMA kernels); "bf16x2" = the fast mode (two bf16 parts: 16-bit significands, |dQ| < 2e-5 max|Q|);
+  // bf16 matrix cores (f32 accuracy, csrc/gemm_f32emu.h; conv2 / conv3 from 512 rows, fc from 4,096; the recurrent net:
+  // conv2 / conv3 of its trunk); "bf16x2" = the fast mode (two bf16 parts: 16-bit significands, |dQ| < 2e-5 max|Q|);
   // anything else = exact f32 MFMA.  "cpu" lockers: always exact f32.
-  int precisionMode(bool recurrent) const {
+  int precisionMode(bool /*recurrent*/) const {
     const char* e = std::getenv("RELA_PRECISION");
     if (deviceIndex < 0 || !e) return 0;
     const std::string m(e);
     if (m == "bf16x2") return 1;
-    if (m == "f32x3") return recurrent ? 0 : 2;
+    if (m == "f32x3") return 2;
     return 0;
   }
 

@@ -51,12 +51,13 @@ class GpuLstmNet:
         self.capi.lib.rela_lstmnet_destroy(self.h)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x2"])
+@pytest.mark.parametrize("precision", ["f32", "f32x3", "bf16x2"])
 @pytest.mark.parametrize("N,A", [(1, 18), (5, 6), (80, 18), (131, 18), (1537, 18), (3200, 18)])
 def test_lstm_step_vs_torch(N, A, precision):
-    """Both precision modes against the plain PyTorch fp32 step, with the launched kernels asserted: in bf16x2 mode
+    """All three precision modes against the plain PyTorch fp32 step, with the launched kernels asserted: in bf16x2 mode
     the trunk's split-bf16 kernels from 128 rows and the rec64 gate GEMM (lstm_gates_x_bf16) from 1,024 rows are
-    compared with torch-fp32 directly."""
+    compared with torch-fp32 directly; in f32x3 mode conv2 / conv3 run on the three-part bf16 kernels from 512 rows
+    (csrc/gemm_f32emu.h), everything else on the f32 kernels."""
     import torch
 
     from rela_amd.pyrela.net import AtariLSTMNet, dueling_q
@@ -69,14 +70,16 @@ def test_lstm_step_vs_torch(N, A, precision):
     legal = (rng.uniform(size=(N, A)) < 0.85).astype(np.float32)
     h_in = rng.normal(0, 0.3, (N, 512)).astype(np.float32)
     c_in = rng.normal(0, 0.5, (N, 512)).astype(np.float32)
-    net.capi.check(net.capi.lib.rela_lstmnet_set_precision(net.h, 1 if precision == "bf16x2" else 0), "set_precision")
+    net.capi.check(net.capi.lib.rela_lstmnet_set_precision(net.h, {"f32": 0, "bf16x2": 1, "f32x3": 2}[precision]), "set_precision")
     with net.capi.launch_census() as census:
         h, c, q, adv = net.step(s, legal, h_in, c_in)
     fast = {CONV12, "conv_bf16s<Conv3F>"} | ({"gemm_rec64_nt"} if N >= 1024 else set())
+    emu = {"gemm_f32emu<conv2>", "gemm_f32emu<conv3>"}
     if precision == "bf16x2" and N >= 128:
         assert fast <= set(census.counts), sorted(census.counts)
     else:
         assert not (fast & set(census.counts)) and "conv1_bf16x3" in census.counts, sorted(census.counts)
+    assert (emu <= set(census.counts)) if (precision == "f32x3" and N >= 512) else not (emu & set(census.counts)), sorted(census.counts)
     ref = AtariLSTMNet("cpu", A)
     ref.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
     with torch.no_grad():

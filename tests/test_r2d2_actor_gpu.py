@@ -40,7 +40,7 @@ def _run(mode, R=8, K=4, precision="f32"):
     online, keep_on = _net(capi, A, 1)
     target, _keep_tg = _net(capi, A, 2)
     for net in (online, target):
-        capi.check(capi.lib.rela_lstmnet_set_precision(net, {"f32": 0, "bf16x2": 1}[precision]), "set_precision")
+        capi.check(capi.lib.rela_lstmnet_set_precision(net, {"f32": 0, "bf16x2": 1, "f32x3": 2}[precision]), "set_precision")
     replay = C.c_void_p()
     capi.check(capi.lib.rela_replay_create(C.byref(replay), 8 * R, 7, 0.9, 0.6, 0, 0), "rela_replay_create")
     rb = (C.c_int64 * 10)(T * 28224, T * 4, T * 4 * A, T * 8, T * 4, T, T * 4, 2048, 2048, 4)

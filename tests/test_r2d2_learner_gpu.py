@@ -111,7 +111,7 @@ R2D2_FAST_KERNELS = {CONV12, "conv_bf16s<Conv3F>", "gemm_rec64_nt", "wgrad_conv1
                      CONV12_JOBS, "conv3_bf16s_jobs", "unsplit_trunk_rows"}
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x2"])
+@pytest.mark.parametrize("precision", ["f32", "f32x3", "bf16x2"])
 def test_hip_r2d2_learner_matches_reference_golden_c4_shape(precision):
     """BASELINE config C4's sequence shape (seq 80 / burn-in 40 / n 3: T = 123) with B = 16, A = 18 -- 1,968 frames,
     1,328 training rows: loss per sequence, aggregated priority and every gradient tensor of the hand-written step
@@ -138,6 +138,8 @@ def test_hip_r2d2_learner_matches_reference_golden_c4_shape(precision):
         assert R2D2_FAST_KERNELS <= set(census.counts), sorted(census.counts)
     else:
         assert not (R2D2_FAST_KERNELS & set(census.counts)), sorted(census.counts)
+    emu = {"gemm_f32emu<conv2>", "gemm_f32emu<conv3>"}  # (f32x3: both trunks, 1,968 frames each, on the three-part kernels)
+    assert (emu <= set(census.counts)) if precision == "f32x3" else not (emu & set(census.counts)), sorted(census.counts)
     np.testing.assert_allclose(loss_seq.cpu().numpy(), np.array(g["loss"]), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(prio.cpu().numpy(), np.array(g["priority"]), rtol=2e-4, atol=2e-4)
     np.testing.assert_allclose(float(loss.cpu()[0]), float((np.array(g["loss"]) * w_np).mean()), rtol=2e-4)
