@@ -45,8 +45,12 @@
 // set (285), the staging instructions folded into the tiles' MFMA shadows with double-buffered weight fragments (277:
 // ~200 v_accvgpr moves per k-step pair -- the allocator parks operands in AGPRs and the VALU, not the matrix core,
 // sets the pace); two blocks per CU with passes of 2 / 1 tiles (OCC = 2: 284 us).  Kernel time scales with 1 / clock (215 us
-// inside bench.py at 2.37 GHz): cycle-bound at ~3,900 cycles per k-step for 1,536 of MFMA.  Next: the loop in ISA-level
-// hands (AGPR-resident operands, counted vmcnt).
+// inside bench.py at 2.37 GHz): cycle-bound at ~3,900 cycles per k-step for 1,536 of MFMA.  SQ counters (conv2, per wave):
+// 317 VALU + 97 MFMA instructions per k-step, all VALU time co-executing with the MFMA pipe, the wave issuing 40 % of
+// its cycles, 32 % in s_waitcnt (LDS: 3 %) and ~25 % in other waits -- the ISA shows an s_waitcnt vmcnt(0) at the top
+// of every k-step pair, where the allocator copies registers that loads are still in flight to into AGPRs (pressure:
+// 256 architectural registers).  The same loads as opaque instructions straight into AGPRs with hand-counted vmcnt
+// (4 TMv + 4 / 2 TMv) measured slower (conv3 180 us; 327 v_accvgpr moves per pair).  Next: the loop in ISA-level hands.
 #pragma once
 #include <hip/hip_runtime.h>
 
