@@ -49,6 +49,15 @@ CFG_COHORT = dict(CFG_BIG, K=64, threads=2)
 CFG_COHORT_512 = dict(CFG_BIG, K=128, threads=4, capacity=2048, batch=64, rounds=4)
 
 
+# r5: ONE actor thread with K = 512 envs -- a 512-row shard, the batch size from which EVERY layer of the f32x3 mode (the
+# headline arithmetic of bench.py) runs its three-part bf16 kernels -- recorded from the REAL reference (one TorchScript
+# call per 512 envs on the CPU).  Ring 2,560 = five blocks of 512.  `online_fc_a_bias_add` is the offset that maximises
+# the smallest top-two gap over the run's frames (tests/golden/make_golden.py e2e_k512_scan).
+CFG_K512 = dict(K=512, multi_step=3, gamma=0.997, capacity=2048, alpha=0.6, beta=0.4, seed=23, episode_len=9,
+                num_action=18, rounds=4, batch=64, online_seed=1001, target_seed=2002, env_seed=6000,
+                online_fc_a_bias_add=[14, 0.00554])
+
+
 def frames_of_run(synth_atari, cfg, steps):
     """The observation every env of the run emits at each of its first `steps` calls (reset or step), as the thread
     loop drives it (rela/thread_loop.h:74-105: all envs share the episode length, so they reset together).  The

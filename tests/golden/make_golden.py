@@ -296,9 +296,10 @@ def ffnet_big_cases():
              td_err_hex=f32_to_hex(err.numpy()))
 
 
-def learner_big_cases():
-    """learner_cases at B = 128 (the learner's split-bf16 kernels start at 128 rows), inputs re-derived from seeds
-    by the test (legal / action / reward / bootstrap / weight: rng 143 in this order)."""
+def learner_big_cases(only=None):
+    """learner_cases at B = 128 (the learner's split-bf16 kernels start at 128 rows) and, r5, at B = 512 (the learner
+    batch of pyrela/main.py:28 and the batch size from which the f32x3 mode's three-part kernels run), inputs
+    re-derived from seeds by the test (legal / action / reward / bootstrap / weight: rng `misc` in this order)."""
     sys.dont_write_bytecode = True
     sys.path.insert(0, "/root/reference/pyrela")
     import types
@@ -308,14 +309,18 @@ def learner_big_cases():
     from net import AtariFFNet
 
     torch.set_num_threads(8)
-    for name, A, B, clip in [("learner_apex_A18_B128", 18, 128, 0.5)]:
+    for name, A, B, clip, seeds in [("learner_apex_A18_B128", 18, 128, 0.5, (3003, 4004, 141, 142, 143)),
+                                    ("learner_apex_A18_B512", 18, 512, 0.5, (3013, 4014, 151, 152, 153))]:
+        if only and name != only:
+            continue
+        s_on, s_tg, s_obs, s_nobs, s_misc = seeds
         multi_step, gamma, lr, eps = 3, 0.997, 1e-3, 1.5e-4
         agent = ApexAgent(lambda: AtariFFNet(A), multi_step, gamma)
-        on, tg = synth_params(A, 3003), synth_params(A, 4004)
+        on, tg = synth_params(A, s_on), synth_params(A, s_tg)
         agent.online_net.load_state_dict({k: torch.from_numpy(v) for k, v in on.items()})
         agent.target_net.load_state_dict({k: torch.from_numpy(v) for k, v in tg.items()})
-        s, ns = synth_obs(B, 141), synth_obs(B, 142)
-        rng = np.random.default_rng(143)
+        s, ns = synth_obs(B, s_obs), synth_obs(B, s_nobs)
+        rng = np.random.default_rng(s_misc)
         legal = (rng.uniform(size=(B, A)) < 0.8).astype(np.float32)
         nlegal = (rng.uniform(size=(B, A)) < 0.8).astype(np.float32)
         legal[:, 0] = 1.0
@@ -350,7 +355,7 @@ def learner_big_cases():
         optim.step()
         after = digest(lambda v: v)
         save(name, [], [], num_action=A, B=B, multi_step=multi_step, gamma=gamma, lr=lr, eps=eps, grad_clip=clip,
-             online_seed=3003, target_seed=4004, obs_seed=141, next_obs_seed=142,
+             online_seed=s_on, target_seed=s_tg, obs_seed=s_obs, next_obs_seed=s_nobs,
              legal=legal.tolist(), next_legal=nlegal.tolist(), action=action.tolist(), reward=reward.tolist(),
              bootstrap=bootstrap.tolist(), weight=weight.tolist(), loss=float(loss),
              priority=priority.numpy().astype(np.float64).tolist(), grad_norm=float(g_norm), grads=grads,
@@ -611,6 +616,43 @@ print("RESULT" + json.dumps({"rounds": rounds, "min_top2_gap": gap, "max_abs_q":
          max_abs_q=rec["max_abs_q"], frames_checked=rec["frames_checked"])
 
 
+def e2e_k512_scan(cfg_name="CFG_K512"):
+    """Prints, for the frames the K = 512 lock-step run can see, the advantage-bias offset of action 14 that maximises
+    the smallest gap between the two best Q-values (the value then written into tests/e2e_lockstep.py CFG_K512)."""
+    code = r"""
+import json, sys
+sys.dont_write_bytecode = True
+sys.path[:0] = [%r, %r, "/root/reference/pyrela"]
+import numpy as np
+import torch
+torch.set_num_threads(8)
+import rela, synth_atari
+from apex import ApexAgent
+from net import AtariFFNet
+from e2e_lockstep import %s as CFG, load_agent_params, frames_of_run
+cfg = dict(CFG, online_fc_a_bias_add=None)
+agent = load_agent_params(ApexAgent(lambda: AtariFFNet(cfg["num_action"]), cfg["multi_step"], cfg["gamma"]), cfg)
+frames = frames_of_run(synth_atari, cfg, 24)
+qs = []
+with torch.no_grad():
+    for t in range(frames.shape[0]):
+        obs = {"s": torch.from_numpy(frames[t]), "legal_move": torch.ones(cfg["K"], cfg["num_action"])}
+        qs.append(agent.online_net(obs).double().numpy())
+q = np.concatenate(qs)
+best = None
+for delta in np.linspace(0.0, 0.03, 3001):
+    qq = q.copy(); qq[:, 14] += delta
+    top = np.sort(qq, axis=1)[:, -2:]
+    gap = float((top[:, 1] - top[:, 0]).min())
+    other = int((qq.argmax(1) != 14).sum())
+    if other >= 20 and (best is None or gap > best[1]):
+        best = (float(delta), gap, other)
+print("RESULT" + json.dumps({"delta": best[0], "min_gap": best[1], "decisions_not_14": best[2], "rows": int(q.shape[0])}))
+""" % (REFBIN, os.path.dirname(HERE), cfg_name)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    print(out.stdout[-2000:], out.stderr[-3000:])
+
+
 def e2e_r2d2_cases(cfg_name="CFG_R2D2", out_name="e2e_lockstep_r2d2", quiet=1.0):
     """The REAL reference's R2D2 path end to end (H6-shimmed module, see oracle/Makefile)."""
     code = r"""
@@ -655,6 +697,10 @@ if __name__ == "__main__":
         e2e_cases()
     if "e2e_big" in which:  # r4: K = 128 rows, reaches the split-bf16 kernels; ~1 minute
         e2e_big_cases()
+    if "e2e_k512_scan" in which:
+        e2e_k512_scan()
+    if "e2e_k512" in which:  # r5: K = 512 rows, reaches every three-part kernel of the f32x3 mode; ~2 minutes
+        e2e_big_cases("CFG_K512", "e2e_lockstep_apex_k512")
     if "e2e_sliding" in which:  # Atari-like sliding frame stacks (for the de-duplicating replay)
         e2e_cases("CFG_SLIDING", "e2e_lockstep_apex_sliding")
     if "replay" in which:
@@ -675,5 +721,7 @@ if __name__ == "__main__":
         ffnet_big_cases()
     if "learner_big" in which:
         learner_big_cases()
+    if "learner_b512" in which:   # r5: only the B = 512 case
+        learner_big_cases("learner_apex_A18_B512")
     if "r2d2loss_big" in which:   # ~2 minutes on 8 cores
         r2d2loss_big_cases()

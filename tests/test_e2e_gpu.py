@@ -155,6 +155,50 @@ def test_lockstep_k128_matches_reference_in_both_precision_modes(mods, dedup_env
                                    err_msg="IS weights, round %d, %s" % (r, precision))
 
 
+# kernels of the f32x3 mode (csrc/ffnet.hip: from 512 rows every dense layer of the trunk runs on the bf16 matrix cores with
+# three-part operands) -- tests/test_ffnet_gpu.py expected_kernels is the per-layer statement
+F32X3_KERNELS = {"conv12_s3", "conv3_img_s3", "gemm_s3<fc>"}
+
+
+@pytest.mark.parametrize("precision", ["f32", "f32x3"])
+def test_lockstep_k512_matches_reference_in_f32_and_f32x3(mods, dedup_env, precision_env, precision):
+    """the HEADLINE arithmetic pinned at engine level to the REAL reference.  One actor thread x 512
+    envs (one 512-row shard: the batch size from which every dense layer of the f32x3 mode runs its three-part bf16
+    kernels) through rela.Context / BasicThreadLoop / DQNActor / FFPrioritizedReplay (alpha 0.6 / beta 0.4), driven
+    exactly like the reference was when tests/golden/e2e_lockstep_apex_k512.json was recorded (its C++ actor, its
+    TorchScript ApexAgent on the CPU: rela/dqn_actor.h:153-203, pyrela/apex.py:30-78, pyrela/net.py:42-53).  Frames,
+    actions, flags, n-step rewards: exact; IS weights (TD priorities through pow and the scan): 1e-4 relative in BOTH
+    modes -- f32x3 gets the f32 mode's tolerance.  Exact greedy actions are a checked expectation: the golden records
+    the smallest top-two gap of the run (1e-4) against |dQ| of a few 1e-7.  The launch census asserts the kernels."""
+    from e2e_lockstep import CFG_K512 as C, load_agent_params, run_lockstep
+    from kernel_names import CONV12
+    from rela_amd import _capi as capi
+    from rela_amd.pyrela.apex import ApexAgent
+    from rela_amd.pyrela.net import AtariFFNet
+
+    rela, synth = mods
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "e2e_lockstep_apex_k512.json")))
+    assert gold["cfg"] == C
+    assert gold["min_top2_gap"] > 20 * 1e-6 * max(1.0, gold["max_abs_q"]), "decisions too close for an exact action comparison"
+    dedup_env(None)
+    precision_env(precision)
+    agent = load_agent_params(ApexAgent(lambda: AtariFFNet(C["num_action"]), C["multi_step"], C["gamma"]), C)
+    with capi.launch_census() as census:
+        rounds = run_lockstep(rela, synth, agent, "cuda:0", "cuda:0", C)
+    ran = set(census.counts)
+    if precision == "f32x3":
+        assert F32X3_KERNELS <= ran and not ((FAST_KERNELS | {CONV12} | F32_KERNELS) & ran), census.counts
+    else:
+        assert F32_KERNELS <= ran and not ((FAST_KERNELS | {CONV12} | F32X3_KERNELS) & ran), census.counts
+    assert len(rounds) == len(gold["expect"])
+    for r, (got, exp) in enumerate(zip(rounds, gold["expect"])):
+        for key in ("s_sum", "s_head", "next_s_sum", "s_planes", "next_s_planes", "a", "terminal", "bootstrap", "eps",
+                    "legal_sum", "num_add"):
+            assert got[key] == exp[key], (precision, r, key)
+        assert np.array_equal(np.float32(got["reward"]), np.float32(exp["reward"])), (precision, r)
+        np.testing.assert_allclose(got["weight"], exp["weight"], rtol=1e-4, err_msg="IS weights, round %d, %s" % (r, precision))
+
+
 @pytest.mark.parametrize("plane_upload", ["1", "0"])
 def test_cohort_plane_upload_matches_reference_sliding_golden(mods, dedup_env, plane_upload):
     """r4: a VectorEnv whose envs all declare a sliding frame stack (rela::FrameRowEnv) uploads only the NEWEST 84x84

@@ -90,11 +90,12 @@ def forward_checked(net, s, legal, precision):
     return q
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x2"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x2", "f32x3"])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "ffnet_*.json"))), ids=os.path.basename)
 def test_ffnet_golden(path, precision, record_property):
-    """Q(s), greedy action and TD priority vs the REAL reference's own net.py / apex.py outputs, in BOTH precision
-    modes.  ffnet_A18_N1024 reaches every split-bf16 kernel (conv12_i8, conv_bf16s<Conv3F>, fc_bf16s),
+    """Q(s), greedy action and TD priority vs the REAL reference's own net.py / apex.py outputs, in ALL THREE precision
+    modes (r5: the headline arithmetic f32x3 is pinned to the reference's recorded Q tables directly, at the f32
+    mode's tolerance, with its kernels asserted through the launch census -- ffnet_A18_N1024 reaches them).  ffnet_A18_N1024 reaches every split-bf16 kernel (conv12_i8, conv_bf16s<Conv3F>, fc_bf16s),
     ffnet_A18_N256_q50 the fast trunk at a trained agent's |Q| of ~55 (every weight tensor x 4.6); the two small
     goldens (N = 5 and 3) run the f32 kernels in either mode -- all asserted through the launch census.
     Tolerance: 1e-4 of max|Q| + 1e-4 relative (the reference's library convolutions sum in another order)."""
@@ -187,11 +188,12 @@ def test_ffnet_vs_torch_fp32(N, precision):
     net.close()
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x2"])
-@pytest.mark.parametrize("N", [6, 128, 1024, 2003, 6400])
+@pytest.mark.parametrize("precision", ["f32", "bf16x2", "f32x3"])
+@pytest.mark.parametrize("N", [6, 128, 1024, 2003, 4100, 6400])
 def test_ffnet_vs_oracle_c(N, precision):
     """The same comparison against the plain-C oracle (oracle/dqn_oracle.c, itself pinned to the reference's
-    goldens by tests/test_oracle_golden.py), in both precision modes, up to bench.py's 6,400 rows."""
+    goldens by tests/test_oracle_golden.py), in all three precision modes, up to bench.py's 6,400 rows (f32x3: every
+    layer's three-part kernel from 512 rows, asserted through the launch census)."""
     from oracle_lib import load
     from synth import synth_obs, synth_params
     from test_oracle_golden import _ffnet_struct
