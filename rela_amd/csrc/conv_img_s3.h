@@ -104,48 +104,66 @@ __global__ __launch_bounds__(256, 1) void conv3_img_s3(const uint8_t* __restrict
   issue_frame(2);
   int cur = 0;  // newest frame whose lines are visible
 
-  for (int t = 0; t < ntiles; ++t) {
-    const int last = min(16 * t + 15, rows - 1) / 49;  // (uniform) newest frame this tile reads
-    if (last > cur) {
-      wait_vm<C::G>();                 // frame cur + 1 has landed (frame cur + 2 may still be in flight)
-      __builtin_amdgcn_s_barrier();    // ... for every wave; and everybody is done with frame cur - 1
-      cur = last;
-      issue_frame(cur + 2);
-    }
+  auto frag_addr = [&](int t) {  // this lane's pixel of tile t: address of its record's unit g in the LDS image
     const int m = min(16 * t + li, rows - 1);
     const int fr = m / 49, pos = m - 49 * fr;
     const int oy = pos / 7, ox = pos - 7 * oy;
-    const uint32_t xa = lds0 + (uint32_t)(fr & 3) * C::SLOT_BYTES + (uint32_t)((oy * C::RQ + ox * C::Q + g) * 16);
-    f32x4 acc = bv, accs = {0.f, 0.f, 0.f, 0.f};
-    u32x4 x[3][3];
-    static_for<3>([&](auto kk) {
-      constexpr int K = decltype(kk)::value;
-      x[K][0] = lds_read128<C::koff(K)>(xa);
-      x[K][1] = lds_read128<C::koff(K) + 128>(xa);
-      x[K][2] = lds_read128<C::koff(K) + 256>(xa);
-    });
+    return lds0 + (uint32_t)(fr & 3) * C::SLOT_BYTES + (uint32_t)((oy * C::RQ + ox * C::Q + g) * 16);
+  };
+  // The fragment ring (three k-steps deep) runs on ACROSS tiles: the last three k-steps of a tile issue the first three
+  // of the next one, whose reads then complete under the epilogue; they are waited for before the loop's back edge, so
+  // no register holds an LDS read in flight where the compiler could touch it.
+  uint32_t xa = frag_addr(0);
+  u32x4 x[3][3];
+  static_for<3>([&](auto kk) {
+    constexpr int K = decltype(kk)::value;
+    x[K][0] = lds_read128<C::koff(K)>(xa);
+    x[K][1] = lds_read128<C::koff(K) + 128>(xa);
+    x[K][2] = lds_read128<C::koff(K) + 256>(xa);
+  });
+  static_for<3>([&](auto kk) { wait_lgkm<0>(x[decltype(kk)::value][0], x[decltype(kk)::value][1], x[decltype(kk)::value][2]); });
+
+  for (int t = 0; t < ntiles; ++t) {
+    f32x4 acc = bv, accs = {0.f, 0.f, 0.f, 0.f}, acct = {0.f, 0.f, 0.f, 0.f};
+    uint32_t xn = xa;
     static_for<C::KS>([&](auto kk) {
       constexpr int K = decltype(kk)::value, R = K % 3;
-      constexpr int YOUNGER = (K + 2 < C::KS ? 6 : (C::KS - 1 - K) * 3);
-      wait_lgkm<YOUNGER>(x[R][0], x[R][1], x[R][2]);
+      if constexpr (K == C::KS - 6) {
+        // the next tile's frame: its lines must be visible before that tile's first reads (issued at k-step KS - 3)
+        const int tn = min(t + 1, ntiles - 1);
+        const int last = min(16 * tn + 15, rows - 1) / 49;  // (uniform) newest frame the next tile reads
+        if (last > cur) {
+          wait_vm<C::G>();               // frame cur + 1 has landed (frame cur + 2 may still be in flight)
+          __builtin_amdgcn_s_barrier();  // ... for every wave; this tile reads frame cur only: cur - 1 is free
+          cur = last;
+          issue_frame(cur + 2);
+        }
+        xn = frag_addr(tn);
+      }
+      wait_lgkm<6>(x[R][0], x[R][1], x[R][2]);
       const bf16x8 x0 = __builtin_bit_cast(bf16x8, x[R][0]), x1 = __builtin_bit_cast(bf16x8, x[R][1]),
                    x2 = __builtin_bit_cast(bf16x8, x[R][2]);
+      // the five small products have accumulators of their own (two chains), added once per tile
       accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[K][2], x0, accs, 0, 0, 0);
-      accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[K][0], x2, accs, 0, 0, 0);
+      acct = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[K][0], x2, acct, 0, 0, 0);
       accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[K][1], x1, accs, 0, 0, 0);
-      accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[K][1], x0, accs, 0, 0, 0);
+      acct = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[K][1], x0, acct, 0, 0, 0);
       accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[K][0], x1, accs, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[K][0], x0, acc, 0, 0, 0);
       if constexpr (K + 3 < C::KS) {
         x[R][0] = lds_read128<C::koff(K + 3)>(xa);
         x[R][1] = lds_read128<C::koff(K + 3) + 128>(xa);
         x[R][2] = lds_read128<C::koff(K + 3) + 256>(xa);
+      } else {
+        x[R][0] = lds_read128<C::koff(K + 3 - C::KS)>(xn);
+        x[R][1] = lds_read128<C::koff(K + 3 - C::KS) + 128>(xn);
+        x[R][2] = lds_read128<C::koff(K + 3 - C::KS) + 256>(xn);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
     // ---- epilogue: ReLU, split, this lane's four channels of its pixel
     if (16 * t + li < rows) {
-      f32x4 v = acc + accs;
+      f32x4 v = acc + (accs + acct);
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
       uint2 p0, p1, p2;
@@ -155,6 +173,8 @@ __global__ __launch_bounds__(256, 1) void conv3_img_s3(const uint8_t* __restrict
       *reinterpret_cast<uint2*>(o + 128) = p1;
       *reinterpret_cast<uint2*>(o + 256) = p2;
     }
+    static_for<3>([&](auto kk) { wait_lgkm<0>(x[decltype(kk)::value][0], x[decltype(kk)::value][1], x[decltype(kk)::value][2]); });
+    xa = xn;
   }
   wait_vm<0>();  // no LDS-DMA may outlive the workgroup's LDS allocation
 }

@@ -30,6 +30,9 @@
 #include "common.h"
 #include "gemm_bf16s.h"
 #include "gemm_f32emu.h"
+#include "gemm_s3.h"
+#include "conv_img_s3.h"
+#include "conv12_s3.h"
 #include "ffnet_layout.h"
 #include "gemm_lds.h"
 #include "prof.h"
@@ -629,11 +632,11 @@ struct ConvFastCfg {
 };
 constexpr int kFastMinN = 1024;  // below this fc_bf16s has too few blocks and the f32 split-K fc is faster
 constexpr int kFastTrunkMinN = 128;  // from here up the split-bf16 convolutions beat the f32 ones
-// f32-accurate bf16 mode (precision 2, gemm_f32emu.h), per layer from the batch size at which it beats the exact f32 MFMA
-// kernel (measured r4, us emu / f32: conv2 25 / 33 and conv3 27 / 33 at 512 rows; fc is one 98-step pass per wave -- 95 us
-// at 512 rows, 115 at 3,200, 150 at 6,554 against 25 / 100 / 203); smaller batches run the f32 kernels (same accuracy,
-// same activation layout).  Byte offsets inside a1 are 32-bit: 51,200 B per sample.
-constexpr int kEmuConvMinN = 512, kEmuFcMinN = 4096, kEmuMaxN = 80000;
+// f32-accurate bf16 mode (precision 2: the f32x3 arithmetic of gemm_f32emu.h).  r5: from kEmuConvMinN rows the whole trunk
+// runs on pre-split activations ("split3 records", gemm_s3.h): conv1 -> conv2 fused per frame (conv12_s3.h), conv3 as an
+// image kernel with resident weights (conv_img_s3.h), fc as an LDS-DMA GEMM over records (gemm_s3.h); smaller batches
+// run the exact f32 MFMA kernels (same accuracy, channel-last f32).  Byte offsets inside the records are 32-bit.
+constexpr int kEmuConvMinN = 512, kEmuFcMinN = 512, kEmuMaxN = 80000;
 // conv2: 20x20x32 -> 9x9x64, stride 2: 2*Q = 2, 2*RQ = 18 = 2 (mod 16)
 using Conv2F = ConvFastCfg<32, 20, 20, 4, 4, 2, 9, 9, 1, 9, 185, 20 * 185>;
 // conv3: 9x9x64 -> 7x7x64, stride 1: Q = 2, RQ = 14 (7 positions per row), SQ = 98 = 2 (mod 16)
@@ -2016,6 +2019,10 @@ extern "C" int rela_ffnet_create(rela_ffnet** out, int num_action, int device) {
   RELA_HIP(hipMalloc(&d.B3e, sizeof(uint4) * f32emu::packed_u4<f32emu::ProbConv3>()));
   RELA_HIP(hipMalloc(&d.Bfe, sizeof(uint4) * f32emu::packed_u4<f32emu::ProbFc>()));
   // opt in to > 64 KB of dynamic LDS once per process/device
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&s3::conv12_s3<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               s3::Conv12S::LDS_TOTAL));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&s3::conv12_s3<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               s3::Conv12S::LDS_TOTAL));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1_bf16x3),
                                hipFuncAttributeMaxDynamicSharedMemorySize, Conv1B::LDS_BYTES));
   RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16s<Conv3F>),
@@ -2172,10 +2179,18 @@ extern "C" int rela_ffnet_set_precision(rela_ffnet* n, int mode) {
 }
 extern "C" int rela_ffnet_precision(const rela_ffnet* n) { return n ? n->precision : 0; }
 
+// split3 records of a2 / a3 (f32x3 mode, gemm_s3.h) live behind the f32 layout of ffnet_layout.h (and the fc split-K
+// partial tiles): 6 bytes per value where the f32 tensors have 4
+constexpr int64_t kRec2Bytes = 81 * 384, kRec3Bytes = 49 * 384;
+static inline int64_t ws_records_offset(int batch) {
+  const int64_t b = batch > 0 ? batch : 0;
+  const int64_t f = (int64_t)sizeof(float) * (kWsFloatsPerSample * b + (b < kFcSplitBelow ? kFcPartFloats : 0)) + 256;
+  return (f + 255) & ~(int64_t)255;
+}
 extern "C" int64_t rela_ffnet_workspace_bytes(const rela_ffnet* n, int batch) {
   (void)n;
   const int64_t b = batch > 0 ? batch : 0;
-  return (int64_t)sizeof(float) * (kWsFloatsPerSample * b + (b < kFcSplitBelow ? kFcPartFloats : 0)) + 256;
+  return ws_records_offset((int)b) + b * (kRec2Bytes + kRec3Bytes) + 256;
 }
 
 extern "C" int rela_ffnet_load(rela_ffnet* n, const rela_ffnet_params* p, int on_device, void* stream_) {
@@ -2290,7 +2305,8 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
              "rela_ffnet_forward: batch %d on a net whose owner declared at most %d rows", N, n->max_rows);
   // (a net packed for small batches only has no bf16 fc fragments: it keeps the f32 fc whatever the threshold says)
   const int fast_min_n = (n->max_rows > 0 && n->max_rows < kFastMinN) ? n->max_rows + 1 : kFastMinN;
-  const int precision = mode < 0 ? n->precision : mode;
+  const bool keep_f32 = mode == 3;  // f32x3 that also leaves a1 / a2 / a3 in channel-last f32 (the learner's online(obs) pass)
+  const int precision = mode < 0 ? n->precision : (mode == 3 ? 2 : mode);
   // Between kFastTrunkMinN and kFastMinN rows the convolutions still win on split-bf16 MFMA (N = 512: 39 us against
   // 90 us in f32) but fc_bf16s has too few blocks (55 us against the 24 us of the f32 split-K GEMM): the trunk runs
   // fast, a3 is turned back into f32 in place and fc takes the f32 path.
@@ -2298,7 +2314,6 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
   // ... and (r3) fc too, as a split-K launch of fc_bf16s, when this net packs the bf16 fc fragments
   const bool fc_split_bf16 = fast_trunk_only && !(n->max_rows > 0 && n->max_rows < kFastTrunkMinN);
   const bool emu_conv = precision == 2 && N >= kEmuConvMinN && N <= kEmuMaxN && !(n->max_rows > 0 && n->max_rows < kEmuConvMinN);
-  const bool emu_fc = precision == 2 && N >= kEmuFcMinN && N <= kEmuMaxN && !(n->max_rows > 0 && n->max_rows < kEmuFcMinN);
   if (fast_trunk_only) {
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
@@ -2354,40 +2369,58 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
                            (const uint8_t*)r3, (const uint4*)d.Bff, (const float*)d.bf, h, N, 0);
     }
   } else {
+  if (emu_conv) {
+    // f32x3 (precision 2; mode 3 = the learner's pass that also leaves a1 / a2 / a3 in f32 for the backward kernels): the
+    // trunk on split3 records.  conv1 -> conv2 fused per frame; conv3 from LDS images with resident weights; fc below.
+    uint8_t* rec2 = static_cast<uint8_t*>(ws) + ws_records_offset(N);
+    uint8_t* rec3 = rec2 + (int64_t)N * kRec2Bytes;
+    {
+      ProfScope prof(name12, s);
+      note_launch("conv12_s3");
+      if (keep_f32)
+        hipLaunchKernelGGL(s3::conv12_s3<true>, dim3(std::min(kNumCU, N)), dim3(s3::Conv12S::kT), s3::Conv12S::LDS_TOTAL, s, s_dev,
+                           (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2e, (const float*)d.b2,
+                           rec2, a1, N);
+      else
+        hipLaunchKernelGGL(s3::conv12_s3<false>, dim3(std::min(kNumCU, N)), dim3(s3::Conv12S::kT), s3::Conv12S::LDS_TOTAL, s, s_dev,
+                           (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2e, (const float*)d.b2,
+                           rec2, (float*)nullptr, N);
+    }
+    {
+      ProfScope prof(names[2], s);
+      note_launch("conv3_img_s3");
+      s3::launch_conv3_img(rec2, d.B3e, d.b3, rec3, N, s);
+    }
+    {
+      ProfScope prof(names[3], s);
+      note_launch("gemm_s3<fc>");
+      s3::launch<s3::ProbFc, false>(rec3, d.Bfe, d.bf, h, N, s);
+    }
+    if (keep_f32) {
+      note_launch("unsplit_s3");
+      const int64_t p2 = (int64_t)N * 81, p3 = (int64_t)N * 49;
+      hipLaunchKernelGGL(s3::unsplit_s3<64>, dim3((unsigned)ceil_div(p2 * 16, 256)), dim3(256), 0, s, (const uint8_t*)rec2, a2, p2);
+      hipLaunchKernelGGL(s3::unsplit_s3<64>, dim3((unsigned)ceil_div(p3 * 16, 256)), dim3(256), 0, s, (const uint8_t*)rec3, a3, p3);
+    }
+  } else {
   if (!fast_trunk_only) {
   {
     ProfScope prof(names[0], s);
     note_launch("conv1_bf16x3"); hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev,
                        d.B1, d.b1, a1, N);
   }
-  // f32x3 mode (precision 2): conv2 / conv3 / fc with BOTH operands as three bf16 parts and six products each on the
-  // bf16 MFMA (gemm_f32emu.h), layer by layer from the batch size at which each beats its exact f32 MFMA kernel;
-  // activations stay channel-last f32 between the layers in either case, conv1 is exact as in the f32 mode
   {
     ProfScope prof(names[1], s);
-    if (emu_conv) {
-      note_launch("gemm_f32emu<conv2>");
-      f32emu::launch<f32emu::ProbConv2, 6, 1>(a1, d.B2e, d.b2, a2, N * 81, s);
-    } else {
-      launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
-    }
+    launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
   }
   {
     ProfScope prof(names[2], s);
-    if (emu_conv) {
-      note_launch("gemm_f32emu<conv3>");
-      f32emu::launch<f32emu::ProbConv3, 6, 1>(a2, d.B3e, d.b3, a3, N * 49, s);
-    } else {
-      launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
-    }
+    launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
   }
   }
-  if (fc_split_bf16) {
+  }
+  if (fc_split_bf16 || emu_conv) {
     // (h is already there)
-  } else if (emu_fc) {
-    ProfScope prof(names[3], s);
-    note_launch("gemm_f32emu<fc>");
-    f32emu::launch<f32emu::ProbFc, 6, 1>(a3, d.Bfe, d.bf, h, N, s);
   } else if (N < kFcSplitBelow) {
     const int splits = fc_splits(N);
     float* part = ha + kHA * N;

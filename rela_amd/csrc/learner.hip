@@ -319,7 +319,7 @@ extern "C" int rela_apex_learner_loss(rela_apex_learner* l, int batch, const voi
     rc = rela_ffnet_forward(l->target, Bn, nobs, nlegal, q_nt, l->ws_tmp, l->ws_bytes, s);
     if (rc != RELA_OK) return rc;
     // f32 activations for the backward, which reads a1..h (the f32x3 mode keeps that layout: it may serve this pass too)
-    rc = ffnet_forward_mode(l->online, Bn, obs, legal, q_on, l->ws_on, l->ws_bytes, s, rela_ffnet_precision(l->online) == 2 ? 2 : 0);
+    rc = ffnet_forward_mode(l->online, Bn, obs, legal, q_on, l->ws_on, l->ws_bytes, s, rela_ffnet_precision(l->online) == 2 ? 3 : 0);
     if (rc != RELA_OK) return rc;
   }
   if (Bn <= 1024) {

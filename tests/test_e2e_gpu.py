@@ -323,7 +323,7 @@ def test_cohort_in_f32x3_mode_agrees_with_the_f32_cohort(mods, dedup_env, precis
 
     rela, synth = mods
     dedup_env(None)
-    emu = {"gemm_f32emu<conv2>", "gemm_f32emu<conv3>"}
+    emu = {"conv12_s3", "conv3_img_s3", "gemm_s3<fc>"}
     runs = {}
     for precision in ("f32", "f32x3"):
         precision_env(precision)

@@ -65,16 +65,19 @@ class GpuNet:
 # tests of the split-bf16 mode assert this through the launch census (rela_prof_count_enable), so a silent fall-back
 # to the f32 kernels -- what a batch below 128 rows gets, by design -- cannot pass for a test of the fast kernels.
 FAST_TRUNK_MIN_N, FAST_FC_MIN_N = 128, 1024
-# csrc/ffnet.hip kEmuConvMinN / kEmuFcMinN: below them the "f32x3" mode runs that layer's exact f32 MFMA kernel
-EMU_CONV_MIN_N, EMU_FC_MIN_N = 512, 4096
+# csrc/ffnet.hip kEmuConvMinN: from this batch size the "f32x3" mode runs EVERY dense layer of the trunk with three-part
+# operands on the bf16 matrix cores (r5: over split3 records -- conv1 -> conv2 fused, conv3 from LDS images, fc as an
+# LDS-DMA GEMM); below it the exact f32 MFMA kernels
+EMU_MIN_N = 512
+F32X3_KERNELS = {"conv12_s3", "conv3_img_s3", "gemm_s3<fc>"}
 
 
 def expected_kernels(N, precision):
     if precision == "bf16x2" and N >= FAST_TRUNK_MIN_N:
         trunk = {CONV12, "conv_bf16s<Conv3F>"}
         return trunk | ({"fc_bf16s"} if N >= FAST_FC_MIN_N else {"fc_bf16s (split-K)"})
-    if precision == "f32x3" and N >= EMU_CONV_MIN_N:
-        return {"conv1_bf16x3", "gemm_f32emu<conv2>", "gemm_f32emu<conv3>"} | ({"gemm_f32emu<fc>"} if N >= EMU_FC_MIN_N else set())
+    if precision == "f32x3" and N >= EMU_MIN_N:
+        return set(F32X3_KERNELS)
     return {"conv1_bf16x3", "conv_mfma<Conv2> (f32)", "conv_mfma<Conv3> (f32)"}
 
 

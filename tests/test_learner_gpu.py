@@ -76,9 +76,9 @@ def test_loss_priority_and_gradients_match_autograd(B, A, precision):
 
     with capi.launch_census() as census:
         loss, prio = learner.backward(batch, w)
-    emu = {"gemm_f32emu<conv2>", "gemm_f32emu<conv3>"}
+    emu = {"conv12_s3", "conv3_img_s3", "gemm_s3<fc>"}
     if precision == "f32x3" and B >= 512:
-        assert emu <= set(census.counts) and census.counts["gemm_f32emu<conv2>"] == 3, census.counts
+        assert emu <= set(census.counts) and census.counts["conv12_s3"] == 3, census.counts
     else:
         assert not (emu & set(census.counts)), census.counts
     per_sample, ref_prio = agent.loss(batch, sync_priority=False)
