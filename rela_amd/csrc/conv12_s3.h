@@ -25,6 +25,13 @@ namespace rela_amd {
 namespace s3 {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+// probe builds only (tools/ubench/s3_probe.hip): leave one part of the kernel out to see what it costs
+#ifndef C12_ABLATE
+#define C12_ABLATE 0
+#endif
+
+constexpr bool kNoCopyOut = C12_ABLATE == 1, kNoStage = C12_ABLATE == 2, kNoEpi1 = C12_ABLATE == 3, kNoEpi2 = C12_ABLATE == 4,
+               kNoConv1 = C12_ABLATE == 5, kNoConv2 = C12_ABLATE == 6;
 
 struct Conv12S {
   static constexpr int kT = 256;
@@ -90,25 +97,23 @@ __global__ __launch_bounds__(256, 1) void conv12_s3(const uint8_t* __restrict__ 
 
   // ---- staging of a frame's cells (clamped cell index; a cell = rows 4Y .. 4Y + 3 x 4 bytes of one plane)
   uint32_t st[F::IT][4];
-  auto cell_of = [&](int j, int& goff, int& loff) {
+  int cgoff[F::IT], cloff[F::IT];  // (frame-invariant: this thread's cells in the frame and in T1)
+#pragma unroll
+  for (int j = 0; j < F::IT; ++j) {
     const int c = min(tid + j * F::kT, F::CELLS - 1);
     const int pl = c / F::NPIX, P = c - pl * F::NPIX;
     const int Y = P / F::GW, X = P - Y * F::GW;
-    goff = pl * F::PLANE_ELEMS + 4 * Y * 84 + 4 * X;
-    loff = pl * F::PLANE1 + P * 16;
-  };
+    cgoff[j] = pl * F::PLANE_ELEMS + 4 * Y * 84 + 4 * X;
+    cloff[j] = pl * F::PLANE1 + P * 16;
+  }
   auto g_load1 = [&](int fr, int j) __attribute__((always_inline)) {
-    const uint8_t* src = in + (size_t)fr * F::IN_ELEMS;
-    int goff, loff;
-    cell_of(j, goff, loff);
+    const uint8_t* src = in + (size_t)fr * F::IN_ELEMS + cgoff[j];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) st[j][r] = *reinterpret_cast<const uint32_t*>(src + goff + r * 84);
+    for (int r = 0; r < 4; ++r) st[j][r] = *reinterpret_cast<const uint32_t*>(src + r * 84);
   };
   auto s_store = [&](int j) __attribute__((always_inline)) {  // x -> x - 128 as int8: flip the sign bits
-    int goff, loff;
-    cell_of(j, goff, loff);
-    *reinterpret_cast<uint4*>(t1 + loff) = make_uint4(st[j][0] ^ 0x80808080u, st[j][1] ^ 0x80808080u, st[j][2] ^ 0x80808080u,
-                                                      st[j][3] ^ 0x80808080u);
+    *reinterpret_cast<uint4*>(t1 + cloff[j]) = make_uint4(st[j][0] ^ 0x80808080u, st[j][1] ^ 0x80808080u, st[j][2] ^ 0x80808080u,
+                                                          st[j][3] ^ 0x80808080u);
   };
 
   // ---- the output tile of the previous frame -> HBM, in slices behind conv1's MFMAs
@@ -164,15 +169,19 @@ __global__ __launch_bounds__(256, 1) void conv12_s3(const uint8_t* __restrict__ 
     static_for<TOT>([&](auto it) {
       constexpr int IDX = decltype(it)::value, KS = IDX / NT, T = IDX - KS * NT, SLOT = IDX % D;
       const i32x4 xv = __builtin_bit_cast(i32x4, x[SLOT]);
-      s_hi[T] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd[KS][0], xv, s_hi[T], 0, 0, 0);
-      s_mid[T] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd[KS][1], xv, s_mid[T], 0, 0, 0);
-      s_lo[T] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd[KS][2], xv, s_lo[T], 0, 0, 0);
+      if constexpr (!kNoConv1) {
+        s_hi[T] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd[KS][0], xv, s_hi[T], 0, 0, 0);
+        s_mid[T] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd[KS][1], xv, s_mid[T], 0, 0, 0);
+        s_lo[T] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wd[KS][2], xv, s_lo[T], 0, 0, 0);
+      } else {
+        asm volatile("" ::"v"(xv));
+      }
       if constexpr (IDX + D < TOT) a_issue(IC<IDX + D>{}, SLOT);
       hook(IC<T0 * 4 + IDX>{});
       __builtin_amdgcn_sched_barrier(0);
     });
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int t = 0; t < (kNoEpi1 ? 0 : NT); ++t) {
       // (the odd group's thirteenth tile is tile 24 again: the same values to the same addresses as the even group's)
       const int rt = min(rg1 + 2 * (T0 + t), 24);
       const int m = rt * 16 + li;
@@ -200,10 +209,12 @@ __global__ __launch_bounds__(256, 1) void conv12_s3(const uint8_t* __restrict__ 
   for (int j = 0; j < F::IT; ++j) s_store(j);
   __syncthreads();
 
-  // copy-out slots: read chunk j from O behind conv1's item 2 j, store it behind item 2 j + 1 (first pass: 20 items)
   auto copy_hook = [&](auto idx_tag) {
     constexpr int IDX = decltype(idx_tag)::value;
-    if constexpr (IDX < 2 * F::OIT) {
+    // copy-out slots: read chunk j from O behind conv1's item 2 j, store it behind item 2 j + 1 (first pass: 20 items)
+    // (measured r5, same box: chunks spaced six items apart instead of one 302 us against 303; a conv1 ring of 8 instead of
+    // 4 items 315)
+    if constexpr (!kNoCopyOut && IDX < 2 * F::OIT) {
       if constexpr (IDX % 2 == 0) o_read(IC<IDX / 2>{});
       else o_write(IC<IDX / 2>{});
     }
@@ -216,6 +227,7 @@ __global__ __launch_bounds__(256, 1) void conv12_s3(const uint8_t* __restrict__ 
     conv1_pass(IC<0>{}, IC<5>{}, copy_hook);
     conv1_pass(IC<5>{}, IC<4>{}, no_hook);
     conv1_pass(IC<9>{}, IC<4>{}, no_hook);
+    if constexpr (kNoEpi1) asm volatile("" ::"v"(sc1), "v"(bv1));
     __syncthreads();  // T2 complete, T1 and O free
     // ---- conv2 from T2, tile by tile; the next frame's cells go into T1 in the second half
     {
@@ -242,20 +254,25 @@ __global__ __launch_bounds__(256, 1) void conv12_s3(const uint8_t* __restrict__ 
         constexpr int IDX = decltype(it)::value, T = IDX / F::KS2, KS = IDX - T * F::KS2, SLOT = IDX % D;
         const bf16x8 x0 = __builtin_bit_cast(bf16x8, xr[SLOT][0]), x1 = __builtin_bit_cast(bf16x8, xr[SLOT][1]),
                      x2 = __builtin_bit_cast(bf16x8, xr[SLOT][2]);
-        accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[KS][2], x0, accs, 0, 0, 0);
-        accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[KS][0], x2, accs, 0, 0, 0);
-        accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[KS][1], x1, accs, 0, 0, 0);
-        accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[KS][1], x0, accs, 0, 0, 0);
-        accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[KS][0], x1, accs, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[KS][0], x0, acc, 0, 0, 0);
+        if constexpr (!kNoConv2) {
+          accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[KS][2], x0, accs, 0, 0, 0);
+          accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[KS][0], x2, accs, 0, 0, 0);
+          accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[KS][1], x1, accs, 0, 0, 0);
+          accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[KS][1], x0, accs, 0, 0, 0);
+          accs = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[KS][0], x1, accs, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[KS][0], x0, acc, 0, 0, 0);
+        } else {
+          asm volatile("" ::"v"(x0), "v"(x1), "v"(x2));
+        }
         if constexpr (IDX + D < TOT) a_issue(IC<IDX + D>{}, SLOT);
         // the next frame's cells: loaded behind items 1, 5, 9, ..., stored (sign bits flipped) in the second half
         static_for<F::IT>([&](auto jj) {
           constexpr int JJ = decltype(jj)::value;
-          if constexpr (IDX == 1 + 4 * JJ) g_load1(nn, JJ);
-          if constexpr (IDX == TOT / 2 + 4 * JJ) s_store(JJ);
+          if constexpr (IDX == 1 + 4 * JJ && !kNoStage) g_load1(nn, JJ);
+          if constexpr (IDX == TOT / 2 + 4 * JJ && !kNoStage) s_store(JJ);
         });
-        if constexpr (KS == F::KS2 - 1) {  // tile T complete: ReLU, split, its record slice into O
+        if constexpr (KS == F::KS2 - 1 && kNoEpi2) asm volatile("" ::"v"(acc), "v"(accs));
+        if constexpr (KS == F::KS2 - 1 && !kNoEpi2) {  // tile T complete: ReLU, split, its record slice into O
           f32x4 v = acc + accs;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;

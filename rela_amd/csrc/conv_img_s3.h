@@ -132,7 +132,11 @@ __global__ __launch_bounds__(256, 1) void conv3_img_s3(const uint8_t* __restrict
         // the next tile's frame: its lines must be visible before that tile's first reads (issued at k-step KS - 3)
         const int tn = min(t + 1, ntiles - 1);
         const int last = min(16 * tn + 15, rows - 1) / 49;  // (uniform) newest frame the next tile reads
+#if defined(S3_ABLATE_FRAMES)
+        if (false) {
+#else
         if (last > cur) {
+#endif
           wait_vm<C::G>();               // frame cur + 1 has landed (frame cur + 2 may still be in flight)
           __builtin_amdgcn_s_barrier();  // ... for every wave; this tile reads frame cur only: cur - 1 is free
           cur = last;
@@ -162,16 +166,26 @@ __global__ __launch_bounds__(256, 1) void conv3_img_s3(const uint8_t* __restrict
       __builtin_amdgcn_sched_barrier(0);
     });
     // ---- epilogue: ReLU, split, this lane's four channels of its pixel
+#if defined(S3_ABLATE_EPILOGUE)
+    asm volatile("" ::"v"(acc), "v"(accs), "v"(acct));
+    if (false) {
+      f32x4 v = acc + (accs + acct);
+#else
     if (16 * t + li < rows) {
       f32x4 v = acc + (accs + acct);
+#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
       uint2 p0, p1, p2;
       split3_4(v, p0, p1, p2);
       uint8_t* o = out + ((size_t)f0 * 49 + (size_t)(16 * t + li)) * 384 + (16 * wave + 4 * g) * 2;
+#if defined(S3_ABLATE_STORES)
+      asm volatile("" ::"v"(p0), "v"(p1), "v"(p2), "v"(o));
+#else
       *reinterpret_cast<uint2*>(o) = p0;
       *reinterpret_cast<uint2*>(o + 128) = p1;
       *reinterpret_cast<uint2*>(o + 256) = p2;
+#endif
     }
     static_for<3>([&](auto kk) { wait_lgkm<0>(x[decltype(kk)::value][0], x[decltype(kk)::value][1], x[decltype(kk)::value][2]); });
     xa = xn;

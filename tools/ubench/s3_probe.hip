@@ -18,6 +18,7 @@ void set_last_error(const char*, ...) {}
 }  // namespace rela_amd
 #include "gemm_s3.h"
 #include "conv_img_s3.h"
+#include "conv12_s3.h"
 #ifndef F32EMU_OCC
 #define F32EMU_OCC 2
 #endif
@@ -210,9 +211,61 @@ static void run(const HostProb& hp, int N, int iters) {
   CK(hipFree(dP));
 }
 
+// timing only (random digits / weights / frames: the values do not matter for the clock): conv1 -> conv2 fused
+static void time_conv12(int N, int iters) {
+  using F = s3::Conv12S;
+  uint8_t *in, *out;
+  uint4 *W1d, *B2;
+  float *sc, *b1, *b2;
+  const size_t in_bytes = (size_t)N * F::IN_ELEMS, out_bytes = (size_t)N * 81 * 384;
+  CK(hipMalloc(&in, in_bytes));
+  CK(hipMalloc(&out, out_bytes));
+  CK(hipMalloc(&W1d, 3 * 2 * 4 * 64 * 16));
+  CK(hipMalloc(&B2, 16 * 4 * 3 * 64 * 16));
+  CK(hipMalloc(&sc, 64 * 4));
+  CK(hipMalloc(&b1, 64 * 4));
+  CK(hipMalloc(&b2, 64 * 4));
+  std::mt19937 rng(7);
+  std::vector<uint8_t> h(in_bytes);
+  for (auto& v : h) v = (uint8_t)rng();
+  CK(hipMemcpy(in, h.data(), in_bytes, hipMemcpyHostToDevice));
+  std::vector<uint8_t> w(3 * 2 * 4 * 64 * 16);
+  for (auto& v : w) v = (uint8_t)(rng() % 200);
+  CK(hipMemcpy(W1d, w.data(), w.size(), hipMemcpyHostToDevice));
+  std::vector<uint16_t> wb(16 * 4 * 3 * 64 * 8);
+  for (auto& v : wb) v = (uint16_t)(0x3c00 + (rng() & 0xff));  // small positive bf16
+  CK(hipMemcpy(B2, wb.data(), wb.size() * 2, hipMemcpyHostToDevice));
+  std::vector<float> f(64, 1e-9f);
+  CK(hipMemcpy(sc, f.data(), 256, hipMemcpyHostToDevice));
+  CK(hipMemcpy(b1, f.data(), 256, hipMemcpyHostToDevice));
+  CK(hipMemcpy(b2, f.data(), 256, hipMemcpyHostToDevice));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&s3::conv12_s3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, F::LDS_TOTAL));
+  auto go = [&]() {
+    hipLaunchKernelGGL(s3::conv12_s3<false>, dim3(std::min(256, N)), dim3(F::kT), F::LDS_TOTAL, 0, in, W1d, sc, b1, B2, b2, out,
+                       (float*)nullptr, N);
+  };
+  for (int i = 0; i < 3; ++i) go();
+  CK(hipDeviceSynchronize());
+  CK(hipGetLastError());
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  CK(hipEventRecord(e0, 0));
+  for (int i = 0; i < iters; ++i) go();
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("{\"layer\": \"conv12\", \"N\": %d, \"us\": %.1f}\n", N, 1e3 * ms / iters);
+}
+
 int main(int argc, char** argv) {
   const int N = argc > 1 ? atoi(argv[1]) : 6554;
   const int iters = argc > 2 ? atoi(argv[2]) : 20;
+  if (argc > 3 && atoi(argv[3]) == 12) {
+    time_conv12(N, iters);
+    return 0;
+  }
   const HostProb p2{"conv2", 1, 512, 64, 81, 12800, x2, w2};
   const HostProb p3{"conv3", 2, 576, 64, 49, 5184, x3, w3};
   const HostProb pf{"fc", 3, 3136, 512, 1, 3136, xf, wf};
