@@ -78,6 +78,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 BYTES_PER_SAMPLE = {"conv1_bf16x3": 28224 + 400 * 32 * 4, "conv2_mfma": 400 * 32 * 4 + 81 * 64 * 4,
                     "conv3_mfma": 81 * 64 * 4 + 49 * 64 * 4, "fc_mfma": 49 * 64 * 4 + 512 * 4, "heads_mfma": 512 * 4 + 32 * 4,
                     "conv12_fused": 28224 + 81 * 64 * 4}
+# f32x3 mode from 512 rows (csrc/gemm_s3.h): activations travel between the layers as split3 records, 6 B per element
+BYTES_PER_SAMPLE_F32X3 = {"conv12_fused": 28224 + 81 * 64 * 6, "conv3_mfma": 81 * 64 * 6 + 49 * 64 * 6, "fc_mfma": 49 * 64 * 6 + 512 * 4}
 PEAK_HBM_GBS = 8000.0
 DTYPE_F32X3 = ("f32 (conv2 / conv3 / fc of the actors' forwards: every f32 operand split EXACTLY in three bf16 parts, six "
                "products each on v_mfma_f32_16x16x32_bf16, f32 accumulation -- error against f64 <= the f32 MFMA kernels' "
@@ -300,7 +302,7 @@ def traffic_from_profiles(label, precision=None):
             # (the f32x3 mode's kernels share the rela_prof labels of the f32 mode's: their PMC records carry a suffix)
             rec = kernels.get(label + "_f32x3") if precision == "f32x3" else None
             if rec is None:
-                if precision == "f32x3" and label in ("conv2_mfma", "conv3_mfma", "fc_mfma"):
+                if precision == "f32x3" and label in ("conv12_fused", "conv2_mfma", "conv3_mfma", "fc_mfma"):
                     continue  # never report another kernel's traffic for this one
                 rec = kernels.get(label)
         except (OSError, ValueError, KeyError):
@@ -1413,20 +1415,23 @@ def main():
             # bf16 MFMA products issued per algorithmic product: conv1 multiplies exact u8 inputs by weights split
             # in 3 bf16 pieces (f32 mode: exact) or 2 (bf16x2 mode); the other layers 3 in bf16x2 mode, f32 MFMA else
             products = (2 if fast else 3) if name == "conv1_bf16x3" else (3 if fast else 0)
-            if region["precision"] == "f32x3" and name in ("conv2_mfma", "conv3_mfma", "fc_mfma"):
+            x3 = region["precision"] == "f32x3" and name in ("conv12_fused", "conv3_mfma", "fc_mfma")
+            if x3:
                 products = 6  # both operands in three bf16 parts, the six products with i + j <= 2
             conv1_i8 = True  # (the half-frame bf16 conv1 -> conv2 kernel was removed in r4)
             if name == "conv12_fused":
-                # conv2: 3 bf16 products per product.  conv1: 3 int8 digit products (csrc/ffnet.hip: conv12_i8) on
-                # v_mfma_i32_16x16x64_i8, which runs at twice the bf16 rate = 1.5 bf16-MFMA-equivalents
+                # conv2: 3 (bf16x2) or 6 (f32x3) bf16 products per product.  conv1: 3 int8 digit products (conv12_i8 /
+                # conv12_s3) on v_mfma_i32_16x16x64_i8, which runs at twice the bf16 rate = 1.5 bf16-MFMA-equivalents
                 f1, f2 = FLOP["conv1_bf16x3"], FLOP["conv2_mfma"]
-                products = ((1.5 if conv1_i8 else 2) * f1 + 3 * f2) / (f1 + f2)
+                products = ((1.5 if conv1_i8 else 2) * f1 + (6 if x3 else 3) * f2) / (f1 + f2)
             peak_class = PEAK_BF16_MFMA_TFLOPS if products else PEAK_F32_MFMA_TFLOPS
-            if region["precision"] == "f32x3" and products == 6:
-                # an f32 product of this mode IS six bf16 MFMA products: the dense peak for f32 results is the bf16
-                # peak / 6 = 416.7 TFLOP/s (the f32 MFMA's own peak, 157.3, is reported next to it)
-                peak_class = PEAK_BF16_MFMA_TFLOPS / 6
-                products = 1
+            if x3:
+                # an f32 product of this mode IS six bf16 MFMA products (conv1 -> conv2 fused: 4.85 on average): the dense
+                # peak for f32 results is the bf16 peak / products; `frac` is therefore the MFMA ISSUE utilisation (what PMC
+                # SQ_VALU_MFMA_BUSY sees); the algorithmic fraction of the bf16 peak and the fraction of the f32 MFMA's
+                # own peak (157.3) ride next to it
+                peak_class = PEAK_BF16_MFMA_TFLOPS / products
+                issued_products, products = products, 1
                 f32x3_note = True
             else:
                 f32x3_note = False
@@ -1438,10 +1443,15 @@ def main():
                         products, "; conv1: three int8 digit products on v_mfma_i32_16x16x64_i8, counted as 1.5 bf16 products"
                         if name == "conv12_fused" and conv1_i8 else "")) if products else "v_mfma_f32_16x16x4_f32"}
             if f32x3_note:
-                mfma["instruction"] = ("v_mfma_f32_16x16x32_bf16, six products per f32 product (both operands as three exact "
-                                       "bf16 parts): peak = 2,500 / 6 TFLOP/s")
+                mfma["instruction"] = ("v_mfma_f32_16x16x32_bf16, %.3g bf16-MFMA products per f32 product (both operands as three "
+                                       "exact bf16 parts%s): peak = 2,500 / %.3g TFLOP/s" % (
+                                           issued_products, "; conv1: three int8 digit products counted as 1.5"
+                                           if name == "conv12_fused" else "", issued_products))
                 mfma["frac_of_f32_mfma_peak"] = ach / PEAK_F32_MFMA_TFLOPS
-            nbytes = BYTES_PER_SAMPLE[name] * ROWS
+                mfma["frac_algorithmic_bf16"] = ach / PEAK_BF16_MFMA_TFLOPS
+                mfma["frac_issued"] = ach / peak_class
+                mfma["products_per_product"] = issued_products
+            nbytes = (BYTES_PER_SAMPLE_F32X3 if x3 else BYTES_PER_SAMPLE)[name] * ROWS
             hbm = {"achieved": nbytes / (avg_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "algorithmic_bytes_per_launch": nbytes}
             hbm["frac"] = hbm["achieved"] / PEAK_HBM_GBS
@@ -1552,6 +1562,9 @@ def main():
                    "frac": r["frac"], "traffic": r["traffic"], "avg_launch_ms": r["avg_launch_ms"]}
             if m is not None and m["products_per_product"] != 1:
                 out["frac_issued"] = m["frac_issued"]  # MFMA issue utilisation (bf16 products issued per product counted)
+            if m is not None and "frac_of_f32_mfma_peak" in m:  # f32x3: the three readings of the same launch, side by side
+                out["frac_algorithmic_bf16"] = m["frac_algorithmic_bf16"]
+                out["frac_of_f32_mfma_peak"] = m["frac_of_f32_mfma_peak"]
             if "sclk_mhz" in r:
                 out["sclk_mhz"] = r["sclk_mhz"]
             return out

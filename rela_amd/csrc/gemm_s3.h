@@ -97,34 +97,38 @@ __device__ __forceinline__ void split3_4(const f32x4& v, uint2& p0, uint2& p1, u
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The kernel.  What r4's gemm_f32emu.h measured as "activation fetches cost 100 us of 263" is the texture addresser:
-// a fragment-shaped load (16 rows x 64 B per wave instruction) keeps it busy ~38 cycles where a whole-line load of the
-// same 1 KB takes ~16 (profiles/r04_f32emu_probe_counters.txt: TA_BUSY 45 % with 6,064 loads per CU), and the
-// pre-split form of that kernel (same loop, no VALU work left in it: 20 vector instructions per 144 MFMAs) ran
-// SLOWER in proportion to its 6 instead of 4 bytes per value.  So here
+// The GEMM kernel (fc 3136 -> 512, the recurrent net's input projection 3136 -> 2048).  What r4's gemm_f32emu.h measured
+// as "activation fetches cost 100 us of 263" is the texture addresser: a fragment-shaped load (16 rows x 64 B per wave
+// instruction) keeps it busy ~38 cycles where a whole-line load of the same 1 KB takes ~16
+// (profiles/r04_f32emu_probe_counters.txt: TA_BUSY 45 % with 6,064 loads per CU), and the pre-split form of that kernel
+// (same loop, 20 vector instructions left per 144 MFMAs) ran SLOWER in proportion to its 6 instead of 4 bytes per
+// value.  So here
 //   * ACTIVATIONS reach LDS by LDS-DMA (global_load_lds_dwordx4: no registers, no staging instructions) in WHOLE
 //     128-byte lines: one wave instruction fetches one part (both channel halves = the two k-steps of a "pair") of 8
 //     consecutive rows.  The LDS image of such a 1 KB block is lane-linear, so the bank spreading is done on the SOURCE
 //     side: lane l fetches (row r = (l & 15) >> 1, 16-byte unit u = 2 (l >> 4) + (l & 1)), which puts unit u of row r at
 //     slot 16 (u >> 1) + 2 r + (u & 1) -- the 16 lanes a ds_read_b128 pass serves (rows 0-7 at unit u0, rows 0-7 at
-//     u0 + 1) then hit the 16 bank groups once each;
-//   * a block owns a range of 16-row tiles and ONE column group of 64 channels; it walks the range in passes of up to
-//     TMV tiles; the four waves own 16 channels each and ALL tiles of the pass, so an activation fragment is fetched
-//     from global memory once per block and read from LDS by four waves (LDS: 128 B/clk of 256);
-//   * WEIGHTS: a wave's own three fragments per k-step arrive by LDS-DMA too (fragment order = lane order: a 1 KB
-//     contiguous read), into a private three-slot ring -- no register holds data in flight, so nothing the compiler
-//     does to registers can touch an outstanding load;
-//   * three activation buffers: pair P + 2 is issued while pair P computes; ONE raw s_barrier per pair (it publishes
-//     pair P's lines and retires the reads of the buffer pair P + 2 lands in); counted vmcnt, never 0 in the loop; the
+//     u0 + 1) then hit the 16 bank groups once each (SQ_LDS_BANK_CONFLICT = 0);
+//   * a block owns a range of 16-row tiles and 128 COLUMNS; it walks the range in passes of up to TMV tiles; the four
+//     waves own 32 columns each and ALL tiles of the pass: an activation fragment is fetched from global memory once
+//     per block and read from LDS by four waves.  (r5, first form: 64 columns and <= 6 tiles per block moved 1.6 GB
+//     through L2 for fc at 6,400 rows and spent more issue slots on its 15 LDS-DMAs per pair -- each with its M0 and
+//     address arithmetic -- than on its 52 MFMAs: 167 us.  Bytes per MFMA go with 1 / rows + 1 / columns.)
+//   * WEIGHTS: a wave's own six fragments per k-step arrive by LDS-DMA too (fragment order = lane order: 1 KB
+//     contiguous reads), into a private two-slot ring -- no register holds data in flight, so nothing the compiler does
+//     to registers can touch an outstanding load;
+//   * two activation buffers: pair P + 1 is issued when pair P starts; ONE raw s_barrier per pair (it publishes pair
+//     P's lines and retires the reads of the buffer pair P + 1 lands in); counted vmcnt, never 0 in the loop; the
 //     pipeline runs on across pass boundaries (next pass's rows, same weights);
 //   * LDS reads are inline asm (the compiler would drain vmcnt before any LDS read it can see while an LDS-DMA is
-//     pending) with counted lgkmcnt: a tile's three fragments are read while the tile before issues its 6 MFMAs.
+//     pending) with counted lgkmcnt: a tile's three fragments are read while the tile before issues its 12 MFMAs.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int TMV = 6;                       // row tiles per pass (LDS: 3 buffers x TMV x 6 KB)
+constexpr int TMV = 8;                       // row tiles per pass
+constexpr int CT = 2;                        // column tiles per wave (32 columns; 128 per block)
 constexpr int kABuf = TMV * 6144;            // one pair of k-steps: [tile][part][rows 0-7 | 8-15] x 1 KB
-constexpr int kBSlot = 3072;                 // one k-step of one wave's weights: [part] x 1 KB
-constexpr int kLdsB = 3 * kABuf;             // the four waves' weight rings (3 slots each) start here
-constexpr int kLdsSpare = kLdsB + 4 * 3 * kBSlot;  // 1 KB landing zone of the padding loads
+constexpr int kBSlot = CT * 3072;            // one k-step of one wave's weights: [column tile][part] x 1 KB
+constexpr int kLdsB = 2 * kABuf;             // the four waves' weight rings (2 slots each) start here
+constexpr int kLdsSpare = kLdsB + 4 * 2 * kBSlot;  // 1 KB landing zone of the padding loads
 constexpr int kLdsTotal = kLdsSpare + 1024;
 static_assert(kLdsTotal <= 160 * 1024, "LDS budget");
 __host__ __device__ constexpr int glds_per_wave(int nt) { return (6 * nt + 3) / 4; }
@@ -159,55 +163,78 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 struct Pipe {            // what the k-loop carries from pass to pass
-  uint32_t g;            // global pair counter (buffer = g % 3)
-  uint32_t s;            // global k-step counter (weight slot = s % 3)
+  uint32_t g;            // global pair counter (buffer = g & 1)
+  uint32_t s;            // global k-step counter (weight slot = s & 1)
 };
 
-// One pass: NT row tiles x this wave's 16 channels over all KS k-steps.  J = LDS-DMA instructions per wave and pair
-// (the block's larger pass size decides it, so that the counts in flight do not change at a pass boundary).
-// offc / offn: this wave's J source offsets (row base + part + this lane's unit) for this pass and the next one.
+// this wave's weights of k-step k -> ring slot `slot`: [column tile j][part] x 1 KB, lane-linear
+template <class P>
+__device__ __forceinline__ void issue_weights(const uint8_t* wsrc, uint8_t* lds, uint32_t bring, int k, uint32_t slot, uint32_t lane) {
+  const uint8_t* src = wsrc + (size_t)k * (kStageU4 * 16) + lane * 16;
+  uint8_t* dst = lds + bring + slot * kBSlot;
+#pragma unroll
+  for (int q = 0; q < CT * 3; ++q) glds16(src + q * 1024, dst + q * 1024);
+}
+
+// One pass: NT row tiles x this wave's 32 columns over all KS k-steps.  J = LDS-DMA instructions per wave and pair for
+// the activations (the block's larger pass size decides it, so that the counts in flight do not change at a pass
+// boundary).  offc / offn: this wave's J source offsets (row base + part + this lane's unit) for this pass and the next.
+// In flight at the top of pair P (issue order): A(P) | W(2P) | W(2P+1) -- then W(2P+1)... see the waits below.
 template <class P, int NT, int J>
 __device__ __forceinline__ void k_pass(const uint8_t* __restrict__ Xb, const uint8_t* __restrict__ wsrc, uint8_t* lds, uint32_t lds0,
                                        const uint32_t (&offc)[J], const uint32_t (&offn)[J], const uint32_t (&ldst)[J],
-                                       uint32_t frag_base, uint32_t wave, f32x4 (&acc)[TMV], f32x4 (&accs)[TMV], Pipe& pp) {
-  constexpr int KP = P::KS / 2;
+                                       uint32_t frag_base, uint32_t wave, f32x4 (&acc)[TMV][CT], f32x4 (&accs)[TMV][CT], Pipe& pp) {
+  constexpr int KP = P::KS / 2, WL = 3 * CT;
   const uint32_t lane = threadIdx.x & 63;
-  const uint32_t bring = kLdsB + wave * 3 * kBSlot;  // this wave's weight ring
+  const uint32_t bring = kLdsB + wave * 2 * kBSlot;  // this wave's weight ring
   for (int kp = 0; kp < KP; ++kp) {
-    const uint32_t abuf = (pp.g % 3) * kABuf;
-    // ---- pair kp's lines have landed (issued two pairs ago); everybody is done with the buffer pair kp + 2 lands in
-    wait_vm<J + 12>();
+    const uint32_t abuf = (pp.g & 1) * kABuf;
+    // ---- pair kp's lines have landed (issued one pair ago; younger: the weights of k-step s, issued since); everybody
+    // is done with the other buffer
+    wait_vm<WL>();
     __builtin_amdgcn_s_barrier();
-    {
-      int k2 = kp + 2;
+    {  // weights of k-step s + 1 (its slot was read last at k-step s - 1), then the next pair's lines
+      int k1 = 2 * kp + 1;
+      issue_weights<P>(wsrc, lds, bring, k1, (pp.s + 1) & 1, lane);
+      int k2 = kp + 1;
       const bool nextp = k2 >= KP;  // (uniform)
       if (nextp) k2 -= KP;
       const uint8_t* src = Xb + P::pair_off(k2);
-      const uint32_t dst = ((pp.g + 2) % 3) * kABuf;
+      const uint32_t dst = ((pp.g + 1) & 1) * kABuf;
 #pragma unroll
       for (int j = 0; j < J; ++j)
         glds16(src + (nextp ? offn[j] : offc[j]), lds + (ldst[j] >= (uint32_t)kLdsSpare ? ldst[j] : dst + ldst[j]));
     }
     static_for<2>([&](auto hh) {
       constexpr int H = decltype(hh)::value;
-      {  // this wave's weights of k-step s + 2 -> ring slot (s + 2) % 3 (read last at k-step s - 1)
-        int k2 = 2 * kp + H + 2;
+      if constexpr (H == 1) {  // weights of k-step s + 1 = the next pair's first (slot read last at k-step s - 1)
+        int k2 = 2 * kp + 2;
         if (k2 >= P::KS) k2 -= P::KS;
-        const uint8_t* src = wsrc + (size_t)k2 * (kStageU4 * 16) + lane * 16;
-        uint8_t* dst = lds + bring + ((pp.s + 2) % 3) * kBSlot;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) glds16(src + p * 1024, dst + p * 1024);
+        issue_weights<P>(wsrc, lds, bring, k2, (pp.s + 1) & 1, lane);
       }
-      wait_vm<J + 6>();  // the weights of k-step s (issued two k-steps ago)
-      const uint32_t wa = lds0 + bring + (pp.s % 3) * kBSlot + lane * 16;
-      u32x4 w0 = lds_read128<0>(wa), w1 = lds_read128<1024>(wa), w2 = lds_read128<2048>(wa);
+      wait_vm<J + WL>();  // the weights of k-step s (younger: the next pair's lines and one k-step of weights)
+      const uint32_t wa = lds0 + bring + (pp.s & 1) * kBSlot + lane * 16;
+      u32x4 wq[CT][3];
+      static_for<CT>([&](auto jj) {
+        constexpr int JJ = decltype(jj)::value;
+        wq[JJ][0] = lds_read128<JJ * 3072>(wa);
+        wq[JJ][1] = lds_read128<JJ * 3072 + 1024>(wa);
+        wq[JJ][2] = lds_read128<JJ * 3072 + 2048>(wa);
+      });
       const uint32_t xa = lds0 + abuf + frag_base + H * 512;
       u32x4 x[2][3];
       x[0][0] = lds_read128<0>(xa);
       x[0][1] = lds_read128<2048>(xa);
       x[0][2] = lds_read128<4096>(xa);
-      wait_lgkm<3>(w0, w1, w2);
-      const bf16x8 wf0 = __builtin_bit_cast(bf16x8, w0), wf1 = __builtin_bit_cast(bf16x8, w1), wf2 = __builtin_bit_cast(bf16x8, w2);
+      static_for<CT>([&](auto jj) {
+        constexpr int JJ = decltype(jj)::value;
+        wait_lgkm<3 + 3 * (CT - 1 - JJ)>(wq[JJ][0], wq[JJ][1], wq[JJ][2]);
+      });
+      bf16x8 wf[CT][3];
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wf[j][q] = __builtin_bit_cast(bf16x8, wq[j][q]);
       static_for<NT>([&](auto tt) {
         constexpr int T = decltype(tt)::value;
         constexpr int C = T & 1;
@@ -223,12 +250,16 @@ __device__ __forceinline__ void k_pass(const uint8_t* __restrict__ Xb, const uin
                      x2 = __builtin_bit_cast(bf16x8, x[C][2]);
         // the five small products have an accumulator of their own (added once per pass): the main one takes ONE
         // rounding per 32 k at the magnitude of the running sum
-        accs[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, x0, accs[T], 0, 0, 0);
-        accs[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0, x2, accs[T], 0, 0, 0);
-        accs[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, x1, accs[T], 0, 0, 0);
-        accs[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, x0, accs[T], 0, 0, 0);
-        accs[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0, x1, accs[T], 0, 0, 0);
-        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0, x0, acc[T], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+          accs[T][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][2], x0, accs[T][j], 0, 0, 0);
+          accs[T][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], x2, accs[T][j], 0, 0, 0);
+          accs[T][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], x1, accs[T][j], 0, 0, 0);
+          accs[T][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], x0, accs[T][j], 0, 0, 0);
+          accs[T][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], x1, accs[T][j], 0, 0, 0);
+          acc[T][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], x0, acc[T][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       });
       pp.s += 1;
     });
@@ -236,21 +267,23 @@ __device__ __forceinline__ void k_pass(const uint8_t* __restrict__ Xb, const uin
   }
 }
 
-// X: split3 records; Wp: pack_f32emu_at's fragment-ordered bf16 triples [cg][ks][u][part][lane] x 8;
+// X: split3 records; Wp: pack_f32emu_at's fragment-ordered bf16 triples [cg64][ks][u][part][lane] x 8;
 // out: OUT_S3 ? records of P::OC channels (6 * OC bytes per row) : f32 [M][OC].
-// gridDim.x = 8 * NCG * (row blocks / 8): consecutive block ids go to the 8 XCDs in turn, so the column groups of one
-// row block (they read the same activations) share an L2.
+// gridDim.x = 8 * NCG * (row blocks / 8) with NCG = OC / 128: consecutive block ids go to the 8 XCDs in turn, so the
+// column groups of one row block (they read the same activations) share an L2.
 template <class P, bool OUT_S3>
 __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb, const uint4* __restrict__ Wp,
                                                  const float* __restrict__ bias, void* __restrict__ out_, int M) {
+  constexpr int NCG = P::OC / (64 * CT);
+  static_assert(P::OC % (64 * CT) == 0, "a block owns 128 columns");
   __shared__ __attribute__((aligned(1024))) uint8_t lds[kLdsTotal];
   const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr_t)lds;
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (a scalar: LDS-DMA destinations are wave-uniform)
   const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
-  const int cg = bi % P::NCG;
-  const int rb = (bi / P::NCG) * 8 + xcd;
-  const int nrb = gridDim.x / P::NCG;
+  const int cg = bi % NCG;
+  const int rb = (bi / NCG) * 8 + xcd;
+  const int nrb = gridDim.x / NCG;
   const int rt_total = (M + 15) >> 4;
   const int r0 = (int)((int64_t)rt_total * rb / nrb), r1 = (int)((int64_t)rt_total * (rb + 1) / nrb);
   const int cnt = r1 - r0;
@@ -260,14 +293,22 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
   const int ntmax = base + (rem ? 1 : 0);
   auto first_of = [&](int p) { return p < rem ? (base + 1) * p : (base + 1) * rem + base * (p - rem); };
   auto size_of = [&](int p) { return p < rem ? base + 1 : base; };
-  const uint8_t* wsrc = reinterpret_cast<const uint8_t*>(Wp) + ((size_t)cg * P::KS * kStageU4 + (size_t)wave * 3 * 64) * 16;
+  // this wave's columns: 128 cg + 32 wave .. + 31 = column tiles u = 2 (wave & 1), + 1 of the 64-column pack group
+  const int cg64 = cg * 2 + (wave >> 1), u0 = 2 * (wave & 1);
+  const uint8_t* wsrc = reinterpret_cast<const uint8_t*>(Wp) + ((size_t)cg64 * P::KS * kStageU4 + (size_t)u0 * 3 * 64) * 16;
+  const int col0 = cg * 128 + 32 * wave + 4 * g;  // this lane's first channel (column tile j: + 16 j)
   // fragment read address of (tile 0, part 0, half 0): rows 8-15 are the second 1 KB block of a (tile, part)
   const uint32_t frag_base = (uint32_t)((li >> 3) * 1024 + (16 * (g >> 1) + 2 * (li & 7) + (g & 1)) * 16);
   // LDS-DMA source: this lane's row inside an 8-row block and its 16-byte unit inside the 128-byte line
   const int lr = (lane & 15) >> 1, lu = 2 * (lane >> 4) + (lane & 1);
 
-  const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + cg * 64 + 16 * wave + 4 * g);
-  f32x4 acc[TMV], accs[TMV];
+  f32x4 bv[CT];
+#pragma unroll
+  for (int j = 0; j < CT; ++j) {
+    bv[j] = *reinterpret_cast<const f32x4*>(bias + col0 + 16 * j);
+    asm volatile("" : "+v"(bv[j]));  // (returned before the first LDS-DMA is issued: see conv_img_s3.h)
+  }
+  f32x4 acc[TMV][CT], accs[TMV][CT];
   Pipe pp{0u, 0u};
 
   auto run = [&](auto ntm) {
@@ -293,46 +334,44 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
     }
     set_off(offc, 0);
     set_off(offn, min(1, passes - 1));
-    // prologue: pairs 0 and 1 of pass 0, each followed by the weights of k-steps 0 and 1 (twice the same bytes: the
-    // loop's counted waits assume six weight loads between two pairs' lines)
+    // prologue: pair 0's lines, then the weights of k-step 0 (what the loop's first counted wait expects in flight)
+    {
+      const uint8_t* src = Xb + P::pair_off(0);
 #pragma unroll
-    for (int kp = 0; kp < 2; ++kp) {
-      const uint8_t* src = Xb + P::pair_off(kp);
-#pragma unroll
-      for (int j = 0; j < J; ++j)
-        glds16(src + offc[j], lds + (ldst[j] >= (uint32_t)kLdsSpare ? ldst[j] : (uint32_t)(kp * kABuf) + ldst[j]));
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          glds16(wsrc + (size_t)h * (kStageU4 * 16) + lane * 16 + q * 1024, lds + kLdsB + wave * 3 * kBSlot + h * kBSlot + q * 1024);
+      for (int j = 0; j < J; ++j) glds16(src + offc[j], lds + ldst[j]);
+      issue_weights<P>(wsrc, lds, kLdsB + wave * 2 * kBSlot, 0, 0, lane);
     }
     for (int p = 0; p < passes; ++p) {
       const int nt = size_of(p);
 #pragma unroll
-      for (int t = 0; t < TMV; ++t) acc[t] = bv, accs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < TMV; ++t)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[t][j] = bv[j], accs[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (nt == NTM)
         k_pass<P, NTM, J>(Xb, wsrc, lds, lds0, offc, offn, ldst, frag_base, wave, acc, accs, pp);
       else if constexpr (NTM > 1)
         k_pass<P, NTM - 1, J>(Xb, wsrc, lds, lds0, offc, offn, ldst, frag_base, wave, acc, accs, pp);
-      // ---- epilogue: ReLU, this lane's four channels of pixel li of every tile
+      // ---- epilogue: ReLU, this lane's four channels (per column tile) of pixel li of every tile
       const int t0 = r0 + first_of(p);
 #pragma unroll
       for (int t = 0; t < TMV; ++t) {
         const int row = (t0 + t) * 16 + li;
         if (t < nt && row < M) {
-          f32x4 v = acc[t] + accs[t];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-          if constexpr (OUT_S3) {
-            uint8_t* o = reinterpret_cast<uint8_t*>(out_) + (size_t)row * (6 * P::OC) + (cg * 64 + 16 * wave + 4 * g) * 2;
-            uint2 p0, p1, p2;
-            split3_4(v, p0, p1, p2);
-            *reinterpret_cast<uint2*>(o) = p0;
-            *reinterpret_cast<uint2*>(o + 2 * P::OC) = p1;
-            *reinterpret_cast<uint2*>(o + 4 * P::OC) = p2;
-          } else {
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out_) + (size_t)row * P::OC + cg * 64 + 16 * wave + 4 * g) = v;
+          for (int j = 0; j < CT; ++j) {
+            f32x4 v = acc[t][j] + accs[t][j];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+            if constexpr (OUT_S3) {
+              uint8_t* o = reinterpret_cast<uint8_t*>(out_) + (size_t)row * (6 * P::OC) + (col0 + 16 * j) * 2;
+              uint2 p0, p1, p2;
+              split3_4(v, p0, p1, p2);
+              *reinterpret_cast<uint2*>(o) = p0;
+              *reinterpret_cast<uint2*>(o + 2 * P::OC) = p1;
+              *reinterpret_cast<uint2*>(o + 4 * P::OC) = p2;
+            } else {
+              *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out_) + (size_t)row * P::OC + col0 + 16 * j) = v;
+            }
           }
         }
       }
@@ -347,18 +386,21 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
     case 3: run(IC<3>{}); break;
     case 4: run(IC<4>{}); break;
     case 5: run(IC<5>{}); break;
-    default: run(IC<6>{}); break;
+    case 6: run(IC<6>{}); break;
+    case 7: run(IC<7>{}); break;
+    default: run(IC<8>{}); break;
   }
   wait_vm<0>();  // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
-// rows M = pixels (conv) or samples (fc).  Byte offsets are 32-bit: the caller keeps M * record bytes below 2^32.
+// rows M = samples (fc).  Byte offsets are 32-bit: the caller keeps M * record bytes below 2^32.
 template <class P, bool OUT_S3>
 inline void launch(const void* X, const uint4* Wp, const float* bias, void* out, int M, hipStream_t s) {
+  constexpr int NCG = P::OC / (64 * CT);
   const int rt_total = (M + 15) / 16;
-  int nrb = std::min(kMaxBlocks / 2 / P::NCG, rt_total);
+  int nrb = std::min(kMaxBlocks / 2 / NCG, rt_total);
   nrb = (nrb + 7) / 8 * 8;
-  hipLaunchKernelGGL((gemm_s3<P, OUT_S3>), dim3(nrb * P::NCG), dim3(kT), 0, s, reinterpret_cast<const uint8_t*>(X), Wp, bias,
+  hipLaunchKernelGGL((gemm_s3<P, OUT_S3>), dim3(nrb * NCG), dim3(kT), 0, s, reinterpret_cast<const uint8_t*>(X), Wp, bias,
                      out, M);
 }
 
