@@ -136,7 +136,9 @@ int rela_replay_add(rela_replay* r, int n, const void* const* rows_dev, const fl
 /* sample(batchsize, device)  prioritized_replay.h:202-233 -> sample_ :258-328 + makeBatch
  * (types.cc:8-46).  Writes batch rows of every field to out_rows_dev[f] (device, batch rows
  * each) and the importance weights (:320-322) to out_weight_dev (f32[batch], device).
- * out_rows_dev may be NULL to skip the gather (benchmark.py:93-96 ignores the batch).
+ * out_rows_dev may be NULL to skip the gather (benchmark.py:93-96 ignores the batch; the owner's half of the native
+ * partition exchange below).  The slots such a gather-less sample evicts stay RESERVED until the update_priority that
+ * ends the batch: inserts block instead of rewriting rows a remote reader may still be gathering.
  * `stream`: the consumer's stream; outputs are valid for work queued on it afterwards.
  * Exactly one batch may be outstanding (:203-206) -> RELA_ESTATE.                          */
 int rela_replay_sample(rela_replay* r, int batch, void* const* out_rows_dev, float* out_weight_dev,
@@ -606,7 +608,10 @@ int rela_prof_counts_json(char* out, int64_t cap);
  *   owner:    rela_replay_sample(part, B / G, NULL, weight_scratch, stream); synchronize; signal the learner
  *   learner:  rela_replay_remote_gather(remote, B / G, rows, raw_w, sum_f, stream); ... loss ...; synchronize; signal
  *   owner:    rela_replay_update_priority(part, ...)
- * The owner must not sample / update between its signal and the learner's.
+ * The owner must not sample / update between its signal and the learner's.  Its actors MAY keep inserting: the library
+ * holds every slot the sample evicted (a draw can land in the very range its own sample pops, and on a full ring blocked
+ * producers would otherwise rewrite exactly those slots) until the owner's update_priority, i.e. until after the
+ * learner's read; inserts into other slots never alias a sampled row (sampled ids are live or held).
  * =================================================================================== */
 #define RELA_IPC_MAX_FIELDS 16
 typedef struct rela_replay_ipc_desc { /* plain bytes: send it to the importing process by any means */

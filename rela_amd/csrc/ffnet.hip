@@ -2394,7 +2394,16 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     {
       ProfScope prof(names[3], s);
       note_launch("gemm_s3<fc>");
-      s3::launch<s3::ProbFc, false>(rec3, d.Bfe, d.bf, h, N, s);
+      const int slices = s3::splitk_slices<s3::ProbFc>(N);
+      if (slices > 1) {  // small batches: the contraction split over blocks, fc_reduce adds slices + bias + ReLU
+        float* part = ha + kHA * N;
+        part += (64 - ((part - static_cast<float*>(ws)) & 63)) & 63;
+        s3::launch<s3::ProbFc, s3::kEpiRaw>(rec3, d.Bfe, d.bf, part, N, s, slices);
+        note_launch("fc_reduce"); hipLaunchKernelGGL(fc_reduce, dim3(ceil_div(N * 128, 256)), dim3(256), 0, s, (const float*)part, slices, N,
+                           (const float*)d.bf, h);
+      } else {
+        s3::launch<s3::ProbFc, s3::kEpiRelu>(rec3, d.Bfe, d.bf, h, N, s);
+      }
     }
     if (keep_f32) {
       note_launch("unsplit_s3");

@@ -183,11 +183,12 @@ __device__ __forceinline__ void issue_weights(const uint8_t* wsrc, uint8_t* lds,
 template <class P, int NT, int J>
 __device__ __forceinline__ void k_pass(const uint8_t* __restrict__ Xb, const uint8_t* __restrict__ wsrc, uint8_t* lds, uint32_t lds0,
                                        const uint32_t (&offc)[J], const uint32_t (&offn)[J], const uint32_t (&ldst)[J],
-                                       uint32_t frag_base, uint32_t wave, f32x4 (&acc)[TMV][CT], f32x4 (&accs)[TMV][CT], Pipe& pp) {
-  constexpr int KP = P::KS / 2, WL = 3 * CT;
+                                       uint32_t frag_base, uint32_t wave, f32x4 (&acc)[TMV][CT], f32x4 (&accs)[TMV][CT], Pipe& pp,
+                                       int kp0, int kp1) {
+  constexpr int WL = 3 * CT;
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t bring = kLdsB + wave * 2 * kBSlot;  // this wave's weight ring
-  for (int kp = 0; kp < KP; ++kp) {
+  for (int kp = kp0; kp < kp1; ++kp) {  // (split-K: this block's slice of the pairs)
     const uint32_t abuf = (pp.g & 1) * kABuf;
     // ---- pair kp's lines have landed (issued one pair ago; younger: the weights of k-step s, issued since); everybody
     // is done with the other buffer
@@ -197,8 +198,8 @@ __device__ __forceinline__ void k_pass(const uint8_t* __restrict__ Xb, const uin
       int k1 = 2 * kp + 1;
       issue_weights<P>(wsrc, lds, bring, k1, (pp.s + 1) & 1, lane);
       int k2 = kp + 1;
-      const bool nextp = k2 >= KP;  // (uniform)
-      if (nextp) k2 -= KP;
+      const bool nextp = k2 >= kp1;  // (uniform)
+      if (nextp) k2 = kp0;
       const uint8_t* src = Xb + P::pair_off(k2);
       const uint32_t dst = ((pp.g + 1) & 1) * kABuf;
 #pragma unroll
@@ -209,7 +210,7 @@ __device__ __forceinline__ void k_pass(const uint8_t* __restrict__ Xb, const uin
       constexpr int H = decltype(hh)::value;
       if constexpr (H == 1) {  // weights of k-step s + 1 = the next pair's first (slot read last at k-step s - 1)
         int k2 = 2 * kp + 2;
-        if (k2 >= P::KS) k2 -= P::KS;
+        if (k2 >= 2 * kp1) k2 = 2 * kp0;
         issue_weights<P>(wsrc, lds, bring, k2, (pp.s + 1) & 1, lane);
       }
       wait_vm<J + WL>();  // the weights of k-step s (younger: the next pair's lines and one k-step of weights)
@@ -268,13 +269,18 @@ __device__ __forceinline__ void k_pass(const uint8_t* __restrict__ Xb, const uin
 }
 
 // X: split3 records; Wp: pack_f32emu_at's fragment-ordered bf16 triples [cg64][ks][u][part][lane] x 8;
-// out: OUT_S3 ? records of P::OC channels (6 * OC bytes per row) : f32 [M][OC].
+// EPI 0: out = relu(bias + sum) as f32 [M][OC] | 1: the same as split3 records (6 * OC bytes per row) | 2: the raw sums,
+// f32 [gridDim.y][M][OC] -- gridDim.y > 1 splits the contraction (small batches: 512 rows x 512 columns are 128 blocks of
+// one tile; fc_reduce adds the slices, the bias and the ReLU).
 // gridDim.x = 8 * NCG * (row blocks / 8) with NCG = OC / 128: consecutive block ids go to the 8 XCDs in turn, so the
 // column groups of one row block (they read the same activations) share an L2.
-template <class P, bool OUT_S3>
+enum { kEpiRelu = 0, kEpiReluS3 = 1, kEpiRaw = 2 };
+template <class P, int EPI>
 __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb, const uint4* __restrict__ Wp,
                                                  const float* __restrict__ bias, void* __restrict__ out_, int M) {
   constexpr int NCG = P::OC / (64 * CT);
+  constexpr bool OUT_S3 = EPI == kEpiReluS3;
+  const int kp0 = (int)((P::KS / 2) * blockIdx.y / gridDim.y), kp1 = (int)((P::KS / 2) * (blockIdx.y + 1) / gridDim.y);
   static_assert(P::OC % (64 * CT) == 0, "a block owns 128 columns");
   __shared__ __attribute__((aligned(1024))) uint8_t lds[kLdsTotal];
   const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr_t)lds;
@@ -305,7 +311,10 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
   f32x4 bv[CT];
 #pragma unroll
   for (int j = 0; j < CT; ++j) {
-    bv[j] = *reinterpret_cast<const f32x4*>(bias + col0 + 16 * j);
+    if constexpr (EPI == kEpiRaw)
+      bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    else
+      bv[j] = *reinterpret_cast<const f32x4*>(bias + col0 + 16 * j);
     asm volatile("" : "+v"(bv[j]));  // (returned before the first LDS-DMA is issued: see conv_img_s3.h)
   }
   f32x4 acc[TMV][CT], accs[TMV][CT];
@@ -336,10 +345,10 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
     set_off(offn, min(1, passes - 1));
     // prologue: pair 0's lines, then the weights of k-step 0 (what the loop's first counted wait expects in flight)
     {
-      const uint8_t* src = Xb + P::pair_off(0);
+      const uint8_t* src = Xb + P::pair_off(kp0);
 #pragma unroll
       for (int j = 0; j < J; ++j) glds16(src + offc[j], lds + ldst[j]);
-      issue_weights<P>(wsrc, lds, kLdsB + wave * 2 * kBSlot, 0, 0, lane);
+      issue_weights<P>(wsrc, lds, kLdsB + wave * 2 * kBSlot, 2 * kp0, 0, lane);
     }
     for (int p = 0; p < passes; ++p) {
       const int nt = size_of(p);
@@ -348,9 +357,9 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[t][j] = bv[j], accs[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (nt == NTM)
-        k_pass<P, NTM, J>(Xb, wsrc, lds, lds0, offc, offn, ldst, frag_base, wave, acc, accs, pp);
+        k_pass<P, NTM, J>(Xb, wsrc, lds, lds0, offc, offn, ldst, frag_base, wave, acc, accs, pp, kp0, kp1);
       else if constexpr (NTM > 1)
-        k_pass<P, NTM - 1, J>(Xb, wsrc, lds, lds0, offc, offn, ldst, frag_base, wave, acc, accs, pp);
+        k_pass<P, NTM - 1, J>(Xb, wsrc, lds, lds0, offc, offn, ldst, frag_base, wave, acc, accs, pp, kp0, kp1);
       // ---- epilogue: ReLU, this lane's four channels (per column tile) of pixel li of every tile
       const int t0 = r0 + first_of(p);
 #pragma unroll
@@ -360,8 +369,10 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
 #pragma unroll
           for (int j = 0; j < CT; ++j) {
             f32x4 v = acc[t][j] + accs[t][j];
+            if constexpr (EPI != kEpiRaw) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+              for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+            }
             if constexpr (OUT_S3) {
               uint8_t* o = reinterpret_cast<uint8_t*>(out_) + (size_t)row * (6 * P::OC) + (col0 + 16 * j) * 2;
               uint2 p0, p1, p2;
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
               *reinterpret_cast<uint2*>(o + 2 * P::OC) = p1;
               *reinterpret_cast<uint2*>(o + 4 * P::OC) = p2;
             } else {
-              *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out_) + (size_t)row * P::OC + col0 + 16 * j) = v;
+              *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out_) + ((size_t)blockIdx.y * M + row) * P::OC + col0 + 16 * j) = v;
             }
           }
         }
@@ -394,14 +405,22 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
 }
 
 // rows M = samples (fc).  Byte offsets are 32-bit: the caller keeps M * record bytes below 2^32.
-template <class P, bool OUT_S3>
-inline void launch(const void* X, const uint4* Wp, const float* bias, void* out, int M, hipStream_t s) {
+// slices > 1 (EPI = kEpiRaw only): the contraction split over gridDim.y, out = f32 [slices][M][OC] raw sums
+template <class P, int EPI>
+inline void launch(const void* X, const uint4* Wp, const float* bias, void* out, int M, hipStream_t s, int slices = 1) {
   constexpr int NCG = P::OC / (64 * CT);
   const int rt_total = (M + 15) / 16;
   int nrb = std::min(kMaxBlocks / 2 / NCG, rt_total);
   nrb = (nrb + 7) / 8 * 8;
-  hipLaunchKernelGGL((gemm_s3<P, OUT_S3>), dim3(nrb * NCG), dim3(kT), 0, s, reinterpret_cast<const uint8_t*>(X), Wp, bias,
-                     out, M);
+  hipLaunchKernelGGL((gemm_s3<P, EPI>), dim3(nrb * NCG, EPI == kEpiRaw ? slices : 1), dim3(kT), 0, s,
+                     reinterpret_cast<const uint8_t*>(X), Wp, bias, out, M);
+}
+// how many slices fill the chip for M rows of P (1 = no split)
+template <class P>
+inline int splitk_slices(int M) {
+  constexpr int NCG = P::OC / (64 * CT);
+  const int blocks = std::min((kMaxBlocks / 2 / NCG + 7) / 8 * 8, ((M + 15) / 16 + 7) / 8 * 8) * NCG;
+  return std::max(1, std::min(8, (kMaxBlocks / 2) / std::max(blocks, 1)));
 }
 
 // f32 channel-last [pixels][C] <-> split3 records (one thread per four channels)

@@ -538,7 +538,7 @@ struct rela_replay {
   // stream instead of queueing behind the sample path's latency-bound chain on `stream`: a block's slots belong to
   // its producer alone between reserve and commit (prioritized_replay.h:58-66 copies them with the mutex released),
   // so only the COMMIT -- weights and sum_, in slot order -- has to take its turn among sample / update.  The
-  // priorities travel through a small ring of staging buffers, so the producer never waits for `stream` at all.
+  // priorities travel through a small ring of staging buffers, (see above)
   // page-locked record a scan that ran off the end of the ring writes (prioritized_replay.h:297-302: the reference
   // prints it and aborts); read at the next sample / update_priority, which then fail with RELA_ESCAN
   ScanFailure* scan_failure = nullptr;
@@ -557,6 +557,12 @@ struct rela_replay {
     hipEvent_t done;
   };
   std::deque<Eviction> evictions;
+  // slots popped by a sample that gathered NOTHING itself (out_rows_dev = NULL: the owner's half of the native
+  // exchange; the learner's rela_replay_remote_gather reads the rows later, from another process, where no event of
+  // this one can order it): they stay reserved -- begin_add counts them as occupied -- until the update_priority that
+  // ends the batch, which the protocol puts behind the learner's read (producers blocked on a full ring
+  // used to rewrite exactly the slots such a sample had just evicted and possibly drawn)
+  int held = 0;
   std::vector<hipEvent_t> ev_pool;
   // rela_replay_set_decoupled_insert: false (default) = an insert runs wholly on `stream`, in order with sample /
   // update; true = its row copies and priority staging run on `copy_stream` (see above)
@@ -752,7 +758,7 @@ extern "C" int rela_replay_units_reserve(rela_replay* r, int count, int nonblock
   // a unit may be overwritten only when no live (or reserved) slot refers to it: FIFO order makes the slot at
   // `head` the one with the smallest reference
   auto fits = [&] {
-    const int64_t oldest = r->size > 0 ? r->dd_slot_min[(size_t)r->head] : r->dd_next_seq;
+    const int64_t oldest = r->size + r->held > 0 ? r->dd_slot_min[(size_t)((r->head - r->held + r->ring) % r->ring)] : r->dd_next_seq;
     return r->dd_next_seq + count - oldest <= r->dd_cap;
   };
   if (r->shut) return RELA_EWOULDBLOCK;
@@ -848,9 +854,9 @@ extern "C" int rela_replay_begin_add(rela_replay* r, int n, int nonblocking, int
   RELA_CHECK(n <= r->ring, RELA_EINVAL, "rela_replay_begin_add: block of %d exceeds the ring (%d)", n, r->ring);
   std::unique_lock<std::mutex> lk(r->m);
   if (r->shut) return RELA_EWOULDBLOCK;
-  if (r->size + n > r->ring) {  // cvSize_.wait :47
+  if (r->size + r->held + n > r->ring) {  // cvSize_.wait :47 (+ the slots a remote reader may still be reading)
     if (nonblocking) return RELA_EWOULDBLOCK;
-    r->cv_size.wait(lk, [&] { return r->shut || r->size + n <= r->ring; });
+    r->cv_size.wait(lk, [&] { return r->shut || r->size + r->held + n <= r->ring; });
     if (r->shut) return RELA_EWOULDBLOCK;
   }
   *first_slot = r->tail;
@@ -1203,8 +1209,10 @@ extern "C" int rela_replay_sample(rela_replay* r, int batch, void* const* out_ro
     RELA_HIP(hipStreamWaitEvent(consumer, r->ev_out, 0));
   }
   r->n_sampled = batch;
+  const bool hold = n_pop > 0 && !out_rows_dev;  // (see rela_replay::held)
+  if (hold) r->held += n_pop;
   lk.unlock();
-  if (n_pop > 0) r->cv_size.notify_all();
+  if (n_pop > 0 && !hold) r->cv_size.notify_all();
   return RELA_OK;
 }
 
@@ -1239,6 +1247,10 @@ extern "C" int rela_replay_update_priority(rela_replay* r, int n, const float* p
     RELA_HIP(hipStreamWaitEvent(producer, r->ev_out, 0));
   }
   r->n_sampled = 0;  // sampledIds_.clear() :244
+  const bool release = r->held > 0;  // the batch is over: whoever read its rows remotely has done so
+  r->held = 0;
+  lk.unlock();
+  if (release) r->cv_size.notify_all();
   return RELA_OK;
 }
 

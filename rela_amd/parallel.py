@@ -455,7 +455,9 @@ class _ModuleNativePartition:
 class NativePartitionServer(PartitionServer):
     """Actor-rank side of the native exchange: `replay` is a rela_amd.replay.FFReplay / RNNReplay, or an adapter with
     export_desc() / sample_ids(n) -> (raw weights, float sum, size) / update_priority(p) (the `rela` module's replays:
-    _ModuleNativePartition)."""
+    _ModuleNativePartition).  Ordering against the actors' INSERTS (which keep running while this thread serves) is the
+    library's: the slots a gather-less sample evicts stay reserved until update_priority (csrc/replay.hip:
+    rela_replay::held), so nothing the learner's peer read can touch is rewritten before `_update_step`."""
 
     def __init__(self, replay, specs, batch, beta, device, flat_sizes=(), on_weights=None, learner_rank=0, group=None,
                  scheduled=False, data_device=None):

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <climits>
 #include <chrono>
 #include <cstdio>
 #include <condition_variable>
@@ -430,7 +431,7 @@ class ModelLocker {
   std::vector<void*> online_, target_;
   std::vector<int> inFlight_;
   int latest_ = 0;
-  int numAction_ = 0;
+  std::atomic<int> numAction_{0};
   Kind kind_ = kFF;
   bool kindKnown_ = false;
   double eta_ = 0.9;
@@ -513,12 +514,21 @@ class ReplayParts {
     return h;
   }
 
+  // One partition: its size.  Several: G x the smallest (0 until every planned partition exists) -- a training loop
+  // gates its first sample on size() >= burn_in (pyrela/main.py:206), and sample() draws B / G from EVERY partition:
+  // the sum over partitions would open the gate while one act device has not inserted yet.
   int size() const {
     std::lock_guard<std::mutex> lk(m_);
-    int n = 0;
-    for (auto& p : parts_)
-      if (p.h) n += rela_replay_size(p.h);
-    return n;
+    const int G = (int)planned_.size();
+    if (G <= 1) {
+      int n = 0;
+      for (auto& p : parts_)
+        if (p.h) n += rela_replay_size(p.h);
+      return n;
+    }
+    int least = INT_MAX;
+    for (int g = 0; g < G; ++g) least = std::min(least, g < (int)parts_.size() && parts_[g].h ? rela_replay_size(parts_[g].h) : 0);
+    return least * G;
   }
   int numAdd() const {
     std::lock_guard<std::mutex> lk(m_);
@@ -643,9 +653,11 @@ class FFPrioritizedReplay {
 
   // the partition of `lockerKey`, created lazily by the first actor that knows the device and the action count
   rela_replay* handle(const void* lockerKey, int device, int numAction) {
-    if (numAction_ != 0 && numAction != numAction_)
-      throw std::runtime_error("FFPrioritizedReplay: actors disagree on the action count");
-    numAction_ = numAction;
+    {  // (several cohort leaders call this concurrently on their first act: ADVICE r4)
+      int seen = 0;
+      if (!numAction_.compare_exchange_strong(seen, numAction) && seen != numAction)
+        throw std::runtime_error("FFPrioritizedReplay: actors disagree on the action count");
+    }
     return core_.handle(lockerKey, device, [&](rela_replay* h) {
       const int64_t A = numAction;
       const int64_t rb[10] = {kObsBytes, kObsBytes, 4, 4, 4 * A, 4 * A, 8, 4, 1, 4};
@@ -796,7 +808,7 @@ class FFPrioritizedReplay {
 
  private:
   ReplayParts core_;
-  int numAction_ = 0;
+  std::atomic<int> numAction_{0};
   int lastBatch_ = 0;
   std::vector<int> lastCounts_;
   std::string lastDevice_;
@@ -817,10 +829,14 @@ class RNNPrioritizedReplay {
   ReplayParts& core() { return core_; }
 
   rela_replay* handle(const void* lockerKey, int device, int numAction, int T) {
-    if (numAction_ != 0 && (numAction != numAction_ || T != T_))
-      throw std::runtime_error("RNNPrioritizedReplay: actors disagree on action count / window length");
-    numAction_ = numAction;
-    T_ = T;
+    {  // (several cohort leaders call this concurrently on their first act: ADVICE r4)
+      int64_t seen = 0;
+      const int64_t mine = ((int64_t)numAction << 32) | (uint32_t)T;
+      if (!shape_.compare_exchange_strong(seen, mine) && seen != mine)
+        throw std::runtime_error("RNNPrioritizedReplay: actors disagree on action count / window length");
+      numAction_ = numAction;
+      T_ = T;
+    }
     return core_.handle(lockerKey, device, [&](rela_replay* h) {
       const int64_t A = numAction, t = T;
       const int64_t rb[10] = {t * kObsBytes, t * 4, t * 4 * A, t * 8, t * 4, t, t * 4, 2048, 2048, 4};
@@ -954,7 +970,8 @@ class RNNPrioritizedReplay {
 
  private:
   ReplayParts core_;
-  int numAction_ = 0, T_ = 0;
+  std::atomic<int64_t> shape_{0};  // numAction << 32 | T, set once
+  std::atomic<int> numAction_{0}, T_{0};
   int lastBatch_ = 0;
   std::vector<int> lastCounts_;
   std::string lastDevice_;

@@ -310,6 +310,43 @@ def test_protocol_errors():
     g.close()
 
 
+def test_gatherless_sample_holds_its_evicted_slots_until_update():
+    """the owner's half of the native exchange samples WITHOUT gathering (out_rows_dev = NULL) and the
+    learner reads the rows later from another process.  A draw can land in the range its own sample evicts, and on a
+    full ring the producers blocked in begin_add used to rewrite exactly those slots.  Now the evicted slots stay
+    reserved until the update_priority that ends the batch: with the ring full, an insert after the gather-less sample
+    would block; the evicted rows (sampled ones among them) are intact when read afterwards; the same insert goes
+    through once update_priority ran.  A gathering sample releases at once, as the reference's blockPop does
+    (rela/prioritized_replay.h:84-103)."""
+    import ctypes as C
+
+    from gpu_util import GpuReplay
+    from rela_amd import _capi as capi
+
+    cap, ring = 16, 20
+    g = GpuReplay(cap, 3, 1.0, 1.0)
+    prio = np.zeros(ring, np.float32)
+    prio[:4] = 1.0  # all the weight on the four OLDEST slots: every draw lands in the range the sample evicts
+    assert g.add_tags(1000 + np.arange(ring), prio) == 0
+    assert g.state()["size"] == ring
+    rc, _, _ = g.sample(8, gather=False)
+    assert rc == 0
+    st = g.state(8)
+    assert st["size"] == cap and set(st["ids"]) <= {0, 1, 2, 3}  # popped for the sampler ...
+    assert g.add_tags([7, 7, 7, 7], np.ones(4, np.float32)) == capi.EWOULDBLOCK  # ... but still held for the reader
+    # what the learner's remote gather would read: the drawn rows, unchanged
+    tags = np.zeros(ring, np.int64)
+    capi.check(capi.lib.rela_replay_debug_read_rows(g.h, 0, 0, ring, tags.ctypes.data_as(C.c_void_p)), "debug_read_rows")
+    assert (tags == 1000 + np.arange(ring)).all()
+    assert g.update(np.ones(8, np.float32)) == 0
+    assert g.add_tags([7, 7, 7, 7], np.ones(4, np.float32)) == 0  # released
+    # a gathering sample releases its evicted slots at once
+    rc, _, _ = g.sample(8, gather=True)
+    assert rc == 0
+    assert g.add_tags([8, 8, 8, 8], np.ones(4, np.float32)) == 0
+    g.close()
+
+
 @pytest.mark.parametrize("kind", ["uniform", "lognormal", "logwide", "sparse", "ties", "pow06", "denorm",
                                   "giant_first", "leading_zeros"])
 @pytest.mark.parametrize("n", [1, 64, 1000, 16384, 16385, 70000])

@@ -159,9 +159,9 @@ static void run(const HostProb& hp, int N, int iters) {
         s3::launch_conv3_img(dR, dP, dB, dOR, N, 0);
       else if constexpr (PS::OC % 128 == 0) {
         if (outs3)
-          s3::launch<PS, true>(dR, dP, dB, dOR, M, 0);
+          s3::launch<PS, s3::kEpiReluS3>(dR, dP, dB, dOR, M, 0);
         else
-          s3::launch<PS, false>(dR, dP, dB, dO, M, 0);
+          s3::launch<PS, s3::kEpiRelu>(dR, dP, dB, dO, M, 0);
       }
     };
     CK(hipMemset(dO, 0xff, oe * 4));
