@@ -2181,7 +2181,6 @@ extern "C" int rela_ffnet_precision(const rela_ffnet* n) { return n ? n->precisi
 
 // split3 records of a2 / a3 (f32x3 mode, gemm_s3.h) live behind the f32 layout of ffnet_layout.h (and the fc split-K
 // partial tiles): 6 bytes per value where the f32 tensors have 4
-constexpr int64_t kRec2Bytes = 81 * 384, kRec3Bytes = 49 * 384;
 static inline int64_t ws_records_offset(int batch) {
   const int64_t b = batch > 0 ? batch : 0;
   const int64_t f = (int64_t)sizeof(float) * (kWsFloatsPerSample * b + (b < kFcSplitBelow ? kFcPartFloats : 0)) + 256;
@@ -2624,16 +2623,23 @@ struct rela_lstmnet {
   float* Bl = nullptr;   // lstm frags [128][912][64]
   float* bl = nullptr;   // b_ih + b_hh, permuted [2048]
   uint8_t* Wrec = nullptr;  // weight_ih_l0 as rec64 rows in the permuted column order [2048][49][64 hi | 64 lo]
+  uint4* Wx3 = nullptr;     // ... as three-part bf16 fragments in the same column order (gemm_s3.h; f32x3 mode)
   bool loaded = false;
   uint64_t version = 0;  // bumped by every load
   // 0 = exact f32; 1 = split-bf16 conv trunk and, from kFastMinN rows up, the x part of the gate GEMM on split-bf16
-  // MFMA too (the recurrent part and the cell stay f32); 2 = f32x3: conv2 / conv3 of the trunk on the three-part bf16
-  // kernels of gemm_f32emu.h from 512 rows up (f32 accuracy), everything else as in mode 0
+  // MFMA too (the recurrent part and the cell stay f32); 2 = f32x3: from 512 rows up the conv trunk AND the x part of the
+  // gate GEMM (3136 -> 2048: three quarters of the step's FLOPs) with three-part operands on the bf16 matrix cores
+  // (conv12_s3.h, conv_img_s3.h, gemm_s3.h: f32 accuracy), the recurrent part, the cell and the heads as in mode 0
   int precision = 0;
 };
 
 namespace {
-constexpr int64_t kLstmWsFloats = kA1 + kA2 + kA3 + kHA + 2048;  // + the x part of the gates (bf16x2 mode)
+constexpr int64_t kLstmWsFloats = kA1 + kA2 + kA3 + kHA + 2048;  // + the x part of the gates (bf16x2 / f32x3 modes)
+using ProbGateX3 = s3::ProbFcT<2048>;
+// split3 records of a2 / a3 behind the f32 layout (f32x3 mode)
+inline int64_t lstm_ws_records_offset(int batch) {
+  return (((int64_t)sizeof(float) * kLstmWsFloats * (batch > 0 ? batch : 0) + 256) + 255) & ~(int64_t)255;
+}
 }
 
 extern "C" int rela_lstmnet_create(rela_lstmnet** out, int num_action, int device) {
@@ -2659,6 +2665,11 @@ extern "C" int rela_lstmnet_create(rela_lstmnet** out, int num_action, int devic
   RELA_HIP(hipMalloc(&d.bh, sizeof(float) * 32));
   RELA_HIP(hipMalloc(&n->Bl, sizeof(float) * (size_t)GemmLstm::CT * GemmLstm::KS * 64));
   RELA_HIP(hipMalloc(&n->Wrec, (size_t)2048 * 49 * 256));
+  RELA_HIP(hipMalloc(&n->Wx3, sizeof(uint4) * f32emu::packed_u4<f32emu::ProbGateX>()));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&s3::conv12_s3<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               s3::Conv12S::LDS_TOTAL));
+  RELA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&s3::conv12_s3<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               s3::Conv12S::LDS_TOTAL));
   RELA_HIP(hipMalloc(&n->bl, sizeof(float) * 2048));
   RELA_HIP(hipMalloc(&d.W1d, sizeof(uint4) * Conv12I::W1_UINT4));
   RELA_HIP(hipMalloc(&d.s1q, sizeof(float) * 32));
@@ -2692,7 +2703,7 @@ extern "C" void rela_lstmnet_destroy(rela_lstmnet* n) {
   DeviceGuard g(n->device);
   (void)hipDeviceSynchronize();
   void* ps[] = {n->d.B1, n->d.b1, n->d.B2, n->d.b2, n->d.B3, n->d.b3, n->d.Bh, n->d.bh, n->Bl, n->bl,
-                n->d.B2f, n->d.B3f, n->Wrec, n->d.W1d, n->d.s1q, n->d.b1q, n->d.B2e, n->d.B3e};
+                n->d.B2f, n->d.B3f, n->Wrec, n->d.W1d, n->d.s1q, n->d.b1q, n->d.B2e, n->d.B3e, n->Wx3};
   for (void* p : ps) (void)hipFree(p);
   delete n;
 }
@@ -2711,7 +2722,7 @@ extern "C" uint64_t rela_lstmnet_version(const rela_lstmnet* n) { return n ? n->
 
 extern "C" int64_t rela_lstmnet_workspace_bytes(const rela_lstmnet* n, int batch) {
   (void)n;
-  return (int64_t)sizeof(float) * kLstmWsFloats * (batch > 0 ? batch : 0) + 256;
+  return lstm_ws_records_offset(batch) + (int64_t)(batch > 0 ? batch : 0) * (kRec2Bytes + kRec3Bytes) + 256;
 }
 
 extern "C" int rela_lstmnet_load(rela_lstmnet* n, const rela_lstmnet_params* p, int on_device, void* stream_) {
@@ -2756,6 +2767,8 @@ extern "C" int rela_lstmnet_load(rela_lstmnet* n, const rela_lstmnet_params* p, 
                      reinterpret_cast<uint16_t*>(n->d.B3e), f32emu::ProbConv3::NCG, f32emu::ProbConv3::KS);
   pack(kPackLstm, dv[6], dv[7], n->Bl, GemmLstm::CT, GemmLstm::KS);
   hipLaunchKernelGGL(pack_wih_rec64_perm, dim3(ceil_div((int64_t)2048 * 3136 / 8, 256)), dim3(256), 0, s, dv[6], n->Wrec);
+  hipLaunchKernelGGL(pack_f32emu, dim3((unsigned)ceil_div(f32emu::packed_u4<f32emu::ProbGateX>() * 8 / 3, 256)), dim3(256), 0, s, 4, dv[6],
+                     reinterpret_cast<uint16_t*>(n->Wx3), f32emu::ProbGateX::NCG, f32emu::ProbGateX::KS);
   pack(kPackHeads, dv[12], dv[10], n->d.Bh, 2, 128);
   hipLaunchKernelGGL(pack_conv1_i8, dim3(32), dim3(256), 0, s, dv[0], dv[1], reinterpret_cast<uint8_t*>(n->d.W1d), n->d.s1q,
                      n->d.b1q);
@@ -2783,8 +2796,39 @@ namespace {
 // split-bf16 MFMA with a3 turned back into f32 in place (a1 is then NOT produced, a2 holds split records)
 // records (with fast): a3 stays in split records (the rec64 operand of the learner's split-bf16 gate GEMM); returns
 // whether it did
+// rec (with emu, N >= kEmuConvMinN): N * (kRec2Bytes + kRec3Bytes) bytes of scratch -- the f32x3 trunk on split3 records
+// (conv12_s3 -> conv3_img_s3); a3's records stay at rec + N * kRec2Bytes for the gate GEMM; keep_f32: a1 / a2 / a3 are
+// ALSO written as channel-last f32 (the learner's online pass); returns whether the records were produced
 bool lstm_trunk_launch(const FFNetDev& d, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, bool fast,
-                       hipStream_t s, const char* const* names, bool records = false, bool emu = false) {
+                       hipStream_t s, const char* const* names, bool records = false, bool emu = false, uint8_t* rec = nullptr,
+                       bool keep_f32 = true) {
+  if (emu && rec && N >= kEmuConvMinN && N <= kEmuMaxN) {
+    uint8_t *rec2 = rec, *rec3 = rec + (int64_t)N * kRec2Bytes;
+    {
+      ProfScope prof(names[1], s);
+      note_launch("conv12_s3");
+      if (keep_f32)
+        hipLaunchKernelGGL(s3::conv12_s3<true>, dim3(std::min(kNumCU, N)), dim3(s3::Conv12S::kT), s3::Conv12S::LDS_TOTAL, s, s_dev,
+                           (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2e, (const float*)d.b2,
+                           rec2, a1, N);
+      else
+        hipLaunchKernelGGL(s3::conv12_s3<false>, dim3(std::min(kNumCU, N)), dim3(s3::Conv12S::kT), s3::Conv12S::LDS_TOTAL, s, s_dev,
+                           (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2e, (const float*)d.b2,
+                           rec2, (float*)nullptr, N);
+    }
+    {
+      ProfScope prof(names[2], s);
+      note_launch("conv3_img_s3");
+      s3::launch_conv3_img(rec2, d.B3e, d.b3, rec3, N, s);
+    }
+    if (keep_f32) {
+      note_launch("unsplit_s3");
+      const int64_t p2 = (int64_t)N * 81, p3 = (int64_t)N * 49;
+      hipLaunchKernelGGL(s3::unsplit_s3<64>, dim3((unsigned)ceil_div(p2 * 16, 256)), dim3(256), 0, s, (const uint8_t*)rec2, a2, p2);
+      hipLaunchKernelGGL(s3::unsplit_s3<64>, dim3((unsigned)ceil_div(p3 * 16, 256)), dim3(256), 0, s, (const uint8_t*)rec3, a3, p3);
+    }
+    return true;
+  }
   if (fast && N >= kFastTrunkMinN) {
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
@@ -2849,9 +2893,28 @@ extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_
   // bf16x2 mode from kFastMinN rows up: a3 stays in split records, the x part of the gates is one split-bf16 GEMM
   // (gemm_bf16s.h: 41 GFLOP at 3,200 rows) and the f32 MFMA kernel only adds h x W_hh (K = 512) and runs the cell
   const bool fast_gates = n->precision == 1 && N >= kFastMinN;
+  uint8_t* rec = static_cast<uint8_t*>(ws) + lstm_ws_records_offset(N);
   const bool recs = lstm_trunk_launch(d, N, s_dev, a1, a2, a3, n->precision == 1, s, kLstmActorNames, fast_gates,
-                                      n->precision == 2);
-  if (fast_gates && recs) {
+                                      n->precision == 2, rec, /*keep_f32=*/false);
+  if (n->precision == 2 && recs) {
+    // f32x3: the x part of the gates (3136 -> 2048) as a three-part GEMM over a3's records -> gx (raw sums, permuted gate
+    // columns); the f32 MFMA kernel adds h x W_hh (K = 512) and the bias and runs the cell
+    {
+      ProfScope prof("lstm_gates_x_f32x3", s);
+      note_launch("gemm_s3<gates_x>");
+      s3::launch<ProbGateX3, s3::kEpiRaw>(rec + (int64_t)N * kRec2Bytes, n->Wx3, nullptr, gx, N, s);
+    }
+    ProfScope prof("lstm_gates_mfma", s);
+    note_launch("gemm_mfma<GemmLstmH> (f32)");
+    if (prefer_bm112(N, GemmLstmH::CT / GemmLstmH::CTB, GemmLstmH::BM))
+      hipLaunchKernelGGL(gemm_mfma<GemmLstmH112>, dim3(GemmLstmH112::CT / GemmLstmH112::CTB, ceil_div(N, GemmLstmH112::BM)),
+                         dim3(kThreads), 0, s, h_in, (const float*)gx, (const float*)n->Bl, (const float*)n->bl, h_out,
+                         c_in, c_out, N);
+    else
+      hipLaunchKernelGGL(gemm_mfma<GemmLstmH>, dim3(GemmLstmH::CT / GemmLstmH::CTB, ceil_div(N, GemmLstmH::BM)),
+                         dim3(kThreads), 0, s, h_in, (const float*)gx, (const float*)n->Bl, (const float*)n->bl, h_out,
+                         c_in, c_out, N);
+  } else if (fast_gates && recs) {
     int rc = gemm16::launch_rec64_nt(reinterpret_cast<const uint8_t*>(a3), n->Wrec, N, 2048, 49, gemm16::EpiPlain{gx, 2048}, s,
                                      "lstm_gates_x_bf16");
     if (rc != RELA_OK) return rc;
@@ -2898,12 +2961,28 @@ extern "C" int rela_lstmnet_step(const rela_lstmnet* n, int N, const uint8_t* s_
 // conv trunk only: frames u8[N][4][84][84] -> a1 / a2 / a3 (channel-last, ffnet_layout.h)
 namespace rela_amd {
 int lstmnet_trunk(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, hipStream_t s,
-                  const char* const* names, bool fast, bool* a3_records) {
+                  const char* const* names, bool fast, bool* a3_records, uint8_t* s3_scratch, bool keep_f32) {
   RELA_CHECK(n && n->loaded, RELA_ESTATE, "lstmnet_trunk: parameters were never loaded");
   RELA_CHECK(N >= 1 && s_dev && a1 && a2 && a3, RELA_EINVAL, "lstmnet_trunk: bad arguments");
   const bool rec = lstm_trunk_launch(n->d, N, s_dev, a1, a2, a3, fast, s, names, a3_records != nullptr,
-                                     !fast && n->precision == 2);
+                                     !fast && n->precision == 2, s3_scratch, keep_f32);
   if (a3_records) *a3_records = rec;
+  RELA_LAUNCH_CHECK();
+  return RELA_OK;
+}
+
+int64_t gate_x3_packed_bytes() { return (int64_t)sizeof(uint4) * f32emu::packed_u4<f32emu::ProbGateX>(); }
+int pack_gate_x3(const float* w_ih_dev, void* dst, bool permuted, hipStream_t s) {
+  RELA_CHECK(w_ih_dev && dst, RELA_EINVAL, "pack_gate_x3: bad arguments");
+  hipLaunchKernelGGL(pack_f32emu, dim3((unsigned)ceil_div(f32emu::packed_u4<f32emu::ProbGateX>() * 8 / 3, 256)), dim3(256), 0, s,
+                     permuted ? 4 : 3, w_ih_dev, reinterpret_cast<uint16_t*>(dst), f32emu::ProbGateX::NCG, f32emu::ProbGateX::KS);
+  RELA_LAUNCH_CHECK();
+  return RELA_OK;
+}
+int gate_x3_gemm(const uint8_t* a3_records, const void* packed, const float* bias, float* gx, int M, hipStream_t s) {
+  RELA_CHECK(a3_records && packed && bias && gx && M >= 1, RELA_EINVAL, "gate_x3_gemm: bad arguments");
+  note_launch("gemm_s3<gates_x>");
+  s3::launch<ProbGateX3, s3::kEpiBias>(a3_records, reinterpret_cast<const uint4*>(packed), bias, gx, M, s);
   RELA_LAUNCH_CHECK();
   return RELA_OK;
 }

@@ -14,6 +14,8 @@ namespace rela_amd {
 
 constexpr int64_t kA1 = 400 * 32, kA2 = 81 * 64, kA3 = 49 * 64, kH = 512, kHA = 32;
 constexpr int64_t kWsFloatsPerSample = kA1 + kA2 + kA3 + kH + kHA;
+// split3 records of a2 / a3 (f32x3 mode, gemm_s3.h): 6 bytes per value where the f32 tensors have 4
+constexpr int64_t kRec2Bytes = 81 * 384, kRec3Bytes = 49 * 384;
 
 struct FFNetWs {
   float *a1, *a2, *a3, *h, *ha;
@@ -84,8 +86,18 @@ namespace rela_amd {
 // fast: conv1 -> conv2 fused and conv3 on split-bf16 MFMA (a3 comes out in f32 as always; a1 is NOT produced and a2 holds
 // split records, so only for passes whose activations nobody reads back)
 // a3_records != NULL (with fast): a3 may stay in split records [rows][49][64 hi | 64 lo] (*a3_records says whether)
+// s3_scratch != NULL (f32x3 nets, N >= 512): N * (kRec2Bytes + kRec3Bytes) bytes -- the trunk runs on split3 records
+// (conv12_s3 -> conv3_img_s3), a3's records stay at s3_scratch + N * kRec2Bytes (*a3_records says whether) and a1 / a2 /
+// a3 are written as f32 only if keep_f32
 int lstmnet_trunk(const rela_lstmnet* n, int N, const uint8_t* s_dev, float* a1, float* a2, float* a3, hipStream_t s,
-                  const char* const* names, bool fast = false, bool* a3_records = nullptr);
+                  const char* const* names, bool fast = false, bool* a3_records = nullptr, uint8_t* s3_scratch = nullptr,
+                  bool keep_f32 = true);
+// weight_ih_l0 (2048, 3136; state_dict layout) -> the three-part bf16 fragments gemm_s3<ProbFcT<2048>> reads
+// (gate_x3_packed_bytes() bytes); permuted: gate columns as 4 * unit + gate (the actors' fused cell) or as stored
+int64_t gate_x3_packed_bytes();
+int pack_gate_x3(const float* w_ih_dev, void* dst, bool permuted, hipStream_t s);
+// the x part of the gates over a3's records: gx[M][2048] = bias + a3 . W_ih^T (bias may not be NULL)
+int gate_x3_gemm(const uint8_t* a3_records, const void* packed, const float* bias, float* gx, int M, hipStream_t s);
 int lstmnet_heads(const rela_lstmnet* n, int N, const float* o, const float* legal, float* ha, float* q, hipStream_t s,
                   const char* name);
 // the online net's trunk on split-bf16 MFMA with conv1's records kept for the rows [a1_lo, N): a1 / a2 / a3 come out as

@@ -118,6 +118,9 @@ struct ProbConv3 {  // a2 [N][9][9][64] -> a3 [N][7][7][64], 3x3 stride 1
     return ((tp / 3) * 9 + tp % 3) * 64 + (ks & 1) * 32;
   }
 };
+struct ProbGateX {  // a3 [N][3136] -> the x part of the LSTM gates [N][2048] (pack mode 4; the kernel is gemm_s3.h's)
+  static constexpr int KS = 98, NCG = 32, OC = 2048;
+};
 struct ProbFc {  // a3 [N][3136] (k = pos * 64 + c) -> h [N][512]
   static constexpr int KS = 98, NCG = 8, OC = 512;
   __device__ static int row_base(int m) { return m * 3136; }
@@ -340,7 +343,8 @@ __global__ __launch_bounds__(kT, OCC) void gemm_f32emu(const float* __restrict__
 }
 
 // f32 weight (state_dict layouts of pyrela/net.py:18-31) -> fragment-ordered bf16 triples.  mode: 1 conv2 (64,32,4,4) |
-// 2 conv3 (64,64,3,3) | 3 fc (512,3136; k = pos * 64 + c <- torch's c * 49 + pos).  One thread per (cg, ks, u, lane, j).
+// 2 conv3 (64,64,3,3) | 3 fc (OC,3136; k = pos * 64 + c <- torch's c * 49 + pos) | 4 the LSTM's input weights with
+// permuted gate columns.  One thread per (cg, ks, u, lane, j).
 __device__ __forceinline__ uint16_t bf16_rne_bits(float v) {
   const uint32_t x = __builtin_bit_cast(uint32_t, v);
   return (uint16_t)((x + 0x7fffu + ((x >> 16) & 1u)) >> 16);
@@ -362,9 +366,12 @@ __device__ __forceinline__ void pack_f32emu_at(int64_t idx, int mode, const floa
   } else if (mode == 2) {
     const int c = k & 63, tap = ProbConv3::tap(k >> 5);
     v = w[((oc * 64 + c) * 3 + tap / 3) * 3 + tap % 3];
-  } else {
+  } else if (mode == 3) {
     const int c = k & 63, pos = k >> 6;
     v = w[(size_t)oc * 3136 + c * 49 + pos];
+  } else {  // 4: weight_ih_l0 (2048, 3136) with the gate columns permuted to 4 * unit + gate (ffnet.hip: GemmLstmH)
+    const int c = k & 63, pos = k >> 6;
+    v = w[(size_t)((oc & 3) * 512 + (oc >> 2)) * 3136 + c * 49 + pos];
   }
   const uint16_t p0 = bf16_rne_bits(v);
   const float r1 = v - bf16_bits_f32(p0);

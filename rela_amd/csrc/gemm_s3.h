@@ -274,7 +274,7 @@ __device__ __forceinline__ void k_pass(const uint8_t* __restrict__ Xb, const uin
 // one tile; fc_reduce adds the slices, the bias and the ReLU).
 // gridDim.x = 8 * NCG * (row blocks / 8) with NCG = OC / 128: consecutive block ids go to the 8 XCDs in turn, so the
 // column groups of one row block (they read the same activations) share an L2.
-enum { kEpiRelu = 0, kEpiReluS3 = 1, kEpiRaw = 2 };
+enum { kEpiRelu = 0, kEpiReluS3 = 1, kEpiRaw = 2, kEpiBias = 3 };  // 3: bias + sum, no ReLU, f32 [M][OC]
 template <class P, int EPI>
 __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb, const uint4* __restrict__ Wp,
                                                  const float* __restrict__ bias, void* __restrict__ out_, int M) {
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
 #pragma unroll
           for (int j = 0; j < CT; ++j) {
             f32x4 v = acc[t][j] + accs[t][j];
-            if constexpr (EPI != kEpiRaw) {
+            if constexpr (EPI == kEpiRelu || EPI == kEpiReluS3) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
             }

@@ -624,6 +624,10 @@ struct rela_r2d2_learner {
   uint8_t* wTrec = nullptr;               // W_ih^T [3136][32 chunks], online                 (data gradient)
   uint8_t *arec = nullptr, *trec = nullptr;  // activations / gate gradients by rows; transposed operands of dW_ih
   uint64_t wver[2] = {1, 1}, rec_ver[2] = {0, 0};  // weight version (repack) / version the records were made from
+  // f32x3 (r5): the trunks on split3 records and the x part of the gates as a three-part GEMM (csrc/gemm_s3.h)
+  uint8_t* s3rec = nullptr;          // rowsAll x (a2 + a3 records)
+  void* wx3[2] = {nullptr, nullptr};  // W_ih of either net as three-part fragments (gate columns as stored)
+  uint64_t x3_ver[2] = {0, 0};
   float *ha = nullptr, *q_on = nullptr, *q_tg = nullptr;              // heads of the training rows
   float *qmin = nullptr, *qa_on = nullptr, *qa_tg = nullptr, *dqa = nullptr, *d_ha = nullptr, *d_o = nullptr;
   float *dc_rec = nullptr;
@@ -727,8 +731,10 @@ int forward_pre(rela_r2d2_learner* l, int which, int Bn, const uint8_t* obs, con
     rc = lstmnet_trunk_records(net, rowsAll, obs, l->a1, l->a2, l->a3, l->burn * Bn, s, kTrunkNames);
     a3_records = true;
   } else {
+    // (f32x3: on split3 records; only the online pass leaves a1 / a2 / a3 in f32, for the backward kernels)
+    const bool x3 = l->precision == 2 && l->s3rec != nullptr;
     rc = lstmnet_trunk(net, rowsAll, obs, l->a1, l->a2, l->a3, s, kTrunkNames, fast_target,
-                       fast_target ? &a3_records : nullptr);
+                       (fast_target || x3) ? &a3_records : nullptr, x3 ? l->s3rec : nullptr, which == 0);
   }
   if (rc != RELA_OK) return rc;
   if (l->precision == 1) {
@@ -750,6 +756,18 @@ int forward_pre(rela_r2d2_learner* l, int which, int Bn, const uint8_t* obs, con
       rc = trunk_unsplit_rows(l->a1 + tr0 * kA1, l->a2 + tr0 * kA2, l->a3 + tr0 * kA3, rowsAll - (int)tr0, s);
       if (rc != RELA_OK) return rc;
     }
+  } else if (a3_records) {
+    // f32x3: W_ih in three bf16 parts (re-packed when the weights changed), the GEMM over a3's records
+    if (l->x3_ver[which] != l->wver[which]) {
+      ProfScope prof("learner_lstm_split_w", s);
+      const rela_lstmnet_params p = lparams_at(l, which == 0 ? l->P : l->PT);
+      rc = pack_gate_x3(p.w_ih, l->wx3[which], false, s);
+      if (rc != RELA_OK) return rc;
+      l->x3_ver[which] = l->wver[which];
+    }
+    ProfScope prof("learner_lstm_gates_x", s);
+    rc = gate_x3_gemm(l->s3rec + (size_t)rowsAll * kRec2Bytes, l->wx3[which], l->bsum[which], l->gxs[which], rowsAll, s);
+    if (rc != RELA_OK) return rc;
   } else {
     ProbGateX p{};
     p.M = rowsAll, p.N = kGates, p.K = kFeat;
@@ -893,6 +911,15 @@ extern "C" int rela_r2d2_learner_create(rela_r2d2_learner** out, int num_action,
     R2_ALLOC(tmp, (size_t)(kGates + kFeat) * chunks * 64, false);  // [2048][chunks] followed by [3136][chunks]
     l->trec = reinterpret_cast<uint8_t*>(tmp);
   }
+  {
+    float* tmp = nullptr;
+    R2_ALLOC(tmp, (rowsAll * (size_t)(kRec2Bytes + kRec3Bytes) + 3) / 4, false);
+    l->s3rec = reinterpret_cast<uint8_t*>(tmp);
+    for (int w = 0; w < 2; ++w) {
+      R2_ALLOC(tmp, ((size_t)gate_x3_packed_bytes() + 3) / 4, false);
+      l->wx3[w] = tmp;
+    }
+  }
   R2_ALLOC(l->a1, rowsAll * kA1, false);
   R2_ALLOC(l->a2, rowsAll * kA2, false);
   R2_ALLOC(l->a3, rowsAll * kA3, false);
@@ -969,6 +996,9 @@ extern "C" void rela_r2d2_learner_destroy(rela_r2d2_learner* l) {
   (void)hipFree(l->wrec[1]);
   (void)hipFree(l->wTrec);
   (void)hipFree(l->arec);
+  (void)hipFree(l->s3rec);
+  (void)hipFree(l->wx3[0]);
+  (void)hipFree(l->wx3[1]);
   (void)hipFree(l->trec);
   rela_lstmnet_destroy(l->online);
   rela_lstmnet_destroy(l->target);

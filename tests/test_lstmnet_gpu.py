@@ -56,8 +56,8 @@ class GpuLstmNet:
 def test_lstm_step_vs_torch(N, A, precision):
     """All three precision modes against the plain PyTorch fp32 step, with the launched kernels asserted: in bf16x2 mode
     the trunk's split-bf16 kernels from 128 rows and the rec64 gate GEMM (lstm_gates_x_bf16) from 1,024 rows are
-    compared with torch-fp32 directly; in f32x3 mode conv2 / conv3 run on the three-part bf16 kernels from 512 rows
-    (csrc/gemm_f32emu.h), everything else on the f32 kernels."""
+    compared with torch-fp32 directly; in f32x3 mode, from 512 rows, the conv trunk and the x part of the gate GEMM run with
+    three-part operands on the bf16 matrix cores (csrc/conv12_s3.h, conv_img_s3.h, gemm_s3.h), the rest on the f32 kernels."""
     import torch
 
     from rela_amd.pyrela.net import AtariLSTMNet, dueling_q
@@ -74,12 +74,14 @@ def test_lstm_step_vs_torch(N, A, precision):
     with net.capi.launch_census() as census:
         h, c, q, adv = net.step(s, legal, h_in, c_in)
     fast = {CONV12, "conv_bf16s<Conv3F>"} | ({"gemm_rec64_nt"} if N >= 1024 else set())
-    emu = {"gemm_f32emu<conv2>", "gemm_f32emu<conv3>"}
+    # f32x3 from 512 rows (r5): the trunk on split3 records and the x part of the gates as a three-part GEMM
+    emu = {"conv12_s3", "conv3_img_s3", "gemm_s3<gates_x>"}
+    x3 = precision == "f32x3" and N >= 512
     if precision == "bf16x2" and N >= 128:
         assert fast <= set(census.counts), sorted(census.counts)
     else:
-        assert not (fast & set(census.counts)) and "conv1_bf16x3" in census.counts, sorted(census.counts)
-    assert (emu <= set(census.counts)) if (precision == "f32x3" and N >= 512) else not (emu & set(census.counts)), sorted(census.counts)
+        assert not (fast & set(census.counts)) and (x3 or "conv1_bf16x3" in census.counts), sorted(census.counts)
+    assert (emu <= set(census.counts)) if x3 else not (emu & set(census.counts)), sorted(census.counts)
     ref = AtariLSTMNet("cpu", A)
     ref.load_state_dict({k: torch.from_numpy(v) for k, v in p.items()})
     with torch.no_grad():
