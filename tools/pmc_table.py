@@ -20,6 +20,14 @@ def short(n):
     m = re.search(r"gemm_f32emu<.*?Prob(Conv2|Conv3|Fc)", n)
     if m:
         return {"Conv2": "conv2_mfma_f32x3", "Conv3": "conv3_mfma_f32x3", "Fc": "fc_mfma_f32x3"}[m.group(1)]
+    # r5: the f32x3 trunk on split3 records (csrc/conv12_s3.h, conv_img_s3.h, gemm_s3.h)
+    if "conv12_s3" in n:
+        return "conv12_fused_f32x3"
+    if "conv3_img_s3" in n:
+        return "conv3_mfma_f32x3"
+    m = re.search(r"gemm_s3<.*?ProbFcT<(\d+)", n)
+    if m:
+        return "fc_mfma_f32x3" if m.group(1) == "512" else "lstm_gates_x_f32x3"
     # split-bf16 path (names = the rela_prof labels bench.py looks traffic up by)
     if "conv12_i8" in n:
         return "conv12_fused"
@@ -59,13 +67,14 @@ def main(root, out_json):
         if name == "pmc_sq":
             for k, v in dur.items():
                 res.setdefault(k, {})["us"] = [x / 1e3 for x in v]
-    keep = ("conv12_fused", "conv1_bf16x3", "conv2_mfma", "conv3_mfma", "fc_mfma", "conv2_mfma_f32x3", "conv3_mfma_f32x3",
-            "fc_mfma_f32x3", "heads_mfma", "lstm_gates_mfma",
+    keep = ("conv12_fused", "conv12_fused_f32x3", "conv1_bf16x3", "conv2_mfma", "conv3_mfma", "fc_mfma", "conv2_mfma_f32x3",
+            "conv3_mfma_f32x3", "fc_mfma_f32x3", "heads_mfma", "lstm_gates_mfma", "lstm_gates_x_f32x3",
             "lstm_gates_x_bf16", "slide_stacks", "replay_scatter_rows",
             "replay_gather_big", "seq_chain", "replay_search", "replay_finish", "replay_update", "replay_append_weights")
     traffic = {}
-    print("| kernel | us | GHz | MFMA busy | HBM read MB | HBM write MB | LDS bank-conflict cycles |")
-    print("|---|---|---|---|---|---|---|")
+    print("every row is PER LAUNCH: averages over the `launches` launches of the kernel in the profiled run\n")
+    print("| kernel | launches | us | GHz | MFMA busy | HBM read MB | HBM write MB | LDS bank-conflict cycles |")
+    print("|---|---|---|---|---|---|---|---|")
     for k in keep:
         d = res.get(k)
         if not d or "us" not in d or "GRBM_GUI_ACTIVE" not in d:
@@ -74,8 +83,8 @@ def main(root, out_json):
         us, cyc = avg("us"), avg("GRBM_GUI_ACTIVE") / 8
         rd, wr = 2 * avg("FETCH_SIZE") * 1024, avg("WRITE_SIZE") * 1024
         traffic[k] = {"read_bytes": rd, "write_bytes": wr, "launch_us": us}
-        print("| %s | %.1f | %.2f | %.1f %% | %.1f | %.1f | %.0f |" % (
-            k, us, cyc / us / 1e3, 100 * avg("SQ_VALU_MFMA_BUSY_CYCLES") / (cyc * 1024), rd / 1e6, wr / 1e6,
+        print("| %s | %d | %.1f | %.2f | %.1f %% | %.1f | %.1f | %.0f |" % (
+            k, len(d["us"]), us, cyc / us / 1e3, 100 * avg("SQ_VALU_MFMA_BUSY_CYCLES") / (cyc * 1024), rd / 1e6, wr / 1e6,
             avg("SQ_LDS_BANK_CONFLICT")))
     if out_json:
         json.dump({"source": "rocprofv3 --pmc passes of tools/profile_forward.py (N = 6400), see tools/pmc_table.py",
