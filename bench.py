@@ -346,8 +346,13 @@ def threaded_leg(seconds=1.0, epochs=3, threads=64, games=100, precision="f32"):
            "note": "bounded sample of the reference's 6 x 30 s protocol; mean of the last half of the valid windows"}
     t0 = time.time()
     for env in ("fresh", "sliding"):
+        # r5: the sliding-stack env -- the drop-in's headline -- gets ONE window of the reference
+        # protocol's own length, 30 s, without and with the sampler (1 s windows moved 1.6 <-> 2.1 M between two passes); the
+        # fresh-LCG env (PCIe-bound) keeps the short windows
+        long_ = env == "sliding" and os.environ.get("RELA_BENCH_THREADED_LONG", "1") != "0"
         cmd = [sys.executable, os.path.join(ROOT, "rela_amd", "pyrela", "benchmark.py"), "--grid", "%dx%d" % (threads, games),
-               "--epoch_sec", str(seconds), "--num_epoch", str(epochs), "--replay_buffer_size", str(1 << 21), "--env", env]
+               "--epoch_sec", "30" if long_ else str(seconds), "--num_epoch", "1" if long_ else str(epochs),
+               "--replay_buffer_size", str(1 << (22 if long_ else 21)), "--env", env] + (["--burn_in_frames", "20000"] if long_ else [])
         try:
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, RELA_PRECISION=precision))
             line = [l for l in res.stdout.splitlines() if l.startswith("act rate: without sample:")][-1]
@@ -355,7 +360,8 @@ def threaded_leg(seconds=1.0, epochs=3, threads=64, games=100, precision="f32"):
         except Exception as e:  # noqa: BLE001  (reported, never fatal for the headline)
             out[env] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             continue
-        out[env] = {"without_sampler": without, "with_sampler": with_}
+        out[env] = {"without_sampler": without, "with_sampler": with_, "window_s": 30.0 if long_ else seconds,
+                    "windows": 1 if long_ else epochs}
     out["wall_s"] = time.time() - t0
     return out
 

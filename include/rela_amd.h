@@ -593,6 +593,13 @@ int rela_prof_summary_json(char* out, int64_t cap);
  * kernels were launched and not silently replaced by the f32 ones.  rela_prof_counts_json writes
  * {"kernel": launches, ...} since the enable / the last call and clears.                         */
 int rela_prof_count_enable(int on);
+/* Compute units left OUT of the grids of the persistent forward kernels (one block per CU: conv1 -> conv2, conv3).  Such a
+ * grid has no slack on 256 CUs: a CU held by another stream's small kernel (the replay's sample chain) when the launch
+ * starts delays one block -- and the launch -- by that kernel's duration.  0 (the library default) = the whole chip, right
+ * when ONE host thread pipelines actors, learner and replay (bench.py: 2.96 M env-steps/s against 2.89 M with 8); the
+ * `rela` module sets 8, right next to an independent sampler thread (threaded benchmark, sliding env, sampler on: 1.96 M
+ * -> 2.26 M env-steps/s).  RELA_CU_RESERVE in the environment wins over both.  The reference has no counterpart.        */
+int rela_runtime_set_cu_reserve(int cus);
 int rela_prof_counts_json(char* out, int64_t cap);
 
 /* ===================================================================================

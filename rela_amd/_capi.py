@@ -185,6 +185,7 @@ _sig("rela_prof_enable", i32, [i32])
 _sig("rela_prof_set_filter", i32, [C.c_char_p])
 _sig("rela_prof_summary_json", i32, [C.c_char_p, i64])
 _sig("rela_prof_count_enable", i32, [i32])
+_sig("rela_runtime_set_cu_reserve", i32, [i32])
 _sig("rela_prof_counts_json", i32, [C.c_char_p, i64])
 
 

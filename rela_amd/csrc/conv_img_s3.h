@@ -193,8 +193,8 @@ __global__ __launch_bounds__(256, 1) void conv3_img_s3(const uint8_t* __restrict
   wait_vm<0>();  // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
-inline void launch_conv3_img(const void* a2, const uint4* Wp, const float* bias, void* out, int N, hipStream_t s) {
-  const int nb = std::min(256, N);
+inline void launch_conv3_img(const void* a2, const uint4* Wp, const float* bias, void* out, int N, hipStream_t s, int blocks = 256) {
+  const int nb = std::max(1, std::min(blocks, N));
   hipLaunchKernelGGL(conv3_img_s3, dim3(nb), dim3(256), 0, s, reinterpret_cast<const uint8_t*>(a2), Wp, bias,
                      reinterpret_cast<uint8_t*>(out), N);
 }

@@ -25,6 +25,7 @@
 // accumulation: every product is exact and the result is fp32-accurate, while the layer drops
 // from MFMA-bound to HBM-bound (28 KB in + 51 KB out per sample).  The /255 of net.py:46 is
 // folded into conv1's weights at load time.
+#include <atomic>
 #include <cstdlib>
 
 #include "common.h"
@@ -253,6 +254,21 @@ __global__ __launch_bounds__(kThreads) void conv_mfma(const void* __restrict__ i
 // the global loads of group g+1 are issued before the k-loop of group g and written to the other
 // buffer halfway through it.  The k-loop then touches only LDS (A) and registers (B).
 constexpr int kNumCU = 256;
+// Blocks of a PERSISTENT kernel (one block per CU, each walking its share of the frames): a grid of exactly 256 has no
+// slack -- one CU held by another stream's small kernel (the replay's single-workgroup chain, a learner GEMM) when the
+// launch starts delays one block by that kernel's whole duration, and with it the launch.  RELA_CU_RESERVE = r leaves r
+// CUs out of such grids (default below; 0 = the full chip).
+std::atomic<int> g_cu_reserve{-1};  // -1: not set (RELA_CU_RESERVE, else 0)
+inline int persistent_blocks(int n) {
+  int r = g_cu_reserve.load(std::memory_order_relaxed);
+  if (r < 0) {
+    const char* e = std::getenv("RELA_CU_RESERVE");
+    r = e ? std::atoi(e) : 0;
+    r = r < 0 ? 0 : (r > 128 ? 128 : r);
+    g_cu_reserve.store(r, std::memory_order_relaxed);
+  }
+  return std::min(kNumCU - r, n);
+}
 
 template <class C>
 __global__ __launch_bounds__(kThreads) void conv_mfma_bstat(const float* __restrict__ in,
@@ -2163,6 +2179,11 @@ extern "C" int rela_ffnet_debug_conv12_records(const rela_ffnet* n, int N, const
   return RELA_OK;
 }
 
+extern "C" int rela_runtime_set_cu_reserve(int cus) {
+  RELA_CHECK(cus >= 0 && cus <= 128, RELA_EINVAL, "rela_runtime_set_cu_reserve: 0..128 compute units");
+  if (!std::getenv("RELA_CU_RESERVE")) rela_amd::g_cu_reserve.store(cus, std::memory_order_relaxed);
+  return RELA_OK;
+}
 extern "C" int rela_ffnet_num_action(const rela_ffnet* n) { return n ? n->num_action : 0; }
 namespace rela_amd {
 int ffnet_load_impl(rela_ffnet* n, const rela_ffnet_params* p, int on_device, void* stream_, const FFNetExtraPacks& extra);
@@ -2317,12 +2338,12 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
       ProfScope prof(name12, s);
-      note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
+      note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(persistent_blocks(N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
     }
     {
       ProfScope prof(names[2], s);
-      note_launch("conv_bf16s<Conv3F>"); hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
+      note_launch("conv_bf16s<Conv3F>"); hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(persistent_blocks(ceil_div(N, Conv3F::S))), dim3(kThreads),
                          Conv3F::LDS_TOTAL, s, (const uint8_t*)r2, (const uint4*)d.B3f, (const float*)d.b3, r3, N);
       if (!fc_split_bf16) {
         note_launch("unsplit_records64"); hipLaunchKernelGGL(unsplit_records64, dim3(ceil_div((int64_t)N * 49, 4)), dim3(256), 0, s, r3, (int64_t)N * 49);
@@ -2353,12 +2374,12 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {  // conv1 (int8 matrix cores) -> conv2 (split-bf16), fused per frame through LDS
       ProfScope prof(name12, s);
-      note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
+      note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(persistent_blocks(N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
     }
     {
       ProfScope prof(names[2], s);
-      note_launch("conv_bf16s<Conv3F>"); hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
+      note_launch("conv_bf16s<Conv3F>"); hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(persistent_blocks(ceil_div(N, Conv3F::S))), dim3(kThreads),
                          Conv3F::LDS_TOTAL, s, (const uint8_t*)r2, (const uint4*)d.B3f, (const float*)d.b3, r3, N);
     }
     {
@@ -2377,18 +2398,18 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
       ProfScope prof(name12, s);
       note_launch("conv12_s3");
       if (keep_f32)
-        hipLaunchKernelGGL(s3::conv12_s3<true>, dim3(std::min(kNumCU, N)), dim3(s3::Conv12S::kT), s3::Conv12S::LDS_TOTAL, s, s_dev,
+        hipLaunchKernelGGL(s3::conv12_s3<true>, dim3(persistent_blocks(N)), dim3(s3::Conv12S::kT), s3::Conv12S::LDS_TOTAL, s, s_dev,
                            (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2e, (const float*)d.b2,
                            rec2, a1, N);
       else
-        hipLaunchKernelGGL(s3::conv12_s3<false>, dim3(std::min(kNumCU, N)), dim3(s3::Conv12S::kT), s3::Conv12S::LDS_TOTAL, s, s_dev,
+        hipLaunchKernelGGL(s3::conv12_s3<false>, dim3(persistent_blocks(N)), dim3(s3::Conv12S::kT), s3::Conv12S::LDS_TOTAL, s, s_dev,
                            (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2e, (const float*)d.b2,
                            rec2, (float*)nullptr, N);
     }
     {
       ProfScope prof(names[2], s);
       note_launch("conv3_img_s3");
-      s3::launch_conv3_img(rec2, d.B3e, d.b3, rec3, N, s);
+      s3::launch_conv3_img(rec2, d.B3e, d.b3, rec3, N, s, persistent_blocks(N));
     }
     {
       ProfScope prof(names[3], s);
@@ -2808,18 +2829,18 @@ bool lstm_trunk_launch(const FFNetDev& d, int N, const uint8_t* s_dev, float* a1
       ProfScope prof(names[1], s);
       note_launch("conv12_s3");
       if (keep_f32)
-        hipLaunchKernelGGL(s3::conv12_s3<true>, dim3(std::min(kNumCU, N)), dim3(s3::Conv12S::kT), s3::Conv12S::LDS_TOTAL, s, s_dev,
+        hipLaunchKernelGGL(s3::conv12_s3<true>, dim3(persistent_blocks(N)), dim3(s3::Conv12S::kT), s3::Conv12S::LDS_TOTAL, s, s_dev,
                            (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2e, (const float*)d.b2,
                            rec2, a1, N);
       else
-        hipLaunchKernelGGL(s3::conv12_s3<false>, dim3(std::min(kNumCU, N)), dim3(s3::Conv12S::kT), s3::Conv12S::LDS_TOTAL, s, s_dev,
+        hipLaunchKernelGGL(s3::conv12_s3<false>, dim3(persistent_blocks(N)), dim3(s3::Conv12S::kT), s3::Conv12S::LDS_TOTAL, s, s_dev,
                            (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2e, (const float*)d.b2,
                            rec2, (float*)nullptr, N);
     }
     {
       ProfScope prof(names[2], s);
       note_launch("conv3_img_s3");
-      s3::launch_conv3_img(rec2, d.B3e, d.b3, rec3, N, s);
+      s3::launch_conv3_img(rec2, d.B3e, d.b3, rec3, N, s, persistent_blocks(N));
     }
     if (keep_f32) {
       note_launch("unsplit_s3");
@@ -2833,11 +2854,11 @@ bool lstm_trunk_launch(const FFNetDev& d, int N, const uint8_t* s_dev, float* a1
     uint8_t *r2 = reinterpret_cast<uint8_t*>(a2), *r3 = reinterpret_cast<uint8_t*>(a3);
     {
       ProfScope prof(names[1], s);
-      note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(std::min(kNumCU, N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
+      note_launch("conv12_i8"); hipLaunchKernelGGL(conv12_i8, dim3(persistent_blocks(N)), dim3(kThreads), Conv12I::LDS_TOTAL, s, s_dev,
                          (const uint4*)d.W1d, (const float*)d.s1q, (const float*)d.b1q, (const uint4*)d.B2f, (const float*)d.b2, r2, N);
     }
     ProfScope prof(names[2], s);
-    note_launch("conv_bf16s<Conv3F>"); hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(std::min(kNumCU, ceil_div(N, Conv3F::S))), dim3(kThreads),
+    note_launch("conv_bf16s<Conv3F>"); hipLaunchKernelGGL(conv_bf16s<Conv3F>, dim3(persistent_blocks(ceil_div(N, Conv3F::S))), dim3(kThreads),
                        Conv3F::LDS_TOTAL, s, (const uint8_t*)r2, (const uint4*)d.B3f, (const float*)d.b3, r3, N);
     if (records) return true;
     note_launch("unsplit_records64"); hipLaunchKernelGGL(unsplit_records64, dim3(ceil_div((int64_t)N * 49, 4)), dim3(256), 0, s, r3, (int64_t)N * 49);

@@ -1746,6 +1746,9 @@ class Context {
 
 PYBIND11_MODULE(rela, m) {
   m.doc() = "MI355X-native drop-in for facebookresearch/rela's `rela` module (C ABI: include/rela_amd.h)";
+  // the module's users run an independent sampler / learner thread next to the actor cohorts: keep a few CUs out of the
+  // persistent forward kernels' grids (include/rela_amd.h: rela_runtime_set_cu_reserve; RELA_CU_RESERVE overrides)
+  (void)rela_runtime_set_cu_reserve(8);
 
   m.def("threaded_stats", [](bool reset) { return gStats.snapshot(reset); }, py::arg("reset") = false,
         "RELA_THREADED_STATS=1: where the actor threads' wall time went since the last reset (diagnostic)");
