@@ -2414,12 +2414,12 @@ int rela_amd::ffnet_forward_mode(const rela_ffnet* n, int N, const uint8_t* s_de
     {
       ProfScope prof(names[3], s);
       note_launch("gemm_s3<fc>");
-      const int slices = s3::splitk_slices<s3::ProbFc>(N);
-      if (slices > 1) {  // small batches: the contraction split over blocks, fc_reduce adds slices + bias + ReLU
+      const s3::Plan pl = s3::plan<s3::ProbFc>(N, N < kFcSplitBelow && (int64_t)8 * N <= 8192);  // (the partial tiles' space)
+      if (pl.slices > 1) {  // small batches: the contraction split over blocks, fc_reduce adds slices + bias + ReLU
         float* part = ha + kHA * N;
         part += (64 - ((part - static_cast<float*>(ws)) & 63)) & 63;
-        s3::launch<s3::ProbFc, s3::kEpiRaw>(rec3, d.Bfe, d.bf, part, N, s, slices);
-        note_launch("fc_reduce"); hipLaunchKernelGGL(fc_reduce, dim3(ceil_div(N * 128, 256)), dim3(256), 0, s, (const float*)part, slices, N,
+        s3::launch<s3::ProbFc, s3::kEpiRaw>(rec3, d.Bfe, d.bf, part, N, s, pl);
+        note_launch("fc_reduce"); hipLaunchKernelGGL(fc_reduce, dim3(ceil_div(N * 128, 256)), dim3(256), 0, s, (const float*)part, pl.slices, N,
                            (const float*)d.bf, h);
       } else {
         s3::launch<s3::ProbFc, s3::kEpiRelu>(rec3, d.Bfe, d.bf, h, N, s);

@@ -138,6 +138,11 @@ typedef const __attribute__((address_space(1))) uint8_t* gbl_ptr_t;
 __device__ __forceinline__ void glds16(const uint8_t* g, uint8_t* l) {
   __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
 }
+// probe builds only (tools/ubench/s3_probe.hip): S3_GEMM_ABLATE 1 = no activation loads in the loop, 2 = no weight loads
+// (the counted waits then return at once: timing only, the results are garbage)
+#ifndef S3_GEMM_ABLATE
+#define S3_GEMM_ABLATE 0
+#endif
 template <int OFF>
 __device__ __forceinline__ u32x4 lds_read128(uint32_t addr) {
   u32x4 r;
@@ -172,6 +177,7 @@ template <class P>
 __device__ __forceinline__ void issue_weights(const uint8_t* wsrc, uint8_t* lds, uint32_t bring, int k, uint32_t slot, uint32_t lane) {
   const uint8_t* src = wsrc + (size_t)k * (kStageU4 * 16) + lane * 16;
   uint8_t* dst = lds + bring + slot * kBSlot;
+  if constexpr (S3_GEMM_ABLATE == 2) return;
 #pragma unroll
   for (int q = 0; q < CT * 3; ++q) glds16(src + q * 1024, dst + q * 1024);
 }
@@ -202,9 +208,11 @@ __device__ __forceinline__ void k_pass(const uint8_t* __restrict__ Xb, const uin
       if (nextp) k2 = kp0;
       const uint8_t* src = Xb + P::pair_off(k2);
       const uint32_t dst = ((pp.g + 1) & 1) * kABuf;
+      if constexpr (S3_GEMM_ABLATE != 1) {
 #pragma unroll
-      for (int j = 0; j < J; ++j)
-        glds16(src + (nextp ? offn[j] : offc[j]), lds + (ldst[j] >= (uint32_t)kLdsSpare ? ldst[j] : dst + ldst[j]));
+        for (int j = 0; j < J; ++j)
+          glds16(src + (nextp ? offn[j] : offc[j]), lds + (ldst[j] >= (uint32_t)kLdsSpare ? ldst[j] : dst + ldst[j]));
+      }
     }
     static_for<2>([&](auto hh) {
       constexpr int H = decltype(hh)::value;
@@ -223,13 +231,19 @@ __device__ __forceinline__ void k_pass(const uint8_t* __restrict__ Xb, const uin
         wq[JJ][2] = lds_read128<JJ * 3072 + 2048>(wa);
       });
       const uint32_t xa = lds0 + abuf + frag_base + H * 512;
-      u32x4 x[2][3];
-      x[0][0] = lds_read128<0>(xa);
-      x[0][1] = lds_read128<2048>(xa);
-      x[0][2] = lds_read128<4096>(xa);
+      // activation fragments: a ring of three tiles -- tile T + 2 is read while tile T issues its 12 MFMAs (192 cycles;
+      // one tile ahead left the LDS round trip under load exposed)
+      u32x4 x[3][3];
+      static_for<(NT < 2 ? NT : 2)>([&](auto tt) {
+        constexpr int T = decltype(tt)::value;
+        x[T][0] = lds_read128<T * 6144>(xa);
+        x[T][1] = lds_read128<T * 6144 + 2048>(xa);
+        x[T][2] = lds_read128<T * 6144 + 4096>(xa);
+      });
+      constexpr int AHEAD = (NT < 2 ? NT : 2) * 3;  // activation reads issued behind the weights' so far
       static_for<CT>([&](auto jj) {
         constexpr int JJ = decltype(jj)::value;
-        wait_lgkm<3 + 3 * (CT - 1 - JJ)>(wq[JJ][0], wq[JJ][1], wq[JJ][2]);
+        wait_lgkm<AHEAD + 3 * (CT - 1 - JJ)>(wq[JJ][0], wq[JJ][1], wq[JJ][2]);
       });
       bf16x8 wf[CT][3];
 #pragma unroll
@@ -238,15 +252,16 @@ __device__ __forceinline__ void k_pass(const uint8_t* __restrict__ Xb, const uin
         for (int q = 0; q < 3; ++q) wf[j][q] = __builtin_bit_cast(bf16x8, wq[j][q]);
       static_for<NT>([&](auto tt) {
         constexpr int T = decltype(tt)::value;
-        constexpr int C = T & 1;
-        if constexpr (T + 1 < NT) {
-          x[C ^ 1][0] = lds_read128<(T + 1) * 6144>(xa);
-          x[C ^ 1][1] = lds_read128<(T + 1) * 6144 + 2048>(xa);
-          x[C ^ 1][2] = lds_read128<(T + 1) * 6144 + 4096>(xa);
-          wait_lgkm<3>(x[C][0], x[C][1], x[C][2]);
-        } else {
-          wait_lgkm<0>(x[C][0], x[C][1], x[C][2]);
+        constexpr int C = T % 3;
+        if constexpr (T + 2 < NT) {
+          constexpr int N2 = (T + 2) % 3;
+          x[N2][0] = lds_read128<(T + 2) * 6144>(xa);
+          x[N2][1] = lds_read128<(T + 2) * 6144 + 2048>(xa);
+          x[N2][2] = lds_read128<(T + 2) * 6144 + 4096>(xa);
         }
+        // younger reads still allowed in flight: those of the tiles after T that were issued
+        constexpr int YOUNGER = 3 * ((T + 2 < NT ? T + 2 : NT - 1) - T);
+        wait_lgkm<YOUNGER>(x[C][0], x[C][1], x[C][2]);
         const bf16x8 x0 = __builtin_bit_cast(bf16x8, x[C][0]), x1 = __builtin_bit_cast(bf16x8, x[C][1]),
                      x2 = __builtin_bit_cast(bf16x8, x[C][2]);
         // the five small products have an accumulator of their own (added once per pass): the main one takes ONE
@@ -405,22 +420,38 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
 }
 
 // rows M = samples (fc).  Byte offsets are 32-bit: the caller keeps M * record bytes below 2^32.
-// slices > 1 (EPI = kEpiRaw only): the contraction split over gridDim.y, out = f32 [slices][M][OC] raw sums
-template <class P, int EPI>
-inline void launch(const void* X, const uint4* Wp, const float* bias, void* out, int M, hipStream_t s, int slices = 1) {
+// How a launch covers M rows: `nrb` row blocks (a multiple of 8: the XCD map) x NCG column groups x `slices` of the
+// contraction.  Large M: one slice, as many row blocks as the chip has CUs for.  Small M (the learner's 512 rows, a
+// cohort's first batches): every row block streams ALL weights of its columns, so few row blocks of ~4 tiles each and the
+// contraction split over up to 8 slices instead (512 rows x 512 columns: 8 x 4 x 8 = 256 blocks, 77 MB of weights
+// through L2 where 32 x 4 x 2 took 307 MB); fc_reduce adds the slices.
+struct Plan {
+  int nrb, slices;
+};
+template <class P>
+inline Plan plan(int M, bool may_split) {
   constexpr int NCG = P::OC / (64 * CT);
   const int rt_total = (M + 15) / 16;
-  int nrb = std::min(kMaxBlocks / 2 / NCG, rt_total);
-  nrb = (nrb + 7) / 8 * 8;
-  hipLaunchKernelGGL((gemm_s3<P, EPI>), dim3(nrb * NCG, EPI == kEpiRaw ? slices : 1), dim3(kT), 0, s,
+  const int full = kMaxBlocks / 2;  // one block per CU
+  Plan pl;
+  pl.nrb = (std::min(full / NCG, rt_total) + 7) / 8 * 8;
+  pl.slices = 1;
+  if (may_split && pl.nrb * NCG * 4 <= full * 3) {  // fewer than 3/4 of the CUs would get a block
+    pl.nrb = ((rt_total + 3) / 4 + 7) / 8 * 8;
+    pl.slices = std::max(1, std::min(8, full / (pl.nrb * NCG)));
+  }
+  return pl;
+}
+// slices > 1 (EPI = kEpiRaw only): out = f32 [slices][M][OC] raw sums
+template <class P, int EPI>
+inline void launch(const void* X, const uint4* Wp, const float* bias, void* out, int M, hipStream_t s, Plan pl) {
+  constexpr int NCG = P::OC / (64 * CT);
+  hipLaunchKernelGGL((gemm_s3<P, EPI>), dim3(pl.nrb * NCG, EPI == kEpiRaw ? pl.slices : 1), dim3(kT), 0, s,
                      reinterpret_cast<const uint8_t*>(X), Wp, bias, out, M);
 }
-// how many slices fill the chip for M rows of P (1 = no split)
-template <class P>
-inline int splitk_slices(int M) {
-  constexpr int NCG = P::OC / (64 * CT);
-  const int blocks = std::min((kMaxBlocks / 2 / NCG + 7) / 8 * 8, ((M + 15) / 16 + 7) / 8 * 8) * NCG;
-  return std::max(1, std::min(8, (kMaxBlocks / 2) / std::max(blocks, 1)));
+template <class P, int EPI>
+inline void launch(const void* X, const uint4* Wp, const float* bias, void* out, int M, hipStream_t s) {
+  launch<P, EPI>(X, Wp, bias, out, M, s, plan<P>(M, false));
 }
 
 // f32 channel-last [pixels][C] <-> split3 records (one thread per four channels)
