@@ -186,11 +186,18 @@ __global__ __launch_bounds__(256, 1) void conv12_s3(const uint8_t* __restrict__ 
       const int rt = min(rg1 + 2 * (T0 + t), 24);
       const int m = rt * 16 + li;
       const int y = m / 20, xx = m - y * 20;
-      const i32x4 ml = s_mid[t] * 256 + s_lo[t];  // exact: |S_mid * 256 + S_lo| < 2^31
-      const f32x4 u = __builtin_convertvector(s_hi[t], f32x4) * 65536.0f + __builtin_convertvector(ml, f32x4);
-      f32x4 v = u * sc1 + bv1;
+      // the exact integer sum S_hi * 2^16 + S_mid * 2^8 + S_lo enters f32 in two halves (|S_mid * 256 + S_lo| < 2^31; the
+      // product with 65536 is exact, so the fused form rounds once where mul + add rounded once too), then ONE rounding
+      // for scale and bias (fused: the file is compiled -ffp-contract=off, so the fusion is spelled out)
+      const i32x4 ml = s_mid[t] * 256 + s_lo[t];
+      const f32x4 hf = __builtin_convertvector(s_hi[t], f32x4), lf = __builtin_convertvector(ml, f32x4);
+      f32x4 v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      for (int r = 0; r < 4; ++r) {
+        const float u = __builtin_fmaf(hf[r], 65536.0f, lf[r]);
+        const float y = __builtin_fmaf(u, sc1[r], bv1[r]);
+        v[r] = y > 0.f ? y : 0.f;
+      }
       uint2 p0, p1, p2;
       split3_4(v, p0, p1, p2);
       uint8_t* rec = t2 + (size_t)(y * F::RQ + xx * F::Q) * 16 + ch1 * 2;

@@ -2869,24 +2869,14 @@ bool lstm_trunk_launch(const FFNetDev& d, int N, const uint8_t* s_dev, float* a1
     note_launch("conv1_bf16x3"); hipLaunchKernelGGL(conv1_bf16x3, dim3(ceil_div(N, Conv1B::S)), dim3(kThreads), Conv1B::LDS_BYTES, s, s_dev, d.B1,
                        d.b1, a1, N);
   }
-  const bool emu_conv = emu && N >= kEmuConvMinN && N <= kEmuMaxN;  // f32x3: as in ffnet_forward_mode
+  // (f32x3 without record scratch, or below its batch threshold: the exact f32 kernels -- same accuracy)
   {
     ProfScope prof(names[1], s);
-    if (emu_conv) {
-      note_launch("gemm_f32emu<conv2>");
-      f32emu::launch<f32emu::ProbConv2, 6, 1>(a1, d.B2e, d.b2, a2, N * 81, s);
-    } else {
-      launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
-    }
+    launch_conv<Conv2>(a1, d.B2, d.b2, a2, N, s);
   }
   {
     ProfScope prof(names[2], s);
-    if (emu_conv) {
-      note_launch("gemm_f32emu<conv3>");
-      f32emu::launch<f32emu::ProbConv3, 6, 1>(a2, d.B3e, d.b3, a3, N * 49, s);
-    } else {
-      launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
-    }
+    launch_conv<Conv3>(a2, d.B3, d.b3, a3, N, s);
   }
   return false;
 }

@@ -1,5 +1,11 @@
 // gemm_f32emu.h -- f32 contractions carried out on the bf16 matrix cores WITHOUT giving up f32 accuracy.
 //
+// r5: the ARITHMETIC defined here (three exact bf16 parts per operand, six products, small terms in their own
+// accumulator) and the weight packing (pack_f32emu_at) are what the library runs; the KERNEL of this file (activations
+// as f32, split in every consumer's k-loop) is no longer launched by it -- csrc/gemm_s3.h, conv12_s3.h and
+// conv_img_s3.h work on activations split once by their producer.  The kernel stays for tools/ubench/f32emu_probe.hip,
+// the A/B that showed what bounded it.
+//
 //   out[m][n] = relu(bias[n] + sum_k X(m, k) * W[k][n])        X, W, bias, out: f32
 //
 // v_mfma_f32_16x16x4_f32 peaks at 157 TFLOP/s on gfx950, v_mfma_f32_16x16x32_bf16 at 2.5 PFLOP/s (16 x).  An f32 number

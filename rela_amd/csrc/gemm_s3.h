@@ -16,13 +16,13 @@
 // A lane's MFMA fragment of part p for k-group g is the 16 bytes at record + p * 2C + (k-step's channel half) * 64 + 16 g:
 // no conversion, no VALU instruction between the load and the matrix core.
 //
-// Kernel: the tiling of gemm_f32emu.h (a wave owns 64 pixels x 64 channels; weights split at load time, fragment order,
-// double-buffered LDS stage shared by the four waves; activations straight from global memory into the registers the
-// MFMAs read, two k-steps ahead; balanced passes of 4 / 3 row tiles), minus the split and minus the separate
-// small-term accumulators (the five small products of a k-step go into the main accumulator BEFORE its x0 w0 product:
-// six roundings per 32 k at the magnitude of the running sum where an f32 FMA chain takes 32).
-// OUT_S3: the epilogue writes split3 records (ReLU, split, three 8-byte stores per lane and column tile) for the next
-// layer; otherwise channel-last f32.
+// This file: the record format, split / unsplit, the address maps of the contractions over records, and the GEMM
+// kernel (fc 3136 -> 512, the recurrent net's input projection 3136 -> 2048).  The convolutions over records are
+// conv12_s3.h (conv1 -> conv2 fused per frame) and conv_img_s3.h (conv3 from LDS images).
+// History (r5, measured): the first form kept gemm_f32emu.h's loop (fragments straight from global
+// memory into registers) minus the split -- slower in proportion to its 6 instead of 4 bytes per value; the second moved
+// the fragments through LDS-DMA in 64-column blocks -- no faster (L2 delivery); the third is below.  Merging the five
+// small products into the main accumulator was tried in the first form: 7.7e-8 mean error per layer against 2.3e-8.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -143,6 +143,10 @@ __device__ __forceinline__ void glds16(const uint8_t* g, uint8_t* l) {
 #ifndef S3_GEMM_ABLATE
 #define S3_GEMM_ABLATE 0
 #endif
+#ifndef S3_GEMM_AHEAD
+#define S3_GEMM_AHEAD 1  // activation fragments read this many tiles ahead of the MFMAs (1: 125-132 us, 2: 150-160 us for fc
+#endif                   // at 6,400 rows on the boxes of r5 -- the deeper ring costs more in registers than the LDS round trip)
+constexpr int kAheadTiles = S3_GEMM_AHEAD;
 template <int OFF>
 __device__ __forceinline__ u32x4 lds_read128(uint32_t addr) {
   u32x4 r;
@@ -231,16 +235,16 @@ __device__ __forceinline__ void k_pass(const uint8_t* __restrict__ Xb, const uin
         wq[JJ][2] = lds_read128<JJ * 3072 + 2048>(wa);
       });
       const uint32_t xa = lds0 + abuf + frag_base + H * 512;
-      // activation fragments: a ring of three tiles -- tile T + 2 is read while tile T issues its 12 MFMAs (192 cycles;
-      // one tile ahead left the LDS round trip under load exposed)
-      u32x4 x[3][3];
-      static_for<(NT < 2 ? NT : 2)>([&](auto tt) {
+      // activation fragments: a ring of kAheadTiles + 1 tiles -- tile T + kAheadTiles is read while tile T issues its MFMAs
+      constexpr int RING = kAheadTiles + 1, PRE = NT < kAheadTiles ? NT : kAheadTiles;
+      u32x4 x[RING][3];
+      static_for<PRE>([&](auto tt) {
         constexpr int T = decltype(tt)::value;
         x[T][0] = lds_read128<T * 6144>(xa);
         x[T][1] = lds_read128<T * 6144 + 2048>(xa);
         x[T][2] = lds_read128<T * 6144 + 4096>(xa);
       });
-      constexpr int AHEAD = (NT < 2 ? NT : 2) * 3;  // activation reads issued behind the weights' so far
+      constexpr int AHEAD = PRE * 3;  // activation reads issued behind the weights' so far
       static_for<CT>([&](auto jj) {
         constexpr int JJ = decltype(jj)::value;
         wait_lgkm<AHEAD + 3 * (CT - 1 - JJ)>(wq[JJ][0], wq[JJ][1], wq[JJ][2]);
@@ -252,15 +256,15 @@ __device__ __forceinline__ void k_pass(const uint8_t* __restrict__ Xb, const uin
         for (int q = 0; q < 3; ++q) wf[j][q] = __builtin_bit_cast(bf16x8, wq[j][q]);
       static_for<NT>([&](auto tt) {
         constexpr int T = decltype(tt)::value;
-        constexpr int C = T % 3;
-        if constexpr (T + 2 < NT) {
-          constexpr int N2 = (T + 2) % 3;
-          x[N2][0] = lds_read128<(T + 2) * 6144>(xa);
-          x[N2][1] = lds_read128<(T + 2) * 6144 + 2048>(xa);
-          x[N2][2] = lds_read128<(T + 2) * 6144 + 4096>(xa);
+        constexpr int C = T % RING;
+        if constexpr (T + kAheadTiles < NT) {
+          constexpr int N2 = (T + kAheadTiles) % RING;
+          x[N2][0] = lds_read128<(T + kAheadTiles) * 6144>(xa);
+          x[N2][1] = lds_read128<(T + kAheadTiles) * 6144 + 2048>(xa);
+          x[N2][2] = lds_read128<(T + kAheadTiles) * 6144 + 4096>(xa);
         }
         // younger reads still allowed in flight: those of the tiles after T that were issued
-        constexpr int YOUNGER = 3 * ((T + 2 < NT ? T + 2 : NT - 1) - T);
+        constexpr int YOUNGER = 3 * ((T + kAheadTiles < NT ? T + kAheadTiles : NT - 1) - T);
         wait_lgkm<YOUNGER>(x[C][0], x[C][1], x[C][2]);
         const bf16x8 x0 = __builtin_bit_cast(bf16x8, x[C][0]), x1 = __builtin_bit_cast(bf16x8, x[C][1]),
                      x2 = __builtin_bit_cast(bf16x8, x[C][2]);

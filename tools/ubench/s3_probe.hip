@@ -196,6 +196,24 @@ static void run(const HostProb& hp, int N, int iters) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = 1e3 * ms / iters;
     const double flop = 2.0 * M * hp.K * hp.OC;
+    if constexpr (PS::OC % 128 == 0) {  // the split-K form of the same launch (raw sums, no reduce): timing only
+      if (outs3 == 0) {
+        const s3::Plan pl = s3::plan<PS>(M, true);
+        if (pl.slices > 1) {
+          float* part;
+          CK(hipMalloc(&part, (size_t)pl.slices * oe * 4));
+          for (int i = 0; i < 3; ++i) s3::launch<PS, s3::kEpiRaw>(dR, dP, dB, part, M, 0, pl);
+          CK(hipEventRecord(e0, 0));
+          for (int i = 0; i < iters; ++i) s3::launch<PS, s3::kEpiRaw>(dR, dP, dB, part, M, 0, pl);
+          CK(hipEventRecord(e1, 0));
+          CK(hipEventSynchronize(e1));
+          float ms2 = 0;
+          CK(hipEventElapsedTime(&ms2, e0, e1));
+          printf("{\"layer\": \"%s\", \"N\": %d, \"splitk\": [%d, %d], \"us\": %.1f}\n", hp.name, N, pl.nrb, pl.slices, 1e3 * ms2 / iters);
+          CK(hipFree(part));
+        }
+      }
+    }
     printf("{\"layer\": \"%s\", \"N\": %d, \"out_s3\": %d, \"us\": %.1f, \"f32_equiv_tflops\": %.1f, "
            "\"bf16_mfma_tflops\": %.1f, \"max_err_vs_f64\": %.3e, \"mean_err_vs_f64\": %.3e, "
            "\"f32_fma_chain_max_err\": %.3e, \"f32_fma_chain_mean_err\": %.3e, \"mean_abs_preact\": %.3e, "
