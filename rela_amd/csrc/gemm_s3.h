@@ -123,7 +123,7 @@ __device__ __forceinline__ void split3_4(const f32x4& v, uint2& p0, uint2& p1, u
 //   * LDS reads are inline asm (the compiler would drain vmcnt before any LDS read it can see while an LDS-DMA is
 //     pending) with counted lgkmcnt: a tile's three fragments are read while the tile before issues its 12 MFMAs.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int TMV = 8;                       // row tiles per pass
+constexpr int TMV = 7;                       // row tiles per pass (7 x 32 accumulator registers per wave: 8 spilled)
 constexpr int CT = 2;                        // column tiles per wave (32 columns; 128 per block)
 constexpr int kABuf = TMV * 6144;            // one pair of k-steps: [tile][part][rows 0-7 | 8-15] x 1 KB
 constexpr int kBSlot = CT * 3072;            // one k-step of one wave's weights: [column tile][part] x 1 KB
@@ -193,7 +193,7 @@ __device__ __forceinline__ void issue_weights(const uint8_t* wsrc, uint8_t* lds,
 template <class P, int NT, int J>
 __device__ __forceinline__ void k_pass(const uint8_t* __restrict__ Xb, const uint8_t* __restrict__ wsrc, uint8_t* lds, uint32_t lds0,
                                        const uint32_t (&offc)[J], const uint32_t (&offn)[J], const uint32_t (&ldst)[J],
-                                       uint32_t frag_base, uint32_t wave, f32x4 (&acc)[TMV][CT], f32x4 (&accs)[TMV][CT], Pipe& pp,
+                                       uint32_t frag_base, uint32_t wave, f32x4 (&acc)[NT][CT], f32x4 (&accs)[NT][CT], Pipe& pp,
                                        int kp0, int kp1) {
   constexpr int WL = 3 * CT;
   const uint32_t lane = threadIdx.x & 63;
@@ -336,7 +336,6 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
       bv[j] = *reinterpret_cast<const f32x4*>(bias + col0 + 16 * j);
     asm volatile("" : "+v"(bv[j]));  // (returned before the first LDS-DMA is issued: see conv_img_s3.h)
   }
-  f32x4 acc[TMV][CT], accs[TMV][CT];
   Pipe pp{0u, 0u};
 
   auto run = [&](auto ntm) {
@@ -369,22 +368,23 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
       for (int j = 0; j < J; ++j) glds16(src + offc[j], lds + ldst[j]);
       issue_weights<P>(wsrc, lds, kLdsB + wave * 2 * kBSlot, 2 * kp0, 0, lane);
     }
-    for (int p = 0; p < passes; ++p) {
-      const int nt = size_of(p);
+    // one pass of NT tiles: accumulators (NT x 2 column tiles x {main, small terms} x 4 registers -- sized by NT, not by
+    // TMV: with all eight tiles' registers live the kernel spilled 1.4 KB per lane and wrote 100 MB of scratch per launch),
+    // the k-loop, the epilogue
+    auto one_pass = [&](auto ntag, int p) {
+      constexpr int NT = decltype(ntag)::value;
+      f32x4 acc[NT][CT], accs[NT][CT];
 #pragma unroll
-      for (int t = 0; t < TMV; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[t][j] = bv[j], accs[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (nt == NTM)
-        k_pass<P, NTM, J>(Xb, wsrc, lds, lds0, offc, offn, ldst, frag_base, wave, acc, accs, pp, kp0, kp1);
-      else if constexpr (NTM > 1)
-        k_pass<P, NTM - 1, J>(Xb, wsrc, lds, lds0, offc, offn, ldst, frag_base, wave, acc, accs, pp, kp0, kp1);
-      // ---- epilogue: ReLU, this lane's four channels (per column tile) of pixel li of every tile
+      k_pass<P, NT, J>(Xb, wsrc, lds, lds0, offc, offn, ldst, frag_base, wave, acc, accs, pp, kp0, kp1);
+      // ---- epilogue: this lane's four channels (per column tile) of pixel li of every tile
       const int t0 = r0 + first_of(p);
 #pragma unroll
-      for (int t = 0; t < TMV; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int row = (t0 + t) * 16 + li;
-        if (t < nt && row < M) {
+        if (row < M) {
 #pragma unroll
           for (int j = 0; j < CT; ++j) {
             f32x4 v = acc[t][j] + accs[t][j];
@@ -405,6 +405,12 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
           }
         }
       }
+    };
+    for (int p = 0; p < passes; ++p) {
+      if (size_of(p) == NTM)
+        one_pass(IC<NTM>{}, p);
+      else if constexpr (NTM > 1)
+        one_pass(IC<NTM - 1>{}, p);
 #pragma unroll
       for (int j = 0; j < J; ++j) offc[j] = offn[j];
       set_off(offn, min(p + 2, passes - 1));
@@ -417,8 +423,7 @@ __global__ __launch_bounds__(kT, 1) void gemm_s3(const uint8_t* __restrict__ Xb,
     case 4: run(IC<4>{}); break;
     case 5: run(IC<5>{}); break;
     case 6: run(IC<6>{}); break;
-    case 7: run(IC<7>{}); break;
-    default: run(IC<8>{}); break;
+    default: run(IC<7>{}); break;
   }
   wait_vm<0>();  // no LDS-DMA may outlive the workgroup's LDS allocation
 }
