@@ -732,19 +732,27 @@ def bench_r2d2(args, world, rank, device):
         # split-bf16 GEMM (three bf16 MFMAs per product) followed by the f32 kernel over h only: the roofline is the x part's
         prof = region["prof"]
         split_gates = "lstm_gates_x_bf16" in prof
-        roof_name = "lstm_gates_x_bf16" if split_gates else "lstm_gates_mfma"
+        x3_gates = "lstm_gates_x_f32x3" in prof  # r5, f32x3: the x part as a three-part GEMM over a3's records (six products)
+        roof_name = "lstm_gates_x_bf16" if split_gates else ("lstm_gates_x_f32x3" if x3_gates else "lstm_gates_mfma")
         rec = prof.get(roof_name, {"total_ms": 0.0, "count": 1})
         avg_ms = rec["total_ms"] / max(rec["count"], 1)
-        flops = (2 * 3136 * 2048 if split_gates else FLOP_LSTM_GATES) * R2_ROWS
-        peak = PEAK_BF16_MFMA_TFLOPS if split_gates else PEAK_F32_MFMA_TFLOPS
+        flops = (2 * 3136 * 2048 if (split_gates or x3_gates) else FLOP_LSTM_GATES) * R2_ROWS
+        products = 3 if split_gates else (6 if x3_gates else 0)
+        peak = PEAK_BF16_MFMA_TFLOPS / (6 if x3_gates else 1) if products else PEAK_F32_MFMA_TFLOPS
         ach = flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else None
         traffic, src = traffic_from_profiles(roof_name)
         roof = {"kernel": roof_name, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": None if ach is None else ach / peak, "traffic": traffic, "traffic_source": src,
                 "avg_launch_ms": avg_ms, "launches": rec["count"], "algorithmic_flop_per_launch": flops,
-                "instruction": "v_mfma_f32_16x16x32_bf16 x3 (split operands)" if split_gates else "v_mfma_f32_16x16x4_f32"}
+                "instruction": ("v_mfma_f32_16x16x32_bf16 x3 (split operands)" if split_gates else
+                                "v_mfma_f32_16x16x32_bf16, six products per f32 product (three exact bf16 parts per operand): "
+                                "peak = 2,500 / 6 TFLOP/s" if x3_gates else "v_mfma_f32_16x16x4_f32")}
         if split_gates and ach is not None:
             roof["frac_issued"] = 3 * ach / peak  # three bf16 products issued per algorithmic product
+        if x3_gates and ach is not None:  # the three readings of the same launch, side by side
+            roof["frac_issued"] = ach / peak
+            roof["frac_algorithmic_bf16"] = ach / PEAK_BF16_MFMA_TFLOPS
+            roof["frac_of_f32_mfma_peak"] = ach / PEAK_F32_MFMA_TFLOPS
         roof.update(region["clock"])
         return roof
 
@@ -755,8 +763,8 @@ def bench_r2d2(args, world, rank, device):
         sample_bytes = 4 * st["safe_size"] + B_LOCAL * sum(replay.row_bytes)
         learner_ms = sum(v["total_ms"] for k, v in prof_all.items() if k.startswith("learner_")) / k_all
         ms_med = head["ms_per_step"]
-        dtype = {"f32": "f32", "f32x3": "f32 (conv2 / conv3 of every trunk forward with f32 operands as three exact bf16 parts on "
-                 "the bf16 MFMA, csrc/gemm_f32emu.h: f32 accuracy; gate GEMMs, recurrences, heads, backward in exact f32)"}.get(
+        dtype = {"f32": "f32", "f32x3": "f32 (every trunk forward and the input half of every forward gate GEMM with f32 operands as "
+                 "three exact bf16 parts on the bf16 MFMA, csrc/gemm_s3.h: f32 accuracy; recurrences, heads, backward in exact f32)"}.get(
             args.precision,
             "f32 results from split-bf16 MFMA (bf16 hi+lo operands, f32 accumulate): the actors' conv trunks and gate GEMM "
             "(h, c, Q within 4e-6), the learner's trunks, LSTM GEMMs and conv gradients; recurrences, cells, heads in f32")

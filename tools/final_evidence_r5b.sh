@@ -14,7 +14,7 @@ pmc() {  # tag, env..., -- script
 SCRIPT=tools/profile_forward.py pmc f32x3 PRECISION=f32x3 ITERS=8
 SCRIPT=tools/profile_forward.py pmc f32 PRECISION=f32 ITERS=8
 SCRIPT=tools/profile_forward.py pmc fast PRECISION=bf16x2 ITERS=8
-SCRIPT=tools/time_r2d2_tick.py pmc r2d2 ROWS=3200 TICKS=12
+SCRIPT=tools/time_r2d2_tick.py pmc r2d2 ROWS=3200 TICKS=12 PRECISION=f32x3
 for tag in f32x3 f32 fast r2d2; do python tools/pmc_table.py $O/pmc_$tag $O/traffic_$tag.json > $O/pmc_table_$tag.md 2>&1; echo "table $tag rc=$?"; cat $O/pmc_table_$tag.md | cut -c1-200; done
 find $O -name "*kernel_trace.csv" -size +3M -delete; find $O -name "*.db" -delete 2>/dev/null
 RELA_PRECISION=f32x3 RELA_THREADED_STATS=1 python rela_amd/pyrela/benchmark.py --grid 64x100 --epoch_sec 30 --num_epoch 6 --replay_buffer_size 4194304 --burn_in_frames 20000 --env sliding > $O/threaded_protocol_sliding_f32x3.log 2>&1; echo "threaded protocol rc=$?"

@@ -45,6 +45,9 @@ def make_net(seed):
 
 
 online, target = make_net(1), make_net(2)
+PRECISION = os.environ.get("PRECISION", "f32")  # f32 | bf16x2 | f32x3 (rela_lstmnet_set_precision)
+for h_ in (online, target):
+    capi.check(capi.lib.rela_lstmnet_set_precision(h_, {"f32": 0, "bf16x2": 1, "f32x3": 2}[PRECISION]), "set_precision")
 replay = C.c_void_p()
 capi.check(capi.lib.rela_replay_create(C.byref(replay), CAP, 7, 0.9, 0.6, 0, 0), "rela_replay_create")
 rb = (C.c_int64 * 10)(T * 28224, T * 4, T * 4 * A, T * 8, T * 4, T, T * 4, 2048, 2048, 4)
