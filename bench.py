@@ -858,13 +858,15 @@ def bench_reference_layout(args, world, rank, device, rehearsal):
     _, total = ffnet_flat_layout(NUM_ACTION)
     K, R = args.steps, args.repeats
     cycle = 20  # actor_sync_freq, pyrela/main.py:213-215
-    # rows per partition.  Native exchange: the learner maps every partition's ring through HIP IPC, and on this pool's
-    # boxes hipIpcOpenMemHandle of ONE allocation of 74 GB (2^20 rows) did not return within 200 s where 37 GB (2^19) take
-    # under a second (r4 rehearsal) -- partitions are held to 2^19 rows there (only the 2-GPU case of the default
-    # 2^20 / G is affected)
+    # rows per partition.  Native exchange: the learner maps every partition's ring.  One hipIpcMemHandle_t per field stopped
+    # working above ~24 GB per field on this pool (r4: partitions were held to 2^19 rows); since r5 the actor ranks create
+    # their partition in 8 GB chunks, which travel as file descriptors at any size (include/rela_amd.h:
+    # rela_replay_export_chunks; tests/test_ipc_gpu.py maps a 2^20-row partition) -- no cap
     part_cap = args.replay_cap // G
-    if args.exchange == "native":
-        part_cap = min(part_cap, 1 << 19)
+    if args.exchange == "native" and rank != 0:
+        from rela_amd import _capi as capi
+
+        capi.check(capi.lib.rela_runtime_set_replay_chunk_bytes(8 << 30), "rela_runtime_set_replay_chunk_bytes")
     torch.manual_seed(SEED + 2)
     agent = ApexAgent(lambda: AtariFFNet(NUM_ACTION), MULTI_STEP, GAMMA).to(device)
     for p_ in agent.parameters():

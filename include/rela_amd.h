@@ -639,6 +639,39 @@ void rela_replay_remote_close(rela_replay_remote* rr);
  * partitions (out_batch = 0: the outputs hold exactly this batch). */
 int rela_replay_remote_gather(rela_replay_remote* rr, int batch, void* const* out_rows_dev, float* raw_w_out,
                               float* sum_f_out, int out_batch, int out_offset, void* stream);
+/* Partitions of ANY size (r5).  One hipIpcMemHandle_t per field stops working at ~24 GB per field on this platform (the
+ * import of a 37 GB frame-stack field does not return; rela_replay_export_ipc refuses such a partition).  A partition
+ * created in CHUNKED mode allocates every field array as chunks of physical HBM of at most `bytes` behind one
+ * contiguous virtual range (HIP virtual memory management; rows stay base + slot * row_bytes, every kernel of the library
+ * is unchanged), and each chunk travels to the importing process as a POSIX file descriptor (a dmabuf):
+ *   owner:    rela_replay_set_chunk_bytes(part, 8 << 30) BEFORE rela_replay_set_schema*   (0 = off: one hipMalloc per field;
+ *             rela_runtime_set_replay_chunk_bytes sets the default of partitions created later, and RELA_REPLAY_CHUNK_GB
+ *             in the environment wins over it)
+ *             rela_replay_export_chunks(part, &desc, fds, RELA_IPC_MAX_FDS): desc.nfds descriptors, in field order;
+ *             send desc as bytes and the descriptors with SCM_RIGHTS over a Unix socket (rela_amd/parallel.py:
+ *             _FdServer), then close() them
+ *   learner:  rela_replay_import_chunks(&remote, &desc, fds, desc.nfds, device); close() the descriptors;
+ *             rela_replay_remote_gather / rela_replay_remote_close exactly as above
+ * The small fixed arrays (ids / weights / state of the last sample) still travel as IPC handles inside desc.ipc, and so do
+ * the fields of a partition that is NOT in chunked mode (field_chunks[f] = 0): rela_replay_export_chunks serves every
+ * partition; rela_replay_export_ipc refuses a chunked one.  A chunked partition has no field left on an IPC handle on
+ * purpose: after a 37 GB field had been mapped from its chunks, hipIpcOpenMemHandle of a 4 GB field of the same partition did
+ * not return (profiles/r05_vmm_mixed_import_hang.log).
+ * Measured on one MI355X, two processes: tests/test_native_exchange_gpu.py (a partition of 2 x 14.8 GB fields in 4 GB
+ * chunks, and RELA_TEST_BIG=1: 2 x 37 GB), profiles/r05_vmm_probe.jsonl.                                              */
+#define RELA_IPC_MAX_FDS 128
+typedef struct rela_replay_chunk_desc {
+  rela_replay_ipc_desc ipc; /* ipc.field_handle[f] is unused where field_chunks[f] > 0 */
+  int32_t abi, nfds;        /* abi = 2 */
+  int32_t field_chunks[RELA_IPC_MAX_FIELDS]; /* 0: the field is ipc.field_handle[f]; n: the next n descriptors */
+  int64_t chunk_bytes[RELA_IPC_MAX_FIELDS];  /* size of every chunk of the field but the last */
+  int64_t mapped_bytes[RELA_IPC_MAX_FIELDS]; /* the field's virtual range (>= ring * row_bytes, whole pages) */
+} rela_replay_chunk_desc;
+int rela_replay_set_chunk_bytes(rela_replay* r, int64_t bytes);
+int rela_runtime_set_replay_chunk_bytes(int64_t bytes);
+int rela_replay_export_chunks(rela_replay* r, rela_replay_chunk_desc* out, int* fds_out, int max_fds);
+int rela_replay_import_chunks(rela_replay_remote** out, const rela_replay_chunk_desc* desc, const int* fds, int nfds,
+                              int device);
 /* the same mapping for a device buffer this library allocated (e.g. rela_apex_learner_flat's parameter buffer): the
  * weight publish across processes -- actors load their nets straight from the learner's mapped buffer */
 int rela_ipc_export_buffer(const void* dev_ptr, unsigned char handle_out[64]);

@@ -32,6 +32,21 @@ class ReplayState(C.Structure):
                 ("dev_error", C.c_int32), ("pad", C.c_int32)]
 
 
+class ReplayIpcDesc(C.Structure):  # rela_replay_ipc_desc
+    _fields_ = [("abi", C.c_int32), ("nfields", C.c_int32), ("ring", C.c_int32), ("device", C.c_int32),
+                ("max_batch", C.c_int32), ("pad", C.c_int32), ("row_bytes", C.c_int64 * 16), ("steps", C.c_int32 * 16),
+                ("field_handle", (C.c_ubyte * 64) * 16), ("ids_handle", C.c_ubyte * 64), ("raw_w_handle", C.c_ubyte * 64),
+                ("state_handle", C.c_ubyte * 64)]
+
+
+class ReplayChunkDesc(C.Structure):  # rela_replay_chunk_desc
+    _fields_ = [("ipc", ReplayIpcDesc), ("abi", C.c_int32), ("nfds", C.c_int32), ("field_chunks", C.c_int32 * 16),
+                ("chunk_bytes", C.c_int64 * 16), ("mapped_bytes", C.c_int64 * 16)]
+
+
+IPC_MAX_FDS = 128
+
+
 class LSTMNetParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "conv3_w", "conv3_b", "w_ih",
                                           "w_hh", "b_ih", "b_hh", "v_w", "v_b", "a_w", "a_b")]
@@ -66,6 +81,10 @@ _sig("rela_memcpy_h2d_async", i32, [vp, vp, i64, vp, i32])
 _sig("rela_replay_set_decoupled_insert", i32, [vp, i32])
 _sig("rela_replay_export_ipc", i32, [vp, vp])
 _sig("rela_replay_import_ipc", i32, [P(vp), vp, i32])
+_sig("rela_replay_set_chunk_bytes", i32, [vp, i64])
+_sig("rela_runtime_set_replay_chunk_bytes", i32, [i64])
+_sig("rela_replay_export_chunks", i32, [vp, vp, P(i32), i32])
+_sig("rela_replay_import_chunks", i32, [P(vp), vp, P(i32), i32, i32])
 _sig("rela_replay_remote_close", None, [vp])
 _sig("rela_replay_remote_gather", i32, [vp, i32, vp, vp, vp, i32, i32, vp])
 _sig("rela_ipc_export_buffer", i32, [vp, vp])

@@ -29,6 +29,7 @@
 #include "prof.h"
 #include "seqsum_dev.h"
 #include "sleef_powf_core.h"
+#include "vmm_field.h"
 
 namespace rela_amd {
 
@@ -583,6 +584,10 @@ struct rela_replay {
   std::vector<int64_t> row_bytes;
   std::vector<int32_t> steps;  // sub-rows per slot (1 = plain field)
   std::vector<uint8_t*> d_fields;
+  // chunk_bytes > 0: every field array is chunks of physical memory of at most that size behind one virtual range
+  // (vmm_field.h), so that a partition of any size can be exported to another process; 0: one hipMalloc per field, vmm[f] null
+  int64_t chunk_bytes = 0;
+  std::vector<VmmRange*> vmm;
   SeqIndex ix;
   HostStage stage;  // pinned staging of the RNG draws / host-side priorities (guarded by m)
   // frame-stack de-duplication (rela_replay_set_schema_dedup): the two stack fields hold int32 references
@@ -594,6 +599,13 @@ struct rela_replay {
   int64_t dd_next_seq = 0;        // sequence number of the next unit
   std::vector<int64_t> dd_slot_min;  // [ring] smallest unit sequence a slot refers to (host; guarded by m)
 };
+
+static std::atomic<int64_t> g_default_chunk_bytes{0};
+extern "C" int rela_runtime_set_replay_chunk_bytes(int64_t bytes) {
+  RELA_CHECK(bytes >= 0, RELA_EINVAL, "rela_runtime_set_replay_chunk_bytes: %lld", (long long)bytes);
+  g_default_chunk_bytes.store(bytes);
+  return RELA_OK;
+}
 
 extern "C" const char* rela_last_error(void) { return g_err; }
 extern "C" int rela_abi_version(void) { return 1; }
@@ -616,6 +628,8 @@ extern "C" int rela_replay_create(rela_replay** out, int capacity, int seed, flo
   r->beta = beta;
   r->prefetch = prefetch;
   r->rng.seed(seed);  // :183
+  r->chunk_bytes = g_default_chunk_bytes.load();
+  if (const char* e = getenv("RELA_REPLAY_CHUNK_GB")) r->chunk_bytes = (int64_t)(atof(e) * (double)((int64_t)1 << 30));
   {  // replay operations are short and sit on the critical path of actors AND learner: highest priority
     int least = 0, greatest = 0;
     RELA_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -673,7 +687,14 @@ extern "C" void rela_replay_destroy(rela_replay* r) {
   (void)hipEventDestroy(r->ev_cin);
   (void)hipEventDestroy(r->ev_cout);
   (void)hipStreamDestroy(r->copy_stream_own);
-  for (auto* p : r->d_fields) (void)hipFree(p);
+  for (size_t f = 0; f < r->d_fields.size(); ++f) {
+    if (f < r->vmm.size() && r->vmm[f]) {
+      r->vmm[f]->destroy();
+      delete r->vmm[f];
+    } else {
+      (void)hipFree(r->d_fields[f]);
+    }
+  }
   seq_index_free(&r->ix);
   r->stage.destroy();
   (void)hipFree(r->d_units);
@@ -697,6 +718,14 @@ extern "C" void rela_replay_destroy(rela_replay* r) {
 extern "C" int rela_replay_set_schema_seq(rela_replay* r, int nfields, const int64_t* row_bytes,
                                           const int32_t* steps);
 
+extern "C" int rela_replay_set_chunk_bytes(rela_replay* r, int64_t bytes) {
+  RELA_CHECK(r && bytes >= 0, RELA_EINVAL, "rela_replay_set_chunk_bytes: bad arguments");
+  std::lock_guard<std::mutex> lk(r->m);
+  RELA_CHECK(r->d_fields.empty(), RELA_ESTATE, "rela_replay_set_chunk_bytes: the schema is already set");
+  r->chunk_bytes = bytes;
+  return RELA_OK;
+}
+
 extern "C" int rela_replay_set_schema(rela_replay* r, int nfields, const int64_t* row_bytes) {
   return rela_replay_set_schema_seq(r, nfields, row_bytes, nullptr);
 }
@@ -711,12 +740,31 @@ extern "C" int rela_replay_set_schema_seq(rela_replay* r, int nfields, const int
   for (int f = 0; f < nfields; ++f) {
     RELA_CHECK(row_bytes[f] > 0, RELA_EINVAL, "rela_replay_set_schema: field %d has %lld bytes", f,
                (long long)row_bytes[f]);
-    uint8_t* p = nullptr;
-    RELA_HIP(hipMalloc(&p, (size_t)row_bytes[f] * (size_t)r->ring));
     const int st = steps ? steps[f] : 1;
     RELA_CHECK(st >= 1 && row_bytes[f] % st == 0, RELA_EINVAL, "rela_replay_set_schema: field %d: %lld bytes not divisible into %d steps",
                f, (long long)row_bytes[f], st);
+    uint8_t* p = nullptr;
+    VmmRange* v = nullptr;
+    const size_t bytes = (size_t)row_bytes[f] * (size_t)r->ring;
+    // chunked mode takes EVERY field, also those of one chunk: mixing the two mappings in the importer is what failed -- after
+    // the 37 GB frame-stack field had been mapped from its chunks, hipIpcOpenMemHandle of the partition's 4.03 GB sequence
+    // field (one hipMalloc) did not return within 90 s (profiles/r05_vmm_mixed_import_hang.log)
+    if (r->chunk_bytes > 0) {
+      v = new VmmRange();
+      hipError_t e = v->create(bytes, (size_t)r->chunk_bytes, r->device);
+      if (e != hipSuccess) {
+        set_last_error("rela_replay_set_schema: field %d: %.1f GB in chunks of %.1f GB: %s", f, (double)bytes / 1e9,
+                       (double)r->chunk_bytes / 1e9, hipGetErrorString(e));
+        v->destroy();
+        delete v;
+        return e == hipErrorOutOfMemory ? RELA_ENOMEM : RELA_ENODEV;
+      }
+      p = v->base;
+    } else {
+      RELA_HIP(hipMalloc(&p, bytes));
+    }
     r->d_fields.push_back(p);
+    r->vmm.push_back(v);
     r->row_bytes.push_back(row_bytes[f]);
     r->steps.push_back(st);
   }
@@ -1409,16 +1457,18 @@ struct rela_replay_remote {
   int64_t row_bytes[RELA_IPC_MAX_FIELDS] = {};
   int32_t steps[RELA_IPC_MAX_FIELDS] = {};
   uint8_t* fields[RELA_IPC_MAX_FIELDS] = {};
+  VmmRange* vmm[RELA_IPC_MAX_FIELDS] = {};  // fields that arrived as chunks (fields[f] = vmm[f]->base)
   int32_t* ids = nullptr;
   float* raw_w = nullptr;
   ReplayDevState* state = nullptr;
 };
 
-extern "C" int rela_replay_export_ipc(rela_replay* r, rela_replay_ipc_desc* out) {
-  RELA_CHECK(r && out, RELA_EINVAL, "rela_replay_export_ipc: bad arguments");
+// `chunks` == nullptr: the plain descriptor (every field one hipIpcMemHandle_t)
+static int export_partition(rela_replay* r, rela_replay_ipc_desc* out, rela_replay_chunk_desc* chunks, int* fds_out,
+                            int max_fds, const char* who) {
   RELA_CHECK(!r->d_fields.empty() && (int)r->d_fields.size() <= RELA_IPC_MAX_FIELDS, RELA_ESTATE,
-             "rela_replay_export_ipc: set the schema first (at most %d fields)", RELA_IPC_MAX_FIELDS);
-  RELA_CHECK(r->dd_ups == 0, RELA_EINVAL, "rela_replay_export_ipc: de-duplicated partitions are not exported");
+             "%s: set the schema first (at most %d fields)", who, RELA_IPC_MAX_FIELDS);
+  RELA_CHECK(r->dd_ups == 0, RELA_EINVAL, "%s: de-duplicated partitions are not exported", who);
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
   DeviceGuard g(r->device);
   std::lock_guard<std::mutex> lk(r->m);
@@ -1428,34 +1478,83 @@ extern "C" int rela_replay_export_ipc(rela_replay* r, rela_replay_ipc_desc* out)
   out->ring = r->ring;
   out->device = r->device;
   out->max_batch = kMaxBatch;
+  int nfds = 0;
+  auto fail = [&](int rc) {
+    for (int k = 0; k < nfds; ++k) (void)::close(fds_out[k]);
+    return rc;
+  };
   for (size_t f = 0; f < r->d_fields.size(); ++f) {
     out->row_bytes[f] = r->row_bytes[f];
     out->steps[f] = r->steps[f];
+    if (VmmRange* v = r->vmm[f]) {
+      if (!chunks) {
+        set_last_error("%s: field %d is made of %d chunks (rela_replay_set_chunk_bytes); export it with "
+                       "rela_replay_export_chunks", who, (int)f, (int)v->handles.size());
+        return RELA_EINVAL;
+      }
+      const int n = (int)v->handles.size();
+      if (nfds + n > max_fds) {
+        set_last_error("%s: more than %d chunk descriptors; use larger chunks", who, max_fds);
+        return fail(RELA_EINVAL);
+      }
+      hipError_t e = v->export_fds(fds_out + nfds);
+      if (e != hipSuccess) {
+        set_last_error("%s: hipMemExportToShareableHandle (field %d): %s", who, (int)f, hipGetErrorString(e));
+        return fail(RELA_ENODEV);
+      }
+      nfds += n;
+      chunks->field_chunks[f] = n;
+      chunks->chunk_bytes[f] = (int64_t)v->chunk;
+      chunks->mapped_bytes[f] = (int64_t)v->bytes;
+      continue;
+    }
     {
       // r4, this pool's boxes: hipIpcOpenMemHandle of a 37 GB allocation (one frame-stack field of a 2^20-row partition)
       // did not return within 200 s in the importing process, 18.5 GB (2^19 rows) maps in under a second: refuse loudly
       hipDeviceptr_t base = nullptr;
       size_t bytes = 0;
-      if (hipMemGetAddressRange(&base, &bytes, r->d_fields[f]) == hipSuccess)
-        RELA_CHECK(bytes <= ((size_t)24 << 30), RELA_EINVAL,
-                   "rela_replay_export_ipc: field %d is one allocation of %.1f GB; HIP IPC imports above ~24 GB do not return on "
-                   "this platform -- use a smaller partition (<= 2^19 frame-stack rows) or the packed exchange",
-                   (int)f, (double)bytes / 1e9);
+      if (hipMemGetAddressRange(&base, &bytes, r->d_fields[f]) == hipSuccess && bytes > ((size_t)24 << 30)) {
+        set_last_error("%s: field %d is one allocation of %.1f GB; HIP IPC imports above ~24 GB do not return on this "
+                       "platform -- create the partition with rela_replay_set_chunk_bytes (or RELA_REPLAY_CHUNK_GB) and "
+                       "export it with rela_replay_export_chunks", who, (int)f, (double)bytes / 1e9);
+        return fail(RELA_EINVAL);
+      }
     }
-    RELA_HIP(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(out->field_handle[f]), r->d_fields[f]));
+    hipError_t e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(out->field_handle[f]), r->d_fields[f]);
+    if (e != hipSuccess) {
+      set_last_error("%s: hipIpcGetMemHandle (field %d): %s", who, (int)f, hipGetErrorString(e));
+      return fail(RELA_ENODEV);
+    }
   }
-  RELA_HIP(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(out->ids_handle), r->d_ids));
-  RELA_HIP(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(out->raw_w_handle), r->d_raw_w));
-  RELA_HIP(hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(out->state_handle), r->d_state));
+  hipError_t e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(out->ids_handle), r->d_ids);
+  if (e == hipSuccess) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(out->raw_w_handle), r->d_raw_w);
+  if (e == hipSuccess) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(out->state_handle), r->d_state);
+  if (e != hipSuccess) {
+    set_last_error("%s: hipIpcGetMemHandle: %s", who, hipGetErrorString(e));
+    return fail(RELA_ENODEV);
+  }
+  if (chunks) chunks->nfds = nfds;
   return RELA_OK;
 }
 
-extern "C" int rela_replay_import_ipc(rela_replay_remote** out, const rela_replay_ipc_desc* desc, int device) {
-  RELA_CHECK(out && desc && desc->abi == 1 && desc->nfields >= 1 && desc->nfields <= RELA_IPC_MAX_FIELDS, RELA_EINVAL,
-             "rela_replay_import_ipc: bad descriptor");
+extern "C" int rela_replay_export_ipc(rela_replay* r, rela_replay_ipc_desc* out) {
+  RELA_CHECK(r && out, RELA_EINVAL, "rela_replay_export_ipc: bad arguments");
+  return export_partition(r, out, nullptr, nullptr, 0, "rela_replay_export_ipc");
+}
+
+extern "C" int rela_replay_export_chunks(rela_replay* r, rela_replay_chunk_desc* out, int* fds_out, int max_fds) {
+  RELA_CHECK(r && out && (fds_out || max_fds == 0) && max_fds >= 0, RELA_EINVAL, "rela_replay_export_chunks: bad arguments");
+  memset(out, 0, sizeof(*out));
+  const int rc = export_partition(r, &out->ipc, out, fds_out, max_fds, "rela_replay_export_chunks");
+  if (rc == RELA_OK) out->abi = 2;
+  return rc;
+}
+
+static int import_partition(rela_replay_remote** out, const rela_replay_ipc_desc* desc, const rela_replay_chunk_desc* chunks,
+                            const int* fds, int nfds, int device, const char* who) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
-    set_last_error("rela_replay_import_ipc: HIP device %d not available (%d visible); there is no CPU path", device, ndev);
+    set_last_error("%s: HIP device %d not available (%d visible); there is no CPU path", who, device, ndev);
     return RELA_ENODEV;
   }
   DeviceGuard g(device);
@@ -1468,16 +1567,41 @@ extern "C" int rela_replay_import_ipc(rela_replay_remote** out, const rela_repla
     return hipIpcOpenMemHandle(p, mh, hipIpcMemLazyEnablePeerAccess);
   };
   hipError_t e = hipSuccess;
+  const char* what = "hipIpcOpenMemHandle";
+  int fd_at = 0;
+  // RELA_IPC_TRACE=1: one line per mapping step on stderr (an import that does not return is this platform's failure mode)
+  const bool trace = getenv("RELA_IPC_TRACE") != nullptr;
   for (int f = 0; f < desc->nfields && e == hipSuccess; ++f) {
     rr->row_bytes[f] = desc->row_bytes[f];
     rr->steps[f] = desc->steps[f];
-    e = open(desc->field_handle[f], reinterpret_cast<void**>(&rr->fields[f]));
+    const int n = chunks ? chunks->field_chunks[f] : 0;
+    if (trace)
+      fprintf(stderr, "[%s] field %d: %.3f GB as %s\n", who, f, (double)desc->row_bytes[f] * desc->ring / 1e9,
+              n > 0 ? "chunks" : "one IPC handle");
+    if (n > 0) {
+      const int64_t need = desc->row_bytes[f] * (int64_t)desc->ring;
+      if (fd_at + n > nfds || chunks->chunk_bytes[f] <= 0 || chunks->mapped_bytes[f] < need ||
+          (chunks->mapped_bytes[f] + chunks->chunk_bytes[f] - 1) / chunks->chunk_bytes[f] != n) {
+        set_last_error("%s: field %d: %d chunks of %lld bytes do not describe %lld mapped bytes (%d descriptors given)", who, f,
+                       n, (long long)chunks->chunk_bytes[f], (long long)chunks->mapped_bytes[f], nfds);
+        rela_replay_remote_close(rr);
+        return RELA_EINVAL;
+      }
+      rr->vmm[f] = new VmmRange();
+      what = "mapping the chunks (hipMemImportFromShareableHandle / hipMemMap / hipMemSetAccess)";
+      e = rr->vmm[f]->import(fds + fd_at, n, (size_t)chunks->chunk_bytes[f], (size_t)chunks->mapped_bytes[f], device);
+      rr->fields[f] = rr->vmm[f]->base;
+      fd_at += n;
+    } else {
+      e = open(desc->field_handle[f], reinterpret_cast<void**>(&rr->fields[f]));
+    }
   }
-  if (e == hipSuccess) e = open(desc->ids_handle, reinterpret_cast<void**>(&rr->ids));
+  if (trace) fprintf(stderr, "[%s] fields mapped (%s); ids / weights / state\n", who, hipGetErrorString(e));
+  if (e == hipSuccess) what = "hipIpcOpenMemHandle", e = open(desc->ids_handle, reinterpret_cast<void**>(&rr->ids));
   if (e == hipSuccess) e = open(desc->raw_w_handle, reinterpret_cast<void**>(&rr->raw_w));
   if (e == hipSuccess) e = open(desc->state_handle, reinterpret_cast<void**>(&rr->state));
   if (e != hipSuccess) {
-    set_last_error("rela_replay_import_ipc: hipIpcOpenMemHandle failed: %s", hipGetErrorString(e));
+    set_last_error("%s: %s failed: %s", who, what, hipGetErrorString(e));
     rela_replay_remote_close(rr);
     return RELA_ENODEV;
   }
@@ -1485,12 +1609,33 @@ extern "C" int rela_replay_import_ipc(rela_replay_remote** out, const rela_repla
   return RELA_OK;
 }
 
+extern "C" int rela_replay_import_ipc(rela_replay_remote** out, const rela_replay_ipc_desc* desc, int device) {
+  RELA_CHECK(out && desc && desc->abi == 1 && desc->nfields >= 1 && desc->nfields <= RELA_IPC_MAX_FIELDS, RELA_EINVAL,
+             "rela_replay_import_ipc: bad descriptor");
+  return import_partition(out, desc, nullptr, nullptr, 0, device, "rela_replay_import_ipc");
+}
+
+extern "C" int rela_replay_import_chunks(rela_replay_remote** out, const rela_replay_chunk_desc* desc, const int* fds, int nfds,
+                                         int device) {
+  RELA_CHECK(out && desc && desc->abi == 2 && desc->ipc.abi == 1 && desc->ipc.nfields >= 1 &&
+                 desc->ipc.nfields <= RELA_IPC_MAX_FIELDS && nfds == desc->nfds && (fds || nfds == 0),
+             RELA_EINVAL, "rela_replay_import_chunks: bad descriptor (or %d descriptors for its %d chunks)", nfds,
+             desc ? desc->nfds : -1);
+  return import_partition(out, &desc->ipc, desc, fds, nfds, device, "rela_replay_import_chunks");
+}
+
 extern "C" void rela_replay_remote_close(rela_replay_remote* rr) {
   if (!rr) return;
   DeviceGuard g(rr->device);
   (void)hipDeviceSynchronize();
-  for (int f = 0; f < rr->nfields; ++f)
-    if (rr->fields[f]) (void)hipIpcCloseMemHandle(rr->fields[f]);
+  for (int f = 0; f < rr->nfields; ++f) {
+    if (rr->vmm[f]) {
+      rr->vmm[f]->destroy();
+      delete rr->vmm[f];
+    } else if (rr->fields[f]) {
+      (void)hipIpcCloseMemHandle(rr->fields[f]);
+    }
+  }
   if (rr->ids) (void)hipIpcCloseMemHandle(rr->ids);
   if (rr->raw_w) (void)hipIpcCloseMemHandle(rr->raw_w);
   if (rr->state) (void)hipIpcCloseMemHandle(rr->state);

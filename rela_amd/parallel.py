@@ -39,6 +39,8 @@ the learner's flat parameter buffers into the actor processes, which load their 
 on torch.distributed: rendezvous, the command words, the B / G importance weights (the gather of 4 B / G bytes per rank
 doubles as "my sample has completed") and the B / G priorities back (doubles as "the learner has read your rows").
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -326,14 +328,93 @@ def ff_batch_namespace(fields):
 
 
 # ---- r4: native data plane over HIP IPC ---------------------------------------------------------------------------
+
+
+class _FdServer:
+    """Owner side of the descriptor hand-over (r5; include/rela_amd.h: rela_replay_export_chunks).  The chunks of a
+    partition's large fields are POSIX file descriptors, and a descriptor only crosses processes as SCM_RIGHTS ancillary
+    data of a Unix socket -- not through torch.distributed.  This serves `fds` ONCE to `clients` connections on an
+    abstract-namespace socket (no file to clean up; `name` goes into the rendezvous object) from a daemon thread, then
+    closes its copies."""
+
+    _count = 0
+
+    def __init__(self, fds, clients=1, timeout=300.0):
+        import socket
+        import threading
+
+        _FdServer._count += 1
+        self.name = "rela-amd-fds-%d-%d" % (os.getpid(), _FdServer._count)
+        self.fds = list(fds)
+        self._sock = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        self._sock.bind("\0" + self.name)
+        self._sock.listen(max(1, clients))
+        self._sock.settimeout(timeout)
+        self.error = None
+        self._thread = threading.Thread(target=self._serve, args=(clients,), daemon=True)
+        self._thread.start()
+
+    def _serve(self, clients):
+        import socket
+
+        try:
+            for _ in range(clients):
+                conn, _ = self._sock.accept()
+                with conn:
+                    socket.send_fds(conn, [len(self.fds).to_bytes(4, "little")], self.fds)
+                    conn.recv(1)  # the importer has the descriptors (its copies) before ours are closed
+        except OSError as e:  # (a learner that never came: the partition keeps working locally)
+            self.error = e
+        finally:
+            self._sock.close()
+            for fd in self.fds:
+                os.close(fd)
+            self.fds = []
+
+    def join(self, timeout=None):
+        self._thread.join(timeout)
+
+
+def _fetch_fds(name, timeout=300.0):
+    import socket
+
+    with socket.socket(socket.AF_UNIX, socket.SOCK_STREAM) as sk:
+        sk.settimeout(timeout)
+        sk.connect("\0" + name)
+        msg, fds, _, _ = socket.recv_fds(sk, 4, 253)
+        sk.send(b"k")
+    assert len(msg) == 4 and int.from_bytes(msg, "little") == len(fds), "descriptor hand-over: %r, %d fds" % (msg, len(fds))
+    return fds
+
+
 def _export_desc(replay_handle):
+    """-> (descriptor bytes, [fd of every chunk]) of a rela_replay*: rela_replay_export_chunks serves partitions with and
+    without chunked fields (none: no descriptors, the fields travel as IPC handles inside the bytes)"""
     import ctypes as C
 
     from . import _capi as capi
 
-    buf = (C.c_ubyte * 4096)()
-    capi.check(capi.lib.rela_replay_export_ipc(replay_handle, buf), "rela_replay_export_ipc")
-    return bytes(buf)
+    desc = capi.ReplayChunkDesc()
+    fds = (C.c_int * capi.IPC_MAX_FDS)()
+    capi.check(capi.lib.rela_replay_export_chunks(replay_handle, C.byref(desc), fds, capi.IPC_MAX_FDS),
+               "rela_replay_export_chunks")
+    return bytes(desc), [fds[i] for i in range(desc.nfds)]
+
+
+def _import_partition(capi, C, entry, dev_index):
+    """learner side: the rendezvous entry of one actor rank -> rela_replay_remote*"""
+    raw = entry["partition"]
+    assert len(raw) == C.sizeof(capi.ReplayChunkDesc), "partition descriptor of %d bytes" % len(raw)
+    buf = capi.ReplayChunkDesc.from_buffer_copy(raw)
+    fds = _fetch_fds(entry["fd_socket"]) if entry.get("fd_socket") else []
+    rr = C.c_void_p()
+    try:
+        arr = (C.c_int * max(1, len(fds)))(*fds)
+        capi.check(capi.lib.rela_replay_import_chunks(C.byref(rr), C.byref(buf), arr, len(fds), dev_index), "rela_replay_import_chunks")
+    finally:
+        for fd in fds:  # the mapping holds its own references
+            os.close(fd)
+    return rr
 
 
 class NativePartitionedReplay(PartitionedReplay):
@@ -363,13 +444,8 @@ class NativePartitionedReplay(PartitionedReplay):
         dist.all_gather_object(descs, mine, group=group)
         self._remote = []
         dev_index = self.data_device.index or 0
-        for r in self.actor_ranks:
-            raw = descs[r]["partition"]  # (sizeof(rela_replay_ipc_desc) bytes, or a padded buffer)
-            buf = (C.c_ubyte * max(4096, len(raw)))()
-            C.memmove(buf, raw, len(raw))
-            rr = C.c_void_p()
-            capi.check(capi.lib.rela_replay_import_ipc(C.byref(rr), buf, dev_index), "rela_replay_import_ipc")
-            self._remote.append(rr)
+        for r in self.actor_ranks:  # IPC handles for the small arrays, file descriptors for the chunks of the large ones
+            self._remote.append(_import_partition(capi, C, descs[r], dev_index))
         # the packed record of a rank shrinks to its importance weights
         self._layout, self._w_off = [], 0
         self.rank_bytes = _pad16(4 * self.b_local)
@@ -443,7 +519,7 @@ class _ModuleNativePartition:
         self.replay, self.device = replay, device
 
     def export_desc(self):
-        return self.replay.export_ipc()
+        return self.replay.export_chunks()
 
     def sample_ids(self, n):
         return self.replay.sample_ids(n)
@@ -472,7 +548,9 @@ class NativePartitionServer(PartitionServer):
         self.replay = replay if hasattr(replay, "sample_ids") else _CapiNativePartition(replay)
         self.data_device = torch.device(data_device if data_device is not None else device)
         descs = [None] * self.world
-        dist.all_gather_object(descs, {"partition": self.replay.export_desc()}, group=group)
+        desc, fds = self.replay.export_desc()
+        self._fd_server = _FdServer(fds) if fds else None  # listening BEFORE the learner learns its name
+        dist.all_gather_object(descs, {"partition": desc, "fd_socket": self._fd_server.name if fds else None}, group=group)
         dev_index = self.data_device.index or 0
         self._flat_ptrs, self._flats = [], []
         for h, n in descs[learner_rank]["flats"]:  # map the learner's flat parameter buffers

@@ -600,6 +600,18 @@ class ReplayParts {
     check(rela_replay_export_ipc(ps[0].h, &d), "rela_replay_export_ipc");
     return py::bytes(reinterpret_cast<const char*>(&d), sizeof(d));
   }
+  // ... for a partition of any size (fields above the chunk size travel as file descriptors, include/rela_amd.h:
+  // rela_replay_export_chunks): -> (descriptor bytes, [fd, ...]); the caller sends the descriptors with SCM_RIGHTS
+  // and closes them (rela_amd/parallel.py: _FdServer)
+  std::pair<py::bytes, std::vector<int>> exportChunks() const {
+    auto ps = parts();
+    if (ps.size() != 1) throw std::runtime_error("export_chunks: the replay must hold exactly one partition");
+    rela_replay_chunk_desc d;
+    std::vector<int> fds(RELA_IPC_MAX_FDS, -1);
+    check(rela_replay_export_chunks(ps[0].h, &d, fds.data(), RELA_IPC_MAX_FDS), "rela_replay_export_chunks");
+    fds.resize(d.nfds);
+    return {py::bytes(reinterpret_cast<const char*>(&d), sizeof(d)), fds};
+  }
   // sample WITHOUT gathering: ids, raw weights and eviction only; -> (raw weights [n], float sum [1], size)
   std::tuple<torch::Tensor, torch::Tensor, int> sampleIds(int n) {
     auto ps = parts();
@@ -781,6 +793,7 @@ class FFPrioritizedReplay {
 
   // native partition exchange (not in the reference's surface): see ReplayParts::exportIpc / sampleIds
   py::bytes exportIpc() { return core_.exportIpc(); }
+  std::pair<py::bytes, std::vector<int>> exportChunks() { return core_.exportChunks(); }
   std::tuple<torch::Tensor, torch::Tensor, int> sampleIds(int n) {
     auto r = core_.sampleIds(n);
     lastBatch_ = n;
@@ -954,6 +967,7 @@ class RNNPrioritizedReplay {
 
   // native partition exchange (not in the reference's surface): see ReplayParts::exportIpc / sampleIds
   py::bytes exportIpc() { return core_.exportIpc(); }
+  std::pair<py::bytes, std::vector<int>> exportChunks() { return core_.exportChunks(); }
   std::tuple<torch::Tensor, torch::Tensor, int> sampleIds(int n) {
     auto r = core_.sampleIds(n);
     lastBatch_ = n;
@@ -1750,6 +1764,12 @@ PYBIND11_MODULE(rela, m) {
   // persistent forward kernels' grids (include/rela_amd.h: rela_runtime_set_cu_reserve; RELA_CU_RESERVE overrides)
   (void)rela_runtime_set_cu_reserve(8);
 
+  m.def("set_replay_chunk_bytes", [](int64_t bytes) {
+          if (rela_runtime_set_replay_chunk_bytes(bytes) != 0) throw std::runtime_error(rela_last_error());
+        }, py::arg("bytes"),
+        "field arrays of replays created AFTER this call that are larger than `bytes` are allocated as chunks of that size, "
+        "so that a partition of any size can be exported to a learner process (include/rela_amd.h: "
+        "rela_replay_set_chunk_bytes); 0 = off; not in the reference");
   m.def("threaded_stats", [](bool reset) { return gStats.snapshot(reset); }, py::arg("reset") = false,
         "RELA_THREADED_STATS=1: where the actor threads' wall time went since the last reset (diagnostic)");
 
@@ -1778,6 +1798,7 @@ PYBIND11_MODULE(rela, m) {
       .def("update_priority", &FFPrioritizedReplay::updatePriority)
       .def("last_sample_raw", &FFPrioritizedReplay::lastSampleRaw_)  // partition exchange only
       .def("export_ipc", &FFPrioritizedReplay::exportIpc)            // native exchange: this partition's IPC descriptor
+      .def("export_chunks", &FFPrioritizedReplay::exportChunks)      // ... of a partition with chunked fields (any size)
       .def("sample_ids", &FFPrioritizedReplay::sampleIds);           // ... and a sample that leaves the rows in place
 
   py::class_<RNNPrioritizedReplay, std::shared_ptr<RNNPrioritizedReplay>>(m, "RNNPrioritizedReplay")
@@ -1788,6 +1809,7 @@ PYBIND11_MODULE(rela, m) {
       .def("update_priority", &RNNPrioritizedReplay::updatePriority)
       .def("last_sample_raw", &RNNPrioritizedReplay::lastSampleRaw_)  // partition exchange only
       .def("export_ipc", &RNNPrioritizedReplay::exportIpc)
+      .def("export_chunks", &RNNPrioritizedReplay::exportChunks)
       .def("sample_ids", &RNNPrioritizedReplay::sampleIds);
 
   py::class_<Env, std::shared_ptr<Env>>(m, "Env");

@@ -321,6 +321,8 @@ def _multi_worker(rank, world, args, port, results):
     else:
         g = rank - 1
         locker = rela.ModelLocker([agent, agent, agent], my_device)
+        if native:  # the learner maps this partition: fields as 8 GB chunks, which travel at any size (include/rela_amd.h)
+            rela.set_replay_chunk_bytes(8 << 30)
         part = (rela.RNNPrioritizedReplay if r2d2 else rela.FFPrioritizedReplay)(
             args.replay_buffer_size // G, args.seed + g, args.priority_exponent, args.importance_exponent, args.prefetch)
         eps_all = utils.generate_eps(args.act_base_eps, args.act_eps_alpha, args.num_thread * args.num_game_per_thread)

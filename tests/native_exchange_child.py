@@ -1,6 +1,6 @@
 """Child of tests/test_ipc_gpu.py::test_native_exchange_three_processes: rank 0 = learner, ranks 1..G = actor ranks, all
 on cuda:0 over gloo (RCCL refuses two ranks on one device).  Exercises rela_amd.parallel's NATIVE data plane: partitions
-exported through HIP IPC, the learner's own gather kernel reading the sampled rows out of the owners' memory, the
+exported through HIP IPC (rank 2's: its large fields as chunks handed over as file descriptors), the learner's own gather kernel reading the sampled rows out of the owners' memory, the
 learner's flat parameter buffers mapped by the actor ranks for the weight publish."""
 import os
 import sys
@@ -58,6 +58,10 @@ if rank == 0:
     rep.close()
     print("LEARNER OK", flush=True)
 else:
+    if rank == 2:  # one partition with its frame-stack fields in 8 MB chunks (9 descriptors each), one with plain IPC handles
+        from rela_amd import _capi as capi
+
+        capi.check(capi.lib.rela_runtime_set_replay_chunk_bytes(8 << 20), "chunk bytes")
     part = FFReplay(2048, 11 + rank, 0.6, BETA, 0, A, dev)
     n = 2048
     tags = torch.arange(n, dtype=torch.int64) + rank * 1000000

@@ -22,30 +22,51 @@ def _payload_of(tags, width):
     return ((np.asarray(tags, np.int64)[:, None] * 31 + col) % 251).astype(np.uint8)
 
 
-def test_remote_gather_reads_the_owners_partition():
+def _remote_gather_against_owner(chunk_bytes, cap=4096, width=4096, rounds=3, timeout=60, n=None):
+    """owner = a child process holding the partition; this process maps it and gathers the rows of the owner's samples"""
     import torch
 
     from rela_amd import _capi as capi
+    from rela_amd.parallel import _import_partition
 
     B, SEQ = 64, 3
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CHUNK_BYTES=str(chunk_bytes), CAP=str(cap), WIDTH=str(width),
+               N=str(n or cap))
     child = subprocess.Popen([sys.executable, os.path.join(HERE, "ipc_owner_child.py")], stdin=subprocess.PIPE,
                              stdout=subprocess.PIPE, text=True, env=env)
+    chunks_hit = set()
     try:
         line = child.stdout.readline()
-        assert line.startswith("DESC "), line
-        desc = (C.c_ubyte * 4096).from_buffer_copy(bytes.fromhex(line[5:].strip()))
-        rr = C.c_void_p()
-        capi.check(capi.lib.rela_replay_import_ipc(C.byref(rr), desc, 0), "rela_replay_import_ipc")
+        if chunk_bytes:
+            assert line.startswith("DESC2 "), line
+            _, sock, hexdesc = line.split()
+            raw = bytes.fromhex(hexdesc)
+            d = capi.ReplayChunkDesc.from_buffer_copy(raw)
+            ring = d.ipc.ring
+            page = 2 << 20  # every field of a chunked partition is whole 2 MB pages in chunks of at most chunk_bytes
+            want = [-(-(-(-(ring * rb) // page) * page) // chunk_bytes) for rb in (8, width, SEQ * 1024)]
+            assert list(d.field_chunks[:3]) == want and d.nfds == sum(want), (list(d.field_chunks[:3]), want, d.nfds)
+            import faulthandler
+
+            faulthandler.dump_traceback_later(90, exit=False)  # (an import that does not return: show where)
+            rr = _import_partition(capi, C, {"partition": raw, "fd_socket": sock}, 0)
+            faulthandler.cancel_dump_traceback_later()
+        else:
+            assert line.startswith("DESC "), line
+            desc = (C.c_ubyte * 4096).from_buffer_copy(bytes.fromhex(line[5:].strip()))
+            rr = C.c_void_p()
+            capi.check(capi.lib.rela_replay_import_ipc(C.byref(rr), desc, 0), "rela_replay_import_ipc")
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        for round_ in range(3):
+        for round_ in range(rounds):
             child.stdin.write("sample\n")
             child.stdin.flush()
             line = child.stdout.readline()
             assert line.startswith("SAMPLED "), line
             exp = json.loads(line[8:])
+            if chunk_bytes:
+                chunks_hit.update(int(sl) * width // chunk_bytes for sl in exp["slots"])
             tags = torch.zeros(B, dtype=torch.int64, device="cuda")
-            pay = torch.zeros((B, 4096), dtype=torch.uint8, device="cuda")
+            pay = torch.zeros((B, width), dtype=torch.uint8, device="cuda")
             seq = torch.zeros((SEQ, B, 1024), dtype=torch.uint8, device="cuda")  # time-major, as rela_replay_sample
             raw = torch.zeros(B, device="cuda")
             sm = torch.zeros(1, device="cuda")
@@ -55,7 +76,7 @@ def test_remote_gather_reads_the_owners_partition():
             torch.cuda.synchronize()
             got_tags = tags.cpu().numpy()
             assert got_tags.tolist() == exp["tags"], round_
-            assert np.array_equal(pay.cpu().numpy(), _payload_of(got_tags, 4096)), round_
+            assert np.array_equal(pay.cpu().numpy(), _payload_of(got_tags, width)), round_
             want_seq = _payload_of(got_tags + 1000003, SEQ * 1024).reshape(B, SEQ, 1024).transpose(1, 0, 2)
             assert np.array_equal(seq.cpu().numpy(), want_seq), round_
             assert np.array_equal(raw.cpu().numpy(), np.float32(exp["raw_w"])), round_
@@ -66,10 +87,31 @@ def test_remote_gather_reads_the_owners_partition():
         capi.lib.rela_replay_remote_close(rr)
         child.stdin.write("quit\n")
         child.stdin.flush()
-        assert child.wait(timeout=60) == 0
+        assert child.wait(timeout=timeout) == 0
     finally:
         if child.poll() is None:
             child.kill()
+    return chunks_hit
+
+
+@pytest.mark.parametrize("chunk_bytes", [0, 2 << 20, 6 << 20], ids=["ipc_handles", "chunks_2MB", "chunks_6MB"])
+def test_remote_gather_reads_the_owners_partition(chunk_bytes):
+    """chunk_bytes > 0 (r5): the 20 MB payload field, the 15 MB sequence field and the 40 KB tag field are chunks of physical
+    memory behind one virtual range each in BOTH processes (10 + 8 + 1 chunks of 2 MB; 4 + 3 + 1 of 6 MB, the last ones
+    partial), handed over as file descriptors on a Unix socket"""
+    hit = _remote_gather_against_owner(chunk_bytes)
+    assert not chunk_bytes or len(hit) >= 3, hit  # the samples came out of several chunks
+
+
+def test_remote_gather_from_a_partition_hipipc_cannot_carry():
+    """a 2^20-transition partition whose frame-stack field is ONE 37 GB array (1,310,720 slots x 28,224 B):
+    hipIpcOpenMemHandle of that allocation did not return in r4 and rela_replay_export_ipc refuses it.  In 8 GB chunks it is
+    exported, mapped by this process and sampled from all over: 1.2 x 2^20 rows inserted, so that live rows reach into the
+    fifth chunk (32 GB up), and every chunk is read by one of the 4 x 64 draws.  (The 4 GB sequence field and the tag field
+    are one chunk each: 7 descriptors.)"""
+    cap = 1 << 20
+    hit = _remote_gather_against_owner(8 << 30, cap=cap, width=28224, rounds=4, timeout=120, n=cap + cap // 5)
+    assert hit == set(range(5)), hit
 
 
 def test_native_exchange_three_processes():

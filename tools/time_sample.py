@@ -62,7 +62,11 @@ torch.cuda.synchronize()
 lat.sort()
 sample_keys = [k for k in us if k.startswith("seq_") or k.startswith("replay_gather") or k in (
     "replay_targets", "replay_search", "replay_pop", "replay_is_weights", "replay_sample_finish")]
-print(json.dumps({"ring": int(1.25 * cap), "batch": B, "size": rep.size(), "us_per_call": us,
+desc, fds = capi.ReplayChunkDesc(), (C.c_int * capi.IPC_MAX_FDS)()  # RELA_REPLAY_CHUNK_GB=8: is the ring really in chunks?
+capi.check(capi.lib.rela_replay_export_chunks(rep.h, C.byref(desc), fds, capi.IPC_MAX_FDS), "export_chunks")
+for i in range(desc.nfds):
+    os.close(fds[i])
+print(json.dumps({"field_chunks": list(desc.field_chunks[:desc.ipc.nfields]), "ring": int(1.25 * cap), "batch": B, "size": rep.size(), "us_per_call": us,
                   "sample_kernels_us": round(sum(us[k] for k in sample_keys), 1),
                   "update_us": us.get("replay_update"),
                   "host_latency_us_median": round(lat[len(lat) // 2] * 1e6, 1),

@@ -32,7 +32,10 @@ PINNED, POSIX_FD, DEVICE, RW = 1, 1, 1, 3
 
 
 def hip():
-    h = C.CDLL("libamdhip64.so")
+    h = C.CDLL(os.environ.get("HIPLIB", "libamdhip64.so"))  # HIPLIB=<torch>/lib/libamdhip64.so: the runtime a torch process has
+    v = C.c_int()
+    h.hipRuntimeGetVersion(C.byref(v))
+    h.version = v.value
     h.hipMemAddressReserve.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t, C.c_void_p, C.c_ulonglong]
     h.hipMemMap.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_ulonglong]
     h.hipMemSetAccess.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(Access), C.c_size_t]
@@ -69,7 +72,9 @@ def child(conn, chunks, chunk):
     handles, rcs = [], []
     for fd in fds:
         hd = C.c_void_p()
-        rcs.append(h.hipMemImportFromShareableHandle(C.byref(hd), C.c_void_p(fd), POSIX_FD))
+        # BYREF=1: osHandle = pointer to the descriptor (HIP 7.0 reads it that way and faults on the value form 7.2 takes)
+        os_handle = C.cast(C.pointer(C.c_int(fd)), C.c_void_p) if os.environ.get("BYREF") == "1" else C.c_void_p(fd)
+        rcs.append(h.hipMemImportFromShareableHandle(C.byref(hd), os_handle, POSIX_FD))
         handles.append(hd)
     out["import_rc"] = sorted(set(rcs))
     base, rc = map_range(h, handles, chunk)
@@ -91,7 +96,8 @@ def main():
     p = ctx.Process(target=child, args=(b, chunks, chunk))
     p.start()  # before this process touches the GPU
     h = hip()
-    res = {"chunks": chunks, "chunk_bytes": chunk, "total_gb": chunks * chunk / 2**30}
+    res = {"chunks": chunks, "chunk_bytes": chunk, "total_gb": chunks * chunk / 2**30, "hip_runtime": h.version,
+           "os_handle": "pointer" if os.environ.get("BYREF") == "1" else "value"}
     gran = C.c_size_t()
     pr = prop()
     res["granularity_rc"] = h.hipMemGetAllocationGranularity(C.byref(gran), C.byref(pr), 0)
