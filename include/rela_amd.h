@@ -656,7 +656,8 @@ int rela_replay_remote_gather(rela_replay_remote* rr, int batch, void* const* ou
  * the fields of a partition that is NOT in chunked mode (field_chunks[f] = 0): rela_replay_export_chunks serves every
  * partition; rela_replay_export_ipc refuses a chunked one.  A chunked partition has no field left on an IPC handle on
  * purpose: after a 37 GB field had been mapped from its chunks, hipIpcOpenMemHandle of a 4 GB field of the same partition did
- * not return (profiles/r05_vmm_mixed_import_hang.log).
+ * not return (profiles/r05_vmm_mixed_import_hang.log).  De-duplicated partitions (rela_replay_set_schema_dedup) are exported
+ * with their unit ring; rela_replay_remote_gather rebuilds the frame stacks from it as rela_replay_sample does.
  * Measured on one MI355X, two processes: tests/test_native_exchange_gpu.py (a partition of 2 x 14.8 GB fields in 4 GB
  * chunks, and RELA_TEST_BIG=1: 2 x 37 GB), profiles/r05_vmm_probe.jsonl.                                              */
 #define RELA_IPC_MAX_FDS 128
@@ -666,6 +667,11 @@ typedef struct rela_replay_chunk_desc {
   int32_t field_chunks[RELA_IPC_MAX_FIELDS]; /* 0: the field is ipc.field_handle[f]; n: the next n descriptors */
   int64_t chunk_bytes[RELA_IPC_MAX_FIELDS];  /* size of every chunk of the field but the last */
   int64_t mapped_bytes[RELA_IPC_MAX_FIELDS]; /* the field's virtual range (>= ring * row_bytes, whole pages) */
+  /* de-duplicated partition (rela_replay_set_schema_dedup; dd_ups = 0: none): fields dd_field[0..1] hold int32 references
+   * into the unit ring, which travels after the fields' descriptors (units_chunks > 0) or as units_handle */
+  int32_t dd_ups, dd_field[2], units_chunks;
+  int64_t dd_unit_bytes, dd_cap, units_chunk_bytes, units_mapped_bytes;
+  unsigned char units_handle[64];
 } rela_replay_chunk_desc;
 int rela_replay_set_chunk_bytes(rela_replay* r, int64_t bytes);
 int rela_runtime_set_replay_chunk_bytes(int64_t bytes);

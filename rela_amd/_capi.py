@@ -41,7 +41,9 @@ class ReplayIpcDesc(C.Structure):  # rela_replay_ipc_desc
 
 class ReplayChunkDesc(C.Structure):  # rela_replay_chunk_desc
     _fields_ = [("ipc", ReplayIpcDesc), ("abi", C.c_int32), ("nfds", C.c_int32), ("field_chunks", C.c_int32 * 16),
-                ("chunk_bytes", C.c_int64 * 16), ("mapped_bytes", C.c_int64 * 16)]
+                ("chunk_bytes", C.c_int64 * 16), ("mapped_bytes", C.c_int64 * 16), ("dd_ups", C.c_int32),
+                ("dd_field", C.c_int32 * 2), ("units_chunks", C.c_int32), ("dd_unit_bytes", C.c_int64), ("dd_cap", C.c_int64),
+                ("units_chunk_bytes", C.c_int64), ("units_mapped_bytes", C.c_int64), ("units_handle", C.c_ubyte * 64)]
 
 
 IPC_MAX_FDS = 128

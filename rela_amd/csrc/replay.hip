@@ -595,6 +595,7 @@ struct rela_replay {
   int dd_ups = 0;                 // units per stack (0 = de-duplication off)
   int64_t dd_unit_bytes = 0, dd_cap = 0;
   uint8_t* d_units = nullptr;     // [dd_cap][dd_unit_bytes]
+  VmmRange* vmm_units = nullptr;  // chunked mode: d_units = vmm_units->base
   int dd_field[2] = {-1, -1};
   int64_t dd_next_seq = 0;        // sequence number of the next unit
   std::vector<int64_t> dd_slot_min;  // [ring] smallest unit sequence a slot refers to (host; guarded by m)
@@ -697,7 +698,12 @@ extern "C" void rela_replay_destroy(rela_replay* r) {
   }
   seq_index_free(&r->ix);
   r->stage.destroy();
-  (void)hipFree(r->d_units);
+  if (r->vmm_units) {
+    r->vmm_units->destroy();
+    delete r->vmm_units;
+  } else {
+    (void)hipFree(r->d_units);
+  }
   (void)hipFree(r->d_w);
   (void)hipFree(r->d_evicted);
   (void)hipFree(r->d_state);
@@ -793,7 +799,22 @@ extern "C" int rela_replay_set_schema_dedup(rela_replay* r, int nfields, const i
   RELA_CHECK(r->dd_cap < ((int64_t)1 << 31), RELA_EINVAL, "rela_replay_set_schema_dedup: unit ring too large");
   r->dd_field[0] = field_a;
   r->dd_field[1] = field_b;
-  RELA_HIP(hipMalloc(&r->d_units, (size_t)r->dd_cap * (size_t)unit_bytes));
+  const size_t unit_ring_bytes = (size_t)r->dd_cap * (size_t)unit_bytes;
+  if (r->chunk_bytes > 0) {  // exported like the field arrays (vmm_field.h)
+    r->vmm_units = new VmmRange();
+    hipError_t e = r->vmm_units->create(unit_ring_bytes, (size_t)r->chunk_bytes, r->device);
+    if (e != hipSuccess) {
+      set_last_error("rela_replay_set_schema_dedup: unit ring of %.1f GB in chunks of %.1f GB: %s", (double)unit_ring_bytes / 1e9,
+                     (double)r->chunk_bytes / 1e9, hipGetErrorString(e));
+      r->vmm_units->destroy();
+      delete r->vmm_units;
+      r->vmm_units = nullptr;
+      return e == hipErrorOutOfMemory ? RELA_ENOMEM : RELA_ENODEV;
+    }
+    r->d_units = r->vmm_units->base;
+  } else {
+    RELA_HIP(hipMalloc(&r->d_units, unit_ring_bytes));
+  }
   r->dd_slot_min.assign((size_t)r->ring, 0);
   return RELA_OK;
 }
@@ -1458,6 +1479,11 @@ struct rela_replay_remote {
   int32_t steps[RELA_IPC_MAX_FIELDS] = {};
   uint8_t* fields[RELA_IPC_MAX_FIELDS] = {};
   VmmRange* vmm[RELA_IPC_MAX_FIELDS] = {};  // fields that arrived as chunks (fields[f] = vmm[f]->base)
+  // de-duplicated partition: the two stack fields hold references into the owner's unit ring
+  int dd_ups = 0, dd_field[2] = {-1, -1};
+  int64_t dd_unit_bytes = 0;
+  uint8_t* units = nullptr;
+  VmmRange* vmm_units = nullptr;
   int32_t* ids = nullptr;
   float* raw_w = nullptr;
   ReplayDevState* state = nullptr;
@@ -1468,7 +1494,8 @@ static int export_partition(rela_replay* r, rela_replay_ipc_desc* out, rela_repl
                             int max_fds, const char* who) {
   RELA_CHECK(!r->d_fields.empty() && (int)r->d_fields.size() <= RELA_IPC_MAX_FIELDS, RELA_ESTATE,
              "%s: set the schema first (at most %d fields)", who, RELA_IPC_MAX_FIELDS);
-  RELA_CHECK(r->dd_ups == 0, RELA_EINVAL, "%s: de-duplicated partitions are not exported", who);
+  RELA_CHECK(r->dd_ups == 0 || chunks, RELA_EINVAL,
+             "%s: a de-duplicated partition needs the unit ring next to its fields; export it with rela_replay_export_chunks", who);
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
   DeviceGuard g(r->device);
   std::lock_guard<std::mutex> lk(r->m);
@@ -1533,6 +1560,34 @@ static int export_partition(rela_replay* r, rela_replay_ipc_desc* out, rela_repl
     set_last_error("%s: hipIpcGetMemHandle: %s", who, hipGetErrorString(e));
     return fail(RELA_ENODEV);
   }
+  if (chunks && r->dd_ups > 0) {  // the unit ring the two stack fields refer into
+    chunks->dd_ups = r->dd_ups;
+    chunks->dd_field[0] = r->dd_field[0], chunks->dd_field[1] = r->dd_field[1];
+    chunks->dd_unit_bytes = r->dd_unit_bytes;
+    chunks->dd_cap = r->dd_cap;
+    if (VmmRange* v = r->vmm_units) {
+      const int n = (int)v->handles.size();
+      if (nfds + n > max_fds) {
+        set_last_error("%s: more than %d chunk descriptors; use larger chunks", who, max_fds);
+        return fail(RELA_EINVAL);
+      }
+      e = v->export_fds(fds_out + nfds);
+      if (e != hipSuccess) {
+        set_last_error("%s: hipMemExportToShareableHandle (unit ring): %s", who, hipGetErrorString(e));
+        return fail(RELA_ENODEV);
+      }
+      nfds += n;
+      chunks->units_chunks = n;
+      chunks->units_chunk_bytes = (int64_t)v->chunk;
+      chunks->units_mapped_bytes = (int64_t)v->bytes;
+    } else {
+      e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(chunks->units_handle), r->d_units);
+      if (e != hipSuccess) {
+        set_last_error("%s: hipIpcGetMemHandle (unit ring): %s", who, hipGetErrorString(e));
+        return fail(RELA_ENODEV);
+      }
+    }
+  }
   if (chunks) chunks->nfds = nfds;
   return RELA_OK;
 }
@@ -1596,6 +1651,32 @@ static int import_partition(rela_replay_remote** out, const rela_replay_ipc_desc
       e = open(desc->field_handle[f], reinterpret_cast<void**>(&rr->fields[f]));
     }
   }
+  if (e == hipSuccess && chunks && chunks->dd_ups > 0) {
+    rr->dd_ups = chunks->dd_ups, rr->dd_unit_bytes = chunks->dd_unit_bytes;
+    rr->dd_field[0] = chunks->dd_field[0], rr->dd_field[1] = chunks->dd_field[1];
+    const int n = chunks->units_chunks;
+    const int64_t need = chunks->dd_cap * chunks->dd_unit_bytes;
+    const bool fields_ok = rr->dd_field[0] >= 0 && rr->dd_field[0] < desc->nfields && rr->dd_field[1] >= 0 &&
+                           rr->dd_field[1] < desc->nfields && rr->dd_ups <= 16 && rr->dd_unit_bytes > 0 && rr->dd_unit_bytes % 16 == 0 &&
+                           desc->row_bytes[rr->dd_field[0]] == 4 * rr->dd_ups && desc->row_bytes[rr->dd_field[1]] == 4 * rr->dd_ups;
+    if (!fields_ok || (n > 0 && (fd_at + n > nfds || chunks->units_chunk_bytes <= 0 || chunks->units_mapped_bytes < need ||
+                                 (chunks->units_mapped_bytes + chunks->units_chunk_bytes - 1) / chunks->units_chunk_bytes != n))) {
+      set_last_error("%s: the unit ring's description is inconsistent (%d chunks, fields %d / %d, %d units per stack)", who, n,
+                     rr->dd_field[0], rr->dd_field[1], rr->dd_ups);
+      rela_replay_remote_close(rr);
+      return RELA_EINVAL;
+    }
+    if (trace) fprintf(stderr, "[%s] unit ring: %.3f GB as %s\n", who, (double)need / 1e9, n > 0 ? "chunks" : "one IPC handle");
+    if (n > 0) {
+      rr->vmm_units = new VmmRange();
+      what = "mapping the unit ring's chunks";
+      e = rr->vmm_units->import(fds + fd_at, n, (size_t)chunks->units_chunk_bytes, (size_t)chunks->units_mapped_bytes, device);
+      rr->units = rr->vmm_units->base;
+      fd_at += n;
+    } else {
+      e = open(chunks->units_handle, reinterpret_cast<void**>(&rr->units));
+    }
+  }
   if (trace) fprintf(stderr, "[%s] fields mapped (%s); ids / weights / state\n", who, hipGetErrorString(e));
   if (e == hipSuccess) what = "hipIpcOpenMemHandle", e = open(desc->ids_handle, reinterpret_cast<void**>(&rr->ids));
   if (e == hipSuccess) e = open(desc->raw_w_handle, reinterpret_cast<void**>(&rr->raw_w));
@@ -1636,6 +1717,12 @@ extern "C" void rela_replay_remote_close(rela_replay_remote* rr) {
       (void)hipIpcCloseMemHandle(rr->fields[f]);
     }
   }
+  if (rr->vmm_units) {
+    rr->vmm_units->destroy();
+    delete rr->vmm_units;
+  } else if (rr->units) {
+    (void)hipIpcCloseMemHandle(rr->units);
+  }
   if (rr->ids) (void)hipIpcCloseMemHandle(rr->ids);
   if (rr->raw_w) (void)hipIpcCloseMemHandle(rr->raw_w);
   if (rr->state) (void)hipIpcCloseMemHandle(rr->state);
@@ -1658,6 +1745,10 @@ extern "C" int rela_replay_remote_gather(rela_replay_remote* rr, int batch, void
     if (!out_rows_dev[f]) continue;
     const int64_t rb = rr->row_bytes[f];
     const int st = rr->steps[f];
+    if (rr->dd_ups > 0 && (f == rr->dd_field[0] || f == rr->dd_field[1])) {
+      RELA_CHECK(((uintptr_t)out_rows_dev[f] & 15) == 0, RELA_EINVAL, "rela_replay_remote_gather: unaligned stack output");
+      continue;  // rebuilt from the unit ring below
+    }
     if (st == 1 && rb <= kSmallRowBytes && small.n < kMaxSmallFields) {
       small.src[small.n] = rr->fields[f];
       small.dst[small.n] = (uint8_t*)out_rows_dev[f];
@@ -1686,6 +1777,16 @@ extern "C" int rela_replay_remote_gather(rela_replay_remote* rr, int batch, void
       const int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (max_units + kThreads - 1) / kThreads), 64);
       hipLaunchKernelGGL(replay_gather_big, dim3(gx, std::min(max_y, 32768), nbig), dim3(kThreads), 0, s, big,
                          (const int32_t*)rr->ids, batch);
+    }
+    for (int q = 0; q < 2 && rr->dd_ups > 0; ++q) {  // stacks out of the owner's unit ring (as rela_replay_sample does locally)
+      const int f = rr->dd_field[q];
+      if (!out_rows_dev[f]) continue;
+      const int64_t nv = rr->dd_unit_bytes >> 4;
+      const int gx = (int)std::min<int64_t>(std::max<int64_t>(1, (nv + kThreads - 1) / kThreads), 64);
+      uint8_t* out = (uint8_t*)out_rows_dev[f] + (int64_t)out_offset * rr->dd_ups * rr->dd_unit_bytes;
+      hipLaunchKernelGGL(replay_gather_dedup, dim3(gx, std::min(batch * rr->dd_ups, 32768)), dim3(kThreads), 0, s,
+                         (const int32_t*)rr->fields[f], (const int32_t*)rr->ids, (const uint8_t*)rr->units, rr->dd_unit_bytes,
+                         rr->dd_ups, out, batch);
     }
   }
   RELA_LAUNCH_CHECK();

@@ -3,12 +3,14 @@
 IPC (rela_replay_export_ipc) and, on request, samples WITHOUT gathering (ids stay in its memory), reporting what a
 local gather of those ids holds so that the parent's remote gather can be checked.  Talks over stdin / stdout lines."""
 import ctypes as C
+import faulthandler
 import json
 import os
 import sys
 import time
 
 T0 = time.perf_counter()
+faulthandler.dump_traceback_later(150, exit=True)  # a blocked owner ends itself: the parent then fails instead of waiting
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -65,7 +65,9 @@ def test_descriptor_structs_match_the_header():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = ('#include <stdio.h>\n#include <stddef.h>\n#include "rela_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu %d\\n",'
            "sizeof(rela_replay_ipc_desc),sizeof(rela_replay_chunk_desc),offsetof(rela_replay_chunk_desc,nfds),"
-           "offsetof(rela_replay_chunk_desc,chunk_bytes),offsetof(rela_replay_chunk_desc,mapped_bytes),RELA_IPC_MAX_FDS);}")
+           "offsetof(rela_replay_chunk_desc,chunk_bytes),offsetof(rela_replay_chunk_desc,mapped_bytes),RELA_IPC_MAX_FDS);"
+           'printf("%zu %zu %zu\\n",offsetof(rela_replay_chunk_desc,dd_ups),offsetof(rela_replay_chunk_desc,dd_unit_bytes),'
+           "offsetof(rela_replay_chunk_desc,units_handle));}")
     exe = "/tmp/rela_desc_layout_%d" % os.getpid()
     subprocess.run(["gcc", "-x", "c", "-I", os.path.join(root, "include"), "-o", exe, "-"], input=src.encode(), check=True)
     try:
@@ -74,4 +76,5 @@ def test_descriptor_structs_match_the_header():
         os.unlink(exe)
     d = capi.ReplayChunkDesc
     assert [int(x) for x in out] == [C.sizeof(capi.ReplayIpcDesc), C.sizeof(d), d.nfds.offset, d.chunk_bytes.offset,
-                                     d.mapped_bytes.offset, capi.IPC_MAX_FDS]
+                                     d.mapped_bytes.offset, capi.IPC_MAX_FDS, d.dd_ups.offset, d.dd_unit_bytes.offset,
+                                     d.units_handle.offset]

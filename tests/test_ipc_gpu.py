@@ -114,6 +114,72 @@ def test_remote_gather_from_a_partition_hipipc_cannot_carry():
     assert hit == set(range(5)), hit
 
 
+@pytest.mark.parametrize("mode", ["stack", "plane"])
+def test_remote_gather_from_a_deduplicated_partition(mode):
+    """a de-duplicated partition (frame stacks once in a unit ring, transitions hold references; "plane": one
+    new 84x84 plane per env-step) crosses processes with its unit ring, and the learner-side gather rebuilds the stacks as
+    rela_replay_sample does in the owner.  The owner is fed by its actor shard from a frame stream this process
+    regenerates: every sampled transition must be obs = the env's stack at its tick (tags in the newest plane), next_obs =
+    the same env's stack n ticks later, action = what the owner stored -- while the owner's actors keep ticking between its
+    sample and this process's read (new units stored ahead; the slots the sample evicted are held)."""
+    import torch
+
+    from ipc_dedup_owner_child import B, NSTEP, A, frames
+    from rela_amd import _capi as capi
+    from rela_amd.parallel import _import_partition, ff_field_specs
+
+    stacks = frames(mode)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DEDUP=mode)
+    child = subprocess.Popen([sys.executable, os.path.join(HERE, "ipc_dedup_owner_child.py")], stdin=subprocess.PIPE,
+                             stdout=subprocess.PIPE, text=True, env=env)
+    try:
+        line = child.stdout.readline()
+        assert line.startswith("DESC2 "), line
+        _, sock, hexdesc = line.split()
+        raw = bytes.fromhex(hexdesc)
+        d = capi.ReplayChunkDesc.from_buffer_copy(raw)
+        ups = {"stack": 1, "plane": 4}[mode]
+        assert d.dd_ups == ups and list(d.dd_field) == [0, 1] and d.dd_unit_bytes == 28224 // ups and d.units_chunks >= 1
+        assert d.ipc.row_bytes[0] == 4 * ups  # references, not frames
+        rr = _import_partition(capi, C, {"partition": raw, "fd_socket": sock}, 0)
+        specs = ff_field_specs(A)
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        evicting = 0
+        for round_ in range(4):
+            child.stdin.write("sample\n")
+            child.stdin.flush()
+            line = child.stdout.readline()
+            assert line.startswith("SAMPLED "), line
+            exp = json.loads(line[8:])
+            assert exp["dev_error"] == 0
+            out = {sp.name: sp.empty(2 * B, "cuda") for sp in specs}  # this partition fills the second half of a batch
+            for t in out.values():
+                t.fill_(0)
+            rows = (C.c_void_p * len(specs))(*[out[sp.name].data_ptr() for sp in specs])
+            capi.check(capi.lib.rela_replay_remote_gather(rr, B, rows, None, None, 2 * B, B, stream), "rela_replay_remote_gather")
+            torch.cuda.synchronize()
+            s, ns = out["s"].cpu().numpy(), out["next_s"].cpu().numpy()
+            assert not s[:B].any() and not ns[:B].any()  # the other partition's half is untouched
+            for b in range(B):
+                t0, r0 = int(s[B + b, 3, 0, 0]), int(s[B + b, 3, 0, 1])
+                assert t0 + NSTEP < exp["tick"], (round_, b, t0)
+                assert np.array_equal(s[B + b], stacks[t0, r0]), (round_, b, t0, r0)
+                assert np.array_equal(ns[B + b], stacks[t0 + NSTEP, r0]), (round_, b, t0, r0)
+            assert out["a"][B:].cpu().numpy().tolist() == exp["a"], round_
+            evicting += exp["added_meanwhile"] < 3 * 12  # blocks were refused: the ring was full of live + held slots
+            child.stdin.write("update\n")
+            child.stdin.flush()
+            assert child.stdout.readline().startswith("UPDATED")
+        assert evicting >= 1, "no round ran against a full ring"
+        capi.lib.rela_replay_remote_close(rr)
+        child.stdin.write("quit\n")
+        child.stdin.flush()
+        assert child.wait(timeout=60) == 0
+    finally:
+        if child.poll() is None:
+            child.kill()
+
+
 def test_native_exchange_three_processes():
     """rela_amd.parallel's native data plane end to end with ONE learner process and TWO actor processes (all on
     cuda:0, gloo for the few control bytes): partitions exported through HIP IPC, every sampled row gathered by the
