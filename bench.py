@@ -1065,6 +1065,10 @@ def main():
                     help="N > 1: replicated (default) = actors + replay partition + learner replica on every rank, gradient "
                          "all-reduce; reference = the reference's own layout, ONE learner rank + N - 1 actor-only ranks "
                          "with replay partitions (pyrela/main.py:131-166, BASELINE C3 / C4)")
+    ap.add_argument("--allreduce", default="rccl", choices=["rccl", "ipc"],
+                    help="--layout replicated, N > 1: how the learner replicas sum their gradient buckets: rccl = torch.distributed "
+                         "(the default); ipc = rela_ipc_allreduce_* (include/rela_amd.h): peer reads of IPC-mapped buckets, summed "
+                         "in rank order, no collective library (validated with 2-3 processes on one GPU; same host only)")
     ap.add_argument("--exchange", default="native", choices=["native", "packed"],
                     help="--layout reference: how sampled rows and weights cross processes: native = partitions and flat "
                          "buffers mapped through HIP IPC, the learner's own gather kernel reads the rows over xGMI "
@@ -1121,7 +1125,7 @@ def main():
     from rela_amd import _capi as capi
     from rela_amd.engine import ApexActorEngine, FFNetHandle
     from rela_amd.engine import dev_view
-    from rela_amd.learner import HipApexLearner, allreduce_grads, global_is_weights
+    from rela_amd.learner import HipApexLearner, allreduce_grads, global_is_weights, sum_grads
     from rela_amd.pyrela.apex import ApexAgent
     from rela_amd.pyrela.net import AtariFFNet
     from rela_amd.replay import FFReplay
@@ -1144,6 +1148,10 @@ def main():
     target.set_precision(args.precision)
     if hip_learner is not None:  # the two gradient-free forwards of td_err; the pass feeding the backward stays f32
         hip_learner.set_precision(args.precision)
+        if world > 1 and args.allreduce == "ipc":  # gradient buckets mapped into every rank; no collective library
+            from rela_amd.parallel import IpcAllReduce
+
+            hip_learner.ipc_allreduce = IpcAllReduce(hip_learner.flat()[1])
 
     replay = FFReplay(args.replay_cap, SEED + rank, ALPHA, BETA, 0, NUM_ACTION, device, dedup=args.dedup,
                       guard_units=(MULTI_STEP + 8) * ROWS)
@@ -1272,9 +1280,7 @@ def main():
                     pending[0] = learner_sample()
                     hip_learner.grad()
                     if world > 1:
-                        g = hip_learner.flat()[1]
-                        dist.all_reduce(g, op=dist.ReduceOp.SUM)
-                        g.div_(world)
+                        sum_grads(hip_learner, world)
                     hip_learner.apply()
                 else:
                     learner_update(batch, weight)
@@ -1509,8 +1515,12 @@ def main():
         dtype = {"f32": "f32", "f32x3": DTYPE_F32X3}.get(args.precision, DTYPE_NOTE)
         comm = None if world == 1 else {"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size()
                                         if dist.get_backend() == "nccl" else 0, "ranks": dist.get_world_size(),
-                                        "collectives_per_step": "all-reduce SUM of the flat 6.8 MB gradient buffer; "
-                                                                "IS weights: SUM of the partition size + MAX of the weight maximum"}
+                                        "gradient_allreduce": args.allreduce,
+                                        "collectives_per_step": ("all-reduce SUM of the flat 6.8 MB gradient buffer"
+                                                                 if args.allreduce == "rccl" else
+                                                                 "gradient buckets summed by peer reads of IPC-mapped buffers "
+                                                                 "(rela_ipc_allreduce_run, no collective)")
+                                        + "; IS weights: SUM of the partition size + MAX of the weight maximum"}
         detail = {
             "metric": "env-steps/s (Ape-X Atari 84x84x4, actor tick + learner grad-step)",
             "value": head["env_steps_per_s"], "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,

@@ -684,6 +684,42 @@ int rela_ipc_export_buffer(const void* dev_ptr, unsigned char handle_out[64]);
 int rela_ipc_import_buffer(const unsigned char handle[64], void** dev_ptr_out, int device);
 int rela_ipc_close_buffer(void* dev_ptr, int device);
 
+/* ===================================================================================
+ * Gradient all-reduce over IPC-mapped buffers (r5; SURVEY 8e.  The reference has no counterpart: one learner,
+ * pyrela/main.py:206-251).  For the replicated layout -- one learner replica per GPU, one process per GPU -- the flat f32
+ * gradient bucket is summed over the ranks without a collective library: every rank maps every other rank's bucket;
+ * rank r sums slice r of all buckets IN RANK ORDER, ((g0 + g1) + g2) + ..., with peer reads, then copies every reduced slice
+ * out of its owner's memory.  All ranks end with bit-identical sums, equal to a host-side f32 sum in rank order.
+ *   every rank:  rela_ipc_allreduce_create(&ar, rank, world, bucket, count, device, device_flags, &desc)
+ *                exchange the descriptors (plain bytes, any means), in rank order:  rela_ipc_allreduce_connect(ar, descs)
+ *   every step:  rela_ipc_allreduce_run(ar, stream)    -- collective: every rank calls it once per step
+ *                bucket := sum over ranks, in place, ordered on `stream` like a kernel
+ * `bucket` must be device memory this library allocated (rela_apex_learner_flat's / rela_r2d2_learner_flat's gradients, or
+ * rela_ipc_alloc_buffer).  device_flags = 1: the phases are ordered by monotonic step counters in a shared page that the
+ * streams' command processors write and wait for (hipStreamWriteValue32 / hipStreamWaitValue32) -- no kernel spins, the
+ * host never waits; connect() tests these operations and ALL ranks fall back to mode 0 if any rank's fail.  Mode 0: a
+ * stream synchronisation and a host barrier (same page) per phase.  rela_ipc_allreduce_mode: what connect() settled on.
+ * Same host only.  csrc/ipc_allreduce.hip states the hazards.  Validated with two and three processes on ONE GPU
+ * (tests/test_ipc_allreduce_gpu.py); RCCL stays bench.py's default (`--allreduce ipc` selects this). */
+#define RELA_IPC_ALLREDUCE_MAX_RANKS 8
+typedef struct rela_ipc_allreduce rela_ipc_allreduce;
+typedef struct rela_ipc_allreduce_desc { /* plain bytes */
+  int32_t abi, rank, world, device, device_flags, pad;
+  int64_t count, bucket_offset; /* the bucket starts bucket_offset bytes into the allocation bucket_handle names */
+  unsigned char bucket_handle[64], red_handle[64];
+  char shm_name[64]; /* rank 0's descriptor: the shared-memory page of the counters and the host barrier */
+} rela_ipc_allreduce_desc;
+int rela_ipc_allreduce_create(rela_ipc_allreduce** out, int rank, int world, float* bucket_dev, int64_t count, int device,
+                              int device_flags, rela_ipc_allreduce_desc* desc_out);
+int rela_ipc_allreduce_connect(rela_ipc_allreduce* ar, const rela_ipc_allreduce_desc* descs /* [world], rank order */);
+int rela_ipc_allreduce_run(rela_ipc_allreduce* ar, void* stream);
+int rela_ipc_allreduce_mode(const rela_ipc_allreduce* ar); /* 1 = stream value operations, 0 = host synchronisation */
+void rela_ipc_allreduce_destroy(rela_ipc_allreduce* ar);
+/* exportable device memory for a caller that has none of the library's own (a Python learner's gradient bucket; tests):
+ * a plain allocation of its own, which rela_ipc_export_buffer / rela_ipc_allreduce_create can name */
+int rela_ipc_alloc_buffer(void** dev_ptr_out, int64_t bytes, int device);
+int rela_ipc_free_buffer(void* dev_ptr, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -49,6 +49,12 @@ class ReplayChunkDesc(C.Structure):  # rela_replay_chunk_desc
 IPC_MAX_FDS = 128
 
 
+class IpcAllreduceDesc(C.Structure):  # rela_ipc_allreduce_desc
+    _fields_ = [("abi", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("device", C.c_int32),
+                ("device_flags", C.c_int32), ("pad", C.c_int32), ("count", C.c_int64), ("bucket_offset", C.c_int64),
+                ("bucket_handle", C.c_ubyte * 64), ("red_handle", C.c_ubyte * 64), ("shm_name", C.c_char * 64)]
+
+
 class LSTMNetParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "conv3_w", "conv3_b", "w_ih",
                                           "w_hh", "b_ih", "b_hh", "v_w", "v_b", "a_w", "a_b")]
@@ -83,6 +89,13 @@ _sig("rela_memcpy_h2d_async", i32, [vp, vp, i64, vp, i32])
 _sig("rela_replay_set_decoupled_insert", i32, [vp, i32])
 _sig("rela_replay_export_ipc", i32, [vp, vp])
 _sig("rela_replay_import_ipc", i32, [P(vp), vp, i32])
+_sig("rela_ipc_allreduce_create", i32, [P(vp), i32, i32, vp, i64, i32, i32, vp])
+_sig("rela_ipc_allreduce_connect", i32, [vp, vp])
+_sig("rela_ipc_allreduce_run", i32, [vp, vp])
+_sig("rela_ipc_allreduce_mode", i32, [vp])
+_sig("rela_ipc_allreduce_destroy", None, [vp])
+_sig("rela_ipc_alloc_buffer", i32, [P(vp), i64, i32])
+_sig("rela_ipc_free_buffer", i32, [vp, i32])
 _sig("rela_replay_set_chunk_bytes", i32, [vp, i64])
 _sig("rela_runtime_set_replay_chunk_bytes", i32, [i64])
 _sig("rela_replay_export_chunks", i32, [vp, vp, P(i32), i32])

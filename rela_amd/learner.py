@@ -25,6 +25,19 @@ def allreduce_grads(params, world_size, group=None):
         off += n
 
 
+def sum_grads(learner, world_size, group=None):
+    """mean of the learner's flat gradient bucket over the ranks, in place.  learner.ipc_allreduce (an
+    rela_amd.parallel.IpcAllReduce over that bucket, set by the caller) replaces the collective library: peer reads of
+    IPC-mapped buckets, summed in rank order (csrc/ipc_allreduce.hip); otherwise torch.distributed (RCCL)."""
+    g = learner.flat()[1]
+    ar = getattr(learner, "ipc_allreduce", None)
+    if ar is not None:
+        ar.run()
+    else:
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+    g.div_(world_size)
+
+
 def global_is_weights(raw_w, partition_sum, partition_size, beta, group=None):
     """Importance weights of one replay PARTITION normalised over ALL partitions.
 
@@ -216,9 +229,7 @@ class HipApexLearner:
     def step(self, batch, weight, world_size=1, group=None):
         loss, prio = self.backward(batch, weight)
         if world_size > 1:  # replicated learners: one flat SUM all-reduce, then the mean
-            g = self.flat()[1]
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
-            g.div_(world_size)
+            sum_grads(self, world_size, group)
         self.apply()
         return loss, prio
 
@@ -405,9 +416,7 @@ class HipR2D2Learner:
     def step(self, batch, weight, world_size=1, group=None):
         loss, prio, _ = self.backward(batch, weight)
         if world_size > 1:
-            g = self.flat()[1]
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
-            g.div_(world_size)
+            sum_grads(self, world_size, group)
         self.apply()
         return loss, prio
 

@@ -590,3 +590,43 @@ class NativePartitionServer(PartitionServer):
         for p in self._flat_ptrs:
             self._capi.lib.rela_ipc_close_buffer(p, self.data_device.index or 0)
         self._flat_ptrs = []
+
+
+# ---- r5: gradient all-reduce over IPC-mapped buffers ---------------------------------------------------------------
+class IpcAllReduce:
+    """The replicated layout's gradient sum without a collective library (include/rela_amd.h: rela_ipc_allreduce_*):
+    `bucket` -- a flat f32 device buffer THIS LIBRARY allocated (HipApexLearner.flat()[1]) -- is summed in place over the
+    ranks of `group`, in rank order, bit-identically on every rank.  The descriptors (IPC handles of the buckets, the name
+    of the shared page of step counters) cross through one all_gather_object at construction; run() is then a collective
+    call without torch.distributed -- and, in mode 1 (stream value operations), without any host wait.  Same host only;
+    RCCL remains the default of bench.py."""
+
+    def __init__(self, bucket, group=None, device_flags=True):
+        import ctypes as C
+
+        from . import _capi as capi
+
+        assert bucket.is_cuda and bucket.dtype == torch.float32 and bucket.is_contiguous()
+        self._C, self._capi, self.bucket = C, capi, bucket
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.device = bucket.device
+        self.h = C.c_void_p()
+        desc = capi.IpcAllreduceDesc()
+        capi.check(capi.lib.rela_ipc_allreduce_create(C.byref(self.h), self.rank, self.world, C.c_void_p(bucket.data_ptr()),
+                                                      bucket.numel(), self.device.index or 0, int(bool(device_flags)),
+                                                      C.byref(desc)), "rela_ipc_allreduce_create")
+        raw = [None] * self.world
+        dist.all_gather_object(raw, bytes(desc), group=group)
+        descs = (capi.IpcAllreduceDesc * self.world)(*[capi.IpcAllreduceDesc.from_buffer_copy(b) for b in raw])
+        capi.check(capi.lib.rela_ipc_allreduce_connect(self.h, descs), "rela_ipc_allreduce_connect")
+        self.mode = capi.lib.rela_ipc_allreduce_mode(self.h)  # 1 = stream value operations, 0 = host synchronisation
+
+    def run(self, stream=None):
+        """bucket := sum over ranks, ordered on `stream` (default: torch's current stream of the bucket's device)"""
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._capi.check(self._capi.lib.rela_ipc_allreduce_run(self.h, self._C.c_void_p(s.cuda_stream)), "rela_ipc_allreduce_run")
+
+    def close(self):
+        if self.h:
+            self._capi.lib.rela_ipc_allreduce_destroy(self.h)
+            self.h = None
