@@ -715,6 +715,28 @@ int rela_ipc_allreduce_connect(rela_ipc_allreduce* ar, const rela_ipc_allreduce_
 int rela_ipc_allreduce_run(rela_ipc_allreduce* ar, void* stream);
 int rela_ipc_allreduce_mode(const rela_ipc_allreduce* ar); /* 1 = stream value operations, 0 = host synchronisation */
 void rela_ipc_allreduce_destroy(rela_ipc_allreduce* ar);
+/* A page of 32-bit words shared by the processes of one host and by their GPUs' command processors (r5; csrc/ipc_page.hip):
+ * the control plane of the native partition exchange.  POSIX shared memory, registered with HIP in every process, so a
+ * word can be written by a stream (after everything queued before it), waited for by a stream (>=: the command
+ * processor waits, no CU spins, the host goes on), read by a kernel (rela_ipc_page_dev_ptr) and read / written / waited
+ * for by host threads.  Step counters only grow, so a wait binds to a value: nothing to re-arm, nothing to acknowledge.
+ * rela_amd/parallel.py keeps, per partition g: sampled[g] (the owner's stream, after its gather-less sample), size[g]
+ * (the partition's item count of that sample), consumed[g] (the learner's stream, after its gather and its priorities) --
+ * the per-step gather of importance weights and scatter of priorities through torch.distributed are gone.       */
+#define RELA_IPC_PAGE_BYTES 4096
+typedef struct rela_ipc_page rela_ipc_page;
+int rela_ipc_page_create(rela_ipc_page** out, char name_out[64], int device); /* zeroed; send the name to the others */
+int rela_ipc_page_open(rela_ipc_page** out, const char* name, int device);
+int rela_ipc_page_unlink(rela_ipc_page* p); /* the creator, once everyone has opened it */
+void rela_ipc_page_close(rela_ipc_page* p);
+void* rela_ipc_page_host_ptr(rela_ipc_page* p);
+void* rela_ipc_page_dev_ptr(rela_ipc_page* p);
+int rela_ipc_page_write32(rela_ipc_page* p, int word, uint32_t value, void* stream); /* stream operation */
+int rela_ipc_page_wait32(rela_ipc_page* p, int word, uint32_t value, void* stream);  /* stream operation: word >= value */
+int rela_ipc_page_host_store32(rela_ipc_page* p, int word, uint32_t value);
+int rela_ipc_page_host_load32(rela_ipc_page* p, int word, uint32_t* value_out);
+int rela_ipc_page_host_wait32(rela_ipc_page* p, int word, uint32_t value, double timeout_s); /* RELA_EWOULDBLOCK on timeout */
+int rela_ipc_page_selftest(rela_ipc_page* p, int word, uint32_t value, int* ok_out); /* do the stream operations work here? */
 /* exportable device memory for a caller that has none of the library's own (a Python learner's gradient bucket; tests):
  * a plain allocation of its own, which rela_ipc_export_buffer / rela_ipc_allreduce_create can name */
 int rela_ipc_alloc_buffer(void** dev_ptr_out, int64_t bytes, int device);

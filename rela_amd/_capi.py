@@ -94,6 +94,18 @@ _sig("rela_ipc_allreduce_connect", i32, [vp, vp])
 _sig("rela_ipc_allreduce_run", i32, [vp, vp])
 _sig("rela_ipc_allreduce_mode", i32, [vp])
 _sig("rela_ipc_allreduce_destroy", None, [vp])
+_sig("rela_ipc_page_create", i32, [P(vp), C.c_char_p, i32])
+_sig("rela_ipc_page_open", i32, [P(vp), C.c_char_p, i32])
+_sig("rela_ipc_page_unlink", i32, [vp])
+_sig("rela_ipc_page_close", None, [vp])
+_sig("rela_ipc_page_host_ptr", vp, [vp])
+_sig("rela_ipc_page_dev_ptr", vp, [vp])
+_sig("rela_ipc_page_write32", i32, [vp, i32, C.c_uint32, vp])
+_sig("rela_ipc_page_wait32", i32, [vp, i32, C.c_uint32, vp])
+_sig("rela_ipc_page_host_store32", i32, [vp, i32, C.c_uint32])
+_sig("rela_ipc_page_host_load32", i32, [vp, i32, P(C.c_uint32)])
+_sig("rela_ipc_page_host_wait32", i32, [vp, i32, C.c_uint32, f64])
+_sig("rela_ipc_page_selftest", i32, [vp, i32, C.c_uint32, P(i32)])
 _sig("rela_ipc_alloc_buffer", i32, [P(vp), i64, i32])
 _sig("rela_ipc_free_buffer", i32, [vp, i32])
 _sig("rela_replay_set_chunk_bytes", i32, [vp, i64])

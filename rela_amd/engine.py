@@ -72,7 +72,7 @@ class _DevMem:
 
 
 def dev_view(ptr, shape, dtype, device):
-    typestr = {torch.uint8: "|u1", torch.float32: "<f4", torch.int64: "<i8"}[dtype]
+    typestr = {torch.uint8: "|u1", torch.float32: "<f4", torch.int64: "<i8", torch.int32: "<i4"}[dtype]
     return torch.as_tensor(_DevMem(ptr, shape, typestr), device=device)
 
 

@@ -35,9 +35,18 @@ RNNReplay): the sampled ROWS no longer travel through a collective.  Every parti
 (include/rela_amd.h: rela_replay_export_ipc) and mapped into the learner process; per step the owner only SAMPLES
 (ids, raw weights, eviction -- no gather), the learner's own gather kernel reads the B / G rows of every partition out
 of the owner's HBM (peer reads over xGMI between GPUs) straight into its batch tensors, and the weight publish maps
-the learner's flat parameter buffers into the actor processes, which load their nets from them directly.  What is left
-on torch.distributed: rendezvous, the command words, the B / G importance weights (the gather of 4 B / G bytes per rank
-doubles as "my sample has completed") and the B / G priorities back (doubles as "the learner has read your rows").
+the learner's flat parameter buffers into the actor processes, which load their nets from them directly.  What was left
+on torch.distributed in r4: rendezvous, the command words, the B / G importance weights (the gather of 4 B / G bytes per
+rank doubled as "my sample has completed") and the B / G priorities back (doubled as "the learner has read your rows").
+
+r5, control = "slots" (the default): the per-step collectives are gone as well.  A page of step counters shared by the
+processes and by their GPUs' command processors (include/rela_amd.h: rela_ipc_page_*) carries the ordering -- the owner's
+stream writes sampled[g] = k behind its sample, the learner waits for that word (a host wait at the moment it needs the
+batch; nothing is parked in a stream), gathers rows AND raw weights, computes
+the importance weights over all partitions itself (the partitions' sizes ride in the page), writes the priorities into
+a buffer the owners have mapped and writes consumed[g] = k; the owner's serving thread waits for that word on the HOST
+(the release of the slots it held is host bookkeeping) and updates from the mapped buffer.  No GPU synchronisation, no
+collective, no command word per step; torch.distributed keeps rendezvous and the publish / stop words.
 """
 import os
 
@@ -417,16 +426,83 @@ def _import_partition(capi, C, entry, dev_index):
     return rr
 
 
+# word indices in the shared control page (include/rela_amd.h: rela_ipc_page_*), one 64-byte line per partition and use
+_W_SAMPLED, _W_CONSUMED, _W_SIZE, _W_TEST = 0, 256, 512, 768
+
+
+class _ControlPage:
+    """ctypes handle on a rela_ipc_page: step counters written / waited for by STREAMS of any process of the host"""
+
+    def __init__(self, device, name=None):
+        import ctypes as C
+
+        from . import _capi as capi
+        from .engine import dev_view
+
+        self._C, self._capi, self.device = C, capi, torch.device(device)
+        self.h = C.c_void_p()
+        if name is None:
+            buf = C.create_string_buffer(64)
+            capi.check(capi.lib.rela_ipc_page_create(C.byref(self.h), buf, self.device.index or 0), "rela_ipc_page_create")
+            self.name = buf.value.decode()
+        else:
+            capi.check(capi.lib.rela_ipc_page_open(C.byref(self.h), name.encode(), self.device.index or 0), "rela_ipc_page_open")
+            self.name = name
+        # the page as kernels of this process see it (sizes are read by the learner's weight computation)
+        self.words = dev_view(capi.lib.rela_ipc_page_dev_ptr(self.h), (1024,), torch.int32, self.device)
+
+    def _stream(self):
+        return self._C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def write(self, word, value):
+        self._capi.check(self._capi.lib.rela_ipc_page_write32(self.h, word, value, self._stream()), "rela_ipc_page_write32")
+
+    def wait(self, word, value):
+        self._capi.check(self._capi.lib.rela_ipc_page_wait32(self.h, word, value, self._stream()), "rela_ipc_page_wait32")
+
+    def host_wait(self, word, value, timeout=600.0):
+        self._capi.check(self._capi.lib.rela_ipc_page_host_wait32(self.h, word, value, timeout), "rela_ipc_page_host_wait32")
+
+    def selftest(self, word):
+        ok = self._C.c_int(0)
+        self._capi.check(self._capi.lib.rela_ipc_page_selftest(self.h, word, 1, self._C.byref(ok)), "rela_ipc_page_selftest")
+        return bool(ok.value)
+
+    def unlink(self):
+        self._capi.lib.rela_ipc_page_unlink(self.h)
+
+    def close(self):
+        if self.h:
+            self.words = None
+            self._capi.lib.rela_ipc_page_close(self.h)
+            self.h = None
+
+
+def _agree_on_slots(page, rank, group):
+    """every rank tests the stream operations on the page; the slot protocol is used only if ALL can"""
+    ok = [None] * dist.get_world_size(group)
+    dist.all_gather_object(ok, bool(page is not None and page.selftest(_W_TEST + 16 * rank)), group=group)
+    return all(ok)
+
+
 class NativePartitionedReplay(PartitionedReplay):
     """Learner side of the native exchange: as PartitionedReplay, but a sample gathers the rows itself out of the
     partitions' memory (rela_replay_remote_gather); only the importance weights arrive through the collective."""
 
-    def __init__(self, specs, batch, beta, device, learner_rank=0, group=None, scheduled=False, flats=(), data_device=None):
+    def __init__(self, specs, batch, beta, device, learner_rank=0, group=None, scheduled=False, flats=(), data_device=None,
+                 control="slots"):
         """device: where the few control tensors of the collectives live (the GPU under RCCL, "cpu" under gloo);
-        data_device: the learner's GPU, where the batch tensors live and the gather kernels run (default: device)"""
+        data_device: the learner's GPU, where the batch tensors live and the gather kernels run (default: device);
+        control: "slots" (r5) -- per step NOTHING goes through torch.distributed: the owners' streams publish "sampled"
+        step counters and their partition sizes in a shared page, this rank waits for those words, gathers rows and raw
+        weights itself, computes the importance weights over all partitions, writes the priorities into a buffer the
+        owners have mapped and publishes "consumed" counters (include/rela_amd.h: rela_ipc_page_*) -- or "collective"
+        (r4: a gather of the weights and a scatter of the priorities per step).  Falls back to "collective" when the
+        stream operations fail any rank's self-test."""
         import ctypes as C
 
         from . import _capi as capi
+        from .engine import dev_view
 
         super().__init__(specs, batch, beta, device, learner_rank, group, scheduled)
         self._C, self._capi = C, capi
@@ -434,8 +510,20 @@ class NativePartitionedReplay(PartitionedReplay):
         assert self.data_device.type == "cuda", "the native exchange gathers on a GPU"
         if self.data_device != self.device:
             self._out = [{sp.name: sp.empty(self.batch, self.data_device) for sp in specs} for _ in range(2)]
+        dev_index = self.data_device.index or 0
+        control = os.environ.get("RELA_EXCHANGE_CONTROL", control)
+        assert control in ("slots", "collective")
         # rendezvous of the descriptors: every actor rank contributes its partition's, the learner its flat buffers'
-        mine = {"flats": []}
+        mine = {"flats": [], "control": control}
+        self._page = self._prio_ptr = None
+        if control == "slots":
+            self._page = _ControlPage(self.data_device)
+            self._prio_ptr = C.c_void_p()  # (library memory: torch's allocator hands out pieces of blocks that do not export)
+            capi.check(capi.lib.rela_ipc_alloc_buffer(C.byref(self._prio_ptr), max(4096, 4 * self.batch), dev_index), "alloc")
+            h = (C.c_ubyte * 64)()
+            capi.check(capi.lib.rela_ipc_export_buffer(self._prio_ptr, h), "rela_ipc_export_buffer")
+            self._prio_ipc = dev_view(self._prio_ptr.value, (self.batch,), torch.float32, self.data_device)
+            mine["page"], mine["prio"] = self._page.name, bytes(h)
         for f in flats:  # device buffers of the learner (rela_*_learner_flat): mapped by the actor ranks for publish
             h = (C.c_ubyte * 64)()
             capi.check(capi.lib.rela_ipc_export_buffer(C.c_void_p(f.data_ptr()), h), "rela_ipc_export_buffer")
@@ -443,7 +531,6 @@ class NativePartitionedReplay(PartitionedReplay):
         descs = [None] * self.world
         dist.all_gather_object(descs, mine, group=group)
         self._remote = []
-        dev_index = self.data_device.index or 0
         for r in self.actor_ranks:  # IPC handles for the small arrays, file descriptors for the chunks of the large ones
             self._remote.append(_import_partition(capi, C, descs[r], dev_index))
         # the packed record of a rank shrinks to its importance weights
@@ -451,10 +538,74 @@ class NativePartitionedReplay(PartitionedReplay):
         self.rank_bytes = _pad16(4 * self.b_local)
         self._recv = [torch.empty(self.world * self.rank_bytes, dtype=torch.uint8, device=self.device) for _ in range(2)]
         self.native = True
+        self.slots = control == "slots" and _agree_on_slots(self._page, self.rank, group)
+        if self._page is not None:
+            self._page.unlink()  # every rank has opened it by now
+        if self.slots:
+            dd = self.data_device
+            self._k = 0                       # steps sampled so far
+            self._slot_step = [0, 0]
+            self._raw = torch.empty((self.G, self.b_local), dtype=torch.float32, device=dd)
+            self._sum = torch.empty((self.G, 1), dtype=torch.float32, device=dd)
+            self._w = [torch.empty(self.batch, dtype=torch.float32, device=dd) for _ in range(2)]
+            self._size_idx = torch.tensor([_W_SIZE + 16 * g for g in range(self.G)], dtype=torch.int64, device=dd)
+
+    def sample(self, async_op=False):
+        if not self.slots:
+            return super().sample(async_op)
+        assert not self._outstanding, "Error: previous samples' priority has not been updated."  # :203-206
+        if self.scheduled:
+            assert self._left > 0, "scheduled mode: publish(..., steps=n) announces the next n sample / update pairs"
+        else:
+            self._bcast_cmd(CMD_SAMPLE)
+        slot = self._slot
+        self._slot ^= 1
+        self._k += 1
+        self._slot_step[slot] = self._k
+        self._outstanding = True
+        pending = _PendingSample(self, slot, None)
+        return pending if async_op else pending.wait()
+
+    def _gather(self, slot):
+        """wait -- on the HOST, at the last moment -- until every owner's stream has published `sampled` = this step, then
+        queue on the caller's stream: rows and raw weights out of the partitions, importance weights over all of them
+        (learner.global_is_weights' arithmetic, computed here).  The wait is not parked in a stream: a stream that
+        waits for a word blocks the hardware queue it shares with other streams of the process, and a prefetched sample
+        measured twice as slow that way (one-GPU rehearsal: 20.7 ms per step against 10.5)."""
+        C, capi, k = self._C, self._capi, self._slot_step[slot]
+        out = self._out[slot]
+        for g in range(self.G):
+            self._page.host_wait(_W_SAMPLED + 16 * g, k)
+        with torch.cuda.device(self.data_device):
+            stream = C.c_void_p(torch.cuda.current_stream(self.data_device).cuda_stream)
+            rows = (C.c_void_p * len(self.specs))(*[out[sp.name].data_ptr() for sp in self.specs])
+            for g, rr in enumerate(self._remote):
+                capi.check(capi.lib.rela_replay_remote_gather(
+                    rr, self.b_local, rows, C.c_void_p(self._raw[g].data_ptr()), C.c_void_p(self._sum[g].data_ptr()), self.batch,
+                    g * self.b_local, stream), "rela_replay_remote_gather")
+            total = self._page.words[self._size_idx].to(torch.float64).sum()
+            w = (total.float() * (self._raw / (float(self.G) * self._sum))).pow(-self.beta)
+            torch.div(w, w.max(), out=self._w[slot].view(self.G, self.b_local))
+
+    def update_priority(self, priority):
+        if not self.slots:
+            return super().update_priority(priority)
+        assert self._outstanding and priority.numel() == self.batch
+        if self.scheduled:
+            self._left -= 1
+        else:
+            self._bcast_cmd(CMD_UPDATE)
+        self._prio_ipc.copy_(priority.detach().reshape(-1))  # the owners read their slices out of this buffer
+        for g in range(self.G):
+            self._page.write(_W_CONSUMED + 16 * g, self._k)  # ... once their host threads have seen this counter
+        self._outstanding = False
 
     def _unpack(self, slot):
         C, capi = self._C, self._capi
         out = self._out[slot]
+        if self.slots:
+            self._gather(slot)
+            return out, self._w[slot]
         stream = C.c_void_p(torch.cuda.current_stream(self.data_device).cuda_stream)
         rows = (C.c_void_p * len(self.specs))(*[out[sp.name].data_ptr() for sp in self.specs])
         for g, rr in enumerate(self._remote):  # peer reads of B / G rows per partition, straight into the batch
@@ -479,6 +630,11 @@ class NativePartitionedReplay(PartitionedReplay):
         for rr in self._remote:
             self._capi.lib.rela_replay_remote_close(rr)
         self._remote = []
+        if self._page is not None:
+            torch.cuda.synchronize(self.data_device)
+            self._page.close()
+            self._capi.lib.rela_ipc_free_buffer(self._prio_ptr, self.data_device.index or 0)
+            self._page = None
 
 
 class _CapiNativePartition:
@@ -552,6 +708,19 @@ class NativePartitionServer(PartitionServer):
         self._fd_server = _FdServer(fds) if fds else None  # listening BEFORE the learner learns its name
         dist.all_gather_object(descs, {"partition": desc, "fd_socket": self._fd_server.name if fds else None}, group=group)
         dev_index = self.data_device.index or 0
+        # the slot protocol (NativePartitionedReplay: control): the learner's control page and priority buffer
+        ld = descs[learner_rank]
+        self._page = self._prio_ptr = None
+        self._g = self.actor_ranks.index(self.rank)
+        self._k = 0
+        if ld.get("control") == "slots":
+            self._page = _ControlPage(self.data_device, ld["page"])
+            self._prio_ptr = C.c_void_p()
+            capi.check(capi.lib.rela_ipc_import_buffer((C.c_ubyte * 64).from_buffer_copy(ld["prio"]), C.byref(self._prio_ptr),
+                                                       dev_index), "rela_ipc_import_buffer")
+            self._prio_view = dev_view(self._prio_ptr.value, (self.batch,), torch.float32, self.data_device)[
+                self._g * self.b_local:(self._g + 1) * self.b_local]
+        self.slots = ld.get("control") == "slots" and _agree_on_slots(self._page, self.rank, group)
         self._flat_ptrs, self._flats = [], []
         for h, n in descs[learner_rank]["flats"]:  # map the learner's flat parameter buffers
             p = C.c_void_p()
@@ -567,6 +736,13 @@ class NativePartitionServer(PartitionServer):
         dd = self.data_device
         # ids, raw weights and eviction only: the rows stay where they are, the learner reads them
         raw_w, part_sum, size = self.replay.sample_ids(self.b_local)
+        if self.slots:  # size and step counter follow the sample in stream order; the host does not wait for anything
+            self._k += 1
+            with torch.cuda.device(dd):
+                self._page.write(_W_SIZE + 16 * self._g, int(size))
+                self._page.write(_W_SAMPLED + 16 * self._g, self._k)
+            self.served += 1
+            return
         raw_w, part_sum = raw_w.to(self.device), part_sum.to(self.device)
         weight = global_is_weights(raw_w, part_sum, size, self.beta, group=self.actor_group)
         self._send[:4 * self.b_local].view(torch.float32).copy_(weight.float())
@@ -575,6 +751,10 @@ class NativePartitionServer(PartitionServer):
         self.served += 1
 
     def _update_step(self):
+        if self.slots:  # a HOST wait (the release of the held slots is host bookkeeping), but no GPU synchronisation
+            self._page.host_wait(_W_CONSUMED + 16 * self._g, self._k)  # = "your rows were read, your priorities are written"
+            self.replay.update_priority(self._prio_view)
+            return
         dist.scatter(self._prio_recv, None, src=self.learner_rank, group=self.group)  # = "your rows were read"
         self.replay.update_priority(self._prio_recv)
 
@@ -590,6 +770,12 @@ class NativePartitionServer(PartitionServer):
         for p in self._flat_ptrs:
             self._capi.lib.rela_ipc_close_buffer(p, self.data_device.index or 0)
         self._flat_ptrs = []
+        if self._page is not None:
+            torch.cuda.synchronize(self.data_device)
+            self._prio_view = None
+            self._capi.lib.rela_ipc_close_buffer(self._prio_ptr, self.data_device.index or 0)
+            self._page.close()
+            self._page = None
 
 
 # ---- r5: gradient all-reduce over IPC-mapped buffers ---------------------------------------------------------------

@@ -53,8 +53,10 @@ if rank == 0:
         assert np.array_equal(fields["reward"].cpu().numpy(), (a % 1000).astype(np.float32))
         wc = w.cpu().numpy()
         assert wc.max() == 1.0 and (wc > 0).all() and np.isfinite(wc).all()
+        print("WEIGHTS %d %s" % (r, wc.tobytes().hex()), flush=True)  # (the parent compares the two control planes bit for bit)
         rep.update_priority(torch.full((BATCH,), 0.5 + 0.1 * r, device=dev))
     rep.stop()
+    print("CONTROL %s" % ("slots" if rep.slots else "collective"), flush=True)
     rep.close()
     print("LEARNER OK", flush=True)
 else:

@@ -180,12 +180,7 @@ def test_remote_gather_from_a_deduplicated_partition(mode):
             child.kill()
 
 
-def test_native_exchange_three_processes():
-    """rela_amd.parallel's native data plane end to end with ONE learner process and TWO actor processes (all on
-    cuda:0, gloo for the few control bytes): partitions exported through HIP IPC, every sampled row gathered by the
-    learner's own kernel out of the owners' memory into the right slice of the batch (tags checked per partition, in
-    sync and asynchronous sampling), importance weights normalised over both partitions, priorities back, and the
-    weight publish read by the actors straight from the learner's mapped flat buffers."""
+def _native_exchange(control):
     import socket
 
     sk = socket.socket()
@@ -195,7 +190,7 @@ def test_native_exchange_three_processes():
     procs = []
     for r in range(3):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+                   MASTER_PORT=str(port), RELA_EXCHANGE_CONTROL=control)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "native_exchange_child.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
@@ -210,3 +205,21 @@ def test_native_exchange_three_processes():
     for r, (rc, o, e) in enumerate(outs):
         assert rc == 0, "rank %d: %s\n%s" % (r, o[-1500:], e[-3000:])
     assert "LEARNER OK" in outs[0][1] and "ACTOR 1 OK" in outs[1][1] and "ACTOR 2 OK" in outs[2][1]
+    assert ("CONTROL %s" % control) in outs[0][1], outs[0][1][-300:]  # (slots: the stream operations passed every self-test)
+    return [ln for ln in outs[0][1].splitlines() if ln.startswith("WEIGHTS ")]
+
+
+def test_native_exchange_three_processes():
+    """rela_amd.parallel's native data plane end to end with ONE learner process and TWO actor processes (all on
+    cuda:0, gloo for rendezvous and command words): partitions exported (one through IPC handles, one in chunks), every
+    sampled row gathered by the learner's own kernel out of the owners' memory into the right slice of the batch (tags
+    checked per partition, in sync and asynchronous sampling), importance weights normalised over both partitions,
+    priorities back, and the weight publish read by the actors straight from the learner's mapped flat buffers.
+    Run with BOTH control planes: r5's slots (step counters in a shared page written and waited for by the streams,
+    weights computed by the learner, priorities read by the owners from a mapped buffer: nothing per step on
+    torch.distributed) and r4's collectives -- the importance weights of all four rounds must agree bit for bit."""
+    slots = _native_exchange("slots")
+    collective = _native_exchange("collective")
+    assert len(slots) == 4 and slots == collective
+
+
