@@ -15,6 +15,9 @@
 //   hipStreamWriteValue32(stream, &mine[rank], step)            -- after everything queued before it, with release semantics
 //   hipStreamWaitValue32(stream, &theirs[p], step, >=)  for all p -- a wait of the stream's command processor, not of a CU
 // Counters only grow, so a wait binds to a VALUE and there is nothing to re-arm: no host barrier, no ring of signals.
+// (A stream that waits for a word blocks the hardware queue it shares with other streams of the process: right here, where
+// the learner's stream has to wait for its peers' gradients anyway; the partition exchange, whose waits would sit in a
+// prefetching side stream, waits on the host instead -- rela_amd/parallel.py.)
 // (Interprocess events, hipIpcGetEventHandle, were the first implementation: on this runtime an event can be recorded 32
 // times, the 33rd hipStreamWaitEvent in another process returns "invalid argument" -- profiles/r05_ipc_event_ring_limit.log.)
 // device_flags = 0, or a runtime on which the stream value operations fail the self-test of connect(): every phase
