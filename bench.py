@@ -1187,6 +1187,9 @@ def main():
     else:
         main_stream = torch.cuda.current_stream(device)
 
+    if os.environ.get("RELA_BENCH_ONE_STREAM", "0") == "1":  # diagnosis: actor tick and learner step strictly one after the
+        actor_stream = main_stream                           # other (the replay keeps its own streams)
+
     def actor_tick():
         i = step_idx[0] % n_pool
         with torch.cuda.stream(actor_stream):
@@ -1253,6 +1256,34 @@ def main():
     # diagnosis only (RELA_BENCH_ONLY=actor|learner): time one side alone; the JSON line says so
     ONLY = os.environ.get("RELA_BENCH_ONLY", "")
 
+    class _HostLaps:
+        """RELA_BENCH_HOSTTIME=1: where the HOST's time per step goes (the calls only queue work; none waits for the GPU
+        by design, so a long lap is launch overhead or a hidden wait)"""
+
+        def __init__(self, on):
+            self.on, self.t, self.acc, self.n = on, 0.0, {}, 0
+
+        def lap(self, name):
+            if not self.on:
+                return
+            now = time.perf_counter()
+            if name is None:
+                self.n += 1
+            else:
+                self.acc[name] = self.acc.get(name, 0.0) + now - self.t
+            self.t = now
+
+        def report(self):
+            if self.on and self.n:
+                print("[bench] host us per step: " + ", ".join("%s %.0f" % (k, v / self.n * 1e6) for k, v in self.acc.items()),
+                      file=sys.stderr, flush=True)
+                self.acc, self.n = {}, 0
+
+    HOST_LAPS = _HostLaps(os.environ.get("RELA_BENCH_HOSTTIME") == "1")
+    # RELA_BENCH_JOIN=0 (diagnosis): the learner's stream does not wait for the tick at the end of every step (the publish
+    # every 20 steps still orders the two)
+    JOIN = os.environ.get("RELA_BENCH_JOIN", "1") == "1"
+
     def one_step():
         # One step = one learner update + one actor tick, sharing the GPU.  Order of the host calls:
         #  1. sample      -- a handful of launches; sees the replay as the previous tick left it (had
@@ -1261,30 +1292,40 @@ def main():
         #  2. actor tick  -- a dozen launches on actor_stream, ~3 ms of GPU work
         #  3. loss / backward / optimiser / update_priority -- ~150 eager PyTorch launches whose
         #                    host-side cost now overlaps the tick's GPU work instead of preceding it
+        lap = HOST_LAPS.lap
         with torch.cuda.stream(main_stream):
+            lap(None)
             if ONLY != "actor":
                 learner_housekeeping()
                 if pending[0] is None:
                     pending[0] = learner_sample()
                 batch, weight, size_at_sample = pending[0]
                 pending[0] = None
+                lap("housekeeping")
             if ONLY != "learner":
                 actor_tick()
+                lap("actor_tick")
             if ONLY != "actor":
                 if PIPE:
                     replay.wait()  # the batch sampled during the previous step's backward half
                 weight = global_weights(weight, size_at_sample)
                 if PIPE:
                     loss, prio = hip_learner.loss(batch, weight)
+                    lap("loss")
                     replay.update_priority(prio)
+                    lap("update_priority")
                     pending[0] = learner_sample()
+                    lap("sample")
                     hip_learner.grad()
+                    lap("grad")
                     if world > 1:
                         sum_grads(hip_learner, world)
                     hip_learner.apply()
+                    lap("apply")
                 else:
                     learner_update(batch, weight)
-            main_stream.wait_stream(actor_stream)
+            if JOIN:
+                main_stream.wait_stream(actor_stream)
 
     # fill the ring to capacity (untimed): real ticks for the history, then bulk inserts
     for _ in range(MULTI_STEP + 1):
@@ -1322,8 +1363,13 @@ def main():
         sync_all()
         t0 = time.perf_counter()
         run_steps(k)
+        t_issue = time.perf_counter() - t0
         sync_all()
         dt = time.perf_counter() - t0
+        if os.environ.get("RELA_BENCH_HOSTTIME") == "1":  # diagnosis: is the host (launches) or the GPU the longer pole?
+            print("[bench] %d steps: host issued them in %.3f ms per step, done after %.3f ms per step" % (
+                k, t_issue / k * 1e3, dt / k * 1e3), file=sys.stderr, flush=True)
+            HOST_LAPS.report()
         if world > 1:
             t = torch.tensor([dt], device=device, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
