@@ -232,8 +232,7 @@ extern "C" int rela_apex_actor_act(rela_apex_actor* a, const rela_ffnet* online,
     RELA_HIP(hipMemcpyAsync(a->legal, legal_host, (size_t)a->R * a->A * sizeof(float), hipMemcpyHostToDevice, s));
   float* eps_s = a->eps_hist + (size_t)slot * a->R;
   float* legal_s = a->legal_hist + (size_t)slot * a->R * a->A;
-  RELA_HIP(hipMemcpyAsync(eps_s, a->eps, (size_t)a->R * sizeof(float), hipMemcpyDeviceToDevice, s));
-  RELA_HIP(hipMemcpyAsync(legal_s, a->legal, (size_t)a->R * a->A * sizeof(float), hipMemcpyDeviceToDevice, s));
+  RELA_HIP(dev_copy2(eps_s, a->eps, (size_t)a->R * sizeof(float), legal_s, a->legal, (size_t)a->R * a->A * sizeof(float), s));
   float* q_s = a->q_hist + (size_t)slot * a->R * a->A;
   a->qh_net[slot] = nullptr;
   int rc = rela_ffnet_forward(online, a->R, obs, legal_s, q_s, a->ws, a->ws_bytes, s);
@@ -264,9 +263,13 @@ extern "C" int rela_apex_actor_post_step(rela_apex_actor* a, const float* reward
   hipStream_t s = (hipStream_t)stream_;
   DeviceGuard g(a->device);
   if (inserted) *inserted = 0;
-  const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  RELA_HIP(hipMemcpyAsync(a->rew + (size_t)a->cur * a->R, reward, (size_t)a->R * sizeof(float), kind, s));
-  RELA_HIP(hipMemcpyAsync(a->term + (size_t)a->cur * a->R, terminal, (size_t)a->R, kind, s));
+  if (on_device) {  // one launch (common.h: dev_copy2), not two of the runtime's blit kernels
+    RELA_HIP(dev_copy2(a->rew + (size_t)a->cur * a->R, reward, (size_t)a->R * sizeof(float), a->term + (size_t)a->cur * a->R, terminal,
+                       (size_t)a->R, s));
+  } else {
+    RELA_HIP(hipMemcpyAsync(a->rew + (size_t)a->cur * a->R, reward, (size_t)a->R * sizeof(float), hipMemcpyHostToDevice, s));
+    RELA_HIP(hipMemcpyAsync(a->term + (size_t)a->cur * a->R, terminal, (size_t)a->R, hipMemcpyHostToDevice, s));
+  }
   const int H = a->n + 1;
   if (a->dd_ups > 0) {
     // de-duplicated replay: the stack acted on this tick enters the unit ring ONCE (one plane, or the whole

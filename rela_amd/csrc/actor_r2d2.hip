@@ -398,12 +398,10 @@ extern "C" int rela_r2d2_actor_act(rela_r2d2_actor* a, const rela_lstmnet* onlin
   if (eps_host) RELA_HIP(hipMemcpyAsync(a->eps, eps_host, R * sizeof(float), hipMemcpyHostToDevice, s));
   if (legal_host) RELA_HIP(hipMemcpyAsync(a->legal, legal_host, R * a->A * sizeof(float), hipMemcpyHostToDevice, s));
   // historyHidden_.push_back(hidden_) :226-228
-  RELA_HIP(hipMemcpyAsync(a->hist_h + (size_t)slot * R * kHid, a->hid_h, HB, hipMemcpyDeviceToDevice, s));
-  RELA_HIP(hipMemcpyAsync(a->hist_c + (size_t)slot * R * kHid, a->hid_c, HB, hipMemcpyDeviceToDevice, s));
+  RELA_HIP(dev_copy2(a->hist_h + (size_t)slot * R * kHid, a->hid_h, HB, a->hist_c + (size_t)slot * R * kHid, a->hid_c, HB, s));
   float* eps_s = a->eps_hist + (size_t)slot * R;
   float* legal_s = a->legal_hist + (size_t)slot * R * a->A;
-  RELA_HIP(hipMemcpyAsync(eps_s, a->eps, R * sizeof(float), hipMemcpyDeviceToDevice, s));
-  RELA_HIP(hipMemcpyAsync(legal_s, a->legal, R * a->A * sizeof(float), hipMemcpyDeviceToDevice, s));
+  RELA_HIP(dev_copy2(eps_s, a->eps, R * sizeof(float), legal_s, a->legal, R * a->A * sizeof(float), s));
   // (the dueling Q of this step goes to the slot's table: compute_priority's online_net(obs, hid) n ticks from now)
   a->qh_net[slot] = nullptr;
   int rc = rela_lstmnet_step(online, a->R, obs, legal_s, a->hid_h, a->hid_c, a->tmp_h, a->tmp_c,

@@ -108,6 +108,32 @@ struct HostStage {
   }
 };
 
+// Two small device-to-device copies as ONE kernel launch.  A tick copies a few KB four times (eps / legal moves into their
+// history slots, rewards / terminals into theirs); as hipMemcpyAsync these are blit kernels of the runtime, and the kernel
+// that follows one starts ~25 us late (profiles/r05_trace_gaps.txt: "after __amd_rocclr_copyBuffer before conv12_s3").
+__global__ static void dev_copy2_kernel(uint8_t* __restrict__ d0, const uint8_t* __restrict__ s0, size_t n0,
+                                        uint8_t* __restrict__ d1, const uint8_t* __restrict__ s1, size_t n1) {
+  const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  uint8_t* d = blockIdx.y ? d1 : d0;
+  const uint8_t* s = blockIdx.y ? s1 : s0;
+  const size_t n = blockIdx.y ? n1 : n0;
+  if ((((uintptr_t)d | (uintptr_t)s | n) & 15) == 0) {
+    for (size_t i = i0; i < (n >> 4); i += stride) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+  } else if ((((uintptr_t)d | (uintptr_t)s | n) & 3) == 0) {
+    for (size_t i = i0; i < (n >> 2); i += stride) reinterpret_cast<uint32_t*>(d)[i] = reinterpret_cast<const uint32_t*>(s)[i];
+  } else {
+    for (size_t i = i0; i < n; i += stride) d[i] = s[i];
+  }
+}
+inline hipError_t dev_copy2(void* d0, const void* s0, size_t n0, void* d1, const void* s1, size_t n1, hipStream_t s) {
+  const size_t m = n0 > n1 ? n0 : n1;
+  const size_t want = (m / 16 + 255) / 256;  // one 16-byte unit per thread up to 2,048 blocks (a 6.5 MB LSTM state: 8 waves per CU)
+  const int gx = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(dev_copy2_kernel, dim3(gx, 2), dim3(256), 0, s, (uint8_t*)d0, (const uint8_t*)s0, n0, (uint8_t*)d1,
+                     (const uint8_t*)s1, n1);
+  return hipGetLastError();
+}
+
 // agent_ops.hip: completes sliding frame stacks of an observation slot from the previous slot (see there)
 int slide_stacks(uint8_t* cur_slot, const uint8_t* prev_slot, const uint8_t* fresh_planes, const uint8_t* restart_dev, int rows,
                  hipStream_t s);

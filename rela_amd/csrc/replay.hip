@@ -1074,7 +1074,9 @@ extern "C" int rela_replay_commit_add_grouped(rela_replay* r, int first_slot, in
   }
   RELA_HIP(hipEventRecord(r->ev_cin, producer));
   RELA_HIP(hipStreamWaitEvent(r->copy_stream, r->ev_cin, 0));
-  RELA_HIP(hipMemcpyAsync(r->d_pstage[k], priority_dev, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, r->copy_stream));
+  // (a copy KERNEL: the producer and the replay stream both wait for this copy, and what follows one of the runtime's blit
+  // kernels starts ~25 us late -- profiles/r05_trace_gaps.txt, "after replay_scatter_small before replay_append_pow")
+  RELA_HIP(dev_copy2(r->d_pstage[k], priority_dev, sizeof(float) * (size_t)n, nullptr, nullptr, 0, r->copy_stream));
   RELA_HIP(hipEventRecord(r->ev_stage[k], r->copy_stream));
   RELA_HIP(hipStreamWaitEvent(producer, r->ev_stage[k], 0));
   RELA_HIP(hipStreamWaitEvent(r->stream, r->ev_stage[k], 0));
