@@ -1380,7 +1380,7 @@ def main():
 
     run_steps(args.warmup)
     sync_all()
-    # Live roofline: HIP events around the four heavy forward kernels only (the dominant kernel is one
+    # Live roofline: HIP events around the four heavy forward kernels only in the exact-f32 regions (the dominant kernel is one
     # of them); timing all ~100 kernels of a step costs 0.37 ms of the step itself, so the full
     # per-kernel table comes from a short untimed pass after the timed region.
     ROOF_FILTER = b"conv12_fused,conv1_bf16x3,conv2_mfma,conv3_mfma,fc_mfma"
