@@ -276,6 +276,15 @@ extern "C" int rela_apex_learner_backward(rela_apex_learner* l, int batch, const
 // d_ha the loss kernel leaves).  `priority_dev` is final when this returns' work is done, so a caller may hand it to
 // update_priority and ask for the next batch while rela_apex_learner_grad still runs (the replay is not touched by
 // the backward pass); the batch's `s` rows must stay untouched until then (conv1's weight gradient reads them).
+// RELA_LEARNER_MERGE_ONLINE=0: the two online forwards of the f32x3 step as two launches per layer again (A/B switch)
+static bool merge_online_forwards() {
+  static const bool on = [] {
+    const char* e = getenv("RELA_LEARNER_MERGE_ONLINE");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 extern "C" int rela_apex_learner_loss(rela_apex_learner* l, int batch, const void* const* rows_dev,
                                       const float* weight_dev, float* priority_dev, float* loss_dev, void* stream_) {
   RELA_CHECK(l && l->loaded, RELA_ESTATE, "rela_apex_learner_loss: parameters were never loaded");
@@ -313,6 +322,23 @@ extern "C" int rela_apex_learner_loss(rela_apex_learner* l, int batch, const voi
     if (rc != RELA_OK) return rc;
     unsplit_side = l->side != nullptr;
     l->pend_rows = 2 * Bn;  // the workspace layout the backward must address
+  } else if (rela_ffnet_precision(l->online) == 2 && Bn >= 512 && merge_online_forwards() &&
+             nobs == obs + (size_t)Bn * 28224 && nlegal == legal + (size_t)Bn * A) {
+    // f32x3 (r5): the two ONLINE forwards as one launch per layer over [s ; s'] when the caller's batch has s' right behind s
+    // and the legal moves likewise (rela_amd.replay.FFReplay's output buffers do).  Same-box A/B at B = 512: 2.033 against
+    // 2.045 ms per bench step, 0.729 against 0.733 ms learner-only (profiles/r05_ab_merge_online.log) -- half a percent;
+    // a caller with separate buffers keeps the three launches (staging copies would cost more than that).
+    const uint8_t* in2 = obs;
+    const float* legal2 = legal;
+    rc = rela_ffnet_forward(l->target, Bn, nobs, nlegal, q_nt, l->ws_tmp, l->ws_bytes, s);
+    if (rc != RELA_OK) return rc;
+    // (the net's declared batch limit only says which weight layouts its loads pack; the three-part ones this launch reads
+    // are packed from 512 rows up, and the workspaces are sized for 2 x the batch)
+    ffnet_set_max_rows(l->online, 2 * l->Bmax);
+    rc = ffnet_forward_mode(l->online, 2 * Bn, in2, legal2, q_on, l->ws_on, l->ws_bytes, s, 3);  // q_no = q_on + Bn * A
+    ffnet_set_max_rows(l->online, l->Bmax);
+    if (rc != RELA_OK) return rc;
+    l->pend_rows = 2 * Bn;  // the workspace layout the backward must address (it reads the first Bn rows)
   } else {
     rc = rela_ffnet_forward(l->online, Bn, nobs, nlegal, q_no, l->ws_tmp, l->ws_bytes, s);
     if (rc != RELA_OK) return rc;

@@ -80,10 +80,13 @@ class FFReplay:
         if (batch, slot) not in self._out:
             dev, A = self.device, self.num_action
             mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+            # next_s right behind s, next_legal_move right behind legal_move: the f32x3 learner then runs the online net over
+            # [s ; s'] as ONE forward without copying anything (csrc/learner.hip: rela_apex_learner_loss)
+            frames, legal = mk((2, batch, 4, 84, 84), torch.uint8), mk((2, batch, A), torch.float32)
             self._out[(batch, slot)] = dict(
-                s=mk((batch, 4, 84, 84), torch.uint8), next_s=mk((batch, 4, 84, 84), torch.uint8),
+                s=frames[0], next_s=frames[1],
                 eps=mk((batch, 1), torch.float32), next_eps=mk((batch, 1), torch.float32),
-                legal_move=mk((batch, A), torch.float32), next_legal_move=mk((batch, A), torch.float32),
+                legal_move=legal[0], next_legal_move=legal[1],
                 a=mk((batch,), torch.int64), reward=mk((batch,), torch.float32), terminal=mk((batch,), torch.bool),
                 bootstrap=mk((batch,), torch.float32), weight=mk((batch,), torch.float32))
         return self._out[(batch, slot)]

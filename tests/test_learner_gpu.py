@@ -17,7 +17,9 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 RTOL, ATOL = 2e-3, 2e-5  # fp32 sums of up to 2e5 terms in different orders (split-K vs MIOpen)
 
 
-def make_batch(B, A, seed, device="cuda"):
+def make_batch(B, A, seed, device="cuda", adjacent=False):
+    """adjacent: next_obs right behind obs in ONE tensor (and the legal moves likewise), as rela_amd.replay.FFReplay hands a
+    sampled batch over -- the f32x3 learner then runs the online net over [s ; s'] as one forward"""
     import torch
     from types import SimpleNamespace
 
@@ -34,8 +36,13 @@ def make_batch(B, A, seed, device="cuda"):
     boot = (torch.rand(B, generator=g) < 0.9).float()
     w = torch.rand(B, generator=g) * 0.9 + 0.1
     to = lambda x: x.to(device)
-    batch = SimpleNamespace(obs={"s": to(s), "eps": to(torch.zeros(B, 1)), "legal_move": to(legal)},
-                            next_obs={"s": to(ns), "eps": to(torch.zeros(B, 1)), "legal_move": to(nlegal)},
+    if adjacent:
+        frames, moves = to(torch.stack([s, ns])), to(torch.stack([legal, nlegal]))
+        s_d, ns_d, legal_d, nlegal_d = frames[0], frames[1], moves[0], moves[1]
+    else:
+        s_d, ns_d, legal_d, nlegal_d = to(s), to(ns), to(legal), to(nlegal)
+    batch = SimpleNamespace(obs={"s": s_d, "eps": to(torch.zeros(B, 1)), "legal_move": legal_d},
+                            next_obs={"s": ns_d, "eps": to(torch.zeros(B, 1)), "legal_move": nlegal_d},
                             action={"a": to(a)}, reward=to(reward), terminal=to(boot < 0.5), bootstrap=to(boot))
     return batch, to(w)
 
@@ -57,10 +64,10 @@ def make_agent(A, seed, multi_step=3, gamma=0.99):
     return agent
 
 
-@pytest.mark.parametrize("precision", ["f32", "f32x3"])
+@pytest.mark.parametrize("precision", ["f32", "f32x3", "f32x3_adjacent"])
 @pytest.mark.parametrize("B,A", [(32, 6), (512, 18), (100, 18)])
 def test_loss_priority_and_gradients_match_autograd(B, A, precision):
-    """(f32x3: from 512 rows conv2 / conv3 of the three forwards run on the f32-accurate three-part bf16 kernels,
+    """(f32x3: from 512 rows conv2 / conv3 / fc of the three forwards run on the f32-accurate three-part bf16 kernels,
     csrc/gemm_f32emu.h -- asserted through the launch census; same tolerances as the exact f32 mode.)"""
     import torch
 
@@ -69,7 +76,9 @@ def test_loss_priority_and_gradients_match_autograd(B, A, precision):
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
     agent = make_agent(A, 3)
-    batch, w = make_batch(B, A, 11)
+    adjacent = precision.endswith("_adjacent")
+    precision = precision.split("_")[0]
+    batch, w = make_batch(B, A, 11, adjacent=adjacent)
     learner = HipApexLearner.from_agent(agent, B)
     learner.set_precision(precision)
     from rela_amd import _capi as capi
@@ -78,7 +87,9 @@ def test_loss_priority_and_gradients_match_autograd(B, A, precision):
         loss, prio = learner.backward(batch, w)
     emu = {"conv12_s3", "conv3_img_s3", "gemm_s3<fc>"}
     if precision == "f32x3" and B >= 512:
-        assert emu <= set(census.counts) and census.counts["conv12_s3"] == 3, census.counts
+        # separate buffers: three launches per layer; s' right behind s (r5): the online net over [s ; s'] as ONE 1,024-row
+        # launch per layer + the target net over s'
+        assert emu <= set(census.counts) and census.counts["conv12_s3"] == (2 if adjacent else 3), census.counts
     else:
         assert not (emu & set(census.counts)), census.counts
     per_sample, ref_prio = agent.loss(batch, sync_priority=False)
