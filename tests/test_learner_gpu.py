@@ -88,8 +88,13 @@ def test_loss_priority_and_gradients_match_autograd(B, A, precision):
     emu = {"conv12_s3", "conv3_img_s3", "gemm_s3<fc>"}
     if precision == "f32x3" and B >= 512:
         # separate buffers: three launches per layer; s' right behind s (r5): the online net over [s ; s'] as ONE 1,024-row
-        # launch per layer + the target net over s'
-        assert emu <= set(census.counts) and census.counts["conv12_s3"] == (2 if adjacent else 3), census.counts
+        # launch per layer + the target net over s'.  (Separately allocated tensors may happen to sit back to back too: the
+        # library looks at the addresses, so does the expectation.)
+        so, sn = batch.obs["s"], batch.next_obs["s"]
+        lo, ln = batch.obs["legal_move"], batch.next_obs["legal_move"]
+        behind = sn.data_ptr() == so.data_ptr() + so.numel() and ln.data_ptr() == lo.data_ptr() + 4 * lo.numel()
+        assert behind or not adjacent
+        assert emu <= set(census.counts) and census.counts["conv12_s3"] == (2 if behind else 3), census.counts
     else:
         assert not (emu & set(census.counts)), census.counts
     per_sample, ref_prio = agent.loss(batch, sync_priority=False)
