@@ -658,8 +658,8 @@ int rela_replay_remote_gather(rela_replay_remote* rr, int batch, void* const* ou
  * purpose: after a 37 GB field had been mapped from its chunks, hipIpcOpenMemHandle of a 4 GB field of the same partition did
  * not return (profiles/r05_vmm_mixed_import_hang.log).  De-duplicated partitions (rela_replay_set_schema_dedup) are exported
  * with their unit ring; rela_replay_remote_gather rebuilds the frame stacks from it as rela_replay_sample does.
- * Measured on one MI355X, two processes: tests/test_native_exchange_gpu.py (a partition of 2 x 14.8 GB fields in 4 GB
- * chunks, and RELA_TEST_BIG=1: 2 x 37 GB), profiles/r05_vmm_probe.jsonl.                                              */
+ * Measured on one MI355X, two processes: tests/test_ipc_gpu.py (partitions of 20 MB and 15 MB fields in 2 MB and 6 MB
+ * chunks; a 2^20-row partition whose frame-stack field is 37 GB in five 8 GB chunks), profiles/r05_vmm_probe.jsonl.                                              */
 #define RELA_IPC_MAX_FDS 128
 typedef struct rela_replay_chunk_desc {
   rela_replay_ipc_desc ipc; /* ipc.field_handle[f] is unused where field_chunks[f] > 0 */
