@@ -360,7 +360,7 @@ extern "C" int rela_apex_learner_loss(rela_apex_learner* l, int batch, const voi
     hipLaunchKernelGGL(learner_loss_grad, dim3(1), dim3(kLT), 0, s, (const float*)l->td, weight_dev, act, legal, Bn,
                        A, l->d_ha, l->loss);
   }
-  if (loss_dev) RELA_HIP(hipMemcpyAsync(loss_dev, l->loss, sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (loss_dev) RELA_HIP(dev_copy2(loss_dev, l->loss, sizeof(float), nullptr, nullptr, 0, s));  // (a kernel, not a blit: common.h)
   if (unsplit_side) lane_dep(l->ev[1], l->side, s);  // the caller's stream owns the workspace again from here
   RELA_LAUNCH_CHECK();
   l->pend_B = l->last_B = Bn;

@@ -775,8 +775,7 @@ int forward_pre(rela_r2d2_learner* l, int which, int Bn, const uint8_t* obs, con
     launch_gemm<TileRows>(p, 1, s, "learner_lstm_gates_x");
   }
   const size_t blk = (size_t)Bn * kHid;
-  RELA_HIP(hipMemcpyAsync(l->Hs[which], h0, blk * sizeof(float), hipMemcpyDeviceToDevice, s));
-  RELA_HIP(hipMemcpyAsync(l->Cs[which], c0, blk * sizeof(float), hipMemcpyDeviceToDevice, s));
+  RELA_HIP(dev_copy2(l->Hs[which], h0, blk * sizeof(float), l->Cs[which], c0, blk * sizeof(float), s));  // (one launch: common.h)
   return RELA_OK;
 }
 
